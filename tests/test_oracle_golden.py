@@ -1,0 +1,228 @@
+"""
+Pins the oracle (oracle/restate.py) against golden vectors captured from the reference
+itself (oracle/gen_golden.py under oracle/shim.py).  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import restate as R
+
+MESHES = ["12x1x1", "6x1x1", "4x1x1", "3x1x1", "6x6x1", "4x4x1", "2x3x1", "4x4x3", "2x2x2", "4x4x4", "6x6x6"]
+
+
+def _mesh(tag):
+    return tuple(int(x) for x in tag.split("x"))
+
+
+@pytest.mark.parametrize("tag", MESHES)
+def test_G1_ktables(golden, tag):
+    g = golden("G1_ktables.npz")
+    mesh = _mesh(tag)
+    nk = int(np.prod(mesh))
+    ks = R.make_kpts_scaled(mesh)
+    assert np.array_equal(ks, g[tag + "/kpts_scaled"])
+    assert np.array_equal(R.round_to_FBZ(ks + 0.5, tol=1e-10), g[tag + "/round_to_FBZ"])
+    assert np.array_equal(R.make_cells(mesh), g[tag + "/cells"])
+    w = R.get_weights_t_reversal(ks)
+    assert np.array_equal(w, g[tag + "/weights"])
+    if nk <= 64:
+        assert np.array_equal(R.minus_k_index(ks), g[tag + "/minus_k"])
+        kp, kidx = R.get_kpairs_kidx(ks)
+        assert np.array_equal(np.array([p + (-1,) * (2 - len(p)) for p in kp]), g[tag + "/kpairs"])
+        assert np.array_equal(kidx, g[tag + "/kidx"])
+        ca = R.CellArith(mesh)
+        assert np.array_equal(np.array([[ca.add(i, j) for j in range(nk)] for i in range(nk)]), g[tag + "/add"])
+        assert np.array_equal(np.array([[ca.subtract(i, j) for j in range(nk)] for i in range(nk)]), g[tag + "/subtract"])
+        assert np.array_equal(np.array([ca.neg(i) for i in range(nk)]), g[tag + "/neg"])
+    for n in (1, 2, 3, 4, 8):
+        kids = R.assign_workload(w, n)
+        ref = g[tag + "/workload_n%d" % n]
+        for r in range(n):
+            assert kids[r] == [int(x) for x in ref[r] if x >= 0]
+
+
+@pytest.mark.parametrize("tag", ["4x1x1", "3x1x1", "2x3x1", "2x2x2", "4x4x1", "4x4x3"])
+@pytest.mark.parametrize("tr", [True, False])
+def test_G1_block_plan(golden, tag, tr):
+    g = golden("G1_ktables.npz")
+    ev = g[tag + "/plan_%s" % ("tr" if tr else "notr")]
+    ks = R.make_kpts_scaled(_mesh(tag))
+    w, plan = R.tr_block_plan(ks, t_reversal_symm=tr)
+    blocks = ev[ev[:, 0] < 2]
+    assert len(blocks) == len(plan)
+    for e, p in zip(blocks, plan):
+        assert (int(e[1]), int(e[2])) == (p[1], p[2])
+        assert bool(e[0]) == p[4]
+    assert list(ev[ev[:, 0] == 2][:, 1]) == [int(x) for x in w if x > 0]
+
+
+def test_known_answers(golden):
+    g = golden("G1_ktables.npz")
+    ks = R.make_kpts_scaled((4, 4, 1))
+    got = [R.kpt_member(np.array(k), ks) for k in ([0.0, 0.25, 0.0], [-0.25, -0.5, 0.0], [-0.0, 0.5, 0.0],
+                                                  [5.5, -1.25, 0.0], [0.01, -0.25, 0.0])]
+    assert [int(x[0]) for x in got[:4]] == [1, 14, 2, 11] and len(got[4]) == 0   # system/test/test_fourier.py:9-41
+    kp, _ = R.get_kpairs_kidx(R.make_kpts_scaled((4, 4, 3)))
+    assert kp[-3] == (29, 34)                                                    # routine/test/test_mfd_mpi.py:21-25
+    assert list(g["known/kpt_member_441"]) == [1, 14, 2, 11, 0]
+
+
+@pytest.mark.parametrize("tag", ["6x1x1", "4x4x1", "2x3x2", "6x6x6"])
+def test_G2_fourier(golden, tag):
+    g = golden("G2_fourier.npz")
+    mesh = _mesh(tag)
+    assert np.abs(R.FFTtoK(g[tag + "/A_R"], mesh) - g[tag + "/FFTtoK"]).max() < 1e-13
+    assert np.abs(R.FFTtoT(g[tag + "/FFTtoK"], mesh) - g[tag + "/FFTtoT_of_FFTtoK"]).max() < 1e-13
+    assert np.abs(R.FFTtoT(g[tag + "/Z_k"], mesh) - g[tag + "/ifftn_full"].real).max() < 1e-13
+    assert np.abs(R.R2k(g[tag + "/S_R"], mesh) - g[tag + "/R2k_spin"]).max() < 1e-13
+    assert np.abs(R.k2R(g[tag + "/R2k_spin"], mesh) - g[tag + "/k2R_spin"]).max() < 1e-13
+
+
+G3_CASES = ["rhf_611", "rhf_661", "uhf_411", "uhf_222_T", "rhf_331_T", "uhf_231_sz", "rhf_444"]
+
+
+@pytest.mark.parametrize("name", G3_CASES)
+@pytest.mark.parametrize("symm", [False, True])
+def test_G3_meanfield(golden, name, symm):
+    g = golden("G3_meanfield.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR = g[name + "/Fock_R"]
+    spin = FR.shape[0]
+    Fk = R.R2k(FR, mesh)
+    H1R = g[name + "/H1_R"]
+    filling = g[name + "/filling"]
+    filling = float(filling) if filling.ndim == 0 else tuple(filling)
+    beta = float(g[name + "/beta"])
+    args = (Fk[0], FR[0], H1R[0]) if spin == 1 else (Fk, FR, H1R)
+    rhoT, mu, E, res = R.HF(mesh, *args, g[name + "/vcor"], filling, spin == 1, beta=beta, symm=symm, ires=True)
+    t = name + ("_symm" if symm else "")
+    assert np.abs(res["e"] - g[t + "/ew"]).max() < 1e-12
+    assert np.abs(res["mo_occ"] - g[t + "/mo_occ"]).max() < 1e-10
+    assert np.abs(np.asarray(mu) - g[t + "/mu"]).max() < 1e-10
+    assert np.abs(res["rho_k"] - g[t + "/rho_k"]).max() < 1e-11
+    assert np.abs(rhoT - g[t + "/rhoT"]).max() < 1e-11
+    assert abs(E - float(g[t + "/E"])) < 1e-10
+
+
+def test_G3_assignocc_corner_cases(golden):
+    g = golden("G3_meanfield.npz")
+    ew = g["deg/ew"]
+    occ, mu, _ = R.assignocc(ew, 5, np.inf, mu0=0.0, thr_deg=1e-6)
+    assert np.array_equal(occ, g["deg/occ"]) and mu == float(g["deg/mu"])
+    occ, mu, nerr = R.assignocc(ew, 5.0, 30.0, mu0=0.1, fix_mu=True)
+    assert np.abs(occ - g["fixmu/occ"]).max() < 1e-15 and abs(nerr - float(g["fixmu/nerr"])) < 1e-13
+    occ, mu, nerr = R.assignocc(ew, 5.0, 30.0, mu0=0.1)
+    assert np.abs(occ - g["fitmu/occ"]).max() < 1e-12 and abs(mu - float(g["fitmu/mu"])) < 1e-11
+    occ, mu, _ = R.assignocc(ew, 5, 40.0, mu0=0.0, Sz=1)
+    assert np.abs(occ - g["sz/occ"]).max() < 1e-12 and np.abs(mu - g["sz/mu"]).max() < 1e-11
+
+
+def _proj(b):
+    b = b.reshape(b.shape[0], -1, b.shape[-1])
+    return np.einsum("spa,sqa->spq", b, b)
+
+
+def test_G4_bath(golden):
+    g = golden("G4_bath.npz")
+    rdm1_lo = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "rdm1_lo.npy"))
+    b = R.get_emb_basis((1, 1, 3), 4, rdm1_lo, imp_idx=[0, 1, 2, 3], val_idx=[0, 1])
+    assert b.shape == g["hchain/basis_valbath"].shape
+    assert np.abs(_proj(b) - _proj(g["hchain/basis_valbath"])).max() < 1e-11
+    b2 = R.get_emb_basis((1, 1, 3), 4, rdm1_lo, imp_idx=[0, 1, 2, 3], val_idx=[0, 1, 2, 3], nbath=2, valence_bath=False)
+    assert np.abs(_proj(b2) - _proj(g["hchain/basis_full_nbath2"])).max() < 1e-11
+    b3 = R.get_emb_basis((1, 1, 3), 4, np.array((rdm1_lo, rdm1_lo)), imp_idx=[0, 1, 2, 3], val_idx=[0, 1, 2, 3],
+                         tol_bath=1e-7, valence_bath=False)
+    assert b3.shape == g["hchain/basis_uhf_tol"].shape
+    assert np.abs(_proj(b3) - _proj(g["hchain/basis_uhf_tol"])).max() < 1e-10
+    # span equality asserted by routine/test/test_slater.py:48-54
+    assert np.abs(_proj(b) - _proj(b2)).max() < 1e-10
+    for name in ("C1", "C2"):
+        mesh = tuple(int(x) for x in g[name + "/mesh"])
+        rho = g[name + "/rhoT"]
+        nlo = rho.shape[-1]
+        for kind in ("svd", "eig"):
+            bb = R.get_emb_basis(mesh, nlo, rho, imp_idx=list(range(nlo)), val_idx=list(range(nlo)), kind=kind)
+            ref = g[name + "/basis_" + kind]
+            assert bb.shape == ref.shape
+            assert np.abs(_proj(bb) - _proj(ref)).max() < 1e-10
+    rho = g["gen/rhoT"]
+    kw = dict(imp_idx=[1, 2, 3, 4, 5], val_idx=[1, 2, 3])
+    for key, extra in (("basis_svd", {}), ("basis_svd_noorth", {"orth": False}), ("basis_svd_fullbath", {"valence_bath": False})):
+        bb = R.get_emb_basis((2, 2, 2), 7, rho, **kw, **extra)
+        ref = g["gen/" + key]
+        assert bb.shape == ref.shape
+        assert np.abs(_proj(bb) - _proj(ref)).max() < 1e-10
+
+
+def test_G5_basis(golden):
+    g = golden("G5_basis.npz")
+    mesh = tuple(int(x) for x in g["mesh"])
+    ks = R.make_kpts_scaled(mesh)
+    ph = R.get_phase_R2k(mesh, ks)
+    assert np.abs(ph - g["phase_R2k"]).max() < 1e-14
+    bk = R.get_basis_k(g["basis"], ph)
+    assert np.abs(bk - g["basis_k"]).max() < 1e-13
+    assert np.abs(R.multiply_basis(g["C_ao_lo"], bk) - g["multiply_basis"]).max() < 1e-13
+    assert np.abs(R.multiply_basis(g["C_ao_lo"][0], bk[0]) - g["multiply_basis_rhf"]).max() < 1e-13
+    assert np.abs(R.multiply_basis(g["C_ao_lo"][0], bk) - g["multiply_basis_mixed"]).max() < 1e-13
+    assert np.abs(R.transform_h1_to_lo(g["h_ao"], g["C_ao_lo"]) - g["h1_to_lo"]).max() < 1e-12
+    assert np.abs(R.transform_h1_to_lo(g["h_ao"][0], g["C_ao_lo"][0]) - g["h1_to_lo_rhf"]).max() < 1e-12
+    assert np.abs(R.transform_rdm1_to_lo(g["h_ao"], g["C_ao_lo"], g["S_ao"]) - g["rdm1_to_lo"]).max() < 1e-12
+    assert np.abs(R.transform_rdm1_to_ao(g["h1_to_lo"], g["C_ao_lo"]) - g["rdm1_to_ao"]).max() < 1e-12
+
+
+G6_CASES = [("m311", 1), ("m311", 2), ("m411", 1), ("m411", 2), ("m231", 1), ("m231", 2), ("m222", 1), ("m222", 2),
+            ("mid411", 1), ("mid411", 2), ("mid221", 1)]
+
+
+@pytest.mark.parametrize("name,spin", G6_CASES)
+def test_G6_eri(golden, name, spin):
+    from libdmet_preview_amd import synth
+    g = golden("G6_eri.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    W0 = g[name + "/W0"]
+    naux, _, nao = W0.shape[:3]
+    st = "%s/s%d" % (name, spin)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    ks = R.make_kpts_scaled(mesh)
+    blocks = R.df_blocks_from_W0(W0, mesh, ks)
+    alt = synth.df_blocks_from_W0(W0, mesh)
+    for (i, j), b in blocks.items():
+        assert np.abs(b - alt[i, j]).max() < 1e-11
+    get = lambda i, j: blocks[(i, j)]
+    scale = np.abs(g[st + "/eri_tr"]).max()
+    for tr in (True, False):
+        e = R.get_emb_eri_fast_gdf(mesh, ks, get, naux, nao, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
+        ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+        assert e.shape == ref.shape
+        assert np.abs(e - ref).max() <= 1e-12 * scale
+        assert np.abs(e - g[st + "/eri_identity"]).max() <= 1e-11 * scale
+    e1 = R.get_emb_eri_fast_gdf(mesh, ks, get, naux, nao, C_ao_lo=C, basis=basis, symmetry=1)
+    assert e1.shape == g[st + "/eri_s1"].shape and np.abs(e1 - g[st + "/eri_s1"]).max() <= 1e-12 * scale
+    if spin == 1:
+        e8 = R.get_emb_eri_fast_gdf(mesh, ks, get, naux, nao, C_ao_lo=C, basis=basis, symmetry=8)
+        assert e8.shape == g[st + "/eri_s8"].shape and np.abs(e8 - g[st + "/eri_s8"]).max() <= 1e-12 * scale
+    eu = R.get_emb_eri_fast_gdf(mesh, ks, get, naux, nao, C_ao_lo=C, basis=basis, unit_eri=True)
+    su = np.abs(g[st + "/eri_unit"]).max()
+    assert np.abs(eu - g[st + "/eri_unit"]).max() <= 1e-12 * su
+    Ck = R.multiply_basis(C, R.get_basis_k(basis, R.get_phase_R2k(mesh, ks)))
+    ec = R.get_emb_eri_fast_gdf(mesh, ks, get, naux, nao, C_ao_eo=Ck)
+    assert np.abs(ec - g[st + "/eri_C_ao_eo"]).max() <= 1e-12 * scale
+    # sharded accumulation (eri_transform_mpi.py:151-157, 203-210): sum over ranks == serial
+    w = R.get_weights_t_reversal(ks)
+    kids = R.assign_workload(w, 2)
+    part = sum(R.get_emb_eri_fast_gdf(mesh, ks, get, naux, nao, C_ao_lo=C, basis=basis, kL_list=k) for k in kids)
+    assert np.abs(part - g[st + "/eri_tr"]).max() <= 1e-12 * scale
+
+
+def test_philox_known_answer():
+    # Random123 kat_vectors: philox4x32-10, counter/key all zero and all ones, and the pi-digits vector
+    r = R.philox4x32_10([0], [0], [0], [0], 0, 0)
+    assert [int(x[0]) for x in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xFFFFFFFF
+    r = R.philox4x32_10([f], [f], [f], [f], f, f)
+    assert [int(x[0]) for x in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = R.philox4x32_10([0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344], 0xa4093822, 0x299f31d0)
+    assert [int(x[0]) for x in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    b = R.df_block_philox(12345, 3, 7, 4, 5)
+    assert b.shape == (4, 5, 5) and np.abs(b.real).max() <= 1 / np.sqrt(5) and abs(b.mean()) < 0.1
