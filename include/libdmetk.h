@@ -1,0 +1,241 @@
+/*
+ * libdmetk.h -- C ABI of the MI355X-native libDMET embedding-construction path.
+ *
+ * The reference (gkclab/libdmet_preview) is pure Python and has no FFI of its
+ * own: the boundary a maintainer would bind is the set of
+ * numpy-level primitives its hot functions reduce to.  Each entry point below
+ * names the reference call site it replaces (paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes stubs that rebind the reference's
+ * Python entry points (HF, get_emb_basis, get_emb_eri, Lattice.k2R/R2k,
+ * multiply_basis) onto these symbols.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the ABI.
+ *   - every function returns 0 on success or a negative dmk_status; the message
+ *     is available from dmk_last_error(ctx).  Nothing throws across the ABI.
+ *   - all array arguments are DEVICE pointers (HBM) unless the name ends in
+ *     `_host`; row-major; complex = interleaved (re, im) f64; all work is
+ *     enqueued on the context's stream and is asynchronous w.r.t. the host
+ *     unless stated.  dmk_malloc/dmk_memcpy_* serve hosts without torch.
+ *   - one context per host thread; contexts are not shared.
+ *   - index bookkeeping (k-points, cells, time-reversal plan) is integer mesh
+ *     arithmetic done on the host side of the library and exposed bit-exactly
+ *     through dmk_kmesh_tables / dmk_eri_plan.
+ */
+#ifndef LIBDMETK_H
+#define LIBDMETK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmk_ctx dmk_ctx;
+
+typedef enum {
+    DMK_OK = 0,
+    DMK_ERR_INVALID = -1,     /* bad argument / shape                        */
+    DMK_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+    DMK_ERR_NOMEM = -3,       /* device allocation failed                    */
+    DMK_ERR_NOCONV = -4,      /* an iterative kernel did not converge        */
+    DMK_ERR_STATE = -5        /* call sequence violated (eri begin/push/...) */
+} dmk_status;
+
+/* ------------------------------------------------------------------------- */
+/* context, memory, diagnostics                                               */
+/* ------------------------------------------------------------------------- */
+
+/* Create a context on `device`.  `stream` is a hipStream_t to enqueue on (pass
+ * NULL for the legacy default stream); it may be changed with dmk_set_stream. */
+int dmk_init(int device, void *stream, dmk_ctx **out);
+int dmk_destroy(dmk_ctx *ctx);
+int dmk_set_stream(dmk_ctx *ctx, void *stream);
+int dmk_sync(dmk_ctx *ctx);
+const char *dmk_last_error(const dmk_ctx *ctx);
+const char *dmk_version(void);
+
+int dmk_malloc(dmk_ctx *ctx, size_t bytes, void **out);
+int dmk_free(dmk_ctx *ctx, void *p);
+int dmk_memset(dmk_ctx *ctx, void *p, int value, size_t bytes);
+int dmk_memcpy_h2d(dmk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int dmk_memcpy_d2h(dmk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int dmk_memcpy_d2d(dmk_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+
+/* HIP-event timing of everything enqueued on the context stream between the
+ * two calls (bench.py's roofline leg).  dmk_timer_stop synchronises. */
+int dmk_timer_start(dmk_ctx *ctx);
+int dmk_timer_stop(dmk_ctx *ctx, double *ms_out_host);
+
+/* Per-kernel-family accumulated HIP-event time since the last reset
+ * (family ids: DMK_FAM_*).  Enabled with dmk_profile(ctx, 1); when enabled
+ * every launch of the family is bracketed by events on the stream. */
+enum { DMK_FAM_DGEMM = 0, DMK_FAM_ZGEMM_HALF1 = 1, DMK_FAM_ZGEMM_HALF2 = 2,
+       DMK_FAM_PHILOX = 3, DMK_FAM_FOLD = 4, DMK_FAM_EIGH = 5, DMK_FAM_BATH = 6,
+       DMK_FAM_ZGEMM_SMALL = 7, DMK_FAM_MISC = 8, DMK_FAM_COUNT = 9 };
+int dmk_profile(dmk_ctx *ctx, int enable);
+int dmk_profile_read(dmk_ctx *ctx, double *ms_host /*[DMK_FAM_COUNT]*/,
+                     int64_t *launches_host /*[DMK_FAM_COUNT]*/, int reset);
+
+/* ------------------------------------------------------------------------- */
+/* a1 / a2 / a15 : k-point, cell and time-reversal bookkeeping (HOST, integer) */
+/* replaces system/fourier.py:46-81 (make_kpts_scaled, round_to_FBZ,           */
+/* kpt_member), system/lattice.py:194-204 (cell add/subtract),                 */
+/* basis_transform/eri_transform.py:142-157 (get_weights_t_reversal),          */
+/* routine/mfd_mpi.py:33-54 (get_kpairs_kidx),                                 */
+/* basis_transform/eri_transform_mpi.py:27-55 (assign_workload).               */
+/* ------------------------------------------------------------------------- */
+
+/* All outputs are host arrays of length nk = mesh[0]*mesh[1]*mesh[2] (any may be
+ * NULL): mesh integers of each k / cell (nk x 3), index of -k, TR weights
+ * {1,2,0}. */
+int dmk_kmesh_tables(const int mesh[3], int32_t *kint_host, int32_t *minus_k_host,
+                     int32_t *weights_host);
+/* j = conserving partner: k_j = k_i - k_L (mod mesh).  out: nk*nk, [kL*nk + i]. */
+int dmk_kconserv_table(const int mesh[3], int32_t *j_of_kL_i_host);
+/* cell index arithmetic: out[i*nk + j] = idx(R_i +/- R_j). */
+int dmk_cell_add_table(const int mesh[3], int sign, int32_t *out_host);
+/* scaled k-points in fftfreq order (nk x 3 f64), bit-identical to make_kpts_scaled. */
+int dmk_kpts_scaled(const int mesh[3], double *kpts_host);
+/* index of a scaled k-vector in the mesh modulo reciprocal lattice vectors;
+ * returns the index or -1 (kpt_member with tol). */
+int dmk_kpt_member(const int mesh[3], const double kpt[3], double tol);
+
+/* Visiting plan of get_emb_eri_fast_gdf's double loop
+ * (basis_transform/eri_transform.py:338-382).  Records are int32 quintuples
+ * (kL, i, j, jm, symmetrise).  Call with plan_host = NULL to get the count. */
+int dmk_eri_plan(const int mesh[3], int t_reversal_symm, int32_t *plan_host,
+                 int64_t capacity_records, int64_t *nrecords_out);
+/* Static partition of irreducible kL over `nranks` (assign_workload).
+ * kl_host receives the kL owned by `rank` (capacity nk); returns the count via n_out. */
+int dmk_assign_workload(const int mesh[3], int t_reversal_symm, int nranks, int rank,
+                        int32_t *kl_host, int *n_out);
+
+/* ------------------------------------------------------------------------- */
+/* a6 : k <-> R Fourier folds                                                  */
+/* replaces system/fourier.py:160-177 (FFTtoK / FFTtoT), :129-158 (R2k / k2R)  */
+/* ------------------------------------------------------------------------- */
+
+/* out_k[k, c] = sum_R exp(-i k.R) in_R[R, c];  in real (in_is_complex=0) or
+ * complex; ncol = product of trailing dims; batch = leading (spin) dim. */
+int dmk_fold_R2k(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch,
+                 const void *in_R, int in_is_complex, void *out_k /* c128 */);
+/* out_R[R, c] = Re[(1/N) sum_k exp(+i k.R) in_k[k, c]]; max |Im| of the full
+ * result is written to *imag_max_dev (device f64, may be NULL) -- the quantity
+ * the reference compares with IMAG_DISCARD_TOL (system/fourier.py:174-175).
+ * k_subset/nsub (host, may be NULL/0) restrict the sum to a shard of k-points
+ * (multi-GPU partial fold). */
+int dmk_fold_k2R(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch,
+                 const void *in_k /* c128 */, double *out_R, double *imag_max_dev,
+                 const int32_t *k_subset_host, int nsub);
+/* complex -> complex variant of k2R (no real-part projection). */
+int dmk_fold_k2R_complex(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch,
+                         const void *in_k, void *out_R);
+
+/* ------------------------------------------------------------------------- */
+/* a3 / a5 : batched Hermitian eigensolver and density build                   */
+/* replaces scipy.linalg.eigh at routine/mfd.py:42-106 (DiagRHF/UHF[_symm])    */
+/* and the loop rho[s,k] = (ev*occ) ev^H at routine/mfd.py:355-357             */
+/* ------------------------------------------------------------------------- */
+
+/* A: batch x n x n c128 (Hermitian; both triangles read).  add: optional n x n
+ * f64 matrix added to every A (vcor.get(k, True)[s]), add_stride = 0 or n*n per
+ * batch group (add_period matrices cycle with period `add_period` batches;
+ * pass add=NULL for none).  w: batch x n ascending.  Vt: batch x n x n c128 with
+ * ROW m = eigenvector m (i.e. Vt[b][m][i] = ev[b][i][m]); use dmk_transpose_c128
+ * for the reference's column layout. */
+int dmk_eigh_batched(dmk_ctx *ctx, int n, int batch, const void *A, const double *add,
+                     int add_group, double *w, void *Vt);
+/* real symmetric variant (routine/slater.py:278, lo/lowdin.py:87): A batch x n x n f64. */
+int dmk_eigh_batched_real(dmk_ctx *ctx, int n, int batch, const double *A, double *w,
+                          double *Vt);
+/* rho[b] = sum_m occ[b,m] v_m v_m^H from Vt (batch x n x n), occ (batch x n). */
+int dmk_occ_density(dmk_ctx *ctx, int n, int batch, const void *Vt, const double *occ,
+                    void *rho /* c128 batch x n x n */);
+int dmk_transpose_c128(dmk_ctx *ctx, int rows, int cols, int batch, const void *in, void *out);
+
+/* ------------------------------------------------------------------------- */
+/* a7 : Schmidt bath                                                           */
+/* replaces routine/slater.py:117-220 (_get_emb_basis_svd): gather of          */
+/* rdm1_env_imp, scipy.linalg.svd (:180), virtual projection + Loewdin         */
+/* (:200-202, lo/lowdin.py:83-101), scatter into `basis` (:212-213)            */
+/* ------------------------------------------------------------------------- */
+
+/* rdm1: ncells x nlo x nlo f64 stripe (one spin).  env_idx (nenv), bath_col
+ * (nb; global site indices of imp_idx_bath, may lie outside cell 0) and
+ * virt_mask (nenv, 0/1) are device int32 arrays.  Outputs: sigma (nb, descending),
+ * U (nenv x nb, left singular vectors, column j <-> sigma[j]).  */
+int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1,
+                 const int32_t *env_idx, int nenv, const int32_t *bath_col, int nb,
+                 double *sigma, double *U);
+/* B = U[:, :nbath]; if orth: B[virt_mask] = 0; B = B (B^T B)^{-1/2} (eigenvalues
+ * <= 1e-14 dropped); then basis[imp_idx, :nimp] = I and
+ * basis[env_idx, nimp:nimp+nbath] = B, basis: (ncells*nlo) x ncol_basis f64 (zeroed here). */
+int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath,
+                      const int32_t *virt_mask, int orth, const int32_t *env_idx,
+                      const int32_t *imp_idx, int nimp, int nsites, int ncol_basis,
+                      double *basis);
+
+/* ------------------------------------------------------------------------- */
+/* a9 / a10 : batched small complex products                                   */
+/* replaces utils/misc.py:49-59 (kdot) under make_basis.multiply_basis         */
+/* (basis_transform/make_basis.py:923-962) and the mdot triple products of     */
+/* transform_h1_to_lo / transform_rdm1_to_lo / _to_ao (:524-644)               */
+/* ------------------------------------------------------------------------- */
+
+/* C[b] = alpha * op(A[b]) op(B[b]);  op: 0 = N, 1 = T, 2 = C (conj-transpose).
+ * A: batch x (rows x cols as stored) c128 row-major with leading dim = cols. */
+int dmk_zgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int batch,
+                      double alpha, const void *A, int64_t strideA, const void *B,
+                      int64_t strideB, void *C, int64_t strideC);
+
+/* ------------------------------------------------------------------------- */
+/* a11 - a14 : density-fitted AO -> EO ERI transform                           */
+/* replaces basis_transform/eri_transform.py:235-399 (get_emb_eri_fast_gdf):   */
+/* _ao2mo.r_e2 (:433), lib.hermi_sum (:372), lib.pack_tril (:375), the         */
+/* Lij_s4 accumulation (:376-378) and _Lij_s4_to_eri's lib.dot calls (:436-485)*/
+/* ------------------------------------------------------------------------- */
+
+typedef struct dmk_eri dmk_eri;
+
+/* C_ao_emb: spin x nk x nao x nemb c128, ALREADY scaled by nk^(-3/4)
+ * (eri_transform.py:289-300).  eri_out: device f64 (spin*(spin+1)/2) x npair x
+ * npair in (aa, ab, bb) order, accumulated into (caller zeroes it, so that
+ * shards can be summed).  flags: bit0 = t_reversal_symm. */
+int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, int spin,
+                  int flags, const void *C_ao_emb, double *eri_out, dmk_eri **out);
+/* Start a momentum-transfer index kL (zeroes the Lij_s4 planes). */
+int dmk_eri_begin_kL(dmk_eri *h, int kL);
+/* Half-transform one AO block L^{(ki,kj)} (naux x nao x nao c128, device) and
+ * accumulate its tril-packed (L|ab) into the current kL's Lij_s4;
+ * symmetrise != 0 adds the transposed term of the time-reversal partner pair. */
+int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq);
+/* Contract the current kL: eri[blk] += w (Re^T Re [+ Im^T Im]) (TR) or Re(X^H X). */
+int dmk_eri_end_kL(dmk_eri *h, int weight);
+/* Device pointers of the current kL's Lij_s4 planes (spin x 2 x naux x npair f64:
+ * Re plane then Im plane) for inspection / tests. */
+int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out);
+int dmk_eri_finish(dmk_eri *h);
+/* ALGORITHMIC flop counters of the work pushed so far:
+ * [0] half transform, [1] contraction. */
+int dmk_eri_flops(const dmk_eri *h, double flops_host[2]);
+
+/* Procedural DF block (synthetic configs): Philox4x32-10,
+ * key (seed_lo, seed_hi), counter (e>>1 lo, e>>1 hi, ki, kj), e = (L*nao+p)*nao+q. */
+int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao,
+                        void *Lpq_out);
+
+/* a14: 4-fold (npair x npair) -> 1-fold (nemb^4) / 8-fold restore
+ * (eri_transform.py:523-544 -> pyscf ao2mo.restore). */
+int dmk_eri_restore(dmk_ctx *ctx, int nemb, int symmetry, const double *eri4, double *out);
+
+/* Bare real contraction C (N x N, ldc) += alpha * X^T Y with X, Y: K x N row-major
+ * (the lib.dot(Lij.T, Lij, alpha, eri, 1) of eri_transform.py:455-476). */
+int dmk_dgemm_tn_acc(dmk_ctx *ctx, int N, int K, double alpha, const double *X,
+                     const double *Y, int64_t ldxy, double *C, int64_t ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBDMETK_H */

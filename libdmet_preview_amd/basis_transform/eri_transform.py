@@ -1,0 +1,405 @@
+"""
+Density-fitted AO -> embedding-orbital ERI transform with the entry points of the reference's
+libdmet/basis_transform/eri_transform.py, computed by libdmetk (HIP, f64 MFMA):
+
+  get_emb_eri            eri_transform.py:44-94     dispatch on the DF object
+  get_unit_eri           eri_transform.py:96-112
+  get_emb_eri_fast_gdf   eri_transform.py:235-399   k-conserving double loop, time-reversal
+                                                     bookkeeping, half transform, contraction
+  get_basis_k            eri_transform.py:118-126
+  get_weights_t_reversal eri_transform.py:142-157
+  eri_restore            eri_transform.py:523-544
+  (MPI twin: eri_transform_mpi.py:57-223 -> `use_mpi=True` shards kL over torch.distributed ranks)
+
+The DF tensor is served by a *block provider* instead of PySCF's `_load3c` on an HDF5 file
+(eri_transform.py:195-227): any object with `.kpts` (nk,3 absolute), `.naux` and
+`load_block(ctx, i, j, out_dev)` (fills a device (naux,nao,nao) c128 buffer with L^{(ki,kj)}).
+`GDFMemory` wraps host arrays / callables, `GDFPhilox` is the procedural synthetic tensor of
+SURVEY.md section 8d generated on the device.
+"""
+import ctypes as C
+import numpy as np
+
+from libdmet_preview_amd._lib import lib, mesh3, get_ctx, DevArray
+from libdmet_preview_amd.settings import KPT_DIFF_TOL
+from libdmet_preview_amd.system import fourier
+from libdmet_preview_amd.system.fourier import round_to_FBZ, kpt_member, get_phase_R2k  # noqa: F401
+from libdmet_preview_amd.basis_transform.make_basis import multiply_basis, bgemm_dev  # noqa: F401
+from libdmet_preview_amd.utils.misc import max_abs, add_spin_dim
+from libdmet_preview_amd.utils import logger as log
+
+ERI_IMAG_TOL = 1e-6
+ERI_SLICE = 2000
+
+
+# ---------------------------------------------------------------------------------------------
+# DF block providers
+# ---------------------------------------------------------------------------------------------
+
+class GDFMemory(object):
+    """In-memory DF tensor: blocks[(i, j)] / blocks[i, j] / blocks(i, j) -> (naux, nao, nao) complex."""
+    def __init__(self, kpts, blocks, naux=None, cell=None):
+        self.kpts = np.asarray(kpts)
+        self.blocks = blocks
+        self.cell = cell
+        if naux is None:
+            b = self.get_block(0, 0)
+            naux = b.shape[0]
+        self.naux = int(naux)
+        self._cderi = "memory"
+
+    def get_block(self, i, j):
+        if callable(self.blocks):
+            return np.asarray(self.blocks(i, j))
+        if isinstance(self.blocks, dict):
+            return np.asarray(self.blocks[(i, j)])
+        return np.asarray(self.blocks[i, j])
+
+    def load_block(self, ctx, i, j, out_dev):
+        out_dev.set(self.get_block(i, j))
+
+
+class GDFPhilox(object):
+    """Procedural DF tensor generated on the device (Philox4x32-10 keyed by (seed, ki, kj))."""
+    def __init__(self, kpts, naux, nao, seed=20241223, cell=None):
+        self.kpts = np.asarray(kpts)
+        self.naux = int(naux)
+        self.nao = int(nao)
+        self.seed = int(seed)
+        self.cell = cell
+        self._cderi = "philox"
+
+    def load_block(self, ctx, i, j, out_dev):
+        ctx.check(lib.dmk_df_block_philox(ctx.h, C.c_uint64(self.seed), int(i), int(j), self.naux, self.nao,
+                                          out_dev.ptr))
+
+
+def _is_provider(mydf):
+    return hasattr(mydf, "load_block") and hasattr(mydf, "kpts")
+
+
+# ---------------------------------------------------------------------------------------------
+# small helpers with reference names
+# ---------------------------------------------------------------------------------------------
+
+def get_basis_k(basis, phase_R2k):
+    """basis_k[s, k] = sum_R basis[s, R] phase[R, k] (eri_transform.py:118-126: einsum 'Rim,Rk->kim'),
+    as one complex MFMA GEMM per spin with the caller's phase table."""
+    basis = np.asarray(basis)
+    phase_R2k = np.ascontiguousarray(phase_R2k, dtype=np.complex128)
+    spin, ncells, nlo, nemb = basis.shape
+    nk = phase_R2k.shape[1]
+    assert phase_R2k.shape[0] == ncells
+    ctx = get_ctx()
+    d_ph = ctx.to_device(phase_R2k)
+    d_b = ctx.to_device(basis, np.complex128)
+    out = bgemm_dev(ctx, "T", "N", nk, nlo * nemb, ncells, spin, d_ph, 0, d_b, ncells * nlo * nemb)
+    return out.get().reshape(spin, nk, nlo, nemb)
+
+
+def get_weights_t_reversal(cell, kpts, tol=KPT_DIFF_TOL):
+    kmesh, perm = _mesh_and_perm(cell, kpts, tol)
+    _, _, w = fourier.kmesh_tables(kmesh)
+    if perm is not None:
+        raise NotImplementedError("k-points must be in np.fft mesh order")
+    w = w.astype(int)
+    assert w.sum() == len(kpts)
+    return w
+
+
+def get_kmesh(cell, kpts):
+    """system/fourier.py:83-89."""
+    scaled_k = np.asarray(cell.get_scaled_kpts(kpts)).round(8)
+    return [len(np.unique(scaled_k[:, d])) for d in range(scaled_k.shape[-1])]
+
+
+def _mesh_and_perm(cell, kpts, tol=KPT_DIFF_TOL):
+    """k-mesh of `kpts` and None if they are already in fftfreq mesh order (else the index map)."""
+    ks = np.asarray(cell.get_scaled_kpts(kpts), dtype=float)
+    ks3 = np.zeros((len(ks), 3))
+    ks3[:, :ks.shape[1]] = ks
+    kmesh = [len(np.unique(ks3[:, d].round(8))) for d in range(3)]
+    if int(np.prod(kmesh)) != len(ks3):
+        raise ValueError("k-points do not form a full Monkhorst-Pack mesh")
+    ref = np.zeros((len(ks3), 3))
+    ref[:, :] = fourier.make_kpts_scaled(kmesh)
+    d = ks3 - ref
+    d -= np.round(d)
+    if np.abs(d).max() < tol:
+        return kmesh, None
+    perm = np.array([fourier.kpt_member_mesh(k, kmesh, tol) for k in ks3])
+    if (perm < 0).any() or len(set(perm.tolist())) != len(perm):
+        raise ValueError("k-points are not a (Gamma-centred) np.fft mesh; kscaled_center shifts are not supported")
+    return kmesh, perm
+
+
+def eri_plan(kmesh, t_reversal_symm=True):
+    """(weights, records) of the reference's double loop; records: int32 (n, 5) = kL, i, j, jm, symmetrise."""
+    m = mesh3(kmesh)
+    n = C.c_int64()
+    rc = lib.dmk_eri_plan(m, 1 if t_reversal_symm else 0, None, 0, C.byref(n))
+    if rc != 0:
+        raise ValueError("dmk_eri_plan failed")
+    rec = np.empty((n.value, 5), dtype=np.int32)
+    rc = lib.dmk_eri_plan(m, 1 if t_reversal_symm else 0, rec.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+    if rc != 0:
+        raise ValueError("dmk_eri_plan failed")
+    if t_reversal_symm:
+        _, _, w = fourier.kmesh_tables(kmesh)
+    else:
+        w = np.ones(m[0] * m[1] * m[2], dtype=np.int32)
+    return w.astype(int), rec
+
+
+def assign_workload(kmesh, n, t_reversal_symm=True):
+    """Per-rank lists of irreducible kL (eri_transform_mpi.py:35-55)."""
+    m = mesh3(kmesh)
+    nk = m[0] * m[1] * m[2]
+    out = []
+    for r in range(n):
+        buf = np.empty(nk, dtype=np.int32)
+        cnt = C.c_int()
+        rc = lib.dmk_assign_workload(m, 1 if t_reversal_symm else 0, int(n), r, buf.ctypes.data_as(C.c_void_p),
+                                     C.byref(cnt))
+        if rc != 0:
+            raise ValueError("dmk_assign_workload failed")
+        out.append([int(x) for x in buf[:cnt.value]])
+    return out
+
+
+def eri_restore(eri, symmetry, nemb):
+    """4-fold -> requested permutation symmetry (eri_transform.py:523-544), on the device."""
+    eri = np.asarray(eri)
+    spin_pair = eri.shape[0]
+    npair = nemb * (nemb + 1) // 2
+    symmetry = int(str(symmetry).replace("s", ""))
+    if symmetry == 4:
+        return np.ascontiguousarray(eri.real).reshape(spin_pair, npair, npair)
+    if symmetry == 8 and spin_pair > 1:
+        raise ValueError("Spin unrestricted ERI does not support 8-fold symmetry.")
+    if symmetry not in (1, 8):
+        raise ValueError("unknown ERI symmetry %s" % symmetry)
+    ctx = get_ctx()
+    shape = (nemb,) * 4 if symmetry == 1 else (npair * (npair + 1) // 2,)
+    out = np.empty((spin_pair,) + shape)
+    for s in range(spin_pair):
+        d = ctx.to_device(eri[s].real.reshape(npair, npair), np.float64)
+        o = ctx.empty(shape, np.float64)
+        ctx.check(lib.dmk_eri_restore(ctx.h, int(nemb), symmetry, d.ptr, o.ptr))
+        out[s] = o.get()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident driver
+# ---------------------------------------------------------------------------------------------
+
+class EriEngine(object):
+    """Owns a dmk_eri pipeline: plan -> (begin_kL, push_block*, end_kL)* on one GPU."""
+
+    def __init__(self, ctx, kmesh, nao, naux, nemb, spin, C_ao_emb_dev, eri_dev, t_reversal_symm=True):
+        self.ctx = ctx
+        self.kmesh = [int(x) for x in kmesh] + [1] * (3 - len(kmesh))
+        self.nao, self.naux, self.nemb, self.spin = int(nao), int(naux), int(nemb), int(spin)
+        self.tr = bool(t_reversal_symm)
+        self.C = C_ao_emb_dev
+        self.eri = eri_dev
+        h = C.c_void_p()
+        ctx.check(lib.dmk_eri_begin(ctx.h, mesh3(self.kmesh), self.nao, self.naux, self.nemb, self.spin,
+                                    1 if self.tr else 0, C_ao_emb_dev.ptr, eri_dev.ptr, C.byref(h)))
+        self.h = h
+        self.weights, self.records = eri_plan(self.kmesh, self.tr)
+        self.block_buf = ctx.empty((self.naux, self.nao, self.nao), np.complex128)
+        # records grouped by kL, in plan order
+        self.by_kL = {}
+        for r in self.records:
+            self.by_kL.setdefault(int(r[0]), []).append(r)
+
+    def irreducible_kL(self):
+        return [kL for kL in range(len(self.weights)) if self.weights[kL] > 0]
+
+    def run_kL(self, kL, provider, user_of_mesh=None, max_blocks=None):
+        ctx = self.ctx
+        ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
+        nblk = 0
+        for r in self.by_kL[kL]:
+            i, j, sym = int(r[1]), int(r[2]), int(r[4])
+            ui, uj = (i, j) if user_of_mesh is None else (int(user_of_mesh[i]), int(user_of_mesh[j]))
+            provider.load_block(ctx, ui, uj, self.block_buf)
+            ctx.check(lib.dmk_eri_push_block(self.h, i, j, sym, self.block_buf.ptr))
+            nblk += 1
+            if max_blocks is not None and nblk >= max_blocks:
+                break
+        ctx.check(lib.dmk_eri_end_kL(self.h, int(self.weights[kL])))
+        return nblk
+
+    def run(self, provider, kL_list=None, user_of_mesh=None):
+        todo = self.irreducible_kL() if kL_list is None else [k for k in kL_list if self.weights[k] > 0]
+        nblk = 0
+        for kL in todo:
+            nblk += self.run_kL(kL, provider, user_of_mesh)
+        return nblk
+
+    def flops(self):
+        f = (C.c_double * 2)()
+        self.ctx.check(lib.dmk_eri_flops(self.h, f))
+        return float(f[0]), float(f[1])
+
+    def planes(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self.ctx.check(lib.dmk_eri_planes(self.h, C.byref(p), C.byref(n)))
+        return self.ctx.wrap(p.value, (self.spin, 2, self.naux, self.nemb * (self.nemb + 1) // 2), np.float64,
+                             keepalive=self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.dmk_eri_finish(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_C_ao_emb_dev(ctx, kmesh, C_ao_lo=None, basis=None, unit_eri=False, C_ao_eo=None, nao=None):
+    """C_ao_emb = C_ao_lo . R2k(basis) / nk^(3/4) (eri_transform.py:270-300) -> device (spin,nk,nao,nemb) c128."""
+    nk = int(np.prod(kmesh))
+    scale = 1.0 / (nk ** 0.75)
+    if C_ao_eo is None:
+        if C_ao_lo is None:
+            C_ao_lo = np.zeros((nk, nao, nao), dtype=np.complex128)
+            C_ao_lo[:, range(nao), range(nao)] = 1.0
+        C_ao_lo = np.asarray(C_ao_lo)
+        if C_ao_lo.ndim == 3:
+            C_ao_lo = C_ao_lo[np.newaxis]
+        if unit_eri:
+            return ctx.to_device(C_ao_lo * scale, np.complex128)
+        if basis is None:
+            n_ao = C_ao_lo.shape[-2]
+            basis = np.eye(nk * n_ao).reshape(1, nk, n_ao, nk * n_ao)
+        basis = np.asarray(basis)
+        if basis.shape[0] < C_ao_lo.shape[0]:
+            basis = add_spin_dim(basis, C_ao_lo.shape[0])
+        if C_ao_lo.shape[0] < basis.shape[0]:
+            C_ao_lo = add_spin_dim(C_ao_lo, basis.shape[0])
+        spin, _, nlo, nemb = basis.shape
+        n_ao = C_ao_lo.shape[-2]
+        d_basis = ctx.to_device(basis, np.complex128 if np.iscomplexobj(basis) else np.float64)
+        basis_k = fourier.fold_R2k_dev(d_basis, kmesh, spin, nlo * nemb)         # (spin, nk, nlo*nemb)
+        d_C = ctx.to_device(C_ao_lo, np.complex128)
+        return bgemm_dev(ctx, "N", "N", n_ao, nemb, nlo, spin * nk, d_C, n_ao * nlo, basis_k, nlo * nemb,
+                         alpha=scale).reshape(spin, nk, n_ao, nemb)
+    if C_ao_lo is not None:
+        raise ValueError("Don't pass both `C_ao_lo` and `C_ao_eo`.")
+    C_ao_eo = np.asarray(C_ao_eo)
+    if C_ao_eo.ndim == 3:
+        C_ao_eo = C_ao_eo[np.newaxis]
+    return ctx.to_device(C_ao_eo * scale, np.complex128)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-signature entry points
+# ---------------------------------------------------------------------------------------------
+
+def get_emb_eri(cell, mydf, C_ao_lo=None, basis=None, unit_eri=False, symmetry=4, t_reversal_symm=True,
+                max_memory=None, swap_idx=None, feri=None, kscaled_center=None, kconserv_tol=KPT_DIFF_TOL,
+                incore=True, fout="H2.h5", **kwargs):
+    """Embedding ERIs with density fitting (see the reference docstring, eri_transform.py:44-67)."""
+    if not _is_provider(mydf):
+        raise ValueError("Unknown DF type for embedding ERI construction.")
+    return get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=C_ao_lo, basis=basis, feri=feri, kscaled_center=kscaled_center,
+                                symmetry=symmetry, max_memory=max_memory, kconserv_tol=kconserv_tol,
+                                unit_eri=unit_eri, swap_idx=swap_idx, t_reversal_symm=t_reversal_symm,
+                                incore=incore, fout=fout, use_mpi=kwargs.get("use_mpi", False))
+
+
+def get_unit_eri(cell, mydf, C_ao_lo=None, symmetry=4, t_reversal_symm=True, max_memory=None, swap_idx=None,
+                 feri=None, kscaled_center=None, kconserv_tol=KPT_DIFF_TOL, incore=True, fout="H2.h5", **kwargs):
+    C_ao_lo = np.asarray(C_ao_lo)
+    if C_ao_lo.ndim == 3:
+        C_ao_lo = C_ao_lo[np.newaxis]
+    basis = np.empty_like(C_ao_lo)
+    return get_emb_eri(cell, mydf, C_ao_lo=C_ao_lo, basis=basis, feri=feri, kscaled_center=kscaled_center,
+                       symmetry=symmetry, max_memory=max_memory, kconserv_tol=kconserv_tol, unit_eri=True,
+                       swap_idx=swap_idx, t_reversal_symm=t_reversal_symm, incore=incore, fout=fout, **kwargs)
+
+
+def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscaled_center=None, symmetry=4,
+                         max_memory=None, C_ao_eo=None, kconserv_tol=KPT_DIFF_TOL, unit_eri=False, swap_idx=None,
+                         t_reversal_symm=True, incore=True, fout="H2.h5", use_mpi=False):
+    """
+    Fast routine to compute the embedding-space ERI on the fly (eri_transform.py:235-399).
+
+    Returns (spin_pair, npair, npair) f64 in (aa, ab, bb) order for symmetry=4, or the restored
+    1-/8-fold forms.  `incore=False` writes the (aa, bb, ab)-ordered result to `fout` (.npy) and
+    returns a dict {"ccdd": memmap} (the HDF5 layout of eri_transform.py:314-320, 506-508).
+    """
+    if kscaled_center is not None:
+        raise NotImplementedError("kscaled_center shifts are not supported by the integer-mesh bookkeeping")
+    if not t_reversal_symm and not incore:
+        raise NotImplementedError
+    ctx = get_ctx()
+    nao = int(cell.nao_nr())
+    kpts = mydf.kpts
+    nkpts = len(kpts)
+    naux = int(mydf.naux)
+    kmesh, perm = _mesh_and_perm(cell, kpts, kconserv_tol)
+    user_of_mesh = None
+    if perm is not None:
+        user_of_mesh = np.empty(nkpts, dtype=np.int64)
+        user_of_mesh[perm] = np.arange(nkpts)
+
+    def reorder(x, axis):
+        if x is None or user_of_mesh is None:
+            return x
+        return np.take(np.asarray(x), user_of_mesh, axis=axis)
+
+    if C_ao_eo is None:
+        Cl = None if C_ao_lo is None else np.asarray(C_ao_lo)
+        if Cl is not None:
+            Cl = reorder(Cl, Cl.ndim - 3)
+        C_dev = make_C_ao_emb_dev(ctx, kmesh, C_ao_lo=Cl, basis=basis, unit_eri=unit_eri, nao=nao)
+    else:
+        if C_ao_lo is not None:
+            raise ValueError("Don't pass both `C_ao_lo` and `C_ao_eo`.")
+        Ce = np.asarray(C_ao_eo)
+        assert (nkpts, nao) == Ce.shape[-3:-1]
+        Ce = reorder(Ce, Ce.ndim - 3)
+        C_dev = make_C_ao_emb_dev(ctx, kmesh, C_ao_eo=Ce)
+    spin, _, nao_c, nemb = C_dev.shape
+    assert nao_c == nao
+    npair = nemb * (nemb + 1) // 2
+    spin_pair = spin * (spin + 1) // 2
+
+    eri_dev = ctx.zeros((spin_pair, npair, npair), np.float64)
+    eng = EriEngine(ctx, kmesh, nao, naux, nemb, spin, C_dev, eri_dev, t_reversal_symm)
+    try:
+        kL_list = None
+        dist = None
+        if use_mpi:
+            from libdmet_preview_amd.parallel import dist as _dist
+            dist = _dist
+            if dist.is_initialized():
+                kL_list = assign_workload(kmesh, dist.world_size(), t_reversal_symm)[dist.rank()]
+        eng.run(mydf, kL_list=kL_list, user_of_mesh=user_of_mesh)
+        if dist is not None and dist.is_initialized():
+            dist.all_reduce_sum_dev(eri_dev)
+        eri = eri_dev.get()
+    finally:
+        eng.close()
+
+    if not incore:
+        order = [0] if spin_pair == 1 else [0, 2, 1]
+        fn = fout if str(fout).endswith(".npy") else str(fout) + ".npy"
+        mm = np.lib.format.open_memmap(fn, mode="w+", dtype=np.float64, shape=eri.shape)
+        mm[:] = eri[order]
+        mm.flush()
+        return {"ccdd": mm}
+    log.debug(1, "ERI restore")
+    return eri_restore(eri, symmetry, nemb)
+
+
+get_emb_eri_fast = get_emb_eri_fast_gdf

@@ -1,0 +1,422 @@
+// K4 -- Schmidt-decomposition bath (SVD flavour).
+//
+// Replaces routine/slater.py:117-220 (`_get_emb_basis_svd`):
+//   :167-175  gather of rdm1_env_imp from the stripe (incl. the lattice.expand branch,
+//             system/lattice.py:304-337, done here as an index map  big[R1,R2] = A[R1-R2]
+//             without materialising the (ncells*nlo)^2 matrix),
+//   :180      scipy.linalg.svd (LAPACK dgesdd) of the tall-skinny (nenv x nb) block,
+//   :200-202  virtual-row projection + Loewdin (lo/lowdin.py:83-101),
+//   :212-213  scatter into C_lo_eo.
+//
+// SVD = Householder QR of the tall matrix (column at a time, every CU streams a row
+// slab; deterministic two-stage reductions, no atomics) + one-sided Jacobi SVD of the
+// small R factor in LDS (high relative accuracy for the singular values that are
+// compared with tol_bath = 1e-9; a Gram-matrix shortcut would square the condition
+// number) + application of Q to [U_r; 0].
+// Bound: HBM / launch latency: algorithmic bytes
+// 8*nenv*(nb + nbath).
+#include "common.h"
+
+int launch_eigh_public(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group,
+                       double *w, void *Vt, int v_real);
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NWAVE = NT / 64;
+constexpr int MAXB = 256;     // row-slab blocks for the tall-matrix kernels
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// A[r][c] = big[env_idx[r]][bath_col[c]],  big[(R1,p),(R2,q)] = rdm1[R1 - R2][p][q]
+__global__ void gather_env_imp_kernel(int n0, int n1, int n2, int nlo, const double *__restrict__ rdm1,
+                                      const int *__restrict__ env_idx, int nenv, const int *__restrict__ bath_col,
+                                      int nb, double *__restrict__ A) {
+    const long long total = (long long)nenv * nb;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(t / nb), c = (int)(t % nb);
+        const int e = env_idx[r], s = bath_col[c];
+        const int R1 = e / nlo, p = e % nlo, R2 = s / nlo, q = s % nlo;
+        const int a0 = R1 / (n1 * n2), a1 = (R1 / n2) % n1, a2 = R1 % n2;
+        const int b0 = R2 / (n1 * n2), b1 = (R2 / n2) % n1, b2 = R2 % n2;
+        const int c0 = (a0 - b0 + n0) % n0, c1 = (a1 - b1 + n1) % n1, c2 = (a2 - b2 + n2) % n2;
+        const int Rd = (c0 * n1 + c1) * n2 + c2;
+        A[t] = rdm1[((long long)Rd * nlo + p) * nlo + q];
+    }
+}
+
+// partial[blk][j] = sum over this block's rows r >= k of  V[r][kcol] * M[r][j]   (j in [j0, ncols))
+// V and M are row-major with leading dims ldv / ldm.  Lanes run along j.
+__global__ __launch_bounds__(NT) void col_dots_kernel(int nrows, int k, const double *__restrict__ V, int ldv, int kcol,
+                                                      const double *__restrict__ M, int ldm, int j0, int ncols,
+                                                      double *__restrict__ partial, int v_unit_diag,
+                                                      double *__restrict__ rowk_out) {
+    extern __shared__ double sh[];   // NWAVE x ncols
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // snapshot of row k of M for the next kernel (which rewrites that row while other
+    // workgroups still need its old values)
+    if (rowk_out != nullptr && blockIdx.x == 0)
+        for (int j = j0 + threadIdx.x; j < ncols; j += NT) rowk_out[j] = M[(long long)k * ldm + j];
+    const int rows_per_blk = (nrows - k + gridDim.x - 1) / gridDim.x;
+    const int r0 = k + blockIdx.x * rows_per_blk;
+    const int r1 = min(nrows, r0 + rows_per_blk);
+    for (int jb = j0; jb < ncols; jb += 64) {
+        const int j = jb + lane;
+        double acc = 0.0;
+        for (int r = r0 + wave; r < r1; r += NWAVE) {
+            double v = V[(long long)r * ldv + kcol];
+            if (v_unit_diag && r == k) v = 1.0;
+            // QR mode (rowk_out given): the j == kcol entry is the norm of the part BELOW the
+            // diagonal (computed directly, never as skk - alpha^2, which cancels)
+            if (j < ncols && !(rowk_out != nullptr && r == k && j == kcol)) acc += v * M[(long long)r * ldm + j];
+        }
+        if (j < ncols) sh[wave * ncols + j] = acc;
+    }
+    __syncthreads();
+    for (int j = j0 + threadIdx.x; j < ncols; j += NT) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) s += sh[w * ncols + j];
+        partial[(long long)blockIdx.x * ncols + j] = s;
+    }
+}
+
+// Householder QR step k on A (nrows x nb): uses partial[blk][j] = sum_{r>=k} A[r][k] A[r][j] for j > k
+// and partial[blk][k] = sum_{r>k} A[r][k]^2.
+__global__ __launch_bounds__(NT) void qr_apply_kernel(int nrows, int nb, int k, double *__restrict__ A,
+                                                      const double *__restrict__ partial, int nblk_partial,
+                                                      const double *__restrict__ rowk, double *__restrict__ tau_out) {
+    extern __shared__ double sh[];   // g[nb] | fac[nb]
+    __shared__ double s_tau, s_beta, s_inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // deterministic reduction of the partials (fixed order), redundantly per block
+    for (int j = k + threadIdx.x; j < nb; j += NT) {
+        double s = 0.0;
+        for (int q = 0; q < nblk_partial; ++q) s += partial[(long long)q * nb + j];
+        sh[j] = s;
+    }
+    __syncthreads();
+    const double alpha = rowk[k];
+    if (threadIdx.x == 0) {
+        const double xnorm2 = sh[k];
+        double tau = 0.0, beta = alpha, inv = 0.0;
+        if (xnorm2 > 0.0) {
+            const double nrm = sqrt(alpha * alpha + xnorm2);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            inv = 1.0 / (alpha - beta);
+        }
+        s_tau = tau; s_beta = beta; s_inv = inv;
+    }
+    __syncthreads();
+    const double tau = s_tau, beta = s_beta, inv = s_inv;
+    // fac_j = tau * v^T a_j,  v = [1; x * inv]:  v^T a_j = A[k][j] + (g_j - alpha A[k][j]) * inv
+    for (int j = k + 1 + threadIdx.x; j < nb; j += NT) {
+        const double akj = rowk[j];
+        sh[nb + j] = tau * (akj + (sh[j] - alpha * akj) * inv);   // sh[j] includes the r = k term
+    }
+    __syncthreads();
+    const int rows_per_blk = (nrows - k + gridDim.x - 1) / gridDim.x;
+    const int r0 = k + blockIdx.x * rows_per_blk;
+    const int r1 = min(nrows, r0 + rows_per_blk);
+    for (int r = r0 + wave; r < r1; r += NWAVE) {
+        const double ark = (r == k) ? alpha : A[(long long)r * nb + k];
+        const double vr = (r == k) ? 1.0 : ark * inv;
+        for (int j = k + 1 + lane; j < nb; j += 64)
+            if (tau != 0.0) A[(long long)r * nb + j] -= sh[nb + j] * vr;
+        if (lane == 0) A[(long long)r * nb + k] = (r == k) ? beta : vr;   // reflector stored in place
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tau_out[k] = tau;
+}
+
+// U (nrows x nc) <- H_k U with H_k = I - tau v v^T, v from column k of QR-factored A (unit diagonal)
+__global__ __launch_bounds__(NT) void q_apply_kernel(int nrows, int nb, int nc, int k, const double *__restrict__ A,
+                                                     const double *__restrict__ tau_arr, double *__restrict__ U,
+                                                     const double *__restrict__ partial, int nblk_partial) {
+    extern __shared__ double sh[];   // t[nc]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double tau = tau_arr[k];
+    if (tau == 0.0) return;
+    for (int j = threadIdx.x; j < nc; j += NT) {
+        double s = 0.0;
+        for (int q = 0; q < nblk_partial; ++q) s += partial[(long long)q * nc + j];
+        sh[j] = tau * s;
+    }
+    __syncthreads();
+    const int rows_per_blk = (nrows - k + gridDim.x - 1) / gridDim.x;
+    const int r0 = k + blockIdx.x * rows_per_blk;
+    const int r1 = min(nrows, r0 + rows_per_blk);
+    for (int r = r0 + wave; r < r1; r += NWAVE) {
+        const double vr = (r == k) ? 1.0 : A[(long long)r * nb + k];
+        for (int j = lane; j < nc; j += 64) U[(long long)r * nc + j] -= sh[j] * vr;
+    }
+}
+
+// One-sided Jacobi SVD of the upper-triangular R (top nb x nb of A).  One workgroup.
+// Output: sigma (descending), Utop (nb x nb row-major, column j <-> sigma[j]).
+__global__ __launch_bounds__(NT) void jacobi_svd_kernel(int nb, const double *__restrict__ A, int lda,
+                                                        double *__restrict__ sigma, double *__restrict__ Utop,
+                                                        int *__restrict__ status) {
+    extern __shared__ double sh[];
+    const int N = nb + (nb & 1);              // padded to even
+    const int ld = nb + 1;                    // column stride (odd: conflict-free column walks)
+    double *G = sh;                           // [N][ld] column-major: G[j*ld + i] = R[i][j]
+    double *nrm = G + (size_t)N * ld;         // [N]
+    __shared__ int s_rot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < N * ld; t += NT) {
+        const int j = t / ld, i = t % ld;
+        G[t] = (j < nb && i < nb && i <= j) ? A[(long long)i * lda + j] : 0.0;
+    }
+    __syncthreads();
+    const double eps = 2.220446049250313e-16;
+    int sweep = 0;
+    for (; sweep < 60; ++sweep) {
+        if (threadIdx.x == 0) s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < N - 1; ++round) {
+            for (int pi = wave; pi < N / 2; pi += NWAVE) {
+                int p, q;
+                if (pi == 0) { p = N - 1; q = round; }
+                else { p = (round + pi) % (N - 1); q = (round - pi + (N - 1)) % (N - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (q >= nb) continue;       // padding column
+                double a = 0.0, b = 0.0, c = 0.0;
+                for (int i = lane; i < nb; i += 64) {
+                    const double gp = G[p * ld + i], gq = G[q * ld + i];
+                    a += gp * gp; b += gq * gq; c += gp * gq;
+                }
+                a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+                if (fabs(c) > eps * sqrt(a * b) && c != 0.0) {
+                    const double zeta = (b - a) / (2.0 * c);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                    for (int i = lane; i < nb; i += 64) {
+                        const double gp = G[p * ld + i], gq = G[q * ld + i];
+                        G[p * ld + i] = cs * gp - sn * gq;
+                        G[q * ld + i] = sn * gp + cs * gq;
+                    }
+                    if (lane == 0) atomicAdd(&s_rot, 1);
+                }
+            }
+            __syncthreads();
+        }
+        const int rot = s_rot;
+        __syncthreads();
+        if (rot == 0) break;
+    }
+    if (threadIdx.x == 0 && sweep >= 60) *status = 2;
+    // norms, ranks (descending, stable), normalised columns
+    for (int j = wave; j < nb; j += NWAVE) {
+        double a = 0.0;
+        for (int i = lane; i < nb; i += 64) a += G[j * ld + i] * G[j * ld + i];
+        a = wave_sum(a);
+        if (lane == 0) nrm[j] = sqrt(a);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nb; j += NT) {
+        const double sj = nrm[j];
+        int rk = 0;
+        for (int q = 0; q < nb; ++q) rk += (nrm[q] > sj || (nrm[q] == sj && q < j)) ? 1 : 0;
+        sigma[rk] = sj;
+        const double inv = sj > 0.0 ? 1.0 / sj : 0.0;
+        for (int i = 0; i < nb; ++i) Utop[(long long)i * nb + rk] = G[j * ld + i] * inv;
+    }
+}
+
+__global__ void mask_copy_kernel(int nenv, int nb, int nbath, const double *__restrict__ U,
+                                 const int *__restrict__ virt_mask, int apply_mask, double *__restrict__ B) {
+    const long long total = (long long)nenv * nbath;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(t / nbath), c = (int)(t % nbath);
+        B[t] = (apply_mask && virt_mask[r]) ? 0.0 : U[(long long)r * nb + c];
+    }
+}
+
+// partial Gram: partial[blk][i*nc + j] = sum_{rows of blk} B[r][i] B[r][j]
+__global__ __launch_bounds__(NT) void gram_partial_kernel(int nrows, int nc, const double *__restrict__ B,
+                                                          double *__restrict__ partial) {
+    const int rows_per_blk = (nrows + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(nrows, r0 + rows_per_blk);
+    for (int t = threadIdx.x; t < nc * nc; t += NT) {
+        const int i = t / nc, j = t % nc;
+        double s = 0.0;
+        for (int r = r0; r < r1; ++r) s += B[(long long)r * nc + i] * B[(long long)r * nc + j];
+        partial[(long long)blockIdx.x * nc * nc + t] = s;
+    }
+}
+__global__ void reduce_partials_kernel(int n, int nblk, const double *__restrict__ partial, double *__restrict__ out) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int q = 0; q < nblk; ++q) s += partial[(long long)q * n + t];
+        out[t] = s;
+    }
+}
+// X = sum_{m: e_m > tol} v_m v_m^T / sqrt(e_m)   from Vt rows (lo/lowdin.py:83-91)
+__global__ void inv_sqrt_kernel(int n, const double *__restrict__ e, const double *__restrict__ Vt, double tol,
+                                double *__restrict__ X) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * n; t += gridDim.x * blockDim.x) {
+        const int i = t / n, j = t % n;
+        double s = 0.0;
+        for (int m = 0; m < n; ++m)
+            if (e[m] > tol) s += Vt[m * n + i] * Vt[m * n + j] / sqrt(e[m]);
+        X[t] = s;
+    }
+}
+// basis[env_idx[r]][nimp + c] = sum_j B[r][j] X[j][c]   (or B itself when X == nullptr)
+__global__ void scatter_bath_kernel(int nenv, int nbath, const double *__restrict__ B, const double *__restrict__ X,
+                                    const int *__restrict__ env_idx, int nimp, int ncol_basis,
+                                    double *__restrict__ basis) {
+    const long long total = (long long)nenv * nbath;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(t / nbath), c = (int)(t % nbath);
+        double s;
+        if (X) {
+            s = 0.0;
+            for (int j = 0; j < nbath; ++j) s += B[(long long)r * nbath + j] * X[j * nbath + c];
+        } else {
+            s = B[t];
+        }
+        if (nimp + c < ncol_basis) basis[(long long)env_idx[r] * ncol_basis + nimp + c] = s;
+    }
+}
+__global__ void scatter_imp_kernel(int nimp, const int *__restrict__ imp_idx, int ncol_basis, double *__restrict__ basis) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nimp && i < ncol_basis) basis[(long long)imp_idx[i] * ncol_basis + i] = 1.0;
+}
+
+int nblocks_for(int nrows) {
+    int nb = (nrows + 4 * NWAVE - 1) / (4 * NWAVE);
+    return nb < 1 ? 1 : (nb > MAXB ? MAXB : nb);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1, const int32_t *env_idx, int nenv,
+                 const int32_t *bath_col, int nb, double *sigma, double *U) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!mesh || nlo <= 0 || !rdm1 || !env_idx || !bath_col || nenv <= 0 || nb <= 0 || !sigma || !U)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: bad arguments");
+    if (nb > 120) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: nb = %d exceeds the supported maximum of 120", nb);
+    if (nenv < nb) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: needs nenv >= nb (tall matrix)");
+    FamScope fs(ctx, DMK_FAM_BATH);
+    // workspace: A (nenv x nb) | partial (MAXB x nb) | tau (nb) | rowk (nb) | Utop (nb x nb) | status
+    const size_t szA = (size_t)nenv * nb, szP = (size_t)MAXB * nb;
+    void *ws = nullptr;
+    int rc = dmk_scratch(ctx, (szA + szP + 2 * (size_t)nb + (size_t)nb * nb + 8) * sizeof(double), &ws);
+    if (rc) return rc;
+    double *A = reinterpret_cast<double *>(ws);
+    double *partial = A + szA;
+    double *tau = partial + szP;
+    double *rowk = tau + nb;
+    double *Utop = rowk + nb;
+    int *status = reinterpret_cast<int *>(Utop + (size_t)nb * nb);
+    DMK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+    {
+        long long total = (long long)nenv * nb;
+        int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(gather_env_imp_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mesh[0], mesh[1], mesh[2], nlo,
+                           rdm1, env_idx, nenv, bath_col, nb, A);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    // Householder QR, one column at a time
+    for (int k = 0; k < nb; ++k) {
+        const int nblk = nblocks_for(nenv - k);
+        hipLaunchKernelGGL(col_dots_kernel, dim3(nblk), dim3(NT), NWAVE * nb * sizeof(double), ctx->stream, nenv, k, A,
+                           nb, k, A, nb, k, nb, partial, 0, rowk);
+        DMK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(qr_apply_kernel, dim3(nblk), dim3(NT), 2 * nb * sizeof(double), ctx->stream, nenv, nb, k, A,
+                           partial, nblk, rowk, tau);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    // SVD of R
+    {
+        const int N = nb + (nb & 1);
+        const size_t lds = ((size_t)N * (nb + 1) + N) * sizeof(double);
+        if (lds > 48 * 1024)
+            DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_svd_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(jacobi_svd_kernel, dim3(1), dim3(NT), lds, ctx->stream, nb, A, nb, sigma, Utop, status);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    // U = Q [Utop; 0]
+    DMK_HIP(ctx, hipMemsetAsync(U, 0, szA * sizeof(double), ctx->stream));
+    DMK_HIP(ctx, hipMemcpyAsync(U, Utop, (size_t)nb * nb * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int k = nb - 1; k >= 0; --k) {
+        const int nblk = nblocks_for(nenv - k);
+        hipLaunchKernelGGL(col_dots_kernel, dim3(nblk), dim3(NT), NWAVE * nb * sizeof(double), ctx->stream, nenv, k, A,
+                           nb, k, U, nb, 0, nb, partial, 1, (double *)nullptr);
+        DMK_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(q_apply_kernel, dim3(nblk), dim3(NT), nb * sizeof(double), ctx->stream, nenv, nb, nb, k, A,
+                           tau, U, partial, nblk);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    int st = 0;
+    DMK_HIP(ctx, hipMemcpyAsync(&st, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "bath_svd: Jacobi SVD did not converge");
+    return DMK_OK;
+}
+
+int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath, const int32_t *virt_mask, int orth,
+                      const int32_t *env_idx, const int32_t *imp_idx, int nimp, int nsites, int ncol_basis,
+                      double *basis) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!U || nenv <= 0 || nb <= 0 || nbath < 0 || nbath > nb || !env_idx || !imp_idx || nimp < 0 || nsites <= 0 ||
+        ncol_basis <= 0 || !basis || (orth && !virt_mask))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "bath_assemble: bad arguments");
+    DMK_HIP(ctx, hipMemsetAsync(basis, 0, (size_t)nsites * ncol_basis * sizeof(double), ctx->stream));
+    if (nimp > 0) {
+        FamScope fs(ctx, DMK_FAM_BATH);
+        hipLaunchKernelGGL(scatter_imp_kernel, dim3((nimp + 255) / 256), dim3(256), 0, ctx->stream, nimp, imp_idx,
+                           ncol_basis, basis);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    if (nbath == 0) return DMK_OK;
+    const int GB = 128;
+    const size_t szB = (size_t)nenv * nbath, szS = (size_t)nbath * nbath;
+    // separate allocation: the eigensolver below uses the context scratch
+    double *wsd = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&wsd), (szB + (size_t)GB * szS + 3 * szS + nbath) * sizeof(double));
+    if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "bath_assemble: workspace allocation failed");
+    double *B = wsd, *partial = B + szB, *S = partial + (size_t)GB * szS, *Vt = S + szS, *X = Vt + szS, *ev = X + szS;
+    int rc = DMK_OK;
+    auto cleanup = [&]() { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(wsd); };
+    {
+        FamScope fs(ctx, DMK_FAM_BATH);
+        const int blocks = (int)std::min<long long>(((long long)szB + 255) / 256, 4096);
+        hipLaunchKernelGGL(mask_copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, nenv, nb, nbath, U, virt_mask,
+                           orth ? 1 : 0, B);
+        if (orth) {
+            hipLaunchKernelGGL(gram_partial_kernel, dim3(GB), dim3(NT), 0, ctx->stream, nenv, nbath, B, partial);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(16), dim3(256), 0, ctx->stream, (int)szS, GB, partial, S);
+        }
+    }
+    if (orth) {
+        rc = launch_eigh_public(ctx, nbath, 1, S, 1, nullptr, 0, ev, Vt, 1);
+        if (rc) { cleanup(); return rc; }
+    }
+    {
+        FamScope fs(ctx, DMK_FAM_BATH);
+        if (orth)
+            hipLaunchKernelGGL(inv_sqrt_kernel, dim3(16), dim3(256), 0, ctx->stream, nbath, ev, Vt, 1e-14, X);
+        const int blocks = (int)std::min<long long>(((long long)szB + 255) / 256, 4096);
+        hipLaunchKernelGGL(scatter_bath_kernel, dim3(blocks), dim3(256), 0, ctx->stream, nenv, nbath, B,
+                           orth ? X : (const double *)nullptr, env_idx, nimp, ncol_basis, basis);
+    }
+    hipError_t le = hipGetLastError();
+    cleanup();
+    if (le != hipSuccess) return dmk_fail(ctx, DMK_ERR_HIP, "bath_assemble: launch failed: %s", hipGetErrorString(le));
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,781 @@
+// C ABI of libdmetk: context, memory, k-mesh bookkeeping (host, integer), folds, ERI pipeline.
+// Kernel launchers live in the sibling .hip files; this file holds no device code except
+// tiny utility kernels (transpose, restore).
+#include "common.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <algorithm>
+
+// =============================================================================================
+// context / errors / memory
+// =============================================================================================
+
+int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else fprintf(stderr, "libdmetk: %s\n", buf);
+    return code;
+}
+
+static thread_local std::string g_noctx_err;
+
+FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f) {
+    if (ctx && ctx->profile) {
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        a = get(); b = get();
+        if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+    if (ctx) ctx->fam_launches[fam] += 1;
+}
+FamScope::~FamScope() {
+    if (ctx && ctx->profile && a && b) {
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({fam, a, b});
+    }
+}
+
+static void drain_pending(dmk_ctx *ctx) {
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+            ctx->fam_ms[p.fam] += ms;
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" {
+
+const char *dmk_version(void) { return "libdmetk 0.1 (gfx950)"; }
+
+int dmk_init(int device, void *stream, dmk_ctx **out) {
+    if (!out) return DMK_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "libdmetk: no HIP device available (%s)\n", hipGetErrorString(e));
+        return DMK_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) return DMK_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return DMK_ERR_HIP;
+    dmk_ctx *c = new dmk_ctx();
+    c->device = device;
+    c->stream = reinterpret_cast<hipStream_t>(stream);
+    if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+        delete c;
+        return DMK_ERR_HIP;
+    }
+    *out = c;
+    return DMK_OK;
+}
+
+int dmk_destroy(dmk_ctx *ctx) {
+    if (!ctx) return DMK_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_pending(ctx);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &p : ctx->phases) (void)hipFree(p.dev);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    (void)hipEventDestroy(ctx->t0);
+    (void)hipEventDestroy(ctx->t1);
+    delete ctx;
+    return DMK_OK;
+}
+
+int dmk_set_stream(dmk_ctx *ctx, void *stream) {
+    if (!ctx) return DMK_ERR_INVALID;
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    return DMK_OK;
+}
+
+int dmk_sync(dmk_ctx *ctx) {
+    if (!ctx) return DMK_ERR_INVALID;
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DMK_OK;
+}
+
+const char *dmk_last_error(const dmk_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+int dmk_malloc(dmk_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return DMK_ERR_INVALID;
+    *out = nullptr;
+    if (bytes == 0) return DMK_OK;
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return DMK_OK;
+}
+int dmk_free(dmk_ctx *ctx, void *p) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (p) DMK_HIP(ctx, hipFree(p));
+    return DMK_OK;
+}
+int dmk_memset(dmk_ctx *ctx, void *p, int value, size_t bytes) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (bytes) DMK_HIP(ctx, hipMemsetAsync(p, value, bytes, ctx->stream));
+    return DMK_OK;
+}
+int dmk_memcpy_h2d(dmk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (bytes) {
+        DMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return DMK_OK;
+}
+int dmk_memcpy_d2h(dmk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (bytes) {
+        DMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return DMK_OK;
+}
+int dmk_memcpy_d2d(dmk_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (bytes) DMK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return DMK_OK;
+}
+
+int dmk_timer_start(dmk_ctx *ctx) {
+    if (!ctx) return DMK_ERR_INVALID;
+    DMK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return DMK_OK;
+}
+int dmk_timer_stop(dmk_ctx *ctx, double *ms_out) {
+    if (!ctx || !ms_out) return DMK_ERR_INVALID;
+    DMK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    DMK_HIP(ctx, hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    DMK_HIP(ctx, hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    *ms_out = ms;
+    return DMK_OK;
+}
+
+int dmk_profile(dmk_ctx *ctx, int enable) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!enable && ctx->profile) { (void)hipStreamSynchronize(ctx->stream); drain_pending(ctx); }
+    ctx->profile = enable != 0;
+    return DMK_OK;
+}
+int dmk_profile_read(dmk_ctx *ctx, double *ms, int64_t *launches, int reset) {
+    if (!ctx) return DMK_ERR_INVALID;
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_pending(ctx);
+    for (int i = 0; i < DMK_FAM_COUNT; ++i) {
+        if (ms) ms[i] = ctx->fam_ms[i];
+        if (launches) launches[i] = ctx->fam_launches[i];
+        if (reset) { ctx->fam_ms[i] = 0; ctx->fam_launches[i] = 0; }
+    }
+    return DMK_OK;
+}
+
+}  // extern "C"
+
+int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DMK_HIP(ctx, hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        hipError_t e = hipMalloc(&ctx->scratch, bytes);
+        if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "scratch hipMalloc(%zu) failed", bytes);
+        ctx->scratch_bytes = bytes;
+    }
+    *out = ctx->scratch;
+    return DMK_OK;
+}
+
+// =============================================================================================
+// a1 / a2 / a15 : integer mesh bookkeeping (host)
+// =============================================================================================
+
+namespace {
+
+struct Mesh {
+    int n[3];
+    int nk;
+    explicit Mesh(const int m[3]) { n[0] = m[0]; n[1] = m[1]; n[2] = m[2]; nk = m[0] * m[1] * m[2]; }
+    bool ok() const { return n[0] > 0 && n[1] > 0 && n[2] > 0 && (long long)n[0] * n[1] * n[2] < (1LL << 24); }
+    void ints(int idx, int a[3]) const {
+        a[2] = idx % n[2];
+        a[1] = (idx / n[2]) % n[1];
+        a[0] = idx / (n[2] * n[1]);
+    }
+    int index(const int a[3]) const { return (a[0] * n[1] + a[1]) * n[2] + a[2]; }
+    static int mod(int x, int m) { int r = x % m; return r < 0 ? r + m : r; }
+    int combine(int i, int j, int sign) const {   // idx(a_i + sign*a_j)
+        int a[3], b[3], c[3];
+        ints(i, a); ints(j, b);
+        for (int d = 0; d < 3; ++d) c[d] = mod(a[d] + sign * b[d], n[d]);
+        return index(c);
+    }
+    int minus(int i) const {
+        int a[3], c[3];
+        ints(i, a);
+        for (int d = 0; d < 3; ++d) c[d] = mod(-a[d], n[d]);
+        return index(c);
+    }
+    // fftfreq integer of mesh index a on an axis of length n
+    static int freq(int a, int n) { return a <= (n - 1) / 2 ? a : a - n; }
+};
+
+void tr_weights(const Mesh &m, int tr, std::vector<int> &w) {
+    w.assign(m.nk, 1);
+    if (!tr) return;
+    for (int i = 0; i < m.nk; ++i) {
+        const int mi = m.minus(i);
+        w[i] = (mi == i) ? 1 : (mi > i ? 2 : 0);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmk_kmesh_tables(const int mesh[3], int32_t *kint, int32_t *minus_k, int32_t *weights) {
+    Mesh m(mesh);
+    if (!m.ok()) return DMK_ERR_INVALID;
+    std::vector<int> w;
+    tr_weights(m, 1, w);
+    for (int i = 0; i < m.nk; ++i) {
+        if (kint) { int a[3]; m.ints(i, a); kint[3 * i] = a[0]; kint[3 * i + 1] = a[1]; kint[3 * i + 2] = a[2]; }
+        if (minus_k) minus_k[i] = m.minus(i);
+        if (weights) weights[i] = w[i];
+    }
+    return DMK_OK;
+}
+
+int dmk_kconserv_table(const int mesh[3], int32_t *out) {
+    Mesh m(mesh);
+    if (!m.ok() || !out) return DMK_ERR_INVALID;
+    for (int kL = 0; kL < m.nk; ++kL)
+        for (int i = 0; i < m.nk; ++i) out[(size_t)kL * m.nk + i] = m.combine(i, kL, -1);
+    return DMK_OK;
+}
+
+int dmk_cell_add_table(const int mesh[3], int sign, int32_t *out) {
+    Mesh m(mesh);
+    if (!m.ok() || !out || (sign != 1 && sign != -1)) return DMK_ERR_INVALID;
+    for (int i = 0; i < m.nk; ++i)
+        for (int j = 0; j < m.nk; ++j) out[(size_t)i * m.nk + j] = m.combine(i, j, sign);
+    return DMK_OK;
+}
+
+int dmk_kpts_scaled(const int mesh[3], double *kpts) {
+    Mesh m(mesh);
+    if (!m.ok() || !kpts) return DMK_ERR_INVALID;
+    for (int i = 0; i < m.nk; ++i) {
+        int a[3];
+        m.ints(i, a);
+        for (int d = 0; d < 3; ++d) {
+            const double val = 1.0 / ((double)m.n[d] * 1.0);      // numpy fftfreq: results * (1/(n*d))
+            kpts[3 * i + d] = (double)Mesh::freq(a[d], m.n[d]) * val;
+        }
+    }
+    return DMK_OK;
+}
+
+int dmk_kpt_member(const int mesh[3], const double kpt[3], double tol) {
+    Mesh m(mesh);
+    if (!m.ok() || !kpt) return DMK_ERR_INVALID;
+    std::vector<double> ks((size_t)3 * m.nk);
+    dmk_kpts_scaled(mesh, ks.data());
+    for (int i = 0; i < m.nk; ++i) {
+        double s = 0.0;
+        for (int d = 0; d < 3; ++d) {
+            double dk = ks[3 * i + d] - kpt[d];
+            dk -= nearbyint(dk);
+            s += dk * dk;
+        }
+        if (sqrt(s) < tol) return i;
+    }
+    return -1;
+}
+
+int dmk_eri_plan(const int mesh[3], int tr, int32_t *plan, int64_t capacity, int64_t *nrec) {
+    Mesh m(mesh);
+    if (!m.ok() || !nrec) return DMK_ERR_INVALID;
+    std::vector<int> w;
+    tr_weights(m, tr, w);
+    std::vector<char> visited(m.nk);
+    int64_t n = 0;
+    for (int kL = 0; kL < m.nk; ++kL) {
+        if (w[kL] <= 0) continue;
+        std::fill(visited.begin(), visited.end(), 0);
+        for (int i = 0; i < m.nk; ++i) {
+            if (visited[i]) continue;
+            visited[i] = 1;
+            const int j = m.combine(i, kL, -1);
+            int jm = -1, sym = 0;
+            if (tr) {
+                jm = m.minus(j);
+                sym = visited[jm] ? 0 : 1;
+            }
+            if (plan) {
+                if (n >= capacity) return DMK_ERR_INVALID;
+                int32_t *r = plan + 5 * n;
+                r[0] = kL; r[1] = i; r[2] = j; r[3] = jm; r[4] = sym;
+            }
+            ++n;
+            if (tr) visited[jm] = 1;
+        }
+    }
+    *nrec = n;
+    return DMK_OK;
+}
+
+int dmk_assign_workload(const int mesh[3], int tr, int nranks, int rank, int32_t *kl, int *n_out) {
+    Mesh m(mesh);
+    if (!m.ok() || nranks <= 0 || rank < 0 || rank >= nranks || !n_out) return DMK_ERR_INVALID;
+    std::vector<int> w, idx1, idx2;
+    tr_weights(m, tr, w);
+    for (int i = 0; i < m.nk; ++i) {
+        if (w[i] == 1) idx1.push_back(i);
+        else if (w[i] == 2) idx2.push_back(i);
+    }
+    const int nibz = (int)(idx1.size() + idx2.size());
+    const int neach = nibz / nranks, extras = nibz % nranks;
+    std::vector<std::vector<int>> kids(nranks);
+    for (size_t i = 0; i < idx1.size(); ++i) kids[i % nranks].push_back(idx1[i]);
+    size_t start = 0;
+    for (int r = 0; r < nranks; ++r) {
+        const int ns = neach + (r < extras ? 1 : 0);
+        long long want = (long long)ns - (long long)kids[r].size();
+        // python slice semantics of idx_2[start:end] (end may fall below start -> empty)
+        long long end = (long long)start + want;
+        long long s = std::min<long long>((long long)start, (long long)idx2.size());
+        long long e2 = std::min<long long>(std::max<long long>(end, 0), (long long)idx2.size());
+        for (long long t = s; t < e2; ++t) kids[r].push_back(idx2[(size_t)t]);
+        start = (size_t)std::max<long long>(end, 0);
+    }
+    *n_out = (int)kids[rank].size();
+    if (kl) for (size_t t = 0; t < kids[rank].size(); ++t) kl[t] = kids[rank][t];
+    return DMK_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// a6 : folds (DFT as a complex GEMM against a cached twiddle matrix)
+// =============================================================================================
+
+namespace {
+
+// P[r][k] = exp(-2 pi i sum_d a_d(k) a_d(r) / n_d), symmetric in (r, k); rows optionally
+// restricted to `subset`.
+int get_phase(dmk_ctx *ctx, const Mesh &m, const int32_t *subset, int nsub, void **dev) {
+    for (auto &p : ctx->phases) {
+        if (p.mesh[0] == m.n[0] && p.mesh[1] == m.n[1] && p.mesh[2] == m.n[2] && p.nsub == nsub &&
+            (nsub == 0 || std::equal(p.subset.begin(), p.subset.end(), subset))) {
+            *dev = p.dev;
+            return DMK_OK;
+        }
+    }
+    // common denominator D = lcm(n0, n1, n2)
+    auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
+    long long D = m.n[0];
+    D = D / gcd(D, m.n[1]) * m.n[1];
+    D = D / gcd(D, m.n[2]) * m.n[2];
+    const int rows = nsub > 0 ? nsub : m.nk;
+    std::vector<double> tw((size_t)2 * D);
+    for (long long t = 0; t < D; ++t) {
+        const long double ang = -2.0L * 3.141592653589793238462643383279502884L * (long double)t / (long double)D;
+        tw[2 * t] = (double)cosl(ang);
+        tw[2 * t + 1] = (double)sinl(ang);
+    }
+    // exact values on the axes
+    for (long long t = 0; t < D; ++t) {
+        if ((4 * t) % D == 0) {
+            const int q = (int)((4 * t) / D);   // angle = -q*pi/2
+            const double c[4] = {1, 0, -1, 0}, s[4] = {0, -1, 0, 1};
+            tw[2 * t] = c[q]; tw[2 * t + 1] = s[q];
+        }
+    }
+    std::vector<double> host((size_t)2 * rows * m.nk);
+    for (int rr = 0; rr < rows; ++rr) {
+        const int r = nsub > 0 ? subset[rr] : rr;
+        if (r < 0 || r >= m.nk) return dmk_fail(ctx, DMK_ERR_INVALID, "fold: k subset index out of range");
+        int a[3];
+        m.ints(r, a);
+        for (int k = 0; k < m.nk; ++k) {
+            int b[3];
+            m.ints(k, b);
+            long long t = 0;
+            for (int d = 0; d < 3; ++d) t += (long long)a[d] * b[d] % m.n[d] * (D / m.n[d]);
+            t %= D;
+            host[2 * ((size_t)rr * m.nk + k)] = tw[2 * t];
+            host[2 * ((size_t)rr * m.nk + k) + 1] = tw[2 * t + 1];
+        }
+    }
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, host.size() * sizeof(double));
+    if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "fold: phase allocation failed");
+    DMK_HIP(ctx, hipMemcpyAsync(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    dmk_ctx::Phase ph;
+    ph.mesh[0] = m.n[0]; ph.mesh[1] = m.n[1]; ph.mesh[2] = m.n[2];
+    ph.dir = 0; ph.nsub = nsub;
+    if (nsub > 0) ph.subset.assign(subset, subset + nsub);
+    ph.dev = d;
+    ctx->phases.push_back(ph);
+    *dev = d;
+    return DMK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmk_fold_R2k(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch, const void *in_R, int in_is_complex,
+                 void *out_k) {
+    if (!ctx) return DMK_ERR_INVALID;
+    Mesh m(mesh);
+    if (!m.ok() || ncol <= 0 || batch <= 0 || !in_R || !out_k || ncol > 0x7fffffffLL)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "fold_R2k: bad arguments");
+    void *P = nullptr;
+    int rc = get_phase(ctx, m, nullptr, 0, &P);
+    if (rc) return rc;
+    ZGemm g;
+    g.M = m.nk; g.N = (int)ncol; g.K = m.nk; g.batch = batch; g.nseg = 1;
+    g.seg[0].A = P; g.seg[0].lda = m.nk; g.seg[0].strideA = 0; g.seg[0].a_kmajor = 1;   // A[kdim=R][m=k] = P[R][k]
+    g.seg[0].B = in_R; g.seg[0].ldb = ncol; g.seg[0].strideB = (int64_t)m.nk * ncol; g.seg[0].b_kmajor = 1;
+    g.seg[0].b_real = in_is_complex ? 0 : 1;
+    g.alpha = 1.0; g.epi = ZEPI_STORE; g.C = out_k; g.ldc = ncol; g.strideC = (int64_t)m.nk * ncol;
+    return launch_zgemm(ctx, g, DMK_FAM_FOLD);
+}
+
+static int fold_k2R_impl(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch, const void *in_k, void *out,
+                         int real_out, double *imag_max, const int32_t *subset, int nsub) {
+    if (!ctx) return DMK_ERR_INVALID;
+    Mesh m(mesh);
+    if (!m.ok() || ncol <= 0 || batch <= 0 || !in_k || !out || ncol > 0x7fffffffLL || nsub < 0 || nsub > m.nk)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "fold_k2R: bad arguments");
+    void *P = nullptr;
+    int rc = get_phase(ctx, m, subset, subset ? nsub : 0, &P);
+    if (rc) return rc;
+    const int kin = (subset && nsub > 0) ? nsub : m.nk;
+    if (imag_max) DMK_HIP(ctx, hipMemsetAsync(imag_max, 0, sizeof(double), ctx->stream));
+    ZGemm g;
+    g.M = m.nk; g.N = (int)ncol; g.K = kin; g.batch = batch; g.nseg = 1;
+    // out[R] = (1/N) sum_k conj(P[k][R]) in[k]  ->  A[kdim=k][m=R] = conj(P[k][R])
+    g.seg[0].A = P; g.seg[0].lda = m.nk; g.seg[0].strideA = 0; g.seg[0].a_kmajor = 1; g.seg[0].conjA = 1;
+    g.seg[0].B = in_k; g.seg[0].ldb = ncol; g.seg[0].strideB = (int64_t)kin * ncol; g.seg[0].b_kmajor = 1;
+    g.alpha = 1.0 / (double)m.nk;
+    g.epi = real_out ? ZEPI_STORE_REAL : ZEPI_STORE;
+    g.C = out; g.ldc = ncol; g.strideC = (int64_t)m.nk * ncol; g.imag_max = imag_max;
+    return launch_zgemm(ctx, g, DMK_FAM_FOLD);
+}
+
+int dmk_fold_k2R(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch, const void *in_k, double *out_R,
+                 double *imag_max_dev, const int32_t *k_subset_host, int nsub) {
+    return fold_k2R_impl(ctx, mesh, ncol, batch, in_k, out_R, 1, imag_max_dev, k_subset_host, nsub);
+}
+int dmk_fold_k2R_complex(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch, const void *in_k, void *out_R) {
+    return fold_k2R_impl(ctx, mesh, ncol, batch, in_k, out_R, 0, nullptr, nullptr, 0);
+}
+
+// =============================================================================================
+// a9 / a10 : generic batched complex product
+// =============================================================================================
+
+int dmk_zgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int batch, double alpha, const void *A,
+                      int64_t strideA, const void *B, int64_t strideB, void *C, int64_t strideC) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (opA < 0 || opA > 2 || opB < 0 || opB > 2 || M < 0 || N < 0 || K < 0 || batch < 0)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "zgemm_batched: bad arguments");
+    if (M == 0 || N == 0 || batch == 0) return DMK_OK;
+    ZGemm g;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.nseg = 1;
+    ZSeg &s = g.seg[0];
+    s.A = A; s.B = B; s.strideA = strideA; s.strideB = strideB;
+    if (opA == 0) { s.a_kmajor = 0; s.lda = K; } else { s.a_kmajor = 1; s.lda = M; s.conjA = (opA == 2); }
+    if (opB == 0) { s.b_kmajor = 1; s.ldb = N; } else { s.b_kmajor = 0; s.ldb = K; s.conjB = (opB == 2); }
+    g.alpha = alpha; g.epi = ZEPI_STORE; g.C = C; g.ldc = N; g.strideC = strideC;
+    if (K == 0) {
+        DMK_HIP(ctx, hipMemsetAsync(C, 0, (size_t)16 * ((size_t)(batch - 1) * strideC + (size_t)M * N), ctx->stream));
+        return DMK_OK;
+    }
+    return launch_zgemm(ctx, g, DMK_FAM_ZGEMM_SMALL);
+}
+
+int dmk_occ_density(dmk_ctx *ctx, int n, int batch, const void *Vt, const double *occ, void *rho) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n <= 0 || batch <= 0 || !Vt || !occ || !rho) return dmk_fail(ctx, DMK_ERR_INVALID, "occ_density: bad arguments");
+    // rho[i][j] = sum_m Vt[m][i] occ[m] conj(Vt[m][j])   (routine/mfd.py:357)
+    ZGemm g;
+    g.M = n; g.N = n; g.K = n; g.batch = batch; g.nseg = 1;
+    ZSeg &s = g.seg[0];
+    s.A = Vt; s.lda = n; s.strideA = (int64_t)n * n; s.a_kmajor = 1;
+    s.B = Vt; s.ldb = n; s.strideB = (int64_t)n * n; s.b_kmajor = 1; s.conjB = 1; s.kscaleB = occ;
+    g.alpha = 1.0; g.epi = ZEPI_STORE; g.C = rho; g.ldc = n; g.strideC = (int64_t)n * n;
+    return launch_zgemm(ctx, g, DMK_FAM_ZGEMM_SMALL);
+}
+
+int dmk_dgemm_tn_acc(dmk_ctx *ctx, int N, int K, double alpha, const double *X, const double *Y, int64_t ldxy,
+                     double *C, int64_t ldc) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (N < 0 || K < 0 || !X || !Y || !C) return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_tn_acc: bad arguments");
+    return launch_dgemm_tn_acc(ctx, N, N, K, alpha, X, ldxy, Y, ldxy, C, ldc);
+}
+
+int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (naux <= 0 || nao <= 0 || !out || ki < 0 || kj < 0) return dmk_fail(ctx, DMK_ERR_INVALID, "df_block_philox: bad arguments");
+    return launch_philox_block(ctx, seed, ki, kj, naux, nao, out);
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// a11 - a14 : ERI pipeline
+// =============================================================================================
+
+struct dmk_eri {
+    dmk_ctx *ctx;
+    Mesh mesh;
+    int nao, naux, nemb, spin, tr;
+    int64_t npair;
+    const double2 *C;     // spin x nk x nao x nemb
+    double *eri;
+    double *planes = nullptr;   // spin x (2 naux) x npair
+    double2 *Ut = nullptr;      // lchunk x nao x nemb
+    int lchunk;
+    int cur_kL = -1;
+    double flops_half = 0.0, flops_contract = 0.0;
+    dmk_eri(dmk_ctx *c, const int m[3]) : ctx(c), mesh(m) {}
+};
+
+extern "C" {
+
+int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, int spin, int flags,
+                  const void *C_ao_emb, double *eri_out, dmk_eri **out) {
+    if (!ctx || !out) return DMK_ERR_INVALID;
+    *out = nullptr;
+    Mesh m(mesh);
+    if (!m.ok() || nao <= 0 || naux <= 0 || nemb <= 0 || (spin != 1 && spin != 2) || !C_ao_emb || !eri_out)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin: bad arguments");
+    dmk_eri *h = new dmk_eri(ctx, mesh);
+    h->nao = nao; h->naux = naux; h->nemb = nemb; h->spin = spin; h->tr = flags & 1;
+    h->npair = (int64_t)nemb * (nemb + 1) / 2;
+    h->C = reinterpret_cast<const double2 *>(C_ao_emb);
+    h->eri = eri_out;
+    h->lchunk = naux;
+    if (const char *e = getenv("DMK_ERI_LCHUNK")) {
+        int v = atoi(e);
+        if (v > 0 && v < naux) h->lchunk = v;
+    }
+    const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
+    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2);
+    hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&h->planes), plane_bytes);
+    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&h->Ut), ut_bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        if (h->planes) (void)hipFree(h->planes);
+        if (h->Ut) (void)hipFree(h->Ut);
+        delete h;
+        return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_begin: workspace allocation failed (%zu + %zu bytes)", plane_bytes, ut_bytes);
+    }
+    *out = h;
+    return DMK_OK;
+}
+
+int dmk_eri_begin_kL(dmk_eri *h, int kL) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (kL < 0 || kL >= h->mesh.nk) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin_kL: kL out of range");
+    if (h->cur_kL >= 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_begin_kL: previous kL not ended");
+    DMK_HIP(ctx, hipMemsetAsync(h->planes, 0, (size_t)h->spin * 2 * h->naux * h->npair * sizeof(double), ctx->stream));
+    h->cur_kL = kL;
+    return DMK_OK;
+}
+
+int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_block: no kL in progress");
+    if (ki < 0 || ki >= h->mesh.nk || kj < 0 || kj >= h->mesh.nk || !Lpq)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_block: bad arguments");
+    const int nao = h->nao, naux = h->naux, nemb = h->nemb;
+    const double2 *L = reinterpret_cast<const double2 *>(Lpq);
+    for (int s = 0; s < h->spin; ++s) {
+        const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
+        const double2 *Cj = h->C + ((size_t)s * h->mesh.nk + kj) * nao * nemb;
+        double *planes = h->planes + (size_t)s * 2 * naux * h->npair;
+        for (int l0 = 0; l0 < naux; l0 += h->lchunk) {
+            const int nl = std::min(h->lchunk, naux - l0);
+            // step 1: Ut[L][q][a] = sum_p Lpq[L][p][q] conj(Ci[p][a])
+            ZGemm g1;
+            g1.M = nao; g1.N = nemb; g1.K = nao; g1.batch = nl; g1.nseg = 1;
+            g1.seg[0].A = L + (size_t)l0 * nao * nao; g1.seg[0].lda = nao; g1.seg[0].strideA = (int64_t)nao * nao;
+            g1.seg[0].B = Ci; g1.seg[0].ldb = nemb; g1.seg[0].strideB = 0; g1.seg[0].conjB = 1;
+            g1.flatten_m = 1; g1.big_tile = 1;
+            g1.epi = ZEPI_STORE; g1.C = h->Ut; g1.ldc = nemb; g1.strideC = (int64_t)nao * nemb;
+            int rc = launch_zgemm(ctx, g1, DMK_FAM_ZGEMM_HALF1);
+            if (rc) return rc;
+            // step 2: S[a][b] = sum_q Ut[L][q][a] Cj[q][b] (+ sum_q Cj[q][a] Ut[L][q][b]); tril-pack, accumulate
+            ZGemm g2;
+            g2.M = nemb; g2.N = nemb; g2.K = nao; g2.batch = nl; g2.nseg = symmetrise ? 2 : 1;
+            g2.seg[0].A = h->Ut; g2.seg[0].lda = nemb; g2.seg[0].strideA = (int64_t)nao * nemb;
+            g2.seg[0].B = Cj; g2.seg[0].ldb = nemb; g2.seg[0].strideB = 0;
+            g2.seg[1].A = Cj; g2.seg[1].lda = nemb; g2.seg[1].strideA = 0;
+            g2.seg[1].B = h->Ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
+            g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1;
+            g2.planes = planes + (size_t)l0 * h->npair; g2.naux = naux; g2.npair = h->npair;
+            rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
+            if (rc) return rc;
+        }
+    }
+    h->flops_half += (double)h->spin * (8.0 * naux * (double)nao * nao * nemb + 8.0 * naux * (double)nao * nemb * nemb);
+    return DMK_OK;
+}
+
+int dmk_eri_end_kL(dmk_eri *h, int weight) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: no kL in progress");
+    int K;
+    double alpha;
+    if (h->tr) {
+        if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL: weight must be 1 or 2");
+        K = weight == 1 ? h->naux : 2 * h->naux;
+        alpha = (double)weight;
+    } else {
+        K = 2 * h->naux;
+        alpha = 1.0;
+    }
+    const int64_t np = h->npair;
+    const double *X0 = h->planes;
+    const double *X1 = h->planes + (size_t)2 * h->naux * np;
+    int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
+    if (rc) return rc;
+    if (h->spin == 2) {
+        rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X1, np, h->eri + (size_t)np * np, np);
+        if (rc) return rc;
+        rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X1, np, X1, np, h->eri + (size_t)2 * np * np, np);
+        if (rc) return rc;
+    }
+    h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
+    h->cur_kL = -1;
+    return DMK_OK;
+}
+
+int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
+    if (!h || !planes_out) return DMK_ERR_INVALID;
+    *planes_out = h->planes;
+    if (elems_out) *elems_out = (int64_t)h->spin * 2 * h->naux * h->npair;
+    return DMK_OK;
+}
+
+int dmk_eri_finish(dmk_eri *h) {
+    if (!h) return DMK_OK;
+    (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->planes) (void)hipFree(h->planes);
+    if (h->Ut) (void)hipFree(h->Ut);
+    delete h;
+    return DMK_OK;
+}
+
+int dmk_eri_flops(const dmk_eri *h, double f[2]) {
+    if (!h || !f) return DMK_ERR_INVALID;
+    f[0] = h->flops_half;
+    f[1] = h->flops_contract;
+    return DMK_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// small utility kernels: transpose, restore
+// =============================================================================================
+
+namespace {
+
+__global__ void transpose_c128_kernel(int rows, int cols, const double2 *__restrict__ in, double2 *__restrict__ out) {
+    __shared__ double2 tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+        const int r = r0 + y, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[y][threadIdx.x] = in[boff + (size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+        const int c = c0 + y, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[boff + (size_t)c * rows + r] = tile[threadIdx.x][y];
+    }
+}
+
+// 4-fold (npair x npair) -> 1-fold (n^4): out[i][j][k][l] = eri4[pair(i,j)][pair(k,l)]
+__global__ void restore_4to1_kernel(int n, const double *__restrict__ e4, double *__restrict__ out) {
+    const long long total = (long long)n * n * n * n;
+    const long long npair = (long long)n * (n + 1) / 2;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(t % n), k = (int)((t / n) % n), j = (int)((t / ((long long)n * n)) % n),
+                  i = (int)(t / ((long long)n * n * n));
+        const long long ij = i >= j ? (long long)i * (i + 1) / 2 + j : (long long)j * (j + 1) / 2 + i;
+        const long long kl = k >= l ? (long long)k * (k + 1) / 2 + l : (long long)l * (l + 1) / 2 + k;
+        out[t] = e4[ij * npair + kl];
+    }
+}
+
+// 4-fold -> 8-fold: out[p(p+1)/2 + q] = eri4[p][q], p >= q
+__global__ void restore_4to8_kernel(long long npair, const double *__restrict__ e4, double *__restrict__ out) {
+    const long long total = npair * (npair + 1) / 2;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        long long p = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (p * (p + 1) / 2 > t) --p;
+        while ((p + 1) * (p + 2) / 2 <= t) ++p;
+        const long long q = t - p * (p + 1) / 2;
+        out[t] = e4[p * npair + q];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmk_transpose_c128(dmk_ctx *ctx, int rows, int cols, int batch, const void *in, void *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (rows <= 0 || cols <= 0 || batch <= 0 || !in || !out || batch > 65535)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "transpose: bad arguments");
+    FamScope fs(ctx, DMK_FAM_MISC);
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, batch), block(32, 8);
+    hipLaunchKernelGGL(transpose_c128_kernel, grid, block, 0, ctx->stream, rows, cols,
+                       reinterpret_cast<const double2 *>(in), reinterpret_cast<double2 *>(out));
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_eri_restore(dmk_ctx *ctx, int nemb, int symmetry, const double *eri4, double *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (nemb <= 0 || !eri4 || !out) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_restore: bad arguments");
+    const long long npair = (long long)nemb * (nemb + 1) / 2;
+    FamScope fs(ctx, DMK_FAM_MISC);
+    if (symmetry == 4) {
+        DMK_HIP(ctx, hipMemcpyAsync(out, eri4, (size_t)npair * npair * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (symmetry == 1) {
+        hipLaunchKernelGGL(restore_4to1_kernel, dim3(2048), dim3(256), 0, ctx->stream, nemb, eri4, out);
+        DMK_CHECK_LAUNCH(ctx);
+    } else if (symmetry == 8) {
+        hipLaunchKernelGGL(restore_4to8_kernel, dim3(2048), dim3(256), 0, ctx->stream, npair, eri4, out);
+        DMK_CHECK_LAUNCH(ctx);
+    } else {
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_restore: symmetry must be 1, 4 or 8");
+    }
+    return DMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Shared internals of libdmetk (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/libdmetk.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+struct dmk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // HIP-event timer (dmk_timer_start/stop)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // per-family profiling
+    bool profile = false;
+    double fam_ms[DMK_FAM_COUNT] = {0};
+    int64_t fam_launches[DMK_FAM_COUNT] = {0};
+    struct Pending { int fam; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    // scratch owned by the context (grown on demand)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // cached twiddle matrices for the folds (device), keyed by mesh + direction
+    struct Phase { int mesh[3]; int dir; int nsub; std::vector<int32_t> subset; void *dev; };
+    std::vector<Phase> phases;
+};
+
+int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);
+
+#define DMK_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return dmk_fail((ctx), DMK_ERR_HIP, "%s failed: %s (%s:%d)", #call,         \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                \
+    } while (0)
+
+#define DMK_CHECK_LAUNCH(ctx)                                                           \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess)                                                          \
+            return dmk_fail((ctx), DMK_ERR_HIP, "kernel launch failed: %s (%s:%d)",     \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                \
+    } while (0)
+
+// RAII bracket that (optionally) times one kernel family launch with HIP events.
+struct FamScope {
+    dmk_ctx *ctx; int fam; hipEvent_t a = nullptr, b = nullptr;
+    FamScope(dmk_ctx *c, int f);
+    ~FamScope();
+};
+
+int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out);
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that the dispatcher places on the
+// same XCD (id % 8) receive a contiguous range of logical ids, so that neighbouring tiles
+// share that XCD's L2 (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned q = nblocks >> 3, r = nblocks & 7u;
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// ---- launchers implemented in the .hip files ---------------------------------------------
+
+// C (M x N, ldc) += alpha * X^T Y;  X: K x M (ldx), Y: K x N (ldy)
+int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
+                        int64_t ldx, const double *Y, int64_t ldy, double *C, int64_t ldc);
+
+struct ZSeg {
+    const void *A = nullptr;   // complex (or real if a_real) operand A
+    const void *B = nullptr;
+    int64_t lda = 0, ldb = 0;          // leading dimension in ELEMENTS
+    int64_t strideA = 0, strideB = 0;  // batch stride in elements
+    int a_kmajor = 1, b_kmajor = 1;    // 1: element (k, m) at k*ld + m ; 0: at m*ld + k
+    int conjA = 0, conjB = 0;
+    int b_real = 0;                    // B holds f64 (imaginary part zero)
+    const double *kscaleB = nullptr;   // optional per-k real scale of B (batch stride K)
+};
+
+enum { ZEPI_STORE = 0, ZEPI_STORE_REAL = 1, ZEPI_PACK_ACC = 2 };
+
+struct ZGemm {
+    int M = 0, N = 0, K = 0, batch = 1;
+    int nseg = 1;
+    ZSeg seg[2];
+    double alpha = 1.0;
+    int flatten_m = 0;      // batch folded into the M-block list (B must be batch invariant)
+    int epi = ZEPI_STORE;
+    void *C = nullptr;      // ZEPI_STORE: c128 [batch][M][ldc] ; ZEPI_STORE_REAL: f64
+    int64_t ldc = 0, strideC = 0;
+    double *imag_max = nullptr;   // ZEPI_STORE_REAL: atomic max |Im|
+    // ZEPI_PACK_ACC: planes[(ri*naux + batch)*npair + a(a+1)/2 + b] += value, a >= b
+    double *planes = nullptr;
+    int64_t naux = 0, npair = 0;
+    int lower_only = 0;     // enumerate only tiles that touch a >= b
+    int big_tile = 0;       // 128x64 instead of 64x64 workgroup tile
+};
+int launch_zgemm(dmk_ctx *ctx, const ZGemm &g, int fam);
+
+int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);

@@ -1,0 +1,428 @@
+// K1 -- batched complex-Hermitian (and real-symmetric) eigensolver, one workgroup per matrix.
+//
+// Replaces scipy.linalg.eigh (LAPACK zheevd / dsyevd) at routine/mfd.py:42-106
+// (DiagRHF / DiagUHF[_symm]: one la.eigh per k-point and spin), routine/slater.py:278
+// (eig bath) and lo/lowdin.py:87 (Loewdin metric).  Like LAPACK with lower=True only the
+// lower triangle of the input is referenced.
+//
+// Algorithm (backward stable, no vendor library on the path):
+//   1. Householder tridiagonalisation  A = Q T Q^H  (unblocked, the zhetd2 recurrence:
+//      p = tau A22 v, w = p - (tau/2)(p^H v) v, A22 -= v w^H + w v^H); the trailing block is
+//      kept as a full Hermitian matrix in HBM/L2 so that the matrix-vector product streams
+//      contiguous rows across the 64 lanes of a wave; reflectors are saved row-major.
+//   2. implicit-shift QL on the real tridiagonal (d, e): one lane runs the scalar recurrence
+//      of a sweep and leaves its Givens pairs in LDS, then all lanes apply the sweep to Z^T
+//      (row i of Z^T = eigenvector i of T, so a rotation touches two contiguous rows).
+//   3. rank sort (ascending, stable) and back-transformation y = H_0 ... H_{n-2} z, four
+//      eigenvectors per wave held in registers, reflector loads software-pipelined.
+//
+// Bound: latency / L2: algorithmic HBM traffic is
+// 2*16*n^2 + 8*n bytes per matrix.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NW = NT / 64;
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {   // conj(a) * b
+    return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct EighArgs {
+    int n, batch;
+    const void *A;          // c128 or f64 (a_real)
+    int a_real;
+    const double *add;      // optional n x n f64 added to each matrix
+    int add_group;          // matrices b and b' share add[(b / add_group)]
+    double *w;              // batch x n
+    void *Vt;               // c128 or f64 (v_real): batch x n x n, row = eigenvector
+    int v_real;
+    double2 *W, *Vh;        // workspaces batch x n x n
+    double *Zt;             // batch x n x n
+    double *d, *e;          // batch x n
+    double2 *tau;           // batch x n
+    int *status;            // device flag, set to 1 on non-convergence
+};
+
+// LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2n] f64 | red[2*NW + 8] f64
+template <int R>
+__global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = g.n;
+    double2 *vbuf = reinterpret_cast<double2 *>(smem);
+    double2 *pbuf = vbuf + n;
+    double *cs = reinterpret_cast<double *>(pbuf + n);
+    double *red = cs + 2 * n;          // 2*NW + 8 doubles
+    int *ired = reinterpret_cast<int *>(red + 2 * NW + 4);
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t nn = (size_t)n * n;
+    double2 *W = g.W + b * nn;
+    double2 *Vh = g.Vh + b * nn;
+    double *Zt = g.Zt + b * nn;
+    double *d = g.d + (size_t)b * n;
+    double *e = g.e + (size_t)b * n;
+    double2 *tau = g.tau + (size_t)b * n;
+
+    // ---- phase 0: W = Hermitian completion of the lower triangle (+ add), Zt = I ------------
+    {
+        const double *addm = g.add ? g.add + (size_t)(g.add_group > 0 ? b / g.add_group : 0) * nn : nullptr;
+        for (size_t idx = tid; idx < nn; idx += NT) {
+            const int i = (int)(idx / n), j = (int)(idx % n);
+            const int lo_i = i >= j ? i : j, lo_j = i >= j ? j : i;
+            double2 v;
+            if (g.a_real) {
+                v = make_double2(reinterpret_cast<const double *>(g.A)[b * nn + (size_t)lo_i * n + lo_j], 0.0);
+            } else {
+                v = reinterpret_cast<const double2 *>(g.A)[b * nn + (size_t)lo_i * n + lo_j];
+                if (i < j) v.y = -v.y;
+                if (i == j) v.y = 0.0;
+            }
+            if (addm) v.x += addm[(size_t)lo_i * n + lo_j];
+            W[idx] = v;
+            Zt[idx] = (i == j) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: Householder tridiagonalisation ------------------------------------------------
+    for (int k = 0; k + 1 < n; ++k) {
+        const int m = n - k - 1;
+        const double2 *rowk = W + (size_t)k * n + (k + 1);   // conj of the column below the diagonal
+        // (a) norm of x[1:]
+        double part = 0.0;
+        for (int t = 1 + tid; t < m; t += NT) {
+            const double2 x = rowk[t];
+            part += x.x * x.x + x.y * x.y;
+        }
+        part = wave_sum(part);
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        // (b) reflector parameters (every thread computes the same scalars)
+        double xnorm2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) xnorm2 += red[q];
+        double2 alpha = rowk[0];
+        alpha.y = -alpha.y;                       // x[0] = conj(W[k][k+1])
+        double2 tk = make_double2(0.0, 0.0), scale = make_double2(0.0, 0.0);
+        double beta = alpha.x;
+        if (!(xnorm2 == 0.0 && alpha.y == 0.0)) {
+            const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
+            beta = alpha.x >= 0.0 ? -nrm : nrm;
+            tk = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
+            const double dr = alpha.x - beta, di = alpha.y;
+            const double den = dr * dr + di * di;
+            scale = make_double2(dr / den, -di / den);   // 1 / (alpha - beta)
+        }
+        const bool active = !(tk.x == 0.0 && tk.y == 0.0);
+        // (c) v -> LDS and reflector store
+        for (int t = tid; t < m; t += NT) {
+            double2 v;
+            if (t == 0) v = make_double2(1.0, 0.0);
+            else {
+                double2 x = rowk[t];
+                x.y = -x.y;
+                v = cmul(x, scale);
+            }
+            vbuf[t] = v;
+            Vh[(size_t)k * n + (k + 1) + t] = v;
+        }
+        if (tid == 0) {
+            tau[k] = tk;
+            d[k] = W[(size_t)k * n + k].x;
+            e[k] = beta;
+        }
+        __syncthreads();
+        if (active) {
+            // (d) p = tau * A22 v   (one row per wave at a time; lanes along the row)
+            for (int i = wave; i < m; i += NW) {
+                const double2 *row = W + (size_t)(k + 1 + i) * n + (k + 1);
+                double sr = 0.0, si = 0.0;
+                for (int j = lane; j < m; j += 64) {
+                    const double2 a = row[j], v = vbuf[j];
+                    sr += a.x * v.x - a.y * v.y;
+                    si += a.x * v.y + a.y * v.x;
+                }
+                sr = wave_sum(sr);
+                si = wave_sum(si);
+                if (lane == 0) pbuf[i] = cmul(tk, make_double2(sr, si));
+            }
+            __syncthreads();
+            // (e) alpha2 = -1/2 tau (p^H v)
+            double ar = 0.0, ai = 0.0;
+            for (int t = tid; t < m; t += NT) {
+                const double2 c = cmulc(pbuf[t], vbuf[t]);
+                ar += c.x;
+                ai += c.y;
+            }
+            ar = wave_sum(ar);
+            ai = wave_sum(ai);
+            if (lane == 0) { red[NW + 2 * wave] = ar; red[NW + 2 * wave + 1] = ai; }
+            __syncthreads();
+            double2 pv = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) { pv.x += red[NW + 2 * q]; pv.y += red[NW + 2 * q + 1]; }
+            double2 a2 = cmul(tk, pv);
+            a2.x *= -0.5;
+            a2.y *= -0.5;
+            __syncthreads();
+            // (f) w = p + alpha2 v   (in place in pbuf)
+            for (int t = tid; t < m; t += NT) {
+                const double2 av = cmul(a2, vbuf[t]);
+                pbuf[t] = make_double2(pbuf[t].x + av.x, pbuf[t].y + av.y);
+            }
+            __syncthreads();
+            // (g) A22 -= v w^H + w v^H
+            const size_t mm = (size_t)m * m;
+            for (size_t idx = tid; idx < mm; idx += NT) {
+                const int i = (int)(idx / m), j = (int)(idx % m);
+                const double2 vi = vbuf[i], wi = pbuf[i], vj = vbuf[j], wj = pbuf[j];
+                // v_i conj(w_j) + w_i conj(v_j)
+                const double ur = vi.x * wj.x + vi.y * wj.y + wi.x * vj.x + wi.y * vj.y;
+                const double ui = vi.y * wj.x - vi.x * wj.y + wi.y * vj.x - wi.x * vj.y;
+                double2 *p = W + (size_t)(k + 1 + i) * n + (k + 1 + j);
+                double2 a = *p;
+                a.x -= ur;
+                a.y -= ui;
+                if (i == j) a.y = 0.0;
+                *p = a;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        d[n - 1] = W[(size_t)(n - 1) * n + (n - 1)].x;
+        e[n - 1] = 0.0;
+        if (n >= 1) tau[n - 1] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+
+    // ---- phase 2: implicit QL with rotation sweeps applied to Zt ---------------------------------
+    // e[i] couples i and i+1.
+    {
+        const double eps = 2.220446049250313e-16;
+        for (int l = 0; l < n; ++l) {
+            int iter = 0;
+            while (true) {
+                // scalar part on one lane: find m, build the sweep
+                if (tid == 0) {
+                    int mm = l;
+                    for (; mm < n - 1; ++mm) {
+                        const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+                        if (fabs(e[mm]) <= eps * dd) break;
+                    }
+                    int cnt = 0;     // number of rotations recorded; rotation q acts on rows (mm-1-q, mm-q)
+                    if (mm != l) {
+                        double gq = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                        double r = sqrt(gq * gq + 1.0);
+                        gq = d[mm] - d[l] + e[l] / (gq + (gq >= 0.0 ? fabs(r) : -fabs(r)));
+                        double s = 1.0, c = 1.0, p = 0.0;
+                        int i = mm - 1;
+                        bool under = false;
+                        for (; i >= l; --i) {
+                            double f = s * e[i];
+                            const double bq = c * e[i];
+                            r = sqrt(f * f + gq * gq);
+                            e[i + 1] = r;
+                            if (r == 0.0) {
+                                d[i + 1] -= p;
+                                e[mm] = 0.0;
+                                under = true;
+                                break;
+                            }
+                            s = f / r;
+                            c = gq / r;
+                            gq = d[i + 1] - p;
+                            r = (d[i] - gq) * s + 2.0 * c * bq;
+                            p = s * r;
+                            d[i + 1] = gq + p;
+                            gq = c * r - bq;
+                            cs[2 * cnt] = c;
+                            cs[2 * cnt + 1] = s;
+                            ++cnt;
+                        }
+                        if (!under) {
+                            d[l] -= p;
+                            e[l] = gq;
+                            e[mm] = 0.0;
+                        }
+                    }
+                    ired[0] = mm;
+                    ired[1] = cnt;
+                }
+                __syncthreads();
+                const int mm = ired[0], cnt = ired[1];
+                if (mm == l) { __syncthreads(); break; }
+                // apply the sweep: rotation q on rows (i, i+1) of Zt with i = mm-1-q
+                for (int rcol = tid; rcol < n; rcol += NT) {
+                    double hi = Zt[(size_t)mm * n + rcol];
+                    for (int q = 0; q < cnt; ++q) {
+                        const int i = mm - 1 - q;
+                        const double c = cs[2 * q], s = cs[2 * q + 1];
+                        const double lo = Zt[(size_t)i * n + rcol];
+                        Zt[(size_t)(i + 1) * n + rcol] = s * lo + c * hi;
+                        hi = c * lo - s * hi;
+                    }
+                    Zt[(size_t)(mm - cnt) * n + rcol] = hi;
+                }
+                __syncthreads();
+                if (++iter > 80) {
+                    if (tid == 0) *g.status = 1;
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: sort + back-transformation ------------------------------------------------------
+    // rank[j] = position of eigenvalue j in ascending order (stable); kept in cs[] as ints
+    int *rank = reinterpret_cast<int *>(cs);
+    for (int j = tid; j < n; j += NT) {
+        const double dj = d[j];
+        int rk = 0;
+        for (int q = 0; q < n; ++q) {
+            const double dq = d[q];
+            rk += (dq < dj || (dq == dj && q < j)) ? 1 : 0;
+        }
+        rank[j] = rk;
+        g.w[(size_t)b * n + rk] = dj;
+    }
+    __syncthreads();
+
+    constexpr int E = (R <= 4) ? 4 : 1;
+    for (int m0 = wave * E; m0 < n; m0 += NW * E) {
+        double2 y[E][R];
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                const int mq = m0 + q;
+                y[q][r] = (mq < n && i < n) ? make_double2(Zt[(size_t)mq * n + i], 0.0) : make_double2(0.0, 0.0);
+            }
+        double2 vnext[R];
+        auto loadv = [&](int k, double2 *v) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                v[r] = (k >= 0 && i > k && i < n) ? Vh[(size_t)k * n + i] : make_double2(0.0, 0.0);
+            }
+        };
+        loadv(n - 2, vnext);
+        for (int k = n - 2; k >= 0; --k) {
+            double2 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = vnext[r];
+            loadv(k - 1, vnext);
+            const double2 tk = tau[k];
+            if (tk.x == 0.0 && tk.y == 0.0) continue;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                double sr = 0.0, si = 0.0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2 c = cmulc(v[r], y[q][r]);
+                    sr += c.x;
+                    si += c.y;
+                }
+                sr = wave_sum(sr);
+                si = wave_sum(si);
+                const double2 f = cmul(tk, make_double2(sr, si));
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double2 u = cmul(f, v[r]);
+                    y[q][r].x -= u.x;
+                    y[q][r].y -= u.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int mq = m0 + q;
+            if (mq >= n) continue;
+            const size_t orow = (size_t)b * nn + (size_t)rank[mq] * n;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                if (i < n) {
+                    if (g.v_real) reinterpret_cast<double *>(g.Vt)[orow + i] = y[q][r].x;
+                    else reinterpret_cast<double2 *>(g.Vt)[orow + i] = y[q][r];
+                }
+            }
+        }
+    }
+}
+
+int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group, double *w,
+                void *Vt, int v_real) {
+    if (n <= 0 || batch <= 0) return DMK_OK;
+    if (n > 1024) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh: n = %d exceeds the supported maximum of 1024", n);
+    const size_t nn = (size_t)n * n;
+    const size_t per = nn * (16 + 16 + 8) + (size_t)n * (8 + 8 + 16);
+    const size_t total = per * batch + 256;
+    void *ws = nullptr;
+    int rc = dmk_scratch(ctx, total, &ws);
+    if (rc) return rc;
+    char *p = reinterpret_cast<char *>(ws);
+    EighArgs g;
+    g.n = n; g.batch = batch; g.A = A; g.a_real = a_real; g.add = add; g.add_group = add_group;
+    g.w = w; g.Vt = Vt; g.v_real = v_real;
+    g.status = reinterpret_cast<int *>(p); p += 256;
+    g.W = reinterpret_cast<double2 *>(p); p += nn * 16 * batch;
+    g.Vh = reinterpret_cast<double2 *>(p); p += nn * 16 * batch;
+    g.tau = reinterpret_cast<double2 *>(p); p += (size_t)n * 16 * batch;
+    g.Zt = reinterpret_cast<double *>(p); p += nn * 8 * batch;
+    g.d = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
+    g.e = reinterpret_cast<double *>(p);
+    DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
+    // reflector rows are only partially written; clear so that masked lanes read zeros
+    DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
+    const size_t lds = (size_t)n * (16 + 16 + 16) + (2 * NW + 8) * 8 + 64;
+    {
+        FamScope fs(ctx, DMK_FAM_EIGH);
+        if (n <= 64) hipLaunchKernelGGL(eigh_kernel<1>, dim3(batch), dim3(NT), lds, ctx->stream, g);
+        else if (n <= 256) hipLaunchKernelGGL(eigh_kernel<4>, dim3(batch), dim3(NT), lds, ctx->stream, g);
+        else hipLaunchKernelGGL(eigh_kernel<16>, dim3(batch), dim3(NT), lds, ctx->stream, g);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    int status = 0;
+    DMK_HIP(ctx, hipMemcpyAsync(&status, g.status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (status != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "eigh: QL iteration did not converge");
+    return DMK_OK;
+}
+
+}  // namespace
+
+int launch_eigh_public(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group,
+                       double *w, void *Vt, int v_real) {
+    return launch_eigh(ctx, n, batch, A, a_real, add, add_group, w, Vt, v_real);
+}
+
+extern "C" {
+
+int dmk_eigh_batched(dmk_ctx *ctx, int n, int batch, const void *A, const double *add, int add_group, double *w,
+                     void *Vt) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n < 0 || batch < 0 || !A || !w || !Vt) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh_batched: bad arguments");
+    return launch_eigh(ctx, n, batch, A, 0, add, add_group, w, Vt, 0);
+}
+
+int dmk_eigh_batched_real(dmk_ctx *ctx, int n, int batch, const double *A, double *w, double *Vt) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n < 0 || batch < 0 || !A || !w || !Vt) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh_batched_real: bad arguments");
+    return launch_eigh(ctx, n, batch, A, 1, nullptr, 0, w, Vt, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""
+Lattice: the k-mesh / cell bookkeeping object the hot path is written against
+(reference: libdmet/system/lattice.py:31-411, 716-726).
+
+Only the parts the embedding-construction path touches are mirrored: cell index
+arithmetic (integer, via libdmetk), the k <-> R transforms (HIP), `expand`, the orbital
+index sets (`val_idx`, `virt_idx`, `core_idx`, `imp_idx`) and the Hamiltonian holders that
+`HF` reads.  No PySCF cell is needed: pass the number of local orbitals (or any object with
+`nao_nr()`) and the k-mesh.
+"""
+import ctypes as C
+import numpy as np
+
+from libdmet_preview_amd._lib import lib, mesh3
+from libdmet_preview_amd.settings import IMAG_DISCARD_TOL
+from libdmet_preview_amd.system import fourier
+from libdmet_preview_amd.system.fourier import (FFTtoK, FFTtoT, k2R, R2k, make_kpts_scaled,  # noqa: F401
+                                                round_to_FBZ, kpt_member, get_phase_R2k)
+from libdmet_preview_amd.utils import logger as log
+
+try:
+    from collections.abc import Iterable
+except ImportError:  # pragma: no cover
+    from collections import Iterable
+
+
+class _UnitCell(object):
+    """Stand-in for a PySCF cell: unit lattice vectors, k_abs = 2 pi k_scaled."""
+    def __init__(self, nao, dimension=3):
+        self._nao = int(nao)
+        self.dimension = dimension
+
+    def nao_nr(self):
+        return self._nao
+
+    def lattice_vectors(self):
+        return np.eye(3)
+
+    def get_scaled_kpts(self, kpts):
+        return np.asarray(kpts) / (2.0 * np.pi)
+
+    def get_abs_kpts(self, kscaled):
+        return np.asarray(kscaled) * (2.0 * np.pi)
+
+
+class Lattice(object):
+    def __init__(self, cell, kmesh):
+        if isinstance(cell, (int, np.integer)):
+            cell = _UnitCell(cell)
+        self.mol = self.cell = cell
+        kmesh = [int(x) for x in kmesh]
+        kmesh = kmesh + [1] * (3 - len(kmesh))
+        self.kmesh = kmesh
+        self.nscsites = self.nao = int(cell.nao_nr())
+        self.dim = getattr(cell, "dimension", 3)
+        self.csize = np.asarray(kmesh)
+        self.ncells = int(np.prod(self.csize))
+        self.cells = fourier.make_cells(kmesh)
+        self.celldict = dict(zip(map(tuple, self.cells), range(self.ncells)))
+        self.kpts_scaled = make_kpts_scaled(kmesh)
+        self.kpts = self.kpts_abs = cell.get_abs_kpts(self.kpts_scaled)
+        self.nkpts = len(self.kpts)
+        self.nsites = self.ncells * self.nscsites
+        self._add = None
+        self._sub = None
+        _, self._neg, self._weights = fourier.kmesh_tables(kmesh)
+
+        self.val_idx = []
+        self.virt_idx = []
+        self.core_idx = []
+
+        self.hcore_lo_k = self.fock_lo_k = self.rdm1_lo_k = None
+        self.hcore_lo_R = self.fock_lo_R = self.rdm1_lo_R = None
+        self.ovlp_lo_k = self.ovlp_lo_R = None
+        self.C_ao_lo = None
+        self.H0 = 0.0
+        self.use_hcore_as_emb_ham = False
+        self.is_model = False
+        self.restricted = None
+
+    # ---- orbital sets (lattice.py:100-163) -----------------------------------------------
+    @property
+    def ncore(self):
+        return len(self.core_idx)
+
+    @property
+    def nval(self):
+        return len(self.val_idx)
+
+    @property
+    def nvirt(self):
+        return len(self.virt_idx)
+
+    @property
+    def nimp(self):
+        return self.nval + self.nvirt
+
+    limp = nimp
+
+    @property
+    def imp_idx(self):
+        return list(self.val_idx) + list(self.virt_idx)
+
+    def set_val_virt_core(self, val, virt, core):
+        self.core_idx = list(core) if isinstance(core, Iterable) else list(range(0, core))
+        self.val_idx = list(val) if isinstance(val, Iterable) else list(range(self.ncore, self.ncore + val))
+        self.virt_idx = (list(virt) if isinstance(virt, Iterable)
+                         else list(range(self.ncore + self.nval, self.ncore + self.nval + virt)))
+        if self.ncore + self.nval + self.nvirt != self.nao:
+            log.warn("ncore (%s) + nval (%s) + nvirt (%s) != nao (%s), \nset_val_virt_core may be incorrect.",
+                     self.ncore, self.nval, self.nvirt, self.nao)
+
+    # ---- cell arithmetic (lattice.py:194-204), integer tables from libdmetk ---------------
+    def _table(self, sign):
+        t = np.empty((self.ncells, self.ncells), dtype=np.int32)
+        rc = lib.dmk_cell_add_table(mesh3(self.kmesh), sign, t.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise ValueError("dmk_cell_add_table failed")
+        return t
+
+    def cell_idx2pos(self, idx):
+        return self.cells[idx % self.ncells]
+
+    def cell_pos2idx(self, pos):
+        return self.celldict[tuple(np.asarray(pos) % self.csize)]
+
+    def add(self, i, j):
+        if self._add is None:
+            self._add = self._table(+1)
+        return int(self._add[i % self.ncells, j % self.ncells])
+
+    def subtract(self, i, j):
+        if self._sub is None:
+            self._sub = self._table(-1)
+        return int(self._sub[i % self.ncells, j % self.ncells])
+
+    def neg(self, i):
+        return int(self._neg[i % self.ncells])
+
+    # ---- transforms (lattice.py:209-219, 399-411) ------------------------------------------
+    def FFTtoK(self, A):
+        return FFTtoK(A, self.kmesh)
+
+    def FFTtoT(self, B, tol=IMAG_DISCARD_TOL):
+        return FFTtoT(B, self.kmesh, tol=tol)
+
+    def k2R(self, A, tol=IMAG_DISCARD_TOL):
+        return k2R(A, self.kmesh, tol=tol)
+
+    def R2k(self, B):
+        return R2k(B, self.kmesh)
+
+    def k2R_basis(self, basis_k):
+        return self.k2R(basis_k)
+
+    def R2k_basis(self, basis_R):
+        return self.R2k(basis_R)
+
+    def expand(self, A, dense=False):
+        """Stripe -> full (lattice.py:304-337): big[(R1),(R2)] = A[R1 - R2]; index gather on the host
+        (model-size matrices only; the bath builder never materialises this)."""
+        A = np.asarray(A)
+        assert A.shape[-3] == self.ncells
+        n = A.shape[-1]
+        nc = self.ncells
+        if self._sub is None:
+            self._sub = self._table(-1)
+        idx = self._sub.astype(np.int64)          # idx[R1, R2] = R1 - R2
+        if A.ndim == 3:
+            big = A[idx]                            # (R1, R2, n, n)
+            return np.ascontiguousarray(big.transpose(0, 2, 1, 3)).reshape(nc * n, nc * n)
+        elif A.ndim == 4:
+            big = A[:, idx]
+            return np.ascontiguousarray(big.transpose(0, 1, 3, 2, 4)).reshape(A.shape[0], nc * n, nc * n)
+        raise ValueError("unknown shape of A, %s" % (A.shape,))
+
+    def extract_stripe(self, A):
+        nc = self.ncells
+        n = A.shape[-1] // nc
+        if A.ndim == 2:
+            return A.reshape((nc, n, nc, n))[:, :, 0]
+        elif A.ndim == 3:
+            return A.reshape((A.shape[0], nc, n, nc, n))[:, :, :, 0]
+        raise ValueError("unknown shape of A, %s" % (A.shape,))
+
+    def transpose(self, A):
+        A = np.asarray(A)
+        neg = self._neg.astype(np.int64)
+        if A.ndim == 3:
+            return np.ascontiguousarray(A[neg].transpose(0, 2, 1))
+        elif A.ndim == 4:
+            return np.ascontiguousarray(A[:, neg].transpose(0, 1, 3, 2))
+        raise ValueError("unknown shape of A, %s" % (A.shape,))
+
+    # ---- Hamiltonian holders read by routine.mfd.HF (lattice.py:716-726) ---------------------
+    def set_Ham_lo(self, fock_lo_R=None, hcore_lo_R=None, fock_lo_k=None, hcore_lo_k=None, H0=0.0,
+                   use_hcore_as_emb_ham=False):
+        """Install LO-basis one-body operators (stripe or k form; the other is derived by a fold)."""
+        if fock_lo_R is None and fock_lo_k is not None:
+            fock_lo_R = self.k2R(fock_lo_k)
+        if fock_lo_k is None and fock_lo_R is not None:
+            fock_lo_k = self.R2k(fock_lo_R)
+        if hcore_lo_R is None and hcore_lo_k is not None:
+            hcore_lo_R = self.k2R(hcore_lo_k)
+        if hcore_lo_k is None and hcore_lo_R is not None:
+            hcore_lo_k = self.R2k(hcore_lo_R)
+        if hcore_lo_R is None:
+            hcore_lo_R, hcore_lo_k = fock_lo_R, fock_lo_k
+        if fock_lo_R is None:
+            fock_lo_R, fock_lo_k = hcore_lo_R, hcore_lo_k
+        self.fock_lo_R, self.fock_lo_k = fock_lo_R, fock_lo_k
+        self.hcore_lo_R, self.hcore_lo_k = hcore_lo_R, hcore_lo_k
+        self.H0 = H0
+        self.use_hcore_as_emb_ham = use_hcore_as_emb_ham
+
+    def getH1(self, kspace=True):
+        return self.hcore_lo_k if kspace else self.hcore_lo_R
+
+    def getFock(self, kspace=True):
+        return self.fock_lo_k if kspace else self.fock_lo_R
+
+    def getH0(self):
+        return self.H0
+
+    def get_ovlp(self, kspace=True):
+        return self.ovlp_lo_k if kspace else self.ovlp_lo_R

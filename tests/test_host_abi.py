@@ -1,0 +1,142 @@
+"""
+CPU-only checks of the C-ABI library: it loads, exports every symbol include/libdmetk.h declares,
+refuses to create a context without a GPU (no CPU fallback), and its integer k-mesh bookkeeping is
+bit-exact against the golden tables captured from the reference.
+"""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from libdmet_preview_amd import _lib
+from libdmet_preview_amd.system import fourier, lattice
+from libdmet_preview_amd.basis_transform import eri_transform as et
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MESHES = ["12x1x1", "6x1x1", "4x1x1", "3x1x1", "6x6x1", "4x4x1", "2x3x1", "4x4x3", "2x2x2", "4x4x4", "6x6x6"]
+
+
+def _mesh(tag):
+    return tuple(int(x) for x in tag.split("x"))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "libdmetk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(dmk_[a-z0-9_A-Z]+)\s*\(", hdr))
+    assert len(names) >= 40
+    for n in sorted(names):
+        assert hasattr(_lib.lib, n), "symbol %s declared in libdmetk.h but not exported" % n
+    assert names == set(_lib.PROTOTYPES.keys())
+
+
+def test_no_cpu_fallback():
+    import subprocess, sys
+    code = ("import os,sys; sys.path.insert(0, %r); os.environ['HIP_VISIBLE_DEVICES']=''; "
+            "os.environ['ROCR_VISIBLE_DEVICES']=''; from libdmet_preview_amd import _lib\n"
+            "try:\n    _lib.Context(0)\n    print('CREATED')\nexcept RuntimeError as e:\n    print('RAISED', e)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout
+    assert "RAISED" in out and "no CPU fallback" in out
+
+
+@pytest.mark.parametrize("tag", MESHES)
+def test_kmesh_tables_bit_exact(golden, tag):
+    g = golden("G1_ktables.npz")
+    mesh = _mesh(tag)
+    nk = int(np.prod(mesh))
+    assert np.array_equal(fourier.make_kpts_scaled(mesh), g[tag + "/kpts_scaled"])
+    kint, minus_k, w = fourier.kmesh_tables(mesh)
+    assert np.array_equal(kint, g[tag + "/cells"])
+    assert np.array_equal(minus_k, g[tag + "/minus_k"])
+    assert np.array_equal(minus_k, g[tag + "/neg"])
+    assert np.array_equal(w, g[tag + "/weights"])
+    assert np.array_equal(fourier.round_to_FBZ(g[tag + "/kpts_scaled"] + 0.5, tol=1e-10), g[tag + "/round_to_FBZ"])
+    for n in (1, 2, 3, 4, 8):
+        kids = et.assign_workload(mesh, n)
+        ref = g[tag + "/workload_n%d" % n]
+        for r in range(n):
+            assert kids[r] == [int(x) for x in ref[r] if x >= 0]
+    if nk <= 64:
+        L = lattice.Lattice(1, mesh)
+        add = np.array([[L.add(i, j) for j in range(nk)] for i in range(nk)])
+        sub = np.array([[L.subtract(i, j) for j in range(nk)] for i in range(nk)])
+        assert np.array_equal(add, g[tag + "/add"]) and np.array_equal(sub, g[tag + "/subtract"])
+        assert np.array_equal(L.cells, g[tag + "/cells"])
+
+
+@pytest.mark.parametrize("tag", MESHES)
+def test_eri_plan_bit_exact(golden, tag):
+    g = golden("G1_ktables.npz")
+    mesh = _mesh(tag)
+    for tr in (True, False):
+        key = tag + "/plan_%s" % ("tr" if tr else "notr")
+        if key not in g.files:
+            continue
+        ev = g[key]
+        w, rec = et.eri_plan(mesh, tr)
+        blocks = ev[ev[:, 0] < 2]
+        assert len(blocks) == len(rec)
+        assert np.array_equal(blocks[:, 1:3], rec[:, 1:3])
+        assert np.array_equal(blocks[:, 0], rec[:, 4])
+        # contraction order and weights
+        assert list(ev[ev[:, 0] == 2][:, 1]) == [int(x) for x in w if x > 0]
+        # kL of each record follows the contraction markers
+        kL_seq, cur = [], iter([k for k in range(len(w)) if w[k] > 0])
+        k = next(cur)
+        for e in ev:
+            if e[0] == 2:
+                k = next(cur, None)
+            else:
+                kL_seq.append(k)
+        assert kL_seq == [int(x) for x in rec[:, 0]]
+
+
+def test_block_counts_match_survey():
+    # C3 8, C4 1184, C5 12152 blocks
+    assert len(et.eri_plan((4, 1, 1))[1]) == 8
+    assert len(et.eri_plan((4, 4, 4))[1]) == 1184
+    assert len(et.eri_plan((6, 6, 6))[1]) == 12152
+
+
+def test_kpt_member_known_answers():
+    # system/test/test_fourier.py:9-41
+    ks = fourier.make_kpts_scaled((4, 4, 1))
+    assert fourier.kpt_member(np.array([0.0, 0.25, 0.0]), ks)[0] == 1
+    assert fourier.kpt_member(np.array([-0.25, -0.50, 0.0]), ks)[0] == 14
+    idx = fourier.kpt_member(np.array([-0.0, 0.50, 0.0]), ks)
+    assert len(idx) == 1 and idx[0] == 2
+    idx = fourier.kpt_member(np.array([5.5, -1.25, 0.0]), ks)
+    assert len(idx) == 1 and idx[0] == 11
+    assert len(fourier.kpt_member(np.array([0.01, -0.25, 0.0]), ks)) == 0
+    assert fourier.kpt_member_mesh([0.0, 0.25, 0.0], (4, 4, 1)) == 1
+    assert fourier.kpt_member_mesh([-0.25, -0.5, 0.0], (4, 4, 1)) == 14
+    assert fourier.kpt_member_mesh([5.5, -1.25, 0.0], (4, 4, 1)) == 11
+    assert fourier.kpt_member_mesh([0.01, -0.25, 0.0], (4, 4, 1)) == -1
+
+
+def test_lattice_expand_matches_reference_semantics():
+    from oracle import restate as R
+    rng = np.random.default_rng(0)
+    mesh = (2, 3, 2)
+    L = lattice.Lattice(3, mesh)
+    A = rng.standard_normal((2, 12, 3, 3))
+    ca = R.CellArith(mesh)
+    assert np.array_equal(L.expand(A), ca.expand(A))
+    assert np.array_equal(L.expand(A[0]), ca.expand(A[0]))
+    assert np.array_equal(L.extract_stripe(L.expand(A)), A)
+
+
+def test_synthetic_hubbard_dispersion():
+    from libdmet_preview_amd import synth
+    H = synth.hubbard_h1_R((6, 1, 1), (2,))
+    Hk = synth.fold_R2k(H, (6, 1, 1))
+    ew = np.sort(np.concatenate([np.linalg.eigvalsh(h) for h in Hk]))
+    exact = np.sort(-2.0 * np.cos(2 * np.pi * np.arange(12) / 12))
+    assert np.abs(ew - exact).max() < 1e-12
+    H2 = synth.hubbard_h1_R((6, 6, 1), (2, 2))
+    Hk2 = synth.fold_R2k(H2, (6, 6, 1))
+    ew2 = np.sort(np.concatenate([np.linalg.eigvalsh(h) for h in Hk2]))
+    kx = 2 * np.pi * np.arange(12) / 12
+    exact2 = np.sort((-2 * np.cos(kx)[:, None] - 2 * np.cos(kx)[None, :]).ravel())
+    assert np.abs(ew2 - exact2).max() < 1e-12
