@@ -1,0 +1,502 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+oracle (oracle/restate.py) on the same seeded inputs and against the golden fixtures captured from the
+reference.  Tolerances are the north star's: k bookkeeping bit-exact (tests/test_host_abi.py),
+<= 1e-10 on density matrices / bath projectors, <= 1e-8 max-abs on the transformed ERI.
+"""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R                      # the checker
+from libdmet_preview_amd import synth
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from libdmet_preview_amd import _lib
+    return _lib.get_ctx()
+
+
+def _lattice(mesh, nlo, val=None, virt=None, core=None):
+    from libdmet_preview_amd.system.lattice import Lattice
+    L = Lattice(int(nlo), mesh)
+    if val is not None:
+        L.val_idx, L.virt_idx, L.core_idx = list(val), list(virt or []), list(core or [])
+    return L
+
+
+class _Vcor(object):
+    def __init__(self, v):
+        self.value = v
+
+    def islocal(self):
+        return True
+
+    def get(self, i=0, kspace=True):
+        return self.value if (kspace or i == 0) else np.zeros_like(self.value)
+
+
+# ---------------------------------------------------------------------------------------------
+# K7: real contraction
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("N,K", [(78, 28), (130, 37), (257, 64), (300, 800), (1000, 123), (2080, 160)])
+def test_dgemm_tn_acc(ctx, N, K):
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(N * 1000 + K)
+    X = rng.standard_normal((K, N))
+    C0 = rng.standard_normal((N, N))
+    dX, dC = ctx.to_device(X), ctx.to_device(C0)
+    ctx.check(lib.dmk_dgemm_tn_acc(ctx.h, N, K, 2.0, dX.ptr, dX.ptr, N, dC.ptr, N))
+    ref = C0 + 2.0 * X.T @ X
+    err = np.abs(dC.get() - ref).max()
+    assert err < 1e-11 * max(1.0, np.abs(ref).max()), err
+
+
+def test_dgemm_tn_is_transpose_detecting(ctx):
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(5)
+    K, N = 20, 150
+    X, Y = rng.standard_normal((K, N)), rng.standard_normal((K, N))
+    dX, dY, dC = ctx.to_device(X), ctx.to_device(Y), ctx.zeros((N, N), np.float64)
+    from libdmet_preview_amd._lib import lib as L
+    # X != Y path through the ERI pipeline is covered by the UHF cases below; here use planes API
+    ctx.check(L.dmk_dgemm_tn_acc(ctx.h, N, K, 1.0, dX.ptr, dY.ptr, N, dC.ptr, N))
+    assert np.abs(dC.get() - X.T @ Y).max() < 1e-12 * K
+
+
+# ---------------------------------------------------------------------------------------------
+# generic complex batched product / basis algebra (a9, a10)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("opA", "NTC")
+@pytest.mark.parametrize("opB", "NTC")
+def test_zgemm_batched_ops(ctx, opA, opB):
+    from libdmet_preview_amd.basis_transform.make_basis import _bgemm
+    rng = np.random.default_rng(ord(opA) * 7 + ord(opB))
+    nb, M, N, K = 3, 37, 21, 50
+    a = rng.standard_normal((nb, M, K) if opA == "N" else (nb, K, M)) + 1j * rng.standard_normal((nb, M, K) if opA == "N" else (nb, K, M))
+    b = rng.standard_normal((nb, K, N) if opB == "N" else (nb, N, K)) + 1j * rng.standard_normal((nb, K, N) if opB == "N" else (nb, N, K))
+    op = {"N": lambda x: x, "T": lambda x: x.transpose(0, 2, 1), "C": lambda x: x.conj().transpose(0, 2, 1)}
+    ref = np.einsum("bmk,bkn->bmn", op[opA](a), op[opB](b))
+    got = _bgemm(opA, opB, a, b)
+    assert np.abs(got - ref).max() < 1e-12 * K
+
+
+def test_G5_basis_algebra(ctx, golden):
+    from libdmet_preview_amd.basis_transform import make_basis as mb
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G5_basis.npz")
+    bk = et.get_basis_k(g["basis"], g["phase_R2k"])
+    assert np.abs(bk - g["basis_k"]).max() < 1e-12
+    assert np.abs(mb.multiply_basis(g["C_ao_lo"], g["basis_k"]) - g["multiply_basis"]).max() < 1e-12
+    r = mb.multiply_basis(g["C_ao_lo"][0], g["basis_k"][0])
+    assert r.shape == g["multiply_basis_rhf"].shape and np.abs(r - g["multiply_basis_rhf"]).max() < 1e-12
+    assert np.abs(mb.multiply_basis(g["C_ao_lo"][0], g["basis_k"]) - g["multiply_basis_mixed"]).max() < 1e-12
+    assert np.abs(mb.transform_h1_to_lo(g["h_ao"], g["C_ao_lo"]) - g["h1_to_lo"]).max() < 1e-11
+    assert np.abs(mb.transform_h1_to_lo(g["h_ao"][0], g["C_ao_lo"][0]) - g["h1_to_lo_rhf"]).max() < 1e-11
+    assert np.abs(mb.transform_rdm1_to_lo(g["h_ao"], g["C_ao_lo"], g["S_ao"]) - g["rdm1_to_lo"]).max() < 1e-11
+    assert np.abs(mb.transform_rdm1_to_ao(g["h1_to_lo"], g["C_ao_lo"]) - g["rdm1_to_ao"]).max() < 1e-11
+    with pytest.raises(ValueError):
+        mb.multiply_basis(np.zeros((2, 2)), np.zeros((2, 2, 2)))
+
+
+# ---------------------------------------------------------------------------------------------
+# K3: folds
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["6x1x1", "4x4x1", "2x3x2", "6x6x6"])
+def test_G2_folds(ctx, golden, tag):
+    from libdmet_preview_amd.system import fourier
+    from libdmet_preview_amd.utils import logger as log
+    g = golden("G2_fourier.npz")
+    mesh = tuple(int(x) for x in tag.split("x"))
+    assert np.abs(fourier.FFTtoK(g[tag + "/A_R"], mesh) - g[tag + "/FFTtoK"]).max() < 1e-12
+    assert np.abs(fourier.FFTtoT(g[tag + "/FFTtoK"], mesh) - g[tag + "/FFTtoT_of_FFTtoK"]).max() < 1e-13
+    n0 = len(log.warnings_seen)
+    out = fourier.FFTtoT(g[tag + "/Z_k"], mesh)          # generic complex input: imaginary part warned, real returned
+    assert np.abs(out - g[tag + "/ifftn_full"].real).max() < 1e-13
+    assert len(log.warnings_seen) == n0 + 1 and "imaginary" in log.warnings_seen[-1]
+    assert np.abs(fourier.R2k(g[tag + "/S_R"], mesh) - g[tag + "/R2k_spin"]).max() < 1e-12
+    assert np.abs(fourier.k2R(g[tag + "/R2k_spin"], mesh) - g[tag + "/k2R_spin"]).max() < 1e-13
+    with pytest.raises(ValueError):
+        fourier.R2k(np.zeros((2, 2)), mesh)
+
+
+def test_fold_roundtrip_full_size(ctx):
+    """Size-independent property at the C5 shape: k2R(R2k(x)) == x and Parseval."""
+    from libdmet_preview_amd.system import fourier
+    mesh, n = (6, 6, 6), 200
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((216, n * n))
+    d = ctx.to_device(x)
+    dk = fourier.fold_R2k_dev(d, mesh, 1, n * n)
+    back = fourier.fold_k2R_dev(dk, mesh, 1, n * n).get().reshape(x.shape)
+    assert np.abs(back - x).max() < 1e-12
+    k = dk.get().reshape(216, -1)
+    assert abs((np.abs(k) ** 2).sum() / 216 - (x ** 2).sum()) < 1e-8 * (x ** 2).sum()
+
+
+def test_fold_k_subset_partial_sums(ctx):
+    """Multi-GPU decomposition of k2R: partial folds over k shards add up to the full fold."""
+    from libdmet_preview_amd.system import fourier
+    mesh = (4, 4, 1)
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal((16, 9)) + 1j * rng.standard_normal((16, 9))
+    full = fourier.fold_k2R_dev(ctx.to_device(z), mesh, 1, 9).get()
+    acc = np.zeros_like(full)
+    for sub in ([0, 1, 2, 3, 12, 13, 14, 15], [4, 5, 6, 7, 8, 9, 10, 11]):
+        acc += fourier.fold_k2R_dev(ctx.to_device(z[sub]), mesh, 1, 9, k_subset=sub).get()
+    assert np.abs(acc - full).max() < 1e-14
+
+
+# ---------------------------------------------------------------------------------------------
+# K10: Philox generator
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("naux,nao,i,j", [(4, 5, 3, 7), (7, 3, 0, 215), (28, 10, 1, 2)])
+def test_philox_block_bit_exact(ctx, naux, nao, i, j):
+    from libdmet_preview_amd.basis_transform.eri_transform import GDFPhilox
+    p = GDFPhilox(np.zeros((1, 3)), naux, nao, seed=0x1234567890ABCDEF)
+    buf = ctx.empty((naux, nao, nao), np.complex128)
+    p.load_block(ctx, i, j, buf)
+    ref = R.df_block_philox(0x1234567890ABCDEF, i, j, naux, nao)
+    assert np.array_equal(buf.get(), ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# K6 + K7: ERI transform
+# ---------------------------------------------------------------------------------------------
+
+G6_CASES = [("m311", 1), ("m311", 2), ("m411", 1), ("m411", 2), ("m231", 1), ("m231", 2), ("m222", 1), ("m222", 2),
+            ("mid411", 1), ("mid411", 2), ("mid221", 1)]
+
+
+def _g6_setup(g, name, spin):
+    from libdmet_preview_amd.system.lattice import _UnitCell
+    from libdmet_preview_amd.basis_transform.eri_transform import GDFMemory
+    from libdmet_preview_amd.system import fourier
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    W0 = g[name + "/W0"]
+    naux, _, nao = W0.shape[:3]
+    cell = _UnitCell(nao)
+    kpts = cell.get_abs_kpts(np.pad(fourier.make_kpts_scaled(mesh), ((0, 0), (0, 0))))
+    blocks = synth.df_blocks_from_W0(W0, mesh)
+    mydf = GDFMemory(kpts, blocks, naux=naux)
+    st = "%s/s%d" % (name, spin)
+    return mesh, cell, mydf, st
+
+
+@pytest.mark.parametrize("name,spin", G6_CASES)
+def test_G6_eri_golden(ctx, golden, name, spin):
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    mesh, cell, mydf, st = _g6_setup(g, name, spin)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    scale = max(1.0, np.abs(g[st + "/eri_tr"]).max())
+    tol = 1e-8          # max-abs, north star; the fixtures' |eri|max is O(1e2..1e4) so this is <= 1e-10 relative
+    for tr in (True, False):
+        e = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
+        ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+        assert e.shape == ref.shape and e.dtype == np.float64
+        assert np.abs(e - ref).max() < tol, (np.abs(e - ref).max(), scale)
+        assert np.abs(e - g[st + "/eri_identity"]).max() < tol
+    e1 = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, symmetry=1)
+    assert e1.shape == g[st + "/eri_s1"].shape and np.abs(e1 - g[st + "/eri_s1"]).max() < tol
+    if spin == 1:
+        e8 = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, symmetry=8)
+        assert e8.shape == g[st + "/eri_s8"].shape and np.abs(e8 - g[st + "/eri_s8"]).max() < tol
+    else:
+        with pytest.raises(ValueError):
+            et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, symmetry=8)
+    eu = et.get_unit_eri(cell, mydf, C_ao_lo=C)
+    assert np.abs(eu - g[st + "/eri_unit"]).max() < tol
+    Ck = R.multiply_basis(C, R.get_basis_k(basis, R.get_phase_R2k(mesh, R.make_kpts_scaled(mesh))))
+    ec = et.get_emb_eri_fast_gdf(cell, mydf, C_ao_eo=Ck)
+    assert np.abs(ec - g[st + "/eri_C_ao_eo"]).max() < tol
+    with pytest.raises(ValueError):
+        et.get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=C, C_ao_eo=Ck)
+    with pytest.raises(ValueError):
+        et.get_emb_eri(cell, object(), C_ao_lo=C, basis=basis)
+    with pytest.raises(NotImplementedError):
+        et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, t_reversal_symm=False, incore=False)
+
+
+def test_eri_outcore_matches_incore(ctx, golden, tmp_path):
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    mesh, cell, mydf, st = _g6_setup(g, "m231", 2)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    inc = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)
+    out = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, incore=False, fout=str(tmp_path / "H2"))
+    assert np.abs(np.asarray(out["ccdd"]) - inc[[0, 2, 1]]).max() < 1e-12      # (aa, bb, ab) on disk
+
+
+def test_eri_sharded_sum(ctx, golden):
+    """kL shards (eri_transform_mpi.py:151-157) accumulate into the same ERI; their sum is the serial result."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    mesh, cell, mydf, st = _g6_setup(g, "m222", 2)
+    nao = cell.nao_nr()
+    C_dev = et.make_C_ao_emb_dev(ctx, mesh, C_ao_lo=g[st + "/C_ao_lo"], basis=g[st + "/basis"])
+    spin, _, _, nemb = C_dev.shape
+    npair = nemb * (nemb + 1) // 2
+    total = np.zeros((3, npair, npair))
+    for kl in et.assign_workload(mesh, 3):
+        eri_dev = ctx.zeros((3, npair, npair), np.float64)
+        eng = et.EriEngine(ctx, mesh, nao, mydf.naux, nemb, spin, C_dev, eri_dev, True)
+        eng.run(mydf, kL_list=kl)
+        total += eri_dev.get()
+        eng.close()
+    assert np.abs(total - g[st + "/eri_tr"]).max() < 1e-8
+
+
+def test_eri_philox_vs_oracle_midsize(ctx):
+    """Procedural blocks (TR mode only) at a size the oracle finishes in seconds; UHF."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd.system.lattice import _UnitCell
+    mesh, nao, naux, nemb, spin, seed = (2, 2, 2), 24, 40, 20, 2, 777
+    nk = 8
+    ks = R.make_kpts_scaled(mesh)
+    cell = _UnitCell(nao)
+    mydf = et.GDFPhilox(cell.get_abs_kpts(ks), naux, nao, seed=seed)
+    rng = np.random.default_rng(9)
+    C = synth.make_C_ao_lo(mesh, nao, nao, spin=spin, seed=4)
+    basis = rng.standard_normal((spin, nk, nao, nemb))
+    got = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)
+    ref = R.get_emb_eri_fast_gdf(mesh, ks, lambda i, j: R.df_block_philox(seed, i, j, naux, nao), naux, nao,
+                                 C_ao_lo=C, basis=basis)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+
+
+def test_eri_properties_large(ctx):
+    """Size-independent properties at a size beyond the oracle's reach (nao 104, naux 64, nemb 136 = C4 tile
+    shapes, mesh 2x2x1): (ab|cd) = (cd|ab) for same-spin blocks and shard additivity."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, nao, naux, nemb, spin = (2, 2, 1), 104, 64, 136, 2
+    ks = R.make_kpts_scaled(mesh)
+    from libdmet_preview_amd.system.lattice import _UnitCell
+    cell = _UnitCell(nao)
+    mydf = et.GDFPhilox(cell.get_abs_kpts(ks), naux, nao, seed=11)
+    rng = np.random.default_rng(10)
+    C = synth.make_C_ao_lo(mesh, nao, nao, spin=spin, seed=6)
+    basis = rng.standard_normal((spin, 4, nao, nemb)) / np.sqrt(nao)
+    e = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)
+    assert np.abs(e[0] - e[0].T).max() < 1e-9 * np.abs(e[0]).max()
+    assert np.abs(e[2] - e[2].T).max() < 1e-9 * np.abs(e[2]).max()
+    # half transform of one block against the oracle's einsum
+    blk = R.df_block_philox(11, 1, 3, naux, nao)
+    Cemb = R.make_C_ao_emb(mesh, ks, C_ao_lo=C, basis=basis)
+    ref = R.pack_tril(R.transform_ao_to_emb(blk.reshape(naux, -1), Cemb, 1, 3))
+    C_dev = ctx.to_device(Cemb)
+    npair = nemb * (nemb + 1) // 2
+    eri_dev = ctx.zeros((3, npair, npair), np.float64)
+    eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    from libdmet_preview_amd._lib import lib
+    ctx.check(lib.dmk_eri_begin_kL(eng.h, 0))
+    buf = ctx.to_device(blk)
+    ctx.check(lib.dmk_eri_push_block(eng.h, 1, 3, 0, buf.ptr))
+    planes = eng.planes().get()
+    got = planes[:, 0] + 1j * planes[:, 1]
+    assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    ctx.check(lib.dmk_eri_end_kL(eng.h, 1))
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# K1 / K2: eigensolver, density, HF
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,batch", [(1, 3), (2, 5), (3, 4), (10, 6), (33, 3), (64, 2), (65, 2), (200, 3)])
+def test_eigh_batched_random(ctx, n, batch):
+    from libdmet_preview_amd.routine import mfd
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))
+    A = A + A.conj().transpose(0, 2, 1)
+    dw, dVt = mfd.eigh_dev(ctx, ctx.to_device(A), n, batch)
+    w, Vt = dw.get(), dVt.get()
+    for b in range(batch):
+        wr = np.linalg.eigvalsh(A[b])
+        scale = max(1.0, np.abs(wr).max())
+        assert np.abs(w[b] - wr).max() < 1e-12 * scale * max(1, n / 10)
+        V = Vt[b].T                                              # columns = eigenvectors
+        assert np.abs(V.conj().T @ V - np.eye(n)).max() < 1e-12 * max(1, n / 10)
+        assert np.abs(A[b] @ V - V * w[b]).max() < 1e-11 * scale * max(1, n / 10)
+
+
+def test_eigh_degenerate_and_lower_triangle(ctx):
+    from libdmet_preview_amd.routine import mfd
+    n = 12
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    lam = np.array([-1.0] * 4 + [0.5] * 5 + [2.0] * 3)
+    A = (Q * lam) @ Q.conj().T
+    A = 0.5 * (A + A.conj().T)
+    junk = A + np.triu(rng.standard_normal((n, n)), 1)          # garbage above the diagonal must be ignored
+    batch = np.stack([A, np.eye(n), junk, np.zeros((n, n))]).astype(np.complex128)
+    dw, dVt = mfd.eigh_dev(ctx, ctx.to_device(batch), n, 4)
+    w, Vt = dw.get(), dVt.get()
+    assert np.abs(w[0] - lam).max() < 1e-13 and np.abs(w[2] - lam).max() < 1e-13
+    assert np.abs(w[1] - 1.0).max() == 0.0 and np.abs(w[3]).max() == 0.0
+    V = Vt[0].T
+    P = V[:, :4] @ V[:, :4].conj().T
+    assert np.abs(P - Q[:, :4] @ Q[:, :4].conj().T).max() < 1e-12
+
+
+def test_Diag_wrappers_vs_oracle(ctx):
+    from libdmet_preview_amd.routine import mfd
+    mesh, nlo = (3, 2, 1), 5
+    FR = synth.make_fock_R(mesh, nlo, spin=2, seed=3)
+    Fk = R.R2k(FR, mesh)
+    v = np.zeros((2, nlo, nlo))
+    v[0], v[1] = np.diag(np.arange(nlo) * 0.1), np.diag(np.arange(nlo) * -0.05)
+    L = _lattice(mesh, nlo)
+    ew, ev = mfd.DiagRHF(Fk[0], _Vcor(v))
+    ewr, _ = R.DiagRHF(Fk[0], v)
+    assert ew.shape == ewr.shape and np.abs(ew - ewr).max() < 1e-12
+    for k in range(6):
+        assert np.abs((Fk[0, k] + v[0]) @ ev[k] - ev[k] * ew[k]).max() < 1e-11
+    ew2, ev2 = mfd.DiagUHF(Fk, _Vcor(v))
+    ewr2, _ = R.DiagUHF(Fk, v)
+    assert ew2.shape == (2, 6, nlo) and np.abs(ew2 - ewr2).max() < 1e-12
+    ew3, ev3 = mfd.DiagUHF_symm(Fk, _Vcor(v), L)
+    ewr3, evr3 = R.DiagUHF_symm(Fk, v, mesh)
+    assert np.abs(ew3 - ewr3).max() < 1e-12
+    for i in range(6):
+        ni = L.neg(i)
+        if ni < i:
+            assert np.array_equal(ev3[:, i], ev3[:, ni].conj())
+    ew4, ev4 = mfd.DiagRHF_symm(Fk[0], None, L)
+    assert np.abs(ew4 - R.DiagRHF_symm(Fk[0], None, mesh)[0]).max() < 1e-12
+    ew5, _ = mfd.DiagUHF(Fk[0], None)                            # 3-d Fock promoted to two identical spins
+    assert np.abs(ew5[0] - ew5[1]).max() == 0.0
+
+
+G3_CASES = ["rhf_611", "rhf_661", "uhf_411", "uhf_222_T", "rhf_331_T", "uhf_231_sz", "rhf_444"]
+
+
+@pytest.mark.parametrize("name", G3_CASES)
+@pytest.mark.parametrize("symm", [False, True])
+def test_G3_HF_golden(ctx, golden, name, symm):
+    from libdmet_preview_amd.routine import mfd
+    g = golden("G3_meanfield.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR, H1R, v = g[name + "/Fock_R"], g[name + "/H1_R"], g[name + "/vcor"]
+    spin, nlo = FR.shape[0], FR.shape[-1]
+    L = _lattice(mesh, nlo)
+    if spin == 1:
+        L.set_Ham_lo(fock_lo_R=FR[0], hcore_lo_R=H1R[0])
+    else:
+        L.set_Ham_lo(fock_lo_R=FR, hcore_lo_R=H1R)
+    filling = g[name + "/filling"]
+    filling = float(filling) if filling.ndim == 0 else tuple(filling)
+    rhoT, mu, E, res = mfd.HF(L, _Vcor(v), filling, spin == 1, beta=float(g[name + "/beta"]), ires=True, symm=symm)
+    t = name + ("_symm" if symm else "")
+    assert rhoT.shape == g[t + "/rhoT"].shape
+    assert np.abs(res["e"] - g[t + "/ew"]).max() < 1e-11
+    assert np.abs(res["mo_occ"] - g[t + "/mo_occ"]).max() < 1e-9
+    assert np.abs(np.asarray(mu) - g[t + "/mu"]).max() < 1e-9
+    assert np.abs(res["rho_k"] - g[t + "/rho_k"]).max() < 1e-10
+    assert np.abs(rhoT - g[t + "/rhoT"]).max() < 1e-10
+    assert abs(E - float(g[t + "/E"])) < 1e-9
+    for s in range(spin):                                       # eigenpairs: residual, never raw vectors
+        for k in range(rhoT.shape[1]):
+            Fk = L.getFock(True)[k] if spin == 1 else L.getFock(True)[s, k]
+            ev = res["coef"][s, k]
+            assert np.abs((Fk + v[s]) @ ev - ev * res["e"][s, k]).max() < 1e-10
+
+
+def test_HF_c5_shape_vs_oracle(ctx):
+    """Config-C5 matrix size (nlo = 200) on a small mesh: eigenvalues, occupations, rho_R vs the oracle."""
+    from libdmet_preview_amd.routine import mfd
+    mesh, nlo = (2, 2, 1), 200
+    FR = synth.make_fock_R(mesh, nlo, spin=2, seed=21)
+    L = _lattice(mesh, nlo)
+    L.set_Ham_lo(fock_lo_R=FR)
+    v = np.zeros((2, nlo, nlo))
+    rhoT, mu, E, res = mfd.HF(L, _Vcor(v), 0.5, False, ires=True)
+    Fk = R.R2k(FR, mesh)
+    rr, mur, Er, resr = R.HF(mesh, Fk, FR, FR, v, 0.5, False, ires=True)
+    assert np.abs(res["e"] - resr["e"]).max() < 1e-11
+    assert np.array_equal(res["mo_occ"], resr["mo_occ"])
+    assert np.abs(rhoT - rr).max() < 1e-10
+    assert abs(E - Er) < 1e-8 * abs(Er)
+    # idempotency of the zero-temperature density (libdmet/test/test_mfd.py:104-111 style)
+    rk = res["rho_k"]
+    assert np.abs(np.einsum("skij,skjl->skil", rk, rk) - rk).max() < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------
+# K4: bath
+# ---------------------------------------------------------------------------------------------
+
+def _proj(b):
+    b = b.reshape(b.shape[0], -1, b.shape[-1])
+    return np.einsum("spa,sqa->spq", b, b)
+
+
+def test_G4_bath_golden(ctx, golden):
+    from libdmet_preview_amd.routine import slater
+    g = golden("G4_bath.npz")
+    rdm1_lo = np.load(os.path.join(os.path.dirname(__file__), "golden", "rdm1_lo.npy"))
+    L = _lattice((1, 1, 3), 4, val=[0, 1], virt=[2, 3])
+    b = slater.get_emb_basis(L, rdm1_lo)
+    assert b.shape == g["hchain/basis_valbath"].shape
+    assert np.linalg.norm(_proj(b) - _proj(g["hchain/basis_valbath"])) < 1e-10
+    L2 = _lattice((1, 1, 3), 4, val=[0, 1, 2, 3], virt=[])
+    b2 = slater.get_emb_basis(L2, rdm1_lo, nbath=2, valence_bath=False)
+    assert np.linalg.norm(_proj(b2) - _proj(g["hchain/basis_full_nbath2"])) < 1e-10
+    b3 = slater.embBasis(L2, np.array((rdm1_lo, rdm1_lo)), tol_bath=1e-7, valence_bath=False)
+    assert b3.shape == g["hchain/basis_uhf_tol"].shape
+    assert np.linalg.norm(_proj(b3) - _proj(g["hchain/basis_uhf_tol"])) < 1e-10
+    assert np.linalg.norm(_proj(b) - _proj(b2)) < 1e-9            # span equality of test_slater.py:48-54
+    for name in ("C1", "C2"):
+        mesh = tuple(int(x) for x in g[name + "/mesh"])
+        rho = g[name + "/rhoT"]
+        nlo = rho.shape[-1]
+        Lm = _lattice(mesh, nlo, val=list(range(nlo)))
+        for kind in ("svd", "eig"):
+            bb = slater.get_emb_basis(Lm, rho, kind=kind)
+            ref = g[name + "/basis_" + kind]
+            assert bb.shape == ref.shape, (name, kind, bb.shape, ref.shape)
+            assert np.linalg.norm(_proj(bb) - _proj(ref)) < 1e-10
+    rho = g["gen/rhoT"]
+    Lg = _lattice((2, 2, 2), 7, val=[1, 2, 3], virt=[4, 5], core=[0])
+    for key, extra in (("basis_svd", {}), ("basis_svd_noorth", {"orth": False}),
+                       ("basis_svd_fullbath", {"valence_bath": False})):
+        bb = slater.get_emb_basis(Lg, rho, **extra)
+        ref = g["gen/" + key]
+        assert bb.shape == ref.shape
+        assert np.linalg.norm(_proj(bb) - _proj(ref)) < 1e-10
+    with pytest.raises(ValueError):
+        slater.get_emb_basis(Lg, rho, kind="nope")
+
+
+def test_bath_c5_shape_vs_oracle(ctx):
+    """Config-C5 bath shape: stripe (216, 200, 200), 56 valence orbitals -> A = 43144 x 56 per spin."""
+    from libdmet_preview_amd.routine import slater
+    mesh, nlo, nval = (6, 6, 6), 200, 56
+    rng = np.random.default_rng(8)
+    # a physical-looking rdm1: projector-like stripe built from a random low-rank real-space vector set
+    nocc = 40
+    V = rng.standard_normal((216 * nlo, nocc)) * np.exp(-0.02 * np.arange(216 * nlo))[:, None]
+    V, _ = np.linalg.qr(V)
+    rdm1 = (V @ V[:nlo].T).reshape(216, nlo, nlo)               # columns of cell 0 of a projector
+    L = _lattice(mesh, nlo, val=list(range(nval)), virt=list(range(nval, nlo)))
+    b = slater.get_emb_basis(L, rdm1)
+    ref, info = R.get_emb_basis(mesh, nlo, rdm1, imp_idx=list(range(nlo)), val_idx=list(range(nval)), return_info=True)
+    assert b.shape == ref.shape
+    # embedding basis is orthonormal; for two orthonormal bases of equal rank
+    # ||B1 B1^T - B2 B2^T||_F = sqrt(2) ||(1 - B2 B2^T) B1||_F  (avoids the 43200^2 projector)
+    B = b.reshape(-1, b.shape[-1])
+    Bref = ref.reshape(-1, ref.shape[-1])
+    assert np.abs(B.T @ B - np.eye(B.shape[1])).max() < 1e-12
+    assert np.abs(Bref.T @ Bref - np.eye(B.shape[1])).max() < 1e-12
+    resid = B - Bref @ (Bref.T @ B)
+    assert np.sqrt(2.0) * np.linalg.norm(resid) < 1e-10, np.sqrt(2.0) * np.linalg.norm(resid)
+    assert info["nbath_s"][0] == b.shape[-1] - nlo

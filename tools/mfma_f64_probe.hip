@@ -11,6 +11,25 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
 
 template<int NACC>
+__global__ __launch_bounds__(256) void cyc_kernel(double* out, long long* cyc, int iters, double a0, double b0){
+  d4 acc[NACC];
+  #pragma unroll
+  for(int i=0;i<NACC;i++) acc[i] = d4{0,0,0,0};
+  double a = a0 + threadIdx.x*1e-9, b = b0;
+  long long t0 = __builtin_readcyclecounter();
+  for(int it=0; it<iters; ++it){
+    #pragma unroll
+    for(int i=0;i<NACC;i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0,0,0);
+  }
+  double s=0;
+  #pragma unroll
+  for(int i=0;i<NACC;i++) s += acc[i][0]+acc[i][1]+acc[i][2]+acc[i][3];
+  long long t1 = __builtin_readcyclecounter();
+  out[blockIdx.x*blockDim.x+threadIdx.x] = s;
+  if((threadIdx.x&63)==0) cyc[blockIdx.x*4 + (threadIdx.x>>6)] = t1-t0;
+}
+
+template<int NACC>
 __global__ __launch_bounds__(256) void peak_kernel(double* out, int iters, double a0, double b0){
   d4 acc[NACC];
   #pragma unroll
@@ -58,6 +77,22 @@ template<int NACC> double run_peak(int blocks, int iters){
   return best;
 }
 
+template<int NACC> void run_cyc(int blocks, int iters, double a0, double b0, const char* tag){
+  double* out; long long* cyc; CK(hipMalloc(&out, sizeof(double)*blocks*256)); CK(hipMalloc(&cyc, sizeof(long long)*blocks*4));
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  cyc_kernel<NACC><<<blocks,256>>>(out, cyc, 10, a0, b0); CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  cyc_kernel<NACC><<<blocks,256>>>(out, cyc, iters, a0, b0);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms,e0,e1));
+  std::vector<long long> h(blocks*4); CK(hipMemcpy(h.data(), cyc, sizeof(long long)*blocks*4, hipMemcpyDeviceToHost));
+  double avg=0; for(auto v: h) avg += v; avg/=h.size();
+  double per = avg/((double)iters*NACC);
+  double tf = (double)blocks*4*iters*NACC*2048.0/(ms*1e-3)/1e12;
+  printf("%s blocks=%d NACC=%d: %.2f TF, s_memtime ticks per MFMA per wave %.1f, ticks/us %.1f\n", tag, blocks, NACC, tf, per, avg/(ms*1e3));
+  CK(hipFree(out)); CK(hipFree(cyc));
+}
+
 int main(){
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p,0));
   printf("device %s CUs=%d clock=%d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
@@ -77,5 +112,13 @@ int main(){
     printf("blocks/CU=%d  NACC=1: %.2f TF  NACC=2: %.2f TF  NACC=4: %.2f TF  NACC=8: %.2f TF  NACC=16: %.2f TF\n", bpc,
       run_peak<1>(blocks,20000), run_peak<2>(blocks,10000), run_peak<4>(blocks,5000), run_peak<8>(blocks,2500), run_peak<16>(blocks,1250));
   }
+  int cus = p.multiProcessorCount;
+  run_cyc<8>(cus, 4000, 1.000001, 0.999999, "1wave/SIMD nonzero");
+  run_cyc<8>(cus*2, 4000, 1.000001, 0.999999, "2wave/SIMD nonzero");
+  run_cyc<8>(cus*2, 4000, 0.0, 0.0, "2wave/SIMD zeros  ");
+  run_cyc<8>(cus*2, 4000, 0.7312893127, -1.3371237, "2wave/SIMD random-ish");
+  run_cyc<8>(1, 4000, 1.000001, 0.999999, "single block     ");
+  run_cyc<8>(8, 4000, 1.000001, 0.999999, "8 blocks         ");
+  run_cyc<8>(64, 4000, 1.000001, 0.999999, "64 blocks        ");
   return 0;
 }
