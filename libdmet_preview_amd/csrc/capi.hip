@@ -554,6 +554,7 @@ struct dmk_eri {
     double *planes = nullptr;   // spin x (2 naux) x npair
     double2 *Ut = nullptr;      // lchunk x nao x nemb
     int lchunk;
+    int use_3m = 1;       // Karatsuba complex product in the half transform (DMK_ERI_3M=0 restores 4M)
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
     dmk_eri(dmk_ctx *c, const int m[3]) : ctx(c), mesh(m) {}
@@ -574,6 +575,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     h->C = reinterpret_cast<const double2 *>(C_ao_emb);
     h->eri = eri_out;
     h->lchunk = naux;
+    if (const char *e = getenv("DMK_ERI_3M")) h->use_3m = atoi(e) != 0;
     if (const char *e = getenv("DMK_ERI_LCHUNK")) {
         int v = atoi(e);
         if (v > 0 && v < naux) h->lchunk = v;
@@ -621,7 +623,7 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g1.M = nao; g1.N = nemb; g1.K = nao; g1.batch = nl; g1.nseg = 1;
             g1.seg[0].A = L + (size_t)l0 * nao * nao; g1.seg[0].lda = nao; g1.seg[0].strideA = (int64_t)nao * nao;
             g1.seg[0].B = Ci; g1.seg[0].ldb = nemb; g1.seg[0].strideB = 0; g1.seg[0].conjB = 1;
-            g1.flatten_m = 1; g1.big_tile = 1;
+            g1.flatten_m = 1; g1.big_tile = 1; g1.use_3m = h->use_3m;
             g1.epi = ZEPI_STORE; g1.C = h->Ut; g1.ldc = nemb; g1.strideC = (int64_t)nao * nemb;
             int rc = launch_zgemm(ctx, g1, DMK_FAM_ZGEMM_HALF1);
             if (rc) return rc;
@@ -632,7 +634,7 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g2.seg[0].B = Cj; g2.seg[0].ldb = nemb; g2.seg[0].strideB = 0;
             g2.seg[1].A = Cj; g2.seg[1].lda = nemb; g2.seg[1].strideA = 0;
             g2.seg[1].B = h->Ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
-            g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1;
+            g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
             g2.planes = planes + (size_t)l0 * h->npair; g2.naux = naux; g2.npair = h->npair;
             rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
             if (rc) return rc;

@@ -102,6 +102,7 @@ struct ZGemm {
     int64_t naux = 0, npair = 0;
     int lower_only = 0;     // enumerate only tiles that touch a >= b
     int big_tile = 0;       // 128x64 instead of 64x64 workgroup tile
+    int use_3m = 0;         // 3 real MFMAs per complex tile step (Karatsuba) instead of 4
 };
 int launch_zgemm(dmk_ctx *ctx, const ZGemm &g, int fam);
 

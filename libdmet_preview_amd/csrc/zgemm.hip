@@ -49,7 +49,11 @@ struct ZArgs {
     unsigned nblocks;
 };
 
-template <int TM, int TN, int EPI>
+// M3 = true: Karatsuba "3M" complex product -- T1 = Ar Br, T2 = Ai Bi, T3 = (Ar+Ai)(Br+Bi),
+// Re = T1 - T2, Im = T3 - T1 - T2: three real MFMAs per complex tile step instead of four
+// (the two operand sums are one v_add_f64 per fragment).  Normwise backward stable; the
+// parity tests hold it to the same 1e-8 / 1e-10 budgets as the 4M form.
+template <int TM, int TN, int EPI, bool M3>
 __global__ __launch_bounds__(NTHREADS, 2) void zgemm_kernel(const ZArgs g) {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
     constexpr int PA = BK * BM / NTHREADS, PB = BK * BN / NTHREADS;
@@ -98,14 +102,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void zgemm_kernel(const ZArgs g) {
         }
     };
 
-    d4_t acc_re[TM][TN], acc_im[TM][TN];
+    // acc_re/acc_im hold (Re, Im) in 4M mode and (T1, T2) in 3M mode; acc_t3 only exists in 3M mode
+    d4_t acc_re[TM][TN], acc_im[TM][TN], acc_t3[M3 ? TM : 1][M3 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             acc_re[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
             acc_im[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+            if (M3) acc_t3[M3 ? i : 0][M3 ? j : 0] = d4_t{0.0, 0.0, 0.0, 0.0};
         }
+    // lower-triangle mode: 16x16 blocks that lie entirely above the diagonal are never needed
+    unsigned skip_mask = 0;
+    if (g.lower_only && !g.flatten_m) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row_max = tile_m * BM + wm * TM * 16 + i * 16 + 15;
+                const int col_min = n0 + wn * TN * 16 + j * 16;
+                if (row_max < col_min) skip_mask |= 1u << (i * TN + j);
+            }
+    }
 
     for (int s = 0; s < g.nseg; ++s) {
         const bool akm = g.a_kmajor[s] != 0, bkm = g.b_kmajor[s] != 0;
@@ -205,15 +223,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void zgemm_kernel(const ZArgs g) {
                 for (int i = 0; i < TM; ++i) a[i] = Ab[(kk * 4 + frag_k) * BM + i * 16];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[j] = Bb[(kk * 4 + frag_k) * BN + j * 16];
+                if (M3) {
+                    double as[TM], bs[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i) as[i] = a[i].x + a[i].y;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc_re[i][j], 0, 0, 0);
-                        acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acc_im[i][j], 0, 0, 0);
-                        acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc_re[i][j], 0, 0, 1);
-                        acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acc_im[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < TN; ++j) bs[j] = b[j].x + b[j].y;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (skip_mask & (1u << (i * TN + j))) continue;
+                            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc_re[i][j], 0, 0, 0);
+                            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc_im[i][j], 0, 0, 0);
+                            acc_t3[M3 ? i : 0][M3 ? j : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                as[i], bs[j], acc_t3[M3 ? i : 0][M3 ? j : 0], 0, 0, 0);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (skip_mask & (1u << (i * TN + j))) continue;
+                            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc_re[i][j], 0, 0, 0);
+                            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].y, acc_im[i][j], 0, 0, 0);
+                            acc_re[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc_re[i][j], 0, 0, 1);
+                            acc_im[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].x, acc_im[i][j], 0, 0, 0);
+                        }
+                }
             }
             if (kt + 1 < nkt) lstore(buf ^ 1);
             __syncthreads();
@@ -234,8 +271,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void zgemm_kernel(const ZArgs g) {
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + wn * TN * 16 + j * 16 + frag_x;
                 if (col >= g.N) continue;
-                const double vr = g.alpha * acc_re[i][j][r];
-                const double vi = g.alpha * acc_im[i][j][r];
+                double vr, vi;
+                if (M3) {
+                    const double t1 = acc_re[i][j][r], t2 = acc_im[i][j][r], t3 = acc_t3[M3 ? i : 0][M3 ? j : 0][r];
+                    vr = g.alpha * (t1 - t2);
+                    vi = g.alpha * ((t3 - t1) - t2);
+                } else {
+                    vr = g.alpha * acc_re[i][j][r];
+                    vi = g.alpha * acc_im[i][j][r];
+                }
                 if (EPI == ZEPI_STORE) {
                     double2 *C = reinterpret_cast<double2 *>(g.C) + (long long)b * g.strideC + (long long)row * g.ldc + col;
                     *C = make_double2(vr, vi);
@@ -265,7 +309,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void zgemm_kernel(const ZArgs g) {
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool M3>
 int launch_cfg(dmk_ctx *ctx, ZArgs &a, const ZGemm &g, int fam) {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 16;
     a.tiles_n = (g.N + BN - 1) / BN;
@@ -296,13 +340,13 @@ int launch_cfg(dmk_ctx *ctx, ZArgs &a, const ZGemm &g, int fam) {
     FamScope fs(ctx, fam);
     switch (g.epi) {
         case ZEPI_STORE:
-            hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_STORE>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);
+            hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_STORE, M3>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);
             break;
         case ZEPI_STORE_REAL:
-            hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_STORE_REAL>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);
+            hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_STORE_REAL, M3>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);
             break;
         default:
-            hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_PACK_ACC>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);
+            hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_PACK_ACC, M3>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);
             break;
     }
     DMK_CHECK_LAUNCH(ctx);
@@ -340,6 +384,7 @@ int launch_zgemm(dmk_ctx *ctx, const ZGemm &g, int fam) {
     } else if (g.C == nullptr) {
         return dmk_fail(ctx, DMK_ERR_INVALID, "zgemm: null C");
     }
-    if (g.big_tile) return launch_cfg<4, 2>(ctx, a, g, fam);
-    return launch_cfg<2, 2>(ctx, a, g, fam);
+    if (g.use_3m) return launch_cfg<2, 2, true>(ctx, a, g, fam);   // (4,2) would spill: 3 accumulator sets
+    if (g.big_tile) return launch_cfg<4, 2, false>(ctx, a, g, fam);
+    return launch_cfg<2, 2, false>(ctx, a, g, fam);
 }

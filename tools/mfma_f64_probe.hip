@@ -77,6 +77,56 @@ template<int NACC> double run_peak(int blocks, int iters){
   return best;
 }
 
+// Hand-pinned variant: 4x4 accumulators in VGPRs, distinct A/B operands, MFMAs issued from inline asm so
+// that hipcc cannot shuttle the accumulators through AGPRs between iterations (which is what limits the
+// intrinsic-based kernels above).  This is the ceiling a register-resident GEMM inner loop can see.
+__global__ __launch_bounds__(256) void asm_kernel(double* out, long long* cyc, int iters, double a0, double b0){
+  d4 acc[4][4];
+  #pragma unroll
+  for(int i=0;i<4;i++)
+  #pragma unroll
+  for(int j=0;j<4;j++) acc[i][j] = d4{0,0,0,0};
+  double a[4], b[4];
+  #pragma unroll
+  for(int i=0;i<4;i++){ a[i] = a0 + threadIdx.x*1e-9 + i*1e-3; b[i] = b0 - i*1e-3; }
+  long long t0 = __builtin_readcyclecounter();
+  for(int it=0; it<iters; ++it){
+    #pragma unroll
+    for(int i=0;i<4;i++)
+    #pragma unroll
+    for(int j=0;j<4;j++)
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+  }
+  asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+  long long t1 = __builtin_readcyclecounter();
+  double s=0;
+  #pragma unroll
+  for(int i=0;i<4;i++)
+  #pragma unroll
+  for(int j=0;j<4;j++) s += acc[i][j][0]+acc[i][j][1]+acc[i][j][2]+acc[i][j][3];
+  out[blockIdx.x*blockDim.x+threadIdx.x] = s;
+  if((threadIdx.x&63)==0) cyc[blockIdx.x*4 + (threadIdx.x>>6)] = t1-t0;
+}
+
+void run_asm(int blocks, int iters, double a0, double b0, const char* tag){
+  double* out; long long* cyc; CK(hipMalloc(&out, sizeof(double)*blocks*256)); CK(hipMalloc(&cyc, sizeof(long long)*blocks*4));
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  asm_kernel<<<blocks,256>>>(out, cyc, 10, a0, b0); CK(hipDeviceSynchronize());
+  double best=0, bper=0, bclk=0;
+  for(int rep=0;rep<3;rep++){
+    CK(hipEventRecord(e0));
+    asm_kernel<<<blocks,256>>>(out, cyc, iters, a0, b0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms,e0,e1));
+    std::vector<long long> h(blocks*4); CK(hipMemcpy(h.data(), cyc, sizeof(long long)*blocks*4, hipMemcpyDeviceToHost));
+    double avg=0; for(auto v: h) avg += v; avg/=h.size();
+    double tf = (double)blocks*4*iters*16*2048.0/(ms*1e-3)/1e12;
+    if(tf>best){best=tf; bper=avg/((double)iters*16); bclk=avg/(ms*1e3);}
+  }
+  printf("asm-pinned %s blocks=%d: %.2f TF, ticks per MFMA per wave %.1f, ticks/us %.1f\n", tag, blocks, best, bper, bclk);
+  CK(hipFree(out)); CK(hipFree(cyc));
+}
+
 template<int NACC> void run_cyc(int blocks, int iters, double a0, double b0, const char* tag){
   double* out; long long* cyc; CK(hipMalloc(&out, sizeof(double)*blocks*256)); CK(hipMalloc(&cyc, sizeof(long long)*blocks*4));
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -117,6 +167,11 @@ int main(){
   run_cyc<8>(cus*2, 4000, 1.000001, 0.999999, "2wave/SIMD nonzero");
   run_cyc<8>(cus*2, 4000, 0.0, 0.0, "2wave/SIMD zeros  ");
   run_cyc<8>(cus*2, 4000, 0.7312893127, -1.3371237, "2wave/SIMD random-ish");
+  run_asm(cus, 2000, 1.000001, 0.999999, "1 wave/SIMD ");
+  run_asm(cus*2, 2000, 1.000001, 0.999999, "2 waves/SIMD");
+  run_asm(cus*2, 2000, 0.731, -1.337, "2 waves/SIMD random-ish");
+  run_asm(cus*4, 2000, 1.000001, 0.999999, "4 waves/SIMD");
+  run_asm(1, 2000, 1.000001, 0.999999, "single block");
   run_cyc<8>(1, 4000, 1.000001, 0.999999, "single block     ");
   run_cyc<8>(8, 4000, 1.000001, 0.999999, "8 blocks         ");
   run_cyc<8>(64, 4000, 1.000001, 0.999999, "64 blocks        ");

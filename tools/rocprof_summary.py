@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 (rocpd sqlite) outputs into the text summaries committed under profiles/.
+
+usage: python tools/rocprof_summary.py <trace.db> [<pmc.db> ...] > profiles/rNN_summary.txt
+"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name[:90]
+
+
+def stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels "
+                       "order by total_duration desc").fetchall()
+    print("== kernel stats (rocprofv3 --kernel-trace --stats): %s" % db)
+    print("%-92s %8s %14s %14s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "%"))
+    for n, c, t, a, p in rows:
+        print("%-92s %8d %14.3f %14.4f %7.2f" % (short(n), c, t / 1e3, a / 1e3, p))   # view is in microseconds
+    print()
+
+
+def pmc(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, counter_name, count(*), avg(counter_value), sum(counter_value) from pmc_events "
+                       "group by name, counter_name order by sum(counter_value) desc").fetchall()
+    print("== PMC (rocprofv3 --kernel-trace --pmc): %s" % db)
+    print("(FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 1/2 of a wide coalesced 16 B/lane stream --")
+    print(" MI355X_MICROARCH.md section HBM -- so the MB column doubles it; WRITE_SIZE matched the known store bytes 1:1)")
+    print("%-92s %-12s %8s %16s %14s" % ("kernel", "counter", "calls", "avg KiB/dispatch", "avg MB (corr.)"))
+    for n, cn, c, a, s in rows:
+        corr = 2.0 if cn == "FETCH_SIZE" else 1.0
+        print("%-92s %-12s %8d %16.1f %14.1f" % (short(n), cn, c, a, a * 1024 * corr / 1e6))
+    print()
+
+
+if __name__ == "__main__":
+    stats(sys.argv[1])
+    for d in sys.argv[2:]:
+        pmc(d)
