@@ -625,8 +625,12 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g1.seg[0].B = Ci; g1.seg[0].ldb = nemb; g1.seg[0].strideB = 0; g1.seg[0].conjB = 1;
             g1.flatten_m = 1; g1.big_tile = 1; g1.use_3m = h->use_3m;
             g1.epi = ZEPI_STORE; g1.C = h->Ut; g1.ldc = nemb; g1.strideC = (int64_t)nao * nemb;
-            int rc = launch_zgemm(ctx, g1, DMK_FAM_ZGEMM_HALF1);
-            if (rc) return rc;
+            int rc = launch_half1_hot(ctx, g1.seg[0].A, Ci, h->Ut, nl, nao, nemb);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                rc = launch_zgemm(ctx, g1, DMK_FAM_ZGEMM_HALF1);
+                if (rc) return rc;
+            }
             // step 2: S[a][b] = sum_q Ut[L][q][a] Cj[q][b] (+ sum_q Cj[q][a] Ut[L][q][b]); tril-pack, accumulate
             ZGemm g2;
             g2.M = nemb; g2.N = nemb; g2.K = nao; g2.batch = nl; g2.nseg = symmetrise ? 2 : 1;
@@ -636,8 +640,12 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g2.seg[1].B = h->Ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
             g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
             g2.planes = planes + (size_t)l0 * h->npair; g2.naux = naux; g2.npair = h->npair;
-            rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
-            if (rc) return rc;
+            rc = launch_half2_hot(ctx, h->Ut, Cj, g2.planes, naux, h->npair, nl, nao, nemb, symmetrise ? 1 : 0);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
+                if (rc) return rc;
+            }
         }
     }
     h->flops_half += (double)h->spin * (8.0 * naux * (double)nao * nao * nemb + 8.0 * naux * (double)nao * nemb * nemb);

@@ -68,6 +68,29 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
     return base + idx;
 }
 
+// LDS-DMA: 16 bytes per lane from `gsrc` (per-lane global address) to LDS byte address
+// `lds_base` (wave-uniform) + 16 * lane.  Issued from inline asm on purpose: hipcc's waitcnt pass does
+// not see it, so it never drains the counted vmcnt ring with a conservative s_waitcnt vmcnt(0) in front
+// of the next ds_read; the caller retires it with its own s_waitcnt vmcnt(N) + s_barrier
+// (cdna_hip_programming.md section 5.7: M0 is written and restored inside the same statement).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) void dmk_lds_void_t;
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) {
+    return (unsigned)(size_t)(dmk_lds_void_t *)p;
+}
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(base)
+                 : "memory");
+}
+#else
+__device__ unsigned lds_addr_of(const void *p);          // host pass: declarations only
+__device__ void glds16(const void *gsrc, unsigned lds_base);
+#endif
+
 // ---- launchers implemented in the .hip files ---------------------------------------------
 
 // C (M x N, ldc) += alpha * X^T Y;  X: K x M (ldx), Y: K x N (ldy)
@@ -107,3 +130,8 @@ struct ZGemm {
 int launch_zgemm(dmk_ctx *ctx, const ZGemm &g, int fam);
 
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
+
+// hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
+int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb);
+int launch_half2_hot(dmk_ctx *ctx, const void *Ut, const void *Cj, double *planes, long long naux, long long npair,
+                     int nL, int nao, int nemb, int symmetrise);

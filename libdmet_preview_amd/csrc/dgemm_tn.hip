@@ -17,6 +17,7 @@
 // Roofline: f64 MFMA: 2*K*M*N flop per call against
 // 8*(K*(M+N) + 2*M*N) bytes.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -146,6 +147,118 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// "big" variant: 512-thread workgroup, 256 x 128 tile, LDS-DMA ring.
+//
+// tools/mfma_f64_probe.hip: a register-resident v_mfma_f64_16x16x4_f64 stream sustains 77.5 TFLOP/s
+// (64.0 cycles per MFMA per SIMD).  rocprof PMC on the 128 x 128 kernel above: MFMA pipe 75 % busy,
+// 20 % of wave-cycles parked on memory waits, 31 GB fetched per launch against 9.5 GB algorithmic --
+// the scarce resource is the L2 -> LDS feed and its latency, not the matrix pipe.  So the eight waves
+// of a 512-thread workgroup (2 per SIMD, wave tile 64 x 64 = 16 accumulators in 128 VGPRs, no AGPR
+// traffic) share one 256 x 128 tile: half the L2 bytes per flop of two independent 128 x 128
+// workgroups.  Operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, the copy
+// engine writes LDS directly) into a 3-stage ring (3 x 52 KiB) issued two K-tiles ahead and retired
+// with a counted s_waitcnt vmcnt(6) plus ONE raw s_barrier per K-tile (BK = 16 -> 64 MFMAs = 4096
+// pipe cycles per wave between barriers).  LDS rows keep a 128-B-mod-256-B stride (A: 272, B: 144
+// doubles) so every ds_read_b64 lane group is conflict-free.  Out-of-range lanes re-read clamped valid
+// columns (their data only reaches masked outputs), so every wave issues exactly six loads per tile
+// and the vmcnt arithmetic holds.  Requires K % 16 == 0, even M, N, ldx, ldy and 16-B aligned bases;
+// anything else takes the kernel above.
+constexpr int GBM = 256, GBN = 128, GBK = 16, GD = 3, GNT = 512;
+constexpr int GA_LD = GBM + 16, GB_LD = GBN + 16;
+constexpr int GA_STAGE = GBK * GA_LD, GB_STAGE = GBK * GB_LD;      // doubles
+constexpr int G_STAGE = GA_STAGE + GB_STAGE;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
+    int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
+    const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
+    int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) double lds[GD * G_STAGE];
+
+    const unsigned nblocks = (unsigned)tiles_m * (unsigned)tiles_n;
+    const unsigned lid = xcd_remap(blockIdx.x, nblocks);
+    constexpr unsigned GROUP = 4;
+    const unsigned per_group = GROUP * (unsigned)tiles_n;
+    const unsigned g = lid / per_group;
+    const unsigned first_m = g * GROUP;
+    const unsigned gsize = min((unsigned)tiles_m - first_m, GROUP);
+    const unsigned in_g = lid - g * per_group;
+    const int tm = (int)(first_m + in_g % gsize);
+    const int tn = (int)(in_g / gsize);
+    const int m0 = tm * GBM, n0 = tn * GBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frag_k = lane >> 4, frag_x = lane & 15;
+
+    int ca0 = m0 + 2 * lane, ca1 = m0 + 128 + 2 * lane, cb = n0 + 2 * lane;
+    if (ca0 + 1 >= M) ca0 = M - 2;
+    if (ca1 + 1 >= M) ca1 = M - 2;
+    if (cb + 1 >= N) cb = N - 2;
+    const double *pA0 = X + ca0, *pA1 = X + ca1, *pB = Y + cb;
+
+    auto issue = [&](int t) {
+        double *st = lds + (t % GD) * G_STAGE;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = wave * 2 + r;
+            const int64_t kg = (int64_t)(t * GBK + k);
+            glds16(pA0 + kg * ldx, lds_addr_of(st + k * GA_LD));
+            glds16(pA1 + kg * ldx, lds_addr_of(st + k * GA_LD + 128));
+            glds16(pB + kg * ldy, lds_addr_of(st + GA_STAGE + k * GB_LD));
+        }
+    };
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int T = K / GBK;
+    issue(0);
+    if (T > 1) issue(1);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < T) issue(t + 2);
+        const double *Ab = lds + (t % GD) * G_STAGE + wm * 64 + frag_x;
+        const double *Bb = lds + (t % GD) * G_STAGE + GA_STAGE + wn * 64 + frag_x;
+#pragma unroll
+        for (int kk = 0; kk < GBK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = Ab[(kk * 4 + frag_k) * GA_LD + i * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bb[(kk * 4 + frag_k) * GB_LD + j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 64 + i * 16 + frag_k + 4 * r;
+            if (row >= M) continue;
+            double *crow = C + (int64_t)row * ldc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + wn * 64 + j * 16 + frag_x;
+                if (col < N) crow[col] += alpha * acc[i][j][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
@@ -157,6 +270,16 @@ int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const d
     const bool vec2 = ((ldx & 1) == 0) && ((ldy & 1) == 0) &&
                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+    static const bool big_enabled = [] { const char *e = getenv("DMK_DGEMM_BIG"); return !(e && atoi(e) == 0); }();
+    if (big_enabled && vec2 && (K % GBK) == 0 && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2 &&
+        (int64_t)M * N >= 4 * GBM * GBN) {
+        const int btm = (M + GBM - 1) / GBM, btn = (N + GBN - 1) / GBN;
+        FamScope fs(ctx, DMK_FAM_DGEMM);
+        hipLaunchKernelGGL(dgemm_tn_acc_big_kernel, dim3((unsigned)(btm * btn)), dim3(GNT), 0, ctx->stream, M, N, K,
+                           alpha, X, ldx, Y, ldy, C, ldc, btm, btn);
+        DMK_CHECK_LAUNCH(ctx);
+        return DMK_OK;
+    }
     FamScope fs(ctx, DMK_FAM_DGEMM);
     if (vec2)
         hipLaunchKernelGGL(dgemm_tn_acc_kernel<true>, dim3((unsigned)nblocks), dim3(NTHREADS), 0,
