@@ -57,7 +57,7 @@ const char *dmk_last_error(const dmk_ctx *ctx);
 const char *dmk_version(void);
 
 int dmk_malloc(dmk_ctx *ctx, size_t bytes, void **out);
-int dmk_free(dmk_ctx *ctx, void *p);
+int dmk_free(dmk_ctx *ctx, void *p);      /* drains the context stream first */
 int dmk_memset(dmk_ctx *ctx, void *p, int value, size_t bytes);
 int dmk_memcpy_h2d(dmk_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int dmk_memcpy_d2h(dmk_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);

@@ -118,7 +118,11 @@ int dmk_malloc(dmk_ctx *ctx, size_t bytes, void **out) {
 }
 int dmk_free(dmk_ctx *ctx, void *p) {
     if (!ctx) return DMK_ERR_INVALID;
-    if (p) DMK_HIP(ctx, hipFree(p));
+    if (p) {
+        // work enqueued on the context stream may still read the buffer: drain it first
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DMK_HIP(ctx, hipFree(p));
+    }
     return DMK_OK;
 }
 int dmk_memset(dmk_ctx *ctx, void *p, int value, size_t bytes) {

@@ -523,7 +523,8 @@ def test_hot_half_transform_planes(ctx, nao, naux, spin):
     ref = np.zeros((spin, naux, npair), dtype=np.complex128)
     for (i, j, sym) in [(1, 0, 1), (3, 2, 0), (0, 1, 1)]:
         blk = R.df_block_philox(5, i, j, naux, nao)
-        ctx.check(lib.dmk_eri_push_block(eng.h, i, j, sym, ctx.to_device(blk).ptr))
+        d_blk = ctx.to_device(blk)
+        ctx.check(lib.dmk_eri_push_block(eng.h, i, j, sym, d_blk.ptr))
         Lij = R.transform_ao_to_emb(blk.reshape(naux, -1), Cemb, i, j)
         if sym:
             Lij = Lij + Lij.transpose(0, 1, 3, 2)
