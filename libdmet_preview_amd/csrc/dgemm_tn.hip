@@ -253,7 +253,10 @@ __global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + frag_x;
-                if (col < N) crow[col] += alpha * acc[i][j][r];
+                // fire-and-forget f64 atomic instead of load-add-store: every C element has exactly ONE writer
+                // per launch (tiles are disjoint, launches are stream-ordered), so the sum is still deterministic,
+                // but the wave no longer sits out one HBM round trip per element row (lab: 60.1 -> 63.6 TF)
+                if (col < N) unsafeAtomicAdd(&crow[col], alpha * acc[i][j][r]);
             }
         }
     }

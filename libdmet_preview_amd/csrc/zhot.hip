@@ -173,8 +173,9 @@ __device__ __forceinline__ void pack_acc(const H2Args &g, int L, int row, int co
         const long long idx = (long long)row * (row + 1) / 2 + col;
         double *pr = g.planes + (long long)L * g.npair + idx;
         double *pi = g.planes + (g.naux + (long long)L) * g.npair + idx;
-        *pr += vr;
-        *pi += vi;
+        // single writer per address per launch -> deterministic; no load latency in the epilogue
+        unsafeAtomicAdd(pr, vr);
+        unsafeAtomicAdd(pi, vi);
     }
 }
 
