@@ -95,7 +95,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("DMK_DEVICE", str(local))
-    distributed = world > 1
+    # DMK_FORCE_DIST=1 initialises the process group even for one rank (exercises the RCCL plumbing on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("DMK_FORCE_DIST", "0") == "1"
+    if distributed and "MASTER_ADDR" not in os.environ:
+        os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517", "RANK": "0", "WORLD_SIZE": "1"})
     if distributed:
         import torch
         import torch.distributed as td
@@ -172,20 +175,21 @@ def main():
         nemb = out["nemb"]
         npair = nemb * (nemb + 1) // 2
         nblk = out["nblocks"]
-        # per-launch algorithmic flop of each ERI kernel family
-        per = {
-            "zgemm_half1": 8.0 * sysm.naux * sysm.nao * sysm.nao * nemb,
-            "zgemm_half2": 8.0 * sysm.naux * sysm.nao * nemb * nemb,
+        # algorithmic flop of each ERI kernel family over the timed region (DESIGN.md
+        # section 5); a step-2 launch covers up to DMK_ERI_GROUP queued AO blocks, so rates are totals / totals
+        fam_flops = {
+            "zgemm_half1": 8.0 * sysm.naux * sysm.nao * sysm.nao * nemb * sysm.spin * nblk * a.steps,
+            "zgemm_half2": 8.0 * sysm.naux * sysm.nao * nemb * nemb * sysm.spin * nblk * a.steps,
+            "dgemm": out["flops_contract"] * a.steps,
         }
         fam_out = {}
         for k, (ms, n) in fam.items():
             if n:
                 fam_out[k] = {"ms_total": round(ms, 3), "launches": n, "ms_avg": round(ms / n, 4)}
-        for k in per:
+        for k in fam_flops:
             if k in fam_out:
-                fam_out[k]["tflops"] = round(per[k] / (fam_out[k]["ms_avg"] * 1e-3) / 1e12, 2)
-        if "dgemm" in fam_out:
-            fam_out["dgemm"]["tflops"] = round(out["flops_contract"] * a.steps / (fam_out["dgemm"]["ms_total"] * 1e-3) / 1e12, 2)
+                fam_out[k]["tflops"] = round(fam_flops[k] / (fam_out[k]["ms_total"] * 1e-3) / 1e12, 2)
+                fam_out[k]["gflop_per_launch"] = round(fam_flops[k] / fam_out[k]["launches"] / 1e9, 2)
         dom = max([k for k in ("zgemm_half1", "zgemm_half2", "dgemm") if k in fam_out],
                   key=lambda k: fam_out[k]["ms_total"])
         achieved = fam_out[dom]["tflops"]

@@ -558,7 +558,11 @@ struct dmk_eri {
     double *planes = nullptr;   // spin x (2 naux) x npair
     double2 *Ut = nullptr;      // lchunk x nao x nemb
     int lchunk;
-    int use_3m = 1;       // Karatsuba complex product in the half transform (DMK_ERI_3M=0 restores 4M)
+    int use_3m = 1;       // Karatsuba complex product in the generic half transform (DMK_ERI_3M=0 restores 4M)
+    // hot path: step-1 outputs of up to `group` consecutive AO blocks are queued and transformed by ONE
+    // step-2 launch whose accumulators (and tril-pack epilogue) are shared by all of them
+    int group = 1, pending = 0;
+    int pend_kj[16], pend_sym[16];
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
     dmk_eri(dmk_ctx *c, const int m[3]) : ctx(c), mesh(m) {}
@@ -584,8 +588,14 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         int v = atoi(e);
         if (v > 0 && v < naux) h->lchunk = v;
     }
+    if (half2_hot_usable(nao, nemb)) {
+        h->lchunk = naux;
+        h->group = 8;
+        if (const char *e = getenv("DMK_ERI_GROUP")) h->group = atoi(e);
+        h->group = std::max(1, std::min(h->group, half2_hot_maxslot()));
+    }
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
-    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2);
+    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1);
     hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&h->planes), plane_bytes);
     hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&h->Ut), ut_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -608,6 +618,26 @@ int dmk_eri_begin_kL(dmk_eri *h, int kL) {
     return DMK_OK;
 }
 
+static int eri_flush(dmk_eri *h) {
+    dmk_ctx *ctx = h->ctx;
+    if (h->pending == 0) return DMK_OK;
+    const int nao = h->nao, naux = h->naux, nemb = h->nemb;
+    const size_t slot_elems = (size_t)naux * nao * nemb;
+    for (int s = 0; s < h->spin; ++s) {
+        const void *cj[16];
+        for (int i = 0; i < h->pending; ++i)
+            cj[i] = h->C + ((size_t)s * h->mesh.nk + h->pend_kj[i]) * nao * nemb;
+        double *planes = h->planes + (size_t)s * 2 * naux * h->npair;
+        const double2 *ut = h->Ut + (size_t)s * h->group * slot_elems;
+        int rc = launch_half2_hot(ctx, ut, (long long)slot_elems, h->pending, cj, h->pend_sym, planes, naux, h->npair,
+                                  naux, nao, nemb);
+        if (rc < 0) return rc;
+        if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_flush: hot step-2 kernel unavailable for a queued block");
+    }
+    h->pending = 0;
+    return DMK_OK;
+}
+
 int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq) {
     if (!h) return DMK_ERR_INVALID;
     dmk_ctx *ctx = h->ctx;
@@ -616,6 +646,36 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
         return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_block: bad arguments");
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const double2 *L = reinterpret_cast<const double2 *>(Lpq);
+    const size_t slot_elems = (size_t)naux * nao * nemb;
+    if (h->group > 1) {
+        // hot path: step 1 now (it consumes the caller's block buffer), step 2 when the queue is full
+        const int slot = h->pending;
+        for (int s = 0; s < h->spin; ++s) {
+            const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
+            double2 *ut = h->Ut + ((size_t)s * h->group + slot) * slot_elems;
+            int rc = launch_half1_hot(ctx, L, Ci, ut, naux, nao, nemb);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                ZGemm g1;
+                g1.M = nao; g1.N = nemb; g1.K = nao; g1.batch = naux; g1.nseg = 1;
+                g1.seg[0].A = L; g1.seg[0].lda = nao; g1.seg[0].strideA = (int64_t)nao * nao;
+                g1.seg[0].B = Ci; g1.seg[0].ldb = nemb; g1.seg[0].strideB = 0; g1.seg[0].conjB = 1;
+                g1.flatten_m = 1; g1.big_tile = 1; g1.use_3m = h->use_3m;
+                g1.epi = ZEPI_STORE; g1.C = ut; g1.ldc = nemb; g1.strideC = (int64_t)nao * nemb;
+                rc = launch_zgemm(ctx, g1, DMK_FAM_ZGEMM_HALF1);
+                if (rc) return rc;
+            }
+        }
+        h->pend_kj[slot] = kj;
+        h->pend_sym[slot] = symmetrise ? 1 : 0;
+        h->pending += 1;
+        if (h->pending == h->group) {
+            int rc = eri_flush(h);
+            if (rc) return rc;
+        }
+        h->flops_half += (double)h->spin * (8.0 * naux * (double)nao * nao * nemb + 8.0 * naux * (double)nao * nemb * nemb);
+        return DMK_OK;
+    }
     for (int s = 0; s < h->spin; ++s) {
         const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
         const double2 *Cj = h->C + ((size_t)s * h->mesh.nk + kj) * nao * nemb;
@@ -644,12 +704,8 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g2.seg[1].B = h->Ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
             g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
             g2.planes = planes + (size_t)l0 * h->npair; g2.naux = naux; g2.npair = h->npair;
-            rc = launch_half2_hot(ctx, h->Ut, Cj, g2.planes, naux, h->npair, nl, nao, nemb, symmetrise ? 1 : 0);
-            if (rc < 0) return rc;
-            if (rc == 0) {
-                rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
-                if (rc) return rc;
-            }
+            rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
+            if (rc) return rc;
         }
     }
     h->flops_half += (double)h->spin * (8.0 * naux * (double)nao * nao * nemb + 8.0 * naux * (double)nao * nemb * nemb);
@@ -660,6 +716,10 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
     if (!h) return DMK_ERR_INVALID;
     dmk_ctx *ctx = h->ctx;
     if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: no kL in progress");
+    {
+        int rcf = eri_flush(h);
+        if (rcf) return rcf;
+    }
     int K;
     double alpha;
     if (h->tr) {
@@ -688,6 +748,10 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
 
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     if (!h || !planes_out) return DMK_ERR_INVALID;
+    {
+        int rcf = eri_flush(h);      // queued blocks must land before anyone looks at the planes
+        if (rcf) return rcf;
+    }
     *planes_out = h->planes;
     if (elems_out) *elems_out = (int64_t)h->spin * 2 * h->naux * h->npair;
     return DMK_OK;

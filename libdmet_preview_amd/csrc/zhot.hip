@@ -30,6 +30,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Ablation switches for tools/zhot_lab.hip only (product builds leave ZHOT_ABL at 0):
+//   1 = no LDS-DMA after the prologue, 2 = no epilogue, 4 = no barrier (results wrong, timing only)
+#ifndef ZHOT_ABL
+#define ZHOT_ABL 0
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 3 < T) issue(t + 3);
+        if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
+        if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
         const double2 *Ab = lds + (t % H1_D) * H1_STAGE + wm * 64 + frag_x;
         const double2 *Bb = lds + (t % H1_D) * H1_STAGE + H1_BK * H1_BM + wn * 32 + frag_x;
 #pragma unroll
@@ -133,6 +139,15 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     }
 
     // ---- epilogue: Ut[L][q][a] ---------------------------------------------------------------
+    if (ZHOT_ABL & 2) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s += acc_re[i][j][0] + acc_im[i][j][1] + acc_re[i][j][2] + acc_im[i][j][3];
+        if (s == 12345.678) g.Ut[tid].x = s;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int gb = tile_m * (H1_BM / 16) + wm * 4 + i;
@@ -159,16 +174,23 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 constexpr int H2_N = 256, H2_BK = 4, H2_D = 4;
 constexpr int H2_STAGE = H2_BK * 2 * H2_N;            // double2 per stage: U[4][256] | C[4][256] = 32 KiB
 
+constexpr int H2_MAXSLOT = 16;
 struct H2Args {
-    const double2 *Ut;     // [nL][nao][256]
-    const double2 *Cj;     // [nao][256]
+    const double2 *Ut;     // [nslot][nL][nao][256]: step-1 outputs of `nslot` consecutive AO blocks
+    const double2 *Cj[H2_MAXSLOT];   // [nao][256] of each block
+    int sym[H2_MAXSLOT];   // add the time-reversal partner term of that block?
+    long long slot_stride; // elements between the Ut of consecutive slots
     double *planes;        // [(ri * naux + L) * npair + pair]
     long long naux, npair;
-    int nL, nao, symmetrise;
+    int nL, nao, nslot;
     unsigned nblocks;
 };
 
 __device__ __forceinline__ void pack_acc(const H2Args &g, int L, int row, int col, double vr, double vi) {
+    if (ZHOT_ABL & 2) {
+        if (vr == 12345.678) g.planes[0] = vi;
+        return;
+    }
     if (row >= col) {
         const long long idx = (long long)row * (row + 1) / 2 + col;
         double *pr = g.planes + (long long)L * g.npair + idx;
@@ -186,19 +208,33 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
     const int L = (int)(lid >> 1), type = (int)(lid & 1);
     const long long nemb = H2_N;
-    const int T = g.nao / H2_BK;
+    const int Tb = g.nao / H2_BK;            // K-tiles per AO block
+    const int T = Tb * g.nslot;              // the ring runs straight through all queued blocks: the
+                                             // accumulators (and the epilogue) are shared by nslot blocks
 
     // LDS-DMA sources: a stage is 16 pieces of 64 complex: pieces 0..3 = U row 0, ..., 12..15 = U row 3? no:
     // layout U[4][256] then C[4][256]: piece p < 16 -> U row p / 4, cols 64 (p % 4); p >= 16 -> C likewise.
     // 32 pieces per stage, 8 waves -> 4 per wave.
     const double2 *Ubase = g.Ut + (long long)L * g.nao * nemb;
-    const double2 *src[4];
+    long long soff[4];       // per-lane element offset of this wave's four pieces inside a block's U or C panel
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const int piece = wave + 8 * h;                  // 0..31
-        const int isC = piece >> 4, rowk = (piece & 15) >> 2, c0 = (piece & 3) * 64;
-        src[h] = (isC ? g.Cj : Ubase) + (long long)rowk * nemb + c0 + lane;
+        const int piece = wave + 8 * h;                  // 0..31: pieces 0-15 = U rows 0-3, 16-31 = C rows 0-3
+        const int rowk = (piece & 15) >> 2, c0 = (piece & 3) * 64;
+        soff[h] = (long long)rowk * nemb + c0 + lane;
     }
+    // pieces wave and wave + 8 are always U, wave + 16 and wave + 24 always C
+    auto issue_tile = [&](int tt) {
+        const int slot = tt / Tb, t = tt - slot * Tb;
+        double2 *st = lds + (tt % H2_D) * H2_STAGE;
+        const long long k0 = (long long)t * H2_BK * nemb;
+        const double2 *ub = Ubase + (long long)slot * g.slot_stride + k0;
+        const double2 *cb = g.Cj[slot] + k0;
+        glds16(ub + soff[0], lds_addr_of(st + (wave) * 64));
+        glds16(ub + soff[1], lds_addr_of(st + (wave + 8) * 64));
+        glds16(cb + soff[2], lds_addr_of(st + (wave + 16) * 64));
+        glds16(cb + soff[3], lds_addr_of(st + (wave + 24) * 64));
+    };
 
     if (type == 1) {
         // ---- two diagonal 128 x 128 triangles: waves 0-3 -> [0,128), waves 4-7 -> [128,256) -----------
@@ -213,13 +249,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             for (int c = 0; c <= R1; ++c) { re1[c] = d4_t{0.0, 0.0, 0.0, 0.0}; im1[c] = d4_t{0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
             for (int c = 0; c <= R2; ++c) { re2[c] = d4_t{0.0, 0.0, 0.0, 0.0}; im2[c] = d4_t{0.0, 0.0, 0.0, 0.0}; }
-            auto issue = [&](int t) {
-                double2 *st = lds + (t % H2_D) * H2_STAGE;
-                const long long k0 = (long long)t * H2_BK;
-#pragma unroll
-                for (int h = 0; h < 4; ++h)
-                    glds16(src[h] + k0 * nemb, lds_addr_of(st + (wave + 8 * h) * 64));
-            };
+            auto issue = issue_tile;
             issue(0);
             if (T > 1) issue(1);
             if (T > 2) issue(2);
@@ -228,8 +258,8 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 3 < T) issue(t + 3);
+                if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
+                if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
                 const double2 *U = lds + (t % H2_D) * H2_STAGE + frag_k * H2_N + d0 + frag_x;
                 const double2 *C = U + H2_BK * H2_N;
                 {
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) ZMFMA4(re2[c], im2[c], a2, b[c]);
                 }
-                if (g.symmetrise) {
+                if (g.sym[t / Tb]) {
                     const double2 a1 = C[R1 * 16], a2 = C[R2 * 16];
                     double2 b[R2 + 1];
 #pragma unroll
@@ -281,13 +311,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             acc_re[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
             acc_im[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
         }
-    auto issue = [&](int t) {
-        double2 *st = lds + (t % H2_D) * H2_STAGE;
-        const long long k0 = (long long)t * H2_BK;
-#pragma unroll
-        for (int h = 0; h < 4; ++h)
-            glds16(src[h] + k0 * nemb, lds_addr_of(st + (wave + 8 * h) * 64));
-    };
+    auto issue = issue_tile;
     issue(0);
     if (T > 1) issue(1);
     if (T > 2) issue(2);
@@ -296,8 +320,8 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 3 < T) issue(t + 3);
+        if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
+        if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
         const double2 *U = lds + (t % H2_D) * H2_STAGE + frag_k * H2_N + frag_x;
         const double2 *C = U + H2_BK * H2_N;
         {
@@ -311,7 +335,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ZMFMA4(acc_re[i][j], acc_im[i][j], a[i], b[j]);
         }
-        if (g.symmetrise) {
+        if (g.sym[t / Tb]) {
             double2 a[2], b[4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = C[128 + wm * 32 + i * 16];
@@ -361,18 +385,27 @@ int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, in
     return 1;
 }
 
-int launch_half2_hot(dmk_ctx *ctx, const void *Ut, const void *Cj, double *planes, long long naux, long long npair,
-                     int nL, int nao, int nemb, int symmetrise) {
-    if (!hot_enabled() || nemb != H2_N || (nao % H2_BK) != 0 || nao < 3 * H2_BK) return 0;
-    if ((reinterpret_cast<uintptr_t>(Ut) | reinterpret_cast<uintptr_t>(Cj)) & 15) return 0;
+int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
+                     const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb) {
+    if (!hot_enabled() || nemb != H2_N || (nao % H2_BK) != 0 || nao < 3 * H2_BK || nslot < 1 || nslot > H2_MAXSLOT)
+        return 0;
+    if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
     H2Args a;
     a.Ut = reinterpret_cast<const double2 *>(Ut);
-    a.Cj = reinterpret_cast<const double2 *>(Cj);
+    for (int i = 0; i < H2_MAXSLOT; ++i) {
+        a.Cj[i] = reinterpret_cast<const double2 *>(Cj[i < nslot ? i : 0]);
+        a.sym[i] = i < nslot ? sym[i] : 0;
+        if (reinterpret_cast<uintptr_t>(a.Cj[i]) & 15) return 0;
+    }
+    a.slot_stride = slot_stride;
     a.planes = planes; a.naux = naux; a.npair = npair;
-    a.nL = nL; a.nao = nao; a.symmetrise = symmetrise;
+    a.nL = nL; a.nao = nao; a.nslot = nslot;
     a.nblocks = (unsigned)(2 * nL);
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }
+
+int half2_hot_usable(int nao, int nemb) { return hot_enabled() && nemb == H2_N && (nao % H2_BK) == 0 && nao >= 3 * H2_BK; }
+int half2_hot_maxslot() { return H2_MAXSLOT; }

@@ -125,7 +125,7 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
     d_rhoR = fourier.fold_k2R_dev(d_rho.reshape(spin, nloc, n * n), sysm.mesh, spin, n * n,
                                   k_subset=None if world == 1 else kmine)
     t = _stage(ctx, timers, "fold_k2R", t)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce_sum_dev(d_rhoR)
         t = _stage(ctx, timers, "allreduce_rho", t)
     return d_rhoR, {"mu": mu, "ew": ew, "occ": ewocc}
@@ -196,7 +196,7 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
         if eri_dev is None:
             eri_dev = ctx.zeros((spin_pair, npair, npair), np.float64)
         nblk, fh, fc = eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list, timers, max_blocks_per_kL)
-        if allreduce_eri and dist.world_size() > 1:
+        if allreduce_eri and dist.is_initialized():
             t = time.perf_counter()
             dist.all_reduce_sum_dev(eri_dev)
             _stage(ctx, timers, "allreduce_eri", t)
