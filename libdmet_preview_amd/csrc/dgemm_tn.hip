@@ -7,6 +7,8 @@
 // stride along the tile edge": global rows stream straight into an LDS image
 // [k][m] with no transpose, and a fragment read is 16 consecutive doubles.
 //
+// Two kernels share the tiling; the LDS-DMA one at the bottom is the production path, the
+// register-staged one handles arbitrary K / odd sizes.
 // Tiling (CDNA4, wave64): 256 threads = 2 x 2 waves, workgroup tile 128 x 128,
 // wave tile 64 x 64 = 4 x 4 v_mfma_f64_16x16x4_f64 accumulators (128 VGPRs),
 // BK = 16, double-buffered LDS (2 x 2 x 16 x 144 x 8 B = 72 KiB -> 2 workgroups
@@ -149,30 +151,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_kernel(
 
 
 // ---------------------------------------------------------------------------------------------
-// "big" variant: 512-thread workgroup, 256 x 128 tile, LDS-DMA ring.
+// LDS-DMA variant (the production path for the ERI contraction).
 //
-// tools/mfma_f64_probe.hip: a register-resident v_mfma_f64_16x16x4_f64 stream sustains 77.5 TFLOP/s
-// (64.0 cycles per MFMA per SIMD).  rocprof PMC on the 128 x 128 kernel above: MFMA pipe 75 % busy,
-// 20 % of wave-cycles parked on memory waits, 31 GB fetched per launch against 9.5 GB algorithmic --
-// the scarce resource is the L2 -> LDS feed and its latency, not the matrix pipe.  So the eight waves
-// of a 512-thread workgroup (2 per SIMD, wave tile 64 x 64 = 16 accumulators in 128 VGPRs, no AGPR
-// traffic) share one 256 x 128 tile: half the L2 bytes per flop of two independent 128 x 128
-// workgroups.  Operands arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, the copy
-// engine writes LDS directly) into a 3-stage ring (3 x 52 KiB) issued two K-tiles ahead and retired
-// with a counted s_waitcnt vmcnt(6) plus ONE raw s_barrier per K-tile (BK = 16 -> 64 MFMAs = 4096
-// pipe cycles per wave between barriers).  LDS rows keep a 128-B-mod-256-B stride (A: 272, B: 144
-// doubles) so every ds_read_b64 lane group is conflict-free.  Out-of-range lanes re-read clamped valid
-// columns (their data only reaches masked outputs), so every wave issues exactly six loads per tile
-// and the vmcnt arithmetic holds.  Requires K % 16 == 0, even M, N, ldx, ldy and 16-B aligned bases;
-// anything else takes the kernel above.
-constexpr int GBM = 256, GBN = 128, GBK = 16, GD = 3, GNT = 512;
-constexpr int GA_LD = GBM + 16, GB_LD = GBN + 16;
-constexpr int GA_STAGE = GBK * GA_LD, GB_STAGE = GBK * GB_LD;      // doubles
-constexpr int G_STAGE = GA_STAGE + GB_STAGE;
+// Measurements that shaped it (tools/mfma_f64_probe.hip, tools/gemm_lab*.hip, MI355X):
+//   * a register-resident v_mfma_f64_16x16x4_f64 stream sustains 77.5 TFLOP/s (64.0 cycles / MFMA / SIMD);
+//   * the register-staged kernel above reaches 58 TF: PMC shows the pipe 75 % busy and 20 % of the
+//     wave cycles parked in s_waitcnt / s_barrier;
+//   * a 512-thread workgroup sharing a 256 x 128 tile (half the L2 bytes per flop) is NOT faster
+//     (60 TF): its two waves per SIMD run in barrier lock-step, so nobody covers the LDS latency
+//     after each barrier.  Two INDEPENDENT 256-thread workgroups per CU desynchronise by themselves;
+//   * read-modify-write of C in the epilogue costs 4-7 %: every C element has exactly one writer per
+//     launch (tiles are disjoint, launches are stream ordered), so a fire-and-forget f64 atomic gives
+//     the same deterministic sum without the HBM round trip.
+// Hence: 128 x 128 tile, 4 waves (wave tile 64 x 64, 16 accumulators in 128 VGPRs, no AGPR traffic),
+// BK = 16, operands by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a 2-stage ring
+// (2 x 36 KiB -> 2 workgroups per CU), one counted s_waitcnt vmcnt + ONE raw s_barrier per K-tile.
+// LDS rows keep the 128-B-mod-256-B stride (144 doubles).  Out-of-range lanes re-read clamped valid
+// columns (only masked outputs see them), so every wave issues exactly 8 loads per tile.
+// Lab, random operands, N = 32896, K = 1600: 67.6 TFLOP/s (87 % of the measured MFMA ceiling).
+// Requires K % 16 == 0, even M, N, ldx, ldy, 16-B aligned bases; otherwise the kernel above runs.
+constexpr int GBK = 16, GD = 2;
+constexpr int G_STAGE = 2 * GBK * LDS_LD;      // doubles per stage: A[16][144] | B[16][144]
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-__global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
+__global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
     int tiles_m, int tiles_n) {
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
 
     const unsigned nblocks = (unsigned)tiles_m * (unsigned)tiles_n;
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
-    constexpr unsigned GROUP = 4;
+    constexpr unsigned GROUP = 8;
     const unsigned per_group = GROUP * (unsigned)tiles_n;
     const unsigned g = lid / per_group;
     const unsigned first_m = g * GROUP;
@@ -188,27 +189,25 @@ __global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
     const unsigned in_g = lid - g * per_group;
     const int tm = (int)(first_m + in_g % gsize);
     const int tn = (int)(in_g / gsize);
-    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
-    int ca0 = m0 + 2 * lane, ca1 = m0 + 128 + 2 * lane, cb = n0 + 2 * lane;
-    if (ca0 + 1 >= M) ca0 = M - 2;
-    if (ca1 + 1 >= M) ca1 = M - 2;
+    int ca = m0 + 2 * lane, cb = n0 + 2 * lane;
+    if (ca + 1 >= M) ca = M - 2;
     if (cb + 1 >= N) cb = N - 2;
-    const double *pA0 = X + ca0, *pA1 = X + ca1, *pB = Y + cb;
+    const double *pA = X + ca, *pB = Y + cb;
 
-    auto issue = [&](int t) {
+    auto issue = [&](int t) {           // wave w streams K rows 4w .. 4w+3 of both operands
         double *st = lds + (t % GD) * G_STAGE;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int k = wave * 2 + r;
+        for (int r = 0; r < 4; ++r) {
+            const int k = wave * 4 + r;
             const int64_t kg = (int64_t)(t * GBK + k);
-            glds16(pA0 + kg * ldx, lds_addr_of(st + k * GA_LD));
-            glds16(pA1 + kg * ldx, lds_addr_of(st + k * GA_LD + 128));
-            glds16(pB + kg * ldy, lds_addr_of(st + GA_STAGE + k * GB_LD));
+            glds16(pA + kg * ldx, lds_addr_of(st + k * LDS_LD));
+            glds16(pB + kg * ldy, lds_addr_of(st + GBK * LDS_LD + k * LDS_LD));
         }
     };
 
@@ -220,21 +219,19 @@ __global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
 
     const int T = K / GBK;
     issue(0);
-    if (T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < T) issue(t + 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t has landed (nothing newer is in flight)
+        __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is done with tile t-1
+        if (t + 1 < T) issue(t + 1);                          // overwrite the stage tile t-1 lived in
         const double *Ab = lds + (t % GD) * G_STAGE + wm * 64 + frag_x;
-        const double *Bb = lds + (t % GD) * G_STAGE + GA_STAGE + wn * 64 + frag_x;
+        const double *Bb = lds + (t % GD) * G_STAGE + GBK * LDS_LD + wn * 64 + frag_x;
 #pragma unroll
         for (int kk = 0; kk < GBK / 4; ++kk) {
             double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = Ab[(kk * 4 + frag_k) * GA_LD + i * 16];
+            for (int i = 0; i < 4; ++i) a[i] = Ab[(kk * 4 + frag_k) * LDS_LD + i * 16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bb[(kk * 4 + frag_k) * GB_LD + j * 16];
+            for (int j = 0; j < 4; ++j) b[j] = Bb[(kk * 4 + frag_k) * LDS_LD + j * 16];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -253,9 +250,6 @@ __global__ __launch_bounds__(GNT, 2) void dgemm_tn_acc_big_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + frag_x;
-                // fire-and-forget f64 atomic instead of load-add-store: every C element has exactly ONE writer
-                // per launch (tiles are disjoint, launches are stream-ordered), so the sum is still deterministic,
-                // but the wave no longer sits out one HBM round trip per element row (lab: 60.1 -> 63.6 TF)
                 if (col < N) unsafeAtomicAdd(&crow[col], alpha * acc[i][j][r]);
             }
         }
@@ -273,13 +267,11 @@ int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const d
     const bool vec2 = ((ldx & 1) == 0) && ((ldy & 1) == 0) &&
                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
-    static const bool big_enabled = [] { const char *e = getenv("DMK_DGEMM_BIG"); return !(e && atoi(e) == 0); }();
-    if (big_enabled && vec2 && (K % GBK) == 0 && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2 &&
-        (int64_t)M * N >= 4 * GBM * GBN) {
-        const int btm = (M + GBM - 1) / GBM, btn = (N + GBN - 1) / GBN;
+    static const bool dma_enabled = [] { const char *e = getenv("DMK_DGEMM_DMA"); return !(e && atoi(e) == 0); }();
+    if (dma_enabled && vec2 && (K % GBK) == 0 && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2) {
         FamScope fs(ctx, DMK_FAM_DGEMM);
-        hipLaunchKernelGGL(dgemm_tn_acc_big_kernel, dim3((unsigned)(btm * btn)), dim3(GNT), 0, ctx->stream, M, N, K,
-                           alpha, X, ldx, Y, ldy, C, ldc, btm, btn);
+        hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel, dim3((unsigned)nblocks), dim3(NTHREADS), 0, ctx->stream, M, N, K,
+                           alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n);
         DMK_CHECK_LAUNCH(ctx);
         return DMK_OK;
     }

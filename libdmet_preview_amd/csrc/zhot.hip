@@ -6,26 +6,31 @@
 //           into the Re / Im planes of Lij_s4
 //   reference: basis_transform/eri_transform.py:368-378, 403-434
 //
-// Why a second implementation next to the generic zgemm.hip: rocprof PMC on the generic
-// 256-thread kernels showed the f64 matrix pipe only 56-62 % busy with 30-45 % of wave cycles
-// parked on memory waits, and cutting the MFMA count by 25 % (3M) changed nothing -- the half
-// transform was bound by the L2 -> LDS feed and its latency, not by the pipe
-// (tools/mfma_f64_probe.hip: 77.5 TFLOP/s is reachable from registers).  Hence:
-//   * 512-thread workgroups (8 waves, 2 per SIMD) share one large tile, so the L2 bytes per MFMA
-//     drop 2-3x;
-//   * operands arrive by LDS-DMA (global_load_lds_dwordx4) into a 4-stage ring, issued three
-//     K-tiles ahead and retired by a counted s_waitcnt vmcnt(N) + ONE raw s_barrier per K-tile;
-//     no staging registers, no scratch, so the counted waits are never drained by the compiler;
-//   * step 2 never computes a block above the diagonal AND keeps every wave busy: per L one
-//     workgroup takes the 128 x 128 off-diagonal square (8 blocks per wave), a second one takes
-//     the two 128 x 128 diagonal triangles with block rows paired (w, 7 - w) so that each wave
-//     owns exactly 9 of the 72 blocks; both segments of the symmetrised product read the SAME
-//     two LDS panels (U and C over all 256 columns), loaded once per K-tile.
-// Complex arithmetic is 4M (four real MFMAs per complex tile step, neg:[1,0,0] for Ai*Bi): the
-// 3M form needs 1.5x the accumulators and does not fit 2 waves/SIMD without spilling.
+// Why a second implementation next to the generic zgemm.hip (numbers: MI355X, rocprof PMC and the
+// ablation labs under tools/):
+//   * the generic register-staged kernels kept the f64 matrix pipe only 56-62 % busy with 30-45 % of
+//     the wave cycles parked in s_waitcnt / s_barrier, and cutting the MFMA count by 25 % (3M) changed
+//     nothing: the half transform was latency-bound on its operand feed, not pipe-bound
+//     (tools/mfma_f64_probe.hip: 77.5 TFLOP/s is reachable from registers);
+//   * operands therefore arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-4 stage ring, issued
+//     two to three K-tiles ahead and retired by a counted s_waitcnt vmcnt(N) + ONE raw s_barrier per
+//     K-tile; no staging registers, no scratch, so the counted waits are never drained by the compiler;
+//   * 256-thread workgroups, TWO per CU: a 512-thread workgroup sharing a larger tile halves the L2
+//     bytes per flop but runs its two waves per SIMD in barrier lock-step and measured 10 % slower
+//     than two independent workgroups that desynchronise by themselves (tools/gemm_lab*.hip);
+//   * step 2 never computes a 16 x 16 block above the diagonal AND keeps every wave equally loaded:
+//     per L four workgroups -- the two 64 x 128 halves of the off-diagonal square (8 blocks per wave)
+//     and the two 128 x 128 diagonal triangles with block rows paired (w, 7 - w) so that each wave owns
+//     exactly 9 of a triangle's 36 blocks; in a triangle both segments of the symmetrised product read
+//     the SAME two LDS panels;
+//   * step 2 runs straight through up to 16 queued AO blocks per launch: accumulators and the
+//     tril-pack epilogue are shared, and the epilogue uses fire-and-forget f64 atomics (exactly one
+//     writer per plane element per launch, so the sum stays deterministic).
+// Complex arithmetic is 4M (four real MFMAs per complex tile step, neg:[1,0,0] for Ai*Bi): the 3M form
+// needs 1.5x the accumulators and does not fit two waves per SIMD without spilling.
 //
-// Constraints (else the caller falls back to zgemm.hip): nao % 8 == 0, nemb == 256 for step 2
-// (nemb <= 256 and % 16 == 0 for step 1 tiles are masked), 16-B aligned operands.
+// Constraints (else the caller falls back to zgemm.hip): nao % 8 == 0, nemb == 256 for step 2,
+// 16-B aligned operands.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -38,8 +43,7 @@
 
 namespace {
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-constexpr int HNT = 512;
+constexpr int HNT = 256;
 
 #define ZMFMA4(ACC_RE, ACC_IM, A, B)                                                              \
     do {                                                                                          \
@@ -50,10 +54,10 @@ constexpr int HNT = 512;
     } while (0)
 
 // =============================================================================================
-// step 1: flattened M-blocks (batch L folded into M), tile 128 x 128, BK = 8, 4-stage ring
+// step 1: flattened M-blocks (batch L folded into M), tile 128 x 64, BK = 8, 3-stage ring (72 KiB)
 // =============================================================================================
-constexpr int H1_BM = 128, H1_BN = 128, H1_BK = 8, H1_D = 4;
-constexpr int H1_STAGE = H1_BK * (H1_BM + H1_BN);     // double2 elements per stage (32 KiB)
+constexpr int H1_BM = 128, H1_BN = 64, H1_BK = 8, H1_D = 3;
+constexpr int H1_STAGE = H1_BK * (H1_BM + H1_BN);     // double2 elements per stage (24 KiB)
 
 struct H1Args {
     const double2 *Lpq;    // [nL][nao][nao]   element (p, q) at p*nao + q
@@ -67,7 +71,7 @@ struct H1Args {
 __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     __shared__ __attribute__((aligned(16))) double2 lds[H1_D * H1_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;            // 2 (M) x 4 (N) waves, wave tile 64 x 32
+    const int wm = wave >> 1, wn = wave & 1;            // 2 (M) x 2 (N) waves, wave tile 64 x 32
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
@@ -75,28 +79,33 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     const int n0 = tile_n * H1_BN;
     const long long nao = g.nao, nemb = g.nemb;
 
-    // ---- per-lane LDS-DMA sources (this wave loads K-row `wave` of every tile: 2 A + 2 B instrs)
-    const double2 *srcA[2], *srcB[2];
+    // ---- per-lane LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB) ----
+    const double2 *srcA[2], *srcB;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int m = 64 * h + lane;
         const int gb = tile_m * (H1_BM / 16) + (m >> 4);
         int L = gb / g.nblk;
         int q = (gb - L * g.nblk) * 16 + (m & 15);
-        if (L >= g.nL) L = g.nL - 1;
+        if (L >= g.nL) L = g.nL - 1;                    // clamped lanes only ever feed masked outputs
         if (q >= g.nao) q = g.nao - 1;
-        srcA[h] = g.Lpq + (long long)L * nao * nao + q + (long long)wave * nao;
-        int col = n0 + 64 * h + lane;
+        srcA[h] = g.Lpq + (long long)L * nao * nao + q;
+    }
+    {
+        int col = n0 + lane;
         if (col >= g.nemb) col = g.nemb - 1;
-        srcB[h] = g.Ci + col + (long long)wave * nemb;
+        srcB = g.Ci + col;
     }
     auto issue = [&](int t) {
         double2 *st = lds + (t % H1_D) * H1_STAGE;
-        const long long k0 = (long long)t * H1_BK;
-        glds16(srcA[0] + k0 * nao, lds_addr_of(st + wave * H1_BM));
-        glds16(srcA[1] + k0 * nao, lds_addr_of(st + wave * H1_BM + 64));
-        glds16(srcB[0] + k0 * nemb, lds_addr_of(st + H1_BK * H1_BM + wave * H1_BN));
-        glds16(srcB[1] + k0 * nemb, lds_addr_of(st + H1_BK * H1_BM + wave * H1_BN + 64));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = wave * 2 + r;
+            const long long kg = (long long)t * H1_BK + k;
+            glds16(srcA[0] + kg * nao, lds_addr_of(st + k * H1_BM));
+            glds16(srcA[1] + kg * nao, lds_addr_of(st + k * H1_BM + 64));
+            glds16(srcB + kg * nemb, lds_addr_of(st + H1_BK * H1_BM + k * H1_BN));
+        }
     };
 
     d4_t acc_re[4][2], acc_im[4][2];
@@ -111,14 +120,11 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     const int T = g.nao / H1_BK;
     issue(0);
     if (T > 1) issue(1);
-    if (T > 2) issue(2);
     for (int t = 0; t < T; ++t) {
-        const int later = T - 1 - t;                    // tiles issued after tile t (at most 2 here)
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile t landed; tile t+1 may be in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-        if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
+        if (!(ZHOT_ABL & 1) && t + 2 < T) issue(t + 2);
         const double2 *Ab = lds + (t % H1_D) * H1_STAGE + wm * 64 + frag_x;
         const double2 *Bb = lds + (t % H1_D) * H1_STAGE + H1_BK * H1_BM + wn * 32 + frag_x;
 #pragma unroll
@@ -169,16 +175,20 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 }
 
 // =============================================================================================
-// step 2 (nemb == 256): per L two workgroups, both streaming the full-width U and C panels
+// step 2 (nemb == 256): per L four workgroups
+//   type 0 / 1 : rows [128,192) / [192,256) x cols [0,128) of the off-diagonal square (8 blocks / wave)
+//   type 2 / 3 : diagonal triangle [0,128)^2 / [128,256)^2, block rows (w, 7-w) per wave (9 blocks / wave)
 // =============================================================================================
-constexpr int H2_N = 256, H2_BK = 4, H2_D = 4;
-constexpr int H2_STAGE = H2_BK * 2 * H2_N;            // double2 per stage: U[4][256] | C[4][256] = 32 KiB
-
+constexpr int H2_N = 256, H2_BK = 4;
 constexpr int H2_MAXSLOT = 16;
+constexpr int H2S_STAGE = H2_BK * 384, H2S_D = 3;     // square: Ua[4][64] | Cb[4][128] | Ca[4][64] | Ub[4][128] (24 KiB)
+constexpr int H2T_STAGE = H2_BK * 256, H2T_D = 4;     // triangle: U[4][128] | C[4][128]                        (16 KiB)
+constexpr int H2_LDS = (H2S_STAGE * H2S_D > H2T_STAGE * H2T_D) ? H2S_STAGE * H2S_D : H2T_STAGE * H2T_D;
+
 struct H2Args {
     const double2 *Ut;     // [nslot][nL][nao][256]: step-1 outputs of `nslot` consecutive AO blocks
     const double2 *Cj[H2_MAXSLOT];   // [nao][256] of each block
-    int sym[H2_MAXSLOT];   // add the time-reversal partner term of that block?
+    unsigned symmask;      // bit s: add the time-reversal partner term of block s?
     long long slot_stride; // elements between the Ut of consecutive slots
     double *planes;        // [(ri * naux + L) * npair + pair]
     long long naux, npair;
@@ -186,15 +196,26 @@ struct H2Args {
     unsigned nblocks;
 };
 
-__device__ __forceinline__ void pack_acc(const H2Args &g, int L, int row, int col, double vr, double vi) {
+// Kernel-argument arrays must only be indexed with compile-time constants, and the argument struct must
+// never be passed by reference: either makes hipcc copy the whole struct to scratch (private memory), whose
+// loads need s_waitcnt vmcnt(0) -- draining the LDS-DMA ring -- and whose per-dispatch scratch set-up cost
+// ~17 ms per launch when this kernel first did it.
+#define H2_PICK_CJ(G, SLOT)                                                                        \
+    ((SLOT) == 0 ? (G).Cj[0] : (SLOT) == 1 ? (G).Cj[1] : (SLOT) == 2 ? (G).Cj[2] : (SLOT) == 3 ? (G).Cj[3]      \
+     : (SLOT) == 4 ? (G).Cj[4] : (SLOT) == 5 ? (G).Cj[5] : (SLOT) == 6 ? (G).Cj[6] : (SLOT) == 7 ? (G).Cj[7]    \
+     : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
+     : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
+
+__device__ __forceinline__ void pack_acc(double *planes, long long naux, long long npair, int L, int row, int col,
+                                         double vr, double vi) {
     if (ZHOT_ABL & 2) {
-        if (vr == 12345.678) g.planes[0] = vi;
+        if (vr == 12345.678) planes[0] = vi;
         return;
     }
     if (row >= col) {
         const long long idx = (long long)row * (row + 1) / 2 + col;
-        double *pr = g.planes + (long long)L * g.npair + idx;
-        double *pi = g.planes + (g.naux + (long long)L) * g.npair + idx;
+        double *pr = planes + (long long)L * npair + idx;
+        double *pi = planes + (naux + (long long)L) * npair + idx;
         // single writer per address per launch -> deterministic; no load latency in the epilogue
         unsafeAtomicAdd(pr, vr);
         unsafeAtomicAdd(pi, vi);
@@ -202,45 +223,40 @@ __device__ __forceinline__ void pack_acc(const H2Args &g, int L, int row, int co
 }
 
 __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
-    __shared__ __attribute__((aligned(16))) double2 lds[H2_D * H2_STAGE];
+    __shared__ __attribute__((aligned(16))) double2 lds[H2_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frag_k = lane >> 4, frag_x = lane & 15;
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
-    const int L = (int)(lid >> 1), type = (int)(lid & 1);
+    const int L = (int)(lid >> 2), type = (int)(lid & 3);
     const long long nemb = H2_N;
     const int Tb = g.nao / H2_BK;            // K-tiles per AO block
-    const int T = Tb * g.nslot;              // the ring runs straight through all queued blocks: the
-                                             // accumulators (and the epilogue) are shared by nslot blocks
-
-    // LDS-DMA sources: a stage is 16 pieces of 64 complex: pieces 0..3 = U row 0, ..., 12..15 = U row 3? no:
-    // layout U[4][256] then C[4][256]: piece p < 16 -> U row p / 4, cols 64 (p % 4); p >= 16 -> C likewise.
-    // 32 pieces per stage, 8 waves -> 4 per wave.
+    const int T = Tb * g.nslot;              // the ring runs straight through all queued blocks
     const double2 *Ubase = g.Ut + (long long)L * g.nao * nemb;
-    long long soff[4];       // per-lane element offset of this wave's four pieces inside a block's U or C panel
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const int piece = wave + 8 * h;                  // 0..31: pieces 0-15 = U rows 0-3, 16-31 = C rows 0-3
-        const int rowk = (piece & 15) >> 2, c0 = (piece & 3) * 64;
-        soff[h] = (long long)rowk * nemb + c0 + lane;
-    }
-    // pieces wave and wave + 8 are always U, wave + 16 and wave + 24 always C
-    auto issue_tile = [&](int tt) {
-        const int slot = tt / Tb, t = tt - slot * Tb;
-        double2 *st = lds + (tt % H2_D) * H2_STAGE;
-        const long long k0 = (long long)t * H2_BK * nemb;
-        const double2 *ub = Ubase + (long long)slot * g.slot_stride + k0;
-        const double2 *cb = g.Cj[slot] + k0;
-        glds16(ub + soff[0], lds_addr_of(st + (wave) * 64));
-        glds16(ub + soff[1], lds_addr_of(st + (wave + 8) * 64));
-        glds16(cb + soff[2], lds_addr_of(st + (wave + 16) * 64));
-        glds16(cb + soff[3], lds_addr_of(st + (wave + 24) * 64));
-    };
+    double *const g_planes = g.planes;
+    const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
+    const unsigned g_symmask = g.symmask;
 
-    if (type == 1) {
-        // ---- two diagonal 128 x 128 triangles: waves 0-3 -> [0,128), waves 4-7 -> [128,256) -----------
-        const int d0 = (wave >> 2) * 128;
-        // tri_body issues its own loads: give it the 4-piece source table through a 2-entry view per call
-        // (pieces wave and wave + 8 belong to U rows, wave + 16 / + 24 to C rows)
+    if (type >= 2) {
+        // ---------------- diagonal triangle [d0, d0+128)^2 ----------------------------------------
+        const int d0 = (type - 2) * 128;
+        // stage = 16 pieces of 64 complex: piece p < 8 -> U row p/2, half p%2 ; p >= 8 -> C likewise; 4 pieces per wave
+        long long soff[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int piece = wave + 4 * h;
+            soff[h] = (long long)((piece & 7) >> 1) * nemb + d0 + (piece & 1) * 64 + lane;
+        }
+        auto issue = [&](int tt) {
+            const int slot = tt / Tb, t = tt - slot * Tb;
+            double2 *st = lds + (tt % H2T_D) * H2T_STAGE;
+            const long long k0 = (long long)t * H2_BK * nemb;
+            const double2 *ub = Ubase + (long long)slot * g_slot_stride + k0;
+            const double2 *cb = H2_PICK_CJ(g, slot) + k0;
+            glds16(ub + soff[0], lds_addr_of(st + (wave) * 64));            // pieces 0-3: U
+            glds16(ub + soff[1], lds_addr_of(st + (wave + 4) * 64));        // pieces 4-7: U
+            glds16(cb + soff[2], lds_addr_of(st + (wave + 8) * 64));        // pieces 8-11: C
+            glds16(cb + soff[3], lds_addr_of(st + (wave + 12) * 64));       // pieces 12-15: C
+        };
         auto run = [&](auto tag) {
             constexpr int R1 = decltype(tag)::value;
             constexpr int R2 = 7 - R1;
@@ -249,7 +265,6 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             for (int c = 0; c <= R1; ++c) { re1[c] = d4_t{0.0, 0.0, 0.0, 0.0}; im1[c] = d4_t{0.0, 0.0, 0.0, 0.0}; }
 #pragma unroll
             for (int c = 0; c <= R2; ++c) { re2[c] = d4_t{0.0, 0.0, 0.0, 0.0}; im2[c] = d4_t{0.0, 0.0, 0.0, 0.0}; }
-            auto issue = issue_tile;
             issue(0);
             if (T > 1) issue(1);
             if (T > 2) issue(2);
@@ -260,9 +275,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
                 if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
-                const double2 *U = lds + (t % H2_D) * H2_STAGE + frag_k * H2_N + d0 + frag_x;
-                const double2 *C = U + H2_BK * H2_N;
-                {
+                const double2 *U = lds + (t % H2T_D) * H2T_STAGE + frag_k * 128 + frag_x;
+                const double2 *C = U + H2_BK * 128;
+                {   // segment 1: S[a][b] += U[q][a] C[q][b]
                     const double2 a1 = U[R1 * 16], a2 = U[R2 * 16];
                     double2 b[R2 + 1];
 #pragma unroll
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) ZMFMA4(re2[c], im2[c], a2, b[c]);
                 }
-                if (g.sym[t / Tb]) {
+                if ((g_symmask >> (t / Tb)) & 1u) {   // segment 2: S[a][b] += C[q][a] U[q][b]   (same two panels)
                     const double2 a1 = C[R1 * 16], a2 = C[R2 * 16];
                     double2 b[R2 + 1];
 #pragma unroll
@@ -287,12 +302,12 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             for (int r = 0; r < 4; ++r) {
                 const int row1 = d0 + R1 * 16 + frag_k + 4 * r, row2 = d0 + R2 * 16 + frag_k + 4 * r;
 #pragma unroll
-                for (int c = 0; c <= R1; ++c) pack_acc(g, L, row1, d0 + c * 16 + frag_x, re1[c][r], im1[c][r]);
+                for (int c = 0; c <= R1; ++c) pack_acc(g_planes, g_naux, g_npair, L, row1, d0 + c * 16 + frag_x, re1[c][r], im1[c][r]);
 #pragma unroll
-                for (int c = 0; c <= R2; ++c) pack_acc(g, L, row2, d0 + c * 16 + frag_x, re2[c][r], im2[c][r]);
+                for (int c = 0; c <= R2; ++c) pack_acc(g_planes, g_naux, g_npair, L, row2, d0 + c * 16 + frag_x, re2[c][r], im2[c][r]);
             }
         };
-        switch (wave & 3) {
+        switch (wave) {
             case 0: run(std::integral_constant<int, 0>{}); break;
             case 1: run(std::integral_constant<int, 1>{}); break;
             case 2: run(std::integral_constant<int, 2>{}); break;
@@ -301,8 +316,32 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         return;
     }
 
-    // ---- off-diagonal square: rows [128,256) x cols [0,128); waves 4 (M) x 2 (N), wave tile 32 x 64 ----
-    const int wm = wave >> 1, wn = wave & 1;
+    // ---------------- off-diagonal half square: rows [r0, r0+64) x cols [0,128) -------------------------
+    const int r0 = 128 + 64 * type;
+    const int wm = wave >> 1, wn = wave & 1;            // wave tile 32 x 64
+    // stage = 24 pieces of 64 complex: 0-3 Ua rows, 4-11 Cb (row*2+half), 12-15 Ca rows, 16-23 Ub (row*2+half)
+    long long soff[6];
+    int isC[6];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) {
+        const int piece = wave + 4 * h;
+        int row, col;
+        if (piece < 4) { row = piece; col = r0; isC[h] = 0; }
+        else if (piece < 12) { row = (piece - 4) >> 1; col = ((piece - 4) & 1) * 64; isC[h] = 1; }
+        else if (piece < 16) { row = piece - 12; col = r0; isC[h] = 1; }
+        else { row = (piece - 16) >> 1; col = ((piece - 16) & 1) * 64; isC[h] = 0; }
+        soff[h] = (long long)row * nemb + col + lane;
+    }
+    auto issue = [&](int tt) {
+        const int slot = tt / Tb, t = tt - slot * Tb;
+        double2 *st = lds + (tt % H2S_D) * H2S_STAGE;
+        const long long k0 = (long long)t * H2_BK * nemb;
+        const double2 *ub = Ubase + (long long)slot * g_slot_stride + k0;
+        const double2 *cb = H2_PICK_CJ(g, slot) + k0;
+#pragma unroll
+        for (int h = 0; h < 6; ++h)
+            glds16((isC[h] ? cb : ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+    };
     d4_t acc_re[2][4], acc_im[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -311,36 +350,34 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             acc_re[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
             acc_im[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
         }
-    auto issue = issue_tile;
     issue(0);
     if (T > 1) issue(1);
-    if (T > 2) issue(2);
     for (int t = 0; t < T; ++t) {
-        const int later = T - 1 - t;
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-        if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
-        const double2 *U = lds + (t % H2_D) * H2_STAGE + frag_k * H2_N + frag_x;
-        const double2 *C = U + H2_BK * H2_N;
+        if (!(ZHOT_ABL & 1) && t + 2 < T) issue(t + 2);
+        const double2 *Ua = lds + (t % H2S_D) * H2S_STAGE + frag_k * 64 + wm * 32 + frag_x;
+        const double2 *Cb = lds + (t % H2S_D) * H2S_STAGE + 256 + frag_k * 128 + wn * 64 + frag_x;
+        const double2 *Ca = Ua + 768;
+        const double2 *Ub = Cb + 768;
         {
             double2 a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = U[128 + wm * 32 + i * 16];
+            for (int i = 0; i < 2; ++i) a[i] = Ua[i * 16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = C[wn * 64 + j * 16];
+            for (int j = 0; j < 4; ++j) b[j] = Cb[j * 16];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ZMFMA4(acc_re[i][j], acc_im[i][j], a[i], b[j]);
         }
-        if (g.sym[t / Tb]) {
+        if ((g_symmask >> (t / Tb)) & 1u) {
             double2 a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = C[128 + wm * 32 + i * 16];
+            for (int i = 0; i < 2; ++i) a[i] = Ca[i * 16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = U[wn * 64 + j * 16];
+            for (int j = 0; j < 4; ++j) b[j] = Ub[j * 16];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -351,10 +388,10 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 128 + wm * 32 + i * 16 + frag_k + 4 * r;
+            const int row = r0 + wm * 32 + i * 16 + frag_k + 4 * r;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                pack_acc(g, L, row, wn * 64 + j * 16 + frag_x, acc_re[i][j][r], acc_im[i][j][r]);
+                pack_acc(g_planes, g_naux, g_npair, L, row, wn * 64 + j * 16 + frag_x, acc_re[i][j][r], acc_im[i][j][r]);
         }
 }
 
@@ -367,7 +404,7 @@ bool hot_enabled() {
 
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb) {
-    if (!hot_enabled() || (nao % H1_BK) != 0 || nao < 3 * H1_BK || nemb < 64 || (long long)nL * nao < 4 * H1_BM) return 0;
+    if (!hot_enabled() || (nao % H1_BK) != 0 || nao < 2 * H1_BK || nemb < 32 || (long long)nL * nao < 4 * H1_BM) return 0;
     if ((reinterpret_cast<uintptr_t>(Lpq) | reinterpret_cast<uintptr_t>(Ci) | reinterpret_cast<uintptr_t>(Ut)) & 15) return 0;
     H1Args a;
     a.Lpq = reinterpret_cast<const double2 *>(Lpq);
@@ -392,15 +429,16 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
     H2Args a;
     a.Ut = reinterpret_cast<const double2 *>(Ut);
+    a.symmask = 0;
     for (int i = 0; i < H2_MAXSLOT; ++i) {
         a.Cj[i] = reinterpret_cast<const double2 *>(Cj[i < nslot ? i : 0]);
-        a.sym[i] = i < nslot ? sym[i] : 0;
+        if (i < nslot && sym[i]) a.symmask |= 1u << i;
         if (reinterpret_cast<uintptr_t>(a.Cj[i]) & 15) return 0;
     }
     a.slot_stride = slot_stride;
     a.planes = planes; a.naux = naux; a.npair = npair;
     a.nL = nL; a.nao = nao; a.nslot = nslot;
-    a.nblocks = (unsigned)(2 * nL);
+    a.nblocks = (unsigned)(4 * nL);
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
