@@ -26,8 +26,8 @@
 //   * step 2 runs straight through up to 16 queued AO blocks per launch: accumulators and the
 //     tril-pack epilogue are shared, and the epilogue uses fire-and-forget f64 atomics (exactly one
 //     writer per plane element per launch, so the sum stays deterministic).
-// Complex arithmetic is 4M (four real MFMAs per complex tile step, neg:[1,0,0] for Ai*Bi): the 3M form
-// needs 1.5x the accumulators and does not fit two waves per SIMD without spilling.
+// Complex arithmetic is 3M (Karatsuba: three real MFMAs per complex tile step, see cmfma below); with LDS-DMA
+// there are no staging registers, so the 1.5x accumulator set still fits two waves per SIMD without spilling.
 //
 // Constraints (else the caller falls back to zgemm.hip): nao % 8 == 0, nemb == 256 for step 2,
 // 16-B aligned operands.
@@ -45,13 +45,61 @@ namespace {
 
 constexpr int HNT = 256;
 
-#define ZMFMA4(ACC_RE, ACC_IM, A, B)                                                              \
-    do {                                                                                          \
-        ACC_RE = __builtin_amdgcn_mfma_f64_16x16x4f64((A).x, (B).x, ACC_RE, 0, 0, 0);             \
-        ACC_IM = __builtin_amdgcn_mfma_f64_16x16x4f64((A).x, (B).y, ACC_IM, 0, 0, 0);             \
-        ACC_RE = __builtin_amdgcn_mfma_f64_16x16x4f64((A).y, (B).y, ACC_RE, 0, 0, 1);             \
-        ACC_IM = __builtin_amdgcn_mfma_f64_16x16x4f64((A).y, (B).x, ACC_IM, 0, 0, 0);             \
-    } while (0)
+// Complex 16 x 16 x 4 tile step on the real f64 MFMA.
+//   ZHOT_3M = 1 (default): Karatsuba "3M" -- T1 += Ar Br, T2 += Ai Bi, T3 += (Ar+Ai)(Br+Bi); Re = T1 - T2,
+//     Im = T3 - T1 - T2.  25 % fewer MFMAs than 4M for 1.5x the accumulator registers; with LDS-DMA there are
+//     no staging registers left in these kernels and the 24 accumulator tiles of a wave fit (254 VGPRs, no
+//     spill).  Normwise backward stable; the parity tests hold it to the same 1e-8 / 1e-10 budgets.
+//   ZHOT_3M = 0: 4M (neg:[1,0,0] supplies the minus sign of Ai Bi).
+#ifndef ZHOT_3M
+#define ZHOT_3M 1
+#endif
+struct cfrag { double2 v; double s; };      // operand fragment and (3M) re + im
+struct cacc {
+    d4_t p, q;                               // 4M: (Re, Im)   3M: (T1, T2)
+#if ZHOT_3M
+    d4_t t;                                  // 3M: T3
+#endif
+};
+__device__ __forceinline__ void cacc_zero(cacc &c) {
+    c.p = d4_t{0.0, 0.0, 0.0, 0.0};
+    c.q = d4_t{0.0, 0.0, 0.0, 0.0};
+#if ZHOT_3M
+    c.t = d4_t{0.0, 0.0, 0.0, 0.0};
+#endif
+}
+__device__ __forceinline__ cfrag cfrag_of(double2 v) {
+    cfrag f;
+    f.v = v;
+    f.s = v.x + v.y;
+    return f;
+}
+__device__ __forceinline__ void cmfma(cacc &c, const cfrag &a, const cfrag &b) {
+#if ZHOT_3M
+    c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.x, c.p, 0, 0, 0);
+    c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.y, c.q, 0, 0, 0);
+    c.t = __builtin_amdgcn_mfma_f64_16x16x4f64(a.s, b.s, c.t, 0, 0, 0);
+#else
+    c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.x, c.p, 0, 0, 0);
+    c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.y, c.q, 0, 0, 0);
+    c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.y, c.p, 0, 0, 1);
+    c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.x, c.q, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ double cacc_re(const cacc &c, int r) {
+#if ZHOT_3M
+    return c.p[r] - c.q[r];
+#else
+    return c.p[r];
+#endif
+}
+__device__ __forceinline__ double cacc_im(const cacc &c, int r) {
+#if ZHOT_3M
+    return (c.t[r] - c.p[r]) - c.q[r];
+#else
+    return c.q[r];
+#endif
+}
 
 // =============================================================================================
 // step 1: flattened M-blocks (batch L folded into M), tile 128 x 64, BK = 8, 3-stage ring (72 KiB)
@@ -108,14 +156,11 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         }
     };
 
-    d4_t acc_re[4][2], acc_im[4][2];
+    cacc acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            acc_re[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-            acc_im[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-        }
+        for (int j = 0; j < 2; ++j) cacc_zero(acc[i][j]);
 
     const int T = g.nao / H1_BK;
     issue(0);
@@ -129,18 +174,19 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         const double2 *Bb = lds + (t % H1_D) * H1_STAGE + H1_BK * H1_BM + wn * 32 + frag_x;
 #pragma unroll
         for (int kk = 0; kk < H1_BK / 4; ++kk) {
-            double2 a[4], b[2];
+            cfrag a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = Ab[(kk * 4 + frag_k) * H1_BM + i * 16];
+            for (int i = 0; i < 4; ++i) a[i] = cfrag_of(Ab[(kk * 4 + frag_k) * H1_BM + i * 16]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                b[j] = Bb[(kk * 4 + frag_k) * H1_BN + j * 16];
-                b[j].y = -b[j].y;                       // conj(C_i)
+                double2 v = Bb[(kk * 4 + frag_k) * H1_BN + j * 16];
+                v.y = -v.y;                             // conj(C_i)
+                b[j] = cfrag_of(v);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) ZMFMA4(acc_re[i][j], acc_im[i][j], a[i], b[j]);
+                for (int j = 0; j < 2; ++j) cmfma(acc[i][j], a[i], b[j]);
         }
     }
 
@@ -150,7 +196,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) s += acc_re[i][j][0] + acc_im[i][j][1] + acc_re[i][j][2] + acc_im[i][j][3];
+            for (int j = 0; j < 2; ++j) s += cacc_re(acc[i][j], 0) + cacc_im(acc[i][j], 1) + cacc_re(acc[i][j], 2) + cacc_im(acc[i][j], 3);
         if (s == 12345.678) g.Ut[tid].x = s;
         return;
     }
@@ -168,7 +214,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 32 + j * 16 + frag_x;
-                if (col < g.nemb) row[col] = make_double2(acc_re[i][j][r], acc_im[i][j][r]);
+                if (col < g.nemb) row[col] = make_double2(cacc_re(acc[i][j], r), cacc_im(acc[i][j], r));
             }
         }
     }
@@ -260,11 +306,11 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         auto run = [&](auto tag) {
             constexpr int R1 = decltype(tag)::value;
             constexpr int R2 = 7 - R1;
-            d4_t re1[R1 + 1], im1[R1 + 1], re2[R2 + 1], im2[R2 + 1];
+            cacc acc1[R1 + 1], acc2[R2 + 1];
 #pragma unroll
-            for (int c = 0; c <= R1; ++c) { re1[c] = d4_t{0.0, 0.0, 0.0, 0.0}; im1[c] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+            for (int c = 0; c <= R1; ++c) cacc_zero(acc1[c]);
 #pragma unroll
-            for (int c = 0; c <= R2; ++c) { re2[c] = d4_t{0.0, 0.0, 0.0, 0.0}; im2[c] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+            for (int c = 0; c <= R2; ++c) cacc_zero(acc2[c]);
             issue(0);
             if (T > 1) issue(1);
             if (T > 2) issue(2);
@@ -277,34 +323,34 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
                 const double2 *U = lds + (t % H2T_D) * H2T_STAGE + frag_k * 128 + frag_x;
                 const double2 *C = U + H2_BK * 128;
-                {   // segment 1: S[a][b] += U[q][a] C[q][b]
-                    const double2 a1 = U[R1 * 16], a2 = U[R2 * 16];
-                    double2 b[R2 + 1];
+                {   // segment 1: S[a][b] += U[q][a] C[q][b]   (one B fragment live at a time)
+                    const cfrag a1 = cfrag_of(U[R1 * 16]), a2 = cfrag_of(U[R2 * 16]);
 #pragma unroll
-                    for (int c = 0; c <= R2; ++c) b[c] = C[c * 16];
-#pragma unroll
-                    for (int c = 0; c <= R1; ++c) ZMFMA4(re1[c], im1[c], a1, b[c]);
-#pragma unroll
-                    for (int c = 0; c <= R2; ++c) ZMFMA4(re2[c], im2[c], a2, b[c]);
+                    for (int c = 0; c <= R2; ++c) {
+                        const cfrag b = cfrag_of(C[c * 16]);
+                        if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
+                        cmfma(acc2[c], a2, b);
+                    }
                 }
                 if ((g_symmask >> (t / Tb)) & 1u) {   // segment 2: S[a][b] += C[q][a] U[q][b]   (same two panels)
-                    const double2 a1 = C[R1 * 16], a2 = C[R2 * 16];
-                    double2 b[R2 + 1];
+                    const cfrag a1 = cfrag_of(C[R1 * 16]), a2 = cfrag_of(C[R2 * 16]);
 #pragma unroll
-                    for (int c = 0; c <= R2; ++c) b[c] = U[c * 16];
-#pragma unroll
-                    for (int c = 0; c <= R1; ++c) ZMFMA4(re1[c], im1[c], a1, b[c]);
-#pragma unroll
-                    for (int c = 0; c <= R2; ++c) ZMFMA4(re2[c], im2[c], a2, b[c]);
+                    for (int c = 0; c <= R2; ++c) {
+                        const cfrag b = cfrag_of(U[c * 16]);
+                        if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
+                        cmfma(acc2[c], a2, b);
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row1 = d0 + R1 * 16 + frag_k + 4 * r, row2 = d0 + R2 * 16 + frag_k + 4 * r;
 #pragma unroll
-                for (int c = 0; c <= R1; ++c) pack_acc(g_planes, g_naux, g_npair, L, row1, d0 + c * 16 + frag_x, re1[c][r], im1[c][r]);
+                for (int c = 0; c <= R1; ++c)
+                    pack_acc(g_planes, g_naux, g_npair, L, row1, d0 + c * 16 + frag_x, cacc_re(acc1[c], r), cacc_im(acc1[c], r));
 #pragma unroll
-                for (int c = 0; c <= R2; ++c) pack_acc(g_planes, g_naux, g_npair, L, row2, d0 + c * 16 + frag_x, re2[c][r], im2[c][r]);
+                for (int c = 0; c <= R2; ++c)
+                    pack_acc(g_planes, g_naux, g_npair, L, row2, d0 + c * 16 + frag_x, cacc_re(acc2[c], r), cacc_im(acc2[c], r));
             }
         };
         switch (wave) {
@@ -342,14 +388,11 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         for (int h = 0; h < 6; ++h)
             glds16((isC[h] ? cb : ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
     };
-    d4_t acc_re[2][4], acc_im[2][4];
+    cacc acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc_re[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-            acc_im[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-        }
+        for (int j = 0; j < 4; ++j) cacc_zero(acc[i][j]);
     issue(0);
     if (T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
@@ -362,26 +405,26 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         const double2 *Ca = Ua + 768;
         const double2 *Ub = Cb + 768;
         {
-            double2 a[2], b[4];
+            cfrag a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = Ua[i * 16];
+            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(Ua[i * 16]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Cb[j * 16];
+            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(Cb[j * 16]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ZMFMA4(acc_re[i][j], acc_im[i][j], a[i], b[j]);
+                for (int j = 0; j < 4; ++j) cmfma(acc[i][j], a[i], b[j]);
         }
         if ((g_symmask >> (t / Tb)) & 1u) {
-            double2 a[2], b[4];
+            cfrag a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = Ca[i * 16];
+            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(Ca[i * 16]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Ub[j * 16];
+            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(Ub[j * 16]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ZMFMA4(acc_re[i][j], acc_im[i][j], a[i], b[j]);
+                for (int j = 0; j < 4; ++j) cmfma(acc[i][j], a[i], b[j]);
         }
     }
 #pragma unroll
@@ -391,7 +434,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             const int row = r0 + wm * 32 + i * 16 + frag_k + 4 * r;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                pack_acc(g_planes, g_naux, g_npair, L, row, wn * 64 + j * 16 + frag_x, acc_re[i][j][r], acc_im[i][j][r]);
+                pack_acc(g_planes, g_naux, g_npair, L, row, wn * 64 + j * 16 + frag_x, cacc_re(acc[i][j], r), cacc_im(acc[i][j], r));
         }
 }
 
