@@ -173,22 +173,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_kernel(
 constexpr int GBK = 16, GD = 2;
 constexpr int G_STAGE = 2 * GBK * LDS_LD;      // doubles per stage: A[16][144] | B[16][144]
 
+// SYMM (X == Y, M == N): C is symmetric, so only tiles with tm >= tn are computed; an off-diagonal tile is
+// also added, transposed, to C[tn-tile][tm-tile] (still one writer per element).  Saves ~1/2 of the aa and bb
+// contractions, i.e. 1/3 of the UHF contraction work.
+template <bool SYMM>
 __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
-    int tiles_m, int tiles_n) {
+    int tiles_m, int tiles_n, unsigned nblocks) {
     __shared__ __attribute__((aligned(16))) double lds[GD * G_STAGE];
 
-    const unsigned nblocks = (unsigned)tiles_m * (unsigned)tiles_n;
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
-    constexpr unsigned GROUP = 8;
-    const unsigned per_group = GROUP * (unsigned)tiles_n;
-    const unsigned g = lid / per_group;
-    const unsigned first_m = g * GROUP;
-    const unsigned gsize = min((unsigned)tiles_m - first_m, GROUP);
-    const unsigned in_g = lid - g * per_group;
-    const int tm = (int)(first_m + in_g % gsize);
-    const int tn = (int)(in_g / gsize);
+    int tm, tn;
+    if (SYMM) {
+        // lid -> (tm, tn), tm >= tn, row-major over the lower triangle
+        unsigned r = (unsigned)((sqrt(8.0 * (double)lid + 1.0) - 1.0) * 0.5);
+        while ((unsigned long long)r * (r + 1) / 2 > lid) --r;
+        while ((unsigned long long)(r + 1) * (r + 2) / 2 <= lid) ++r;
+        tm = (int)r;
+        tn = (int)(lid - (unsigned long long)r * (r + 1) / 2);
+    } else {
+        constexpr unsigned GROUP = 8;
+        const unsigned per_group = GROUP * (unsigned)tiles_n;
+        const unsigned g = lid / per_group;
+        const unsigned first_m = g * GROUP;
+        const unsigned gsize = min((unsigned)tiles_m - first_m, GROUP);
+        const unsigned in_g = lid - g * per_group;
+        tm = (int)(first_m + in_g % gsize);
+        tn = (int)(in_g / gsize);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -250,7 +263,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = n0 + wn * 64 + j * 16 + frag_x;
-                if (col < N) unsafeAtomicAdd(&crow[col], alpha * acc[i][j][r]);
+                if (col < N) {
+                    unsafeAtomicAdd(&crow[col], alpha * acc[i][j][r]);
+                    if (SYMM && tm != tn) unsafeAtomicAdd(&C[(int64_t)col * ldc + row], alpha * acc[i][j][r]);
+                }
             }
         }
     }
@@ -269,9 +285,16 @@ int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const d
                       ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
     static const bool dma_enabled = [] { const char *e = getenv("DMK_DGEMM_DMA"); return !(e && atoi(e) == 0); }();
     if (dma_enabled && vec2 && (K % GBK) == 0 && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2) {
+        static const bool symm_enabled = [] { const char *e = getenv("DMK_DGEMM_SYMM"); return !(e && atoi(e) == 0); }();
         FamScope fs(ctx, DMK_FAM_DGEMM);
-        hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel, dim3((unsigned)nblocks), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                           alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n);
+        if (symm_enabled && X == Y && ldx == ldy && M == N && tiles_m >= 2) {
+            const int64_t ntri = (int64_t)tiles_m * (tiles_m + 1) / 2;
+            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<true>, dim3((unsigned)ntri), dim3(NTHREADS), 0, ctx->stream, M, N, K,
+                               alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n, (unsigned)ntri);
+        } else {
+            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<false>, dim3((unsigned)nblocks), dim3(NTHREADS), 0, ctx->stream, M, N, K,
+                               alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n, (unsigned)nblocks);
+        }
         DMK_CHECK_LAUNCH(ctx);
         return DMK_OK;
     }

@@ -39,7 +39,38 @@ def pmc(db):
     print()
 
 
+FAMILY = [("dgemm_tn_acc", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"),
+          ("philox_block", "philox"), ("eigh_kernel", "eigh")]
+
+
+def traffic_json(dbs, out):
+    """HBM bytes per launch per kernel family: FETCH_SIZE (x2 gfx950 correction for wide coalesced streams) + WRITE_SIZE."""
+    import json
+    acc = {}
+    for db in dbs:
+        con = sqlite3.connect(db)
+        for n, cn, c, a in con.execute("select name, counter_name, count(*), avg(counter_value) from pmc_events "
+                                       "group by name, counter_name"):
+            if cn not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            for key, fam in FAMILY:
+                if key in n:
+                    e = acc.setdefault(fam, {"launches_sampled": 0})
+                    e[cn + "_KiB_per_launch"] = a
+                    e["launches_sampled"] = max(e["launches_sampled"], c)
+    for fam, e in acc.items():
+        f = e.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024 * 2.0
+        w = e.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
+        e["hbm_bytes_per_launch"] = f + w
+        e["note"] = "FETCH_SIZE x2 (gfx950 counts 1/2 of a wide coalesced stream) + WRITE_SIZE, separate --pmc passes"
+    json.dump(acc, open(out, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    stats(sys.argv[1])
-    for d in sys.argv[2:]:
+    args = sys.argv[1:]
+    if args and args[0] == "--traffic-json":
+        traffic_json(args[2:], args[1])
+        sys.exit(0)
+    stats(args[0])
+    for d in args[1:]:
         pmc(d)
