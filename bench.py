@@ -194,8 +194,11 @@ def main():
         # (0.75x) and pad to 16-row blocks (step 1: ceil(nao/16)*16/nao; step 2: 136 of 128.5 blocks); DESIGN.md section 4
         hot = (nemb == 256 and sysm.nao % 8 == 0)
         pad1 = (-(-sysm.nao // 16) * 16) / float(sysm.nao)
+        tl = -(-npair // 128)                                   # contraction tiles per side
+        symm = (tl * (tl + 1) / 2.0) / float(tl * tl)           # aa / bb launches compute the lower tile triangle only
+        dg = (symm + 1.0 + symm) / 3.0 if sysm.spin == 2 else symm
         exec_ratio = {"zgemm_half1": 0.75 * pad1 if hot else 1.0, "zgemm_half2": 0.75 * (136 * 256.0 / npair) if hot else 1.25,
-                      "dgemm": 1.0}
+                      "dgemm": dg if (sysm.naux % 16 == 0 and npair % 2 == 0) else 1.0}
         for k, rr in exec_ratio.items():
             if k in fam_out:
                 fam_out[k]["executed_mfma_tflops"] = round(fam_out[k]["tflops"] * rr, 2)
