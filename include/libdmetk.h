@@ -235,6 +235,30 @@ int dmk_eri_restore(dmk_ctx *ctx, int nemb, int symmetry, const double *eri4, do
 int dmk_dgemm_tn_acc(dmk_ctx *ctx, int N, int K, double alpha, const double *X,
                      const double *Y, int64_t ldxy, double *C, int64_t ldc);
 
+/* Rectangular form of the real contraction: C (M x N, ldc) += alpha * X^T Y, X: K x M (ldx), Y: K x N (ldy).
+ * Used for the overlap S = A^T B of dmet/HubPhSymm.py:39 (basisMatching) and the particle weights of
+ * routine/bcs.py:92. */
+int dmk_dgemm_tn_acc_rect(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X, int64_t ldx,
+                          const double *Y, int64_t ldy, double *C, int64_t ldc);
+/* Full SVD of a small square matrix A = U diag(sigma) Vt (one-sided Jacobi, n <= 84; sigma descending;
+ * columns of U belonging to exactly zero singular values are returned as zero).  Replaces
+ * scipy.linalg.svd at dmet/HubPhSymm.py:42. */
+int dmk_svd_small(dmk_ctx *ctx, int n, const double *A, double *sigma, double *U, double *Vt);
+/* C (M x N) = A (M x K) op(B), row-major f64, tall-skinny times small (basis rotations A' = A u, B' = B vt^T of
+ * dmet/HubPhSymm.py:46-47; slater.py:76-77).  transB != 0: B is stored N x K and used transposed. */
+int dmk_dgemm_nn_small(dmk_ctx *ctx, int64_t M, int N, int K, const double *A, const double *B, int transB,
+                       double *C);
+/* Particle weight of Nambu bath columns, routine/bcs.py:92: U viewed as (ncell, period, nb);
+ * w[j] = sum_{c, p < keep} U[c][p][j]^2. */
+int dmk_bcs_weight(dmk_ctx *ctx, int ncell, int period, int keep, int nb, const double *U, double *w);
+/* BCS embedding basis assembly, routine/bcs.py:88-103: basis (2, ncells, 2n, n+nval) from the left singular
+ * vectors U ((ncells-1)*2n x 2nval) and the weight ordering order[2nval] (device int32). */
+int dmk_bcs_assemble(dmk_ctx *ctx, int ncells, int n, int nval, const double *U, const int *order, double *basis);
+/* out (batch, r_out, c_out) = zero padded in (batch, r_in, c_in): unit ERI -> embedding ERI container,
+ * routine/slater_helper.py:494-518 (unit2emb). */
+int dmk_pad_block_f64(dmk_ctx *ctx, int batch, int64_t r_in, int64_t c_in, const double *in, int64_t r_out,
+                      int64_t c_out, double *out);
+
 #ifdef __cplusplus
 }
 #endif

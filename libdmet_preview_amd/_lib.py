@@ -68,6 +68,12 @@ PROTOTYPES = {
     "dmk_df_block_philox": (c_int, [c_vp, C.c_uint64, c_int, c_int, c_int, c_int, c_vp]),
     "dmk_eri_restore": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_dgemm_tn_acc": (c_int, [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_i64, c_vp, c_i64]),
+    "dmk_dgemm_tn_acc_rect": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]),
+    "dmk_svd_small": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_dgemm_nn_small": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "dmk_bcs_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "dmk_bcs_assemble": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dmk_pad_block_f64": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

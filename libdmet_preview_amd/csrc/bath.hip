@@ -159,19 +159,24 @@ __global__ __launch_bounds__(NT) void q_apply_kernel(int nrows, int nb, int nc, 
 
 // One-sided Jacobi SVD of the upper-triangular R (top nb x nb of A).  One workgroup.
 // Output: sigma (descending), Utop (nb x nb row-major, column j <-> sigma[j]).
+// upper_only: the input is an R factor (entries below the diagonal are ignored).  Vt_out (optional):
+// right singular vectors, row j <-> sigma[j]; needs a second LDS image.
 __global__ __launch_bounds__(NT) void jacobi_svd_kernel(int nb, const double *__restrict__ A, int lda,
                                                         double *__restrict__ sigma, double *__restrict__ Utop,
-                                                        int *__restrict__ status) {
+                                                        int *__restrict__ status, int upper_only,
+                                                        double *__restrict__ Vt_out) {
     extern __shared__ double sh[];
     const int N = nb + (nb & 1);              // padded to even
     const int ld = nb + 1;                    // column stride (odd: conflict-free column walks)
     double *G = sh;                           // [N][ld] column-major: G[j*ld + i] = R[i][j]
     double *nrm = G + (size_t)N * ld;         // [N]
+    double *V = nrm + N;                      // [N][ld] (only when Vt_out != nullptr)
     __shared__ int s_rot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = threadIdx.x; t < N * ld; t += NT) {
         const int j = t / ld, i = t % ld;
-        G[t] = (j < nb && i < nb && i <= j) ? A[(long long)i * lda + j] : 0.0;
+        G[t] = (j < nb && i < nb && (!upper_only || i <= j)) ? A[(long long)i * lda + j] : 0.0;
+        if (Vt_out) V[t] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
     const double eps = 2.220446049250313e-16;
@@ -200,6 +205,11 @@ __global__ __launch_bounds__(NT) void jacobi_svd_kernel(int nb, const double *__
                         const double gp = G[p * ld + i], gq = G[q * ld + i];
                         G[p * ld + i] = cs * gp - sn * gq;
                         G[q * ld + i] = sn * gp + cs * gq;
+                        if (Vt_out) {
+                            const double vp = V[p * ld + i], vq = V[q * ld + i];
+                            V[p * ld + i] = cs * vp - sn * vq;
+                            V[q * ld + i] = sn * vp + cs * vq;
+                        }
                     }
                     if (lane == 0) atomicAdd(&s_rot, 1);
                 }
@@ -226,6 +236,85 @@ __global__ __launch_bounds__(NT) void jacobi_svd_kernel(int nb, const double *__
         sigma[rk] = sj;
         const double inv = sj > 0.0 ? 1.0 / sj : 0.0;
         for (int i = 0; i < nb; ++i) Utop[(long long)i * nb + rk] = G[j * ld + i] * inv;
+        if (Vt_out)
+            for (int i = 0; i < nb; ++i) Vt_out[(long long)rk * nb + i] = V[j * ld + i];
+    }
+}
+
+// C (M x N) = A (M x K) op(B), row-major f64, small K and N (tall-skinny times small);
+// op(B) = B (K x N) or, with transB, B^T with B stored N x K
+__global__ void rowmat_small_kernel(long long M, int N, int K, const double *__restrict__ A, const double *__restrict__ B,
+                                    int transB, double *__restrict__ C) {
+    const long long total = M * N;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t / N;
+        const int c = (int)(t % N);
+        double s = 0.0;
+        if (transB)
+            for (int k = 0; k < K; ++k) s += A[r * K + k] * B[(long long)c * K + k];
+        else
+            for (int k = 0; k < K; ++k) s += A[r * K + k] * B[(long long)k * N + c];
+        C[t] = s;
+    }
+}
+
+// particle weight of the Nambu bath columns (routine/bcs.py:92): w[j] = sum_{c, p < keep} U[c][p][j]^2,
+// U viewed as (ncell, period, nb); one workgroup per column, fixed-order reduction
+__global__ __launch_bounds__(NT) void bcs_weight_kernel(int ncell, int period, int keep, int nb,
+                                                        const double *__restrict__ U, double *__restrict__ w) {
+    __shared__ double red[NWAVE];
+    const int j = blockIdx.x;
+    double s = 0.0;
+    const int rows = ncell * keep;
+    for (int t = threadIdx.x; t < rows; t += NT) {
+        const int c = t / keep, p = t % keep;
+        const double v = U[((long long)c * period + p) * nb + j];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < NWAVE; ++i) tot += red[i];
+        w[j] = tot;
+    }
+}
+
+// routine/bcs.py:88-103: basis (2, ncells, 2n, n + nval);  identity on the impurity block of cell 0,
+// alpha bath = columns order[:nval] of U, beta bath = columns order[nval:] with the particle / hole halves swapped
+__global__ void bcs_assemble_kernel(int ncells, int n, int nval, const double *__restrict__ U,
+                                    const int *__restrict__ order, double *__restrict__ basis) {
+    const int ncol = n + nval, n2 = 2 * n, nb = 2 * nval;
+    const long long total = 2LL * ncells * n2 * ncol;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(t % ncol);
+        const int r = (int)((t / ncol) % n2);
+        const int c = (int)((t / ((long long)ncol * n2)) % ncells);
+        const int s = (int)(t / ((long long)ncol * n2 * ncells));
+        double v = 0.0;
+        if (c == 0) {
+            v = (col < n && r == col) ? 1.0 : 0.0;
+        } else if (col >= n) {
+            const int j = col - n;
+            const int src_r = (s == 0) ? r : (r + n) % n2;
+            const int src_c = order[s == 0 ? j : nval + j];
+            v = U[((long long)(c - 1) * n2 + src_r) * nb + src_c];
+        }
+        basis[t] = v;
+    }
+}
+
+// out (batch, r_out, c_out) = zero-padded copy of in (batch, r_in, c_in)   (slater_helper.py:517-518)
+__global__ void pad_block_kernel(int batch, long long r_in, long long c_in, const double *__restrict__ in,
+                                 long long r_out, long long c_out, double *__restrict__ out) {
+    const long long total = (long long)batch * r_out * c_out;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long c = t % c_out, r = (t / c_out) % r_out, b = t / (c_out * r_out);
+        out[t] = (r < r_in && c < c_in) ? in[(b * r_in + r) * c_in + c] : 0.0;
     }
 }
 
@@ -345,7 +434,8 @@ int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1, c
         if (lds > 48 * 1024)
             DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_svd_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(jacobi_svd_kernel, dim3(1), dim3(NT), lds, ctx->stream, nb, A, nb, sigma, Utop, status);
+        hipLaunchKernelGGL(jacobi_svd_kernel, dim3(1), dim3(NT), lds, ctx->stream, nb, A, nb, sigma, Utop, status, 1,
+                           (double *)nullptr);
         DMK_CHECK_LAUNCH(ctx);
     }
     // U = Q [Utop; 0]
@@ -417,6 +507,80 @@ int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath
     cleanup();
     if (le != hipSuccess) return dmk_fail(ctx, DMK_ERR_HIP, "bath_assemble: launch failed: %s", hipGetErrorString(le));
     return rc;
+}
+
+
+int dmk_svd_small(dmk_ctx *ctx, int n, const double *A, double *sigma, double *U, double *Vt) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n <= 0 || !A || !sigma || !U || !Vt) return dmk_fail(ctx, DMK_ERR_INVALID, "svd_small: bad arguments");
+    if (n > 84) return dmk_fail(ctx, DMK_ERR_INVALID, "svd_small: n = %d exceeds the supported maximum of 84", n);
+    FamScope fs(ctx, DMK_FAM_BATH);
+    void *ws = nullptr;
+    int rc = dmk_scratch(ctx, 256, &ws);
+    if (rc) return rc;
+    int *status = reinterpret_cast<int *>(ws);
+    DMK_HIP(ctx, hipMemsetAsync(status, 0, sizeof(int), ctx->stream));
+    const int N = n + (n & 1);
+    const size_t lds = (2 * (size_t)N * (n + 1) + N) * sizeof(double);
+    if (lds > 48 * 1024)
+        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(jacobi_svd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(jacobi_svd_kernel, dim3(1), dim3(NT), lds, ctx->stream, n, A, n, sigma, U, status, 0, Vt);
+    DMK_CHECK_LAUNCH(ctx);
+    int st = 0;
+    DMK_HIP(ctx, hipMemcpyAsync(&st, status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "svd_small: Jacobi SVD did not converge");
+    return DMK_OK;
+}
+
+int dmk_dgemm_nn_small(dmk_ctx *ctx, int64_t M, int N, int K, const double *A, const double *B, int transB,
+                       double *C) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (M < 0 || N <= 0 || K <= 0 || !A || !B || !C) return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_nn_small: bad arguments");
+    if (M == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_MISC);
+    const int blocks = (int)std::min<long long>((M * N + 255) / 256, 8192);
+    hipLaunchKernelGGL(rowmat_small_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (long long)M, N, K, A, B, transB, C);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_bcs_weight(dmk_ctx *ctx, int ncell, int period, int keep, int nb, const double *U, double *w) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (ncell < 0 || period <= 0 || keep < 0 || keep > period || nb <= 0 || !U || !w)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "bcs_weight: bad arguments");
+    FamScope fs(ctx, DMK_FAM_BATH);
+    hipLaunchKernelGGL(bcs_weight_kernel, dim3(nb), dim3(NT), 0, ctx->stream, ncell, period, keep, nb, U, w);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_bcs_assemble(dmk_ctx *ctx, int ncells, int n, int nval, const double *U, const int *order, double *basis) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (ncells <= 0 || n <= 0 || nval <= 0 || nval > n || !U || !order || !basis)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "bcs_assemble: bad arguments");
+    FamScope fs(ctx, DMK_FAM_BATH);
+    const long long total = 2LL * ncells * 2 * n * (n + nval);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(bcs_assemble_kernel, dim3(blocks), dim3(256), 0, ctx->stream, ncells, n, nval, U, order, basis);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_pad_block_f64(dmk_ctx *ctx, int batch, int64_t r_in, int64_t c_in, const double *in, int64_t r_out,
+                      int64_t c_out, double *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (batch < 0 || r_in < 0 || c_in < 0 || r_out < r_in || c_out < c_in || !in || !out)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "pad_block: bad arguments");
+    const long long total = (long long)batch * r_out * c_out;
+    if (total == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_MISC);
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(pad_block_kernel, dim3(blocks), dim3(256), 0, ctx->stream, batch, (long long)r_in, (long long)c_in,
+                       in, (long long)r_out, (long long)c_out, out);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
 }
 
 }  // extern "C"

@@ -536,6 +536,13 @@ int dmk_dgemm_tn_acc(dmk_ctx *ctx, int N, int K, double alpha, const double *X, 
     return launch_dgemm_tn_acc(ctx, N, N, K, alpha, X, ldxy, Y, ldxy, C, ldc);
 }
 
+int dmk_dgemm_tn_acc_rect(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X, int64_t ldx,
+                          const double *Y, int64_t ldy, double *C, int64_t ldc) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (M < 0 || N < 0 || K < 0 || !X || !Y || !C) return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_tn_acc_rect: bad arguments");
+    return launch_dgemm_tn_acc(ctx, M, N, K, alpha, X, ldx, Y, ldy, C, ldc);
+}
+
 int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out) {
     if (!ctx) return DMK_ERR_INVALID;
     if (naux <= 0 || nao <= 0 || !out || ki < 0 || kj < 0) return dmk_fail(ctx, DMK_ERR_INVALID, "df_block_philox: bad arguments");

@@ -1,0 +1,40 @@
+"""
+The hot-path piece of libdmet/dmet/HubPhSymm.py: basisMatching (:37-48), the rotation of the alpha and
+beta bath orbitals of a UHF Schmidt basis to maximal overlap.
+
+    S = A^T B  (dmk_dgemm_tn_acc_rect, K = ncells * nlo)      S = u gamma vt  (dmk_svd_small, Jacobi in LDS)
+    A' = A u,  B' = B vt^T                                    (dmk_dgemm_nn_small)
+"""
+import numpy as np
+
+from libdmet_preview_amd._lib import lib, get_ctx
+from libdmet_preview_amd.utils import logger as log
+
+
+def basis_matching_dev(ctx, d_A, d_B, nrow, nb):
+    """Device form: d_A, d_B (nrow, nb) f64 -> (d_A', d_B', gamma numpy)."""
+    d_S = ctx.zeros((nb, nb), np.float64)
+    ctx.check(lib.dmk_dgemm_tn_acc_rect(ctx.h, nb, nb, int(nrow), 1.0, d_A.ptr, nb, d_B.ptr, nb, d_S.ptr, nb))
+    d_g = ctx.empty((nb,), np.float64)
+    d_u = ctx.empty((nb, nb), np.float64)
+    d_vt = ctx.empty((nb, nb), np.float64)
+    ctx.check(lib.dmk_svd_small(ctx.h, nb, d_S.ptr, d_g.ptr, d_u.ptr, d_vt.ptr))
+    d_A2 = ctx.empty((nrow, nb), np.float64)
+    d_B2 = ctx.empty((nrow, nb), np.float64)
+    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, int(nrow), nb, nb, d_A.ptr, d_u.ptr, 0, d_A2.ptr))
+    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, int(nrow), nb, nb, d_B.ptr, d_vt.ptr, 1, d_B2.ptr))
+    return d_A2, d_B2, d_g.get()
+
+
+def basisMatching(basis):
+    basis = np.asarray(basis, dtype=np.float64)
+    assert basis.shape[0] == 2 and basis.ndim == 4
+    _, ncells, nlo, nb = basis.shape
+    ctx = get_ctx()
+    d_A = ctx.to_device(basis[0].reshape(ncells * nlo, nb))
+    d_B = ctx.to_device(basis[1].reshape(ncells * nlo, nb))
+    d_A2, d_B2, gamma = basis_matching_dev(ctx, d_A, d_B, ncells * nlo, nb)
+    log.result("overlap statistics:\n larger than 0.9: %3d  smaller than 0.9: %3d\n"
+               " average: %10.6f  min: %10.6f",
+               np.sum(gamma > 0.9), np.sum(gamma < 0.9), np.average(gamma), np.min(gamma))
+    return np.asarray([d_A2.get().reshape(ncells, nlo, nb), d_B2.get().reshape(ncells, nlo, nb)])

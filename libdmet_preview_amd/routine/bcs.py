@@ -1,0 +1,134 @@
+"""
+BCS (Nambu) embedding basis with the reference's entry point (libdmet/routine/bcs.py:25-135):
+
+  embBasis(lattice, GRho, local=True)     projective bath  (:33-107, the branch without "sites")
+  embBasis(lattice, GRho, local=False)    quasiparticle bath, Phys. Rev. B 93, 035126 (:109-135)
+
+The projective bath is the Slater Schmidt step on the generalised density matrix: GRho is treated as
+the stripe of a lattice with 2*nscsites orbitals per cell, so the env x imp block is gathered and
+factorised by dmk_bath_svd exactly like routine/slater.py; the particle weights (:92) and the
+alpha / beta column assignment (:93-103) run in dmk_bcs_weight / dmk_bcs_assemble.
+"""
+import numpy as np
+
+from libdmet_preview_amd._lib import lib, get_ctx
+from libdmet_preview_amd.routine.bcs_helper import *          # noqa: F401,F403  (reference re-exports them)
+from libdmet_preview_amd.routine.slater import bath_svd_dev
+from libdmet_preview_amd.utils import logger as log
+
+
+def embBasis(lattice, GRho, local=True, **kwargs):
+    if local:
+        return _embBasis_proj(lattice, GRho, **kwargs)
+    else:
+        return _embBasis_phsymm(lattice, GRho, **kwargs)
+
+
+get_emb_basis = embBasis
+
+
+def emb_basis_proj_dev(ctx, kmesh, ncells, nscsites, val_idx, d_GRho):
+    """Device form: d_GRho (ncells, 2n, 2n) f64 -> d_basis (2, ncells, 2n, n+nval), sigma, w, order, d_U."""
+    n, nval = int(nscsites), len(val_idx)
+    nenv, nb = (ncells - 1) * 2 * n, 2 * nval
+    cols = np.asarray(list(val_idx) + [i + n for i in val_idx], dtype=np.int32)
+    env = np.arange(2 * n, 2 * n * ncells, dtype=np.int32)
+    d_sigma, d_U = bath_svd_dev(ctx, kmesh, 2 * n, d_GRho, ctx.to_device(env), nenv, ctx.to_device(cols), nb)
+    d_w = ctx.empty((nb,), np.float64)
+    ctx.check(lib.dmk_bcs_weight(ctx.h, ncells - 1, 2 * n, n, nb, d_U.ptr, d_w.ptr))
+    w = d_w.get()
+    order = np.argsort(w, kind='mergesort')[::-1]
+    d_basis = ctx.empty((2, ncells, 2 * n, n + nval), np.float64)
+    ctx.check(lib.dmk_bcs_assemble(ctx.h, int(ncells), n, nval, d_U.ptr,
+                                   ctx.to_device(np.ascontiguousarray(order, dtype=np.int32)).ptr, d_basis.ptr))
+    return d_basis, d_sigma.get(), w, order, d_U
+
+
+def _embBasis_proj(lattice, GRho, **kwargs):
+    ncells, nscsites, nval = lattice.ncells, lattice.nscsites, lattice.nval
+    if "sites" in kwargs:
+        # the reference's "sites" branch reads an undefined name (bcs.py:44-45) and cannot run
+        raise NotImplementedError('keyword "sites" is not supported')
+    if kwargs.get("localize_bath", None) is not None:
+        raise NotImplementedError("localize_bath is outside the HIP path")
+    GRho = np.ascontiguousarray(np.asarray(GRho).real, dtype=np.float64)
+    log.eassert(GRho.shape == (ncells, 2 * nscsites, 2 * nscsites), "GRho must be (ncells, 2*nscsites, 2*nscsites)")
+    ctx = get_ctx()
+    d_basis, sigma, w, order, d_U = emb_basis_proj_dev(ctx, lattice.kmesh, ncells, nscsites, lattice.val_idx,
+                                                       ctx.to_device(GRho))
+    log.debug(0, "Zero singular values number: %s", np.sum(np.abs(sigma) < 1e-8))
+    log.debug(1, "Singular values:\n%s", sigma)
+    w1 = w[order]
+    wA, wB = w1[:nval], 1.0 - w1[nval:]
+    log.debug(0, "particle character:\nspin A max %.2f min %.2f mean %.2f"
+              "\nspin B max %.2f min %.2f mean %.2f", np.max(wA), np.min(wA), np.average(wA),
+              np.max(wB), np.min(wB), np.average(wB))
+    log.info("Bath coupling strength\n%s\n%s", sigma[order[:nval]], sigma[order[nval:]])
+    if kwargs.get("only_return_bath", False):
+        return d_U.get().reshape((ncells - 1, nscsites * 2, nval * 2))
+    return d_basis.get()
+
+
+def _eigh_real(ctx, A):
+    """Symmetric eigenproblem of one small real matrix on the device: ew ascending, ev columns."""
+    m = A.shape[-1]
+    d_w = ctx.empty((1, m), np.float64)
+    d_Vt = ctx.empty((1, m, m), np.float64)
+    ctx.check(lib.dmk_eigh_batched_real(ctx.h, m, 1, ctx.to_device(A, np.float64).ptr, d_w.ptr, d_Vt.ptr))
+    return d_w.get()[0], np.ascontiguousarray(d_Vt.get()[0].T)
+
+
+def _inv_sqrt_factor(ctx, M):
+    """inv(A^T) for A = MatSqrt(M) = ev sqrt(ew) (routine/slater.py:38-50): ev diag(ew^-1/2)."""
+    log.eassert(np.abs(M - M.T).max() < 1e-10, "matrix must be symmetric")
+    ew, ev = _eigh_real(ctx, M)
+    if ew[0] < 0:
+        ew = ew + 1e-11
+    log.eassert((ew >= 0).all(), "matrix must be positive definite")
+    log.check(ew[0] > 1e-10, "small eigenvalue for rho_imp,"
+              "cut-off is recommended\nthe first 5 eigenvalues are %s", ew[:5])
+    return ev / np.sqrt(ew)[None, :]
+
+
+def _rotate_rows(ctx, d_b, nrow, m, X):
+    """b (nrow, m) @ X (m, m) on the device."""
+    d_out = ctx.empty((nrow, m), np.float64)
+    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, int(nrow), m, m, d_b.ptr, ctx.to_device(X, np.float64).ptr, 0, d_out.ptr))
+    return d_out
+
+
+def _orthonormalize_dev(ctx, d_b, nrow, m):
+    """routine/slater.py:59-78 on a device (nrow, m) block."""
+    d_ov = ctx.zeros((m, m), np.float64)
+    ctx.check(lib.dmk_dgemm_tn_acc_rect(ctx.h, m, m, int(nrow), 1.0, d_b.ptr, m, d_b.ptr, m, d_ov.ptr, m))
+    ov = d_ov.get()
+    log.debug(1, "basis overlap is\n%s", ov)
+    if np.allclose(ov - np.diag(np.diag(ov)), 0.):
+        return _rotate_rows(ctx, d_b, nrow, m, np.diag(1. / np.sqrt(np.diag(ov))))
+    ew, ev = _eigh_real(ctx, ov)
+    ew, ev = ew[::-1], ev[:, ::-1]
+    return _rotate_rows(ctx, d_b, nrow, m, ev * (ew ** (-0.5))[None, :])
+
+
+def _embBasis_phsymm(lattice, GRho, **kwargs):
+    """BCS bath from quasiparticle embedding.  Phys. Rev. B, 93, 035126 (2016)."""
+    if "sites" in kwargs:
+        log.error('keyword "sites" not supported.')
+    log.eassert(lattice.nval == lattice.nscsites, "Non-local bath does not support truncation.")
+    ncells, nscsites = lattice.ncells, lattice.nscsites
+    m = 2 * nscsites
+    GRho = np.ascontiguousarray(np.asarray(GRho).real, dtype=np.float64)
+    ctx = get_ctx()
+    basis = np.empty((2, ncells, m, m))
+    # particle part -> alpha spin
+    d_G = ctx.to_device(GRho.reshape(ncells * m, m))
+    d_BA1 = _rotate_rows(ctx, d_G, ncells * m, m, _inv_sqrt_factor(ctx, GRho[0]))
+    basis[0] = _orthonormalize_dev(ctx, d_BA1, ncells * m, m).get().reshape(ncells, m, m)
+    # hole part -> beta spin
+    GRho_h = -GRho
+    GRho_h[0] += np.eye(m)
+    d_Gh = ctx.to_device(GRho_h.reshape(ncells * m, m))
+    d_BA2 = _rotate_rows(ctx, d_Gh, ncells * m, m, _inv_sqrt_factor(ctx, GRho_h[0]))
+    BA2 = _orthonormalize_dev(ctx, d_BA2, ncells * m, m).get().reshape(ncells, m, m)
+    basis[1, :, :nscsites], basis[1, :, nscsites:] = BA2[:, nscsites:], BA2[:, :nscsites]
+    return basis

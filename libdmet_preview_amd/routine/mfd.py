@@ -3,6 +3,7 @@ Mean-field routines with the reference's entry points (libdmet/routine/mfd.py), 
 k-point diagonalisation, density build and k->R fold running on the MI355X through libdmetk:
 
   DiagRHF / DiagUHF / DiagRHF_symm / DiagUHF_symm   mfd.py:33-108  -> dmk_eigh_batched (all k, s in one launch)
+  DiagGHF[_symm] / DiagBdG[symm]                    mfd.py:591-641, 429-478 -> same kernel on (2 nlo) matrices
   HF                                                mfd.py:235-427 -> + dmk_occ_density + dmk_fold_k2R
   assignocc / check_nelec                           mfd.py:860-957 (host: sort + scalar root find)
 
@@ -112,6 +113,94 @@ def DiagUHF_symm(Fock, vcor, lattice, **kwargs):
         Fock = np.asarray((Fock, Fock))
     neg = [lattice.cell_pos2idx(-lattice.cell_idx2pos(i)) for i in range(Fock.shape[-3])]
     return _diag(Fock[:2], vcor, 2, symm_neg=neg)
+
+
+def _diag_nambu(A, add, symm_lattice=None):
+    """Batched eigh of (nk, m, m) complex matrices + one real (m, m) shift shared by all k; lower triangle only."""
+    ctx = get_ctx()
+    nk, m = A.shape[0], A.shape[-1]
+    d_A = ctx.to_device(A, np.complex128)
+    d_add = ctx.to_device(add[None], np.float64)
+    d_w, d_Vt = eigh_dev(ctx, d_A, m, nk, d_add, nk)
+    ew = d_w.get().reshape(nk, m)
+    ev = _vt_to_ev(ctx, d_Vt, m, nk).get().reshape(nk, m, m)
+    if symm_lattice is not None:
+        computed = set()
+        for i in range(nk):
+            ni = symm_lattice.cell_pos2idx(-symm_lattice.cell_idx2pos(i))
+            if ni in computed:
+                ew[i], ev[i] = ew[ni], ev[ni].conj()
+            else:
+                computed.add(i)
+    return ew, ev
+
+
+def _ghf_shift(vcor, nao, mu):
+    """The k-independent part of mfd.py:597-608: vcor blocks (lower triangle convention) and -/+ mu."""
+    v = np.asarray(vcor.get(0, True))
+    if np.iscomplexobj(v) and max_abs(v.imag) > 0.0:
+        raise NotImplementedError("complex correlation potential is outside the HIP path")
+    v = v.real
+    add = np.zeros((2 * nao, 2 * nao))
+    add[:nao, :nao] = v[0]
+    add[nao:, nao:] = v[1]
+    add[nao:, :nao] = v[2].T
+    add[:nao, nao:] = v[2]
+    if mu is not None:
+        add[range(nao), range(nao)] -= mu
+        add[range(nao, 2 * nao), range(nao, 2 * nao)] += mu
+    return add
+
+
+def DiagGHF(GFock, vcor, mu, **kwargs):
+    """mfd.py:591-610: generalised (spin-orbital) Fock, one eigh per k on the device."""
+    GFock = np.asarray(GFock)
+    nao = GFock.shape[-1] // 2
+    return _diag_nambu(GFock, _ghf_shift(vcor, nao, mu))
+
+
+def DiagGHF_symm(GFock, vcor, mu, lattice, **kwargs):
+    """mfd.py:612-641."""
+    GFock = np.asarray(GFock)
+    nao = GFock.shape[-1] // 2
+    return _diag_nambu(GFock, _ghf_shift(vcor, nao, mu), symm_lattice=lattice)
+
+
+def _bdg_matrix(Fock):
+    """Block-diagonal (F_a, -F_b) part of the BdG matrix (mfd.py:439-447); vcor and mu enter as the shift."""
+    Fock = np.asarray(Fock)
+    if Fock.ndim == 3:
+        Fock = np.asarray((Fock, Fock))
+    nk, n = Fock.shape[-3], Fock.shape[-1]
+    A = np.zeros((nk, 2 * n, 2 * n), dtype=np.complex128)
+    A[:, :n, :n] = Fock[0]
+    A[:, n:, n:] = -Fock[1]
+    return A, n
+
+
+def _bdg_shift(vcor, n, mu):
+    v = np.asarray(vcor.get(0, True))
+    if np.iscomplexobj(v) and max_abs(v.imag) > 0.0:
+        raise NotImplementedError("complex correlation potential is outside the HIP path")
+    v = v.real
+    add = np.zeros((2 * n, 2 * n))
+    add[:n, :n] = v[0] - mu * np.eye(n)
+    add[n:, n:] = -v[1] + mu * np.eye(n)
+    add[:n, n:] = v[2]
+    add[n:, :n] = v[2].T
+    return add
+
+
+def DiagBdG(Fock, vcor, mu, **kwargs):
+    """mfd.py:429-449."""
+    A, n = _bdg_matrix(Fock)
+    return _diag_nambu(A, _bdg_shift(vcor, n, mu))
+
+
+def DiagBdGsymm(Fock, vcor, mu, lattice, **kwargs):
+    """mfd.py:451-478."""
+    A, n = _bdg_matrix(Fock)
+    return _diag_nambu(A, _bdg_shift(vcor, n, mu), symm_lattice=lattice)
 
 
 # ---------------------------------------------------------------------------------------------

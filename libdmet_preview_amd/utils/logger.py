@@ -52,3 +52,9 @@ def eassert(cond, msg, *args):
     if not cond:
         error(msg, *args)
         raise Exception(msg % args if args else msg)
+
+
+def check(cond, msg, *args):
+    """utils/logger.py:57-60: a failed check is a warning, not an error."""
+    if not cond:
+        warn(msg, *args)

@@ -167,6 +167,10 @@ class _Vcor(object):
             return self.value
         return np.zeros_like(self.value)
 
+    def length(self):
+        n = self.value.shape[-1]
+        return n * (n + 1) + n * n
+
 
 def gen_G3():
     """mean-field diag + occupations + density (ew, occ, mu, rho; never raw eigenvectors)."""
@@ -368,11 +372,111 @@ def gen_G6():
     print("G6 done")
 
 
+def gen_G7():
+    """Nambu / BCS twin (a8), GHF + BdG diag (a3), alpha/beta bath matching (a7), unit2emb (a14)."""
+    from libdmet.routine import mfd, bcs, bcs_helper as bh, slater_helper as sh
+    from libdmet.dmet import HubPhSymm
+    from libdmet.system import lattice as rl
+    out = {}
+    cases = [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]
+    for name, mesh, n, val in cases:
+        nk = int(np.prod(mesh))
+        L = _duck_lattice(mesh, n, val=val)
+        rng = np.random.default_rng(1000 + n)
+        FR = synth.make_fock_R(mesh, n, spin=2, seed=300 + n)
+        Fk = synth.fold_R2k(FR, mesh)
+        v = rng.standard_normal((3, n, n)) * 0.2
+        v[0] = 0.5 * (v[0] + v[0].T)
+        v[1] = 0.5 * (v[1] + v[1].T)
+        mu = 0.37
+        vc = _Vcor(v)
+        ew, ev = mfd.DiagBdG(Fk, vc, mu)
+        ews, evs = mfd.DiagBdGsymm(Fk, vc, mu, L)
+        occ = (ew < 0).astype(float)
+        GRho_k = np.einsum("kpm,km,kqm->kpq", ev, occ, ev.conj())
+        GRho_k_s = np.einsum("kpm,km,kqm->kpq", evs, (ews < 0).astype(float), evs.conj())
+        GRho = rl.FFTtoT(GRho_k, mesh)
+        out[name + "/mesh"], out[name + "/Fock_R"], out[name + "/vcor"] = np.array(mesh), FR, v
+        out[name + "/mu"], out[name + "/val"] = np.asarray(mu), np.array(val)
+        out[name + "/bdg_ew"], out[name + "/bdg_GRho_k"] = ew, GRho_k
+        out[name + "/bdg_symm_ew"], out[name + "/bdg_symm_GRho_k"] = ews, GRho_k_s
+        out[name + "/GRho"] = GRho
+        # GHF: Hermitian generalised Fock with a k-dependent off-diagonal block
+        X = rng.standard_normal((nk, 2 * n, 2 * n)) * 0.1
+        GF_R = np.zeros((nk, 2 * n, 2 * n))
+        GF_R[:, :n, :n], GF_R[:, n:, n:] = FR[0], -FR[1]
+        D_R = synth.make_fock_R(mesh, n, spin=1, seed=17 + n)[0] * 0.3
+        GF_R[:, :n, n:] = D_R
+        GF_R[:, n:, :n] = rl.Lattice.transpose(L, D_R)
+        GFk = synth.fold_R2k(GF_R[None], mesh)[0]
+        gw, gv = mfd.DiagGHF(GFk, vc, mu)
+        gws, gvs = mfd.DiagGHF_symm(GFk, vc, mu, L)
+        gw0, gv0 = mfd.DiagGHF(GFk, vc, None)
+        out[name + "/GFock_R"] = GF_R
+        out[name + "/ghf_ew"], out[name + "/ghf_symm_ew"], out[name + "/ghf_nomu_ew"] = gw, gws, gw0
+        out[name + "/ghf_rho_k"] = np.einsum("kpm,km,kqm->kpq", gv, (gw < 0).astype(float), gv.conj())
+        out[name + "/ghf_symm_rho_k"] = np.einsum("kpm,km,kqm->kpq", gvs, (gws < 0).astype(float), gvs.conj())
+        # BCS embedding basis, projective and quasiparticle flavours
+        basis = bcs.embBasis(L, GRho)
+        out[name + "/basis_proj"] = basis
+        if len(val) == n:
+            out[name + "/basis_phsymm"] = bcs.embBasis(L, GRho, local=False)
+        # Nambu bookkeeping on a generic dense matrix
+        G0 = GRho[0]
+        rA, rB, kBA = bh.extractRdm(G0)
+        out[name + "/extractRdm"] = np.asarray([rA, rB, kBA])
+        out[name + "/extractH1"] = np.asarray(bh.extractH1(G0))
+        out[name + "/combineRdm"] = bh.combineRdm(rA, rB, -kBA.T)
+        out[name + "/swapSpin"] = bh.swapSpin(G0)
+        can = bh.basisToCanonical(basis)
+        out[name + "/canonical"] = can
+        out[name + "/toSpin"] = bh.basisToSpin(can)
+        # one-body folds: trans-inv (H1 stripe with pairing), local (vcor), imp, imp_env
+        H3 = np.asarray([FR[0], FR[1], D_R])
+        for tag, fn, H in [("ti3", bh.transform_trans_inv, H3), ("ti2", bh.transform_trans_inv, FR),
+                           ("ti1", bh.transform_trans_inv, FR[0]),
+                           ("loc3", bh.transform_local, v), ("loc2", bh.transform_local, v[:2]),
+                           ("loc1", bh.transform_local, v[0]),
+                           ("imp3", bh.transform_imp, v), ("imp1", bh.transform_imp, v[0]),
+                           ("ie3", bh.transform_imp_env, H3), ("ie1", bh.transform_imp_env, FR[0])]:
+            (hA, hB), hD, e0 = fn(basis, L, H)
+            out["%s/%s_H" % (name, tag)] = np.asarray([hA, hB, hD])
+            out["%s/%s_E0" % (name, tag)] = np.asarray(e0)
+        out[name + "/dV_dparam"] = bh.get_dV_dparam(basis, L, vc)
+        gA, gB, gD = bh.transform_local_grad(basis, L)
+        out[name + "/grad_D_A"] = gD[0]
+        out[name + "/grad_D_D"] = gD[1]
+    # a7: alpha/beta bath matching on a UHF Schmidt basis (bath columns only, as dmet/HubPhSymm.py:78 does)
+    g4 = np.load(os.path.join(GOLD, "G4_bath.npz"))
+    b = g4["gen/basis_svd"]
+    nimp = 7
+    bath = np.ascontiguousarray(b[:, :, :, nimp:])
+    out["match/in"] = bath
+    out["match/out"] = HubPhSymm.basisMatching(bath)
+    rngm = np.random.default_rng(99)
+    q = np.linalg.qr(rngm.standard_normal((2, 40, 6)))[0].reshape(2, 5, 8, 6)
+    out["match2/in"] = q
+    out["match2/out"] = HubPhSymm.basisMatching(q)
+    # a14: unit2emb for the three storage symmetries + spin reorder
+    rngu = np.random.default_rng(5)
+    nu, neo = 3, 5
+    npu = nu * (nu + 1) // 2
+    u4 = rngu.standard_normal((3, npu, npu))
+    u1 = rngu.standard_normal((1, nu, nu, nu, nu))
+    u8 = rngu.standard_normal((1, npu * (npu + 1) // 2))
+    out["u2e/in4"], out["u2e/out4"] = u4, sh.unit2emb(u4, neo)
+    out["u2e/in1"], out["u2e/out1"] = u1, sh.unit2emb(u1, neo)
+    out["u2e/in8"], out["u2e/out8"] = u8, sh.unit2emb(u8, neo)
+    out["u2e/neo"] = np.asarray(neo)
+    np.savez_compressed(os.path.join(GOLD, "G7_bcs.npz"), **out)
+    print("G7 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
     for g in which:
         globals()["gen_" + g]()
 

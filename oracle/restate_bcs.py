@@ -1,0 +1,362 @@
+"""
+oracle/restate_bcs.py -- CPU restatement (numpy) of the Nambu / BCS twin of the hot path and of the
+remaining small rows of SURVEY.md section 8a:
+
+  a3   DiagGHF / DiagGHF_symm (routine/mfd.py:591-641), DiagBdG / DiagBdGsymm (:429-478)
+  a7   HubPhSymm.basisMatching (dmet/HubPhSymm.py:37-48)
+  a8   routine/bcs_helper.py (:14-70, :176-207, :248-316, :346-430) and bcs.embBasis (routine/bcs.py:25-135)
+  a14  slater_helper.unit2emb (routine/slater_helper.py:494-528) and the caller's spin-block reorder
+       (routine/slater.py:461-462)
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package.  Pinned against the reference itself through tests/golden/G7_bcs.npz
+(oracle/gen_golden.py gen_G7, reference functions executed under oracle/shim.py).
+"""
+import itertools as it
+
+import numpy as np
+import scipy.linalg as la
+
+from oracle.restate import CellArith
+
+
+# ---------------------------------------------------------------------------------------------
+# a3: generalised / Nambu diagonalisations
+# ---------------------------------------------------------------------------------------------
+
+def _neg_table(kmesh):
+    ca = CellArith(kmesh)
+    return [ca.cell_pos2idx(-ca.cell_idx2pos(i)) for i in range(ca.ncells)]
+
+
+def _symm_fill(ew, ev, kmesh, solve):
+    """mfd.py:461-476 / :629-640: the later member of a (k, -k) pair is the conjugate of the earlier."""
+    neg = _neg_table(kmesh)
+    done = set()
+    for i in range(ew.shape[0]):
+        if neg[i] in done:
+            ew[i], ev[i] = ew[neg[i]], ev[neg[i]].conj()
+        else:
+            ew[i], ev[i] = solve(i)
+            done.add(i)
+    return ew, ev
+
+
+def DiagGHF(GFock, vcor_mat, mu, kmesh=None):
+    """mfd.py:591-610 (kmesh given: DiagGHF_symm :612-641).  Only the lower triangle is referenced."""
+    G = np.array(GFock, dtype=np.complex128, copy=True)
+    nk, nso, _ = G.shape
+    nao = nso // 2
+    G[:, :nao, :nao] += vcor_mat[0]
+    G[:, nao:, nao:] += vcor_mat[1]
+    G[:, nao:, :nao] += vcor_mat[2].conj().T
+    if mu is not None:
+        G[:, range(nao), range(nao)] -= mu
+        G[:, range(nao, nso), range(nao, nso)] += mu
+    ew = np.empty((nk, nso))
+    ev = np.empty((nk, nso, nso), dtype=np.complex128)
+    solve = lambda k: la.eigh(G[k], lower=True)
+    if kmesh is None:
+        for k in range(nk):
+            ew[k], ev[k] = solve(k)
+        return ew, ev
+    return _symm_fill(ew, ev, kmesh, solve)
+
+
+def DiagBdG(Fock, vcor_mat, mu, kmesh=None):
+    """mfd.py:429-449 (kmesh given: DiagBdGsymm :451-478)."""
+    Fock = np.asarray(Fock)
+    if Fock.ndim == 3:
+        Fock = np.asarray((Fock, Fock))
+    nk, n = Fock.shape[-3], Fock.shape[-1]
+    ew = np.empty((nk, 2 * n))
+    ev = np.empty((nk, 2 * n, 2 * n), dtype=np.complex128)
+
+    def solve(i):
+        t = np.empty((2 * n, 2 * n), dtype=np.complex128)
+        t[:n, :n] = Fock[0, i] + vcor_mat[0] - mu * np.eye(n)
+        t[n:, n:] = -Fock[1, i] - vcor_mat[1] + mu * np.eye(n)
+        t[:n, n:] = vcor_mat[2]
+        t[n:, :n] = vcor_mat[2].conj().T
+        return la.eigh(t)
+
+    if kmesh is None:
+        for i in range(nk):
+            ew[i], ev[i] = solve(i)
+        return ew, ev
+    return _symm_fill(ew, ev, kmesh, solve)
+
+
+# ---------------------------------------------------------------------------------------------
+# a7: alpha / beta bath matching
+# ---------------------------------------------------------------------------------------------
+
+def basisMatching(basis):
+    """dmet/HubPhSymm.py:37-48: S = A^T B = u g vt;  A' = A u, B' = B vt^T."""
+    A, B = basis[0], basis[1]
+    S = np.tensordot(A, B, axes=((0, 1), (0, 1)))
+    u, gamma, vt = la.svd(S)
+    return np.asarray([np.tensordot(A, u, axes=(2, 0)), np.tensordot(B, vt, axes=(2, 1))]), gamma
+
+
+# ---------------------------------------------------------------------------------------------
+# a14: unit ERI -> embedding ERI container
+# ---------------------------------------------------------------------------------------------
+
+def init_H2(norb, eri_symmetry, spin_dim=None):
+    """slater_helper.py:444-471."""
+    sd = () if spin_dim is None else (spin_dim,)
+    npair = norb * (norb + 1) // 2
+    if eri_symmetry == 1:
+        return np.zeros(sd + (norb,) * 4)
+    if eri_symmetry == 4:
+        return np.zeros(sd + (npair, npair))
+    if eri_symmetry == 8:
+        return np.zeros(sd + (npair * (npair + 1) // 2,))
+    raise ValueError("unknown ERI symmetry: %s" % eri_symmetry)
+
+
+def unit2emb(H2_unit, neo):
+    """slater_helper.py:494-518 (in-core branch)."""
+    sp = H2_unit.shape[0]
+    sym = {5: 1, 3: 4, 2: 8}.get(H2_unit.ndim)
+    if sym is None:
+        raise ValueError
+    out = init_H2(neo, sym, spin_dim=sp)
+    out[tuple(map(slice, H2_unit.shape))] = H2_unit
+    return out
+
+
+def reorder_spin_blocks(H2):
+    """routine/slater.py:461-462: (aa, ab, bb) -> (aa, bb, ab)."""
+    return H2[[0, 2, 1]] if H2.shape[0] == 3 else H2
+
+
+# ---------------------------------------------------------------------------------------------
+# a8: Nambu-matrix bookkeeping (bcs_helper.py:14-70)
+# ---------------------------------------------------------------------------------------------
+
+def extractRdm(GRho):
+    n = GRho.shape[0] // 2
+    assert 2 * n == GRho.shape[0]
+    return GRho[:n, :n].copy(), np.eye(n) - GRho[n:, n:], GRho[n:, :n].copy()
+
+
+def extractH1(GFock):
+    n = GFock.shape[0] // 2
+    assert 2 * n == GFock.shape[0]
+    return GFock[:n, :n].copy(), -GFock[n:, n:], GFock[n:, :n].copy()
+
+
+def combineRdm(rhoA, rhoB, kappaAB):
+    n = rhoA.shape[0]
+    return np.block([[rhoA, -kappaAB], [-kappaAB.T, np.eye(n) - rhoB]])
+
+
+def swapSpin(GRho):
+    rhoA, rhoB, kappaBA = extractRdm(GRho)
+    n = rhoA.shape[0]
+    return np.block([[rhoB, -kappaBA], [-kappaBA.T, np.eye(n) - rhoA]])
+
+
+def basisToCanonical(basis):
+    assert basis.shape[0] == 2
+    shape = list(basis.shape[1:])
+    nb, ns = shape[-1], shape[-2] // 2
+    shape[-1] *= 2
+    out = np.empty(tuple(shape))
+    out[..., :nb] = basis[0]
+    out[..., :ns, nb:] = basis[1, ..., ns:, :]
+    out[..., ns:, nb:] = basis[1, ..., :ns, :]
+    return out
+
+
+def basisToSpin(basis):
+    shape = [2] + list(basis.shape)
+    shape[-1] //= 2
+    nb, ns = shape[-1], shape[-2] // 2
+    out = np.empty(tuple(shape))
+    out[0] = basis[..., :nb]
+    out[1, ..., :ns, :] = basis[..., ns:, nb:]
+    out[1, ..., ns:, :] = basis[..., :ns, nb:]
+    return out
+
+
+def separate_basis(basis):
+    """bcs_helper.py:176-180 -> VA, VB, UA, UB."""
+    n = basis.shape[2] // 2
+    return basis[0, :, :n], basis[1, :, :n], basis[1, :, n:], basis[0, :, n:]
+
+
+# ---------------------------------------------------------------------------------------------
+# a8: one-body folds into the embedding (bcs_helper.py:182-207, 248-268, 346-388)
+# ---------------------------------------------------------------------------------------------
+
+def lattice_transpose(kmesh, A):
+    """system/lattice.py transpose: A^T[R] = A[-R]^T."""
+    neg = _neg_table(kmesh)
+    return np.asarray([A[neg[i]].T for i in range(A.shape[0])])
+
+
+def contract_trans_inv(basisL, basisR, kmesh, H):
+    ca = CellArith(kmesh)
+    res = np.zeros((basisL.shape[2], basisR.shape[2]))
+    for i, j in it.product(range(ca.ncells), repeat=2):
+        res += basisL[i].T @ H[ca.subtract(i, j)] @ basisR[j]
+    return res
+
+
+def contract_local(basisL, basisR, kmesh, H):
+    return sum(basisL[i].T @ H @ basisR[i] for i in range(basisL.shape[0]))
+
+
+def contract_imp(basisL, basisR, kmesh, H):
+    return basisL[0].T @ H @ basisR[0]
+
+
+def contract_imp_env(basisL, basisR, kmesh, H):
+    ca = CellArith(kmesh)
+    r1 = sum(basisL[0].T @ H[i] @ basisR[i] for i in range(ca.ncells))
+    r2 = sum(basisL[i].T @ H[ca.subtract(i, 0)] @ basisR[0] for i in range(ca.ncells))
+    return 0.5 * (r1 + r2)
+
+
+def _split_H(H, nd_single):
+    if H.ndim == nd_single:
+        return H, H, np.zeros_like(H)
+    if H.shape[0] == 2:
+        return H[0], H[1], np.zeros_like(H[0])
+    if H.shape[0] == 3:
+        return H[0], H[1], H[2]
+    raise ValueError("unknown shape of H: %s" % (H.shape,))
+
+
+def _nambu_fold(basis, kmesh, H, nd_single, contract, tr):
+    VA, VB, UA, UB = separate_basis(basis)
+    HA, HB, D = _split_H(H, nd_single)
+    DT = tr(D)
+    c = lambda L, h, R: contract(L, R, kmesh, h)
+    rA = c(VA, HA, VA) - c(UB, HB, UB) + c(VA, D, UB) + c(UB, DT, VA)
+    rB = c(VB, HB, VB) - c(UA, HA, UA) - c(VB, DT, UA) - c(UA, D, VB)
+    rD = c(VA, HA, UA) - c(UB, HB, VB) + c(VA, D, VB) + c(UB, DT, UA)
+    E0 = np.trace(c(UA, HA, UA) + c(UB, HB, UB) + c(UA, D, VB) + c(VB, DT, UA))
+    return np.asarray((rA, rB)), rD, E0
+
+
+def transform_trans_inv(basis, kmesh, H):
+    return _nambu_fold(basis, kmesh, H, 3, contract_trans_inv, lambda D: lattice_transpose(kmesh, D))
+
+
+def transform_local(basis, kmesh, H):
+    return _nambu_fold(basis, kmesh, H, 2, contract_local, lambda D: D.T)
+
+
+def transform_imp(basis, kmesh, H):
+    return _nambu_fold(basis, kmesh, H, 2, contract_imp, lambda D: D.T)
+
+
+def transform_imp_env(basis, kmesh, H):
+    return _nambu_fold(basis, kmesh, H, 3, contract_imp_env, lambda D: lattice_transpose(kmesh, D))
+
+
+# ---------------------------------------------------------------------------------------------
+# a8: derivative of the embedded potential w.r.t. the local vcor entries (bcs_helper.py:270-430)
+# ---------------------------------------------------------------------------------------------
+
+def contract_local_grad(basisL, basisR):
+    """sum_c L[c,i,p] R[c,j,q] -> (i, j, p, q)."""
+    return np.einsum("cip,cjq->ijpq", basisL, basisR)
+
+
+def contract_local_grad_DT(basisL, basisR):
+    """sum_c L[c,j,p] R[c,i,q] -> (i, j, p, q)."""
+    return np.einsum("cjp,ciq->ijpq", basisL, basisR)
+
+
+def transform_local_grad(basis):
+    VA, VB, UA, UB = separate_basis(basis)
+    g, gT = contract_local_grad, contract_local_grad_DT
+    A = (np.asarray([g(VA, VA), -g(UA, UA)]), g(VA, UA), None)
+    B = (np.asarray([-g(UB, UB), g(VB, VB)]), -g(UB, VB), None)
+    D = (np.asarray([g(VA, UB) + gT(UB, VA), -gT(VB, UA) - g(UA, VB)]), g(VA, VB) + gT(UB, UA), None)
+    return A, B, D
+
+
+def get_dV_dparam(basis, nparam):
+    def sym_triu(a):
+        a = a + a.transpose((1, 0, 2, 3))
+        a[np.arange(a.shape[0]), np.arange(a.shape[1])] *= 0.5
+        return a[np.triu_indices(a.shape[0])]
+
+    nb = basis.shape[-1]
+    rA, rB, rD = transform_local_grad(basis)
+    flat = lambda x: x.reshape((-1,) + x.shape[-2:])
+    cols = []
+    for which in range(3):      # -> H_A, H_B, D blocks of the embedded Nambu matrix
+        pick = (lambda r: r[0][0]) if which == 0 else (lambda r: r[0][1]) if which == 1 else (lambda r: r[1])
+        cols.append(np.concatenate([sym_triu(pick(rA)), sym_triu(pick(rB)), flat(pick(rD))], axis=0))
+    dA, dB, dD = cols
+    out = np.empty((nparam, 2 * nb, 2 * nb))
+    for ip in range(nparam):
+        out[ip, :nb, :nb] = dA[ip]
+        out[ip, nb:, nb:] = -dB[ip]
+        out[ip, :nb, nb:] = dD[ip]
+        out[ip, nb:, :nb] = dD[ip].T
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# a8: BCS embedding basis (routine/bcs.py:25-135)
+# ---------------------------------------------------------------------------------------------
+
+def embBasis_proj(GRho, nscsites, val_idx):
+    """bcs.py:78-104 (the branch without "sites").  Returns basis, sigma, B."""
+    ncells = GRho.shape[0]
+    n, nval = nscsites, len(val_idx)
+    basis = np.zeros((2, ncells, 2 * n, n + nval))
+    cols = list(val_idx) + [i + n for i in val_idx]
+    A = GRho[1:].reshape(n * (ncells - 1) * 2, 2 * n)[:, cols]
+    u, sigma, vt = la.svd(A, full_matrices=False)
+    B = u.reshape((ncells - 1, 2 * n, 2 * nval))
+    basis[0, 0, :n, :n] = np.eye(n)
+    basis[1, 0, :n, :n] = np.eye(n)
+    w = np.diag(np.tensordot(B[:, :n], B[:, :n], axes=((0, 1), (0, 1))))
+    order = np.argsort(w, kind="mergesort")[::-1]
+    oA, oB = order[:nval], order[nval:]
+    basis[0, 1:, :, n:] = B[:, :, oA]
+    basis[1, 1:, :n, n:] = B[:, n:, oB]
+    basis[1, 1:, n:, n:] = B[:, :n, oB]
+    return basis, sigma, B, w
+
+
+def MatSqrt(M):
+    """routine/slater.py:38-50."""
+    ew, ev = la.eigh(M)
+    if ew[0] < 0:
+        ew = ew + 1e-11
+    assert (ew >= 0).all()
+    return ev @ np.diag(np.sqrt(ew))
+
+
+def orthonormalizeBasis(b):
+    """routine/slater.py:59-78."""
+    ov = np.tensordot(b, b, axes=((0, 1), (0, 1)))
+    if np.allclose(ov - np.diag(np.diag(ov)), 0.0):
+        return np.tensordot(b, np.diag(1.0 / np.sqrt(np.diag(ov))), axes=(2, 0))
+    ew, ev = la.eigh(ov)
+    ew, ev = ew[::-1], ev[:, ::-1]
+    return np.tensordot(np.tensordot(b, ev, axes=(2, 0)), np.diag(ew ** -0.5), axes=(2, 0))
+
+
+def embBasis_phsymm(GRho, nscsites):
+    """bcs.py:109-135: quasiparticle bath; particle part -> alpha, hole part -> beta."""
+    ncells, n = GRho.shape[0], nscsites
+    basis = np.empty((2, ncells, 2 * n, 2 * n))
+    A1 = MatSqrt(GRho[0])
+    basis[0] = orthonormalizeBasis(np.dot(GRho, la.inv(A1.T)))
+    Gh = -GRho
+    Gh[0] += np.eye(2 * n)
+    A2 = MatSqrt(Gh[0])
+    BA2 = orthonormalizeBasis(np.dot(Gh, la.inv(A2.T)))
+    basis[1, :, :n], basis[1, :, n:] = BA2[:, n:], BA2[:, :n]
+    return basis

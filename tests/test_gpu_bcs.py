@@ -1,0 +1,225 @@
+"""
+GPU parity tests (-m gpu) for the rows of SURVEY.md section 8a completed after the ERI path: a3 GHF / BdG
+diagonalisations, a7 basisMatching, a8 BCS twin (bcs_helper folds, embBasis), a14 unit2emb.  The HIP path,
+through the C ABI, against oracle/restate_bcs.py and the golden fixture G7 captured from the reference.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R
+from oracle import restate_bcs as B
+from tests.test_oracle_bcs import CASES, _case, col_sign_dev
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from libdmet_preview_amd import _lib
+    return _lib.get_ctx()
+
+
+def _lattice(mesh, nlo, val):
+    from libdmet_preview_amd.system.lattice import Lattice
+    L = Lattice(int(nlo), mesh)
+    L.val_idx, L.virt_idx, L.core_idx = list(val), [], [i for i in range(nlo) if i not in val]
+    return L
+
+
+class _Vcor(object):
+    def __init__(self, v):
+        self.value = v
+
+    def get(self, i=0, kspace=True):
+        return self.value if (kspace or i == 0) else np.zeros_like(self.value)
+
+    def length(self):
+        n = self.value.shape[-1]
+        return n * (n + 1) + n * n
+
+
+def _occ_proj(ew, ev):
+    return np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bdg_ghf(ctx, golden, name):
+    from libdmet_preview_amd.routine import mfd
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    L = _lattice(mesh, FR.shape[-1], val)
+    vc = _Vcor(v)
+    for symm in (False, True):
+        ew, ev = (mfd.DiagBdGsymm(Fk, vc, mu, L) if symm else mfd.DiagBdG(Fk, vc, mu))
+        t = "bdg_symm" if symm else "bdg"
+        assert np.abs(ew - g["%s/%s_ew" % (name, t)]).max() < 1e-10
+        assert np.abs(_occ_proj(ew, ev) - g["%s/%s_GRho_k" % (name, t)]).max() < 1e-10
+        m = ev.shape[-1]
+        assert np.abs(np.einsum("kpm,kpn->kmn", ev.conj(), ev) - np.eye(m)).max() < 1e-12
+    # restricted input (one Fock for both spins) takes the same path
+    ew1, _ = mfd.DiagBdG(Fk[0], vc, mu)
+    ewo, _ = B.DiagBdG(Fk[0], v, mu)
+    assert np.abs(ew1 - ewo).max() < 1e-10
+    GFk = R.FFTtoK(g[name + "/GFock_R"], mesh)
+    for symm, mu_ in ((False, mu), (True, mu), (False, None)):
+        ew, ev = (mfd.DiagGHF_symm(GFk, vc, mu_, L) if symm else mfd.DiagGHF(GFk, vc, mu_))
+        t = "ghf_symm" if symm else ("ghf" if mu_ is not None else "ghf_nomu")
+        assert np.abs(ew - g["%s/%s_ew" % (name, t)]).max() < 1e-10
+        if mu_ is not None:
+            assert np.abs(_occ_proj(ew, ev) - g["%s/%s_rho_k" % (name, t)]).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bcs_emb_basis(ctx, golden, name):
+    from libdmet_preview_amd.routine import bcs
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    n = FR.shape[-1]
+    L = _lattice(mesh, n, val)
+    GRho = g[name + "/GRho"]
+    basis = bcs.embBasis(L, GRho)
+    ref = g[name + "/basis_proj"]
+    assert basis.shape == ref.shape
+    assert np.array_equal(basis[:, 0], ref[:, 0])
+    for s in range(2):
+        assert col_sign_dev(basis[s][1:, :, n:], ref[s][1:, :, n:]) < 1e-9
+    # both spins together span the left singular space: gauge-free projector check (<= 1e-10 Frobenius)
+    o_basis, o_sigma, o_B, o_w = B.embBasis_proj(GRho, n, val)
+    Bd = bcs.embBasis(L, GRho, only_return_bath=True)
+    a, b = Bd.reshape(-1, Bd.shape[-1]), o_B.reshape(-1, o_B.shape[-1])
+    assert np.sqrt(2.0) * np.linalg.norm(b - a @ (a.T @ b)) < 1e-10
+    assert np.abs(a.T @ a - np.eye(a.shape[1])).max() < 1e-12
+    assert bcs.get_emb_basis is bcs.embBasis
+    with pytest.raises(NotImplementedError):
+        bcs.embBasis(L, GRho, sites=[0])
+    if name + "/basis_phsymm" in g:
+        ph = bcs.embBasis(L, GRho, local=False)
+        refp = g[name + "/basis_phsymm"]
+        for s in range(2):
+            a, b = ph[s].reshape(-1, 2 * n), refp[s].reshape(-1, 2 * n)
+            assert np.abs(a @ a.T - b @ b.T).max() < 1e-9
+            assert np.abs(a.T @ a - np.eye(2 * n)).max() < 1e-10
+    else:
+        with pytest.raises(Exception):
+            bcs.embBasis(L, GRho, local=False)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bcs_folds(ctx, golden, name):
+    from libdmet_preview_amd.routine import bcs_helper as bh
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    n = FR.shape[-1]
+    L = _lattice(mesh, n, val)
+    basis = g[name + "/basis_proj"]
+    D_R = g[name + "/GFock_R"][:, :n, n:]
+    H3 = np.asarray([FR[0], FR[1], D_R])
+    todo = [("ti3", bh.transform_trans_inv, H3), ("ti2", bh.transform_trans_inv, FR), ("ti1", bh.transform_trans_inv, FR[0]),
+            ("loc3", bh.transform_local, v), ("loc2", bh.transform_local, v[:2]), ("loc1", bh.transform_local, v[0]),
+            ("imp3", bh.transform_imp, v), ("imp1", bh.transform_imp, v[0]),
+            ("ie3", bh.transform_imp_env, H3), ("ie1", bh.transform_imp_env, FR[0])]
+    for tag, fn, H in todo:
+        (hA, hB), hD, e0 = fn(basis, L, H)
+        assert np.abs(np.asarray([hA, hB, hD]) - g["%s/%s_H" % (name, tag)]).max() < 1e-10, tag
+        assert abs(e0 - float(g["%s/%s_E0" % (name, tag)])) < 1e-10, tag
+    VA, VB, UA, UB = bh.separate_basis(basis)
+    assert np.abs(bh.contract_trans_inv(VA, UB, L, D_R) - B.contract_trans_inv(VA, UB, mesh, D_R)).max() < 1e-11
+    assert np.abs(bh.contract_local(VB, UA, L, v[2]) - B.contract_local(VB, UA, mesh, v[2])).max() < 1e-12
+    assert np.abs(bh.contract_imp_env(VA, VB, L, FR[1]) - B.contract_imp_env(VA, VB, mesh, FR[1])).max() < 1e-12
+    dV = bh.get_dV_dparam(basis, L, _Vcor(v))
+    assert np.abs(dV - g[name + "/dV_dparam"]).max() < 1e-12
+    gA, gB, gD = bh.transform_local_grad(basis, L)
+    assert np.abs(gD[0] - g[name + "/grad_D_A"]).max() < 1e-12
+    assert np.abs(gD[1] - g[name + "/grad_D_D"]).max() < 1e-12
+    assert np.abs(bh.contract_local_grad(VA, UB, L) - B.contract_local_grad(VA, UB)).max() < 1e-12
+    assert np.abs(bh.contract_local_grad_DT(UB, VA, L) - B.contract_local_grad_DT(UB, VA)).max() < 1e-12
+    # bookkeeping mirrors are bit-exact
+    G0 = g[name + "/GRho"][0]
+    assert np.array_equal(np.asarray(bh.extractRdm(G0)), g[name + "/extractRdm"])
+    assert np.array_equal(np.asarray(bh.extractH1(G0)), g[name + "/extractH1"])
+    assert np.array_equal(bh.swapSpin(G0), g[name + "/swapSpin"])
+    assert np.array_equal(bh.basisToCanonical(basis), g[name + "/canonical"])
+    assert np.array_equal(bh.basisToSpin(g[name + "/canonical"]), basis)
+
+
+@pytest.mark.parametrize("tag", ["match", "match2"])
+def test_basis_matching(ctx, golden, tag):
+    from libdmet_preview_amd.dmet.HubPhSymm import basisMatching
+    g = golden("G7_bcs.npz")
+    out = basisMatching(g[tag + "/in"])
+    ref = g[tag + "/out"]
+    nb = ref.shape[-1]
+    a, b = out.reshape(2, -1, nb), ref.reshape(2, -1, nb)
+    for j in range(nb):
+        sgn = np.sign(np.dot(a[0][:, j], b[0][:, j]))
+        assert np.abs(a[0][:, j] - sgn * b[0][:, j]).max() < 1e-10
+        assert np.abs(a[1][:, j] - sgn * b[1][:, j]).max() < 1e-10
+    S = np.tensordot(out[0], out[1], axes=((0, 1), (0, 1)))
+    assert np.abs(S - np.diag(np.diag(S))).max() < 1e-12
+    assert (np.diff(np.diag(S)) <= 1e-14).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 33, 56, 84])
+def test_svd_small(ctx, n):
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    if n >= 7:
+        A[:, 3] = A[:, 1] * 1e-9 + A[:, 2]          # nearly dependent columns: tiny singular value
+    dA = ctx.to_device(A)
+    ds, dU, dVt = ctx.empty((n,), np.float64), ctx.empty((n, n), np.float64), ctx.empty((n, n), np.float64)
+    ctx.check(lib.dmk_svd_small(ctx.h, n, dA.ptr, ds.ptr, dU.ptr, dVt.ptr))
+    s, U, Vt = ds.get(), dU.get(), dVt.get()
+    sref = np.linalg.svd(A, compute_uv=False)
+    assert np.abs(s - sref).max() < 1e-13 * max(1.0, sref[0])
+    assert np.abs((U * s) @ Vt - A).max() < 1e-12 * max(1.0, sref[0])
+    assert np.abs(Vt @ Vt.T - np.eye(n)).max() < 1e-12
+    assert np.abs(U.T @ U - np.eye(n)).max() < 1e-7    # columns of tiny sigma lose orthogonality like 1/sigma
+
+
+def test_svd_small_rejects_big(ctx):
+    from libdmet_preview_amd._lib import lib, DmkError
+    d = ctx.zeros((85, 85), np.float64)
+    with pytest.raises(DmkError):
+        ctx.check(lib.dmk_svd_small(ctx.h, 85, d.ptr, d.ptr, d.ptr, d.ptr))
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 3, 7), (130, 64, 33), (400, 257, 1000), (56, 56, 43200)])
+def test_dgemm_tn_acc_rect(ctx, M, N, K):
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(M + N + K)
+    X, Y, C0 = rng.standard_normal((K, M)), rng.standard_normal((K, N)), rng.standard_normal((M, N))
+    dX, dY, dC = ctx.to_device(X), ctx.to_device(Y), ctx.to_device(C0)
+    ctx.check(lib.dmk_dgemm_tn_acc_rect(ctx.h, M, N, K, -0.5, dX.ptr, M, dY.ptr, N, dC.ptr, N))
+    ref = C0 - 0.5 * X.T @ Y
+    assert np.abs(dC.get() - ref).max() < 1e-12 * np.sqrt(K) * 10
+
+
+def test_dgemm_nn_small(ctx):
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(3)
+    A, Bm = rng.standard_normal((1000, 9)), rng.standard_normal((9, 6))
+    dA, dB, dC = ctx.to_device(A), ctx.to_device(Bm), ctx.empty((1000, 6), np.float64)
+    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, 1000, 6, 9, dA.ptr, dB.ptr, 0, dC.ptr))
+    assert np.abs(dC.get() - A @ Bm).max() < 1e-13
+    dBt = ctx.to_device(np.ascontiguousarray(Bm.T))
+    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, 1000, 6, 9, dA.ptr, dBt.ptr, 1, dC.ptr))
+    assert np.abs(dC.get() - A @ Bm).max() < 1e-13
+
+
+def test_unit2emb(ctx, golden):
+    from libdmet_preview_amd.routine import slater_helper as sh
+    g = golden("G7_bcs.npz")
+    neo = int(g["u2e/neo"])
+    for k in ("4", "1", "8"):
+        assert np.array_equal(sh.unit2emb(g["u2e/in" + k], neo), g["u2e/out" + k])
+    x = g["u2e/in4"]
+    assert np.array_equal(sh.reorder_spin_blocks(x), x[[0, 2, 1]])
+    assert np.array_equal(sh.reorder_spin_blocks(x[:1]), x[:1])
+    with pytest.raises(ValueError):
+        sh.unit2emb(np.zeros((1, 2, 2, 2)), neo)
+    with pytest.raises(ValueError):
+        sh.init_H2(4, 2)
+    box = {"ccdd": np.array(g["u2e/in4"])}
+    out = sh.unit2emb(box, neo)
+    assert out is box and np.array_equal(box["ccdd"], g["u2e/out4"])

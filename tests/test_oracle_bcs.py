@@ -1,0 +1,131 @@
+"""
+Pins oracle/restate_bcs.py (rows a3 GHF/BdG, a7 basisMatching, a8 BCS twin, a14 unit2emb of SURVEY.md
+section 8a) against tests/golden/G7_bcs.npz, captured from the reference under oracle/shim.py.  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import restate as R
+from oracle import restate_bcs as B
+
+CASES = ["c611", "c441", "c222"]
+
+
+def col_sign_dev(a, b):
+    """max over columns of min(|a - b|, |a + b|): equality up to a sign per column."""
+    a = a.reshape(-1, a.shape[-1])
+    b = b.reshape(-1, b.shape[-1])
+    return max(min(np.abs(a[:, j] - b[:, j]).max(), np.abs(a[:, j] + b[:, j]).max()) for j in range(a.shape[1]))
+
+
+def _case(g, name):
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR = g[name + "/Fock_R"]
+    Fk = np.asarray([R.FFTtoK(FR[s], mesh) for s in range(2)])
+    return mesh, FR, Fk, g[name + "/vcor"], float(g[name + "/mu"]), [int(x) for x in g[name + "/val"]]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_G7_bdg_ghf(golden, name):
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    for symm in (False, True):
+        ew, ev = B.DiagBdG(Fk, v, mu, kmesh=mesh if symm else None)
+        t = "bdg_symm" if symm else "bdg"
+        assert np.abs(ew - g["%s/%s_ew" % (name, t)]).max() < 1e-11
+        rho = np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+        assert np.abs(rho - g["%s/%s_GRho_k" % (name, t)]).max() < 1e-10
+    GFk = R.FFTtoK(g[name + "/GFock_R"], mesh)
+    for symm, mu_ in ((False, mu), (True, mu), (False, None)):
+        ew, ev = B.DiagGHF(GFk, v, mu_, kmesh=mesh if symm else None)
+        t = "ghf_symm" if symm else ("ghf" if mu_ is not None else "ghf_nomu")
+        assert np.abs(ew - g["%s/%s_ew" % (name, t)]).max() < 1e-11
+        if mu_ is not None:
+            rho = np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+            assert np.abs(rho - g["%s/%s_rho_k" % (name, t)]).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_G7_nambu_bookkeeping(golden, name):
+    g = golden("G7_bcs.npz")
+    G0 = g[name + "/GRho"][0]
+    rA, rB, kBA = B.extractRdm(G0)
+    assert np.array_equal(np.asarray([rA, rB, kBA]), g[name + "/extractRdm"])
+    assert np.array_equal(np.asarray(B.extractH1(G0)), g[name + "/extractH1"])
+    assert np.array_equal(B.combineRdm(rA, rB, -kBA.T), g[name + "/combineRdm"])
+    assert np.array_equal(B.swapSpin(G0), g[name + "/swapSpin"])
+    basis = g[name + "/basis_proj"]
+    can = B.basisToCanonical(basis)
+    assert np.array_equal(can, g[name + "/canonical"])
+    assert np.array_equal(B.basisToSpin(can), g[name + "/toSpin"])
+    assert np.array_equal(B.basisToSpin(can), basis)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_G7_emb_basis(golden, name):
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    n = FR.shape[-1]
+    GRho = g[name + "/GRho"]
+    basis, sigma, Bm, w = B.embBasis_proj(GRho, n, val)
+    ref = g[name + "/basis_proj"]
+    assert basis.shape == ref.shape
+    assert np.array_equal(basis[:, 0], ref[:, 0])
+    for s in range(2):
+        assert col_sign_dev(basis[s][1:, :, n:], ref[s][1:, :, n:]) < 1e-9
+    if name + "/basis_phsymm" in g:
+        ph = B.embBasis_phsymm(GRho, n)
+        refp = g[name + "/basis_phsymm"]
+        for s in range(2):
+            a, b = ph[s].reshape(-1, 2 * n), refp[s].reshape(-1, 2 * n)
+            assert np.abs(a @ a.T - b @ b.T).max() < 1e-9
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_G7_folds(golden, name):
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    basis = g[name + "/basis_proj"]
+    GF_R = g[name + "/GFock_R"]
+    n = FR.shape[-1]
+    D_R = GF_R[:, :n, n:]
+    H3 = np.asarray([FR[0], FR[1], D_R])
+    todo = [("ti3", B.transform_trans_inv, H3), ("ti2", B.transform_trans_inv, FR), ("ti1", B.transform_trans_inv, FR[0]),
+            ("loc3", B.transform_local, v), ("loc2", B.transform_local, v[:2]), ("loc1", B.transform_local, v[0]),
+            ("imp3", B.transform_imp, v), ("imp1", B.transform_imp, v[0]),
+            ("ie3", B.transform_imp_env, H3), ("ie1", B.transform_imp_env, FR[0])]
+    for tag, fn, H in todo:
+        (hA, hB), hD, e0 = fn(basis, mesh, H)
+        assert np.abs(np.asarray([hA, hB, hD]) - g["%s/%s_H" % (name, tag)]).max() < 1e-11, tag
+        assert abs(e0 - float(g["%s/%s_E0" % (name, tag)])) < 1e-10, tag
+    dV = B.get_dV_dparam(basis, n * (n + 1) + n * n)
+    assert np.abs(dV - g[name + "/dV_dparam"]).max() < 1e-12
+    gA, gB, gD = B.transform_local_grad(basis)
+    assert np.abs(gD[0] - g[name + "/grad_D_A"]).max() < 1e-12
+    assert np.abs(gD[1] - g[name + "/grad_D_D"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["match", "match2"])
+def test_G7_basis_matching(golden, tag):
+    g = golden("G7_bcs.npz")
+    out, gamma = B.basisMatching(g[tag + "/in"])
+    ref = g[tag + "/out"]
+    nb = ref.shape[-1]
+    a, b = out.reshape(2, -1, nb), ref.reshape(2, -1, nb)
+    for j in range(nb):
+        sgn = np.sign(np.dot(a[0][:, j], b[0][:, j]))
+        assert np.abs(a[0][:, j] - sgn * b[0][:, j]).max() < 1e-10
+        assert np.abs(a[1][:, j] - sgn * b[1][:, j]).max() < 1e-10     # the pair flips together
+    S = np.tensordot(out[0], out[1], axes=((0, 1), (0, 1)))
+    assert np.abs(S - np.diag(gamma)).max() < 1e-12
+
+
+def test_G7_unit2emb(golden):
+    g = golden("G7_bcs.npz")
+    neo = int(g["u2e/neo"])
+    for k in ("4", "1", "8"):
+        assert np.array_equal(B.unit2emb(g["u2e/in" + k], neo), g["u2e/out" + k])
+    x = g["u2e/in4"]
+    assert np.array_equal(B.reorder_spin_blocks(x), x[[0, 2, 1]])
+    with pytest.raises(ValueError):
+        B.unit2emb(np.zeros((1, 2, 2, 2)), neo)
