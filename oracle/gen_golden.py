@@ -472,11 +472,147 @@ def gen_G7():
     print("G7 done")
 
 
+def _psd_eri(rng, nb, naux, spin):
+    """DF-like 4-fold ERI blocks: (aa, bb, ab) = (Xa^T Xa, Xb^T Xb, Xa^T Xb), X (naux, npair)."""
+    npair = nb * (nb + 1) // 2
+    Xa = rng.standard_normal((naux, npair)) / np.sqrt(naux)
+    if spin == 1:
+        return (Xa.T @ Xa)[None]
+    Xb = rng.standard_normal((naux, npair)) / np.sqrt(naux)
+    return np.asarray([Xa.T @ Xa, Xb.T @ Xb, Xa.T @ Xb])
+
+
+def gen_G8():
+    """Embedding Hamiltonian (section 8f rank 1): get_emb_Ham, _get_jk, get_veff, one-body folds."""
+    from libdmet.routine import slater, mfd, slater_helper as sh
+    from libdmet.solver import scf as rscf
+    shim.patch_scf()
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+    out = {}
+    for name, mesh, nlo, spin, val in [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3]), ("rhf_411", (4, 1, 1), 5, 1, [1, 2, 3]),
+                                       ("uhf_222", (2, 2, 2), 3, 2, [0, 1, 2])]:
+        nk = int(np.prod(mesh))
+        rng = np.random.default_rng(4000 + nlo)
+        L = _duck_lattice(mesh, nlo, val=val, virt=[i for i in range(nlo) if i > max(val)],
+                          core=[i for i in range(nlo) if i < min(val)])
+        FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=500 + nlo)
+        Fk = synth.fold_R2k(FR, mesh)
+        HR = 0.6 * FR
+        Hk = synth.fold_R2k(HR, mesh)
+        SR = np.zeros((nk, nlo, nlo))
+        SR[0] = np.eye(nlo)
+        pert = synth.make_fock_R(mesh, nlo, spin=1, seed=9)[0] * 0.02
+        SR = SR + pert
+        Sk = synth.fold_R2k(SR[None], mesh)[0]
+        sq = (lambda x: x[0]) if spin == 1 else (lambda x: x)
+        L.fock_lo_k, L.fock_lo_R = sq(Fk), sq(FR)
+        L.hcore_lo_k, L.hcore_lo_R = sq(Hk), sq(HR)
+        L.vhf_lo_k = sq(Fk - Hk)
+        L.ovlp_lo_k = Sk
+        L.JK_imp = None
+        L.Ham = None
+        L.H0 = 1.25
+        v = rng.standard_normal((2, nlo, nlo)) * 0.1
+        v = 0.5 * (v + v.transpose(0, 2, 1))
+        if spin == 1:
+            v[1] = v[0]
+        vc = _Vcor(v)
+        rhoT, mu, E, res = mfd.HF(L, vc, 0.5, spin == 1, beta=np.inf, ires=True)
+        L.rdm1_lo_k = res["rho_k"] * (2.0 if spin == 1 else 1.0)     # restricted: spin-traced (slater.py:481)
+        L.rdm1_lo_R = rhoT
+        basis = slater.get_emb_basis(L, rhoT)
+        nb = basis.shape[-1]
+        H2 = _psd_eri(rng, nb, 7, spin)
+        out[name + "/mesh"], out[name + "/val"] = np.array(mesh), np.array(val)
+        out[name + "/Fock_R"], out[name + "/H1_R"], out[name + "/S_R"], out[name + "/vcor"] = FR, HR, SR, v
+        out[name + "/rdm1_lo_k"], out[name + "/basis"], out[name + "/H2"] = L.rdm1_lo_k, basis, H2
+        JK_imp2 = rng.standard_normal((nlo, nlo))
+        JK_imp2 = JK_imp2 + JK_imp2.T
+        JK_imp3 = np.asarray([JK_imp2, 0.5 * JK_imp2])[:spin]
+        out[name + "/JK_imp2"], out[name + "/JK_imp3"] = JK_imp2, JK_imp3
+        runs = [("ib", dict()), ("ib_vcor", dict(add_vcor=True)), ("ib_vcor_fit", dict(add_vcor=True, fitting=True)),
+                ("nib", dict(int_bath=False)), ("nib_jk2", dict(int_bath=False, JK_imp=JK_imp2)),
+                ("nib_jk3", dict(int_bath=False, JK_imp=JK_imp3)), ("nib_hcore", dict(int_bath=False, hcore=True))]
+        for tag, kw in runs:
+            kw = dict(kw)
+            L.JK_imp = kw.pop("JK_imp", None)
+            L.use_hcore_as_emb_ham = kw.pop("hcore", False)
+            L.JK_core = "unset"
+            Himp, _ = slater.get_emb_Ham(L, basis, vc, H2_given=H2, **kw)
+            out["%s/%s_H1" % (name, tag)] = Himp.H1["cd"]
+            out["%s/%s_ovlp" % (name, tag)] = np.asarray(Himp.ovlp)
+            out["%s/%s_H0" % (name, tag)] = np.asarray(Himp.H0)
+            if L.JK_core is not None:
+                out["%s/%s_JK_core" % (name, tag)] = np.asarray(L.JK_core)
+            assert Himp.H2["ccdd"] is H2 and Himp.norb == nb and Himp.restricted == (spin == 1)
+        L.JK_imp, L.use_hcore_as_emb_ham = None, False
+        # ERI x density in every storage form the reference accepts
+        dm = slater.foldRho_k(L.rdm1_lo_k, L.R2k_basis(basis))
+        out[name + "/rdm1_emb"] = dm
+        vj, vk = rscf._get_jk(dm, H2)
+        out[name + "/jk_s4_vj"], out[name + "/jk_s4_vk"] = vj, vk
+        H2_s1 = np.asarray([shim.restore(1, h, nb) for h in H2])
+        vj1, vk1 = rscf._get_jk(dm, H2_s1)
+        assert np.allclose(vj1, vj) and np.allclose(vk1, vk)
+        out[name + "/jk_s1_vj"], out[name + "/jk_s1_vk"] = vj1, vk1
+        vj8, vk8 = rscf._get_jk(dm, shim.restore(8, H2[0], nb))              # spin_dim 0, s8
+        out[name + "/jk_s8_vj"], out[name + "/jk_s8_vk"] = vj8, vk8
+        vjr, vkr = rscf._get_jk(dm, H2[:1])                                   # spin-free ERI, any dm spin
+        out[name + "/jk_res_vj"], out[name + "/jk_res_vk"] = vjr, vkr
+        for hyb in (1.0, 0.0, 0.4):
+            out["%s/veff_hyb%.1f" % (name, hyb)] = slater.get_veff(dm, H2, hyb=hyb)
+        out[name + "/veff_dm2d"] = slater.get_veff(dm[0], H2[:1])
+        # one-body folds, real-space forms
+        for s in range(spin):
+            out["%s/ti_sym_%d" % (name, s)] = sh.transform_trans_inv(basis[s], L, FR[s])
+            out["%s/ti_full_%d" % (name, s)] = sh.transform_trans_inv(basis[s], L, FR[s], symmetric=False)
+            out["%s/tloc_%d" % (name, s)] = sh.transform_local(basis[s], L, v[s])
+            out["%s/timp_%d" % (name, s)] = sh.transform_imp(basis[s], L, v[s])
+            out["%s/tie_%d" % (name, s)] = sh.transform_imp_env(basis[s], L, FR[s])
+        out[name + "/foldRho"] = slater.foldRho(rhoT if rhoT.ndim == 4 else rhoT[None], L, basis)
+        out[name + "/h1_emb"] = slater.transform_h1(L.hcore_lo_k, L.R2k_basis(basis))
+    # model lattices (C1 / C2): local Hubbard U, interacting bath -> transform_eri_local + s1 J/K
+    for name, mesh, cs, spin in [("C1", (6, 1, 1), (2,), 1), ("C2", (6, 6, 1), (2, 2), 1), ("C1u", (6, 1, 1), (2,), 2)]:
+        H1 = synth.hubbard_h1_R(mesh, cs)
+        nlo = H1.shape[-1]
+        U = 4.0
+        Hk = synth.fold_R2k(H1, mesh)
+        L = _duck_lattice(mesh, nlo, val=list(range(nlo)))
+        L.is_model = True
+        L.H2_format, L.eri_symmetry = "local", 1
+        LatH2 = np.zeros((nlo,) * 4)
+        for i in range(nlo):
+            LatH2[i, i, i, i] = U
+        L.getH2 = lambda compact=False, kspace=False, _h=LatH2: _h
+        v = np.zeros((2, nlo, nlo))
+        v[0] = np.diag(U / 2 + 0.3 * (-1.0) ** np.arange(nlo))
+        v[1] = np.diag(U / 2 - 0.3 * (-1.0) ** np.arange(nlo)) if spin == 2 else v[0]
+        vc = _Vcor(v)
+        L.hcore_lo_k = L.fock_lo_k = Hk
+        L.hcore_lo_R = L.fock_lo_R = H1
+        SR = np.zeros_like(H1)
+        SR[0] = np.eye(nlo)
+        L.ovlp_lo_k = synth.fold_R2k(SR[None], mesh)[0]
+        L.JK_imp, L.Ham, L.H0 = None, None, 0.0
+        rhoT, mu, E, res = mfd.HF(L, vc, 0.5, spin == 1, beta=np.inf, ires=True)
+        L.rdm1_lo_k = res["rho_k"] * (2.0 if spin == 1 else 1.0)
+        basis = slater.get_emb_basis(L, rhoT)
+        Himp, _ = slater.get_emb_Ham(L, basis, vc)
+        out[name + "/mesh"], out[name + "/H1_R"], out[name + "/vcor"] = np.array(mesh), H1, v
+        out[name + "/rdm1_lo_k"], out[name + "/basis"], out[name + "/LatH2"] = L.rdm1_lo_k, basis, LatH2
+        out[name + "/H1"], out[name + "/H2"] = Himp.H1["cd"], Himp.H2["ccdd"]
+        out[name + "/JK_core"] = np.asarray(L.JK_core)
+        Hn, _ = slater.get_emb_Ham(L, basis, vc, int_bath=False)
+        out[name + "/nib_H1"], out[name + "/nib_H2"] = Hn.H1["cd"], Hn.H2["ccdd"]
+    np.savez_compressed(os.path.join(GOLD, "G8_embham.npz"), **out)
+    print("G8 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
     for g in which:
         globals()["gen_" + g]()
 

@@ -224,6 +224,22 @@ def install():
     _installed = True
 
 
+def patch_scf():
+    """Bind the restated PySCF primitives used by libdmet.solver.scf._get_jk (solver/scf.py:255-335)."""
+    install()
+    from libdmet.solver import scf as rscf
+    from oracle import restate_ham
+
+    class _hf(object):
+        dot_eri_dm = staticmethod(restate_ham.dot_eri_dm)
+
+    class _ao2mo_mod(object):
+        restore = staticmethod(restore)
+    rscf.hf = _hf
+    rscf.ao2mo = _ao2mo_mod
+    return rscf
+
+
 def quiet():
     from libdmet.utils import logger as log
     log.verbose = "RESULT"
