@@ -73,7 +73,7 @@ int dmk_timer_stop(dmk_ctx *ctx, double *ms_out_host);
  * every launch of the family is bracketed by events on the stream. */
 enum { DMK_FAM_DGEMM = 0, DMK_FAM_ZGEMM_HALF1 = 1, DMK_FAM_ZGEMM_HALF2 = 2,
        DMK_FAM_PHILOX = 3, DMK_FAM_FOLD = 4, DMK_FAM_EIGH = 5, DMK_FAM_BATH = 6,
-       DMK_FAM_ZGEMM_SMALL = 7, DMK_FAM_MISC = 8, DMK_FAM_COUNT = 9 };
+       DMK_FAM_ZGEMM_SMALL = 7, DMK_FAM_MISC = 8, DMK_FAM_JK = 9, DMK_FAM_COUNT = 10 };
 int dmk_profile(dmk_ctx *ctx, int enable);
 int dmk_profile_read(dmk_ctx *ctx, double *ms_host /*[DMK_FAM_COUNT]*/,
                      int64_t *launches_host /*[DMK_FAM_COUNT]*/, int reset);
@@ -258,6 +258,20 @@ int dmk_bcs_assemble(dmk_ctx *ctx, int ncells, int n, int nval, const double *U,
  * routine/slater_helper.py:494-518 (unit2emb). */
 int dmk_pad_block_f64(dmk_ctx *ctx, int batch, int64_t r_in, int64_t c_in, const double *in, int64_t r_out,
                       int64_t c_out, double *out);
+
+/* ---- ERI x density -------------------------------------------------------
+ * Coulomb / exchange matrices from one 4-fold packed ERI block E (npair x npair, leading dimension ld, device),
+ * replacing pyscf.scf.hf.dot_eri_dm as called from solver/scf.py:255-335 (_get_jk):
+ *     vj_row[i][j] = sum_kl (ij|kl) dm_row[k][l]        J: ijkl,kl->ij
+ *     vj_col[k][l] = sum_ij (ij|kl) dm_col[i][j]        the transposed alpha-beta block, solver/scf.py:325-327
+ *     vk[j][k]     = sum_il (ij|kl) dm_k[i][l]          K: ijkl,il->jk
+ * Any of the three densities may be NULL (its output is then not touched).  Densities and outputs are device
+ * (n x n) f64 row-major.  One streaming pass over E for J (both directions) and one for K; no atomics. */
+int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *dm_row, const double *dm_col,
+              const double *dm_k, double *vj_row, double *vj_col, double *vk);
+/* 1-fold (n^4) or 8-fold (tril of npair x npair) ERI -> 4-fold (npair x npair): ao2mo.restore(4, .) at
+ * solver/scf.py:311-321. */
+int dmk_eri_to_s4(dmk_ctx *ctx, int n, int from_symmetry, const double *in, double *out);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "dmk_bcs_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "dmk_bcs_assemble": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmk_pad_block_f64": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
+    "dmk_jk_s4": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():
@@ -81,7 +83,7 @@ for _name, (_res, _args) in PROTOTYPES.items():
     _f.restype = _res
     _f.argtypes = _args
 
-FAMILIES = ["dgemm", "zgemm_half1", "zgemm_half2", "philox", "fold", "eigh", "bath", "zgemm_small", "misc"]
+FAMILIES = ["dgemm", "zgemm_half1", "zgemm_half2", "philox", "fold", "eigh", "bath", "zgemm_small", "misc", "jk"]
 
 
 class DmkError(RuntimeError):

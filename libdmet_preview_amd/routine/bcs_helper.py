@@ -19,9 +19,9 @@ real GEMM C_s^T C_t over the cell index (dmk_dgemm_tn_acc_rect).
 import numpy as np
 
 from libdmet_preview_amd._lib import lib, get_ctx
-from libdmet_preview_amd.basis_transform.make_basis import bgemm_dev
-from libdmet_preview_amd.system import fourier
 from libdmet_preview_amd.utils import logger as log
+from libdmet_preview_amd.utils.devmat import quad_trans_inv as _quad_trans_inv, quad_local as _quad_local, \
+    quad_imp_env as _quad_imp_env
 
 
 # ---------------------------------------------------------------------------------------------
@@ -79,96 +79,6 @@ def separate_basis(basis):
     nscsites = basis.shape[2] // 2
     # VA, VB, UA, UB
     return basis[0, :, :nscsites], basis[1, :, :nscsites], basis[1, :, nscsites:], basis[0, :, nscsites:]
-
-
-# ---------------------------------------------------------------------------------------------
-# device building blocks: stacks of complex matrices (batch, r, c)
-# ---------------------------------------------------------------------------------------------
-
-class _Stack(object):
-    __slots__ = ("d", "batch", "r", "c")
-
-    def __init__(self, d, batch, r, c):
-        self.d, self.batch, self.r, self.c = d, int(batch), int(r), int(c)
-
-    def flat(self):
-        """(batch, r, c) viewed as one (batch*r, c) matrix."""
-        return _Stack(self.d, 1, self.batch * self.r, self.c)
-
-    def rows(self):
-        """(batch, r, c) viewed as one (batch, r*c) matrix."""
-        return _Stack(self.d, 1, self.batch, self.r * self.c)
-
-    def get(self):
-        return self.d.get().reshape(self.batch, self.r, self.c)
-
-
-def _up(ctx, a):
-    a = np.asarray(a)
-    if a.ndim == 2:
-        a = a[None]
-    return _Stack(ctx.to_device(a, np.complex128), a.shape[0], a.shape[1], a.shape[2])
-
-
-def _mm(ctx, opA, A, opB, B, alpha=1.0):
-    """op(A[b]) op(B[b]); a stack of one matrix is broadcast over the other's batch."""
-    batch = max(A.batch, B.batch)
-    assert A.batch in (1, batch) and B.batch in (1, batch)
-    M, K = (A.r, A.c) if opA == "N" else (A.c, A.r)
-    K2, N = (B.r, B.c) if opB == "N" else (B.c, B.r)
-    assert K == K2, (K, K2)
-    sA = A.r * A.c if A.batch == batch else 0
-    sB = B.r * B.c if B.batch == batch else 0
-    return _Stack(bgemm_dev(ctx, opA, opB, M, N, K, batch, A.d, sA, B.d, sB, alpha=alpha), batch, M, N)
-
-
-def _sum_batch(ctx, A):
-    """sum_b A[b] as a (1 x batch) times (batch x r*c) product."""
-    ones = _Stack(ctx.to_device(np.ones((1, 1, A.batch)), np.complex128), 1, 1, A.batch)
-    s = _mm(ctx, "N", ones, "N", A.rows())
-    return _Stack(s.d, 1, A.r, A.c)
-
-
-def _fold(ctx, lattice, a):
-    """R -> k of a real (ncells, r, c) stack (unnormalised, exp(-ik.R)), result stays on the device."""
-    a = np.ascontiguousarray(a, dtype=np.float64)
-    nk, r, c = a.shape
-    d = fourier.fold_R2k_dev(ctx.to_device(a), lattice.kmesh, 1, r * c)
-    return _Stack(d, nk, r, c)
-
-
-def _quad_trans_inv(ctx, lattice, CL, G, CR=None):
-    """sum_{ij} CL[i]^T G[i - j] CR[j]  =  (1/nk) Re sum_k CL_k^H G_k CR_k."""
-    nk = lattice.ncells
-    Lk = _fold(ctx, lattice, CL)
-    Rk = Lk if CR is None else _fold(ctx, lattice, CR)
-    T = _mm(ctx, "N", _fold(ctx, lattice, G), "N", Rk)
-    res = _mm(ctx, "C", Lk.flat(), "N", T.flat(), alpha=1.0 / nk).get()[0]
-    if np.abs(res.imag).max(initial=0.0) > 1e-7:
-        log.warn("transform_trans_inv: has imag part %s", np.abs(res.imag).max())
-    return np.ascontiguousarray(res.real)
-
-
-def _quad_local(ctx, CL, G, CR=None):
-    """sum_i CL[i]^T G CR[i]."""
-    L = _up(ctx, CL)
-    R = L if CR is None else _up(ctx, CR)
-    T = _mm(ctx, "N", _up(ctx, G), "N", R)
-    return np.ascontiguousarray(_mm(ctx, "T", L.flat(), "N", T.flat()).get()[0].real)
-
-
-def _quad_imp_env(ctx, CL, G, CR=None):
-    """0.5 (sum_i CL[0]^T G[i] CR[i] + sum_i CL[i]^T G[i] CR[0])   (bcs_helper.py:363-370; i - 0 = i)."""
-    L = _up(ctx, CL)
-    R = L if CR is None else _up(ctx, CR)
-    Gd = _up(ctx, G)
-    L0 = _up(ctx, np.asarray(CL)[0])
-    R0 = L0 if CR is None else _up(ctx, np.asarray(CR)[0])
-    s1 = _sum_batch(ctx, _mm(ctx, "N", Gd, "N", R))              # sum_i G[i] CR[i]
-    s2 = _sum_batch(ctx, _mm(ctx, "T", L, "N", Gd))              # sum_i CL[i]^T G[i]
-    r1 = _mm(ctx, "T", L0, "N", s1).get()[0].real
-    r2 = _mm(ctx, "N", s2, "N", R0).get()[0].real
-    return 0.5 * (r1 + r2)
 
 
 # ---------------------------------------------------------------------------------------------

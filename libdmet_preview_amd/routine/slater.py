@@ -6,11 +6,21 @@ The SVD flavour never materialises `lattice.expand(rdm1)` (slater.py:167-171): t
 gathered on the device from the stripe by index arithmetic, factorised (Householder QR + Jacobi SVD,
 dmk_bath_svd), thresholded on the host (`(sigma >= tol_bath).sum()`, slater.py:181-185) and
 orthogonalised / scattered by dmk_bath_assemble (slater.py:200-213, lo/lowdin.py:83-101).
+
+get_emb_Ham (slater.py:320-704) completes the exit of the path: H2 from the DF transform (or the cell-local
+4-index transform for models), H1 = basis^H (hcore + vhf) basis - JK_emb with JK_emb from dmk_jk_s4.
 """
 import numpy as np
 
 from libdmet_preview_amd._lib import lib, mesh3, get_ctx
+from libdmet_preview_amd.basis_transform.eri_transform import get_emb_eri, get_unit_eri
+from libdmet_preview_amd.routine.slater_helper import *       # noqa: F401,F403  (reference: slater.py:35)
+from libdmet_preview_amd.routine.slater_helper import (transform_trans_inv, transform_trans_inv_k, transform_local,
+                                                       transform_imp, transform_eri_local, unit2emb)
+from libdmet_preview_amd.solver.scf import _get_jk, _get_veff
+from libdmet_preview_amd.system import integral
 from libdmet_preview_amd.utils import logger as log
+from libdmet_preview_amd.utils.misc import add_spin_dim
 
 
 def _index_sets(lattice, imp_idx, val_idx, valence_bath):
@@ -146,3 +156,169 @@ def _get_emb_basis_eig(lattice, rdm1, **kwargs):
         bath_assemble_dev(ctx, d_U, nenv, nb, nb, d_virt, orth, d_env, d_imp, nimp, nsites, nimp + nb, d_basis)
         basis[s] = d_basis.get()
     return basis.reshape(spin, ncells, nlo, nimp + nb)
+
+
+# ---------------------------------------------------------------------------------------------
+# embedding Hamiltonian (routine/slater.py:320-704)
+# ---------------------------------------------------------------------------------------------
+
+def transform_h1(H1_k, basis_k):
+    """(spin, nbasis, nbasis) = per spin (1/nk) Re sum_k basis_k^H H1_k basis_k   (slater.py:682-689)."""
+    basis_k = np.asarray(basis_k)
+    spin, nbasis = basis_k.shape[0], basis_k.shape[-1]
+    H1_k = add_spin_dim(H1_k, spin, non_spin_dim=3)
+    H1 = np.empty((spin, nbasis, nbasis))
+    for s in range(spin):
+        H1[s] = transform_trans_inv_k(basis_k[s], H1_k[s])
+    return H1
+
+
+foldRho_k = transform_h1
+
+
+def foldRho(rho, lattice, basis):
+    """Density matrix into the embedding space from the real-space stripe (slater.py:691-701)."""
+    spin, nbasis = rho.shape[0], basis.shape[-1]
+    rdm1_emb = np.empty((spin, nbasis, nbasis))
+    for s in range(spin):
+        rdm1_emb[s] = transform_trans_inv(basis[s], lattice, rho[s])
+    return rdm1_emb
+
+
+def get_veff(rdm1, eri, hyb=1.0, ghf=False, hyb_j=1.0):
+    """Effective potential of the embedding Hamiltonian (slater.py:477-523); rdm1 is spin traced if restricted."""
+    if ghf:
+        raise NotImplementedError("the GHF effective potential is outside the HIP path")
+    rdm1 = np.asarray(rdm1)
+    if rdm1.ndim == 2:
+        rdm1 = rdm1[None]
+    spin = rdm1.shape[0]
+    if hyb == 1.0:      # HF
+        veff = _get_veff(rdm1, eri)
+    elif hyb == 0.0:    # pure DFT, J only
+        vj = _get_jk(rdm1, eri, with_j=True, with_k=False)[0]
+        veff = vj if spin == 1 else vj[0] + vj[1]
+    else:               # hybrid DFT
+        vj, vk = _get_jk(rdm1, eri, with_j=True, with_k=True)
+        veff = vj - vk * (hyb * 0.5) if spin == 1 else vj[0] + vj[1] - vk * hyb
+    return veff
+
+
+def _embHam2e(lattice, basis, vcor, local, int_bath=True, last_aabb=True, **kwargs):
+    """H2_emb (slater.py:372-475): DF transform for ab-initio lattices, cell-local 4-index transform for models."""
+    nbasis, spin = basis.shape[-1], basis.shape[0]
+    if lattice.is_model:
+        LatH2 = lattice.getH2(compact=False, kspace=False)
+        log.eassert(local, "non local bath is outside the HIP path")
+        if lattice.H2_format == 'local':
+            if int_bath:
+                H2 = transform_eri_local(basis, lattice, LatH2)
+            else:
+                H2 = unit2emb(np.asarray((LatH2,) * (spin * (spin + 1) // 2)), nbasis)
+        elif lattice.H2_format == "spin local":
+            if int_bath:
+                raise NotImplementedError
+            H2 = unit2emb(np.asarray(LatH2), nbasis)
+        else:
+            raise NotImplementedError("H2_format %s is outside the HIP path" % lattice.H2_format)
+    else:
+        opts = dict(kscaled_center=kwargs.get("kscaled_center", None), symmetry=lattice.eri_symmetry,
+                    max_memory=kwargs.get("max_memory", None), swap_idx=kwargs.get("swap_idx", None),
+                    t_reversal_symm=kwargs.get("t_reversal_symm", True), incore=kwargs.get("incore", True),
+                    fout=kwargs.get("fout", "H2.h5"), use_mpi=kwargs.get("use_mpi", False))
+        if int_bath:
+            H2 = get_emb_eri(lattice.cell, lattice.df, C_ao_lo=lattice.C_ao_lo, basis=basis, **opts)
+            if last_aabb and isinstance(H2, np.ndarray) and H2.shape[0] == 3:
+                H2 = H2[[0, 2, 1]]
+        else:
+            H2 = get_unit_eri(lattice.cell, lattice.df, C_ao_lo=lattice.C_ao_lo, **opts)
+            if last_aabb and isinstance(H2, np.ndarray) and H2.shape[0] == 3:
+                H2 = H2[[0, 2, 1]]
+            H2 = unit2emb(H2, nbasis)
+    if isinstance(H2, np.ndarray):
+        log.info("H2 memory allocated size = %d MB", H2.size * 8. / 1024 / 1024)
+    return H2
+
+
+def _embHam1e(lattice, basis, vcor, H2_emb, int_bath=True, add_vcor=False, **kwargs):
+    """H1_emb and ovlp_emb (slater.py:525-680), Hartree-Fock branches; sets lattice.JK_core."""
+    for k in ("dft", "qsgw", "vxc_dc"):
+        if kwargs.get(k, False):
+            raise NotImplementedError("%s embedding Hamiltonian is outside the HIP path" % k)
+    spin = basis.shape[0]
+    basis_k = lattice.R2k_basis(basis)
+    hcore_k = lattice.getH1(kspace=True)
+    fock_k = lattice.getFock(kspace=True)
+    ovlp_k = lattice.get_ovlp(kspace=True)
+    JK_imp = lattice.get_JK_imp()
+    if not isinstance(H2_emb, np.ndarray):
+        H2_emb = np.asarray(H2_emb["ccdd"])
+
+    hcore_emb = transform_h1(hcore_k, basis_k)
+    ovlp_emb = transform_h1(ovlp_k, basis_k)
+    if ovlp_emb.ndim == 3 and ovlp_emb.shape[0] == 1:
+        ovlp_emb = ovlp_emb[0]
+
+    if int_bath:
+        rdm1_emb = foldRho_k(lattice.rdm1_lo_k, basis_k)
+        if not lattice.is_model:
+            fock_k = lattice.hcore_lo_k + lattice.vhf_lo_k
+        H1 = transform_h1(fock_k, basis_k)
+        # subtract JK_emb = rho_kl [2 (ij||kl) - (il||jk)], all indices in the embedding basis
+        H1 -= get_veff(rdm1_emb, H2_emb)
+        lattice.JK_core = H1 - hcore_emb
+    else:
+        add_vcor = True
+        if lattice.use_hcore_as_emb_ham:
+            H1 = hcore_emb
+            lattice.JK_core = None
+        else:
+            H1 = transform_h1(fock_k, basis_k)
+            if JK_imp is not None:
+                JK_imp = np.asarray(JK_imp)
+                if JK_imp.ndim == 2:
+                    JK_emb = np.asarray([transform_imp(basis[s], lattice, JK_imp) for s in range(spin)])
+                else:
+                    JK_emb = np.asarray([transform_imp(basis[s], lattice, JK_imp[s]) for s in range(spin)])
+            else:
+                JK_emb = get_veff(foldRho_k(lattice.rdm1_lo_k, basis_k), H2_emb)
+            H1 -= JK_emb
+            lattice.JK_core = H1 - hcore_emb
+
+    if add_vcor:
+        log.eassert(vcor.islocal(), "nonlocal correlation potential cannot be treated in this routine")
+        for s in range(spin):
+            H1[s] += transform_local(basis[s], lattice, vcor.get()[s])
+            if not "fitting" in kwargs or not kwargs["fitting"]:
+                H1[s] -= transform_imp(basis[s], lattice, vcor.get()[s])
+    return H1, ovlp_emb
+
+
+def get_emb_Ham(lattice, basis, vcor, local=True, **kwargs):
+    """
+    Embedding Hamiltonian (slater.py:320-370): two-body part first (JK_emb needs it), then the one-body part.
+
+    Kwargs: incore, H2_given (ndarray), int_bath, add_vcor, fitting, and the ERI-transform options.
+    Returns (ImpHam, None) with ImpHam an integral.Integral.
+    """
+    basis = np.asarray(basis)
+    spin, nbasis = basis.shape[0], basis.shape[-1]
+    log.info("Two-body part")
+    H2_given = kwargs.get("H2_given", None)
+    if H2_given is None:
+        if kwargs.get("H2_fname", None) is not None:
+            raise NotImplementedError("H2_fname (HDF5) is not available; pass H2_given")
+        H2 = _embHam2e(lattice, basis, vcor, local, **kwargs)
+    else:
+        log.debug(1, "Using specified H2 array.")
+        H2 = H2_given
+    log.info("One-body part")
+    H1, ovlp_emb = _embHam1e(lattice, basis, vcor, H2, **kwargs)
+    H0 = lattice.getH0()
+    if isinstance(H2, np.ndarray):
+        H2 = {"ccdd": H2}
+    ImpHam = integral.Integral(nbasis, spin == 1, False, H0, {"cd": H1}, H2, ovlp=ovlp_emb)
+    return ImpHam, None
+
+
+embHam = get_emb_Ham

@@ -72,7 +72,13 @@ class Lattice(object):
         self.hcore_lo_k = self.fock_lo_k = self.rdm1_lo_k = None
         self.hcore_lo_R = self.fock_lo_R = self.rdm1_lo_R = None
         self.ovlp_lo_k = self.ovlp_lo_R = None
+        self.vhf_lo_k = None
         self.C_ao_lo = None
+        self.df = None
+        self.JK_imp = self.JK_core = self.Ham = None
+        self.eri_symmetry = 4
+        self.H2_format = None
+        self._H2_local = None
         self.H0 = 0.0
         self.use_hcore_as_emb_ham = False
         self.is_model = False
@@ -223,4 +229,38 @@ class Lattice(object):
         return self.H0
 
     def get_ovlp(self, kspace=True):
+        """LO overlap; identity in the (orthonormal) LO basis unless one was installed (lattice.py:728-732)."""
+        if self.ovlp_lo_k is None:
+            ov_R = np.zeros((self.ncells, self.nscsites, self.nscsites))
+            ov_R[0] = np.eye(self.nscsites)
+            self.ovlp_lo_R = ov_R
+            self.ovlp_lo_k = np.asarray([np.eye(self.nscsites, dtype=np.complex128)] * self.ncells)
         return self.ovlp_lo_k if kspace else self.ovlp_lo_R
+
+    def getImpJK(self):
+        """lattice.py:754-760."""
+        if self.JK_imp is not None:
+            return self.JK_imp
+        elif self.Ham is not None:
+            return self.Ham.getImpJK()
+        return None
+
+    get_JK_imp = getImpJK
+
+    def get_JK_core(self):
+        return self.JK_core
+
+    def getH2(self, kpts=None, compact=False, kspace=True, use_Ham=False):
+        """Model lattices: the cell-local two-body tensor installed by set_H2_local (lattice.py:738-751)."""
+        if kspace:
+            raise NotImplementedError
+        if self._H2_local is None:
+            raise ValueError("no local H2 installed; call set_H2_local")
+        return self._H2_local
+
+    def set_H2_local(self, H2, H2_format="local"):
+        """Install a cell-local ERI ((spin_pair,) nscsites^4) and mark the lattice as a model."""
+        self._H2_local = np.asarray(H2)
+        self.H2_format = H2_format
+        self.eri_symmetry = 1
+        self.is_model = True
