@@ -97,13 +97,27 @@ __global__ __launch_bounds__(NT) void jk_j_kernel(long long npair, const double 
     }
 }
 
-__global__ void jk_colsum_kernel(long long npair, int nblk, const double *__restrict__ part, double *__restrict__ ycol) {
-    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < npair;
-         c += (long long)gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += part[(long long)b * npair + c];
-        ycol[c] = s;
+// ycol[c] = sum_b part[b][c]: 64 columns per workgroup, wave w adds the blocks b = w, w+4, ... (coalesced 512 B
+// rows, four independent chains), combined in a fixed order
+__global__ __launch_bounds__(NT) void jk_colsum_kernel(long long npair, int nblk, const double *__restrict__ part,
+                                                       double *__restrict__ ycol) {
+    __shared__ double red[NW][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < npair) {
+        int b = wave;
+        for (; b + 3 * NW < nblk; b += 4 * NW) {
+            s0 += part[(long long)b * npair + c];
+            s1 += part[(long long)(b + NW) * npair + c];
+            s2 += part[(long long)(b + 2 * NW) * npair + c];
+            s3 += part[(long long)(b + 3 * NW) * npair + c];
+        }
+        for (; b < nblk; b += NW) s0 += part[(long long)b * npair + c];
     }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < npair) ycol[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // One workgroup per packed row r = pair(i, j).  Yi[r][:] = M dm[i,:],  Yj[r][:] = M dm[j,:],  M[k][l] = E[r][pair(k,l)].
@@ -136,28 +150,58 @@ __global__ __launch_bounds__(NT) void jk_k_kernel(int n, const double *__restric
         yj[m] = 0.0;
     }
     const double *Er = E + r * ld;
-    for (int k = wave; k < n; k += NW) {
-        const double *row = Er + (long long)k * (k + 1) / 2;
-        const double xik = xi[k], xjk = xj[k];
-        double pa = 0.0, pb = 0.0;
+    // rows k and n-1-k of the triangle hold n+1 elements together: every wave iteration moves the same number of
+    // bytes and has both rows' loads in flight before the first use
+    const int nhalf = (n + 1) / 2;
+    double v0[NM], v1[NM], w0n[NM], w1n[NM];
+    auto load_pair = [&](int p, double (&a0)[NM], double (&a1)[NM]) {
+        const int k0 = p, k1 = n - 1 - p;
+        const double *row0 = Er + (long long)k0 * (k0 + 1) / 2;
+        const double *row1 = Er + (long long)k1 * (k1 + 1) / 2;
+        const bool two = k1 != k0;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int l = lane + 64 * m;
-            if (l <= k) {
-                const double v = row[l];
-                yi[m] = fma(v, xik, yi[m]);            // y[l] += M[k][l] x[k]   (includes the diagonal once)
-                yj[m] = fma(v, xjk, yj[m]);
-                if (l < k) {
-                    pa = fma(v, xli[m], pa);           // y[k] += M[k][l] x[l]
-                    pb = fma(v, xlj[m], pb);
-                }
+            a0[m] = (p < nhalf && l <= k0) ? row0[l] : 0.0;
+            a1[m] = (p < nhalf && two && l <= k1) ? row1[l] : 0.0;
+        }
+    };
+    load_pair(wave, v0, v1);
+    for (int p = wave; p < nhalf; p += NW) {
+        const int k0 = p, k1 = n - 1 - p;
+        const bool two = k1 != k0;
+        load_pair(p + NW, w0n, w1n);                       // next pair's rows in flight while this one is reduced
+        const double xi0 = xi[k0], xj0 = xj[k0], xi1 = xi[k1], xj1 = xj[k1];
+        double pa0 = 0.0, pb0 = 0.0, pa1 = 0.0, pb1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int l = lane + 64 * m;
+            yi[m] = fma(v0[m], xi0, yi[m]);                // y[l] += M[k][l] x[k]   (includes the diagonal once)
+            yj[m] = fma(v0[m], xj0, yj[m]);
+            yi[m] = fma(v1[m], xi1, yi[m]);
+            yj[m] = fma(v1[m], xj1, yj[m]);
+            const double w0 = (l < k0) ? v0[m] : 0.0, w1 = (l < k1) ? v1[m] : 0.0;
+            pa0 = fma(w0, xli[m], pa0);                    // y[k] += M[k][l] x[l],  l < k
+            pb0 = fma(w0, xlj[m], pb0);
+            pa1 = fma(w1, xli[m], pa1);
+            pb1 = fma(w1, xlj[m], pb1);
+        }
+        pa0 = wave_sum(pa0);
+        pb0 = wave_sum(pb0);
+        pa1 = wave_sum(pa1);
+        pb1 = wave_sum(pb1);
+        if (lane == 0) {
+            ai[k0] = pa0;
+            aj[k0] = pb0;
+            if (two) {
+                ai[k1] = pa1;
+                aj[k1] = pb1;
             }
         }
-        pa = wave_sum(pa);
-        pb = wave_sum(pb);
-        if (lane == 0) {
-            ai[k] = pa;
-            aj[k] = pb;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            v0[m] = w0n[m];
+            v1[m] = w1n[m];
         }
     }
 #pragma unroll
@@ -259,7 +303,8 @@ int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *
         DMK_CHECK_LAUNCH(ctx);
         if (dm_row) hipLaunchKernelGGL(jk_unpack_kernel, dim3(gsq), dim3(256), 0, ctx->stream, n, yrow, vj_row);
         if (dm_col) {
-            hipLaunchKernelGGL(jk_colsum_kernel, dim3(gsmall), dim3(256), 0, ctx->stream, npair, nblk, part, ycol);
+            hipLaunchKernelGGL(jk_colsum_kernel, dim3((unsigned)((npair + 63) / 64)), dim3(NT), 0, ctx->stream, npair,
+                               nblk, part, ycol);
             hipLaunchKernelGGL(jk_unpack_kernel, dim3(gsq), dim3(256), 0, ctx->stream, n, ycol, vj_col);
         }
         DMK_CHECK_LAUNCH(ctx);

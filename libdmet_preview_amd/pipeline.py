@@ -4,6 +4,7 @@ Device-resident embedding-construction iteration on synthetic k-sampled tensors:
     Fock_k + vcor --eigh--> (ew, ev) --occupations--> rho_k --k2R--> rho_R   (routine/mfd.py:235-360)
     rho_R --Schmidt bath--> basis = C_lo_eo                                   (routine/slater.py:98-220)
     basis --R2k, C_ao_lo--> C_ao_emb --DF half transform + contraction--> ERI (eri_transform.py:235-399)
+    basis, ERI, rho --one-body folds + ERI x density--> H1_emb = fock_emb - JK_emb      (routine/slater.py:525-680)
 
 Inputs live in HBM before the iteration starts; only scalars and O(nk*nlo) vectors (eigenvalues,
 occupations, singular values) cross PCIe.  Multi-GPU (one process per GPU):
@@ -19,6 +20,7 @@ from libdmet_preview_amd.basis_transform import eri_transform as et
 from libdmet_preview_amd.basis_transform.make_basis import bgemm_dev
 from libdmet_preview_amd.parallel import dist
 from libdmet_preview_amd.routine import mfd, slater
+from libdmet_preview_amd.solver import scf
 from libdmet_preview_amd.system import fourier
 from libdmet_preview_amd.system.lattice import _UnitCell
 
@@ -39,6 +41,7 @@ class SyntheticSystem(object):
         FR = synth.make_fock_R(self.mesh, nlo, spin=spin, seed=seed)
         self.Fock_R = FR
         self.d_Fock_k = ctx.to_device(synth.fold_R2k(FR, self.mesh), np.complex128)       # (spin, nk, n, n)
+        self.hcore_scale = 0.5                        # synthetic hcore = 0.5 Fock (vhf = the other half), as in G3
         v = np.zeros((2, nlo, nlo))
         self.vcor = v
         self.d_vcor = ctx.to_device(v[:spin])
@@ -166,6 +169,43 @@ def c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers=None):
     return d_C
 
 
+def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None):
+    """One-body part of the embedding Hamiltonian (slater.py:525-606, interacting bath, HF):
+    H1 = basis^H fock basis - JK_emb(rdm1_emb, ERI), JK_core = H1 - hcore_emb.  Everything is replicated
+    (every rank holds rho_R and, after the all-reduce, the ERI).  Returns host (spin, nemb, nemb) arrays."""
+    timers = {} if timers is None else timers
+    n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
+    t = time.perf_counter()
+    d_bk = fourier.fold_R2k_dev(d_basis.reshape(spin, nk, n * nemb), sysm.mesh, spin, n * nemb)
+    d_rho_k = fourier.fold_R2k_dev(d_rhoR.reshape(spin, nk, n * n), sysm.mesh, spin, n * n)
+
+    def fold(d_op_k):
+        """(spin, nemb, nemb) real:  (1/nk) Re sum_k B_k^H op_k B_k."""
+        d_T = bgemm_dev(ctx, "N", "N", n, nemb, n, spin * nk, d_op_k, n * n, d_bk, n * nemb)
+        d_R = bgemm_dev(ctx, "C", "N", nemb, nemb, nk * n, spin, d_bk, nk * n * nemb, d_T, nk * n * nemb, alpha=1.0 / nk)
+        return np.ascontiguousarray(d_R.get().reshape(spin, nemb, nemb).real)
+
+    fock_emb = fold(sysm.d_Fock_k)
+    rdm1_emb = fold(d_rho_k)
+    hcore_emb = sysm.hcore_scale * fock_emb
+    t = _stage(ctx, timers, "emb_h1", t)
+    npair = nemb * (nemb + 1) // 2
+    blk = lambda b: eri_dev.offset(b * npair * npair, (npair, npair))
+    if spin == 1:
+        d_dm = ctx.to_device(2.0 * rdm1_emb[0])                         # restricted: spin-traced density (slater.py:481)
+        vj, _, vk = scf.jk_dev(ctx, nemb, blk(0), d_dm, None, d_dm)
+        veff = (vj.get() - 0.5 * vk.get())[None]
+    else:
+        d_dm = ctx.to_device(rdm1_emb)
+        # the transform leaves the blocks in (aa, ab, bb) order (eri_transform.py:465-467)
+        (vj_s, vj_x), vk = scf.jk_blocks_dev(ctx, nemb, blk(0), blk(2), blk(1), d_dm)
+        vj = np.asarray([vj_s[0].get() + vj_x[0].get(), vj_s[1].get() + vj_x[1].get()])
+        veff = vj - np.asarray([vk[0].get(), vk[1].get()])
+    H1 = fock_emb - veff
+    _stage(ctx, timers, "emb_jk", t)
+    return {"H1": H1, "JK_core": H1 - hcore_emb, "rdm1_emb": rdm1_emb, "veff": veff, "fock_emb": fock_emb}
+
+
 def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_blocks_per_kL=None):
     """DF half transform + contraction over this rank's kL shard; returns (nblocks, flops_half, flops_contract)."""
     timers = {} if timers is None else timers
@@ -183,7 +223,8 @@ def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_bloc
     return nblk, fh, fc
 
 
-def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per_kL=None, allreduce_eri=True):
+def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per_kL=None, allreduce_eri=True,
+              emb_ham=True):
     """One embedding-construction pass.  Returns a dict with the products and per-stage seconds."""
     timers = {} if timers is None else timers
     d_rhoR, mf = mean_field_stage(ctx, sysm, timers)
@@ -201,4 +242,6 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
             dist.all_reduce_sum_dev(eri_dev)
             _stage(ctx, timers, "allreduce_eri", t)
         out.update({"C_ao_emb": d_C, "eri": eri_dev, "nblocks": nblk, "flops_half": fh, "flops_contract": fc})
+        if emb_ham:
+            out["emb_ham"] = emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers)
     return out
