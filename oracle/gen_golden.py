@@ -608,11 +608,111 @@ def gen_G8():
     print("G8 done")
 
 
+def _fit_case(name, mesh, nlo, spin, val, seed):
+    """A small lattice + a perturbed target density for the vcor fit."""
+    from libdmet.routine import slater, mfd
+    nk = int(np.prod(mesh))
+    L = _duck_lattice(mesh, nlo, val=val, virt=[i for i in range(nlo) if i > max(val)],
+                      core=[i for i in range(nlo) if i < min(val)])
+    FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=seed)
+    Fk = synth.fold_R2k(FR, mesh)
+    sq = (lambda x: x[0]) if spin == 1 else (lambda x: x)
+    L.fock_lo_k = L.hcore_lo_k = sq(Fk)
+    L.fock_lo_R = L.hcore_lo_R = sq(FR)
+    SR = np.zeros((nk, nlo, nlo))
+    SR[0] = np.eye(nlo)
+    L.ovlp_lo_k = synth.fold_R2k(SR[None], mesh)[0]
+    L.JK_imp = L.Ham = None
+    v0 = _Vcor(np.zeros((2, nlo, nlo)))
+    rhoT, mu, E, res = mfd.HF(L, v0, 0.5, spin == 1, beta=np.inf, ires=True)
+    basis = slater.get_emb_basis(L, rhoT)
+    rng = np.random.default_rng(seed + 1)
+    target = slater.foldRho_k(res["rho_k"], L.R2k_basis(basis))
+    noise = 0.05 * rng.standard_normal(target.shape)
+    target = target + 0.5 * (noise + noise.transpose(0, 2, 1))
+    return L, FR, basis, target
+
+
+def gen_G9():
+    """vcor least-squares fit in the embedding space (section 8f rank 2)."""
+    from libdmet.routine import slater, fit as rfit
+    from libdmet.dmet import Hubbard
+    shim.patch_scf()
+    out = {}
+    # VcorLocal: every branch of dmet/Hubbard.py:599-770
+    rng = np.random.default_rng(2)
+    for tag, kw in [("r", dict(restricted=True, bogoliubov=False)), ("u", dict(restricted=False, bogoliubov=False)),
+                    ("rb", dict(restricted=True, bogoliubov=True)), ("rbg", dict(restricted=True, bogoliubov=True, ghf=True)),
+                    ("ub", dict(restricted=False, bogoliubov=True)),
+                    ("ubr", dict(restricted=False, bogoliubov=True, bogo_res=True))]:
+        for itag, idx in [("all", None), ("sub", [1, 3, 4])]:
+            v = Hubbard.VcorLocal(nscsites=5, idx_range=idx, **kw)
+            p = rng.standard_normal(v.length())
+            v.update(p)
+            key = "vcor/%s_%s" % (tag, itag)
+            out[key + "/param"], out[key + "/value"], out[key + "/grad"] = p, v.get(), v.gradient()
+            if hasattr(v, "diag_indices"):
+                out[key + "/diag"] = np.asarray(v.diag_indices())
+    # the fit objective, its gradients and the converged fit
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    cases = [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3], 11), ("rhf_411", (4, 1, 1), 5, 1, [1, 2, 3], 12),
+             ("uhf_222", (2, 2, 2), 3, 2, [0, 1, 2], 13)]
+    for name, mesh, nlo, spin, val, seed in cases:
+        L, FR, basis, target = _fit_case(name, mesh, nlo, spin, val, seed)
+        nb = basis.shape[-1]
+        out[name + "/mesh"], out[name + "/val"], out[name + "/Fock_R"] = np.array(mesh), np.array(val), FR
+        out[name + "/basis"], out[name + "/target"] = basis, target
+        runs = [("t0", np.inf, dict()), ("ft", 15.0, dict()), ("ft_fixmu", 15.0, dict(fix_mu=True, mu0=0.1)),
+                ("t0_imp", np.inf, dict(imp_fit=True)), ("t0_det", np.inf, dict(det=True)),
+                ("t0_idx", np.inf, dict(imp_idx=[0, 1], det_idx=[nb - 1])),
+                ("t0_rdg", np.inf, dict(remove_diag_grad=True))]
+        for tag, beta, kw in runs:
+            v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            vfit, e0, e1 = slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=40, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            rp = np.random.default_rng(5)
+            P = 0.1 * rp.standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](p.copy()) for p in P])
+            out[key + "/probe_grad"] = np.asarray([captured["fgrad"](p.copy()) for p in P])
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        out[name + "/dV_dparam"] = slater.get_dV_dparam(v, basis, L.R2k_basis(basis), L)
+        out[name + "/dV_dparam_full"] = slater.get_dV_dparam(v, basis, L.R2k_basis(basis), L, compact=False)
+    slater.minimize = real_minimize
+    # the optimiser drivers on analytic objectives (host control flow)
+    A = np.diag(np.arange(1.0, 7.0)) + 0.3 * np.ones((6, 6))
+    b = np.arange(6.0) - 2.0
+    quad = lambda x: float(np.sqrt(0.5 * x @ A @ x - b @ x + 20.0))
+    qgrad = lambda x: (A @ x - b) / (2.0 * quad(x))
+    rosen = lambda x: float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2) + 1e-3)
+    rgrad = lambda x: np.concatenate([[0.0], 200.0 * (x[1:] - x[:-1] ** 2)]) + \
+        np.concatenate([-400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1]), [0.0]])
+    out["opt/A"], out["opt/b"] = A, b
+    for tag, fn, fg, x0, kw in [("quad_cg", quad, qgrad, np.zeros(6), dict(method="CG")),
+                                ("quad_cg_num", quad, None, np.zeros(6), dict(method="CG")),
+                                ("quad_sd", quad, qgrad, np.zeros(6), dict(method="SD")),
+                                ("rosen_cg", rosen, rgrad, np.array([-0.5, 0.4, 0.3]), dict(method="CG", MaxIter=25)),
+                                ("quad_bfgs", quad, qgrad, np.zeros(6), dict(method="BFGS"))]:
+        mi = kw.pop("MaxIter", 60)
+        x, y, pat, gn = rfit.minimize(fn, x0.copy(), mi, fg, **kw)
+        out["opt/%s_x" % tag], out["opt/%s_res" % tag] = x, np.asarray([y, pat, gn])
+        out["opt/%s_x0" % tag] = x0
+    np.savez_compressed(os.path.join(GOLD, "G9_vcorfit.npz"), **out)
+    print("G9 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
     for g in which:
         globals()["gen_" + g]()
 

@@ -1,0 +1,282 @@
+"""
+oracle/restate_fit.py -- CPU restatement (numpy/scipy) of SURVEY.md section 8(f) rank 2: the correlation-potential
+least-squares fit in the embedding space,
+
+  Hubbard.VcorLocal            dmet/Hubbard.py:551-786     local vcor parametrisation (evaluate / gradient / diag_indices)
+  slater.get_dV_dparam         routine/slater.py:851-907   (local branch, transform_local_sparseH slater_helper.py:91-100)
+  slater.FitVcorEmb            routine/slater.py:909-1329  errfunc, gradfunc (T = 0), gradfunc_ft (finite T)
+  ftsystem.get_dw_dv           routine/ftsystem.py:151-213
+
+The optimiser driver (routine/fit.py + fit_helper.py: Polak-Ribiere CG with a bounded scalar line search) is host
+control flow; it is pinned on the product side directly against iterates captured from the reference
+(tests/test_host_fit.py).
+
+TEST INFRASTRUCTURE ONLY.  Pinned against the reference through tests/golden/G9_vcorfit.npz
+(oracle/gen_golden.py gen_G9: the reference's own FitVcorEmb closures captured at fixed parameter vectors).
+"""
+import itertools as it
+from math import sqrt
+
+import numpy as np
+import scipy.linalg as la
+
+from oracle.restate import R2k, assignocc
+from oracle.restate_ham import transform_h1
+
+ZERO_TOL = 1e-10
+
+
+# ---------------------------------------------------------------------------------------------
+# VcorLocal (dmet/Hubbard.py:551-786)
+# ---------------------------------------------------------------------------------------------
+
+def triu_diag_indices(n):
+    return np.cumsum([0] + list(range(n, 1, -1)))
+
+
+class VcorLocal(object):
+    """Local correlation potential: symmetric (spin, nscsites, nscsites) blocks on idx_range, optional pairing block."""
+
+    def __init__(self, restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, ghf=False):
+        self.restricted, self.bogoliubov, self.bogo_res, self.ghf = restricted, bogoliubov, bogo_res, ghf
+        self.nscsites = nscsites
+        self.idx_range = list(range(nscsites)) if idx_range is None else list(idx_range)
+        nidx = len(self.idx_range)
+        ntri = nidx * (nidx + 1) // 2
+        self.nV = ntri if restricted else 2 * ntri
+        if not bogoliubov:
+            self.nD = 0
+        elif restricted or bogo_res:
+            self.nD = ntri
+        else:
+            self.nD = nidx * nidx
+        self.sym_pairs = list(it.combinations_with_replacement(self.idx_range, 2))
+        self.all_pairs = list(it.product(self.idx_range, repeat=2))
+        self.param = np.zeros(self.nV + self.nD)
+        self.value = self.evaluate()
+
+    def length(self):
+        return self.nV + self.nD
+
+    def islocal(self):
+        return True
+
+    is_local = islocal
+
+    def update(self, param):
+        self.param = param
+        self.value = self.evaluate()
+
+    def get(self, i=0, kspace=True):
+        return self.value if (kspace or i == 0) else np.zeros_like(self.value)
+
+    def _terms(self):
+        """[(param offset, spin block, sign, pair list, symmetric?)] of every branch of Hubbard.py:599-770."""
+        nV = self.nV
+        if not self.bogoliubov:
+            if self.restricted:
+                return [(0, 0, 1, self.sym_pairs, True), (0, 1, 1, self.sym_pairs, True)]
+            return [(0, 0, 1, self.sym_pairs, True), (nV // 2, 1, 1, self.sym_pairs, True)]
+        if self.restricted:
+            return [(0, 0, 1, self.sym_pairs, True), (0, 1, -1 if self.ghf else 1, self.sym_pairs, True),
+                    (nV, 2, 1, self.sym_pairs, True)]
+        if self.bogo_res:
+            return [(0, 0, 1, self.sym_pairs, True), (nV // 2, 1, 1, self.sym_pairs, True), (nV, 2, 1, self.sym_pairs, True)]
+        return [(0, 0, 1, self.sym_pairs, True), (nV // 2, 1, 1, self.sym_pairs, True), (nV, 2, 1, self.all_pairs, False)]
+
+    def evaluate(self):
+        assert self.param.shape == (self.length(),)
+        V = np.zeros((3 if self.bogoliubov else 2, self.nscsites, self.nscsites))
+        for off, blk, sign, pairs, sym in self._terms():
+            for idx, (i, j) in enumerate(pairs):
+                V[blk, i, j] = sign * self.param[idx + off]
+                if sym:
+                    V[blk, j, i] = sign * self.param[idx + off]
+        return V
+
+    def gradient(self):
+        g = np.zeros((self.length(), 3 if self.bogoliubov else 2, self.nscsites, self.nscsites))
+        for off, blk, sign, pairs, sym in self._terms():
+            for idx, (i, j) in enumerate(pairs):
+                g[idx + off, blk, i, j] = sign
+                if sym:
+                    g[idx + off, blk, j, i] = sign
+        return g
+
+    def diag_indices(self):
+        idx = triu_diag_indices(len(self.idx_range))
+        if self.restricted:
+            return [idx]
+        return [idx, np.asarray(idx) + self.nV // 2]
+
+
+# ---------------------------------------------------------------------------------------------
+# dV / dparam (slater.py:851-907, local branch)
+# ---------------------------------------------------------------------------------------------
+
+def transform_local_sparseH(basis, H, thr=1e-7):
+    """slater_helper.py:91-100: sum over the entries |H[j,k]| > thr of basis[:, j]^T basis[:, k] H[j,k]."""
+    nb = basis.shape[-1]
+    res = np.zeros((nb, nb))
+    for j, k in zip(*np.nonzero(abs(H) > thr)):
+        res += np.dot(basis[:, j].T, basis[:, k]) * H[j, k]
+    return res
+
+
+def get_dV_dparam(vcor, basis, compact=True):
+    spin, nk, nlo, nb = basis.shape
+    g = vcor.gradient()
+    tril = np.tril_indices(nb)
+    out = np.empty((vcor.length(), spin, nb * (nb + 1) // 2)) if compact else np.empty((vcor.length(), spin, nb, nb))
+    for s in range(spin):
+        for ip in range(vcor.length()):
+            m = transform_local_sparseH(basis[s], g[ip, s])
+            out[ip, s] = m[tril] if compact else m
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# finite-T response (ftsystem.py:151-213)
+# ---------------------------------------------------------------------------------------------
+
+def fermi_smearing_occ(mu, mo_energy, beta):
+    mo_energy = np.asarray(mo_energy)
+    mu = np.asarray(mu).reshape(-1, *([1] * (mo_energy.ndim - 1)))
+    de = beta * (mo_energy - mu)
+    occ = np.zeros_like(mo_energy)
+    idx = de < 100
+    occ[idx] = 1.0 / (np.exp(de[idx]) + 1.0)
+    return occ
+
+
+def get_dw_dv(mo_energy, mo_coeff, drho, mu, beta, fix_mu=True, compact=False, fit_idx=None):
+    spin, _, norb = mo_coeff.shape
+    if fit_idx is None:
+        fit_idx = range(norb)
+    fit_idx = list(fit_idx)
+    f = fermi_smearing_occ(mu, mo_energy, beta)
+    h = 1.0 - f
+    dw_dv = np.zeros((spin, norb, norb))
+    for s in range(spin):
+        de = mo_energy[s, :, None] - mo_energy[s]
+        zero = np.abs(de) < ZERO_TOL
+        inv = np.zeros_like(de)
+        inv[~zero] = 1.0 / de[~zero]
+        K = inv * (f[s, :, None] - f[s])
+        K[zero] = (f[s, :, None] * h[s])[zero] * (-beta)
+        C = mo_coeff[s]
+        tmp = (C[fit_idx].T @ (2.0 * drho[s]) @ C[fit_idx]) * K
+        dw_dv[s] = C @ tmp @ C.T
+        if not fix_mu:
+            ff = f[s] * h[s]
+            fsum = np.sum(ff)
+            if abs(fsum) > ZERO_TOL:
+                drho_dmu = (C * ff) @ C.T
+                dw_dmu = np.einsum('ij,ij->', drho[s], drho_dmu[fit_idx][:, fit_idx]) * 2.0 * beta
+                dw_dv[s] += drho_dmu * (dw_dmu / fsum)
+    if compact:
+        tl = np.tril_indices(norb)
+        packed = np.asarray([m[tl] for m in dw_dv]) * 2.0
+        dg = np.cumsum([0] + list(range(2, norb + 1)))
+        packed[:, dg] *= 0.5
+        return packed
+    return dw_dv
+
+
+# ---------------------------------------------------------------------------------------------
+# the fit objective and its gradients (slater.py:1040-1215)
+# ---------------------------------------------------------------------------------------------
+
+class EmbFit(object):
+    """errfunc / gradfunc of FitVcorEmb for given (rho target, fock_k, ovlp_k, basis, vcor)."""
+
+    def __init__(self, rho, kmesh, basis, vcor, beta, fock_k, ovlp_k, nelec, imp_idx=None, det_idx=None,
+                 mu0=None, fix_mu=False, tol_deg=1e-3, remove_diag_grad=False):
+        self.spin, self.nb = basis.shape[0], basis.shape[-1]
+        spin, nb = self.spin, self.nb
+        self.beta, self.nelec, self.mu0, self.fix_mu, self.tol_deg = beta, nelec, mu0, fix_mu, tol_deg
+        self.vcor, self.remove_diag_grad = vcor, remove_diag_grad
+        if imp_idx is None and det_idx is None:
+            imp_idx, det_idx = list(range(nb)), []
+        imp_idx, det_idx = list(imp_idx or []), list(det_idx or [])
+        self.fit_idx = imp_idx + det_idx
+        nimp, nidx = len(imp_idx), len(self.fit_idx)
+        self.imp_mesh, self.det_mesh = np.ix_(imp_idx, imp_idx), (det_idx, det_idx)
+        self.imp_fill, self.det_fill = (slice(nimp), slice(nimp)), (range(nimp, nidx), range(nimp, nidx))
+        basis_k = np.asarray([R2k(basis[s], kmesh) for s in range(spin)])
+        fock_k = np.asarray(fock_k)
+        if fock_k.ndim == 3:
+            fock_k = fock_k[None]
+        self.embH1 = transform_h1(fock_k, basis_k)
+        self.ovlp = transform_h1(ovlp_k, basis_k)
+        self.dV = get_dV_dparam(vcor, basis, compact=True)
+        self.tril = np.tril_indices(nb)
+        self.target = np.zeros((spin, nidx, nidx))
+        for s in range(spin):
+            self.target[s][self.imp_fill] = rho[s][self.imp_mesh]
+            self.target[s][self.det_fill] = rho[s][self.det_mesh]
+
+    def Vemb(self, param):
+        tmp = np.tensordot(param, self.dV, axes=(0, 0))
+        v = np.zeros((self.spin, self.nb, self.nb))
+        for s in range(self.spin):
+            v[s][self.tril] = tmp[s]
+        return v
+
+    def _solve(self, param):
+        spin, nb = self.spin, self.nb
+        H = self.embH1 + self.Vemb(param)
+        ew, ev = np.empty((spin, nb)), np.empty((spin, nb, nb))
+        for s in range(spin):
+            ew[s], ev[s] = la.eigh(H[s], self.ovlp[s])
+        if not self.fix_mu:
+            ne = self.nelec
+            mu = (0.5 * (ew[0][ne - 1] + ew[0][ne]) if spin == 1 else
+                  [0.5 * (ew[s][ne[s] - 1] + ew[s][ne[s]]) for s in range(2)])
+        else:
+            mu = self.mu0
+        occ, mu, _ = assignocc(ew, self.nelec, self.beta, mu, fix_mu=self.fix_mu, thr_deg=self.tol_deg)
+        rho1 = np.zeros_like(self.target)
+        for s in range(spin):
+            tmp = np.dot(ev[s] * occ[s], ev[s].T)
+            rho1[s][self.imp_fill] = tmp[self.imp_mesh]
+            rho1[s][self.det_fill] = tmp[self.det_mesh]
+        return ew, ev, occ, mu, rho1 - self.target
+
+    def errfunc(self, param):
+        drho = self._solve(param)[4]
+        return la.norm(drho) / sqrt(self.spin)
+
+    def _finish(self, res):
+        if self.remove_diag_grad:
+            for s in range(self.spin):
+                d = self.vcor.diag_indices()[s]
+                res[d] -= np.average(res[d])
+        return res
+
+    def gradfunc(self, param):
+        """T = 0 analytic gradient (slater.py:1096-1154)."""
+        spin, nb = self.spin, self.nb
+        ew, ev, occ, mu, drho = self._solve(param)
+        val = la.norm(drho)
+        nocc = int(np.round(np.sum(occ) / spin))
+        dw = np.empty((spin, nb * (nb + 1) // 2))
+        dg = (np.arange(nb), np.arange(nb))
+        for s in range(spin):
+            eo, evirt = ew[s, :nocc], ew[s, nocc:]
+            co, cv = ev[s][:, :nocc], ev[s][:, nocc:]
+            e_mn = 1.0 / (-evirt.reshape((-1, 1)) + eo)
+            t = (cv[self.fit_idx].T @ drho[s] @ co[self.fit_idx]) * e_mn / (val * sqrt(spin))
+            full = cv @ t @ co.T
+            full = (full + full.T) * 2.0
+            full[dg] *= 0.5
+            dw[s] = full[self.tril]
+        return self._finish(np.tensordot(self.dV, dw, axes=((1, 2), (0, 1))))
+
+    def gradfunc_ft(self, param):
+        """finite-T analytic gradient (slater.py:1156-1197)."""
+        ew, ev, occ, mu, drho = self._solve(param)
+        val = la.norm(drho)
+        dw_dv = get_dw_dv(ew, ev, drho, mu, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=True)
+        res = self.dV.reshape(self.dV.shape[0], -1).dot(dw_dv.ravel()) / (2.0 * val * sqrt(self.spin))
+        return self._finish(res)

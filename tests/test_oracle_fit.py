@@ -1,0 +1,80 @@
+"""
+Pins oracle/restate_fit.py (vcor least-squares fit in the embedding space) against
+tests/golden/G9_vcorfit.npz: the reference's VcorLocal, get_dV_dparam and the errfunc / gradfunc closures of
+FitVcorEmb captured at fixed parameter vectors under oracle/shim.py.  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import restate as R
+from oracle import restate_fit as F
+
+CASES = ["uhf_231", "rhf_411", "uhf_222"]
+VC = {"r": dict(restricted=True, bogoliubov=False), "u": dict(restricted=False, bogoliubov=False),
+      "rb": dict(restricted=True, bogoliubov=True), "rbg": dict(restricted=True, bogoliubov=True, ghf=True),
+      "ub": dict(restricted=False, bogoliubov=True), "ubr": dict(restricted=False, bogoliubov=True, bogo_res=True)}
+
+
+def fit_runs(nb):
+    return [("t0", np.inf, dict()), ("ft", 15.0, dict()), ("ft_fixmu", 15.0, dict(fix_mu=True, mu0=0.1)),
+            ("t0_imp", np.inf, dict(imp_fit=True)), ("t0_det", np.inf, dict(det=True)),
+            ("t0_idx", np.inf, dict(imp_idx=[0, 1], det_idx=[nb - 1])), ("t0_rdg", np.inf, dict(remove_diag_grad=True))]
+
+
+def fit_inputs(g, name):
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR, basis, target = g[name + "/Fock_R"], g[name + "/basis"], g[name + "/target"]
+    val = [int(x) for x in g[name + "/val"]]
+    spin, nlo = basis.shape[0], FR.shape[-1]
+    Fk = R.R2k(FR, mesh)
+    Sk = np.asarray([np.eye(nlo, dtype=complex)] * basis.shape[1])
+    ncore = min(val)
+    nelec = ncore + len(val) if spin == 1 else [ncore + len(val)] * 2
+    return mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec
+
+
+def idx_sets(kw, nimp, nb):
+    """imp_idx / det_idx resolution of slater.py:985-1005."""
+    if kw.get("imp_fit"):
+        return list(range(nimp)), []
+    if kw.get("det"):
+        return [], list(range(nimp))
+    return kw.get("imp_idx"), kw.get("det_idx")
+
+
+@pytest.mark.parametrize("tag", sorted(VC))
+@pytest.mark.parametrize("itag", ["all", "sub"])
+def test_G9_vcor_local(golden, tag, itag):
+    g = golden("G9_vcorfit.npz")
+    key = "vcor/%s_%s" % (tag, itag)
+    v = F.VcorLocal(nscsites=5, idx_range=None if itag == "all" else [1, 3, 4], **VC[tag])
+    p = g[key + "/param"]
+    assert v.length() == len(p)
+    v.update(p)
+    assert np.array_equal(v.get(), g[key + "/value"])
+    assert np.array_equal(v.gradient(), g[key + "/grad"])
+    assert np.array_equal(np.asarray(v.diag_indices()), g[key + "/diag"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_G9_objective_and_gradient(golden, name):
+    g = golden("G9_vcorfit.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    nb = basis.shape[-1]
+    v = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    assert np.abs(F.get_dV_dparam(v, basis) - g[name + "/dV_dparam"]).max() < 1e-13
+    assert np.abs(F.get_dV_dparam(v, basis, compact=False) - g[name + "/dV_dparam_full"]).max() < 1e-13
+    for tag, beta, kw in fit_runs(nb):
+        imp_idx, det_idx = idx_sets(kw, nlo - min(val), nb)
+        fit = F.EmbFit(target, mesh, basis, v, beta, Fk if spin == 2 else Fk[0], Sk, nelec, imp_idx=imp_idx, det_idx=det_idx,
+                       mu0=kw.get("mu0"), fix_mu=kw.get("fix_mu", False), remove_diag_grad=kw.get("remove_diag_grad", False))
+        key = "%s/%s" % (name, tag)
+        grad = fit.gradfunc if beta == np.inf else fit.gradfunc_ft
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-12, key
+            assert np.abs(grad(p) - gr).max() < 1e-9 * max(1.0, np.abs(gr).max()), key
+        # the reference's converged parameters are a (local) minimum of the restated objective too
+        pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
+        assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12
+        assert abs(fit.errfunc(pfit) - e1) < 1e-11
+        assert e1 <= e0 + 1e-12
