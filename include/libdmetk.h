@@ -73,7 +73,7 @@ int dmk_timer_stop(dmk_ctx *ctx, double *ms_out_host);
  * every launch of the family is bracketed by events on the stream. */
 enum { DMK_FAM_DGEMM = 0, DMK_FAM_ZGEMM_HALF1 = 1, DMK_FAM_ZGEMM_HALF2 = 2,
        DMK_FAM_PHILOX = 3, DMK_FAM_FOLD = 4, DMK_FAM_EIGH = 5, DMK_FAM_BATH = 6,
-       DMK_FAM_ZGEMM_SMALL = 7, DMK_FAM_MISC = 8, DMK_FAM_JK = 9, DMK_FAM_COUNT = 10 };
+       DMK_FAM_ZGEMM_SMALL = 7, DMK_FAM_MISC = 8, DMK_FAM_JK = 9, DMK_FAM_FIT = 10, DMK_FAM_COUNT = 11 };
 int dmk_profile(dmk_ctx *ctx, int enable);
 int dmk_profile_read(dmk_ctx *ctx, double *ms_host /*[DMK_FAM_COUNT]*/,
                      int64_t *launches_host /*[DMK_FAM_COUNT]*/, int reset);
@@ -272,6 +272,37 @@ int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *
 /* 1-fold (n^4) or 8-fold (tril of npair x npair) ERI -> 4-fold (npair x npair): ao2mo.restore(4, .) at
  * solver/scf.py:311-321. */
 int dmk_eri_to_s4(dmk_ctx *ctx, int n, int from_symmetry, const double *in, double *out);
+
+/* ---- correlation-potential fit (routine/slater.py:851-1329) ------------------
+ * Row dots and column sums of a row-major matrix A (M x N, lda) in ONE streaming pass:
+ *     yrow[r] = sum_c A[r][c] xrow[c]   (xrow != NULL)      -> grad[p] = <dV_dparam[p], dw_dV>,  slater.py:1141
+ *     ycol[c] = sum_r A[r][c] xcol[r]   (xcol != NULL)      -> V_emb = param . dV_dparam,        slater.py:1059-1071
+ * Per-block partials are reduced in a fixed order (no atomics). */
+int dmk_dgemv2(dmk_ctx *ctx, int64_t M, int64_t N, const double *A, int64_t lda, const double *xrow, const double *xcol,
+               double *yrow, double *ycol);
+/* C[b] = alpha op(A[b]) op(B[b]) + beta C[b]; real f64, row-major with leading dimensions, op 0 = N, 1 = T.
+ * The nemb x nemb algebra of errfunc / gradfunc (np.dot / mdot at slater.py:1088, 1136-1138; ftsystem.py:183-186). */
+int dmk_dgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int batch, double alpha, const double *A,
+                      int64_t lda, int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
+                      int64_t ldc, int64_t strideC);
+/* tril[b][pair(k,l)] = full[b][k][l] + full[b][l][k] (k > l), full[b][k][k]: the "x2, diagonal x0.5, tril" packing of
+ * slater.py:1138-1141 / ftsystem.py:206-211 (and of the J density, solver/scf.py). */
+int dmk_sym_fold(dmk_ctx *ctx, int n, int batch, const double *full, double *tril);
+/* full[b] = symmetric unpack of tril[b] (+ add_tril[b] when not NULL): embH1 + V_emb, slater.py:1074. */
+int dmk_sym_unpack(dmk_ctx *ctx, int n, int batch, const double *tril, const double *add_tril, double *full);
+/* out[r][c] = in[row_idx ? row_idx[r] : r][col_idx ? col_idx[c] : c]  (fit_idx selections, slater.py:1089-1090, 1136). */
+int dmk_gather2d_f64(dmk_ctx *ctx, int nrow, int ncol, const int32_t *row_idx, const int32_t *col_idx, const double *in,
+                     int64_t ld_in, double *out);
+/* mode 0: out = A o B (Hadamard);  mode 1: out[r][c] = A[r][c] * B[r]  (ev * ewocc, slater.py:1088). */
+int dmk_ewise_mul(dmk_ctx *ctx, int mode, int64_t nrow, int64_t ncol, const double *A, const double *B, double *out);
+/* diff = a - b (diff may be NULL), *sumsq_dev = sum (a - b)^2 in a fixed order: la.norm(drho), slater.py:1094. */
+int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, double *diff, double *sumsq_dev);
+/* dV_dparam rows from the cell Gram matrix G[(i,p),(j,q)] = sum_c B[c,i,p] B[c,j,q] (row-major, ldg):
+ * entry e (one (parameter, spin) pair) = sum over its nonzeros z in [nz_ptr[e], nz_ptr[e+1]) of
+ * nz_val[z] * G[(nz_i[z], p), (nz_j[z], q)], written tril-packed at dV + out_off[e].
+ * Replaces the loop over transform_local_sparseH at slater.py:868-877 (slater_helper.py:91-100). */
+int dmk_vcor_dV_dparam(dmk_ctx *ctx, int nent, int nb, const double *G, int64_t ldg, const int32_t *nz_ptr,
+                       const int32_t *nz_i, const int32_t *nz_j, const double *nz_val, const int64_t *out_off, double *dV);
 
 #ifdef __cplusplus
 }

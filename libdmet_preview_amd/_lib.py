@@ -76,6 +76,15 @@ PROTOTYPES = {
     "dmk_pad_block_f64": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "dmk_jk_s4": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "dmk_dgemv2": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_dgemm_batched": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_i64, c_vp, c_i64,
+                                  c_i64, c_dbl, c_vp, c_i64, c_i64]),
+    "dmk_sym_fold": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "dmk_sym_unpack": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dmk_gather2d_f64": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "dmk_ewise_mul": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "dmk_sub_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_vcor_dV_dparam": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():
@@ -83,7 +92,7 @@ for _name, (_res, _args) in PROTOTYPES.items():
     _f.restype = _res
     _f.argtypes = _args
 
-FAMILIES = ["dgemm", "zgemm_half1", "zgemm_half2", "philox", "fold", "eigh", "bath", "zgemm_small", "misc", "jk"]
+FAMILIES = ["dgemm", "zgemm_half1", "zgemm_half2", "philox", "fold", "eigh", "bath", "zgemm_small", "misc", "jk", "fit"]
 
 
 class DmkError(RuntimeError):

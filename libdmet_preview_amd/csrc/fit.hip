@@ -1,0 +1,366 @@
+// K12 -- device pieces of the correlation-potential least-squares fit.
+//
+// routine/slater.py:909-1329 (FitVcorEmb): every objective / gradient evaluation is
+//     V_emb = sum_p param[p] dV_dparam[p]          (slater.py:1059-1071, np.tensordot over nparam)
+//     ew, ev = eigh(embH1 + V_emb, ovlp_emb)       (K1, eigh.hip)
+//     rho = (ev occ) ev^T, drho, |drho|            (small dense algebra, nemb x nemb)
+//     dw_dV = ev [(C^T drho C) o K] ev^T           (slater.py:1131-1141 / ftsystem.py:151-213)
+//     grad[p] = <dV_dparam[p], dw_dV>              (slater.py:1141, np.tensordot over spin * npair)
+// dV_dparam is (nparam, spin, npair) f64 = 1.7 GB at C5 (3192 x 2 x 32896): the two contractions with it are
+// HBM-bound streaming passes and share ONE kernel (gemv2: row dots and column sums of a row-major matrix in the
+// same pass, 2-D grid, per-block partials reduced in a fixed order -- bit-reproducible, no atomics).
+// The nemb x nemb algebra runs through a plain LDS-tiled real GEMM (64 x 64 tile, f64 FMA): at <= 256^3 it is
+// launch-latency bound, not worth the matrix pipe.
+// dV_dparam itself (slater.py:851-907 with transform_local_sparseH, slater_helper.py:91-100) is a gather from the
+// cell Gram matrix G[(i,p),(j,q)] = sum_c B[c,i,p] B[c,j,q] (one symmetric MFMA GEMM, dgemm_tn.hip).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int NW = NT / 64;
+constexpr int RB = 32;            // rows per workgroup (gemv2)
+constexpr int CI = 8;             // column iterations per workgroup (gemv2): 2048 columns
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void tril_rc(long long t, int &k, int &l) {
+    k = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long long)(k + 1) * (k + 2) / 2 <= t) ++k;
+    while ((long long)k * (k + 1) / 2 > t) --k;
+    l = (int)(t - (long long)k * (k + 1) / 2);
+}
+
+// rowpart[cc][r] = sum_{c in chunk cc} A[r][c] xrow[c];   colpart[rb][c] = sum_{r in block rb} A[r][c] xcol[r]
+__global__ __launch_bounds__(NT) void gemv2_kernel(long long M, long long N, const double *__restrict__ A, long long lda,
+                                                   const double *__restrict__ xrow, const double *__restrict__ xcol,
+                                                   double *__restrict__ rowpart, double *__restrict__ colpart) {
+    __shared__ double red[NW][RB];
+    __shared__ double xc[RB];
+    const long long r0 = (long long)blockIdx.x * RB;
+    const long long c0 = (long long)blockIdx.y * NT * CI;
+    const int nr = (int)((M - r0) < RB ? (M - r0) : RB);
+    if (threadIdx.x < RB) xc[threadIdx.x] = (xcol && threadIdx.x < nr) ? xcol[r0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    double racc[RB];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) racc[rr] = 0.0;
+    const double *Ab = A + r0 * lda;
+#pragma unroll 1
+    for (int it = 0; it < CI; ++it) {
+        const long long c = c0 + (long long)it * NT + threadIdx.x;
+        if (c < N) {
+            const double x1 = xrow ? xrow[c] : 0.0;
+            double v[RB];
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) v[rr] = (rr < nr) ? Ab[rr * lda + c] : 0.0;
+            double cacc = 0.0;
+#pragma unroll
+            for (int rr = 0; rr < RB; ++rr) {
+                racc[rr] = fma(v[rr], x1, racc[rr]);
+                cacc = fma(v[rr], xc[rr], cacc);
+            }
+            if (colpart) colpart[(long long)blockIdx.x * N + c] = cacc;
+        }
+    }
+    if (rowpart) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const double s = wave_sum(racc[rr]);
+            if (lane == 0) red[wave][rr] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < nr) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red[w][threadIdx.x];
+            rowpart[(long long)blockIdx.y * M + r0 + threadIdx.x] = s;
+        }
+    }
+}
+
+// y[c] = sum_b part[b][c]  (64 columns per workgroup, wave w takes b = w, w+4, ...; fixed combination order)
+__global__ __launch_bounds__(NT) void partsum_kernel(long long n, int nblk, const double *__restrict__ part,
+                                                     double *__restrict__ y) {
+    __shared__ double red[NW][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < n) {
+        int b = wave;
+        for (; b + 3 * NW < nblk; b += 4 * NW) {
+            s0 += part[(long long)b * n + c];
+            s1 += part[(long long)(b + NW) * n + c];
+            s2 += part[(long long)(b + 2 * NW) * n + c];
+            s3 += part[(long long)(b + 3 * NW) * n + c];
+        }
+        for (; b < nblk; b += NW) s0 += part[(long long)b * n + c];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && c < n) y[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// C[b] = alpha op(A[b]) op(B[b]) + beta C[b], row-major with leading dimensions; 64 x 64 tile, BK = 16
+template <int TA, int TB>
+__global__ __launch_bounds__(NT) void dgemm_small_kernel(int M, int N, int K, double alpha, const double *__restrict__ A,
+                                                         long long lda, long long sA, const double *__restrict__ B,
+                                                         long long ldb, long long sB, double beta, double *__restrict__ C,
+                                                         long long ldc, long long sC) {
+    __shared__ double As[16][65], Bs[16][65];
+    const int b = blockIdx.z;
+    A += (long long)b * sA;
+    B += (long long)b * sB;
+    C += (long long)b * sC;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = threadIdx.x + e * NT;                  // 1024 elements per operand tile
+            {
+                const int kk = TA ? idx / 64 : idx % 16, mm = TA ? idx % 64 : idx / 16;
+                const int m = m0 + mm, k = k0 + kk;
+                As[kk][mm] = (m < M && k < K) ? (TA ? A[(long long)k * lda + m] : A[(long long)m * lda + k]) : 0.0;
+            }
+            {
+                const int kk = TB ? idx % 16 : idx / 64, nn = TB ? idx / 16 : idx % 64;
+                const int n = n0 + nn, k = k0 + kk;
+                Bs[kk][nn] = (n < N && k < K) ? (TB ? B[(long long)n * ldb + k] : B[(long long)k * ldb + n]) : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < M && n < N) {
+                double *c = C + (long long)m * ldc + n;
+                *c = (beta == 0.0) ? alpha * acc[i][j] : alpha * acc[i][j] + beta * (*c);
+            }
+        }
+}
+
+// packed lower triangle <-> full symmetric, batched
+__global__ void sym_fold_kernel(int n, int batch, const double *__restrict__ full, double *__restrict__ tril) {
+    const long long npair = (long long)n * (n + 1) / 2, total = npair * batch;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / npair;
+        int k, l;
+        tril_rc(t % npair, k, l);
+        const double *f = full + b * n * n;
+        tril[t] = (k == l) ? f[(long long)k * n + k] : f[(long long)k * n + l] + f[(long long)l * n + k];
+    }
+}
+__global__ void sym_unpack_kernel(int n, int batch, const double *__restrict__ tril, const double *__restrict__ add_tril,
+                                  double *__restrict__ full) {
+    const long long npair = (long long)n * (n + 1) / 2, total = (long long)n * n * batch;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / ((long long)n * n), e = t % ((long long)n * n);
+        const int i = (int)(e / n), j = (int)(e % n);
+        const int a = i > j ? i : j, c = i > j ? j : i;
+        const long long p = b * npair + (long long)a * (a + 1) / 2 + c;
+        full[t] = tril[p] + (add_tril ? add_tril[p] : 0.0);
+    }
+}
+
+// out[r][c] = in[ridx ? ridx[r] : r][cidx ? cidx[c] : c]
+__global__ void gather2d_kernel(int nr, int nc, const int *__restrict__ ridx, const int *__restrict__ cidx,
+                                const double *__restrict__ in, long long ld_in, double *__restrict__ out) {
+    const long long total = (long long)nr * nc;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(t / nc), c = (int)(t % nc);
+        out[t] = in[(long long)(ridx ? ridx[r] : r) * ld_in + (cidx ? cidx[c] : c)];
+    }
+}
+
+// out = A o B   (mode 0);  out[r][c] = A[r][c] * s[r]   (mode 1, B = s)
+__global__ void ewise_kernel(int mode, long long nr, long long nc, const double *__restrict__ A, const double *__restrict__ B,
+                             double *__restrict__ out) {
+    const long long total = nr * nc;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x)
+        out[t] = A[t] * (mode == 0 ? B[t] : B[t / nc]);
+}
+
+// diff = a - b, sumsq = sum diff^2 ; one workgroup, fixed order
+__global__ __launch_bounds__(NT) void sub_sumsq_kernel(long long n, const double *__restrict__ a, const double *__restrict__ b,
+                                                       double *__restrict__ diff, double *__restrict__ sumsq) {
+    __shared__ double red[NW];
+    double s = 0.0;
+    for (long long t = threadIdx.x; t < n; t += NT) {
+        const double d = a[t] - b[t];
+        if (diff) diff[t] = d;
+        s = fma(d, d, s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sumsq[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dV[ip][pair(p,q)] = sum over the nonzeros (i, j, val) of parameter-spin entry ip of  val * G[(i,p),(j,q)]
+__global__ void dv_dparam_kernel(int nent, int nb, long long ldg, const double *__restrict__ G, const int *__restrict__ ptr,
+                                 const int *__restrict__ zi, const int *__restrict__ zj, const double *__restrict__ zv,
+                                 double *__restrict__ dV, const long long *__restrict__ out_off) {
+    const long long npair = (long long)nb * (nb + 1) / 2;
+    const int ent = blockIdx.y;
+    if (ent >= nent) return;
+    const int z0 = ptr[ent], z1 = ptr[ent + 1];
+    double *o = dV + out_off[ent];
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npair;
+         t += (long long)gridDim.x * blockDim.x) {
+        int p, q;
+        tril_rc(t, p, q);
+        double s = 0.0;
+        for (int z = z0; z < z1; ++z)
+            s = fma(zv[z], G[((long long)zi[z] * nb + p) * ldg + (long long)zj[z] * nb + q], s);
+        o[t] = s;
+    }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+int grid_for(long long total, int cap = 8192) { return (int)std::min<long long>((total + 255) / 256, cap); }
+
+}  // namespace
+
+extern "C" {
+
+int dmk_dgemv2(dmk_ctx *ctx, int64_t M, int64_t N, const double *A, int64_t lda, const double *xrow, const double *xcol,
+               double *yrow, double *ycol) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (M <= 0 || N <= 0 || !A || lda < N || (xrow && !yrow) || (xcol && !ycol) || (!xrow && !xcol))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "dgemv2: bad arguments");
+    FamScope fs(ctx, DMK_FAM_FIT);
+    const int nrb = (int)((M + RB - 1) / RB), ncc = (int)((N + NT * CI - 1) / (NT * CI));
+    const size_t b_row = xrow ? align256((size_t)ncc * M * 8) : 0, b_col = xcol ? align256((size_t)nrb * N * 8) : 0;
+    void *ws = nullptr;
+    int rc = dmk_scratch(ctx, b_row + b_col + 256, &ws);
+    if (rc) return rc;
+    double *rowpart = reinterpret_cast<double *>(ws);
+    double *colpart = reinterpret_cast<double *>(static_cast<char *>(ws) + b_row);
+    hipLaunchKernelGGL(gemv2_kernel, dim3(nrb, ncc), dim3(NT), 0, ctx->stream, (long long)M, (long long)N, A, (long long)lda,
+                       xrow, xcol, xrow ? rowpart : (double *)nullptr, xcol ? colpart : (double *)nullptr);
+    DMK_CHECK_LAUNCH(ctx);
+    if (xrow) hipLaunchKernelGGL(partsum_kernel, dim3((unsigned)((M + 63) / 64)), dim3(NT), 0, ctx->stream, (long long)M, ncc,
+                                 rowpart, yrow);
+    if (xcol) hipLaunchKernelGGL(partsum_kernel, dim3((unsigned)((N + 63) / 64)), dim3(NT), 0, ctx->stream, (long long)N, nrb,
+                                 colpart, ycol);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_dgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int batch, double alpha, const double *A,
+                      int64_t lda, int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double beta, double *C,
+                      int64_t ldc, int64_t strideC) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (opA < 0 || opA > 1 || opB < 0 || opB > 1 || M < 0 || N < 0 || K < 0 || batch < 0 || !A || !B || !C)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_batched: bad arguments");
+    if (M == 0 || N == 0 || batch == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_FIT);
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+#define DG_LAUNCH(TA, TB)                                                                                             \
+    hipLaunchKernelGGL((dgemm_small_kernel<TA, TB>), grid, dim3(NT), 0, ctx->stream, M, N, K, alpha, A, (long long)lda,    \
+                       (long long)strideA, B, (long long)ldb, (long long)strideB, beta, C, (long long)ldc, (long long)strideC)
+    if (opA == 0 && opB == 0) DG_LAUNCH(0, 0);
+    else if (opA == 0) DG_LAUNCH(0, 1);
+    else if (opB == 0) DG_LAUNCH(1, 0);
+    else DG_LAUNCH(1, 1);
+#undef DG_LAUNCH
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_sym_fold(dmk_ctx *ctx, int n, int batch, const double *full, double *tril) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n <= 0 || batch <= 0 || !full || !tril) return dmk_fail(ctx, DMK_ERR_INVALID, "sym_fold: bad arguments");
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(sym_fold_kernel, dim3(grid_for((long long)n * (n + 1) / 2 * batch)), dim3(256), 0, ctx->stream, n, batch,
+                       full, tril);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_sym_unpack(dmk_ctx *ctx, int n, int batch, const double *tril, const double *add_tril, double *full) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n <= 0 || batch <= 0 || !full || !tril) return dmk_fail(ctx, DMK_ERR_INVALID, "sym_unpack: bad arguments");
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(sym_unpack_kernel, dim3(grid_for((long long)n * n * batch)), dim3(256), 0, ctx->stream, n, batch, tril,
+                       add_tril, full);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_gather2d_f64(dmk_ctx *ctx, int nrow, int ncol, const int32_t *row_idx, const int32_t *col_idx, const double *in,
+                     int64_t ld_in, double *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (nrow < 0 || ncol < 0 || !in || !out) return dmk_fail(ctx, DMK_ERR_INVALID, "gather2d: bad arguments");
+    if (nrow == 0 || ncol == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(gather2d_kernel, dim3(grid_for((long long)nrow * ncol)), dim3(256), 0, ctx->stream, nrow, ncol, row_idx,
+                       col_idx, in, (long long)ld_in, out);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_ewise_mul(dmk_ctx *ctx, int mode, int64_t nrow, int64_t ncol, const double *A, const double *B, double *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if ((mode != 0 && mode != 1) || nrow < 0 || ncol < 0 || !A || !B || !out)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "ewise_mul: bad arguments");
+    if (nrow == 0 || ncol == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(ewise_kernel, dim3(grid_for(nrow * ncol)), dim3(256), 0, ctx->stream, mode, (long long)nrow,
+                       (long long)ncol, A, B, out);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, double *diff, double *sumsq_dev) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n < 0 || !a || !b || !sumsq_dev) return dmk_fail(ctx, DMK_ERR_INVALID, "sub_sumsq: bad arguments");
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(sub_sumsq_kernel, dim3(1), dim3(NT), 0, ctx->stream, (long long)n, a, b, diff, sumsq_dev);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_vcor_dV_dparam(dmk_ctx *ctx, int nent, int nb, const double *G, int64_t ldg, const int32_t *nz_ptr,
+                       const int32_t *nz_i, const int32_t *nz_j, const double *nz_val, const int64_t *out_off, double *dV) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (nent < 0 || nb <= 0 || !G || !nz_ptr || !nz_i || !nz_j || !nz_val || !out_off || !dV)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "vcor_dV_dparam: bad arguments");
+    if (nent == 0) return DMK_OK;
+    if (nent > 65535) return dmk_fail(ctx, DMK_ERR_INVALID, "vcor_dV_dparam: more than 65535 entries per call");
+    FamScope fs(ctx, DMK_FAM_FIT);
+    const long long npair = (long long)nb * (nb + 1) / 2;
+    hipLaunchKernelGGL(dv_dparam_kernel, dim3(grid_for(npair, 256), nent), dim3(256), 0, ctx->stream, nent, nb, (long long)ldg, G,
+                       nz_ptr, nz_i, nz_j, nz_val, dV, reinterpret_cast<const long long *>(out_off));
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""
+The correlation-potential parametrisation of libdmet/dmet/Hubbard.py:551-786 (`VcorLocal`, alias `vcor_zeros`):
+symmetric spin blocks on `idx_range` (one shared, or one per spin), plus the pairing block of the BCS variants.
+Host bookkeeping only; the potential enters the device path through `vcor.get()` (mean-field diag) and
+`vcor.gradient()` (dV_dparam of the fit).
+"""
+import itertools as it
+import numpy as np
+
+from libdmet_preview_amd.routine import vcor
+from libdmet_preview_amd.utils import logger as log
+
+
+def triu_diag_indices(n):
+    """Positions of the diagonal entries in a row-major packed upper triangle (utils/misc.py:200-204)."""
+    return np.cumsum([0] + list(range(n, 1, -1)))
+
+
+class _VcorLocal(vcor.Vcor):
+    def __init__(self, restricted, bogoliubov, nscsites, idx_range, bogo_res, v_idx, ghf):
+        vcor.Vcor.__init__(self)
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, bogoliubov, bogo_res
+        self.nscsites, self.idx_range = nscsites, idx_range
+        self.grad = None
+        self.diag_idx = None
+        nidx = len(idx_range)
+        ntri = nidx * (nidx + 1) // 2
+        sym = list(it.combinations_with_replacement(idx_range, 2))
+        if v_idx is not None:
+            if not restricted:
+                raise NotImplementedError
+            sym = [tuple(p) for p in v_idx]
+            ntri = len(sym)
+            self._v_idx_diag = [i for i, (a, b) in enumerate(sym) if a == b]
+        else:
+            self._v_idx_diag = None
+        self.nV = ntri if restricted else 2 * ntri
+        if not bogoliubov:
+            self.nD = 0
+        elif restricted or bogo_res:
+            self.nD = nidx * (nidx + 1) // 2
+        else:
+            self.nD = nidx * nidx
+        nV = self.nV
+        # (parameter offset, matrix block, sign, index pairs, mirrored?) -- one entry per assignment of Hubbard.py:599-770
+        if not bogoliubov:
+            second = 0 if restricted else nV // 2
+            self._terms = [(0, 0, 1, sym, True), (second, 1, 1, sym, True)]
+        elif restricted:
+            self._terms = [(0, 0, 1, sym, True), (0, 1, -1 if ghf else 1, sym, True), (nV, 2, 1, sym, True)]
+        elif bogo_res:
+            self._terms = [(0, 0, 1, sym, True), (nV // 2, 1, 1, sym, True), (nV, 2, 1, sym, True)]
+        else:
+            self._terms = [(0, 0, 1, sym, True), (nV // 2, 1, 1, sym, True),
+                           (nV, 2, 1, list(it.product(idx_range, repeat=2)), False)]
+        self.update(np.zeros(self.length()))
+
+    def length(self):
+        return self.nV + self.nD
+
+    def evaluate(self):
+        log.eassert(self.param.shape == (self.length(),), "wrong parameter shape, require %s", (self.length(),))
+        V = np.zeros((3 if self.bogoliubov else 2, self.nscsites, self.nscsites))
+        for off, blk, sign, pairs, mirror in self._terms:
+            for idx, (i, j) in enumerate(pairs):
+                V[blk, i, j] = sign * self.param[idx + off]
+                if mirror:
+                    V[blk, j, i] = sign * self.param[idx + off]
+        return V
+
+    def gradient(self):
+        if self.grad is None:
+            g = np.zeros((self.length(), 3 if self.bogoliubov else 2, self.nscsites, self.nscsites))
+            for off, blk, sign, pairs, mirror in self._terms:
+                for idx, (i, j) in enumerate(pairs):
+                    g[idx + off, blk, i, j] = sign
+                    if mirror:
+                        g[idx + off, blk, j, i] = sign
+            self.grad = g
+        return self.grad
+
+    def diag_indices(self):
+        if self._v_idx_diag is not None:
+            return self._v_idx_diag
+        if self.diag_idx is None:
+            idx = triu_diag_indices(len(self.idx_range))
+            self.diag_idx = [idx] if self.restricted else [idx, np.asarray(idx) + self.nV // 2]
+        return self.diag_idx
+
+    def show(self):
+        vcor_mat = self.get()
+        string = "vcor\n"
+        string += "nao %d \n" % vcor_mat.shape[-1]
+        string += "idx range %s, length %s\n" % (self.idx_range, len(self.idx_range))
+        string += "res: %s, bogo: %s, bogo res: %s\n" % (self.restricted, self.bogoliubov, self.bogo_res)
+        string += str(vcor_mat[np.ix_(np.arange(vcor_mat.shape[0]), self.idx_range, self.idx_range)])
+        return string
+
+
+def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, v_idx=None, d_idx=None, ghf=False):
+    """Local correlation potential on `idx_range` (default: all nscsites orbitals)."""
+    if idx_range is None:
+        idx_range = list(range(0, nscsites))
+    if d_idx is not None:
+        raise NotImplementedError
+    return _VcorLocal(restricted, bogoliubov, nscsites, list(idx_range), bogo_res, v_idx, ghf)
+
+
+vcor_zeros = VcorLocal

@@ -39,8 +39,8 @@ def emb_basis_proj_dev(ctx, kmesh, ncells, nscsites, val_idx, d_GRho):
     w = d_w.get()
     order = np.argsort(w, kind='mergesort')[::-1]
     d_basis = ctx.empty((2, ncells, 2 * n, n + nval), np.float64)
-    ctx.check(lib.dmk_bcs_assemble(ctx.h, int(ncells), n, nval, d_U.ptr,
-                                   ctx.to_device(np.ascontiguousarray(order, dtype=np.int32)).ptr, d_basis.ptr))
+    d_order = ctx.to_device(np.ascontiguousarray(order, dtype=np.int32))      # keep alive across the launch
+    ctx.check(lib.dmk_bcs_assemble(ctx.h, int(ncells), n, nval, d_U.ptr, d_order.ptr, d_basis.ptr))
     return d_basis, d_sigma.get(), w, order, d_U
 
 
@@ -74,7 +74,8 @@ def _eigh_real(ctx, A):
     m = A.shape[-1]
     d_w = ctx.empty((1, m), np.float64)
     d_Vt = ctx.empty((1, m, m), np.float64)
-    ctx.check(lib.dmk_eigh_batched_real(ctx.h, m, 1, ctx.to_device(A, np.float64).ptr, d_w.ptr, d_Vt.ptr))
+    d_A = ctx.to_device(A, np.float64)
+    ctx.check(lib.dmk_eigh_batched_real(ctx.h, m, 1, d_A.ptr, d_w.ptr, d_Vt.ptr))
     return d_w.get()[0], np.ascontiguousarray(d_Vt.get()[0].T)
 
 
@@ -93,7 +94,9 @@ def _inv_sqrt_factor(ctx, M):
 def _rotate_rows(ctx, d_b, nrow, m, X):
     """b (nrow, m) @ X (m, m) on the device."""
     d_out = ctx.empty((nrow, m), np.float64)
-    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, int(nrow), m, m, d_b.ptr, ctx.to_device(X, np.float64).ptr, 0, d_out.ptr))
+    d_X = ctx.to_device(X, np.float64)
+    ctx.check(lib.dmk_dgemm_nn_small(ctx.h, int(nrow), m, m, d_b.ptr, d_X.ptr, 0, d_out.ptr))
+    ctx.sync()                                   # d_X goes out of scope here
     return d_out
 
 

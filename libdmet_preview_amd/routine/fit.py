@@ -1,0 +1,207 @@
+"""
+Optimiser drivers of the correlation-potential fit with the reference's entry point
+(libdmet/routine/fit.py:17-45 `minimize`; fit.py:47-187, fit_helper.py:174-484).
+
+Host control flow only: the objective / gradient callables they drive are the device evaluations of
+routine/slater.py (FitVcorEmb).  Same algorithms and stopping rules as the reference so that the iterates
+coincide: steepest descent, Polak-Ribiere(+) conjugate gradient and BFGS, each with the bounded scalar line
+search `minimize_scalar(bounds=(0, scale))`, scale = max(|mean of the last two steps|, min_step), and the
+Nelder-Mead fallback when the bounded search lands above f(0).  Norms are max-abs (fit_helper.py:33).
+"""
+import numpy as np
+from scipy.optimize import minimize_scalar, fmin
+
+from libdmet_preview_amd.utils import logger as log
+from libdmet_preview_amd.utils.misc import max_abs
+
+norm = max_abs
+
+
+def _numeric_grad(fn, callback, eps, diag_idx=None):
+    """Central differences, one parameter at a time (fit.py:166-184); diag_idx groups have their mean removed."""
+    def grad(x):
+        if callback is not None:
+            ref = callback(x)
+            fn1 = lambda x1: fn(x1, ref=ref)
+        else:
+            fn1 = fn
+        g = np.empty(len(x))
+        for ix in range(len(x)):
+            dx = np.zeros_like(x)
+            dx[ix] = eps
+            g[ix] = (0.5 / eps) * (fn1(x + dx) - fn1(x - dx))
+        if diag_idx is not None:
+            for idx in diag_idx:
+                g[idx] -= np.average(g[idx])
+        return g
+    return grad
+
+
+def _line_search(phi, f0, steps, min_step, xatol, fallback=True):
+    """Bounded Brent search on [0, scale]; returns (step, value)."""
+    scale = max(abs(np.average(steps[-2:])), min_step)
+    res = minimize_scalar(phi, bounds=(0.0, scale), method="bounded", options={"maxiter": 100, "xatol": xatol})
+    if res.fun > f0:
+        # the bounded search can return a local minimum above f(0)
+        if fallback:
+            xopt, fopt, _, _, _ = fmin(phi, 0.0, disp=False, xtol=xatol * 0.1, full_output=True)
+            if fopt <= f0:
+                return xopt[0], fopt
+            res_fun = fopt
+        else:
+            res_fun = res.fun
+        log.warn("line search fails, resulting value  %20.12f is\nlarger than the previous step value %20.12f",
+                 res_fun, f0)
+        return 0.0, f0
+    return res.x, res.fun
+
+
+def minimize_SD(fn, x0, MaxIter=300, fgrad=None, callback=None, ytol=1e-7, gtol=1e-3, dx_tol=1e-7, **kwargs):
+    """Steepest descent with the damped direction h * 10 / (1 + h.h), h = 10 g / y (fit.py:47-150)."""
+    eps = kwargs.get("eps", 1e-5)
+    init_step, min_step, xatol = kwargs.get("init_step", 1.0), kwargs.get("min_step", 0.1), kwargs.get("xatol", 1e-5)
+    if fgrad is None:
+        fgrad = _numeric_grad(fn, callback, eps)
+    x = x0
+    y = fn(x)
+    steps = [init_step]
+    pattern = 0
+    g = None
+    for it in range(MaxIter):
+        if y < ytol * 0.1 and it != 0:
+            pattern = 1
+            break
+        g = fgrad(x)
+        if norm(g) < min(1e-5, gtol):
+            pattern = 2
+            break
+        h = 10 * g / y
+        dx = h * 10 / (1 + np.sum(h * h))
+        if callback is None:
+            phi = lambda step: fn(x - step * dx)
+        else:
+            ref_ = callback(x)
+            phi = lambda step: fn(x - step * dx, ref_)
+        step, y_new = _line_search(phi, y, steps, min_step, xatol, fallback=False)
+        steps.append(step)
+        dx = dx * step
+        if y_new > y * 1.5:
+            pattern = 3
+            break
+        if abs(y - y_new) < ytol and norm(g) < gtol:
+            pattern = 3
+            x = x - dx
+            y = y_new
+            break
+        if norm(dx) < dx_tol:
+            pattern = 3
+            x = x - dx
+            y = y_new
+            break
+        x = x - dx
+        y = y_new
+        log.debug(0, "%4d %20.12f %20.12f %20.12f %15.3e", it, y, norm(g), norm(dx), step)
+    return x, y, pattern, norm(g)
+
+
+def _downhill(fn, x0, method, MaxIter, fgrad, callback, ytol, gtol, dx_tol, **kwargs):
+    """CG (Polak-Ribiere with restart at beta < 0) or BFGS + line search (fit_helper.py:174-484)."""
+    eps = kwargs.get("eps", 1e-5)
+    init_step, min_step, xatol = kwargs.get("init_step", 1.0), kwargs.get("min_step", 0.1), kwargs.get("xatol", 1e-5)
+    if fgrad is None:
+        fgrad = _numeric_grad(fn, callback, eps, kwargs.get("diag_idx", None))
+    f = lambda x: fn(np.copy(x))
+    fp = lambda x: np.asarray(fgrad(np.copy(x)))
+    xk = np.asarray(x0).flatten()
+    gfk = fp(xk)
+    old_fval = f(xk)
+    steps = [init_step]
+    k = 0
+    nfev, ngev = 1, 1
+    bfgs = (method == 'BFGS')
+    if bfgs:
+        N = len(xk)
+        I = np.eye(N, dtype=int)
+        Hk = I
+    else:
+        pk = -gfk
+    gnorm = norm(gfk)
+    while k < MaxIter and (not bfgs or gnorm > gtol):
+        if bfgs:
+            pk = -np.dot(Hk, gfk)
+        else:
+            deltak = np.dot(gfk, gfk)
+        phi = lambda step: f(xk + step * pk)
+        alpha_k, new_fval = _line_search(phi, old_fval, steps, min_step, xatol)
+        steps.append(alpha_k)
+        dy = abs(new_fval - old_fval)
+        norm_dx = norm(pk) * alpha_k
+        if not bfgs and abs(norm_dx) < dx_tol:
+            log.debug(0, "CG: dx (%20.12g) < %15.8g reached.", norm_dx, dx_tol)
+            break
+        old_fval = new_fval
+        xkp1 = xk + alpha_k * pk
+        gfkp1 = fp(xkp1)
+        ngev += 1
+        yk = gfkp1 - gfk
+        if bfgs:
+            sk = xkp1 - xk
+        else:
+            beta_k = max(0, np.dot(yk, gfkp1) / deltak)
+            pk = -gfkp1 + beta_k * pk
+        xk, gfk = xkp1, gfkp1
+        gnorm = norm(gfk)
+        if not bfgs:
+            log.debug(0, "%4d %20.12f %20.12f %20.12f %15.3e", k, old_fval, gnorm, norm_dx, alpha_k)
+        if callback is not None:
+            callback(xk)
+        k += 1
+        if gnorm < gtol:
+            log.debug(0, "%s: gnorm (%20.12g) < %15.8g reached.", method, gnorm, gtol)
+            break
+        if dy < ytol:
+            log.debug(0, "%s: dy (%20.12g) < %15.8g reached.", method, dy, ytol)
+            break
+        if bfgs:
+            log.debug(0, "%4d %20.12f %20.12f %20.12f %15.3e", k, old_fval, gnorm, norm_dx, alpha_k)
+            if abs(norm_dx) < dx_tol:
+                break
+            if not np.isfinite(old_fval):
+                break
+            ys = np.dot(yk, sk)
+            rhok = 1.0 / ys if ys != 0.0 else 1000.0
+            if np.isinf(rhok):
+                rhok = 1000.0
+            A1 = I - sk[:, np.newaxis] * yk[np.newaxis, :] * rhok
+            A2 = I - yk[:, np.newaxis] * sk[np.newaxis, :] * rhok
+            Hk = np.dot(A1, np.dot(Hk, A2)) + (rhok * sk[:, np.newaxis] * sk[np.newaxis, :])
+    if k >= MaxIter:
+        log.info("Warning: Maximum number of iterations has been exceeded.")
+    log.info("         Current function value: %f" % old_fval)
+    log.info("         Iterations: %d" % k)
+    return xk, old_fval, 3, norm(gfk)
+
+
+def minimize_CG(fn, x0, MaxIter=300, fgrad=None, callback=None, ytol=1e-7, gtol=1e-3, dx_tol=1e-7, **kwargs):
+    return _downhill(fn, x0, 'CG', MaxIter, fgrad, callback, ytol, gtol, dx_tol, **kwargs)
+
+
+def minimize_BFGS(fn, x0, MaxIter=300, fgrad=None, callback=None, ytol=1e-7, gtol=1e-3, dx_tol=1e-7, **kwargs):
+    return _downhill(fn, x0, 'BFGS', MaxIter, fgrad, callback, ytol, gtol, dx_tol, **kwargs)
+
+
+def minimize(fn, x0, MaxIter=300, fgrad=None, callback=None, method='CG', ytol=1e-7, gtol=1e-3, dx_tol=1e-7, **kwargs):
+    """Main wrapper for the minimisers: returns (x, y, converge_pattern, gnorm)."""
+    log.info("%s used in minimizer", method)
+    method = method.lower().strip()
+    if method == 'cg':
+        driver = minimize_CG
+    elif method == 'bfgs':
+        driver = minimize_BFGS
+    elif method == 'sd':
+        driver = minimize_SD
+    elif method in ('ciah', 'trust-ncg'):
+        raise NotImplementedError("minimiser %s needs PySCF's CIAH / SciPy trust-region internals; use CG, BFGS or SD" % method)
+    else:
+        raise ValueError("Unknown method %s" % method)
+    return driver(fn, x0, MaxIter=MaxIter, fgrad=fgrad, callback=callback, ytol=ytol, gtol=gtol, dx_tol=dx_tol, **kwargs)

@@ -1,0 +1,62 @@
+"""
+Host control flow of the vcor fit (no GPU needed): the optimiser drivers of libdmet_preview_amd/routine/fit.py against
+iterates captured from the reference's routine/fit.py on analytic objectives (golden G9, `opt/*`), and the
+VcorLocal parametrisation of libdmet_preview_amd/dmet/Hubbard.py against the reference's.
+"""
+import numpy as np
+import pytest
+
+from tests.test_oracle_fit import VC
+
+
+def _objectives(g):
+    A, b = g["opt/A"], g["opt/b"]
+    quad = lambda x: float(np.sqrt(0.5 * x @ A @ x - b @ x + 20.0))
+    qgrad = lambda x: (A @ x - b) / (2.0 * quad(x))
+    rosen = lambda x: float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2) + 1e-3)
+    rgrad = lambda x: np.concatenate([[0.0], 200.0 * (x[1:] - x[:-1] ** 2)]) + \
+        np.concatenate([-400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1]), [0.0]])
+    return {"quad_cg": (quad, qgrad, dict(method="CG"), 60), "quad_cg_num": (quad, None, dict(method="CG"), 60),
+            "quad_sd": (quad, qgrad, dict(method="SD"), 60), "rosen_cg": (rosen, rgrad, dict(method="CG"), 25),
+            "quad_bfgs": (quad, qgrad, dict(method="BFGS"), 60)}
+
+
+@pytest.mark.parametrize("tag", ["quad_cg", "quad_cg_num", "quad_sd", "rosen_cg", "quad_bfgs"])
+def test_minimize_matches_reference_iterates(golden, tag):
+    from libdmet_preview_amd.routine import fit
+    g = golden("G9_vcorfit.npz")
+    fn, fg, kw, mi = _objectives(g)[tag]
+    x, y, pat, gn = fit.minimize(fn, g["opt/%s_x0" % tag].copy(), mi, fg, **kw)
+    xr, (yr, patr, gnr) = g["opt/%s_x" % tag], g["opt/%s_res" % tag]
+    assert np.abs(x - xr).max() < 1e-9, (x, xr)
+    assert abs(y - yr) < 1e-11 and int(pat) == int(patr) and abs(gn - gnr) < 1e-8
+
+
+def test_minimize_rejects_unknown_method():
+    from libdmet_preview_amd.routine import fit
+    with pytest.raises(ValueError):
+        fit.minimize(lambda x: 0.0, np.zeros(2), method="nope")
+    with pytest.raises(NotImplementedError):
+        fit.minimize(lambda x: 0.0, np.zeros(2), method="ciah")
+
+
+@pytest.mark.parametrize("tag", sorted(VC))
+@pytest.mark.parametrize("itag", ["all", "sub"])
+def test_vcor_local(golden, tag, itag):
+    from libdmet_preview_amd.dmet import Hubbard
+    g = golden("G9_vcorfit.npz")
+    key = "vcor/%s_%s" % (tag, itag)
+    v = Hubbard.VcorLocal(nscsites=5, idx_range=None if itag == "all" else [1, 3, 4], **VC[tag])
+    p = g[key + "/param"]
+    assert v.length() == len(p) and v.islocal() and v.is_local()
+    assert np.array_equal(v.get(), np.zeros_like(g[key + "/value"]))       # starts from zero parameters
+    v.update(p)
+    assert np.array_equal(v.get(), g[key + "/value"])
+    assert np.array_equal(v.get(3, kspace=False), np.zeros_like(g[key + "/value"]))
+    assert np.array_equal(v.gradient(), g[key + "/grad"])
+    assert np.array_equal(np.asarray(v.diag_indices()), g[key + "/diag"])
+    # assign() projects a matrix back onto the parameters
+    w = Hubbard.VcorLocal(nscsites=5, idx_range=None if itag == "all" else [1, 3, 4], **VC[tag])
+    w.assign(g[key + "/value"])
+    assert np.abs(w.param - p).max() < 1e-14
+    assert "idx range" in w.show()
