@@ -26,11 +26,7 @@ constexpr int NT = 256;
 constexpr int NWAVE = NT / 64;
 constexpr int MAXB = 256;     // row-slab blocks for the tall-matrix kernels
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return dmk_wave_sum(v); }
 
 // A[r][c] = big[env_idx[r]][bath_col[c]],  big[(R1,p),(R2,q)] = rdm1[R1 - R2][p][q]
 __global__ void gather_env_imp_kernel(int n0, int n1, int n2, int nlo, const double *__restrict__ rdm1,

@@ -86,9 +86,31 @@ __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_base) {
                  : "v"(gsrc), "s"(base)
                  : "memory");
 }
+// Wave64 sum through the DPP crossbar (quad_perm, row_ror, row_bcast) instead of six ds_bpermute round trips:
+// every lane of the wave gets the total (read back from lane 63).  Fixed combination order: deterministic.
+// The whole wave must be active at the call.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dmk_dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dmk_wave_sum(double v) {
+    v += dmk_dpp_mov<0xb1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v += dmk_dpp_mov<0x4e, 0xf>(v);      // quad_perm [2,3,0,1]
+    v += dmk_dpp_mov<0x124, 0xf>(v);     // row_ror 4
+    v += dmk_dpp_mov<0x128, 0xf>(v);     // row_ror 8   -> every lane holds its row's total
+    v += dmk_dpp_mov<0x142, 0xa>(v);     // row_bcast 15 into rows 1, 3
+    v += dmk_dpp_mov<0x143, 0xc>(v);     // row_bcast 31 into rows 2, 3 -> lane 63 holds the wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 #else
 __device__ unsigned lds_addr_of(const void *p);          // host pass: declarations only
 __device__ void glds16(const void *gsrc, unsigned lds_base);
+__device__ double dmk_wave_sum(double v);
 #endif
 
 // ---- launchers implemented in the .hip files ---------------------------------------------

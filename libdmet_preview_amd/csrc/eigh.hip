@@ -31,11 +31,7 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {   // conj(a) * b
     return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return dmk_wave_sum(v); }
 
 struct EighArgs {
     int n, batch;
@@ -74,6 +70,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     double *e = g.e + (size_t)b * n;
     double2 *tau = g.tau + (size_t)b * n;
 
+    long long tphase[5];
+    tphase[0] = wall_clock64();
     // ---- phase 0: W = Hermitian completion of the lower triangle (+ add), Zt = I ------------
     {
         const double *addm = g.add ? g.add + (size_t)(g.add_group > 0 ? b / g.add_group : 0) * nn : nullptr;
@@ -95,6 +93,7 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     }
     __syncthreads();
 
+    tphase[1] = wall_clock64();
     // ---- phase 1: Householder tridiagonalisation ------------------------------------------------
     for (int k = 0; k + 1 < n; ++k) {
         const int m = n - k - 1;
@@ -207,84 +206,145 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     }
     __syncthreads();
 
+    tphase[2] = wall_clock64();
     // ---- phase 2: implicit QL with rotation sweeps applied to Zt ---------------------------------
-    // e[i] couples i and i+1.
+    // e[i] couples i and i+1.  d and e live in LDS for this phase; the split point is found with a ballot over 64
+    // candidates at a time; the scalar recurrence of a sweep runs on one lane with the next (d[i], e[i]) already in
+    // registers and ONE reciprocal square root per rotation (v_rsq_f64 + two Newton steps) instead of a square
+    // root and two divisions; the sweep is then applied to Zt with the row loads of eight rotations in flight.
     {
+        double *dl = red + 2 * NW + 8;            // [n]
+        double *el = dl + n;                      // [n]
+        for (int t = tid; t < n; t += NT) {
+            dl[t] = d[t];
+            el[t] = e[t];
+        }
+        __syncthreads();
         const double eps = 2.220446049250313e-16;
+        long long t_scalar = 0, t_apply = 0, n_rot = 0, n_sweep = 0;
         for (int l = 0; l < n; ++l) {
             int iter = 0;
             while (true) {
-                // scalar part on one lane: find m, build the sweep
-                if (tid == 0) {
-                    int mm = l;
-                    for (; mm < n - 1; ++mm) {
-                        const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
-                        if (fabs(e[mm]) <= eps * dd) break;
+                const long long tq0 = wall_clock64();
+                // first negligible off-diagonal at or after l: wave 0 scans 64 candidates per step
+                if (wave == 0) {
+                    int found = n - 1;
+                    for (int base = l; base < n - 1; base += 64) {
+                        const int mq = base + lane;
+                        bool small = false;
+                        if (mq < n - 1) small = fabs(el[mq]) <= eps * (fabs(dl[mq]) + fabs(dl[mq + 1]));
+                        const unsigned long long mask = __ballot(small);
+                        if (mask != 0ull) {
+                            found = base + __ffsll((long long)mask) - 1;
+                            break;
+                        }
                     }
+                    if (lane == 0) ired[0] = found;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    const int mm = ired[0];
                     int cnt = 0;     // number of rotations recorded; rotation q acts on rows (mm-1-q, mm-q)
                     if (mm != l) {
-                        double gq = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                        double gq = (dl[l + 1] - dl[l]) / (2.0 * el[l]);
                         double r = sqrt(gq * gq + 1.0);
-                        gq = d[mm] - d[l] + e[l] / (gq + (gq >= 0.0 ? fabs(r) : -fabs(r)));
+                        gq = dl[mm] - dl[l] + el[l] / (gq + (gq >= 0.0 ? fabs(r) : -fabs(r)));
                         double s = 1.0, c = 1.0, p = 0.0;
                         int i = mm - 1;
                         bool under = false;
+                        double d_hi = dl[mm];                          // d[i+1], untouched so far in this sweep
+                        double e_i = el[i], d_i = dl[i];
                         for (; i >= l; --i) {
-                            double f = s * e[i];
-                            const double bq = c * e[i];
-                            r = sqrt(f * f + gq * gq);
-                            e[i + 1] = r;
-                            if (r == 0.0) {
-                                d[i + 1] -= p;
-                                e[mm] = 0.0;
+                            const double e_nx = (i > l) ? el[i - 1] : 0.0, d_nx = (i > l) ? dl[i - 1] : 0.0;   // prefetch
+                            const double f = s * e_i;
+                            const double bq = c * e_i;
+                            const double x = f * f + gq * gq;
+                            if (x == 0.0) {
+                                el[i + 1] = 0.0;
+                                dl[i + 1] = d_hi - p;
+                                el[mm] = 0.0;
                                 under = true;
                                 break;
                             }
-                            s = f / r;
-                            c = gq / r;
-                            gq = d[i + 1] - p;
-                            r = (d[i] - gq) * s + 2.0 * c * bq;
+                            double y = __builtin_amdgcn_rsq(x);
+                            y = y * (1.5 - 0.5 * x * y * y);
+                            y = y * (1.5 - 0.5 * x * y * y);
+                            r = x * y;
+                            r = r + 0.5 * y * fma(-r, r, x);           // sqrt(x) to the last bit or so
+                            el[i + 1] = r;
+                            s = f * y;
+                            c = gq * y;
+                            gq = d_hi - p;
+                            r = (d_i - gq) * s + 2.0 * c * bq;
                             p = s * r;
-                            d[i + 1] = gq + p;
+                            dl[i + 1] = gq + p;
                             gq = c * r - bq;
                             cs[2 * cnt] = c;
                             cs[2 * cnt + 1] = s;
                             ++cnt;
+                            d_hi = d_i;
+                            d_i = d_nx;
+                            e_i = e_nx;
                         }
                         if (!under) {
-                            d[l] -= p;
-                            e[l] = gq;
-                            e[mm] = 0.0;
+                            dl[l] = d_hi - p;                          // d_hi == original d[l] here
+                            el[l] = gq;
+                            el[mm] = 0.0;
                         }
                     }
-                    ired[0] = mm;
                     ired[1] = cnt;
                 }
                 __syncthreads();
                 const int mm = ired[0], cnt = ired[1];
+                const long long tq1 = wall_clock64();
+                t_scalar += tq1 - tq0;
+                n_rot += cnt;
+                n_sweep += 1;
                 if (mm == l) { __syncthreads(); break; }
                 // apply the sweep: rotation q on rows (i, i+1) of Zt with i = mm-1-q
                 for (int rcol = tid; rcol < n; rcol += NT) {
                     double hi = Zt[(size_t)mm * n + rcol];
-                    for (int q = 0; q < cnt; ++q) {
-                        const int i = mm - 1 - q;
-                        const double c = cs[2 * q], s = cs[2 * q + 1];
-                        const double lo = Zt[(size_t)i * n + rcol];
-                        Zt[(size_t)(i + 1) * n + rcol] = s * lo + c * hi;
-                        hi = c * lo - s * hi;
+                    double lo[8], nx[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nx[u] = (u < cnt) ? Zt[(size_t)(mm - 1 - u) * n + rcol] : 0.0;
+                    for (int q0 = 0; q0 < cnt; q0 += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) lo[u] = nx[u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int q = q0 + 8 + u;
+                            nx[u] = (q < cnt) ? Zt[(size_t)(mm - 1 - q) * n + rcol] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int q = q0 + u;
+                            if (q < cnt) {
+                                const double c = cs[2 * q], sn = cs[2 * q + 1];
+                                Zt[(size_t)(mm - q) * n + rcol] = sn * lo[u] + c * hi;
+                                hi = c * lo[u] - sn * hi;
+                            }
+                        }
                     }
                     Zt[(size_t)(mm - cnt) * n + rcol] = hi;
                 }
                 __syncthreads();
+                t_apply += wall_clock64() - tq1;
                 if (++iter > 80) {
                     if (tid == 0) *g.status = 1;
                     break;
                 }
             }
         }
+        __syncthreads();
+        for (int t = tid; t < n; t += NT) d[t] = dl[t];
+        if (b == 0 && tid == 0) {
+            long long *tp = reinterpret_cast<long long *>(g.status + 2);
+            tp[4] = t_scalar; tp[5] = t_apply; tp[6] = n_rot; tp[7] = n_sweep;
+        }
     }
     __syncthreads();
 
+    tphase[3] = wall_clock64();
     // ---- phase 3: sort + back-transformation ------------------------------------------------------
     // rank[j] = position of eigenvalue j in ascending order (stable); kept in cs[] as ints
     int *rank = reinterpret_cast<int *>(cs);
@@ -362,6 +422,11 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
             }
         }
     }
+    if (b == 0 && tid == 0) {       // phase clocks of matrix 0 (100 MHz wall clock), read with DMK_EIGH_TIMING=1
+        long long *tp = reinterpret_cast<long long *>(g.status + 2);
+        tphase[4] = wall_clock64();
+        for (int q = 0; q < 4; ++q) tp[q] = tphase[q + 1] - tphase[q];
+    }
 }
 
 int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group, double *w,
@@ -388,9 +453,15 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
     // reflector rows are only partially written; clear so that masked lanes read zeros
     DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
-    const size_t lds = (size_t)n * (16 + 16 + 16) + (2 * NW + 8) * 8 + 64;
+    const size_t lds = (size_t)n * (16 + 16 + 16 + 16) + (2 * NW + 8) * 8 + 64;
     {
         FamScope fs(ctx, DMK_FAM_EIGH);
+        if (lds > 48 * 1024) {
+            const void *fn = n <= 64 ? reinterpret_cast<const void *>(eigh_kernel<1>)
+                             : n <= 256 ? reinterpret_cast<const void *>(eigh_kernel<4>)
+                                        : reinterpret_cast<const void *>(eigh_kernel<16>);
+            DMK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (n <= 64) hipLaunchKernelGGL(eigh_kernel<1>, dim3(batch), dim3(NT), lds, ctx->stream, g);
         else if (n <= 256) hipLaunchKernelGGL(eigh_kernel<4>, dim3(batch), dim3(NT), lds, ctx->stream, g);
         else hipLaunchKernelGGL(eigh_kernel<16>, dim3(batch), dim3(NT), lds, ctx->stream, g);
@@ -400,6 +471,13 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     DMK_HIP(ctx, hipMemcpyAsync(&status, g.status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (status != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "eigh: QL iteration did not converge");
+    if (getenv("DMK_EIGH_TIMING")) {
+        long long tp[8];
+        DMK_HIP(ctx, hipMemcpy(tp, g.status + 2, sizeof(tp), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[eigh n=%d batch=%d] matrix 0: init %.3f ms, tridiag %.3f ms, QL %.3f ms (scalar %.3f, apply %.3f; %lld rotations in "
+                "%lld sweeps), sort+back %.3f ms\n", n, batch, tp[0] * 1e-5, tp[1] * 1e-5, tp[2] * 1e-5, tp[4] * 1e-5, tp[5] * 1e-5,
+                tp[6], tp[7], tp[3] * 1e-5);
+    }
     return DMK_OK;
 }
 

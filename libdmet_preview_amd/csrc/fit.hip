@@ -22,11 +22,7 @@ constexpr int NW = NT / 64;
 constexpr int RB = 32;            // rows per workgroup (gemv2)
 constexpr int CI = 8;             // column iterations per workgroup (gemv2): 2048 columns
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return dmk_wave_sum(v); }
 
 __device__ __forceinline__ void tril_rc(long long t, int &k, int &l) {
     k = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);

@@ -23,11 +23,7 @@ constexpr int NT = 256;
 constexpr int NW = NT / 64;
 constexpr int JRB = 32;          // packed rows per workgroup in the J kernel
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return dmk_wave_sum(v); }
 
 // x~[pair(k,l)] = dm[k][l] + dm[l][k] (k > l), dm[k][k]
 __global__ void jk_fold_dm_kernel(int n, const double *__restrict__ dm, double *__restrict__ xt) {

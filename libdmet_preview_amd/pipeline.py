@@ -206,6 +206,50 @@ def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None):
     return {"H1": H1, "JK_core": H1 - hcore_emb, "rdm1_emb": rdm1_emb, "veff": veff, "fock_emb": fock_emb}
 
 
+def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, noise=0.02, seed=77):
+    """Correlation-potential fit in the embedding space (routine/slater.py:909-1329) on the synthetic system:
+    the target is the mean-field embedded density plus a seeded symmetric perturbation (it stands in for the
+    impurity solver's density), the potential is VcorLocal on the valence orbitals (C5: 56 -> 3192 parameters).
+    Returns per-evaluation timings; replicated work (every rank holds basis and target)."""
+    from libdmet_preview_amd.dmet import Hubbard
+    from libdmet_preview_amd.system.lattice import Lattice
+    n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
+    L = Lattice(n, sysm.mesh)
+    L.val_idx, L.virt_idx, L.core_idx = list(sysm.val_idx), [i for i in range(n) if i not in sysm.val_idx], []
+    Fk = sysm.d_Fock_k.get().reshape(spin, nk, n, n)
+    L.fock_lo_k = L.hcore_lo_k = Fk if spin == 2 else Fk[0]
+    basis = d_basis.get().reshape(spin, nk, n, nemb)
+    rng = np.random.default_rng(seed)
+    x = noise * rng.standard_normal(rdm1_emb.shape)
+    target = rdm1_emb + 0.5 * (x + x.transpose(0, 2, 1))
+    v = Hubbard.VcorLocal(spin == 1, False, n, idx_range=sysm.val_idx)
+    ctx.sync()
+    t0 = time.perf_counter()
+    v, e0, e1 = slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=MaxIter, nelec=int(round(nemb * sysm.filling)) if spin == 1
+                                  else [int(round(nemb * sysm.filling))] * 2)
+    ctx.sync()
+    t_total = time.perf_counter() - t0
+    fit = slater.FitVcorEmb.last_fit
+    p = v.param.copy()
+    reps = 3
+    ctx.sync()
+    t = time.perf_counter()
+    for r in range(reps):
+        fit.errfunc(p + 1e-9 * (r + 1))
+    ctx.sync()
+    t_err = (time.perf_counter() - t) / reps
+    t = time.perf_counter()
+    for r in range(reps):
+        fit.gradfunc(p + 1e-9 * (r + 11))
+    ctx.sync()
+    t_grad = (time.perf_counter() - t) / reps
+    dV_bytes = fit.d_dV.nbytes
+    return {"nparam": int(v.length()), "nemb": int(nemb), "MaxIter": int(MaxIter), "err_begin": float(e0), "err_end": float(e1),
+            "seconds_total": t_total, "objective_evals": int(fit.nfev), "gradient_evals": int(fit.ngev),
+            "ms_per_objective": 1e3 * t_err, "ms_per_objective_plus_gradient": 1e3 * t_grad,
+            "dV_dparam_bytes": int(dV_bytes), "vcor": v}
+
+
 def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_blocks_per_kL=None):
     """DF half transform + contraction over this rank's kL shard; returns (nblocks, flops_half, flops_contract)."""
     timers = {} if timers is None else timers
