@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--max-blocks-per-kl", type=int, default=0, help="debug: truncate the i-loop (0 = all)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--fit-iters", type=int, default=3, help="CG iterations of the vcor fit measured after the timed steps "
+                                                            "(0 = skip); reported under \"vcor_fit\", never part of `value`")
     return p.parse_args()
 
 
@@ -242,6 +244,23 @@ def main():
             "eri_only_tflops": round(flops / a.steps / (timers.get("eri", 1e-9) / a.steps) / 1e12, 3),
             "roofline": roofline,
         }
+        # ERI x density inside the step: two J passes + one J(both directions) pass + two K passes over 8.66 GB blocks
+        if "jk" in fam_out and sysm.spin == 2:
+            gb = 5 * 8.0 * npair * npair / 1e9
+            res["emb_ham"] = {"jk_ms_per_step": round(fam_out["jk"]["ms_total"] / a.steps, 3),
+                              "jk_algorithmic_GB_per_step": round(gb, 2),
+                              "jk_GBps": round(gb * a.steps / (fam_out["jk"]["ms_total"] * 1e-3), 1), "hbm_peak_GBps": 8000.0}
+        if a.fit_iters > 0:
+            # vcor least-squares fit of the BASELINE target (config 5): measured once, outside the timed region
+            fit = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], nemb, out["emb_ham"]["rdm1_emb"], MaxIter=a.fit_iters)
+            fit.pop("vcor")
+            passes_bytes = 2.0 * fit["dV_dparam_bytes"]
+            fit["note"] = ("FitVcorEmb, VcorLocal on the valence orbitals, CG with analytic gradient; one objective = one pass over "
+                           "dV_dparam + one eigh(nemb) per spin + nemb^3 algebra; objective+gradient = two passes; the eigh "
+                           "latency of two %dx%d matrices dominates" % (nemb, nemb))
+            fit["dV_stream_GBps_if_only_cost"] = round(passes_bytes / (fit["ms_per_objective_plus_gradient"] * 1e-3) / 1e9, 1)
+            res["vcor_fit"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in fit.items()}
+            res["iteration_plus_fit_wall_s"] = round(elapsed / a.steps + fit["seconds_total"], 4)
         if not a.no_cpu_baseline:
             th, tc, desc, threads = cpu_baseline(sysm, nemb, a.cpu_seconds)
             fh, fc = out["flops_half"], out["flops_contract"]

@@ -172,3 +172,13 @@ def test_fit_nonorthogonal_overlap_and_numeric_gradient(ctx, golden):
     assert e1 <= e0
     with pytest.raises(NotImplementedError):
         slater.FitVcorEmb(target, L, basis, v4, np.inf, idem_fit=True)
+
+
+def test_pipeline_fit_round_trip(ctx):
+    """Hidden-parameter round trip on a small synthetic system: the fit must drive the error towards zero."""
+    from libdmet_preview_amd import pipeline
+    sysm = pipeline.SyntheticSystem(ctx, (3, 2, 1), 8, 6, 3, 2, seed=31, name="t")
+    out = pipeline.iteration(ctx, sysm)
+    res = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], out["nemb"], out["emb_ham"]["rdm1_emb"], MaxIter=60)
+    assert res["err_end"] < 1e-2 * res["err_begin"], res
+    assert res["objective_evals"] > 0 and res["gradient_evals"] > 0
