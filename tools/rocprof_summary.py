@@ -40,7 +40,8 @@ def pmc(db):
 
 
 FAMILY = [("dgemm_tn_acc", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"),
-          ("philox_block", "philox"), ("eigh_kernel", "eigh")]
+          ("philox_block", "philox"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"), ("jk_k_kernel", "jk_k"),
+          ("gemv2_kernel", "gemv2")]
 
 
 def traffic_json(dbs, out):
