@@ -22,8 +22,9 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 320;          // five waves: during the QL phase four apply rotation sweeps while the fifth produces them
 constexpr int NW = NT / 64;
+constexpr int NC = NT - 64;      // consumer threads of the QL phase
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -49,7 +50,7 @@ struct EighArgs {
     int *status;            // device flag, set to 1 on non-convergence
 };
 
-// LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2n] f64 | red[2*NW + 8] f64
+// LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2][2n] f64 | red[3*NW + 2] f64 | 16 ints | dl[n] | el[n]
 template <int R>
 __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     double2 *vbuf = reinterpret_cast<double2 *>(smem);
     double2 *pbuf = vbuf + n;
     double *cs = reinterpret_cast<double *>(pbuf + n);
-    double *red = cs + 2 * n;          // 2*NW + 8 doubles
-    int *ired = reinterpret_cast<int *>(red + 2 * NW + 4);
+    double *red = cs + 4 * n;          // 3*NW + 2 doubles
+    int *ired = reinterpret_cast<int *>(red + 3 * NW + 2);     // 16 ints
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,45 +208,58 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     __syncthreads();
 
     tphase[2] = wall_clock64();
-    // ---- phase 2: implicit QL with rotation sweeps applied to Zt ---------------------------------
-    // e[i] couples i and i+1.  d and e live in LDS for this phase; the split point is found with a ballot over 64
-    // candidates at a time; the scalar recurrence of a sweep runs on one lane with the next (d[i], e[i]) already in
-    // registers and ONE reciprocal square root per rotation (v_rsq_f64 + two Newton steps) instead of a square
-    // root and two divisions; the sweep is then applied to Zt with the row loads of eight rotations in flight.
+    // ---- phase 2: implicit QL, rotation sweeps applied to Zt ---------------------------------------
+    // e[i] couples i and i+1.  The sequential recurrence that generates a sweep (one lane) and the application of a
+    // sweep to Zt (all columns in parallel) only meet through the rotation list, so they run CONCURRENTLY: wave NW-1
+    // produces sweeps into a double-buffered list in LDS, waves 0..NW-2 consume them, each on its own columns
+    // (a sweep on a column only depends on the previous sweep on that column).  Hand-over is by sequence counters
+    // in LDS.  The tridiagonal (d, e) lives in LDS; the split point is found by a 64-wide ballot; a rotation
+    // costs one v_rsq_f64 + two Newton steps instead of a square root and two divisions; the sweep is applied with
+    // the row loads of eight rotations in flight.
     {
-        double *dl = red + 2 * NW + 8;            // [n]
-        double *el = dl + n;                      // [n]
+        volatile int *ctl = ired;                 // [0] sweeps published, [1] producer finished, [2..2+NW-2] consumer progress
+        int *meta = ired + 8;                     // [2][2] = (mm, cnt) per buffer
+        double *dl = reinterpret_cast<double *>(ired + 16);   // [n]
+        double *el = dl + n;                                  // [n]
         for (int t = tid; t < n; t += NT) {
             dl[t] = d[t];
             el[t] = e[t];
         }
+        if (tid < 16) ired[tid] = 0;
         __syncthreads();
         const double eps = 2.220446049250313e-16;
-        long long t_scalar = 0, t_apply = 0, n_rot = 0, n_sweep = 0;
-        for (int l = 0; l < n; ++l) {
-            int iter = 0;
-            while (true) {
-                const long long tq0 = wall_clock64();
-                // first negligible off-diagonal at or after l: wave 0 scans 64 candidates per step
-                if (wave == 0) {
-                    int found = n - 1;
+        if (wave == NW - 1) {
+            // ---------------- producer ----------------
+            int k = 0;
+            bool fail = false;
+            for (int l = 0; l < n && !fail; ++l) {
+                int iter = 0;
+                while (true) {
+                    int mm = n - 1;
                     for (int base = l; base < n - 1; base += 64) {
                         const int mq = base + lane;
                         bool small = false;
                         if (mq < n - 1) small = fabs(el[mq]) <= eps * (fabs(dl[mq]) + fabs(dl[mq + 1]));
                         const unsigned long long mask = __ballot(small);
                         if (mask != 0ull) {
-                            found = base + __ffsll((long long)mask) - 1;
+                            mm = base + __ffsll((long long)mask) - 1;
                             break;
                         }
                     }
-                    if (lane == 0) ired[0] = found;
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    const int mm = ired[0];
-                    int cnt = 0;     // number of rotations recorded; rotation q acts on rows (mm-1-q, mm-q)
-                    if (mm != l) {
+                    if (mm == l) break;
+                    // buffer k & 1 is free once every consumer has finished sweep k - 2
+                    if (k >= 2) {
+                        while (true) {
+                            int lowest = ctl[2];
+#pragma unroll
+                            for (int w = 1; w < NW - 1; ++w) lowest = min(lowest, ctl[2 + w]);
+                            if (lowest >= k - 1) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    double *csb = cs + (size_t)(k & 1) * 2 * n;
+                    if (lane == 0) {
+                        int cnt = 0;     // rotation q acts on rows (mm-1-q, mm-q)
                         double gq = (dl[l + 1] - dl[l]) / (2.0 * el[l]);
                         double r = sqrt(gq * gq + 1.0);
                         gq = dl[mm] - dl[l] + el[l] / (gq + (gq >= 0.0 ? fabs(r) : -fabs(r)));
@@ -255,10 +269,11 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                         double d_hi = dl[mm];                          // d[i+1], untouched so far in this sweep
                         double e_i = el[i], d_i = dl[i];
                         for (; i >= l; --i) {
-                            const double e_nx = (i > l) ? el[i - 1] : 0.0, d_nx = (i > l) ? dl[i - 1] : 0.0;   // prefetch
                             const double f = s * e_i;
                             const double bq = c * e_i;
                             const double x = f * f + gq * gq;
+                            const int ip = i > l ? i - 1 : l;          // next iteration's (e, d), clamped: no branch
+                            const double e_nx = el[ip], d_nx = dl[ip];
                             if (x == 0.0) {
                                 el[i + 1] = 0.0;
                                 dl[i + 1] = d_hi - p;
@@ -279,8 +294,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                             p = s * r;
                             dl[i + 1] = gq + p;
                             gq = c * r - bq;
-                            cs[2 * cnt] = c;
-                            cs[2 * cnt + 1] = s;
+                            csb[2 * cnt] = c;
+                            csb[2 * cnt + 1] = s;
                             ++cnt;
                             d_hi = d_i;
                             d_i = d_nx;
@@ -291,18 +306,37 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                             el[l] = gq;
                             el[mm] = 0.0;
                         }
+                        meta[2 * (k & 1)] = mm;
+                        meta[2 * (k & 1) + 1] = cnt;
                     }
-                    ired[1] = cnt;
+                    __threadfence_block();
+                    ++k;
+                    if (lane == 0) ctl[0] = k;
+                    if (++iter > 80) {
+                        if (lane == 0) *g.status = 1;
+                        fail = true;
+                        break;
+                    }
                 }
-                __syncthreads();
-                const int mm = ired[0], cnt = ired[1];
-                const long long tq1 = wall_clock64();
-                t_scalar += tq1 - tq0;
-                n_rot += cnt;
-                n_sweep += 1;
-                if (mm == l) { __syncthreads(); break; }
-                // apply the sweep: rotation q on rows (i, i+1) of Zt with i = mm-1-q
-                for (int rcol = tid; rcol < n; rcol += NT) {
+            }
+            __threadfence_block();
+            if (lane == 0) ctl[1] = 1;
+        } else {
+            // ---------------- consumers ----------------
+            int k = 0;
+            while (true) {
+                const int fin = ctl[1];
+                const int avail = ctl[0];
+                if (avail <= k) {
+                    if (fin) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                __threadfence_block();
+                const int mm = meta[2 * (k & 1)], cnt = meta[2 * (k & 1) + 1];
+                const double *csb = cs + (size_t)(k & 1) * 2 * n;
+                // rotation q on rows (i, i+1) of Zt with i = mm-1-q
+                for (int rcol = tid; rcol < n; rcol += NC) {
                     double hi = Zt[(size_t)mm * n + rcol];
                     double lo[8], nx[8];
 #pragma unroll
@@ -319,7 +353,7 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                         for (int u = 0; u < 8; ++u) {
                             const int q = q0 + u;
                             if (q < cnt) {
-                                const double c = cs[2 * q], sn = cs[2 * q + 1];
+                                const double c = csb[2 * q], sn = csb[2 * q + 1];
                                 Zt[(size_t)(mm - q) * n + rcol] = sn * lo[u] + c * hi;
                                 hi = c * lo[u] - sn * hi;
                             }
@@ -327,19 +361,16 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                     }
                     Zt[(size_t)(mm - cnt) * n + rcol] = hi;
                 }
-                __syncthreads();
-                t_apply += wall_clock64() - tq1;
-                if (++iter > 80) {
-                    if (tid == 0) *g.status = 1;
-                    break;
-                }
+                ++k;
+                __threadfence_block();
+                if (lane == 0) ctl[2 + wave] = k;
             }
         }
         __syncthreads();
         for (int t = tid; t < n; t += NT) d[t] = dl[t];
         if (b == 0 && tid == 0) {
             long long *tp = reinterpret_cast<long long *>(g.status + 2);
-            tp[4] = t_scalar; tp[5] = t_apply; tp[6] = n_rot; tp[7] = n_sweep;
+            tp[4] = 0; tp[5] = 0; tp[6] = 0; tp[7] = ctl[0];
         }
     }
     __syncthreads();
@@ -453,7 +484,7 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
     // reflector rows are only partially written; clear so that masked lanes read zeros
     DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
-    const size_t lds = (size_t)n * (16 + 16 + 16 + 16) + (2 * NW + 8) * 8 + 64;
+    const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64;
     {
         FamScope fs(ctx, DMK_FAM_EIGH);
         if (lds > 48 * 1024) {
