@@ -11,12 +11,18 @@ get_emb_Ham (slater.py:320-704) completes the exit of the path: H2 from the DF t
 4-index transform for models), H1 = basis^H (hcore + vhf) basis - JK_emb with JK_emb from dmk_jk_s4.
 """
 from math import sqrt
+try:
+    from collections.abc import Iterable
+except ImportError:  # pragma: no cover
+    from collections import Iterable
 
 import numpy as np
 
 from libdmet_preview_amd._lib import lib, mesh3, get_ctx
 from libdmet_preview_amd.routine import ftsystem
 from libdmet_preview_amd.routine.fit import minimize
+from libdmet_preview_amd.routine.mfd import check_nelec as mfd_check_nelec
+from libdmet_preview_amd.settings import IMAG_DISCARD_TOL
 from libdmet_preview_amd.utils.misc import max_abs
 from libdmet_preview_amd.basis_transform.eri_transform import get_emb_eri, get_unit_eri
 from libdmet_preview_amd.routine.slater_helper import *       # noqa: F401,F403  (reference: slater.py:35)
@@ -661,3 +667,158 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
             vcor.update(param_new)
     FitVcorEmb.last_fit = fit          # evaluation counters / device state of the most recent fit (bench, tests)
     return vcor, err_begin, err_end
+
+
+class FullFitDevice(object):
+    """errfunc of FitVcorFull (slater.py:1448-1478): the whole lattice is re-diagonalised for every parameter vector
+    (dmk_eigh_batched over all k and spins with the trial vcor as the shared shift, Fock_k resident in HBM),
+    occupations on the host, density on the device and either its fold into the embedding space (imp + bath fit)
+    or its cell-0 block (impurity / diagonal fit)."""
+
+    def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, imp_bath_fit, fix_mu=False):
+        from libdmet_preview_amd.routine import mfd
+        from libdmet_preview_amd.system import fourier
+        from libdmet_preview_amd.basis_transform.make_basis import bgemm_dev
+        self._mfd, self._fourier, self._bgemm = mfd, fourier, bgemm_dev
+        self.ctx, self.vcor, self.lattice = ctx, vcor, lattice
+        basis = np.asarray(basis, dtype=np.float64)
+        spin, nk, n, nb = basis.shape
+        self.spin, self.nk, self.n, self.nb = spin, nk, n, nb
+        self.beta, self.nelec, self.fix_mu, self.imp_bath_fit = beta, nelec, fix_mu, imp_bath_fit
+        Fock = np.asarray(lattice.getFock(kspace=True))
+        if Fock.ndim == 3:
+            Fock = Fock[np.newaxis]
+        if Fock.shape[0] < spin:
+            Fock = np.asarray((Fock[0],) * spin)
+        self.d_F = ctx.to_device(Fock[:spin].reshape(spin * nk, n, n), np.complex128)
+        if imp_bath_fit:
+            self.d_bk = fourier.fold_R2k_dev(ctx.to_device(basis.reshape(spin, nk, n * nb)), lattice.kmesh, spin, n * nb)
+        self.fit_idx = list(imp_idx) + list(det_idx)
+        nimp, nidx = len(imp_idx), len(self.fit_idx)
+        self.nidx = nidx
+        W = np.zeros((nidx, nidx))
+        W[:nimp, :nimp] = 1.0
+        W[range(nimp, nidx), range(nimp, nidx)] = 1.0
+        target = np.zeros((spin, nidx, nidx))
+        for s in range(spin):
+            target[s][:nimp, :nimp] = rho[s][np.ix_(imp_idx, imp_idx)]
+            target[s][range(nimp, nidx), range(nimp, nidx)] = rho[s][det_idx, det_idx]
+        self.d_W = ctx.to_device(np.asarray([W] * spin))
+        self.d_target = ctx.to_device(target)
+        self.d_fit = ctx.to_device(np.asarray(self.fit_idx, dtype=np.int32))
+        self.d_rfit = ctx.empty((spin, nidx, nidx), np.float64)
+        self.d_drho = ctx.empty((spin, nidx, nidx), np.float64)
+        self.d_ss = ctx.empty((1,), np.float64)
+        self.nfev = 0
+
+    def errfunc(self, param):
+        self.nfev += 1
+        ctx, spin, nk, n, nb, nidx = self.ctx, self.spin, self.nk, self.n, self.nb, self.nidx
+        mfd = self._mfd
+        self.vcor.update(param)
+        v = np.ascontiguousarray(np.asarray(self.vcor.get(0, True))[:spin].real, dtype=np.float64)
+        d_add = ctx.to_device(v)
+        d_w, d_Vt = mfd.eigh_dev(ctx, self.d_F, n, spin * nk, d_add, nk)
+        ew = d_w.get().reshape(spin, nk, n)
+        occ, mu, nerr = mfd.assignocc(ew, self.nelec, self.beta, mu0=0.0, fix_mu=self.fix_mu)
+        d_occ = ctx.to_device(np.ascontiguousarray(occ).reshape(spin * nk, n), np.float64)
+        d_rho = mfd.density_dev(ctx, d_Vt, d_occ, n, spin * nk)                   # (spin*nk, n, n) c128
+        if self.imp_bath_fit:
+            d_T = self._bgemm(ctx, "N", "N", n, nb, n, spin * nk, d_rho, n * n, self.d_bk, n * nb)
+            d_R = self._bgemm(ctx, "C", "N", nb, nb, nk * n, spin, self.d_bk, nk * n * nb, d_T, nk * n * nb, alpha=1.0 / nk)
+            dens = np.ascontiguousarray(d_R.get().reshape(spin, nb, nb).real)
+            m = nb
+        else:
+            imax = ctx.zeros((1,), np.float64)
+            d_rhoR = self._fourier.fold_k2R_dev(d_rho.reshape(spin, nk, n * n), self.lattice.kmesh, spin, n * n, imag_max=imax)
+            dens = np.ascontiguousarray(d_rhoR.get().reshape(spin, nk, n, n)[:, 0])      # (1/nk) sum_k rho_k, real part
+            if float(imax.get()[0]) > IMAG_DISCARD_TOL:
+                log.warn("rhoT has imag part %s", float(imax.get()[0]))
+            m = n
+        d_dens = ctx.to_device(dens)
+        for s in range(spin):
+            ctx.check(lib.dmk_gather2d_f64(ctx.h, nidx, nidx, self.d_fit.ptr, self.d_fit.ptr, d_dens.offset(s * m * m, (m, m)).ptr,
+                                           m, self.d_rfit.offset(s * nidx * nidx, (nidx, nidx)).ptr))
+        ctx.check(lib.dmk_ewise_mul(ctx.h, 0, spin * nidx, nidx, self.d_rfit.ptr, self.d_W.ptr, self.d_rfit.ptr))
+        ctx.check(lib.dmk_sub_sumsq(ctx.h, spin * nidx * nidx, self.d_rfit.ptr, self.d_target.ptr, self.d_drho.ptr, self.d_ss.ptr))
+        val = float(np.sqrt(self.d_ss.get()[0]))
+        ctx.sync()
+        return val / sqrt(spin)
+
+
+def FitVcorFull(rho, lattice, basis, vcor, beta, filling, MaxIter=20, imp_fit=False, imp_idx=None, det=False, det_idx=None,
+                CG_check=False, BFGS=False, diff_criterion=None, scf=False, **kwargs):
+    """
+    Fit the correlation potential in the full lattice space (slater.py:1352-1682).  The objective runs on the device
+    (FullFitDevice); the gradient is the reference's numerical one (`num_grad=True`, central differences inside the
+    minimiser) -- its analytic finite-T lattice gradient and the SCF variant are outside the HIP path.
+    """
+    if scf or getattr(vcor, "is_vcor_kpts", False):
+        raise NotImplementedError("scf / k-dependent vcor in FitVcorFull are outside the HIP path")
+    if not kwargs.get("num_grad", False):
+        raise NotImplementedError("FitVcorFull: only num_grad=True is available on the HIP path "
+                                  "(the reference itself has no analytic T = 0 gradient, slater.py:1631-1634)")
+    basis = np.asarray(basis)
+    param_begin = vcor.param.copy()
+    spin, nkpts, nao, nbasis = basis.shape
+    assert len(rho) == spin
+    imp_bath_fit = False
+    if imp_fit:
+        if imp_idx is None:
+            imp_idx = list(range(lattice.nimp))
+        det_idx = []
+    elif det:
+        imp_idx = []
+        if det_idx is None:
+            det_idx = list(range(lattice.nimp))
+    elif imp_idx is None:
+        if det_idx is None:
+            imp_idx, det_idx = list(range(nbasis)), []
+            imp_bath_fit = True
+        else:
+            imp_idx = []
+    elif det_idx is None:
+        det_idx = []
+    imp_idx, det_idx = list(imp_idx), list(det_idx)
+    if np.asarray(rho).shape[-1] != nao:
+        log.warn("FitVcorFull: target rho should has shape (%s, %s, %s) , now has shape %s ...", spin, nao, nao,
+                 np.asarray(rho).shape)
+    if isinstance(filling, Iterable):
+        nelec = [nkpts * nao * filling[0], nkpts * nao * filling[1]]
+        nelec[0], nelec[1] = mfd_check_nelec(nelec[0])[0], mfd_check_nelec(nelec[1])[0]
+    else:
+        nelec = mfd_check_nelec(spin * nkpts * nao * filling)[0]
+    ctx = get_ctx()
+    fit = FullFitDevice(ctx, np.asarray(rho), lattice, basis, vcor, beta, nelec, imp_idx, det_idx, imp_bath_fit,
+                        fix_mu=kwargs.get("fix_mu", False))
+    log.warn("You are using numerical gradient...")
+    err_begin = fit.errfunc(param_begin)
+    param, err_end, pattern, gnorm_res = minimize(fit.errfunc, param_begin.copy(), MaxIter, None, **kwargs)
+    vcor.update(param)
+    log.info("Minimizer converge pattern: %d ", pattern)
+    log.info("Current function value: %15.8f", err_end)
+    log.info("Norm of gradients: %s", gnorm_res)
+    log.info("Norm diff of x: %6.3e", max_abs(param - param_begin))
+    FitVcorFull.last_fit = fit
+    return vcor, err_begin, err_end
+
+
+def FitVcorTwoStep(rho, lattice, basis, vcor, beta, filling, MaxIter1=300, MaxIter2=0, **kwargs):
+    """Main wrapper for correlation potential fitting (slater.py:1684-1714): embedding-space stage, then lattice stage."""
+    import copy
+    vcor_new = copy.deepcopy(vcor)
+    log.result("Using two-step vcor fitting")
+    err_begin = None
+    if MaxIter1 > 0:
+        log.info("Impurity model stage  max %d steps", MaxIter1)
+        vcor_new, err_begin, err_end = FitVcorEmb(rho, lattice, basis, vcor_new, beta, MaxIter=MaxIter1, **kwargs)
+        log.result("residue (begin) = %20.12f", err_begin)
+        log.info("residue (end)   = %20.12f", err_end)
+    if MaxIter2 > 0:
+        log.info("Full lattice stage  max %d steps", MaxIter2)
+        vcor_new, err_begin2, err_end = FitVcorFull(rho, lattice, basis, vcor_new, beta, filling, MaxIter=MaxIter2, **kwargs)
+        if err_begin is None:
+            err_begin = err_begin2
+    log.result("residue (begin) = %20.12f", err_begin)
+    log.result("residue (end)   = %20.12f", err_end)
+    return vcor_new, err_end

@@ -708,11 +708,51 @@ def gen_G9():
     print("G9 done")
 
 
+def gen_G10():
+    """Lattice-space vcor fit (FitVcorFull, numerical gradient) and the two-step wrapper (section 8f rank 2)."""
+    from libdmet.routine import slater, mfd
+    from libdmet.dmet import Hubbard
+    shim.patch_scf()
+    out = {}
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"] = fn
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    for name, mesh, nlo, spin, val, seed in [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3], 11), ("rhf_411", (4, 1, 1), 5, 1, [1, 2, 3], 12)]:
+        L, FR, basis, target = _fit_case(name, mesh, nlo, spin, val, seed)
+        nb = basis.shape[-1]
+        rng = np.random.default_rng(seed + 7)
+        x = 0.05 * rng.standard_normal((spin, nlo, nlo))
+        v0 = _Vcor(np.zeros((2, nlo, nlo)))
+        rho_loc = mfd.HF(L, v0, 0.5, spin == 1, beta=np.inf)[0][:, 0] + 0.5 * (x + x.transpose(0, 2, 1))
+        out[name + "/mesh"], out[name + "/val"], out[name + "/Fock_R"] = np.array(mesh), np.array(val), FR
+        out[name + "/basis"], out[name + "/target_emb"], out[name + "/target_loc"] = basis, target, rho_loc
+        runs = [("bath_t0", target, np.inf, dict()), ("imp_t0", rho_loc, np.inf, dict(imp_fit=True)),
+                ("det_ft", rho_loc, 12.0, dict(det=True)), ("idx_ft", rho_loc, 12.0, dict(imp_idx=[0, 1], det_idx=[nlo - 1]))]
+        for tag, rho, beta, kw in runs:
+            v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            vfit, e0, e1 = slater.FitVcorFull(rho, L, basis, v, beta, 0.5, MaxIter=2, num_grad=True, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](p.copy()) for p in P])
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        v2, e_end = slater.FitVcorTwoStep(target, L, basis, v, np.inf, 0.5, MaxIter1=5, MaxIter2=1, num_grad=True)
+        out[name + "/twostep_param"], out[name + "/twostep_err"] = np.array(v2.param), np.asarray(e_end)
+    slater.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G10_vcorfit_full.npz"), **out)
+    print("G10 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10"]
     for g in which:
         globals()["gen_" + g]()
 

@@ -280,3 +280,50 @@ class EmbFit(object):
         dw_dv = get_dw_dv(ew, ev, drho, mu, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=True)
         res = self.dV.reshape(self.dV.shape[0], -1).dot(dw_dv.ravel()) / (2.0 * val * sqrt(self.spin))
         return self._finish(res)
+
+
+# ---------------------------------------------------------------------------------------------
+# lattice-space objective (slater.py:1448-1478, FitVcorFull.errfunc)
+# ---------------------------------------------------------------------------------------------
+
+class FullFit(object):
+    def __init__(self, rho, kmesh, basis, vcor, beta, Fock_k, filling, imp_idx=None, det_idx=None, fix_mu=False):
+        from oracle.restate import check_nelec
+        spin, nk, n, nb = basis.shape
+        self.spin, self.nk, self.n, self.nb, self.beta, self.vcor, self.fix_mu = spin, nk, n, nb, beta, vcor, fix_mu
+        self.imp_bath_fit = imp_idx is None and det_idx is None
+        if self.imp_bath_fit:
+            imp_idx, det_idx = list(range(nb)), []
+        imp_idx, det_idx = list(imp_idx or []), list(det_idx or [])
+        nimp, nidx = len(imp_idx), len(imp_idx) + len(det_idx)
+        self.imp_mesh, self.det_mesh = np.ix_(imp_idx, imp_idx), (det_idx, det_idx)
+        self.imp_fill, self.det_fill = (slice(nimp), slice(nimp)), (range(nimp, nidx), range(nimp, nidx))
+        self.target = np.zeros((spin, nidx, nidx))
+        for s in range(spin):
+            self.target[s][self.imp_fill] = rho[s][self.imp_mesh]
+            self.target[s][self.det_fill] = rho[s][self.det_mesh]
+        Fock_k = np.asarray(Fock_k)
+        self.Fock = Fock_k if Fock_k.ndim == 4 else Fock_k[None]
+        self.basis_k = np.asarray([R2k(basis[s], kmesh) for s in range(spin)])
+        self.nelec = check_nelec(spin * nk * n * filling, None)[0]
+
+    def errfunc(self, param):
+        spin, nk, n = self.spin, self.nk, self.n
+        self.vcor.update(param)
+        v = self.vcor.get(0, True)
+        ew = np.empty((spin, nk, n))
+        ev = np.empty((spin, nk, n, n), dtype=np.complex128)
+        for s in range(spin):
+            for k in range(nk):
+                ew[s, k], ev[s, k] = la.eigh(self.Fock[s, k] + v[s])
+        occ, mu, _ = assignocc(ew, self.nelec, self.beta, 0.0, fix_mu=self.fix_mu)
+        rho_k = np.einsum('skpm,skm,skqm->skpq', ev, occ, ev.conj())
+        rho1 = np.zeros_like(self.target)
+        if self.imp_bath_fit:
+            rho1[:] = transform_h1(rho_k, self.basis_k)
+        else:
+            rhoT = rho_k.sum(axis=1).real / nk
+            for s in range(spin):
+                rho1[s][self.imp_fill] = rhoT[s][self.imp_mesh]
+                rho1[s][self.det_fill] = rhoT[s][self.det_mesh]
+        return la.norm(rho1 - self.target) / sqrt(spin)

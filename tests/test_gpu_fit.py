@@ -182,3 +182,38 @@ def test_pipeline_fit_round_trip(ctx):
     res = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], out["nemb"], out["emb_ham"]["rdm1_emb"], MaxIter=60)
     assert res["err_end"] < 1e-2 * res["err_begin"], res
     assert res["objective_evals"] > 0 and res["gradient_evals"] > 0
+
+
+@pytest.mark.parametrize("name", ["uhf_231", "rhf_411"])
+def test_fit_full_lattice_and_two_step(ctx, golden, name):
+    """FitVcorFull (device objective, numerical gradient) and FitVcorTwoStep against the reference's runs (golden G10)."""
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.dmet import Hubbard
+    from tests.test_oracle_fit import FULL_RUNS
+    g = golden("G10_vcorfit_full.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR, basis = g[name + "/Fock_R"], g[name + "/basis"]
+    val = [int(x) for x in g[name + "/val"]]
+    spin, nlo = basis.shape[0], FR.shape[-1]
+    Fk = R.R2k(FR, mesh)
+    L = _lattice(mesh, nlo, val, Fk, spin)
+    for tag, tkey, beta, kw in FULL_RUNS:
+        kw = dict(kw)
+        if kw.get("det_idx") == [-1]:
+            kw["det_idx"] = [nlo - 1]
+        key = "%s/%s" % (name, tag)
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        vfit, e0, e1 = slater.FitVcorFull(g[name + "/" + tkey], L, basis, v, beta, 0.5, MaxIter=2, num_grad=True, **kw)
+        fit = slater.FitVcorFull.last_fit
+        pfit = np.array(vfit.param)                       # errfunc updates the vcor object in place, like the reference's
+        for p, e in zip(g[key + "/probe"], g[key + "/probe_err"]):
+            assert abs(fit.errfunc(p) - e) < 1e-10, key
+        r0, r1 = g[key + "/err"]
+        assert abs(e0 - r0) < 1e-10 and abs(e1 - r1) < 1e-6, (key, e1, r1)
+        assert np.abs(pfit - g[key + "/param"]).max() < 1e-3, key
+    v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    v2, e_end = slater.FitVcorTwoStep(g[name + "/target_emb"], L, basis, v, np.inf, 0.5, MaxIter1=5, MaxIter2=1, num_grad=True)
+    assert v2 is not v and abs(e_end - float(g[name + "/twostep_err"])) < 1e-6
+    assert np.abs(v2.param - g[name + "/twostep_param"]).max() < 1e-3
+    with pytest.raises(NotImplementedError):
+        slater.FitVcorFull(g[name + "/target_emb"], L, basis, v, 12.0, 0.5, MaxIter=1)

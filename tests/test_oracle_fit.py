@@ -78,3 +78,29 @@ def test_G9_objective_and_gradient(golden, name):
         assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12
         assert abs(fit.errfunc(pfit) - e1) < 1e-11
         assert e1 <= e0 + 1e-12
+
+
+FULL_RUNS = [("bath_t0", "target_emb", np.inf, dict()), ("imp_t0", "target_loc", np.inf, dict(imp_fit=True)),
+             ("det_ft", "target_loc", 12.0, dict(det=True)), ("idx_ft", "target_loc", 12.0, dict(imp_idx=[0, 1], det_idx=[-1]))]
+
+
+@pytest.mark.parametrize("name", ["uhf_231", "rhf_411"])
+def test_G10_full_lattice_objective(golden, name):
+    g = golden("G10_vcorfit_full.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR, basis = g[name + "/Fock_R"], g[name + "/basis"]
+    val = [int(x) for x in g[name + "/val"]]
+    spin, nlo = basis.shape[0], FR.shape[-1]
+    Fk = R.R2k(FR, mesh)
+    for tag, tkey, beta, kw in FULL_RUNS:
+        v = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        kw = dict(kw)
+        if kw.get("det_idx") == [-1]:
+            kw["det_idx"] = [nlo - 1]
+        imp_idx, det_idx = idx_sets(kw, nlo - min(val), None)
+        fit = F.FullFit(g[name + "/" + tkey], mesh, basis, v, beta, Fk if spin == 2 else Fk[0], 0.5, imp_idx=imp_idx, det_idx=det_idx)
+        key = "%s/%s" % (name, tag)
+        for p, e in zip(g[key + "/probe"], g[key + "/probe_err"]):
+            assert abs(fit.errfunc(p) - e) < 1e-11, key
+        assert abs(fit.errfunc(np.zeros(v.length())) - g[key + "/err"][0]) < 1e-11
+        assert abs(fit.errfunc(g[key + "/param"]) - g[key + "/err"][1]) < 1e-10
