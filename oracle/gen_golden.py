@@ -748,11 +748,50 @@ def gen_G10():
     print("G10 done")
 
 
+def gen_G11():
+    """AO -> LO of the mean-field operators in front of the path (section 8f rank 4): set_Ham / transform_obj_to_lo / update_Ham."""
+    out = {}
+    rng = np.random.default_rng(21)
+    for name, mesh, nao, nlo, spin in [("rhf", (2, 3, 1), 5, 4, 1), ("uhf", (2, 2, 2), 4, 4, 2)]:
+        nk = int(np.prod(mesh))
+        L = _duck_lattice(mesh, nlo)
+        L.vxc_ao_k = L.vxc_lo_k = L.vxc_lo_R = None
+        L.bigcell = None
+        C = synth.make_C_ao_lo(mesh, nao, nlo, spin=spin, seed=3)
+        herm = lambda seed, sc: synth.fold_R2k(synth.make_fock_R(mesh, nao, spin=spin, seed=seed) * sc, mesh)
+        S = synth.fold_R2k(synth.make_fock_R(mesh, nao, spin=1, seed=5) * 0.03, mesh)[0] + np.eye(nao)
+        hcore, vj, vk = herm(6, 1.0), herm(7, 0.3), herm(8, 0.2)
+        rdm1 = herm(9, 0.1)
+        if spin == 1:
+            C, hcore, vj, vk, rdm1 = C[0], hcore[0], vj[0], vk[0], rdm1[0]
+            vhf = vj - 0.5 * vk
+        else:
+            vhf = vj[0] + vj[1] - vk
+        L.set_Ham(None, None, C, eri_symmetry=4, ovlp=S, hcore=hcore, rdm1=rdm1, vj=vj, vk=vk, vhf=vhf, H0=0.5)
+        for k in ("C", "S", "hcore", "vj", "vk", "rdm1", "vhf"):
+            out["%s/in_%s" % (name, k)] = locals()[k]
+        out[name + "/mesh"] = np.array(mesh)
+        names = ["hcore_lo_k", "ovlp_lo_k", "fock_lo_k", "fock_hf_lo_k", "veff_lo_k", "vhf_lo_k", "rdm1_lo_k",
+                 "hcore_lo_R", "ovlp_lo_R", "fock_lo_R", "fock_hf_lo_R", "veff_lo_R", "vhf_lo_R", "rdm1_lo_R"]
+        for k in names:
+            out["%s/%s" % (name, k)] = np.asarray(getattr(L, k))
+        # update_Ham with a new LO density and an externally supplied vhf
+        x = rng.standard_normal(L.rdm1_lo_R.shape) * 0.05
+        new_R = L.rdm1_lo_R + x
+        new_vhf = vhf * 1.1
+        L.update_Ham(new_R, vhf=new_vhf)
+        out[name + "/upd_rdm1_R"], out[name + "/upd_vhf"] = new_R, new_vhf
+        for k in ("rdm1_ao_k", "fock_lo_k", "rdm1_lo_k", "fock_lo_R", "vhf_lo_R"):
+            out["%s/upd_%s" % (name, k)] = np.asarray(getattr(L, k))
+    np.savez_compressed(os.path.join(GOLD, "G11_setham.npz"), **out)
+    print("G11 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11"]
     for g in which:
         globals()["gen_" + g]()
 

@@ -260,3 +260,27 @@ def test_pipeline_emb_ham_stage(ctx, spin):
     assert np.abs(ham["H1"] - H1).max() < 1e-10 * sc
     assert np.abs(ham["JK_core"] - JKc).max() < 1e-10 * sc
     assert "emb_jk" in out["timers"] and "emb_h1" in out["timers"]
+
+
+@pytest.mark.parametrize("name", ["rhf", "uhf"])
+def test_set_Ham_and_update_Ham(ctx, golden, name):
+    """Lattice.set_Ham / transform_obj_to_lo / update_Ham (AO -> LO in front of the path) against golden G11."""
+    from libdmet_preview_amd.system.lattice import Lattice
+    g = golden("G11_setham.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    C, S, hcore, vj, vk, rdm1, vhf = (g["%s/in_%s" % (name, k)] for k in ("C", "S", "hcore", "vj", "vk", "rdm1", "vhf"))
+    L = Lattice(int(C.shape[-1]), mesh)
+    L.set_Ham(None, None, C, eri_symmetry=4, ovlp=S, hcore=hcore, rdm1=rdm1, vj=vj, vk=vk, H0=0.5)    # vhf from vj, vk
+    assert L.H0 == 0.5 and L.has_Ham and L.restricted == (C.ndim == 3)
+    for k in ["hcore", "ovlp", "fock", "fock_hf", "veff", "vhf", "rdm1"]:
+        assert np.abs(getattr(L, k + "_lo_k") - g["%s/%s_lo_k" % (name, k)]).max() < 1e-11, k
+        assert np.abs(getattr(L, k + "_lo_R") - g["%s/%s_lo_R" % (name, k)].real).max() < 1e-11, k
+    L.update_Ham(g[name + "/upd_rdm1_R"], vhf=g[name + "/upd_vhf"])
+    for k in ("rdm1_ao_k", "fock_lo_k", "rdm1_lo_k", "fock_lo_R", "vhf_lo_R"):
+        ref = g["%s/upd_%s" % (name, k)]
+        ref = ref.real if k.endswith("_R") else ref
+        assert np.abs(getattr(L, k) - ref).max() < 1e-11, k
+    with pytest.raises(ValueError):
+        Lattice(int(C.shape[-1]), mesh).set_Ham(None, None, C, ovlp=S, hcore=hcore)       # no rdm1, no kmf
+    with pytest.raises(NotImplementedError):
+        L.set_Ham(None, None, C, ovlp=S, hcore=hcore, rdm1=rdm1, vhf=vhf, vxc=vhf)
