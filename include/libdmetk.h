@@ -213,6 +213,9 @@ int dmk_eri_begin_kL(dmk_eri *h, int kL);
 int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq);
 /* Contract the current kL: eri[blk] += w (Re^T Re [+ Im^T Im]) (TR) or Re(X^H X). */
 int dmk_eri_end_kL(dmk_eri *h, int weight);
+/* GSO (partial particle-hole) contraction of basis_transform/eri_transform.py:1252-1277 (_Lij_s4_to_eri_gso):
+ * eri[0] += w [(a - b)^T (a - b)] over the Re (and, w = 2, Im) planes of the two flavours; needs spin = 2 at begin. */
+int dmk_eri_end_kL_gso(dmk_eri *h, int weight);
 /* Device pointers of the current kL's Lij_s4 planes (spin x 2 x naux x npair f64:
  * Re plane then Im plane) for inspection / tests. */
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out);

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "dmk_eri_begin_kL": (c_int, [c_vp, c_int]),
     "dmk_eri_push_block": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
     "dmk_eri_end_kL": (c_int, [c_vp, c_int]),
+    "dmk_eri_end_kL_gso": (c_int, [c_vp, c_int]),
     "dmk_eri_planes": (c_int, [c_vp, P(c_vp), P(c_i64)]),
     "dmk_eri_finish": (c_int, [c_vp]),
     "dmk_eri_flops": (c_int, [c_vp, P(c_dbl)]),

@@ -197,8 +197,9 @@ def eri_restore(eri, symmetry, nemb):
 class EriEngine(object):
     """Owns a dmk_eri pipeline: plan -> (begin_kL, push_block*, end_kL)* on one GPU."""
 
-    def __init__(self, ctx, kmesh, nao, naux, nemb, spin, C_ao_emb_dev, eri_dev, t_reversal_symm=True):
+    def __init__(self, ctx, kmesh, nao, naux, nemb, spin, C_ao_emb_dev, eri_dev, t_reversal_symm=True, gso=False):
         self.ctx = ctx
+        self.gso = bool(gso)
         self.kmesh = [int(x) for x in kmesh] + [1] * (3 - len(kmesh))
         self.nao, self.naux, self.nemb, self.spin = int(nao), int(naux), int(nemb), int(spin)
         self.tr = bool(t_reversal_symm)
@@ -230,7 +231,10 @@ class EriEngine(object):
             nblk += 1
             if max_blocks is not None and nblk >= max_blocks:
                 break
-        ctx.check(lib.dmk_eri_end_kL(self.h, int(self.weights[kL])))
+        if self.gso:
+            ctx.check(lib.dmk_eri_end_kL_gso(self.h, int(self.weights[kL])))
+        else:
+            ctx.check(lib.dmk_eri_end_kL(self.h, int(self.weights[kL])))
         return nblk
 
     def run(self, provider, kL_list=None, user_of_mesh=None):
@@ -403,3 +407,54 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
 
 
 get_emb_eri_fast = get_emb_eri_fast_gdf
+
+
+def get_emb_eri_gso(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscaled_center=None, symmetry=4, max_memory=None,
+                    kconserv_tol=KPT_DIFF_TOL, unit_eri=False, swap_idx=None, t_reversal_symm=True, basis_k=None,
+                    incore=True, fout="H2.h5"):
+    """
+    Embedding ERI with the partial particle-hole (GSO) transform (eri_transform.py:1104-1250).
+
+    C_ao_lo ((spin,) nkpts, nao, nlo); basis (ncells, 2 nlo, nemb) in R, its alpha / beta row halves are the two
+    flavours of the half transform; the contraction is (a - b)^T (a - b) (dmk_eri_end_kL_gso).  Returns
+    (1, npair, npair) f64 for symmetry = 4 or the restored forms.
+    """
+    if kscaled_center is not None:
+        raise NotImplementedError("kscaled_center shifts are not supported by the integer-mesh bookkeeping")
+    if not incore:
+        raise NotImplementedError("out-of-core GSO ERI is outside the HIP path")
+    if basis_k is not None:
+        raise NotImplementedError("pass the R-space basis; basis_k input is outside the HIP path")
+    ctx = get_ctx()
+    nao = int(cell.nao_nr())
+    kpts = mydf.kpts
+    nkpts = len(kpts)
+    naux = int(mydf.naux)
+    kmesh, perm = _mesh_and_perm(cell, kpts, kconserv_tol)
+    user_of_mesh = None
+    if perm is not None:
+        user_of_mesh = np.empty(nkpts, dtype=np.int64)
+        user_of_mesh[perm] = np.arange(nkpts)
+    Cl = add_spin_dim(np.asarray(C_ao_lo), 2)          # always two flavours (eri_transform.py:1131-1133)
+    if user_of_mesh is not None:
+        Cl = np.take(Cl, user_of_mesh, axis=1)
+    if unit_eri:
+        C_dev = make_C_ao_emb_dev(ctx, kmesh, C_ao_lo=Cl, unit_eri=True, nao=nao)
+    else:
+        assert basis is not None and np.asarray(basis).ndim == 3
+        basis = np.asarray(basis)
+        nlo = basis.shape[1] // 2
+        sep = np.asarray((basis[:, :nlo], basis[:, nlo:]))          # spinless.separate_basis
+        C_dev = make_C_ao_emb_dev(ctx, kmesh, C_ao_lo=Cl, basis=sep, nao=nao)
+    spin, _, nao_c, nemb = C_dev.shape
+    assert nao_c == nao and spin == 2
+    npair = nemb * (nemb + 1) // 2
+    eri_dev = ctx.zeros((1, npair, npair), np.float64)
+    eng = EriEngine(ctx, kmesh, nao, naux, nemb, 2, C_dev, eri_dev, t_reversal_symm, gso=True)
+    try:
+        eng.run(mydf, user_of_mesh=user_of_mesh)
+        eri = eri_dev.get()
+    finally:
+        eng.close()
+    log.debug(1, "ERI restore")
+    return eri_restore(eri, symmetry, nemb)

@@ -753,6 +753,50 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
     return DMK_OK;
 }
 
+namespace {
+__global__ void planes_sub_kernel(long long n, double *__restrict__ a, const double *__restrict__ b) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        a[t] -= b[t];
+}
+}  // namespace
+
+// GSO (partial particle-hole) contraction, eri_transform.py:1252-1277: with the two "spin" flavours a, b of the
+// half-transformed tensor, aaaa + bbbb - aabb - bbaa = (a - b)^T (a - b): ONE symmetric GEMM on the difference planes.
+int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: no kL in progress");
+    if (h->spin != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: needs the two flavours (spin = 2)");
+    {
+        int rcf = eri_flush(h);
+        if (rcf) return rcf;
+    }
+    int K;
+    double alpha;
+    if (h->tr) {
+        if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: weight must be 1 or 2");
+        K = weight == 1 ? h->naux : 2 * h->naux;
+        alpha = (double)weight;
+    } else {
+        K = 2 * h->naux;
+        alpha = 1.0;
+    }
+    const int64_t np = h->npair;
+    double *X0 = h->planes;
+    const double *X1 = h->planes + (size_t)2 * h->naux * np;
+    const long long nel = (long long)2 * h->naux * np;
+    {
+        FamScope fs(ctx, DMK_FAM_MISC);
+        hipLaunchKernelGGL(planes_sub_kernel, dim3(8192), dim3(256), 0, ctx->stream, nel, X0, X1);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
+    if (rc) return rc;
+    h->flops_contract += 2.0 * (double)K * (double)np * (double)np;
+    h->cur_kL = -1;
+    return DMK_OK;
+}
+
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     if (!h || !planes_out) return DMK_ERR_INVALID;
     {

@@ -787,11 +787,52 @@ def gen_G11():
     print("G11 done")
 
 
+def gen_G12():
+    """GSO (spinless) twins, section 8f rank 4: spinless.get_emb_basis and get_emb_eri_gso."""
+    from oracle import restate
+    et = shim.patch_eri_transform()
+    from libdmet.system import fourier as rf
+    from libdmet.routine import spinless
+    out = {}
+    # --- GSO bath from the generalised density matrices of G7 --------------------------------------
+    g7 = np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        GRho = g7[name + "/GRho"]
+        out["bath/%s/basis" % name] = spinless.get_emb_basis(L, GRho)
+        out["bath/%s/basis_full" % name] = spinless.get_emb_basis(L, GRho, valence_bath=False)
+    # --- GSO ERI ---------------------------------------------------------------------------------
+    for name, mesh, nao, naux, nemb in [("m311", (3, 1, 1), 3, 2, 5), ("m221", (2, 2, 1), 4, 3, 6), ("m222", (2, 2, 2), 3, 2, 4)]:
+        nk = int(np.prod(mesh))
+        ks = rf.make_kpts_scaled(mesh)
+        cell = shim.FakeCell(nao)
+        kpts = cell.get_abs_kpts(ks)
+        W0 = synth.make_W0(mesh, naux, nao, seed=2000 + nk + nao)
+        blocks = synth.df_blocks_from_W0(W0, mesh)
+        mydf = shim.FakeGDF(cell, kpts, lambda i, j, b=blocks: b[i, j], naux=naux, blockdim=max(1, naux // 2 + 1))
+        rng = np.random.default_rng(77 + nk)
+        basis = rng.standard_normal((nk, 2 * nao, nemb))
+        out[name + "/mesh"], out[name + "/W0"], out[name + "/basis"] = np.array(mesh), W0, basis
+        for spin in (1, 2):
+            C_ao_lo = synth.make_C_ao_lo(mesh, nao, nao, spin=spin, seed=60 + spin)
+            Cin = C_ao_lo[0] if spin == 1 else C_ao_lo
+            st = "%s/s%d" % (name, spin)
+            out[st + "/C_ao_lo"] = Cin
+            etr = et.get_emb_eri_gso(cell, mydf, C_ao_lo=Cin, basis=basis, max_memory=1)
+            eno = et.get_emb_eri_gso(cell, mydf, C_ao_lo=Cin, basis=basis, t_reversal_symm=False, max_memory=1)
+            assert np.abs(etr - eno).max() < 1e-10 * max(1.0, np.abs(etr).max())
+            out[st + "/eri_tr"], out[st + "/eri_notr"] = etr, eno
+            out[st + "/eri_s1"] = et.get_emb_eri_gso(cell, mydf, C_ao_lo=Cin, basis=basis, symmetry=1, max_memory=1)
+            out[st + "/eri_unit"] = et.get_emb_eri_gso(cell, mydf, C_ao_lo=Cin, basis=basis, unit_eri=True, max_memory=1)
+    np.savez_compressed(os.path.join(GOLD, "G12_gso.npz"), **out)
+    print("G12 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12"]
     for g in which:
         globals()["gen_" + g]()
 

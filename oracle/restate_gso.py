@@ -1,0 +1,105 @@
+"""
+oracle/restate_gso.py -- CPU restatement (numpy) of the generalised-spin-orbital (GSO, "spinless") twins of the path,
+SURVEY.md section 8(f) rank 4:
+
+  spinless._get_emb_basis_svd     routine/spinless.py:58-163     Schmidt bath of the generalised density matrix
+  eri_transform.get_emb_eri_gso   basis_transform/eri_transform.py:1104-1250
+  _Lij_s4_to_eri_gso              basis_transform/eri_transform.py:1252-1310  (aaaa + bbbb - aabb - bbaa)
+
+TEST INFRASTRUCTURE ONLY.  Pinned against tests/golden/G12_gso.npz (oracle/gen_golden.py gen_G12: the reference's
+own functions under oracle/shim.py; the ERI driver over the restated PySCF primitives of oracle/shim.py).
+"""
+import numpy as np
+import scipy.linalg as la
+
+from oracle.restate import (KPT_DIFF_TOL, add_spin_dim, eri_restore, get_basis_k, get_phase_R2k, get_weights_t_reversal,
+                            kpt_member, max_abs, multiply_basis, pack_tril, transform_ao_to_emb, vec_lowdin)
+
+
+def get_emb_basis_gso(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9, nbath=None):
+    """routine/spinless.py:58-163 (orth = True)."""
+    rdm1 = np.asarray(rdm1)
+    ncells, nso, _ = rdm1.shape
+    assert nso == 2 * nlo
+    val2 = list(val_idx) + [i + nlo for i in val_idx]
+    imp2 = list(imp_idx) + [i + nlo for i in imp_idx]
+    bath_cols = val2 if valence_bath else imp2
+    env, virt, alpha = [], [], []
+    for R in range(ncells):
+        for s in range(2):
+            for i in range(nlo):
+                idx = R * nso + s * nlo + i
+                if idx not in bath_cols:
+                    env.append(idx)
+                    virt.append(idx in imp2)
+                    alpha.append(s == 0)
+    nimp = len(imp2)
+    A = rdm1.reshape(ncells * nso, nso)[env][:, bath_cols]
+    u, sigma, vt = la.svd(A, full_matrices=False)
+    if nbath is None:
+        nbath = int((sigma >= tol_bath).sum())
+    assert nbath % 2 == 0
+    B = u[:, :nbath].copy()
+    B[np.asarray(virt)] = 0.0
+    B = vec_lowdin(B)
+    w = np.einsum("ai,ai->i", B[np.asarray(alpha)], B[np.asarray(alpha)])
+    order = np.argsort(w, kind="mergesort")[::-1]
+    basis = np.zeros((ncells * nso, nimp + nbath))
+    basis[imp2, :nimp] = np.eye(nimp)
+    basis[env, nimp:] = B[:, order]
+    return basis.reshape(ncells, nso, nimp + nbath), sigma, w
+
+
+def Lij_s4_to_eri_gso(Lij_s4, eri, weight=1, t_reversal_symm=False):
+    """eri_transform.py:1252-1283."""
+    if t_reversal_symm:
+        parts = [Lij_s4.real] if weight == 1 else [Lij_s4.real, Lij_s4.imag]
+        for P in parts:
+            a, b = P
+            eri[0] += weight * (a.T @ a + b.T @ b - a.T @ b - b.T @ a)
+    else:
+        a, b = Lij_s4
+        ab = -(a.conj().T @ b)
+        eri[0] += a.conj().T @ a + b.conj().T @ b + ab + ab.conj().T
+
+
+def get_emb_eri_gso(kmesh, kpts_scaled, get_block, naux, nao, C_ao_lo, basis, symmetry=4, unit_eri=False,
+                    t_reversal_symm=True, kconserv_tol=KPT_DIFF_TOL):
+    """eri_transform.py:1104-1250, in-core branch."""
+    kscaled = np.asarray(kpts_scaled, dtype=float)
+    nk = len(kscaled)
+    C_ao_lo = add_spin_dim(np.asarray(C_ao_lo), 2)
+    if unit_eri:
+        C_ao_emb = C_ao_lo / (nk ** 0.75)
+    else:
+        nlo = basis.shape[1] // 2
+        bk = get_basis_k(basis[None], get_phase_R2k(kmesh, kscaled))[0]
+        C_ao_emb = multiply_basis(C_ao_lo, np.asarray((bk[:, :nlo], bk[:, nlo:]))) / (nk ** 0.75)
+    spin, _, _, nemb = C_ao_emb.shape
+    npair = nemb * (nemb + 1) // 2
+    weights = get_weights_t_reversal(kscaled) if t_reversal_symm else np.ones(nk, dtype=int)
+    eri = np.zeros((1, npair, npair), dtype=float if t_reversal_symm else np.complex128)
+    for kL in range(nk):
+        if weights[kL] <= 0:
+            continue
+        Lij_s4 = np.zeros((spin, naux, npair), dtype=np.complex128)
+        visited = np.zeros(nk, dtype=bool)
+        for i in range(nk):
+            if visited[i]:
+                continue
+            visited[i] = True
+            for j in range(nk):
+                kc = -kscaled[i] + kscaled[j] + kscaled[kL]
+                if max_abs(np.round(kc) - kc) > kconserv_tol:
+                    continue
+                if t_reversal_symm:
+                    jm = kpt_member(-kscaled[j], kscaled)[0]
+                Lpq = np.asarray(get_block(i, j), dtype=np.complex128).reshape(naux, nao * nao)
+                Lij = transform_ao_to_emb(Lpq, C_ao_emb, i, j)
+                if t_reversal_symm and (not visited[jm]):
+                    Lij = Lij + Lij.transpose(0, 1, 3, 2)
+                Lij_s4 += pack_tril(Lij)
+                if t_reversal_symm:
+                    visited[jm] = True
+        Lij_s4_to_eri_gso(Lij_s4, eri, weight=weights[kL], t_reversal_symm=t_reversal_symm)
+    return eri_restore(eri.real, symmetry, nemb)

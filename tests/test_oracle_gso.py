@@ -1,0 +1,54 @@
+"""
+Pins oracle/restate_gso.py (GSO twins) against tests/golden/G12_gso.npz captured from the
+reference (spinless.get_emb_basis, get_emb_eri_gso) under oracle/shim.py.  CPU only.
+"""
+import numpy as np
+import pytest
+
+from oracle import restate as R
+from oracle import restate_gso as G
+
+BATH = [("c611", 2, [0, 1]), ("c441", 4, [0, 1, 2, 3]), ("c222", 5, [1, 2, 3])]
+ERI = ["m311", "m221", "m222"]
+
+
+def col_sign_dev(a, b):
+    a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    return max(min(np.abs(a[:, j] - b[:, j]).max(), np.abs(a[:, j] + b[:, j]).max()) for j in range(a.shape[1]))
+
+
+@pytest.mark.parametrize("name,n,val", BATH)
+def test_G12_gso_bath(golden, name, n, val):
+    g7, g = golden("G7_bcs.npz"), golden("G12_gso.npz")
+    GRho = g7[name + "/GRho"]
+    imp = list(val) + [i for i in range(n) if i > max(val)]
+    for key, vb in (("basis", True), ("basis_full", False)):
+        b, sigma, w = G.get_emb_basis_gso(GRho, n, val, imp, valence_bath=vb)
+        ref = g["bath/%s/%s" % (name, key)]
+        assert b.shape == ref.shape
+        nimp = 2 * len(imp)
+        assert np.array_equal(b[..., :nimp], ref[..., :nimp])
+        assert col_sign_dev(b[..., nimp:], ref[..., nimp:]) < 1e-9
+
+
+def eri_inputs(g, name):
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    W0, basis = g[name + "/W0"], g[name + "/basis"]
+    ks = R.make_kpts_scaled(mesh)
+    blocks = R.df_blocks_from_W0(W0, mesh, ks)
+    return mesh, ks, blocks, W0.shape[0], W0.shape[2], basis
+
+
+@pytest.mark.parametrize("name", ERI)
+def test_G12_gso_eri(golden, name):
+    g = golden("G12_gso.npz")
+    mesh, ks, blocks, naux, nao, basis = eri_inputs(g, name)
+    get = lambda i, j: blocks[(i, j)]
+    for spin in (1, 2):
+        st = "%s/s%d" % (name, spin)
+        C = g[st + "/C_ao_lo"]
+        for tr, key in ((True, "eri_tr"), (False, "eri_notr")):
+            e = G.get_emb_eri_gso(mesh, ks, get, naux, nao, C, basis, t_reversal_symm=tr)
+            assert np.abs(e - g[st + "/" + key]).max() < 1e-10 * max(1.0, np.abs(e).max())
+        assert np.abs(G.get_emb_eri_gso(mesh, ks, get, naux, nao, C, basis, symmetry=1) - g[st + "/eri_s1"]).max() < 1e-10
+        assert np.abs(G.get_emb_eri_gso(mesh, ks, get, naux, nao, C, basis, unit_eri=True) - g[st + "/eri_unit"]).max() < 1e-10
