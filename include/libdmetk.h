@@ -105,6 +105,9 @@ int dmk_kpt_member(const int mesh[3], const double kpt[3], double tol);
 /* Visiting plan of get_emb_eri_fast_gdf's double loop
  * (basis_transform/eri_transform.py:338-382).  Records are int32 quintuples
  * (kL, i, j, jm, symmetrise).  Call with plan_host = NULL to get the count. */
+/* Time-reversal mask of a list of k-point pairs given as mesh indices (npairs, 2): basis_transform/eri_transform.py:1409-1427
+ * (get_mask_kptij_lst).  mask[p] = index of the first later pair (-ki, -kj), -2 for a pair already claimed, -1 otherwise. */
+int dmk_kptij_mask(const int mesh[3], int npairs, const int32_t *pairs, int32_t *mask);
 int dmk_eri_plan(const int mesh[3], int t_reversal_symm, int32_t *plan_host,
                  int64_t capacity_records, int64_t *nrecords_out);
 /* Static partition of irreducible kL over `nranks` (assign_workload).

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "dmk_kpts_scaled": (c_int, [_int3, c_vp]),
     "dmk_kpt_member": (c_int, [_int3, P(c_dbl), c_dbl]),
     "dmk_eri_plan": (c_int, [_int3, c_int, c_vp, c_i64, P(c_i64)]),
+    "dmk_kptij_mask": (c_int, [_int3, c_int, c_vp, c_vp]),
     "dmk_assign_workload": (c_int, [_int3, c_int, c_int, c_int, c_vp, P(c_int)]),
     "dmk_fold_R2k": (c_int, [c_vp, _int3, c_i64, c_int, c_vp, c_int, c_vp]),
     "dmk_fold_k2R": (c_int, [c_vp, _int3, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int]),

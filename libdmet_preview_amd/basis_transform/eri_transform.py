@@ -59,6 +59,157 @@ class GDFMemory(object):
         out_dev.set(self.get_block(i, j))
 
 
+def _pack_tril_last2(a):
+    n = a.shape[-1]
+    il = np.tril_indices(n)
+    return np.ascontiguousarray(a[..., il[0], il[1]])
+
+
+def _unpack_tril_hermi(p, n):
+    """lib.unpack_tril(..., filltriu=HERMITIAN): upper triangle = conjugate of the lower one."""
+    il = np.tril_indices(n)
+    out = np.zeros(p.shape[:-1] + (n, n), dtype=p.dtype)
+    out[..., il[1], il[0]] = p.conj()
+    out[..., il[0], il[1]] = p
+    return out
+
+
+class CderiProvider(object):
+    """DF blocks from a PySCF-style `cderi` container.
+
+    `feri` is any mapping with the HDF5 layout the reference reads and writes (eri_transform.py:159-227 sr_loop /
+    _load3c, :1312-1396 transform_gdf_to_lo): "j3c-kptij" (npairs, 2, 3) absolute k-point pairs (only i >= j stored),
+    "j3c/<pair>/<segment>" with shape (naux_seg, nao*nao), or (naux_seg, nao*(nao+1)/2) lower-triangular packed when
+    ki == kj (real at Gamma).  A pair stored as (kj, ki) is served conjugate-transposed.  An open h5py.File works as
+    is; on a box without h5py the same layout in a dict (or np.load of an .npz with "/"-joined keys) does."""
+
+    def __init__(self, feri, kpts, nao, cell=None, tol=KPT_DIFF_TOL):
+        self.feri, self.kpts, self.nao, self.cell = feri, np.asarray(kpts), int(nao), cell
+        self._cderi = feri
+        kptij = np.asarray(self._get("j3c-kptij"))
+        self.kptij = kptij
+        find = lambda k: int(np.where(np.abs(self.kpts - np.asarray(k)[None]).max(axis=1) < tol)[0][0])
+        self.pair_of = {}
+        for p, (ki, kj) in enumerate(kptij):
+            self.pair_of[(find(ki), find(kj))] = p
+        self.naux = max(self._pair_rows(p) for p in range(len(kptij)))
+
+    def _get(self, key):
+        f = self.feri
+        try:
+            return f[key]
+        except (KeyError, ValueError):
+            node = f
+            for part in key.split("/"):
+                node = node[part]
+            return node
+
+    def _segments(self, p):
+        segs, s = [], 0
+        while True:
+            try:
+                segs.append(np.asarray(self._get("j3c/%d/%d" % (p, s))))
+            except (KeyError, IndexError, ValueError):
+                break
+            s += 1
+        if not segs:
+            raise KeyError("cderi container has no dataset j3c/%d/0" % p)
+        return segs
+
+    def _pair_rows(self, p):
+        return sum(x.shape[0] for x in self._segments(p))
+
+    def get_block(self, i, j):
+        nao = self.nao
+        if (i, j) in self.pair_of:
+            swap, p = False, self.pair_of[(i, j)]
+        elif (j, i) in self.pair_of:
+            swap, p = True, self.pair_of[(j, i)]
+        else:
+            raise KeyError("k-point pair (%d, %d) is not in the cderi container" % (i, j))
+        L = np.concatenate(self._segments(p), axis=0)
+        if L.shape[1] == nao * (nao + 1) // 2 and nao > 1:
+            L = _unpack_tril_hermi(L.astype(np.complex128), nao)
+        else:
+            L = L.astype(np.complex128).reshape(-1, nao, nao)
+        if swap:
+            L = L.conj().transpose(0, 2, 1)
+        if L.shape[0] < self.naux:                   # auxiliary-basis drop on some pairs: pad with zeros
+            L = np.concatenate([L, np.zeros((self.naux - L.shape[0], nao, nao), dtype=L.dtype)], axis=0)
+        return np.ascontiguousarray(L)
+
+    def load_block(self, ctx, i, j, out_dev):
+        out_dev.set(self.get_block(i, j))
+
+
+def get_mask_kptij_lst(cell, kptij_lst, tol=KPT_DIFF_TOL):
+    """k-point pair mask for time reversal symmetry: -1 self map, -2 already used, else the partner's index
+    (eri_transform.py:1409-1427).  Integer mesh arithmetic inside libdmetk (dmk_kptij_mask)."""
+    kptij_lst = np.asarray(kptij_lst)
+    npairs = len(kptij_lst)
+    flat = kptij_lst.reshape(npairs * 2, -1)
+    ks = np.asarray(cell.get_scaled_kpts(flat), dtype=float)
+    ks3 = np.zeros((len(ks), 3))
+    ks3[:, :ks.shape[1]] = ks
+    frac = np.round(ks3 - np.floor(ks3), 8)
+    frac[frac >= 1.0 - 1e-8] = 0.0                      # scaled coordinates modulo 1
+    kmesh = [len(np.unique(frac[:, d])) for d in range(3)]
+    idx = np.array([fourier.kpt_member_mesh(k, kmesh, tol) for k in ks3], dtype=np.int32)
+    if (idx < 0).any():
+        raise ValueError("k-point pairs are not on a Gamma-centred mesh")
+    pairs = np.ascontiguousarray(idx.reshape(npairs, 2))
+    mask = np.empty(npairs, dtype=np.int32)
+    rc = lib.dmk_kptij_mask(mesh3(kmesh), npairs, pairs.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("dmk_kptij_mask failed")
+    return mask.astype(int)
+
+
+def transform_gdf_to_lo(mydf, C_ao_lo, fname=None, t_reversal_symm=True, cell=None):
+    """
+    Transform the DF tensor to the LO basis, L_lo^{(ki,kj)} = C_i^H L^{(ki,kj)} C_j, and store it in the cderi layout
+    (eri_transform.py:1312-1407): pairs i >= j only, packed lower triangle when ki == kj (real at Gamma), the
+    time-reversed partner pair written as the conjugate.  The two products per pair run on the device
+    (dmk_zgemm_batched over the auxiliary index).  Returns a CderiProvider over a dict (also saved to `fname` as .npz).
+    """
+    ctx = get_ctx()
+    C_ao_lo = np.asarray(C_ao_lo)
+    nkpts, nao, nlo = C_ao_lo.shape
+    kpts = np.asarray(mydf.kpts)
+    assert nkpts == len(kpts)
+    cell = cell if cell is not None else getattr(mydf, "cell", None)
+    naux = int(mydf.naux)
+    kptij_lst = np.asarray([(kpts[i], kpts[j]) for i in range(nkpts) for j in range(i + 1)])
+    pair_ij = [(i, j) for i in range(nkpts) for j in range(i + 1)]
+    mask = get_mask_kptij_lst(cell, kptij_lst) if t_reversal_symm else -np.ones(len(kptij_lst), dtype=int)
+    is_gamma = lambda k: np.abs(np.asarray(k)).max() < KPT_DIFF_TOL
+    out = {"j3c-kptij": kptij_lst}
+    d_C = ctx.to_device(C_ao_lo, np.complex128)
+    d_L = ctx.empty((naux, nao, nao), np.complex128)
+    for k, (i, j) in enumerate(pair_ij):
+        if mask[k] == -2:
+            continue
+        mydf.load_block(ctx, i, j, d_L)
+        d_Ci = d_C.offset(i * nao * nlo, (nao, nlo))
+        d_Cj = d_C.offset(j * nao * nlo, (nao, nlo))
+        d_T = bgemm_dev(ctx, "N", "N", nao, nlo, nao, naux, d_L, nao * nao, d_Cj, 0)           # L C_j
+        Lij = bgemm_dev(ctx, "C", "N", nlo, nlo, nao, naux, d_Ci, 0, d_T, nao * nlo).get()     # C_i^H (L C_j)
+        if is_gamma(kptij_lst[k][0]) and is_gamma(kptij_lst[k][1]):
+            if max_abs(Lij.imag) >= 1e-6:
+                log.warn("transform_gdf_to_lo: Gamma-point block has an imaginary part %s", max_abs(Lij.imag))
+            data = _pack_tril_last2(Lij.real)
+        elif i == j:
+            data = _pack_tril_last2(Lij)
+        else:
+            data = Lij.reshape(naux, nlo * nlo)
+        out["j3c/%d/0" % k] = data
+        if mask[k] != -1:
+            out["j3c/%d/0" % mask[k]] = data.conj()
+    if fname is not None:
+        np.savez(fname if str(fname).endswith(".npz") else str(fname) + ".npz", **out)
+    return CderiProvider(out, kpts, nlo, cell=cell)
+
+
 class GDFPhilox(object):
     """Procedural DF tensor generated on the device (Philox4x32-10 keyed by (seed, ki, kj))."""
     def __init__(self, kpts, naux, nao, seed=20241223, cell=None):

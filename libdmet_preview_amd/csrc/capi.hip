@@ -310,6 +310,29 @@ int dmk_kpt_member(const int mesh[3], const double kpt[3], double tol) {
     return -1;
 }
 
+// basis_transform/eri_transform.py:1409-1427 (get_mask_kptij_lst) on mesh indices: pair p' = (-ki, -kj) of pair p.
+// mask[p] = index of the time-reversed partner (first later pair), -2 for a pair already claimed, -1 otherwise.
+int dmk_kptij_mask(const int mesh[3], int npairs, const int32_t *pairs, int32_t *mask) {
+    Mesh m(mesh);
+    if (!m.ok() || npairs < 0 || (npairs > 0 && (!pairs || !mask))) return DMK_ERR_INVALID;
+    for (int p = 0; p < npairs; ++p) {
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= m.nk || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= m.nk) return DMK_ERR_INVALID;
+        mask[p] = -1;
+    }
+    for (int i = 0; i < npairs; ++i) {
+        if (mask[i] != -1) continue;
+        const int na = m.minus(pairs[2 * i]), nb = m.minus(pairs[2 * i + 1]);
+        for (int j = i + 1; j < npairs; ++j) {
+            if (pairs[2 * j] == na && pairs[2 * j + 1] == nb) {
+                mask[i] = j;
+                mask[j] = -2;
+                break;
+            }
+        }
+    }
+    return DMK_OK;
+}
+
 int dmk_eri_plan(const int mesh[3], int tr, int32_t *plan, int64_t capacity, int64_t *nrec) {
     Mesh m(mesh);
     if (!m.ok() || !nrec) return DMK_ERR_INVALID;

@@ -828,11 +828,79 @@ def gen_G12():
     print("G12 done")
 
 
+class _FakeH5(dict):
+    """dict-backed stand-in for h5py.File: records what the reference writes ('a/b/c' keys)."""
+    registry = {}
+
+    def __new__(cls, fname, mode="r"):
+        if mode == "r" and fname in cls.registry:
+            return cls.registry[fname]
+        obj = dict.__new__(cls)
+        cls.registry[fname] = obj
+        return obj
+
+    def __init__(self, fname, mode="r"):
+        pass
+
+    def __setitem__(self, key, val):
+        dict.__setitem__(self, key, np.array(val, copy=True))
+
+    def close(self):
+        pass
+
+
+def gen_G13():
+    """On-disk DF layout (section 8f rank 3): what the reference's transform_gdf_to_lo writes, and get_mask_kptij_lst."""
+    et = shim.patch_eri_transform()
+    from libdmet.system import fourier as rf
+
+    class _H5Mod(object):
+        File = _FakeH5
+    et.h5py = _H5Mod
+    out = {}
+    for name, mesh, nao, nlo, naux in [("m311", (3, 1, 1), 4, 3, 3), ("m221", (2, 2, 1), 3, 3, 2), ("m231", (2, 3, 1), 3, 2, 2)]:
+        nk = int(np.prod(mesh))
+        ks = rf.make_kpts_scaled(mesh)
+        cell = shim.FakeCell(nao)
+        kpts = cell.get_abs_kpts(ks)
+        W0 = synth.make_W0(mesh, naux, nao, seed=3000 + nk + nao)
+        blocks = synth.df_blocks_from_W0(W0, mesh)
+
+        class _GDF(shim.FakeGDF):
+            def __init__(self, cell_, kpts_, b=blocks):
+                shim.FakeGDF.__init__(self, cell_, kpts_, lambda i, j: b[i, j], naux=naux, blockdim=naux)
+                self.kpts_band, self._j_only = None, False
+        mydf = _GDF(cell, kpts)
+        src = "src_%s.h5" % name
+        _FakeH5(src, "w")["j3c-kptij"] = np.asarray([(ki, kpts[j]) for i, ki in enumerate(kpts) for j in range(i + 1)])
+        mydf._cderi = src
+        C = synth.make_C_ao_lo(mesh, nao, nlo, spin=1, seed=70)[0]
+        out[name + "/mesh"], out[name + "/W0"], out[name + "/C_ao_lo"] = np.array(mesh), W0, C
+        for tr in (True, False):
+            dst = "dst_%s_%d.h5" % (name, tr)
+            et.transform_gdf_to_lo(mydf, C, fname=dst, t_reversal_symm=tr)
+            f = _FakeH5.registry[dst]
+            tag = "%s/%s" % (name, "tr" if tr else "notr")
+            out[tag + "/keys"] = np.array(sorted(f.keys()))
+            for k, v in f.items():
+                out["%s/data/%s" % (tag, k)] = v
+        kptij = np.asarray([(ki, kpts[j]) for i, ki in enumerate(kpts) for j in range(i + 1)])
+        out[name + "/mask"] = et.get_mask_kptij_lst(cell, kptij)
+    for mesh in [(4, 1, 1), (4, 4, 1), (2, 2, 2), (3, 3, 1)]:
+        ks = rf.make_kpts_scaled(mesh)
+        cell = shim.FakeCell(2)
+        kpts = cell.get_abs_kpts(ks)
+        kptij = np.asarray([(ki, kpts[j]) for i, ki in enumerate(kpts) for j in range(i + 1)])
+        out["mask/%s" % "x".join(map(str, mesh))] = et.get_mask_kptij_lst(cell, kptij)
+    np.savez_compressed(os.path.join(GOLD, "G13_cderi.npz"), **out)
+    print("G13 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13"]
     for g in which:
         globals()["gen_" + g]()
 

@@ -247,6 +247,10 @@ def quiet():
 
 class FakeCell(object):
     """Duck-typed pyscf Cell: identity lattice vectors, k = 2 pi * scaled."""
+    def copy(self):
+        import copy as _copy
+        return _copy.copy(self)
+
     def __init__(self, nao, dimension=3):
         self._nao = nao
         self.dimension = dimension
@@ -283,6 +287,33 @@ class FakeGDF(object):
         return int(idx[0])
 
 
+def kpts_is_zero(kpt):
+    """kpts_helper.is_zero / gamma_point: the sum of |kpt| over all components below KPT_DIFF_TOL."""
+    return np.abs(np.asarray(kpt)).sum() < 1e-6
+
+
+def kpts_member(kpt, kpts):
+    """kpts_helper.member: indices of the rows of kpts equal to kpt."""
+    kpts = np.reshape(kpts, (len(kpts), -1))
+    return np.where(np.abs(kpts - np.ravel(kpt)[None]).max(axis=1) < 1e-6)[0]
+
+
+def kpts_unique(kpts):
+    """kpts_helper.unique: (unique rows, first indices, inverse map) in order of first appearance."""
+    kpts = np.asarray(kpts)
+    uniq, idx, inv = [], [], np.zeros(len(kpts), dtype=int)
+    for i, k in enumerate(kpts):
+        for u, ku in enumerate(uniq):
+            if np.abs(k - ku).max() < 1e-6:
+                inv[i] = u
+                break
+        else:
+            inv[i] = len(uniq)
+            uniq.append(k)
+            idx.append(i)
+    return np.asarray(uniq), np.asarray(idx), inv
+
+
 def patch_eri_transform():
     """Bind restated primitives into libdmet.basis_transform.eri_transform."""
     install()
@@ -313,4 +344,9 @@ def patch_eri_transform():
             yield blk[b0:b0 + blksize].reshape(-1, nao * nao)
     et.sr_loop = sr_loop
     et.get_naoaux = lambda gdf: gdf.naux
+    # pyscf.pbc.lib.kpts_helper primitives (restated): is_zero / gamma_point / member / unique
+    et.is_zero = kpts_is_zero
+    et.gamma_point = kpts_is_zero
+    et.member = kpts_member
+    et.unique = kpts_unique
     return et
