@@ -88,6 +88,8 @@ int dmk_destroy(dmk_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &p : ctx->phases) (void)hipFree(p.dev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    for (int w = 0; w < 2; ++w)
+        if (ctx->eri_ws[w]) (void)hipFree(ctx->eri_ws[w]);
     (void)hipEventDestroy(ctx->t0);
     (void)hipEventDestroy(ctx->t1);
     delete ctx;
@@ -585,6 +587,7 @@ struct dmk_eri {
     int64_t npair;
     const double2 *C;     // spin x nk x nao x nemb
     double *eri;
+    size_t ws_bytes[2] = {0, 0};   // capacities of planes / Ut (they may come from the context's cache)
     double *planes = nullptr;   // spin x (2 naux) x npair
     double2 *Ut = nullptr;      // lchunk x nao x nemb
     int lchunk;
@@ -626,9 +629,29 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     }
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
     const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1);
-    hipError_t e1 = hipMalloc(reinterpret_cast<void **>(&h->planes), plane_bytes);
-    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&h->Ut), ut_bytes);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
+    // reuse the workspace parked in the context by the previous pipeline when it is large enough
+    const size_t want[2] = {plane_bytes, ut_bytes};
+    void *got[2] = {nullptr, nullptr};
+    for (int w = 0; w < 2; ++w) {
+        if (ctx->eri_ws[w] && ctx->eri_ws_bytes[w] >= want[w]) {
+            got[w] = ctx->eri_ws[w];
+            h->ws_bytes[w] = ctx->eri_ws_bytes[w];
+            ctx->eri_ws[w] = nullptr;
+            ctx->eri_ws_bytes[w] = 0;
+        } else {
+            if (ctx->eri_ws[w]) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(ctx->eri_ws[w]);
+                ctx->eri_ws[w] = nullptr;
+                ctx->eri_ws_bytes[w] = 0;
+            }
+            if (hipMalloc(&got[w], want[w]) != hipSuccess) got[w] = nullptr;
+            h->ws_bytes[w] = want[w];
+        }
+    }
+    h->planes = reinterpret_cast<double *>(got[0]);
+    h->Ut = reinterpret_cast<double2 *>(got[1]);
+    if (!h->planes || !h->Ut) {
         if (h->planes) (void)hipFree(h->planes);
         if (h->Ut) (void)hipFree(h->Ut);
         delete h;
@@ -833,9 +856,18 @@ int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
 
 int dmk_eri_finish(dmk_eri *h) {
     if (!h) return DMK_OK;
-    (void)hipStreamSynchronize(h->ctx->stream);
-    if (h->planes) (void)hipFree(h->planes);
-    if (h->Ut) (void)hipFree(h->Ut);
+    dmk_ctx *ctx = h->ctx;
+    (void)hipStreamSynchronize(ctx->stream);
+    void *mine[2] = {h->planes, h->Ut};
+    for (int w = 0; w < 2; ++w) {
+        if (!mine[w]) continue;
+        if (!ctx->eri_ws[w]) {                      // park it for the next pipeline
+            ctx->eri_ws[w] = mine[w];
+            ctx->eri_ws_bytes[w] = h->ws_bytes[w];
+        } else {
+            (void)hipFree(mine[w]);
+        }
+    }
     delete h;
     return DMK_OK;
 }

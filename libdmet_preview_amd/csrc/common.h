@@ -29,6 +29,10 @@ struct dmk_ctx {
     // cached twiddle matrices for the folds (device), keyed by mesh + direction
     struct Phase { int mesh[3]; int dir; int nsub; std::vector<int32_t> subset; void *dev; };
     std::vector<Phase> phases;
+    // workspace of the last ERI pipeline (plane set + Ut slots, several GB): kept across dmk_eri_finish /
+    // dmk_eri_begin so that a self-consistency loop does not pay hipMalloc of it (~0.25 s) every iteration
+    void *eri_ws[2] = {nullptr, nullptr};
+    size_t eri_ws_bytes[2] = {0, 0};
 };
 
 int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);
