@@ -256,8 +256,9 @@ def main():
             fit.pop("vcor")
             passes_bytes = 2.0 * fit["dV_dparam_bytes"]
             fit["note"] = ("FitVcorEmb, VcorLocal on the valence orbitals, CG with analytic gradient; one objective = one pass over "
-                           "dV_dparam + one eigh(nemb) per spin + nemb^3 algebra; objective+gradient = two passes; the eigh "
-                           "latency of two %dx%d matrices dominates" % (nemb, nemb))
+                           "dV_dparam + one eigh(nemb) per spin (multi-CU block Jacobi, warm started from the previous evaluation) "
+                           "+ nemb^3 algebra; objective+gradient = two passes; the eigensolve of two %dx%d matrices "
+                           "is still most of it" % (nemb, nemb))
             fit["dV_stream_GBps_if_only_cost"] = round(passes_bytes / (fit["ms_per_objective_plus_gradient"] * 1e-3) / 1e9, 1)
             res["vcor_fit"] = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in fit.items()}
             res["iteration_plus_fit_wall_s"] = round(elapsed / a.steps + fit["seconds_total"], 4)

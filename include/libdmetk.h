@@ -154,6 +154,13 @@ int dmk_eigh_batched(dmk_ctx *ctx, int n, int batch, const void *A, const double
 int dmk_eigh_batched_real(dmk_ctx *ctx, int n, int batch, const double *A, double *w,
                           double *Vt);
 /* rho[b] = sum_m occ[b,m] v_m v_m^H from Vt (batch x n x n), occ (batch x n). */
+/* Low-latency symmetric eigensolver for a FEW small real matrices (batch * n/32 <= 256, n <= 576): parallel block
+ * one-sided Jacobi over several CUs (csrc/jacobi_eigh.hip).  A: batch x n x n f64, symmetric, FULL storage when V0 is
+ * given (else only the lower triangle is read).  V0 (optional): batch x n x n, rows = approximate eigenvectors
+ * (orthonormal) of a nearby matrix -- the warm start of the vcor-fit line search (routine/slater.py:1075, 1098).
+ * w ascending, Vt rows = eigenvectors.  sweeps_out (optional): sweeps taken by the slowest matrix. */
+int dmk_eigh_jacobi_real(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt,
+                         int *sweeps_out);
 int dmk_occ_density(dmk_ctx *ctx, int n, int batch, const void *Vt, const double *occ,
                     void *rho /* c128 batch x n x n */);
 int dmk_transpose_c128(dmk_ctx *ctx, int rows, int cols, int batch, const void *in, void *out);

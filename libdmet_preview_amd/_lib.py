@@ -54,6 +54,7 @@ PROTOTYPES = {
     "dmk_fold_k2R_complex": (c_int, [c_vp, _int3, c_i64, c_int, c_vp, c_vp]),
     "dmk_eigh_batched": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "dmk_eigh_batched_real": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dmk_eigh_jacobi_real": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, P(c_int)]),
     "dmk_occ_density": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmk_transpose_c128": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "dmk_bath_svd": (c_int, [c_vp, _int3, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),

@@ -244,6 +244,15 @@ int grid_for(long long total, int cap = 8192) { return (int)std::min<long long>(
 
 }  // namespace
 
+// C[b] = A[b] B[b] (row-major, contiguous) for the other translation units
+int launch_dgemm_small_nn(dmk_ctx *ctx, int M, int N, int K, int batch, const double *A, const double *B, double *C) {
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    hipLaunchKernelGGL((dgemm_small_kernel<0, 0>), grid, dim3(NT), 0, ctx->stream, M, N, K, 1.0, A, (long long)K, (long long)M * K, B,
+                       (long long)N, (long long)K * N, 0.0, C, (long long)N, (long long)M * N);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
 extern "C" {
 
 int dmk_dgemv2(dmk_ctx *ctx, int64_t M, int64_t N, const double *A, int64_t lda, const double *xrow, const double *xcol,

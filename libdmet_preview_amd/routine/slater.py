@@ -10,6 +10,7 @@ orthogonalised / scattered by dmk_bath_assemble (slater.py:200-213, lo/lowdin.py
 get_emb_Ham (slater.py:320-704) completes the exit of the path: H2 from the DF transform (or the cell-local
 4-index transform for models), H1 = basis^H (hcore + vhf) basis - JK_emb with JK_emb from dmk_jk_s4.
 """
+import ctypes as C
 from math import sqrt
 try:
     from collections.abc import Iterable
@@ -406,7 +407,7 @@ class EmbFitDevice(object):
     (ftsystem.py:151-213) are the same expression with different K."""
 
     def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, fock_k, ovlp_k, mu0=None,
-                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False):
+                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi"):
         from libdmet_preview_amd.routine import mfd
         self._mfd = mfd
         self.ctx, self.vcor = ctx, vcor
@@ -460,6 +461,11 @@ class EmbFitDevice(object):
         self.d_dw, self.d_grad = e(spin, self.npair), e(self.nparam)
         self._key, self._state = None, None
         self.nfev = self.ngev = 0
+        # eigensolver: "jacobi" (multi-CU, warm started: latency) or "ql" (batched Householder + QL); DMK_FIT_EIGH overrides
+        import os
+        choice = os.environ.get("DMK_FIT_EIGH", eigh)
+        self.use_jacobi = (choice == "jacobi") and nb <= 576 and spin * ((nb + 31) // 32) <= 256
+        self._have_prev, self.sweeps = False, 0
 
     # -- forward pass ------------------------------------------------------------------------------
     def _gemm(self, opA, opB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0):
@@ -482,7 +488,15 @@ class EmbFitDevice(object):
             self._gemm(0, 0, nb, nb, nb, self.d_H, nb, self.d_X, nb, self.d_T, nb)          # H X
             self._gemm(0, 0, nb, nb, nb, self.d_X, nb, self.d_T, nb, self.d_T2, nb)         # X H X  (X symmetric)
             d_A = self.d_T2
-        ctx.check(lib.dmk_eigh_batched_real(ctx.h, nb, spin, d_A.ptr, self.d_w.ptr, self.d_Vp.ptr))
+        if self.use_jacobi:
+            # low-latency multi-CU Jacobi, warm-started from the eigenvectors of the previous evaluation
+            sw = C.c_int()
+            ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, nb, spin, d_A.ptr, self.d_Vp.ptr if self._have_prev else None,
+                                               self.d_w.ptr, self.d_Vp.ptr, C.byref(sw)))
+            self._have_prev = True
+            self.sweeps += sw.value
+        else:
+            ctx.check(lib.dmk_eigh_batched_real(ctx.h, nb, spin, d_A.ptr, self.d_w.ptr, self.d_Vp.ptr))
         if self.d_X is not None:
             self._gemm(0, 0, nb, nb, nb, self.d_Vp, nb, self.d_X, nb, self.d_Vt, nb)        # rows: (X v_m)^T
             d_Vt = self.d_Vt
@@ -629,7 +643,8 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
     ctx = get_ctx()
     fit = EmbFitDevice(ctx, np.asarray(rho), lattice, basis, vcor, beta, nelec, imp_idx, det_idx, fock_k,
                        lattice.get_ovlp(kspace=True), mu0=kwargs.get("mu0", None), fix_mu=kwargs.get("fix_mu", False),
-                       tol_deg=kwargs.get("tol_deg", 1e-3), remove_diag_grad=kwargs.get("remove_diag_grad", False))
+                       tol_deg=kwargs.get("tol_deg", 1e-3), remove_diag_grad=kwargs.get("remove_diag_grad", False),
+                       eigh=kwargs.get("eigh", "jacobi"))
     errfunc, gradfunc = fit.errfunc, fit.gradfunc
     err_begin = errfunc(vcor.param)
     if beta == np.inf:
