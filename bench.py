@@ -269,9 +269,10 @@ def main():
             res["cpu_baseline"] = {"value": round(v, 4), "unit": "TFLOP/s", "cores": threads, "kind": "port",
                                    "sample": desc, "half_transform_tflops": round(th, 4),
                                    "contraction_tflops": round(tc, 4)}
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if distributed:
         import torch.distributed as td
+        dist.barrier()           # rank 0 may still have been measuring the fit / CPU baseline: tear down together
         td.destroy_process_group()
 
 
