@@ -112,18 +112,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void zgemm_kernel(const ZArgs g) {
             acc_im[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
             if (M3) acc_t3[M3 ? i : 0][M3 ? j : 0] = d4_t{0.0, 0.0, 0.0, 0.0};
         }
-    // lower-triangle mode: 16x16 blocks that lie entirely above the diagonal are never needed
+    // 16x16 blocks that are never needed cost no MFMA issue slots (wave-uniform mask): blocks entirely beyond the
+    // matrix edge (a 136-wide problem on 64-wide tiles leaves an 8-row strip in the last tile row: 3 of its 4
+    // block rows are empty) and, in lower-triangle mode, blocks entirely above the diagonal
     unsigned skip_mask = 0;
-    if (g.lower_only && !g.flatten_m) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row_max = tile_m * BM + wm * TM * 16 + i * 16 + 15;
-                const int col_min = n0 + wn * TN * 16 + j * 16;
-                if (row_max < col_min) skip_mask |= 1u << (i * TN + j);
+        for (int j = 0; j < TN; ++j) {
+            const int col_min = n0 + wn * TN * 16 + j * 16;
+            bool skip = col_min >= g.N;
+            if (g.flatten_m) {
+                const long long gb = (long long)tile_m * (BM / 16) + wm * TM + i;
+                skip |= gb >= (long long)g.batch * g.nblk;
+            } else {
+                const int row_min = tile_m * BM + wm * TM * 16 + i * 16;
+                skip |= row_min >= g.M;
+                if (g.lower_only) skip |= (row_min + 15 < col_min);
             }
-    }
+            if (skip) skip_mask |= 1u << (i * TN + j);
+        }
 
     for (int s = 0; s < g.nseg; ++s) {
         const bool akm = g.a_kmajor[s] != 0, bkm = g.b_kmajor[s] != 0;
