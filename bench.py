@@ -161,6 +161,28 @@ def main():
     fam = ctx.profile_read(reset=True)
     ctx.profile(False)
     elapsed = t1 - t0
+    if sysm.naux == 0:
+        # model lattices (BASELINE configs 1-2: Hubbard): no DF tensor, the step is diag + occupations + density + fold + bath
+        if rank == 0:
+            eigh_ms, eigh_n = fam.get("eigh", (0.0, 0))
+            n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
+            alg_bytes = 2.0 * 16 * spin * nk * n * n + 8.0 * spin * nk * n            # SURVEY.md section 8d, diag row
+            res = {"metric": "DMET embedding-construction iteration (diag+bath) wall-clock", "value": round(elapsed / a.steps, 6),
+                   "unit": "s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+                   "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "%s: mesh %s nlo %d nemb %d spin %d (model lattice, no DF tensor)"
+                                          % (a.workload, "x".join(map(str, sysm.mesh)), n, out["nemb"], spin)},
+                   "stage_seconds_per_step": {k: round(v / a.steps, 6) for k, v in timers.items()},
+                   "roofline": {"bound": "hbm", "kernel": "eigh", "achieved": round(alg_bytes / max(eigh_ms / max(eigh_n, 1), 1e-9) / 1e6, 3),
+                                "peak": 8000.0, "unit": "GB/s", "frac": round(alg_bytes / max(eigh_ms / max(eigh_n, 1), 1e-9) / 1e6 / 8000.0, 6),
+                                "traffic": None, "note": "launch/latency bound at this size (SURVEY.md section 8d): %d matrices of %dx%d"
+                                                         % (spin * nk, n, n)}}
+            print(json.dumps(res), flush=True)
+        if distributed:
+            import torch.distributed as td
+            dist.barrier()
+            td.destroy_process_group()
+        return
     flops = (out["flops_half"] + out["flops_contract"]) * a.steps
     if distributed:
         agg = dist.all_reduce_sum_numpy(np.array([flops, 0.0]))
