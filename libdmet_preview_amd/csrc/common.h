@@ -159,6 +159,9 @@ int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, i
 
 // hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb);
+// step 2 for a general nemb: flattened hot kernel into P (nL x nemb x nemb c128) + deterministic fold/pack into the planes
+int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
+                      int nL, int nao, int nemb, int sym);
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb);
 int half2_hot_usable(int nao, int nemb);

@@ -107,15 +107,20 @@ __device__ __forceinline__ double cacc_im(const cacc &c, int r) {
 constexpr int H1_BM = 128, H1_BN = 64, H1_BK = 8, H1_D = 3;
 constexpr int H1_STAGE = H1_BK * (H1_BM + H1_BN);     // double2 elements per stage (24 KiB)
 
+// out[L][m][n] = sum_k A[L][k][m] * op(B[k][n]),  op = conj (step 1: B = C_i) or identity (step 2 of general nemb: B = C_j).
+// A is K-major: element (k, m) of batch L at L * (nao * mrows) + k * mrows + m  (step 1: Lpq, mrows = nao; step 2: Ut,
+// mrows = nemb).  The batch index is folded into M in 16-row blocks.
 struct H1Args {
-    const double2 *Lpq;    // [nL][nao][nao]   element (p, q) at p*nao + q
-    const double2 *Ci;     // [nao][nemb]
-    double2 *Ut;           // [nL][nao][nemb]
-    int nL, nao, nemb, nblk;   // nblk = ceil(nao / 16)
+    const double2 *Lpq;    // A
+    const double2 *Ci;     // B [nao][nemb]
+    double2 *Ut;           // out [nL][mrows][nemb]
+    int nL, nao, nemb, nblk;   // nao = K; nblk = ceil(mrows / 16)
+    int mrows;
     int tiles_m, tiles_n;
     unsigned nblocks;
 };
 
+template <bool CONJB>
 __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     __shared__ __attribute__((aligned(16))) double2 lds[H1_D * H1_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
     const int tile_m = (int)(lid / (unsigned)g.tiles_n), tile_n = (int)(lid % (unsigned)g.tiles_n);
     const int n0 = tile_n * H1_BN;
-    const long long nao = g.nao, nemb = g.nemb;
+    const long long nao = g.nao, nemb = g.nemb, mrows = g.mrows;
 
     // ---- per-lane LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB) ----
     const double2 *srcA[2], *srcB;
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         int L = gb / g.nblk;
         int q = (gb - L * g.nblk) * 16 + (m & 15);
         if (L >= g.nL) L = g.nL - 1;                    // clamped lanes only ever feed masked outputs
-        if (q >= g.nao) q = g.nao - 1;
-        srcA[h] = g.Lpq + (long long)L * nao * nao + q;
+        if (q >= g.mrows) q = g.mrows - 1;
+        srcA[h] = g.Lpq + (long long)L * nao * mrows + q;
     }
     {
         int col = n0 + lane;
@@ -150,8 +155,8 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         for (int r = 0; r < 2; ++r) {
             const int k = wave * 2 + r;
             const long long kg = (long long)t * H1_BK + k;
-            glds16(srcA[0] + kg * nao, lds_addr_of(st + k * H1_BM));
-            glds16(srcA[1] + kg * nao, lds_addr_of(st + k * H1_BM + 64));
+            glds16(srcA[0] + kg * mrows, lds_addr_of(st + k * H1_BM));
+            glds16(srcA[1] + kg * mrows, lds_addr_of(st + k * H1_BM + 64));
             glds16(srcB + kg * nemb, lds_addr_of(st + H1_BK * H1_BM + k * H1_BN));
         }
     };
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 double2 v = Bb[(kk * 4 + frag_k) * H1_BN + j * 16];
-                v.y = -v.y;                             // conj(C_i)
+                if (CONJB) v.y = -v.y;                  // conj(C_i)
                 b[j] = cfrag_of(v);
             }
 #pragma unroll
@@ -209,8 +214,8 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qb + frag_k + 4 * r;
-            if (q >= g.nao) continue;
-            double2 *row = g.Ut + ((long long)L * nao + q) * nemb;
+            if (q >= g.mrows) continue;
+            double2 *row = g.Ut + ((long long)L * mrows + q) * nemb;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 32 + j * 16 + frag_x;
@@ -446,21 +451,83 @@ bool hot_enabled() {
 }  // namespace
 
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
-int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb) {
-    if (!hot_enabled() || (nao % H1_BK) != 0 || nao < 2 * H1_BK || nemb < 32 || (long long)nL * nao < 4 * H1_BM) return 0;
-    if ((reinterpret_cast<uintptr_t>(Lpq) | reinterpret_cast<uintptr_t>(Ci) | reinterpret_cast<uintptr_t>(Ut)) & 15) return 0;
+static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out, int nL, int K, int mrows, int N, bool conjB,
+                           int fam) {
+    if (!hot_enabled() || (K % H1_BK) != 0 || K < 2 * H1_BK || N < 32 || (long long)nL * mrows < 4 * H1_BM) return 0;
+    if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) return 0;
     H1Args a;
-    a.Lpq = reinterpret_cast<const double2 *>(Lpq);
-    a.Ci = reinterpret_cast<const double2 *>(Ci);
-    a.Ut = reinterpret_cast<double2 *>(Ut);
-    a.nL = nL; a.nao = nao; a.nemb = nemb;
-    a.nblk = (nao + 15) / 16;
+    a.Lpq = reinterpret_cast<const double2 *>(A);
+    a.Ci = reinterpret_cast<const double2 *>(B);
+    a.Ut = reinterpret_cast<double2 *>(out);
+    a.nL = nL; a.nao = K; a.nemb = N; a.mrows = mrows;
+    a.nblk = (mrows + 15) / 16;
     const long long total_blk = (long long)nL * a.nblk;
     a.tiles_m = (int)((total_blk + H1_BM / 16 - 1) / (H1_BM / 16));
-    a.tiles_n = (nemb + H1_BN - 1) / H1_BN;
+    a.tiles_n = (N + H1_BN - 1) / H1_BN;
     a.nblocks = (unsigned)(a.tiles_m * a.tiles_n);
-    FamScope fs(ctx, DMK_FAM_ZGEMM_HALF1);
-    hipLaunchKernelGGL(half1_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    FamScope fs(ctx, fam);
+    if (conjB) hipLaunchKernelGGL(half1_kernel<true>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(half1_kernel<false>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    DMK_CHECK_LAUNCH(ctx);
+    return 1;
+}
+
+int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb) {
+    return launch_flat_hot(ctx, Lpq, Ci, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1);
+}
+
+// Step 2 for a general embedding dimension: P[L][a][b] = sum_q Ut[L][q][a] C_j[q][b] with the flattened kernel above
+// (Ut is K-major exactly like the AO block of step 1), then planes[L][pair(a,b)] += P[a][b] (+ P[b][a] when the
+// time-reversal partner is folded in, eri_transform.py:372-378) by fold_pack_kernel.  One writer per plane element:
+// deterministic.  Returns 0 if the shape is not covered.
+namespace {
+constexpr int FP_ROWS = 16;
+__global__ __launch_bounds__(256) void fold_pack_kernel(const double2 *__restrict__ P, double *__restrict__ planes, long long naux,
+                                                        long long npair, int nemb, int sym) {
+    __shared__ double2 strip[FP_ROWS][257];             // strip[al][b] = P[b][a0 + al]   (nemb <= 256 per pass)
+    const int L = blockIdx.y, a0 = blockIdx.x * FP_ROWS;
+    const double2 *PL = P + (long long)L * nemb * nemb;
+    double *re = planes + (long long)L * npair, *im = planes + (naux + L) * npair;
+    const int amax = min(a0 + FP_ROWS, nemb);
+    for (int b0 = 0; b0 < amax; b0 += 256) {            // only b <= a is needed
+        const int bw = min(256, amax - b0);
+        if (sym) {
+            for (int t = threadIdx.x; t < bw * FP_ROWS; t += 256) {
+                const int al = t % FP_ROWS, b = t / FP_ROWS;
+                const int a = a0 + al;
+                strip[al][b] = (a < nemb) ? PL[(long long)(b0 + b) * nemb + a] : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+        }
+        for (int al = 0; al < FP_ROWS; ++al) {
+            const int a = a0 + al;
+            if (a >= nemb) break;
+            for (int b = threadIdx.x; b < bw; b += 256) {
+                const int bg = b0 + b;
+                if (bg > a) break;
+                double2 v = PL[(long long)a * nemb + bg];
+                if (sym) {
+                    const double2 u = strip[al][b];
+                    v.x += u.x;
+                    v.y += u.y;
+                }
+                const long long pr = (long long)a * (a + 1) / 2 + bg;
+                re[pr] += v.x;
+                im[pr] += v.y;
+            }
+        }
+        if (sym) __syncthreads();
+    }
+}
+}  // namespace
+
+int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
+                      int nL, int nao, int nemb, int sym) {
+    const int rc = launch_flat_hot(ctx, Ut, Cj, P, nL, nao, nemb, nemb, false, DMK_FAM_ZGEMM_HALF2);
+    if (rc <= 0) return rc;
+    FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
+    hipLaunchKernelGGL(fold_pack_kernel, dim3((nemb + FP_ROWS - 1) / FP_ROWS, nL), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const double2 *>(P), planes, naux, npair, nemb, sym);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }

@@ -274,6 +274,34 @@ def test_eri_philox_vs_oracle_midsize(ctx):
     assert np.abs(got - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("nemb,spin", [(40, 2), (56, 1), (33, 2)])
+def test_eri_flat_step2_vs_oracle(ctx, nemb, spin):
+    """General-nemb step 2 (flattened hot kernel + fold pass) against the oracle, and against the tiled kernel."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd.system.lattice import _UnitCell
+    mesh, nao, naux, seed = (2, 2, 1), 24, 40, 4242
+    nk = 4
+    ks = R.make_kpts_scaled(mesh)
+    cell = _UnitCell(nao)
+    mydf = et.GDFPhilox(cell.get_abs_kpts(ks), naux, nao, seed=seed)
+    rng = np.random.default_rng(nemb)
+    C = synth.make_C_ao_lo(mesh, nao, nao, spin=spin, seed=4)
+    basis = rng.standard_normal((spin, nk, nao, nemb))
+    ref = R.get_emb_eri_fast_gdf(mesh, ks, lambda i, j: R.df_block_philox(seed, i, j, naux, nao), naux, nao,
+                                 C_ao_lo=C, basis=basis)
+    tiled = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)                  # default: tiled two-segment kernel
+    os.environ["DMK_ERI_FLAT2"] = "1"                                            # opt-in variant
+    try:
+        got = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)
+        again = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)
+    finally:
+        del os.environ["DMK_ERI_FLAT2"]
+    assert np.abs(got - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+    assert np.abs(tiled - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
+    assert np.abs(got - tiled).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(got, again)                        # one writer per plane element: bit-reproducible
+
+
 def test_eri_properties_large(ctx):
     """Size-independent properties at a size beyond the oracle's reach (nao 104, naux 64, nemb 136 = C4 tile
     shapes, mesh 2x2x1): (ab|cd) = (cd|ab) for same-spin blocks and shard additivity."""
