@@ -310,6 +310,12 @@ int dmk_gather2d_f64(dmk_ctx *ctx, int nrow, int ncol, const int32_t *row_idx, c
 int dmk_ewise_mul(dmk_ctx *ctx, int mode, int64_t nrow, int64_t ncol, const double *A, const double *B, double *out);
 /* diff = a - b (diff may be NULL), *sumsq_dev = sum (a - b)^2 in a fixed order: la.norm(drho), slater.py:1094. */
 int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, double *diff, double *sumsq_dev);
+/* Divided-difference matrix of the occupations for the fit gradient, K[b][p][q] = (f_p - f_q)/(e_p - e_q) with the
+ * degenerate limit -beta f_p (1 - f_q) (routine/ftsystem.py:170-181); beta <= 0: the T = 0 form 1/(e_occ - e_virt) on the
+ * occupied-virtual blocks split at nocc (routine/slater.py:1126-1134).  ew, f: batch x n (f unused at T = 0). */
+int dmk_fit_kmat(dmk_ctx *ctx, int n, int batch, const double *ew, const double *f, double beta, int nocc, double *K);
+/* y += alpha x */
+int dmk_axpy_f64(dmk_ctx *ctx, int64_t n, double alpha, const double *x, double *y);
 /* dV_dparam rows from the cell Gram matrix G[(i,p),(j,q)] = sum_c B[c,i,p] B[c,j,q] (row-major, ldg):
  * entry e (one (parameter, spin) pair) = sum over its nonzeros z in [nz_ptr[e], nz_ptr[e+1]) of
  * nz_val[z] * G[(nz_i[z], p), (nz_j[z], q)], written tril-packed at dV + out_off[e].

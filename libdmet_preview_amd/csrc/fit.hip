@@ -239,6 +239,34 @@ __global__ void dv_dparam_kernel(int nent, int nb, long long ldg, const double *
     }
 }
 
+// K[b][p][q] = (f_p - f_q) / (e_p - e_q), and -beta f_p (1 - f_q) where |e_p - e_q| < 1e-10 (routine/ftsystem.py:170-181);
+// beta <= 0 selects the T = 0 form of routine/slater.py:1126-1134: K = 1 / (e_occ - e_virt) on the (virt, occ) and
+// (occ, virt) blocks split at index nocc, zero elsewhere
+__global__ void fit_kmat_kernel(int n, int batch, const double *__restrict__ ew, const double *__restrict__ f, double beta, int nocc,
+                                double *__restrict__ K) {
+    const long long total = (long long)batch * n * n;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / ((long long)n * n)), p = (int)((t / n) % n), q = (int)(t % n);
+        const double ep = ew[(long long)b * n + p], eq = ew[(long long)b * n + q];
+        double v;
+        if (beta <= 0.0) {
+            if (p >= nocc && q < nocc) v = 1.0 / (eq - ep);
+            else if (p < nocc && q >= nocc) v = 1.0 / (ep - eq);
+            else v = 0.0;
+        } else {
+            const double fp = f[(long long)b * n + p], fq = f[(long long)b * n + q];
+            const double de = ep - eq;
+            v = (fabs(de) < 1e-10) ? -beta * fp * (1.0 - fq) : (fp - fq) / de;
+        }
+        K[t] = v;
+    }
+}
+
+__global__ void axpy_kernel(long long n, double alpha, const double *__restrict__ x, double *__restrict__ y) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        y[t] = fma(alpha, x[t], y[t]);
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int grid_for(long long total, int cap = 8192) { return (int)std::min<long long>((total + 255) / 256, cap); }
 
@@ -349,6 +377,26 @@ int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, dou
     if (n < 0 || !a || !b || !sumsq_dev) return dmk_fail(ctx, DMK_ERR_INVALID, "sub_sumsq: bad arguments");
     FamScope fs(ctx, DMK_FAM_FIT);
     hipLaunchKernelGGL(sub_sumsq_kernel, dim3(1), dim3(NT), 0, ctx->stream, (long long)n, a, b, diff, sumsq_dev);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_fit_kmat(dmk_ctx *ctx, int n, int batch, const double *ew, const double *f, double beta, int nocc, double *K) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n <= 0 || batch <= 0 || !ew || !K || (beta > 0.0 && !f) || (beta <= 0.0 && (nocc < 0 || nocc > n)))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "fit_kmat: bad arguments");
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(fit_kmat_kernel, dim3(grid_for((long long)batch * n * n)), dim3(256), 0, ctx->stream, n, batch, ew, f, beta, nocc, K);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_axpy_f64(dmk_ctx *ctx, int64_t n, double alpha, const double *x, double *y) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n < 0 || !x || !y) return dmk_fail(ctx, DMK_ERR_INVALID, "axpy: bad arguments");
+    if (n == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (long long)n, alpha, x, y);
     DMK_CHECK_LAUNCH(ctx);
     return DMK_OK;
 }

@@ -530,34 +530,24 @@ class EmbFitDevice(object):
         return self._forward(param)[3] / sqrt(self.spin)
 
     # -- gradient ----------------------------------------------------------------------------------
-    def _kmat(self, ew, occ, mu):
-        """Divided differences of the occupations, K[p,q] = (f_p - f_q) / (e_p - e_q)."""
-        spin, nb = self.spin, self.nb
-        K = np.zeros((spin, nb, nb))
+    def _kmat_dev(self, occ, mu):
+        """Divided differences of the occupations on the device (dmk_fit_kmat); returns f (1 - f) at finite T."""
+        ctx, spin, nb = self.ctx, self.spin, self.nb
         if self.beta == np.inf:
             nocc = int(np.round(np.sum(occ) / spin))                      # slater.py:1126
-            for s in range(spin):
-                e_mn = 1.0 / (-ew[s, nocc:].reshape((-1, 1)) + ew[s, :nocc])
-                K[s, nocc:, :nocc] = e_mn
-                K[s, :nocc, nocc:] = e_mn.T
-            return K, None
-        f = ftsystem.fermi_smearing_occ(mu, ew, self.beta)
-        h = 1.0 - f
-        for s in range(spin):
-            de = ew[s, :, None] - ew[s]
-            zero = np.abs(de) < ftsystem.ZERO_TOL
-            inv = np.zeros_like(de)
-            inv[~zero] = 1.0 / de[~zero]
-            K[s] = inv * (f[s, :, None] - f[s])
-            K[s][zero] = (f[s, :, None] * h[s])[zero] * (-self.beta)
-        return K, f * h
+            ctx.check(lib.dmk_fit_kmat(ctx.h, nb, spin, self.d_w.ptr, None, -1.0, nocc, self.d_K.ptr))
+            return None
+        f = np.ascontiguousarray(ftsystem.fermi_smearing_occ(mu, self._ew, self.beta), dtype=np.float64)
+        ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_occ.ptr, f.ctypes.data, f.nbytes))
+        ctx.check(lib.dmk_fit_kmat(ctx.h, nb, spin, self.d_w.ptr, self.d_occ.ptr, float(self.beta), 0, self.d_K.ptr))
+        return f * (1.0 - f)
 
     def gradfunc(self, param):
         self.ngev += 1
         ctx, spin, nb, nidx = self.ctx, self.spin, self.nb, self.nidx
         ew, occ, mu, val, d_Vt = self._forward(param)
-        K, ff = self._kmat(ew, occ, mu)
-        ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_K.ptr, K.ctypes.data, K.nbytes))
+        self._ew = ew
+        ff = self._kmat_dev(occ, mu)
         for s in range(spin):                                              # C = ev[fit_idx]^T : (orbital m, fitted index a)
             ctx.check(lib.dmk_gather2d_f64(ctx.h, nb, nidx, None, self.d_fit.ptr, d_Vt.offset(s * nb * nb, (nb, nb)).ptr, nb,
                                            self.d_C.offset(s * nb * nidx, (nb, nidx)).ptr))
@@ -566,25 +556,23 @@ class EmbFitDevice(object):
         ctx.check(lib.dmk_ewise_mul(ctx.h, 0, spin * nb, nb, self.d_T.ptr, self.d_K.ptr, self.d_T.ptr))
         self._gemm(0, 0, nb, nb, nb, self.d_T, nb, d_Vt, nb, self.d_T2, nb)                                # tmp ev^T
         self._gemm(1, 0, nb, nb, nb, d_Vt, nb, self.d_T2, nb, self.d_sc, nb)                               # ev tmp ev^T
-        dw_extra = None
         if ff is not None and not self.fix_mu:
-            # response of the chemical potential (ftsystem.py:189-204)
+            # response of the chemical potential (ftsystem.py:189-204): dw_dv += drho_dmu (dw_dmu / sum f(1-f)), per spin
             ffd = np.ascontiguousarray(ff)
             ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_occ.ptr, ffd.ctypes.data, ffd.nbytes))
             ctx.check(lib.dmk_ewise_mul(ctx.h, 1, spin * nb, nb, d_Vt.ptr, self.d_occ.ptr, self.d_T.ptr))
             self._gemm(1, 0, nb, nb, nb, d_Vt, nb, self.d_T, nb, self.d_T2, nb)                            # drho_dmu
-            drho_dmu = self.d_T2.get().reshape(spin, nb, nb)
-            drho = self.d_drho.get().reshape(spin, nidx, nidx)
-            dw_extra = np.zeros((spin, nb, nb))
             for s in range(spin):
-                fsum = np.sum(ff[s])
-                if abs(fsum) > ftsystem.ZERO_TOL:
-                    dw_dmu = np.einsum('ij,ij->', drho[s], drho_dmu[s][self.fit_idx][:, self.fit_idx]) * 2.0 * self.beta
-                    dw_extra[s] = drho_dmu[s] * (dw_dmu / fsum)
-            d_neg = ctx.to_device(-dw_extra)
-            ctx.check(lib.dmk_sub_sumsq(ctx.h, spin * nb * nb, self.d_sc.ptr, d_neg.ptr, self.d_sc.ptr,
-                                        self.d_ss.ptr))                     # d_sc += dw_extra  (a - (-b))
-            ctx.sync()
+                fsum = float(np.sum(ff[s]))
+                if abs(fsum) <= ftsystem.ZERO_TOL:
+                    continue
+                d_dm = self.d_T2.offset(s * nb * nb, (nb, nb))
+                d_sub = self.d_rfit.offset(s * nidx * nidx, (nidx, nidx))                                   # scratch: drho_dmu[fit, fit]
+                ctx.check(lib.dmk_gather2d_f64(ctx.h, nidx, nidx, self.d_fit.ptr, self.d_fit.ptr, d_dm.ptr, nb, d_sub.ptr))
+                ctx.check(lib.dmk_dgemv2(ctx.h, 1, nidx * nidx, self.d_drho.offset(s * nidx * nidx, (nidx * nidx,)).ptr,
+                                         nidx * nidx, d_sub.ptr, None, self.d_ss.ptr, None))                 # <drho, drho_dmu[fit,fit]>
+                dw_dmu = float(self.d_ss.get()[0]) * 2.0 * self.beta
+                ctx.check(lib.dmk_axpy_f64(ctx.h, nb * nb, dw_dmu / fsum, d_dm.ptr, self.d_sc.offset(s * nb * nb, (nb, nb)).ptr))
         ctx.check(lib.dmk_sym_fold(ctx.h, nb, spin, self.d_sc.ptr, self.d_dw.ptr))
         ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, self.d_dw.ptr,
                                  None, self.d_grad.ptr, None))
