@@ -306,7 +306,8 @@ int dmk_sym_unpack(dmk_ctx *ctx, int n, int batch, const double *tril, const dou
 /* out[r][c] = in[row_idx ? row_idx[r] : r][col_idx ? col_idx[c] : c]  (fit_idx selections, slater.py:1089-1090, 1136). */
 int dmk_gather2d_f64(dmk_ctx *ctx, int nrow, int ncol, const int32_t *row_idx, const int32_t *col_idx, const double *in,
                      int64_t ld_in, double *out);
-/* mode 0: out = A o B (Hadamard);  mode 1: out[r][c] = A[r][c] * B[r]  (ev * ewocc, slater.py:1088). */
+/* mode 0: out = A o B (Hadamard);  mode 1: out[r][c] = A[r][c] * B[r]  (ev * ewocc, slater.py:1088);
+ * mode 2: A and out are complex128 viewed as doubles (ncol = 2 x complex columns), B real: out = A o B (ftsystem.py:263). */
 int dmk_ewise_mul(dmk_ctx *ctx, int mode, int64_t nrow, int64_t ncol, const double *A, const double *B, double *out);
 /* diff = a - b (diff may be NULL), *sumsq_dev = sum (a - b)^2 in a fixed order: la.norm(drho), slater.py:1094. */
 int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, double *diff, double *sumsq_dev);
@@ -314,6 +315,10 @@ int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, dou
  * degenerate limit -beta f_p (1 - f_q) (routine/ftsystem.py:170-181); beta <= 0: the T = 0 form 1/(e_occ - e_virt) on the
  * occupied-virtual blocks split at nocc (routine/slater.py:1126-1134).  ew, f: batch x n (f unused at T = 0). */
 int dmk_fit_kmat(dmk_ctx *ctx, int n, int batch, const double *ew, const double *f, double beta, int nocc, double *K);
+/* dst[(idx[a] ld_dst + idx[b]) elem_stride] += alpha src[a][b], src m x m: drho placed at the fitted indices of a zeroed
+ * full matrix (elem_stride 2 writes the real parts of a complex128 matrix); ftsystem.py:263 in matrix form. */
+int dmk_scatter2d_add_f64(dmk_ctx *ctx, int m, const int32_t *idx, const double *src, double alpha, double *dst, int64_t ld_dst,
+                          int elem_stride);
 /* y += alpha x */
 int dmk_axpy_f64(dmk_ctx *ctx, int64_t n, double alpha, const double *x, double *y);
 /* dV_dparam rows from the cell Gram matrix G[(i,p),(j,q)] = sum_c B[c,i,p] B[c,j,q] (row-major, ldg):

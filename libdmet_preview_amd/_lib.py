@@ -88,6 +88,7 @@ PROTOTYPES = {
     "dmk_ewise_mul": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "dmk_sub_sumsq": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "dmk_fit_kmat": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_dbl, c_int, c_vp]),
+    "dmk_scatter2d_add_f64": (c_int, [c_vp, c_int, c_vp, c_vp, c_dbl, c_vp, c_i64, c_int]),
     "dmk_axpy_f64": (c_int, [c_vp, c_i64, c_dbl, c_vp, c_vp]),
     "dmk_vcor_dV_dparam": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }

@@ -194,13 +194,13 @@ __global__ void gather2d_kernel(int nr, int nc, const int *__restrict__ ridx, co
     }
 }
 
-// out = A o B   (mode 0);  out[r][c] = A[r][c] * s[r]   (mode 1, B = s)
+// out = A o B   (mode 0);  out[r][c] = A[r][c] * s[r]   (mode 1, B = s);  mode 2: A, out complex (nc counts doubles), B real
 __global__ void ewise_kernel(int mode, long long nr, long long nc, const double *__restrict__ A, const double *__restrict__ B,
                              double *__restrict__ out) {
     const long long total = nr * nc;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x)
-        out[t] = A[t] * (mode == 0 ? B[t] : B[t / nc]);
+        out[t] = A[t] * (mode == 0 ? B[t] : (mode == 1 ? B[t / nc] : B[t >> 1]));
 }
 
 // diff = a - b, sumsq = sum diff^2 ; one workgroup, fixed order
@@ -259,6 +259,16 @@ __global__ void fit_kmat_kernel(int n, int batch, const double *__restrict__ ew,
             v = (fabs(de) < 1e-10) ? -beta * fp * (1.0 - fq) : (fp - fq) / de;
         }
         K[t] = v;
+    }
+}
+
+// dst[(idx[a] * ld + idx[b]) * estride] += alpha src[a][b]; repeated indices accumulate (f64 atomics)
+__global__ void scatter2d_kernel(int m, const int *__restrict__ idx, const double *__restrict__ src, double alpha,
+                                 double *__restrict__ dst, long long ld, int estride) {
+    const long long total = (long long)m * m;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int a = (int)(t / m), b = (int)(t % m);
+        atomicAdd(dst + ((long long)idx[a] * ld + idx[b]) * estride, alpha * src[t]);
     }
 }
 
@@ -362,7 +372,7 @@ int dmk_gather2d_f64(dmk_ctx *ctx, int nrow, int ncol, const int32_t *row_idx, c
 
 int dmk_ewise_mul(dmk_ctx *ctx, int mode, int64_t nrow, int64_t ncol, const double *A, const double *B, double *out) {
     if (!ctx) return DMK_ERR_INVALID;
-    if ((mode != 0 && mode != 1) || nrow < 0 || ncol < 0 || !A || !B || !out)
+    if (mode < 0 || mode > 2 || (mode == 2 && (ncol & 1)) || nrow < 0 || ncol < 0 || !A || !B || !out)
         return dmk_fail(ctx, DMK_ERR_INVALID, "ewise_mul: bad arguments");
     if (nrow == 0 || ncol == 0) return DMK_OK;
     FamScope fs(ctx, DMK_FAM_FIT);
@@ -387,6 +397,19 @@ int dmk_fit_kmat(dmk_ctx *ctx, int n, int batch, const double *ew, const double 
         return dmk_fail(ctx, DMK_ERR_INVALID, "fit_kmat: bad arguments");
     FamScope fs(ctx, DMK_FAM_FIT);
     hipLaunchKernelGGL(fit_kmat_kernel, dim3(grid_for((long long)batch * n * n)), dim3(256), 0, ctx->stream, n, batch, ew, f, beta, nocc, K);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+int dmk_scatter2d_add_f64(dmk_ctx *ctx, int m, const int32_t *idx, const double *src, double alpha, double *dst, int64_t ld_dst,
+                          int elem_stride) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (m < 0 || !idx || !src || !dst || ld_dst <= 0 || elem_stride <= 0)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "scatter2d_add: bad arguments");
+    if (m == 0) return DMK_OK;
+    FamScope fs(ctx, DMK_FAM_FIT);
+    hipLaunchKernelGGL(scatter2d_kernel, dim3(grid_for((long long)m * m)), dim3(256), 0, ctx->stream, m, idx, src, alpha, dst,
+                       (long long)ld_dst, elem_stride);
     DMK_CHECK_LAUNCH(ctx);
     return DMK_OK;
 }

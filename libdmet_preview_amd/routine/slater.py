@@ -712,10 +712,20 @@ class FullFitDevice(object):
         self.d_rfit = ctx.empty((spin, nidx, nidx), np.float64)
         self.d_drho = ctx.empty((spin, nidx, nidx), np.float64)
         self.d_ss = ctx.empty((1,), np.float64)
-        self.nfev = 0
+        self.nfev = self.ngev = 0
+        self._key, self._state = None, None
+        # dV_dparam of the lattice problem: tril-packed vcor.gradient() (get_dV_dparam_full, slater.py:1331-1350)
+        g = np.asarray(vcor.gradient())
+        self.nparam, self.npair = g.shape[0], n * (n + 1) // 2
+        tl = np.tril_indices(n)
+        self.d_dV = ctx.to_device(np.ascontiguousarray(g[:, :spin][:, :, tl[0], tl[1]], dtype=np.float64))
+        self.d_even = ctx.to_device(np.arange(0, 2 * n, 2, dtype=np.int32))
 
-    def errfunc(self, param):
-        self.nfev += 1
+    def _forward(self, param):
+        param = np.ascontiguousarray(param, dtype=np.float64)
+        key = param.tobytes()
+        if key == self._key:
+            return self._state
         ctx, spin, nk, n, nb, nidx = self.ctx, self.spin, self.nk, self.n, self.nb, self.nidx
         mfd = self._mfd
         self.vcor.update(param)
@@ -746,21 +756,92 @@ class FullFitDevice(object):
         ctx.check(lib.dmk_sub_sumsq(ctx.h, spin * nidx * nidx, self.d_rfit.ptr, self.d_target.ptr, self.d_drho.ptr, self.d_ss.ptr))
         val = float(np.sqrt(self.d_ss.get()[0]))
         ctx.sync()
-        return val / sqrt(spin)
+        self._key, self._state = key, (ew, mu, val, d_w, d_Vt)
+        return self._state
+
+    def errfunc(self, param):
+        self.nfev += 1
+        return self._forward(param)[2] / sqrt(self.spin)
+
+    def gradfunc(self, param):
+        """Analytic finite-T gradient (slater.py:1480-1640, local vcor): for every k
+            dw_dv_k = ev_k^* [(ev_k[fit]^T 2 drho ev_k[fit]^*) o K_k] ev_k^T  (+ the per-k chemical-potential response),
+        all k and spins in batched complex GEMMs on the resident eigenvectors; the k sum, real part, "x2 tril" packing
+        and the contraction with dV_dparam are streaming kernels.  Row m of Vt is eigenvector m, so
+        ev[fit]^T D' ev[fit]^* = Vt D Vt^H with D = drho scattered to the fitted indices, and ev^* X ev^T = Vt^H X Vt."""
+        if self.imp_bath_fit:
+            raise NotImplementedError("imp + bath fit has no analytic gradient (slater.py:1510-1512)")
+        if self.beta == np.inf:
+            raise NotImplementedError("no analytic T = 0 lattice gradient (slater.py:1642-1645)")
+        self.ngev += 1
+        ctx, spin, nk, n, nidx, beta = self.ctx, self.spin, self.nk, self.n, self.nidx, self.beta
+        B, n2 = spin * nk, n * n
+        bg = self._bgemm
+        ew, mu, val, d_w, d_Vt = self._forward(param)
+        f = np.empty((spin, nk, n))
+        for k in range(nk):
+            f[:, k] = ftsystem.fermi_smearing_occ(mu, ew[:, k], beta)
+        d_f = ctx.to_device(np.ascontiguousarray(f).reshape(B, n))
+        d_K = ctx.empty((B, n, n), np.float64)
+        ctx.check(lib.dmk_fit_kmat(ctx.h, n, B, d_w.ptr, d_f.ptr, float(beta), 0, d_K.ptr))
+        d_D = ctx.zeros((spin, n, n), np.complex128)
+        for s in range(spin):
+            ctx.check(lib.dmk_scatter2d_add_f64(ctx.h, nidx, self.d_fit.ptr, self.d_drho.offset(s * nidx * nidx, (nidx, nidx)).ptr,
+                                                2.0, d_D.offset(s * n2, (n, n)).ptr, n, 2))
+        d_T1 = ctx.empty((B, n, n), np.complex128)
+        for s in range(spin):
+            bg(ctx, "N", "N", n, n, n, nk, d_Vt.offset(s * nk * n2, (nk, n, n)), n2, d_D.offset(s * n2, (n, n)), 0,
+               C=d_T1.offset(s * nk * n2, (nk, n, n)))
+        d_tmp = bg(ctx, "N", "C", n, n, n, B, d_T1, n2, d_Vt, n2)
+        ctx.check(lib.dmk_ewise_mul(ctx.h, 2, B * n, 2 * n, d_tmp.ptr, d_K.ptr, d_tmp.ptr))
+        bg(ctx, "C", "N", n, n, n, B, d_Vt, n2, d_tmp, n2, C=d_T1)
+        d_G = bg(ctx, "N", "N", n, n, n, B, d_T1, n2, d_Vt, n2, C=d_tmp)
+        d_sum = ctx.empty((spin, n, n), np.complex128)
+        d_one = ctx.to_device(np.ones(nk))
+        for s in range(spin):
+            ctx.check(lib.dmk_dgemv2(ctx.h, nk, 2 * n2, d_G.offset(s * nk * n2, (nk, n, n)).ptr, 2 * n2, None, d_one.ptr, None,
+                                     d_sum.offset(s * n2, (n, n)).ptr))
+        if not self.fix_mu:
+            ff = f * (1.0 - f)
+            fsum = ff.sum(axis=2)                                                   # per (spin, k): ftsystem.py:271-273
+            d_ff = ctx.to_device(np.ascontiguousarray(ff).reshape(B, n))
+            d_rmu = self._mfd.density_dev(ctx, d_Vt, d_ff, n, B)                    # drho_dmu / beta for every k
+            d_y = ctx.empty((B,), np.float64)
+            for s in range(spin):
+                ctx.check(lib.dmk_dgemv2(ctx.h, nk, 2 * n2, d_rmu.offset(s * nk * n2, (nk, n, n)).ptr, 2 * n2,
+                                         d_D.offset(s * n2, (n, n)).ptr, None, d_y.offset(s * nk, (nk,)).ptr, None))
+            y = d_y.get().reshape(spin, nk)                                         # sum 2 drho o Re drho_dmu[fit, fit]
+            coef = np.where(np.abs(fsum) > ftsystem.ZERO_TOL, beta * y / np.where(fsum == 0.0, 1.0, fsum), 0.0)
+            d_c = ctx.to_device(np.ascontiguousarray(coef).reshape(B))
+            d_mu = ctx.empty((spin, n, n), np.complex128)
+            for s in range(spin):
+                ctx.check(lib.dmk_dgemv2(ctx.h, nk, 2 * n2, d_rmu.offset(s * nk * n2, (nk, n, n)).ptr, 2 * n2, None,
+                                         d_c.offset(s * nk, (nk,)).ptr, None, d_mu.offset(s * n2, (n, n)).ptr))
+            ctx.check(lib.dmk_axpy_f64(ctx.h, 2 * spin * n2, 1.0, d_mu.ptr, d_sum.ptr))
+        d_re = ctx.empty((spin, n, n), np.float64)
+        for s in range(spin):
+            ctx.check(lib.dmk_gather2d_f64(ctx.h, n, n, None, self.d_even.ptr, d_sum.offset(s * n2, (n, n)).ptr, 2 * n,
+                                           d_re.offset(s * n2, (n, n)).ptr))
+        d_dw = ctx.empty((spin, self.npair), np.float64)
+        ctx.check(lib.dmk_sym_fold(ctx.h, n, spin, d_re.ptr, d_dw.ptr))
+        d_grad = ctx.empty((self.nparam,), np.float64)
+        ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, d_dw.ptr, None,
+                                 d_grad.ptr, None))
+        return d_grad.get() / (2.0 * val * sqrt(spin) * nk)
 
 
 def FitVcorFull(rho, lattice, basis, vcor, beta, filling, MaxIter=20, imp_fit=False, imp_idx=None, det=False, det_idx=None,
                 CG_check=False, BFGS=False, diff_criterion=None, scf=False, **kwargs):
     """
     Fit the correlation potential in the full lattice space (slater.py:1352-1682).  The objective runs on the device
-    (FullFitDevice); the gradient is the reference's numerical one (`num_grad=True`, central differences inside the
-    minimiser) -- its analytic finite-T lattice gradient and the SCF variant are outside the HIP path.
+    (FullFitDevice); the gradient is the reference's analytic finite-T lattice gradient (FullFitDevice.gradfunc,
+    slater.py:1480-1640) or, with `num_grad=True` (required at T = 0 as in the reference), central differences inside
+    the minimiser.  The SCF variant and k-dependent vcor are outside the HIP path.
     """
     if scf or getattr(vcor, "is_vcor_kpts", False):
         raise NotImplementedError("scf / k-dependent vcor in FitVcorFull are outside the HIP path")
-    if not kwargs.get("num_grad", False):
-        raise NotImplementedError("FitVcorFull: only num_grad=True is available on the HIP path "
-                                  "(the reference itself has no analytic T = 0 gradient, slater.py:1631-1634)")
+    if not kwargs.get("num_grad", False) and beta == np.inf:
+        raise NotImplementedError("FitVcorFull: no analytic T = 0 gradient, pass num_grad=True (slater.py:1642-1645)")
     basis = np.asarray(basis)
     param_begin = vcor.param.copy()
     spin, nkpts, nao, nbasis = basis.shape
@@ -794,9 +875,14 @@ def FitVcorFull(rho, lattice, basis, vcor, beta, filling, MaxIter=20, imp_fit=Fa
     ctx = get_ctx()
     fit = FullFitDevice(ctx, np.asarray(rho), lattice, basis, vcor, beta, nelec, imp_idx, det_idx, imp_bath_fit,
                         fix_mu=kwargs.get("fix_mu", False))
-    log.warn("You are using numerical gradient...")
+    if kwargs.get("num_grad", False):
+        log.warn("You are using numerical gradient...")
+        gradfunc = None
+    else:
+        log.info("Using analytic gradient for finite T, beta = %s", beta)
+        gradfunc = fit.gradfunc
     err_begin = fit.errfunc(param_begin)
-    param, err_end, pattern, gnorm_res = minimize(fit.errfunc, param_begin.copy(), MaxIter, None, **kwargs)
+    param, err_end, pattern, gnorm_res = minimize(fit.errfunc, param_begin.copy(), MaxIter, gradfunc, **kwargs)
     vcor.update(param)
     log.info("Minimizer converge pattern: %d ", pattern)
     log.info("Current function value: %15.8f", err_end)

@@ -472,6 +472,45 @@ def gen_G7():
     print("G7 done")
 
 
+def gen_G14():
+    """Analytic finite-T gradient of the lattice-space fit (FitVcorFull.gradfunc_ft, slater.py:1480-1640)."""
+    from libdmet.routine import slater, mfd
+    from libdmet.dmet import Hubbard
+    shim.patch_scf()
+    out = {}
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["grad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    for name, mesh, nlo, spin, val, seed in [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3], 21), ("rhf_411", (4, 1, 1), 5, 1, [1, 2, 3], 22),
+                                             ("rhf_222", (2, 2, 2), 6, 1, [0, 1, 2, 3, 4, 5], 23)]:
+        L, FR, basis, target = _fit_case(name, mesh, nlo, spin, val, seed)
+        rng = np.random.default_rng(seed + 7)
+        x = 0.05 * rng.standard_normal((spin, nlo, nlo))
+        v0 = _Vcor(np.zeros((2, nlo, nlo)))
+        rho_loc = mfd.HF(L, v0, 0.5, spin == 1, beta=np.inf)[0][:, 0] + 0.5 * (x + x.transpose(0, 2, 1))
+        out[name + "/mesh"], out[name + "/val"], out[name + "/Fock_R"] = np.array(mesh), np.array(val), FR
+        out[name + "/basis"], out[name + "/target_loc"] = basis, rho_loc
+        runs = [("imp_ft", 10.0, dict(imp_fit=True)), ("det_ft", 12.0, dict(det=True)),
+                ("idx_ft_fixmu", 8.0, dict(imp_idx=[0, 1], det_idx=[nlo - 1], fix_mu=True)),
+                ("imp_ft_bfgs", 15.0, dict(imp_fit=True, method="BFGS"))]
+        for tag, beta, kw in runs:
+            v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            vfit, e0, e1 = slater.FitVcorFull(rho_loc, L, basis, v, beta, 0.5, MaxIter=4, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](p.copy()) for p in P])
+            out[key + "/probe_grad"] = np.asarray([captured["grad"](p.copy()) for p in P])
+    slater.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G14_vcorfit_full_grad.npz"), **out)
+    print("G14 done")
+
+
 def _psd_eri(rng, nb, naux, spin):
     """DF-like 4-fold ERI blocks: (aa, bb, ab) = (Xa^T Xa, Xb^T Xb, Xa^T Xb), X (naux, npair)."""
     npair = nb * (nb + 1) // 2
@@ -900,7 +939,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14"]
     for g in which:
         globals()["gen_" + g]()
 

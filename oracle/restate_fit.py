@@ -156,7 +156,7 @@ def get_dw_dv(mo_energy, mo_coeff, drho, mu, beta, fix_mu=True, compact=False, f
     fit_idx = list(fit_idx)
     f = fermi_smearing_occ(mu, mo_energy, beta)
     h = 1.0 - f
-    dw_dv = np.zeros((spin, norb, norb))
+    dw_dv = np.zeros((spin, norb, norb), dtype=np.asarray(mo_coeff).dtype)
     for s in range(spin):
         de = mo_energy[s, :, None] - mo_energy[s]
         zero = np.abs(de) < ZERO_TOL
@@ -165,13 +165,13 @@ def get_dw_dv(mo_energy, mo_coeff, drho, mu, beta, fix_mu=True, compact=False, f
         K = inv * (f[s, :, None] - f[s])
         K[zero] = (f[s, :, None] * h[s])[zero] * (-beta)
         C = mo_coeff[s]
-        tmp = (C[fit_idx].T @ (2.0 * drho[s]) @ C[fit_idx]) * K
-        dw_dv[s] = C @ tmp @ C.T
+        tmp = (C[fit_idx].T @ (2.0 * drho[s]) @ C[fit_idx].conj()) * K                  # ftsystem.py:263
+        dw_dv[s] = C.conj() @ tmp @ C.T
         if not fix_mu:
             ff = f[s] * h[s]
             fsum = np.sum(ff)
             if abs(fsum) > ZERO_TOL:
-                drho_dmu = (C * ff) @ C.T
+                drho_dmu = (C * ff) @ C.conj().T
                 dw_dmu = np.einsum('ij,ij->', drho[s], drho_dmu[fit_idx][:, fit_idx]) * 2.0 * beta
                 dw_dv[s] += drho_dmu * (dw_dmu / fsum)
     if compact:
@@ -298,6 +298,7 @@ class FullFit(object):
         nimp, nidx = len(imp_idx), len(imp_idx) + len(det_idx)
         self.imp_mesh, self.det_mesh = np.ix_(imp_idx, imp_idx), (det_idx, det_idx)
         self.imp_fill, self.det_fill = (slice(nimp), slice(nimp)), (range(nimp, nidx), range(nimp, nidx))
+        self.fit_idx = imp_idx + det_idx
         self.target = np.zeros((spin, nidx, nidx))
         for s in range(spin):
             self.target[s][self.imp_fill] = rho[s][self.imp_mesh]
@@ -307,7 +308,7 @@ class FullFit(object):
         self.basis_k = np.asarray([R2k(basis[s], kmesh) for s in range(spin)])
         self.nelec = check_nelec(spin * nk * n * filling, None)[0]
 
-    def errfunc(self, param):
+    def _solve(self, param):
         spin, nk, n = self.spin, self.nk, self.n
         self.vcor.update(param)
         v = self.vcor.get(0, True)
@@ -317,6 +318,38 @@ class FullFit(object):
             for k in range(nk):
                 ew[s, k], ev[s, k] = la.eigh(self.Fock[s, k] + v[s])
         occ, mu, _ = assignocc(ew, self.nelec, self.beta, 0.0, fix_mu=self.fix_mu)
+        return ew, ev, occ, mu
+
+    def gradfunc_ft(self, param):
+        """finite-T analytic lattice gradient (slater.py:1480-1640, the local-vcor branch 1631-1640): every k point
+        contributes its own get_dw_dv (chemical-potential response normalised per k, as the reference does)."""
+        spin, nk, n = self.spin, self.nk, self.n
+        if self.imp_bath_fit:
+            raise NotImplementedError                                       # slater.py:1510-1512
+        ew, ev, occ, mu = self._solve(param)
+        rhoT = np.einsum('skpm,skm,skqm->spq', ev, occ, ev.conj()).real / nk
+        rho1 = np.zeros_like(self.target)
+        for s in range(spin):
+            rho1[s][self.imp_fill] = rhoT[s][self.imp_mesh]
+            rho1[s][self.det_fill] = rhoT[s][self.det_mesh]
+        drho = rho1 - self.target
+        val = la.norm(drho)
+        g = self.vcor.gradient()                                            # (nparam, 2|spin, n, n)
+        nparam = g.shape[0]
+        tril = np.tril_indices(n)
+        dV = np.asarray([[g[i, s][tril] for s in range(g.shape[1])] for i in range(nparam)])     # pack_tril (slater.py:1345-1348)
+        if spin == 1:
+            dV = dV[:, [0]]
+        res = np.zeros(nparam)
+        for k in range(nk):
+            dw_dv = get_dw_dv(ew[:, k], ev[:, k], drho, mu, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx,
+                              compact=True).real
+            res += dV.reshape(nparam, -1).dot(dw_dv.ravel())
+        return res.real / (2.0 * val * sqrt(spin) * nk)
+
+    def errfunc(self, param):
+        spin, nk, n = self.spin, self.nk, self.n
+        ew, ev, occ, mu = self._solve(param)
         rho_k = np.einsum('skpm,skm,skqm->skpq', ev, occ, ev.conj())
         rho1 = np.zeros_like(self.target)
         if self.imp_bath_fit:

@@ -219,6 +219,38 @@ def test_fit_full_lattice_and_two_step(ctx, golden, name):
         slater.FitVcorFull(g[name + "/target_emb"], L, basis, v, 12.0, 0.5, MaxIter=1)
 
 
+@pytest.mark.parametrize("name", ["uhf_231", "rhf_411", "rhf_222"])
+def test_fit_full_lattice_analytic_gradient(ctx, golden, name):
+    """FitVcorFull with the analytic finite-T lattice gradient on the device against the reference's gradfunc_ft
+    values and fit results (golden G14)."""
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.dmet import Hubbard
+    from tests.test_oracle_fit import GRAD_RUNS
+    g = golden("G14_vcorfit_full_grad.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR, basis = g[name + "/Fock_R"], g[name + "/basis"]
+    val = [int(x) for x in g[name + "/val"]]
+    spin, nlo = basis.shape[0], FR.shape[-1]
+    Fk = R.R2k(FR, mesh)
+    L = _lattice(mesh, nlo, val, Fk, spin)
+    for tag, beta, kw in GRAD_RUNS:
+        kw = dict(kw)
+        if kw.get("det_idx") == [-1]:
+            kw["det_idx"] = [nlo - 1]
+        key = "%s/%s" % (name, tag)
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        vfit, e0, e1 = slater.FitVcorFull(g[name + "/target_loc"], L, basis, v, beta, 0.5, MaxIter=4, **kw)
+        fit = slater.FitVcorFull.last_fit
+        assert fit.ngev > 0
+        pfit = np.array(vfit.param)
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-10, key
+            assert np.abs(fit.gradfunc(p) - gr).max() < 1e-9 * max(1.0, np.abs(gr).max()), key
+        r0, r1 = g[key + "/err"]
+        assert abs(e0 - r0) < 1e-10 and abs(e1 - r1) < 1e-6, (key, e1, r1)
+        assert np.abs(pfit - g[key + "/param"]).max() < 1e-4, key
+
+
 @pytest.mark.parametrize("n,batch", [(1, 1), (2, 3), (7, 2), (31, 1), (32, 2), (33, 2), (100, 3), (256, 2), (300, 1)])
 def test_eigh_jacobi(ctx, n, batch):
     """Multi-CU block Jacobi eigensolver, cold and warm start, against LAPACK."""

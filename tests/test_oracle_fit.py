@@ -104,3 +104,41 @@ def test_G10_full_lattice_objective(golden, name):
             assert abs(fit.errfunc(p) - e) < 1e-11, key
         assert abs(fit.errfunc(np.zeros(v.length())) - g[key + "/err"][0]) < 1e-11
         assert abs(fit.errfunc(g[key + "/param"]) - g[key + "/err"][1]) < 1e-10
+
+
+GRAD_RUNS = [("imp_ft", 10.0, dict(imp_fit=True)), ("det_ft", 12.0, dict(det=True)),
+             ("idx_ft_fixmu", 8.0, dict(imp_idx=[0, 1], det_idx=[-1], fix_mu=True)),
+             ("imp_ft_bfgs", 15.0, dict(imp_fit=True, method="BFGS"))]
+GRAD_CASES = ["uhf_231", "rhf_411", "rhf_222"]
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_G14_full_lattice_gradient(golden, name):
+    """FitVcorFull.gradfunc_ft (slater.py:1480-1640) captured from the reference at fixed parameter vectors."""
+    g = golden("G14_vcorfit_full_grad.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    FR, basis = g[name + "/Fock_R"], g[name + "/basis"]
+    val = [int(x) for x in g[name + "/val"]]
+    spin, nlo = basis.shape[0], FR.shape[-1]
+    Fk = R.R2k(FR, mesh)
+    for tag, beta, kw in GRAD_RUNS:
+        v = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        kw = dict(kw)
+        if kw.get("det_idx") == [-1]:
+            kw["det_idx"] = [nlo - 1]
+        imp_idx, det_idx = idx_sets(kw, nlo - min(val), None)
+        fit = F.FullFit(g[name + "/target_loc"], mesh, basis, v, beta, Fk if spin == 2 else Fk[0], 0.5, imp_idx=imp_idx,
+                        det_idx=det_idx, fix_mu=kw.get("fix_mu", False))
+        key = "%s/%s" % (name, tag)
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-11, key
+            assert np.abs(fit.gradfunc_ft(p) - gr).max() < 1e-9 * max(1.0, np.abs(gr).max()), key
+        if kw.get("fix_mu"):
+            # with the chemical potential fixed the reference's formula is the exact derivative (central differences); with
+            # a floating mu it normalises the mu response per k point (slater.py:1359-1362 flags it), so only parity holds
+            p = g[key + "/probe"][0]
+            e = np.zeros_like(p)
+            e[1] = 1e-5
+            fd = (fit.errfunc(p + e) - fit.errfunc(p - e)) / 2e-5
+            assert abs(fd - fit.gradfunc_ft(p)[1]) < 1e-6, key
+        assert abs(fit.errfunc(g[key + "/param"]) - g[key + "/err"][1]) < 1e-10
