@@ -1,0 +1,105 @@
+"""
+Rebinding of the reference's entry points to this package.
+
+The reference has no plugin interface: its hot-path callables are plain module attributes, and several callers bind
+them BY NAME at import time (`from ...eri_transform import get_emb_eri` in routine/slater.py:32-33,
+`from libdmet.routine.mfd import HF` in dmet/HubPhSymm.py:22, the star import of `fourier` in system/lattice.py:23),
+so the defining module AND every importing module's copy have to be replaced.  `install()` does exactly that from
+the table below and returns a handle `uninstall()` undoes; nothing here computes anything.
+
+    import libdmet_preview_amd.patch as hip
+    handle = hip.install()            # after `import libdmet`, before building Lattice objects
+    ...
+    hip.uninstall(handle)
+
+`install` raises if the HIP library cannot be loaded (there is no CPU fallback to bind) and, with `strict=True`
+(default), if a name of the table is missing on the reference side -- a renamed entry point must not be skipped
+silently.
+"""
+import importlib
+
+# (our module, [reference modules that hold a copy], [names])  -- reference file:line of every import-time binding
+_FUNCTIONS = [
+    # Lattice.k2R / R2k / FFTtoK / FFTtoT resolve these from the module globals (system/lattice.py:23 star import)
+    ("system.fourier", ["system.fourier", "system.lattice"], ["FFTtoK", "FFTtoT", "k2R", "R2k"]),
+    # HF() looks the diagonalisers up in its own module globals (routine/mfd.py:283-298)
+    ("routine.mfd", ["routine.mfd"],
+     ["DiagRHF", "DiagUHF", "DiagRHF_symm", "DiagUHF_symm", "DiagGHF", "DiagGHF_symm", "DiagBdG", "DiagBdGsymm",
+      "assignocc"]),
+    # AO -> LO -> EO basis products (basis_transform/__init__.py star import; eri_transform.py:27)
+    ("basis_transform.make_basis", ["basis_transform.make_basis", "basis_transform"],
+     ["multiply_basis", "transform_h1_to_lo", "transform_rdm1_to_lo", "transform_rdm1_to_ao"]),
+    ("basis_transform.make_basis", ["basis_transform.eri_transform"], ["multiply_basis"]),
+    # Schmidt bath; called as slater.embBasis (dmet/HubPhSymm.py:77)
+    ("routine.slater", ["routine.slater"],
+     ["get_emb_basis", "embBasis", "get_emb_Ham", "embHam", "transform_h1", "foldRho", "foldRho_k", "get_veff",
+      "get_dV_dparam", "FitVcorEmb", "FitVcorFull", "FitVcorTwoStep"]),
+    # the ERI transform; routine/slater.py:32-33 holds its own copy
+    ("basis_transform.eri_transform", ["basis_transform.eri_transform", "basis_transform", "routine.slater"],
+     ["get_emb_eri", "get_unit_eri"]),
+    # spinless.py:518-538 imports get_emb_eri_gso lazily from the module; cderi layout helpers
+    ("basis_transform.eri_transform", ["basis_transform.eri_transform"],
+     ["get_emb_eri_gso", "get_mask_kptij_lst", "transform_gdf_to_lo", "eri_restore"]),
+    # J / K on the resident ERI (routine/slater.py:30 imports them by name)
+    ("solver.scf", ["solver.scf", "routine.slater"], ["_get_jk", "_get_veff"]),
+    # one-body folds (routine/slater.py:35 star-imports slater_helper)
+    ("routine.slater_helper", ["routine.slater_helper", "routine.slater"],
+     ["transform_trans_inv", "transform_trans_inv_k", "transform_local", "transform_imp", "transform_imp_env",
+      "transform_4idx", "transform_eri_local", "unit2emb"]),
+    # BCS twin (routine/bcs.py:13 star-imports bcs_helper)
+    ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
+     ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
+      "contract_imp_env", "transform_imp_env", "transform_local_grad", "get_dV_dparam"]),
+    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis"]),
+    # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
+    ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
+    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis"]),
+    ("dmet.HubPhSymm", ["dmet.HubPhSymm"], ["basisMatching"]),
+]
+# methods of the reference's Lattice replaced by ours (they only touch duck-typed attributes; system/lattice.py:416-673)
+_LATTICE_METHODS = ["set_Ham", "setHam", "set_Ham_model", "setHam_model", "update_Ham", "transform_obj_to_lo"]
+# HF itself: dmet/HubPhSymm.py:22 binds it by name, dmet/Hubbard.py:9 star-imports that module
+_HF_HOLDERS = ["routine.mfd", "dmet.HubPhSymm", "dmet.Hubbard"]
+
+
+def binding_table():
+    """The rebinding plan as (our dotted module, reference dotted module, attribute) triples."""
+    out = []
+    for ours, refs, names in _FUNCTIONS:
+        for r in refs:
+            for n in names:
+                out.append((ours, r, n))
+    for r in _HF_HOLDERS:
+        out.append(("routine.mfd", r, "HF"))
+    return out
+
+
+def install(reference_package="libdmet", replace_hf=True, strict=True):
+    """Rebind the reference's hot-path entry points to the HIP implementations; returns the undo handle."""
+    from libdmet_preview_amd import _lib          # noqa: F401 -- loading libdmetk.so fails loudly here if it is missing
+    undo = []
+
+    def bind(ref_mod, name, value):
+        if not hasattr(ref_mod, name):
+            if strict:
+                raise AttributeError("%s has no attribute %s to rebind" % (ref_mod.__name__, name))
+            return
+        undo.append((ref_mod, name, getattr(ref_mod, name)))
+        setattr(ref_mod, name, value)
+
+    for ours, ref, name in binding_table():
+        if name == "HF" and not replace_hf:
+            continue
+        mine = importlib.import_module("libdmet_preview_amd." + ours)
+        bind(importlib.import_module(reference_package + "." + ref), name, getattr(mine, name))
+    ref_lat = importlib.import_module(reference_package + ".system.lattice")
+    from libdmet_preview_amd.system import lattice as my_lat
+    for name in _LATTICE_METHODS:
+        bind(ref_lat.Lattice, name, getattr(my_lat.Lattice, name))
+    return undo
+
+
+def uninstall(handle):
+    for obj, name, old in reversed(handle):
+        setattr(obj, name, old)
+    del handle[:]
