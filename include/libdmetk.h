@@ -221,6 +221,16 @@ int dmk_eri_begin_kL(dmk_eri *h, int kL);
  * accumulate its tril-packed (L|ab) into the current kL's Lij_s4;
  * symmetrise != 0 adds the transposed term of the time-reversal partner pair. */
 int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq);
+/* The same for an AO block in HOST memory (what sr_loop / _load3c hand over, eri_transform.py:195-227, 358-366): the
+ * block is copied to one of two device staging blocks (`slot` 0 | 1) on a separate copy stream and transformed on the
+ * compute stream as soon as it has landed, so the copy of block n+1 overlaps the transform of block n.  Returns
+ * without waiting.  The host buffer may be refilled once dmk_eri_host_slot_wait(h, slot) has returned (use two pinned
+ * buffers from dmk_host_alloc and alternate the slots; pageable memory works but copies synchronously). */
+int dmk_eri_push_block_host(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq_host, int slot);
+int dmk_eri_host_slot_wait(dmk_eri *h, int slot);
+/* Page-locked host memory for the block feed. */
+int dmk_host_alloc(dmk_ctx *ctx, size_t bytes, void **out);
+int dmk_host_free(dmk_ctx *ctx, void *p);
 /* Contract the current kL: eri[blk] += w (Re^T Re [+ Im^T Im]) (TR) or Re(X^H X). */
 int dmk_eri_end_kL(dmk_eri *h, int weight);
 /* GSO (partial particle-hole) contraction of basis_transform/eri_transform.py:1252-1277 (_Lij_s4_to_eri_gso):

@@ -63,6 +63,10 @@ PROTOTYPES = {
     "dmk_eri_begin": (c_int, [c_vp, _int3, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, P(c_vp)]),
     "dmk_eri_begin_kL": (c_int, [c_vp, c_int]),
     "dmk_eri_push_block": (c_int, [c_vp, c_int, c_int, c_int, c_vp]),
+    "dmk_eri_push_block_host": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int]),
+    "dmk_eri_host_slot_wait": (c_int, [c_vp, c_int]),
+    "dmk_host_alloc": (c_int, [c_vp, c_sz, P(c_vp)]),
+    "dmk_host_free": (c_int, [c_vp, c_vp]),
     "dmk_eri_end_kL": (c_int, [c_vp, c_int]),
     "dmk_eri_end_kL_gso": (c_int, [c_vp, c_int]),
     "dmk_eri_planes": (c_int, [c_vp, P(c_vp), P(c_i64)]),
@@ -243,6 +247,33 @@ class DevArray(object):
             lib.dmk_free(self.ctx.h, self.ptr)
         self.ptr = None
         self._own = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray(object):
+    """Page-locked host memory (dmk_host_alloc) exposed as a numpy array `.a`; the feed buffers of the host block path."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.dtype = np.dtype(dtype)
+        shape = tuple(int(x) for x in (shape if hasattr(shape, "__iter__") else (shape,)))
+        nbytes = int(np.prod(shape)) * self.dtype.itemsize
+        p = c_vp()
+        ctx.check(lib.dmk_host_alloc(ctx.h, max(nbytes, 16), C.byref(p)))
+        self.ptr = p
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        self.a = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.a = None
+            lib.dmk_host_free(self.ctx.h, self.ptr)
+        self.ptr = None
 
     def __del__(self):
         try:

@@ -58,6 +58,10 @@ class GDFMemory(object):
     def load_block(self, ctx, i, j, out_dev):
         out_dev.set(self.get_block(i, j))
 
+    def load_block_host(self, i, j, out):
+        """Fill the pinned feed buffer `out` (naux, nao, nao) c128; EriEngine overlaps its copy with the transform."""
+        out[...] = self.get_block(i, j).reshape(out.shape)
+
 
 def _pack_tril_last2(a):
     n = a.shape[-1]
@@ -140,6 +144,9 @@ class CderiProvider(object):
 
     def load_block(self, ctx, i, j, out_dev):
         out_dev.set(self.get_block(i, j))
+
+    def load_block_host(self, i, j, out):
+        out[...] = self.get_block(i, j)
 
 
 def get_mask_kptij_lst(cell, kptij_lst, tol=KPT_DIFF_TOL):
@@ -362,6 +369,7 @@ class EriEngine(object):
         self.h = h
         self.weights, self.records = eri_plan(self.kmesh, self.tr)
         self.block_buf = ctx.empty((self.naux, self.nao, self.nao), np.complex128)
+        self.host_buf, self.host_slot = None, 0
         # records grouped by kL, in plan order
         self.by_kL = {}
         for r in self.records:
@@ -374,11 +382,24 @@ class EriEngine(object):
         ctx = self.ctx
         ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
         nblk = 0
+        host_feed = hasattr(provider, "load_block_host")
+        if host_feed and self.host_buf is None:
+            from libdmet_preview_amd._lib import PinnedArray
+            self.host_buf = [PinnedArray(ctx, (self.naux, self.nao, self.nao), np.complex128) for _ in range(2)]
         for r in self.by_kL[kL]:
             i, j, sym = int(r[1]), int(r[2]), int(r[4])
             ui, uj = (i, j) if user_of_mesh is None else (int(user_of_mesh[i]), int(user_of_mesh[j]))
-            provider.load_block(ctx, ui, uj, self.block_buf)
-            ctx.check(lib.dmk_eri_push_block(self.h, i, j, sym, self.block_buf.ptr))
+            if host_feed:
+                # blocks that live on the host (HDF5 / memory): fill one pinned buffer while the other one is being
+                # copied and the previous block is being transformed (dmk_eri_push_block_host)
+                slot = self.host_slot
+                ctx.check(lib.dmk_eri_host_slot_wait(self.h, slot))
+                provider.load_block_host(ui, uj, self.host_buf[slot].a)
+                ctx.check(lib.dmk_eri_push_block_host(self.h, i, j, sym, self.host_buf[slot].ptr, slot))
+                self.host_slot = 1 - slot
+            else:
+                provider.load_block(ctx, ui, uj, self.block_buf)
+                ctx.check(lib.dmk_eri_push_block(self.h, i, j, sym, self.block_buf.ptr))
             nblk += 1
             if max_blocks is not None and nblk >= max_blocks:
                 break
@@ -411,6 +432,9 @@ class EriEngine(object):
         if getattr(self, "h", None):
             lib.dmk_eri_finish(self.h)
             self.h = None
+        for b in (getattr(self, "host_buf", None) or []):
+            b.free()
+        self.host_buf = None
 
     def __del__(self):
         try:

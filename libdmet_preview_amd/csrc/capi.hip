@@ -600,6 +600,11 @@ struct dmk_eri {
     int pend_kj[16], pend_sym[16];
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
+    // host feed (dmk_eri_push_block_host): two device staging blocks filled on a copy stream while the compute stream
+    // transforms the other one; created on first use
+    hipStream_t copy_stream = nullptr;
+    double2 *dstage[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     dmk_eri(dmk_ctx *c, const int m[3]) : ctx(c), mesh(m) {}
 };
 
@@ -866,10 +871,65 @@ int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     return DMK_OK;
 }
 
+int dmk_eri_push_block_host(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq_host, int slot) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (slot < 0 || slot > 1 || !Lpq_host) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_block_host: bad arguments");
+    if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_block_host: no kL in progress");
+    const size_t bytes = (size_t)h->naux * h->nao * h->nao * sizeof(double2);
+    if (!h->copy_stream) {
+        DMK_HIP(ctx, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            DMK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&h->dstage[i]), bytes));
+            DMK_HIP(ctx, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
+            DMK_HIP(ctx, hipEventCreateWithFlags(&h->ev_consumed[i], hipEventDisableTiming));
+            DMK_HIP(ctx, hipEventRecord(h->ev_consumed[i], ctx->stream));
+        }
+    }
+    // the staging block is free once the step-1 launches that read it have run
+    DMK_HIP(ctx, hipStreamWaitEvent(h->copy_stream, h->ev_consumed[slot], 0));
+    DMK_HIP(ctx, hipMemcpyAsync(h->dstage[slot], Lpq_host, bytes, hipMemcpyHostToDevice, h->copy_stream));
+    DMK_HIP(ctx, hipEventRecord(h->ev_copied[slot], h->copy_stream));
+    DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_copied[slot], 0));
+    int rc = dmk_eri_push_block(h, ki, kj, symmetrise, h->dstage[slot]);
+    if (rc) return rc;
+    DMK_HIP(ctx, hipEventRecord(h->ev_consumed[slot], ctx->stream));
+    return DMK_OK;
+}
+
+int dmk_eri_host_slot_wait(dmk_eri *h, int slot) {
+    if (!h) return DMK_ERR_INVALID;
+    if (slot < 0 || slot > 1) return dmk_fail(h->ctx, DMK_ERR_INVALID, "eri_host_slot_wait: bad slot");
+    if (h->copy_stream) DMK_HIP(h->ctx, hipEventSynchronize(h->ev_copied[slot]));
+    return DMK_OK;
+}
+
+int dmk_host_alloc(dmk_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return DMK_ERR_INVALID;
+    *out = nullptr;
+    DMK_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return DMK_OK;
+}
+
+int dmk_host_free(dmk_ctx *ctx, void *p) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (p) DMK_HIP(ctx, hipHostFree(p));
+    return DMK_OK;
+}
+
 int dmk_eri_finish(dmk_eri *h) {
     if (!h) return DMK_OK;
     dmk_ctx *ctx = h->ctx;
     (void)hipStreamSynchronize(ctx->stream);
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(h->dstage[i]);
+            (void)hipEventDestroy(h->ev_copied[i]);
+            (void)hipEventDestroy(h->ev_consumed[i]);
+        }
+        (void)hipStreamDestroy(h->copy_stream);
+    }
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;

@@ -426,16 +426,19 @@ class EmbFitDevice(object):
         # generalised problem: X = S^-1/2 (symmetric), skipped for an orthonormal embedding basis
         self.d_X = None
         if max_abs(ovlp - np.eye(nb)) > 1e-13:
-            X = np.empty_like(ovlp)
+            self.d_X = ctx.empty((spin, nb, nb), np.float64)
             for s in range(spin):
                 d_w = ctx.empty((1, nb), np.float64)
                 d_V = ctx.empty((1, nb, nb), np.float64)
                 d_S = ctx.to_device(ovlp[s])
                 ctx.check(lib.dmk_eigh_batched_real(ctx.h, nb, 1, d_S.ptr, d_w.ptr, d_V.ptr))
-                w, Vt = d_w.get()[0], d_V.get()[0]
+                w = d_w.get()[0]
                 log.eassert(w[0] > 0, "embedding overlap is not positive definite")
-                X[s] = (Vt.T / np.sqrt(w)) @ Vt
-            self.d_X = ctx.to_device(X)
+                d_sc = ctx.to_device(1.0 / np.sqrt(w))
+                d_T = ctx.empty((nb, nb), np.float64)
+                ctx.check(lib.dmk_ewise_mul(ctx.h, 1, nb, nb, d_V.ptr, d_sc.ptr, d_T.ptr))          # rows v_m / sqrt(w_m)
+                ctx.check(lib.dmk_dgemm_batched(ctx.h, 1, 0, nb, nb, nb, 1, 1.0, d_V.ptr, nb, nb * nb, d_T.ptr, nb, nb * nb,
+                                                0.0, self.d_X.offset(s * nb * nb, (nb, nb)).ptr, nb, nb * nb))
         self.d_dV = get_dV_dparam_dev(ctx, vcor, basis)
         # fitted entries: the imp x imp block and the det diagonal of rho[fit_idx, fit_idx] (slater.py:1012-1017)
         self.fit_idx = list(imp_idx) + list(det_idx)

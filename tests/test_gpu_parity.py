@@ -565,6 +565,57 @@ def test_hot_half_transform_planes(ctx, nao, naux, spin):
     eng.close()
 
 
+@pytest.mark.parametrize("nao,naux,nemb,spin", [(40, 24, 256, 2), (10, 7, 12, 1), (24, 16, 40, 2)])
+def test_host_block_feed_matches_device_feed(ctx, nao, naux, nemb, spin):
+    """dmk_eri_push_block_host (two pinned buffers, copy stream overlapped with the transform) against
+    dmk_eri_push_block on device-resident blocks: same kernels in the same order, so the planes and the contracted
+    ERI agree bit for bit; hot (nemb = 256) and generic kernels."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd._lib import lib, PinnedArray
+    mesh, nk = (3, 2, 1), 6
+    npair = nemb * (nemb + 1) // 2
+    rng = np.random.default_rng(nao + nemb)
+    Cemb = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Cemb)
+    blocks = {}
+
+    def block(i, j):
+        if (i, j) not in blocks:
+            blocks[(i, j)] = R.df_block_philox(9, i, j, naux, nao)
+        return blocks[(i, j)]
+    out = []
+    for feed in ("device", "host"):
+        eri_dev = ctx.zeros((spin * (spin + 1) // 2, npair, npair), np.float64)
+        eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+        prov = et.GDFMemory(np.zeros((nk, 3)), block, naux=naux)
+        if feed == "device":
+            prov = type("DevOnly", (), {"load_block": lambda self, c, i, j, o: o.set(block(i, j))})()
+        eng.run(prov)
+        ctx.sync()
+        out.append(eri_dev.get())
+        eng.close()
+    assert np.array_equal(out[0], out[1])
+    assert np.abs(out[0]).max() > 0
+    # raw C ABI: pageable host memory is accepted too (synchronous copy), and a bad slot is an error
+    eri_dev = ctx.zeros((spin * (spin + 1) // 2, npair, npair), np.float64)
+    eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    kL = eng.irreducible_kL()[1]
+    ctx.check(lib.dmk_eri_begin_kL(eng.h, kL))
+    for n, r in enumerate(eng.by_kL[kL]):
+        i, j, sym = int(r[1]), int(r[2]), int(r[4])
+        blk = np.ascontiguousarray(block(i, j))
+        ctx.check(lib.dmk_eri_push_block_host(eng.h, i, j, sym, blk.ctypes.data, n & 1))
+        ctx.check(lib.dmk_eri_host_slot_wait(eng.h, n & 1))
+    assert lib.dmk_eri_push_block_host(eng.h, 0, 0, 0, blk.ctypes.data, 2) != 0
+    ctx.check(lib.dmk_eri_end_kL(eng.h, int(eng.weights[kL])))
+    ctx.sync()
+    eng.close()
+    p = PinnedArray(ctx, (4, 3), np.complex128)
+    p.a[...] = 1 + 2j
+    assert p.a.sum() == 12 * (1 + 2j)
+    p.free()
+
+
 def test_hot_contraction_big(ctx):
     """dgemm_big (LDS-DMA ring, 256 x 128 tiles) on stacked Re/Im planes incl. masked edge tiles."""
     from libdmet_preview_amd._lib import lib

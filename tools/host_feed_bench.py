@@ -1,0 +1,76 @@
+"""
+PCIe-inclusive rate of the ERI transform: C5-shaped AO blocks (800 x 200 x 200 c128 = 512 MB) fed
+ (a) from HBM (Philox regenerated on the device: the bench default),
+ (b) from two pinned host buffers through dmk_eri_push_block_host (copy stream overlapped with the transform; the
+     buffers are pre-filled, i.e. the provider's own read cost is excluded),
+ (c) like (b) but every block is first copied by the CPU from pageable memory into the pinned buffer (what an HDF5
+     reader that cannot read into pinned memory pays).
+One irreducible kL with time-reversal weight 2 (all its blocks + the contraction).  usage: python tools/host_feed_bench.py
+"""
+import json
+import sys
+import time
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+    from libdmet_preview_amd._lib import get_ctx
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    ctx = get_ctx()
+    mesh, nao, naux, nemb, spin = (6, 6, 6), 200, 800, 256, 2
+    nk = 216
+    npair = nemb * (nemb + 1) // 2
+    rng = np.random.default_rng(1)
+    C_dev = ctx.to_device((rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb)))
+                          * nk ** -0.75 / np.sqrt(nao))
+    eri_dev = ctx.zeros((3, npair, npair), np.float64)
+    eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    kL = [k for k in eng.irreducible_kL() if eng.weights[k] == 2][0]
+    nblk = len(eng.by_kL[kL])
+    block_bytes = naux * nao * nao * 16
+    pageable = (rng.standard_normal((naux, nao, nao)) + 1j * rng.standard_normal((naux, nao, nao))) / np.sqrt(nao)
+
+    class Dev(object):
+        def __init__(self):
+            self.p = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=3)
+
+        def load_block(self, c, i, j, o):
+            self.p.load_block(c, i, j, o)
+
+    class HostPrefilled(object):
+        def load_block_host(self, i, j, out):
+            pass
+
+    class HostMemcpy(object):
+        def load_block_host(self, i, j, out):
+            np.copyto(out, pageable)
+
+    res = {}
+    for name, prov in (("device_philox", Dev()), ("host_pinned_prefilled", HostPrefilled()), ("host_cpu_fill", HostMemcpy())):
+        if name != "device_philox" and eng.host_buf is not None:
+            for b in eng.host_buf:
+                b.a[...] = pageable
+        for rep in range(2):                       # first pass warms up (allocations, pinned buffers)
+            if name != "device_philox" and eng.host_buf is None:
+                eng.run_kL(kL, prov, max_blocks=2)
+                for b in eng.host_buf:
+                    b.a[...] = pageable
+            f0 = eng.flops()
+            ctx.sync()
+            t0 = time.perf_counter()
+            n = eng.run_kL(kL, prov)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            f1 = eng.flops()
+        fl = (f1[0] - f0[0]) + (f1[1] - f0[1])
+        res[name] = {"blocks": n, "seconds": round(dt, 4), "ms_per_block": round(1e3 * dt / n, 3),
+                     "tflops": round(fl / dt / 1e12, 2),
+                     "host_GBps": None if name == "device_philox" else round(n * block_bytes / dt / 1e9, 1)}
+    eng.close()
+    print(json.dumps({"workload": "C5 blocks, one kL (w=2), %d blocks of %.0f MB" % (nblk, block_bytes / 1e6), "results": res}))
+
+
+if __name__ == "__main__":
+    main()
