@@ -347,8 +347,14 @@ def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7):
     spin, ncells, nlo, nb = basis.shape
     npair = nb * (nb + 1) // 2
     nparam = vcor.length()
-    g = np.asarray(vcor.gradient())[:, :spin]                       # (nparam, spin, nlo, nlo)
-    nz = np.nonzero(np.abs(g) > thr)                                 # entries in (param, spin, row, col) order
+    if hasattr(vcor, "grad_entries"):                                # sparse description, same order as np.nonzero below
+        gp, gb, gi, gj, gv = vcor.grad_entries()
+        keep = (gb < spin) & (np.abs(gv) > thr)
+        nz, vals = (gp[keep], gb[keep], gi[keep], gj[keep]), gv[keep]
+    else:
+        g = np.asarray(vcor.gradient())[:, :spin]                   # (nparam, spin, nlo, nlo)
+        nz = np.nonzero(np.abs(g) > thr)                             # entries in (param, spin, row, col) order
+        vals = g[nz]
     used = np.unique(np.concatenate([nz[2], nz[3]])) if len(nz[0]) else np.zeros(0, dtype=int)
     pos = -np.ones(nlo, dtype=np.int64)
     pos[used] = np.arange(len(used))
@@ -358,7 +364,7 @@ def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7):
     m = len(used) * nb
     for s in range(spin):
         sel = nz[1] == s
-        ip, zi, zj, zv = nz[0][sel], pos[nz[2][sel]], pos[nz[3][sel]], g[nz][sel]
+        ip, zi, zj, zv = nz[0][sel], pos[nz[2][sel]], pos[nz[3][sel]], vals[sel]
         if len(ip) == 0:
             continue
         ents = np.unique(ip)                                          # parameters with entries in this spin block
