@@ -55,6 +55,9 @@ _FUNCTIONS = [
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
     ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis"]),
     ("dmet.HubPhSymm", ["dmet.HubPhSymm"], ["basisMatching"]),
+    # Loewdin orthogonalisation (routine/slater.py imports lo.lowdin's vec_lowdin by name)
+    ("lo.lowdin", ["lo.lowdin"], ["_lowdin", "_vec_lowdin", "vec_lowdin", "vec_lowdin_k"]),
+    ("lo.lowdin", ["routine.slater"], ["vec_lowdin"]),
 ]
 # methods of the reference's Lattice replaced by ours (they only touch duck-typed attributes; system/lattice.py:416-673)
 _LATTICE_METHODS = ["set_Ham", "setHam", "set_Ham_model", "setHam_model", "update_Ham", "transform_obj_to_lo"]

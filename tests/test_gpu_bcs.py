@@ -70,6 +70,22 @@ def test_bdg_ghf(ctx, golden, name):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_mfd_mpi_ghf_symm(ctx, golden, name):
+    """routine/mfd_mpi.py twin: irreducible k points from the integer tables, reference call signature
+    (cell, GFock, vcor_mat, mu, kpairs, kidx); single rank here, the sharded sum is covered by the gloo test."""
+    from libdmet_preview_amd.routine import mfd_mpi
+    g = golden("G7_bcs.npz")
+    mesh, FR, Fk, v, mu, val = _case(g, name)
+    GFk = R.FFTtoK(g[name + "/GFock_R"], mesh)
+    ks = R.make_kpts_scaled(mesh)
+    cell = type("Cell", (), {"get_scaled_kpts": staticmethod(lambda k: np.asarray(k))})()
+    kpairs, kidx = mfd_mpi.get_kpairs_kidx(cell, ks)
+    ew, ev = mfd_mpi.DiagGHF_symm(cell, GFk, np.asarray(v), mu, kpairs, kidx)
+    assert np.abs(ew - g[name + "/ghf_symm_ew"]).max() < 1e-10
+    assert np.abs(_occ_proj(ew, ev) - g[name + "/ghf_symm_rho_k"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_bcs_emb_basis(ctx, golden, name):
     from libdmet_preview_amd.routine import bcs
     g = golden("G7_bcs.npz")

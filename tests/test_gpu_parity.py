@@ -505,6 +505,40 @@ def test_G4_bath_golden(ctx, golden):
         slater.get_emb_basis(Lg, rho, kind="nope")
 
 
+def test_lowdin_module(ctx):
+    """lo/lowdin.py twins (_lowdin, _vec_lowdin, vec_lowdin) against the oracle restatement of lowdin.py:83-134."""
+    from libdmet_preview_amd.lo import lowdin
+    rng = np.random.default_rng(21)
+    n, m, nk = 9, 5, 4
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    S1 = A @ A.conj().T + n * np.eye(n)
+    assert np.abs(lowdin._lowdin(S1) - R._lowdin(S1)).max() < 1e-12
+    Sr = S1.real
+    assert lowdin._lowdin(Sr).dtype == np.float64 and np.abs(lowdin._lowdin(Sr) - R._lowdin(Sr)).max() < 1e-12
+    # rank-deficient metric: the near-null direction is dropped (tol), like the reference
+    v = rng.standard_normal((n, 3))
+    assert np.abs(lowdin._lowdin(v @ v.T, tol=1e-10) - R._lowdin(v @ v.T, tol=1e-10)).max() < 1e-10
+    c = rng.standard_normal((n, m)) + 1j * rng.standard_normal((n, m))
+    assert np.abs(lowdin._vec_lowdin(c, S1) - R.vec_lowdin(c, S1)).max() < 1e-12
+    assert np.abs(lowdin._vec_lowdin(c.real) - R.vec_lowdin(c.real)).max() < 1e-12
+    f = rng.uniform(0.5, 1.5, m)
+    ref = (c * f) @ R._lowdin(c.conj().T @ S1 @ c)
+    assert np.abs(lowdin._vec_lowdin(c, S1, f) - ref).max() < 1e-12
+    # (spin, k) batches
+    Sk = np.array([S1 + k * np.eye(n) for k in range(nk)])
+    Ck = rng.standard_normal((2, nk, n, m)) + 1j * rng.standard_normal((2, nk, n, m))
+    out = lowdin.vec_lowdin(Ck, Sk)
+    for s in range(2):
+        for k in range(nk):
+            assert np.abs(out[s, k] - R.vec_lowdin(Ck[s, k], Sk[k])).max() < 1e-12
+            assert np.abs(out[s, k].conj().T @ Sk[k] @ out[s, k] - np.eye(m)).max() < 1e-12
+    assert np.abs(lowdin.vec_lowdin(Ck[0], Sk) - out[0]).max() < 1e-14
+    out2 = lowdin.vec_lowdin_k(Ck[:, 0], S1)
+    assert np.abs(out2[1] - R.vec_lowdin(Ck[1, 0], S1)).max() < 1e-12
+    with pytest.raises(NotImplementedError):
+        lowdin.vec_lowdin(Ck, Sk, f=np.ones((2, nk, m)))
+
+
 def test_bath_c5_shape_vs_oracle(ctx):
     """Config-C5 bath shape: stripe (216, 200, 200), 56 valence orbitals -> A = 43144 x 56 per spin."""
     from libdmet_preview_amd.routine import slater

@@ -52,11 +52,22 @@ def test_kmesh_tables_bit_exact(golden, tag):
     assert np.array_equal(minus_k, g[tag + "/neg"])
     assert np.array_equal(w, g[tag + "/weights"])
     assert np.array_equal(fourier.round_to_FBZ(g[tag + "/kpts_scaled"] + 0.5, tol=1e-10), g[tag + "/round_to_FBZ"])
+    from libdmet_preview_amd.basis_transform import eri_transform_mpi as etm
+    from libdmet_preview_amd.routine import mfd_mpi
     for n in (1, 2, 3, 4, 8):
         kids = et.assign_workload(mesh, n)
         ref = g[tag + "/workload_n%d" % n]
+        kids_ref_sig = etm.assign_workload(w, n)                  # reference signature (weights, n): same partition
         for r in range(n):
             assert kids[r] == [int(x) for x in ref[r] if x >= 0]
+            assert [int(x) for x in kids_ref_sig[r]] == kids[r]
+        segs = [mfd_mpi._task_location(nk, r, n) for r in range(n)]
+        assert segs[0][0] == 0 and segs[-1][1] == nk and all(segs[r][1] == segs[r + 1][0] for r in range(n - 1))
+        assert max(b - a for a, b in segs) - min(b - a for a, b in segs) <= 1
+    cell = type("Cell", (), {"get_scaled_kpts": staticmethod(lambda k: np.asarray(k))})()
+    kpairs, kidx = mfd_mpi.get_kpairs_kidx(cell, g[tag + "/kpts_scaled"])
+    assert np.array_equal(np.array([p + (-1,) * (2 - len(p)) for p in kpairs]), g[tag + "/kpairs"])
+    assert np.array_equal(kidx, g[tag + "/kidx"])
     if nk <= 64:
         L = lattice.Lattice(1, mesh)
         add = np.array([[L.add(i, j) for j in range(nk)] for i in range(nk)])
