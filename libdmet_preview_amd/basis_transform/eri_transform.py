@@ -240,6 +240,111 @@ def _is_provider(mydf):
 # small helpers with reference names
 # ---------------------------------------------------------------------------------------------
 
+def _as_cderi_provider(gdf):
+    if isinstance(gdf, CderiProvider) or hasattr(gdf, "get_block"):
+        return gdf
+    cderi = getattr(gdf, "_cderi", None)
+    if cderi is None or isinstance(cderi, str):
+        raise NotImplementedError("HDF5 cderi files need h5py: pass a CderiProvider over the opened file / a mapping")
+    return CderiProvider(cderi, gdf.kpts, gdf.cell.nao_nr(), cell=gdf.cell)
+
+
+def get_naoaux(gdf):
+    """The maximum dimension of the auxiliary basis over the stored k-point pairs (eri_transform.py:159-193)."""
+    prov = _as_cderi_provider(gdf)
+    if isinstance(prov, CderiProvider):
+        rows = [prov._pair_rows(p) for p in range(len(prov.kptij))]
+        if len(np.unique(rows)) != 1:
+            log.warn("aux basis drop may happened.")
+        return int(max(rows))
+    return int(prov.naux)
+
+
+def sr_loop(gdf, kpti_kptj=np.zeros((2, 3)), max_memory=2000, compact=True, blksize=None):
+    """Yield the DF block of one k-point pair in auxiliary slices, (nslice, nao*nao) c128 -- lower-triangular packed
+    (nslice, nao*(nao+1)/2) when kpti == kptj and compact (eri_transform.py:195-227)."""
+    prov = _as_cderi_provider(gdf)
+    kpts = np.asarray(prov.kpts)
+    kpti, kptj = np.asarray(kpti_kptj)
+    find = lambda k: int(np.where(np.abs(kpts - k[None]).max(axis=1) < KPT_DIFF_TOL)[0][0])
+    i, j = find(kpti), find(kptj)
+    L = np.asarray(prov.get_block(i, j))
+    nao = L.shape[-1]
+    L = L.reshape(L.shape[0], nao, nao)
+    same = np.abs(kpti - kptj).max() < KPT_DIFF_TOL
+    if blksize is None:
+        is_real = same and np.abs(kpti).max() < KPT_DIFF_TOL
+        blksize = max_memory * 1e6 / (8 if is_real else 16) / (nao ** 2 * 2) / 2
+        blksize = max(16, min(int(blksize), int(getattr(gdf, "blockdim", 240))))
+    for b0 in range(0, L.shape[0], int(blksize)):
+        blk = L[b0:b0 + int(blksize)]
+        if same and compact:
+            yield np.ascontiguousarray(_pack_tril_last2(blk), dtype=np.complex128)
+        else:
+            yield np.ascontiguousarray(blk.reshape(blk.shape[0], nao * nao), dtype=np.complex128)
+
+
+def transform_ao_to_emb(Lpq, basis, kp, kq, Lpq_beta=None):
+    """(L|ab) = sum_pq conj(C_kp[p,a]) Lpq[L,p,q] C_kq[q,b] for every spin: Lpq (nL, nao*nao), basis = C_ao_emb
+    (spin, nk, nao, nemb) -> (spin, nL, nemb*nemb) c128 (eri_transform.py:403-434, PySCF _ao2mo.r_e2); two batched
+    complex MFMA GEMMs per spin with the coefficient matrices shared by all L (stride 0)."""
+    basis = np.asarray(basis)
+    if basis.ndim == 3:
+        basis = basis[np.newaxis]
+    spin, _, nao, nemb = basis.shape
+    Ls = [Lpq] * spin if Lpq_beta is None else [Lpq, Lpq_beta]
+    nL = np.asarray(Ls[0]).shape[0]
+    ctx = get_ctx()
+    out = np.empty((spin, nL, nemb * nemb), dtype=np.complex128)
+    d_L = None
+    for s in range(spin):
+        if d_L is None or Lpq_beta is not None:
+            d_L = ctx.to_device(np.asarray(Ls[s]).reshape(nL, nao, nao), np.complex128)
+        d_Ci = ctx.to_device(basis[s, kp], np.complex128)
+        d_Cj = ctx.to_device(basis[s, kq], np.complex128)
+        d_T = bgemm_dev(ctx, "C", "N", nemb, nao, nao, nL, d_Ci, 0, d_L, nao * nao)            # C_i^H L
+        out[s] = bgemm_dev(ctx, "N", "N", nemb, nemb, nao, nL, d_T, nemb * nao, d_Cj, 0).get().reshape(nL, nemb * nemb)
+    return out
+
+
+def _Lij_s4_to_eri(Lij_s4, eri, weight=1, t_reversal_symm=False):
+    """Contract (L|ij) to (ij|kl) and accumulate it into `eri` in place (eri_transform.py:436-521): with time reversal
+    eri += w (Re^T Re [+ Im^T Im for w = 2]) over the spin blocks (aa, ab, bb) -- (aa, bb, ab) for the out-of-core
+    {"ccdd": array} form --, without it eri += L^H L (complex).  Real f64 MFMA GEMMs on the Re / Im planes."""
+    Lij_s4 = np.asarray(Lij_s4)
+    if Lij_s4.ndim == 2:
+        Lij_s4 = Lij_s4[np.newaxis]
+    spin, nL, npair = Lij_s4.shape
+    if t_reversal_symm and weight not in (1, 2):
+        raise ValueError
+    outcore = not isinstance(eri, np.ndarray)
+    if outcore:
+        assert t_reversal_symm
+    target = eri["ccdd"] if outcore else eri
+    ctx = get_ctx()
+    d_re = [ctx.to_device(np.ascontiguousarray(Lij_s4[s].real)) for s in range(spin)]
+    need_im = (not t_reversal_symm) or weight == 2
+    d_im = [ctx.to_device(np.ascontiguousarray(Lij_s4[s].imag)) for s in range(spin)] if need_im else None
+    blocks = [(0, 0, 0)] if spin == 1 else ([(0, 0, 0), (1, 1, 1), (2, 0, 1)] if outcore else [(0, 0, 0), (1, 0, 1), (2, 1, 1)])
+
+    def tn(alpha, dX, dY, dC):
+        ctx.check(lib.dmk_dgemm_tn_acc_rect(ctx.h, npair, npair, nL, float(alpha), dX.ptr, npair, dY.ptr, npair, dC.ptr, npair))
+    for slot, a, b in blocks:
+        d_C = ctx.zeros((npair, npair), np.float64)
+        if t_reversal_symm:
+            tn(weight, d_re[a], d_re[b], d_C)
+            if weight == 2:
+                tn(2.0, d_im[a], d_im[b], d_C)
+            target[slot] += d_C.get()
+        else:
+            tn(1.0, d_re[a], d_re[b], d_C)
+            tn(1.0, d_im[a], d_im[b], d_C)
+            d_I = ctx.zeros((npair, npair), np.float64)
+            tn(1.0, d_re[a], d_im[b], d_I)
+            tn(-1.0, d_im[a], d_re[b], d_I)
+            target[slot] += d_C.get() + 1j * d_I.get()
+    return eri
+
 def get_basis_k(basis, phase_R2k):
     """basis_k[s, k] = sum_R basis[s, R] phase[R, k] (eri_transform.py:118-126: einsum 'Rim,Rk->kim'),
     as one complex MFMA GEMM per spin with the caller's phase table."""

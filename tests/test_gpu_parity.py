@@ -650,6 +650,69 @@ def test_host_block_feed_matches_device_feed(ctx, nao, naux, nemb, spin):
     p.free()
 
 
+@pytest.mark.parametrize("spin", [1, 2])
+def test_reference_named_eri_pieces(ctx, spin):
+    """transform_ao_to_emb / _Lij_s4_to_eri / sr_loop / get_naoaux with the reference's numpy signatures
+    (eri_transform.py:159-227, 403-521) against the oracle restatement."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    rng = np.random.default_rng(40 + spin)
+    nk, nao, nemb, nL = 3, 7, 5, 11
+    npair = nemb * (nemb + 1) // 2
+    Cemb = rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))
+    Lpq = rng.standard_normal((nL, nao * nao)) + 1j * rng.standard_normal((nL, nao * nao))
+    got = et.transform_ao_to_emb(Lpq, Cemb, 2, 1)
+    ref = R.transform_ao_to_emb(Lpq, Cemb, 2, 1).reshape(spin, nL, nemb * nemb)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+    if spin == 2:
+        Lb = rng.standard_normal((nL, nao * nao)) + 1j * rng.standard_normal((nL, nao * nao))
+        got = et.transform_ao_to_emb(Lpq, Cemb, 0, 1, Lpq_beta=Lb)
+        refb = R.transform_ao_to_emb(Lb, Cemb, 0, 1).reshape(spin, nL, -1)
+        refa = R.transform_ao_to_emb(Lpq, Cemb, 0, 1).reshape(spin, nL, -1)
+        assert np.abs(got[0] - refa[0]).max() < 1e-11 and np.abs(got[1] - refb[1]).max() < 1e-11
+    assert np.abs(et.transform_ao_to_emb(Lpq, Cemb[0], 1, 1)[0] - R.transform_ao_to_emb(Lpq, Cemb[:1], 1, 1)[0].reshape(nL, -1)).max() < 1e-11
+    Lij = rng.standard_normal((spin, nL, npair)) + 1j * rng.standard_normal((spin, nL, npair))
+    nb = spin * (spin + 1) // 2
+    for w, tr in ((1, True), (2, True), (1, False)):
+        e0 = rng.standard_normal((nb, npair, npair)).astype(np.float64 if tr else np.complex128)
+        e_ref, e_got = e0.copy(), e0.copy()
+        R.Lij_s4_to_eri(Lij, e_ref, w, tr)
+        et._Lij_s4_to_eri(Lij if spin == 2 else Lij[0], e_got, w, tr)
+        assert np.abs(e_got - e_ref).max() < 1e-11 * np.abs(e_ref).max(), (w, tr)
+    # out-of-core form: {"ccdd": array} in (aa, bb, ab) order
+    h = {"ccdd": np.zeros((nb, npair, npair))}
+    et._Lij_s4_to_eri(Lij, h, 2, True)
+    e_ref = np.zeros((nb, npair, npair))
+    R.Lij_s4_to_eri(Lij, e_ref, 2, True)
+    order = [0] if spin == 1 else [0, 2, 1]
+    assert np.abs(h["ccdd"] - e_ref[order]).max() < 1e-11 * np.abs(e_ref).max()
+    with pytest.raises(ValueError):
+        et._Lij_s4_to_eri(Lij, e_ref, 3, True)
+    # cderi readers
+    kpts = np.array([[0.0, 0, 0], [0.5, 0, 0]])
+    naux = 6
+    L00 = rng.standard_normal((naux, nao, nao))
+    L00 = L00 + L00.transpose(0, 2, 1)
+    L10 = rng.standard_normal((naux - 1, nao, nao)) + 1j * rng.standard_normal((naux - 1, nao, nao))
+    L11 = rng.standard_normal((naux, nao, nao)) + 1j * rng.standard_normal((naux, nao, nao))
+    L11 = L11 + L11.conj().transpose(0, 2, 1)
+    il = np.tril_indices(nao)
+    feri = {"j3c-kptij": np.array([[kpts[0], kpts[0]], [kpts[1], kpts[0]], [kpts[1], kpts[1]]]),
+            "j3c/0/0": L00[:, il[0], il[1]], "j3c/1/0": L10[:4].reshape(4, -1), "j3c/1/1": L10[4:].reshape(naux - 5, -1),
+            "j3c/2/0": L11[:, il[0], il[1]]}
+    cell = type("Cell", (), {"nao_nr": lambda self: nao})()
+    gdf = type("GDF", (), {})()
+    gdf._cderi, gdf.kpts, gdf.cell, gdf.blockdim = feri, kpts, cell, 4
+    assert et.get_naoaux(gdf) == naux
+    got = np.concatenate(list(et.sr_loop(gdf, kpts[[1, 0]], compact=False, blksize=2)))
+    assert np.abs(got[:naux - 1] - L10.reshape(naux - 1, -1)).max() == 0 and np.abs(got[naux - 1:]).max() == 0
+    got = np.concatenate(list(et.sr_loop(gdf, kpts[[0, 1]], compact=False)))            # swapped pair: conjugate transpose
+    assert np.abs(got[:naux - 1] - L10.conj().transpose(0, 2, 1).reshape(naux - 1, -1)).max() == 0
+    got = np.concatenate(list(et.sr_loop(gdf, kpts[[1, 1]], compact=True)))
+    assert got.shape == (naux, nao * (nao + 1) // 2) and np.abs(got - L11[:, il[0], il[1]]).max() == 0
+    got = np.concatenate(list(et.sr_loop(gdf, kpts[[0, 0]], compact=False)))
+    assert np.abs(got - L00.reshape(naux, -1)).max() == 0
+
+
 def test_hot_contraction_big(ctx):
     """dgemm_big (LDS-DMA ring, 256 x 128 tiles) on stacked Re/Im planes incl. masked edge tiles."""
     from libdmet_preview_amd._lib import lib
