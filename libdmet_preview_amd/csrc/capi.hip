@@ -686,17 +686,15 @@ static int eri_flush(dmk_eri *h) {
     if (h->pending == 0) return DMK_OK;
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const size_t slot_elems = (size_t)naux * nao * nemb;
-    for (int s = 0; s < h->spin; ++s) {
-        const void *cj[16];
-        for (int i = 0; i < h->pending; ++i)
-            cj[i] = h->C + ((size_t)s * h->mesh.nk + h->pend_kj[i]) * nao * nemb;
-        double *planes = h->planes + (size_t)s * 2 * naux * h->npair;
-        const double2 *ut = h->Ut + (size_t)s * h->group * slot_elems;
-        int rc = launch_half2_hot(ctx, ut, (long long)slot_elems, h->pending, cj, h->pend_sym, planes, naux, h->npair,
-                                  naux, nao, nemb);
-        if (rc < 0) return rc;
-        if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_flush: hot step-2 kernel unavailable for a queued block");
-    }
+    // one launch for both spin channels: C, Ut and the planes of spin 1 sit at constant offsets from those of spin 0
+    const void *cj[16];
+    for (int i = 0; i < h->pending; ++i)
+        cj[i] = h->C + (size_t)h->pend_kj[i] * nao * nemb;
+    int rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->planes, naux, h->npair, naux,
+                              nao, nemb, h->spin, (long long)h->group * (long long)slot_elems,
+                              (long long)h->mesh.nk * nao * nemb, 2LL * naux * h->npair);
+    if (rc < 0) return rc;
+    if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_flush: hot step-2 kernel unavailable for a queued block");
     h->pending = 0;
     return DMK_OK;
 }

@@ -163,6 +163,7 @@ int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, in
 int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
                       int nL, int nao, int nemb, int sym);
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
-                     const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb);
+                     const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);
 int half2_hot_usable(int nao, int nemb);
 int half2_hot_maxslot();

@@ -245,6 +245,12 @@ struct H2Args {
     long long naux, npair;
     int nL, nao, nslot;
     unsigned nblocks;
+    // both spin channels in ONE launch (4 nL nspin workgroups): one ramp-up / drain per group of queued blocks instead
+    // of one per spin (measured at C5: 2 x 8.19 ms -> 15.75 ms).  Cutting the last rounds of workgroups into shorter
+    // ones (slot ranges accumulated through partial buffers) was tried on top and measured slower: the launch is
+    // throughput-bound in steady state, the extra epilogues cost more than the shorter drain saves.
+    int nspin;
+    long long ut_spin_stride, cj_spin_stride, planes_spin_stride;   // elements between the spin channels
 };
 
 // Kernel-argument arrays must only be indexed with compile-time constants, and the argument struct must
@@ -278,12 +284,15 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frag_k = lane >> 4, frag_x = lane & 15;
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
-    const int L = (int)(lid >> 2), type = (int)(lid & 3);
+    const int Lall = (int)(lid >> 2), type = (int)(lid & 3);
+    const int sp = Lall >= g.nL ? 1 : 0;     // nspin <= 2
+    const int L = Lall - sp * g.nL;
     const long long nemb = H2_N;
     const int Tb = g.nao / H2_BK;            // K-tiles per AO block
     const int T = Tb * g.nslot;              // the ring runs straight through all queued blocks
-    const double2 *Ubase = g.Ut + (long long)L * g.nao * nemb;
-    double *const g_planes = g.planes;
+    const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb;
+    double *const g_planes = g.planes + (long long)sp * g.planes_spin_stride;
+    const long long cj_off = (long long)sp * g.cj_spin_stride;
     const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
     const unsigned g_symmask = g.symmask;
 
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             double2 *st = lds + (tt % H2T_D) * H2T_STAGE;
             const long long k0 = (long long)t * H2_BK * nemb;
             const double2 *ub = Ubase + (long long)slot * g_slot_stride + k0;
-            const double2 *cb = H2_PICK_CJ(g, slot) + k0;
+            const double2 *cb = H2_PICK_CJ(g, slot) + cj_off + k0;
             glds16(ub + soff[0], lds_addr_of(st + (wave) * 64));            // pieces 0-3: U
             glds16(ub + soff[1], lds_addr_of(st + (wave + 4) * 64));        // pieces 4-7: U
             glds16(cb + soff[2], lds_addr_of(st + (wave + 8) * 64));        // pieces 8-11: C
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         double2 *st = lds + (tt % H2S_D) * H2S_STAGE;
         const long long k0 = (long long)t * H2_BK * nemb;
         const double2 *ub = Ubase + (long long)slot * g_slot_stride + k0;
-        const double2 *cb = H2_PICK_CJ(g, slot) + k0;
+        const double2 *cb = H2_PICK_CJ(g, slot) + cj_off + k0;
 #pragma unroll
         for (int h = 0; h < 6; ++h)
             glds16((isC[h] ? cb : ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
@@ -533,8 +542,10 @@ int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, dou
 }
 
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
-                     const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb) {
-    if (!hot_enabled() || nemb != H2_N || (nao % H2_BK) != 0 || nao < 3 * H2_BK || nslot < 1 || nslot > H2_MAXSLOT)
+                     const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
+    if (!hot_enabled() || nemb != H2_N || (nao % H2_BK) != 0 || nao < 3 * H2_BK || nslot < 1 || nslot > H2_MAXSLOT ||
+        nspin < 1 || nspin > 2)
         return 0;
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
     H2Args a;
@@ -548,7 +559,9 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.slot_stride = slot_stride;
     a.planes = planes; a.naux = naux; a.npair = npair;
     a.nL = nL; a.nao = nao; a.nslot = nslot;
-    a.nblocks = (unsigned)(4 * nL);
+    a.nspin = nspin;
+    a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
+    a.nblocks = (unsigned)(4 * nL * nspin);
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);

@@ -568,7 +568,7 @@ def test_bath_c5_shape_vs_oracle(ctx):
 # hot kernels (zhot.hip, dgemm_big): production tile shapes, nemb = 256
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("nao,naux,spin", [(40, 24, 1), (200, 8, 2), (104, 19, 1)])
+@pytest.mark.parametrize("nao,naux,spin", [(40, 24, 1), (200, 8, 2), (104, 19, 1), (16, 160, 1), (24, 80, 2), (16, 130, 2)])
 def test_hot_half_transform_planes(ctx, nao, naux, spin):
     """nemb = 256 triggers the LDS-DMA ring kernels; checked block-by-block against the oracle's r_e2 restatement,
     with and without the time-reversal partner term, accumulating over two pushes."""
@@ -583,7 +583,12 @@ def test_hot_half_transform_planes(ctx, nao, naux, spin):
     eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
     ctx.check(lib.dmk_eri_begin_kL(eng.h, 1))
     ref = np.zeros((spin, naux, npair), dtype=np.complex128)
-    for (i, j, sym) in [(1, 0, 1), (3, 2, 0), (0, 1, 1)]:
+    # naux >= 80: more work items than resident workgroups -> the tail of the step-2 launch is cut into slot ranges
+    # accumulated through the partial buffers; 11 pushes = one full group of 8 queued blocks + a group of 3
+    pushes = [(1, 0, 1), (3, 2, 0), (0, 1, 1)]
+    if naux >= 80:
+        pushes = pushes + [(2, 3, 1), (0, 0, 0), (1, 1, 1), (2, 0, 0), (3, 1, 1), (0, 2, 1), (1, 3, 0), (2, 2, 1)]
+    for (i, j, sym) in pushes:
         blk = R.df_block_philox(5, i, j, naux, nao)
         d_blk = ctx.to_device(blk)
         ctx.check(lib.dmk_eri_push_block(eng.h, i, j, sym, d_blk.ptr))

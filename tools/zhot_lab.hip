@@ -23,7 +23,7 @@ int main() {
         for (int rep = 0; rep < 4; ++rep) {
             CK(hipEventRecord(e0));
             if (which == 1) launch_half1_hot(&ctx, Lpq, C, Ut, naux, nao, nemb);
-            else { const void *cj[1] = {C}; int sy[1] = {1}; launch_half2_hot(&ctx, Ut, 0, 1, cj, sy, planes, naux, npair, naux, nao, nemb); }
+            else { const void *cj[1] = {C}; int sy[1] = {1}; launch_half2_hot(&ctx, Ut, 0, 1, cj, sy, planes, naux, npair, naux, nao, nemb, 1, 0, 0, 0); }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (rep && ms < best) best = ms;
