@@ -711,12 +711,15 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
     if (h->group > 1) {
         // hot path: step 1 now (it consumes the caller's block buffer), step 2 when the queue is full
         const int slot = h->pending;
-        for (int s = 0; s < h->spin; ++s) {
+        // both spin channels in one launch (they share the AO block); per-spin generic kernels only if it declines
+        int rc_hot = launch_half1_hot(ctx, L, h->C + (size_t)ki * nao * nemb, h->Ut + (size_t)slot * slot_elems, naux, nao, nemb,
+                                      h->spin, (long long)h->mesh.nk * nao * nemb, (long long)h->group * (long long)slot_elems);
+        if (rc_hot < 0) return rc_hot;
+        for (int s = 0; s < h->spin && rc_hot == 0; ++s) {
             const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
             double2 *ut = h->Ut + ((size_t)s * h->group + slot) * slot_elems;
-            int rc = launch_half1_hot(ctx, L, Ci, ut, naux, nao, nemb);
-            if (rc < 0) return rc;
-            if (rc == 0) {
+            int rc = 0;
+            {
                 ZGemm g1;
                 g1.M = nao; g1.N = nemb; g1.K = nao; g1.batch = naux; g1.nseg = 1;
                 g1.seg[0].A = L; g1.seg[0].lda = nao; g1.seg[0].strideA = (int64_t)nao * nao;

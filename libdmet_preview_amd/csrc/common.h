@@ -158,7 +158,8 @@ int launch_zgemm(dmk_ctx *ctx, const ZGemm &g, int fam);
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
 
 // hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
-int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb);
+int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin = 1,
+                     long long ci_spin_stride = 0, long long ut_spin_stride = 0);
 // step 2 for a general nemb: flattened hot kernel into P (nL x nemb x nemb c128) + deterministic fold/pack into the planes
 int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
                       int nL, int nao, int nemb, int sym);

@@ -118,6 +118,10 @@ struct H1Args {
     int mrows;
     int tiles_m, tiles_n;
     unsigned nblocks;
+    // both spin channels in one launch: the same A tile (AO block) against C_i of spin 0 / spin 1 into their own Ut;
+    // the workgroups of one M tile are adjacent (n tile fastest, then spin), so they share the A tile in L2
+    int nspin;
+    long long b_spin_stride, out_spin_stride;
 };
 
 template <bool CONJB>
@@ -128,9 +132,14 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
-    const int tile_m = (int)(lid / (unsigned)g.tiles_n), tile_n = (int)(lid % (unsigned)g.tiles_n);
+    const unsigned per_m = (unsigned)(g.tiles_n * g.nspin);
+    const int tile_m = (int)(lid / per_m);
+    const unsigned rest = lid - (unsigned)tile_m * per_m;
+    const int sp = (int)(rest / (unsigned)g.tiles_n), tile_n = (int)(rest - (unsigned)sp * (unsigned)g.tiles_n);
     const int n0 = tile_n * H1_BN;
     const long long nao = g.nao, nemb = g.nemb, mrows = g.mrows;
+    const double2 *const Bsp = g.Ci + (long long)sp * g.b_spin_stride;
+    double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride;
 
     // ---- per-lane LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB) ----
     const double2 *srcA[2], *srcB;
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     {
         int col = n0 + lane;
         if (col >= g.nemb) col = g.nemb - 1;
-        srcB = g.Ci + col;
+        srcB = Bsp + col;
     }
     auto issue = [&](int t) {
         double2 *st = lds + (t % H1_D) * H1_STAGE;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) s += cacc_re(acc[i][j], 0) + cacc_im(acc[i][j], 1) + cacc_re(acc[i][j], 2) + cacc_im(acc[i][j], 3);
-        if (s == 12345.678) g.Ut[tid].x = s;
+        if (s == 12345.678) Osp[tid].x = s;
         return;
     }
 #pragma unroll
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         for (int r = 0; r < 4; ++r) {
             const int q = qb + frag_k + 4 * r;
             if (q >= g.mrows) continue;
-            double2 *row = g.Ut + ((long long)L * mrows + q) * nemb;
+            double2 *row = Osp + ((long long)L * mrows + q) * nemb;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = n0 + wn * 32 + j * 16 + frag_x;
@@ -461,7 +470,7 @@ bool hot_enabled() {
 
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
 static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out, int nL, int K, int mrows, int N, bool conjB,
-                           int fam) {
+                           int fam, int nspin = 1, long long b_spin_stride = 0, long long out_spin_stride = 0) {
     if (!hot_enabled() || (K % H1_BK) != 0 || K < 2 * H1_BK || N < 32 || (long long)nL * mrows < 4 * H1_BM) return 0;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) return 0;
     H1Args a;
@@ -473,7 +482,8 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     const long long total_blk = (long long)nL * a.nblk;
     a.tiles_m = (int)((total_blk + H1_BM / 16 - 1) / (H1_BM / 16));
     a.tiles_n = (N + H1_BN - 1) / H1_BN;
-    a.nblocks = (unsigned)(a.tiles_m * a.tiles_n);
+    a.nspin = nspin; a.b_spin_stride = b_spin_stride; a.out_spin_stride = out_spin_stride;
+    a.nblocks = (unsigned)(a.tiles_m * a.tiles_n * nspin);
     FamScope fs(ctx, fam);
     if (conjB) hipLaunchKernelGGL(half1_kernel<true>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL(half1_kernel<false>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
@@ -481,8 +491,10 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     return 1;
 }
 
-int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb) {
-    return launch_flat_hot(ctx, Lpq, Ci, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1);
+int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin,
+                     long long ci_spin_stride, long long ut_spin_stride) {
+    if (nspin < 1 || nspin > 2) return 0;
+    return launch_flat_hot(ctx, Lpq, Ci, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1, nspin, ci_spin_stride, ut_spin_stride);
 }
 
 // Step 2 for a general embedding dimension: P[L][a][b] = sum_q Ut[L][q][a] C_j[q][b] with the flattened kernel above
