@@ -221,6 +221,15 @@ int dmk_eri_begin_kL(dmk_eri *h, int kL);
  * accumulate its tril-packed (L|ab) into the current kL's Lij_s4;
  * symmetrise != 0 adds the transposed term of the time-reversal partner pair. */
 int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq);
+/* Block ring: `*nslots_out` device buffers of one AO block each (naux x nao x nao c128, contiguous: slot s at
+ * ring + s * naux*nao*nao) owned by the pipeline, for producers that write blocks on the device (a generator kernel, a
+ * device-side reader).  The caller fills slot number (blocks pushed so far in this group) mod nslots and calls
+ * dmk_eri_push_ring_slot: the block is only queued; when `nslots` blocks are queued (or the kL ends) ONE step-1 launch
+ * transforms all of them and one step-2 launch accumulates them -- one ramp-up and drain of the GPU per group instead of
+ * one per block.  *nslots_out == 0: this shape runs the generic kernels, use dmk_eri_push_block.  A slot may be
+ * rewritten as soon as the push that completes its group has returned (work is stream-ordered). */
+int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out);
+int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise);
 /* The same for an AO block in HOST memory (what sr_loop / _load3c hand over, eri_transform.py:195-227, 358-366): the
  * block is copied to one of two device staging blocks (`slot` 0 | 1) on a separate copy stream and transformed on the
  * compute stream as soon as it has landed, so the copy of block n+1 overlaps the transform of block n.  Returns

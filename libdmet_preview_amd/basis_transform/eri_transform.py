@@ -475,6 +475,13 @@ class EriEngine(object):
         self.weights, self.records = eri_plan(self.kmesh, self.tr)
         self.block_buf = ctx.empty((self.naux, self.nao, self.nao), np.complex128)
         self.host_buf, self.host_slot = None, 0
+        # block ring of the hot path: device-side producers write straight into the pipeline's queue slots and step 1
+        # runs once per group of queued blocks (dmk_eri_block_ring); nslots == 0 for shapes on the generic kernels
+        ring, nslots = C.c_void_p(), C.c_int()
+        ctx.check(lib.dmk_eri_block_ring(self.h, C.byref(ring), C.byref(nslots)))
+        self.ring_slots, self.ring_pos = int(nslots.value), 0
+        self.ring = [ctx.wrap(ring.value + s * self.block_buf.nbytes, (self.naux, self.nao, self.nao), np.complex128)
+                     for s in range(self.ring_slots)]
         # records grouped by kL, in plan order
         self.by_kL = {}
         for r in self.records:
@@ -502,12 +509,17 @@ class EriEngine(object):
                 provider.load_block_host(ui, uj, self.host_buf[slot].a)
                 ctx.check(lib.dmk_eri_push_block_host(self.h, i, j, sym, self.host_buf[slot].ptr, slot))
                 self.host_slot = 1 - slot
+            elif self.ring_slots:
+                provider.load_block(ctx, ui, uj, self.ring[self.ring_pos])
+                ctx.check(lib.dmk_eri_push_ring_slot(self.h, i, j, sym))
+                self.ring_pos = (self.ring_pos + 1) % self.ring_slots
             else:
                 provider.load_block(ctx, ui, uj, self.block_buf)
                 ctx.check(lib.dmk_eri_push_block(self.h, i, j, sym, self.block_buf.ptr))
             nblk += 1
             if max_blocks is not None and nblk >= max_blocks:
                 break
+        self.ring_pos = 0                      # ending the kL flushes the queue
         if self.gso:
             ctx.check(lib.dmk_eri_end_kL_gso(self.h, int(self.weights[kL])))
         else:

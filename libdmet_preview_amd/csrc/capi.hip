@@ -597,7 +597,11 @@ struct dmk_eri {
     // hot path: step-1 outputs of up to `group` consecutive AO blocks are queued and transformed by ONE
     // step-2 launch whose accumulators (and tril-pack epilogue) are shared by all of them
     int group = 1, pending = 0;
-    int pend_kj[16], pend_sym[16];
+    int pend_kj[16], pend_sym[16], pend_ki[16];
+    // block ring (dmk_eri_block_ring / dmk_eri_push_ring_slot): `group` AO-block buffers owned by the pipeline; blocks
+    // written there are queued WITHOUT running step 1, and the flush runs ONE step-1 launch over all of them
+    double2 *ring = nullptr;
+    int ring_pending = 0;       // queued ring slots whose step 1 has not run yet (they are the first `ring_pending` slots)
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
     // host feed (dmk_eri_push_block_host): two device staging blocks filled on a copy stream while the compute stream
@@ -681,9 +685,27 @@ int dmk_eri_begin_kL(dmk_eri *h, int kL) {
     return DMK_OK;
 }
 
+static int eri_ring_step1(dmk_eri *h) {
+    dmk_ctx *ctx = h->ctx;
+    if (h->ring_pending == 0) return DMK_OK;
+    const int nao = h->nao, naux = h->naux, nemb = h->nemb;
+    const size_t slot_elems = (size_t)naux * nao * nemb;
+    int rc = launch_half1_hot_multi(ctx, h->ring, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->C, h->Ut,
+                                    (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * nao * nemb,
+                                    (long long)h->group * (long long)slot_elems);
+    if (rc < 0) return rc;
+    if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
+    h->ring_pending = 0;
+    return DMK_OK;
+}
+
 static int eri_flush(dmk_eri *h) {
     dmk_ctx *ctx = h->ctx;
     if (h->pending == 0) return DMK_OK;
+    {
+        int rc1 = eri_ring_step1(h);
+        if (rc1) return rc1;
+    }
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const size_t slot_elems = (size_t)naux * nao * nemb;
     // one launch for both spin channels: C, Ut and the planes of spin 1 sit at constant offsets from those of spin 0
@@ -710,6 +732,10 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
     const size_t slot_elems = (size_t)naux * nao * nemb;
     if (h->group > 1) {
         // hot path: step 1 now (it consumes the caller's block buffer), step 2 when the queue is full
+        if (h->ring_pending) {
+            int rc1 = eri_ring_step1(h);
+            if (rc1) return rc1;
+        }
         const int slot = h->pending;
         // both spin channels in one launch (they share the AO block); per-spin generic kernels only if it declines
         int rc_hot = launch_half1_hot(ctx, L, h->C + (size_t)ki * nao * nemb, h->Ut + (size_t)slot * slot_elems, naux, nao, nemb,
@@ -861,6 +887,45 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
     return DMK_OK;
 }
 
+int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out) {
+    if (!h || !ring_out || !nslots_out) return DMK_ERR_INVALID;
+    *ring_out = nullptr;
+    *nslots_out = 0;
+    if (h->group <= 1) return DMK_OK;                 // generic path: no queue, use dmk_eri_push_block
+    if (!h->ring) {
+        const size_t bytes = (size_t)h->group * h->naux * h->nao * h->nao * sizeof(double2);
+        if (hipMalloc(reinterpret_cast<void **>(&h->ring), bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            h->ring = nullptr;
+            return DMK_OK;                            // not fatal: the caller falls back to dmk_eri_push_block
+        }
+    }
+    *ring_out = h->ring;
+    *nslots_out = h->group;
+    return DMK_OK;
+}
+
+int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_ring_slot: no kL in progress");
+    if (!h->ring || h->group <= 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_ring_slot: no block ring (dmk_eri_block_ring)");
+    if (ki < 0 || ki >= h->mesh.nk || kj < 0 || kj >= h->mesh.nk)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_ring_slot: bad arguments");
+    if (h->ring_pending != h->pending)
+        return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_ring_slot: ring slots and directly pushed blocks cannot share a group");
+    const int slot = h->pending;
+    h->pend_ki[slot] = ki;
+    h->pend_kj[slot] = kj;
+    h->pend_sym[slot] = symmetrise ? 1 : 0;
+    h->pending += 1;
+    h->ring_pending += 1;
+    h->flops_half += (double)h->spin * (8.0 * h->naux * (double)h->nao * h->nao * h->nemb +
+                                        8.0 * h->naux * (double)h->nao * h->nemb * h->nemb);
+    if (h->pending == h->group) return eri_flush(h);
+    return DMK_OK;
+}
+
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     if (!h || !planes_out) return DMK_ERR_INVALID;
     {
@@ -931,6 +996,7 @@ int dmk_eri_finish(dmk_eri *h) {
         }
         (void)hipStreamDestroy(h->copy_stream);
     }
+    if (h->ring) (void)hipFree(h->ring);
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;

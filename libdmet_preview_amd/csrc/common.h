@@ -163,6 +163,9 @@ int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, in
 // step 2 for a general nemb: flattened hot kernel into P (nL x nemb x nemb c128) + deterministic fold/pack into the planes
 int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
                       int nL, int nao, int nemb, int sym);
+int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_stride, int nslot, const int *ki, const void *C,
+                           void *Ut, long long ut_slot_stride, int nL, int nao, int nemb, int nspin, long long ci_spin_stride,
+                           long long ut_spin_stride);
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);

@@ -122,7 +122,19 @@ struct H1Args {
     // the workgroups of one M tile are adjacent (n tile fastest, then spin), so they share the A tile in L2
     int nspin;
     long long b_spin_stride, out_spin_stride;
+    // several queued AO blocks in one launch (one ramp-up / drain instead of one per block): block `slot` is the A
+    // operand Lpq + slot * a_slot_stride, its B operand Ci + bk[slot] * b_k_stride, its output Ut + slot * out_slot_stride
+    int nslot;
+    unsigned per_slot;      // workgroups per block = tiles_m * tiles_n * nspin
+    long long a_slot_stride, out_slot_stride, b_k_stride;
+    int bk[16];
 };
+
+#define H1_PICK_BK(G, SLOT)                                                                        \
+    ((SLOT) == 0 ? (G).bk[0] : (SLOT) == 1 ? (G).bk[1] : (SLOT) == 2 ? (G).bk[2] : (SLOT) == 3 ? (G).bk[3]      \
+     : (SLOT) == 4 ? (G).bk[4] : (SLOT) == 5 ? (G).bk[5] : (SLOT) == 6 ? (G).bk[6] : (SLOT) == 7 ? (G).bk[7]    \
+     : (SLOT) == 8 ? (G).bk[8] : (SLOT) == 9 ? (G).bk[9] : (SLOT) == 10 ? (G).bk[10] : (SLOT) == 11 ? (G).bk[11] \
+     : (SLOT) == 12 ? (G).bk[12] : (SLOT) == 13 ? (G).bk[13] : (SLOT) == 14 ? (G).bk[14] : (G).bk[15])
 
 template <bool CONJB>
 __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
@@ -131,15 +143,18 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     const int wm = wave >> 1, wn = wave & 1;            // 2 (M) x 2 (N) waves, wave tile 64 x 32
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
-    const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
+    const unsigned lid_all = xcd_remap(blockIdx.x, g.nblocks);
+    const int slot = (int)(lid_all / g.per_slot);
+    const unsigned lid = lid_all - (unsigned)slot * g.per_slot;
     const unsigned per_m = (unsigned)(g.tiles_n * g.nspin);
     const int tile_m = (int)(lid / per_m);
     const unsigned rest = lid - (unsigned)tile_m * per_m;
     const int sp = (int)(rest / (unsigned)g.tiles_n), tile_n = (int)(rest - (unsigned)sp * (unsigned)g.tiles_n);
     const int n0 = tile_n * H1_BN;
     const long long nao = g.nao, nemb = g.nemb, mrows = g.mrows;
-    const double2 *const Bsp = g.Ci + (long long)sp * g.b_spin_stride;
-    double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride;
+    const double2 *const Asl = g.Lpq + (long long)slot * g.a_slot_stride;
+    const double2 *const Bsp = g.Ci + (long long)sp * g.b_spin_stride + (long long)H1_PICK_BK(g, slot) * g.b_k_stride;
+    double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride + (long long)slot * g.out_slot_stride;
 
     // ---- per-lane LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB) ----
     const double2 *srcA[2], *srcB;
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         int q = (gb - L * g.nblk) * 16 + (m & 15);
         if (L >= g.nL) L = g.nL - 1;                    // clamped lanes only ever feed masked outputs
         if (q >= g.mrows) q = g.mrows - 1;
-        srcA[h] = g.Lpq + (long long)L * nao * mrows + q;
+        srcA[h] = Asl + (long long)L * nao * mrows + q;
     }
     {
         int col = n0 + lane;
@@ -470,7 +485,9 @@ bool hot_enabled() {
 
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
 static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out, int nL, int K, int mrows, int N, bool conjB,
-                           int fam, int nspin = 1, long long b_spin_stride = 0, long long out_spin_stride = 0) {
+                           int fam, int nspin = 1, long long b_spin_stride = 0, long long out_spin_stride = 0, int nslot = 1,
+                           long long a_slot_stride = 0, long long out_slot_stride = 0, long long b_k_stride = 0,
+                           const int *bk = nullptr) {
     if (!hot_enabled() || (K % H1_BK) != 0 || K < 2 * H1_BK || N < 32 || (long long)nL * mrows < 4 * H1_BM) return 0;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) return 0;
     H1Args a;
@@ -483,7 +500,12 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     a.tiles_m = (int)((total_blk + H1_BM / 16 - 1) / (H1_BM / 16));
     a.tiles_n = (N + H1_BN - 1) / H1_BN;
     a.nspin = nspin; a.b_spin_stride = b_spin_stride; a.out_spin_stride = out_spin_stride;
-    a.nblocks = (unsigned)(a.tiles_m * a.tiles_n * nspin);
+    if (nslot < 1 || nslot > 16) return 0;
+    a.nslot = nslot; a.a_slot_stride = a_slot_stride; a.out_slot_stride = out_slot_stride; a.b_k_stride = b_k_stride;
+    for (int i = 0; i < 16; ++i) a.bk[i] = (bk && i < nslot) ? bk[i] : 0;
+    a.per_slot = (unsigned)(a.tiles_m * a.tiles_n * nspin);
+    if ((unsigned long long)a.per_slot * (unsigned)nslot > 0x7fffffffull) return 0;
+    a.nblocks = a.per_slot * (unsigned)nslot;
     FamScope fs(ctx, fam);
     if (conjB) hipLaunchKernelGGL(half1_kernel<true>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL(half1_kernel<false>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
@@ -495,6 +517,16 @@ int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, in
                      long long ci_spin_stride, long long ut_spin_stride) {
     if (nspin < 1 || nspin > 2) return 0;
     return launch_flat_hot(ctx, Lpq, Ci, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1, nspin, ci_spin_stride, ut_spin_stride);
+}
+
+// Step 1 of `nslot` queued AO blocks in one launch: block s at Lpq + s * a_slot_stride, transformed with
+// C[spin][ki[s]] (C: [spin][nk][nao][nemb], spin stride ci_spin_stride) into Ut + s * ut_slot_stride (+ spin stride).
+int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_stride, int nslot, const int *ki, const void *C,
+                           void *Ut, long long ut_slot_stride, int nL, int nao, int nemb, int nspin, long long ci_spin_stride,
+                           long long ut_spin_stride) {
+    if (nspin < 1 || nspin > 2) return 0;
+    return launch_flat_hot(ctx, Lpq, C, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1, nspin, ci_spin_stride, ut_spin_stride,
+                           nslot, a_slot_stride, ut_slot_stride, (long long)nao * nemb, ki);
 }
 
 // Step 2 for a general embedding dimension: P[L][a][b] = sum_q Ut[L][q][a] C_j[q][b] with the flattened kernel above
