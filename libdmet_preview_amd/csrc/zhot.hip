@@ -36,7 +36,7 @@
 #include <type_traits>
 
 // Ablation switches for tools/zhot_lab.hip only (product builds leave ZHOT_ABL at 0):
-//   1 = no LDS-DMA after the prologue, 2 = no epilogue, 4 = no barrier (results wrong, timing only)
+//   1 = no LDS-DMA after the prologue, 2 = no epilogue, 4 = no barrier, 8 = no 3M operand sums, 16 = no LDS fragment reads (results wrong, timing only)
 #ifndef ZHOT_ABL
 #define ZHOT_ABL 0
 #endif
@@ -68,10 +68,20 @@ __device__ __forceinline__ void cacc_zero(cacc &c) {
     c.t = d4_t{0.0, 0.0, 0.0, 0.0};
 #endif
 }
+// ablation 16: fragments come from a register pair filled once (no LDS reads in the loop; timing only)
+__device__ __forceinline__ double2 lds_frag(const double2 *p) {
+#if (ZHOT_ABL & 16)
+    double2 v;
+    asm volatile("; no lds read" : "=v"(v.x), "=v"(v.y) : "v"(p));
+    return v;
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ cfrag cfrag_of(double2 v) {
     cfrag f;
     f.v = v;
-    f.s = v.x + v.y;
+    f.s = (ZHOT_ABL & 8) ? v.x : v.x + v.y;      // ablation 8: no VALU add (results wrong, timing only)
     return f;
 }
 __device__ __forceinline__ void cmfma(cacc &c, const cfrag &a, const cfrag &b) {
@@ -205,10 +215,10 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         for (int kk = 0; kk < H1_BK / 4; ++kk) {
             cfrag a[4], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = cfrag_of(Ab[(kk * 4 + frag_k) * H1_BM + i * 16]);
+            for (int i = 0; i < 4; ++i) a[i] = cfrag_of(lds_frag(&Ab[(kk * 4 + frag_k) * H1_BM + i * 16]));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                double2 v = Bb[(kk * 4 + frag_k) * H1_BN + j * 16];
+                double2 v = lds_frag(&Bb[(kk * 4 + frag_k) * H1_BN + j * 16]);
                 if (CONJB) v.y = -v.y;                  // conj(C_i)
                 b[j] = cfrag_of(v);
             }
@@ -362,19 +372,19 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 const double2 *U = lds + (t % H2T_D) * H2T_STAGE + frag_k * 128 + frag_x;
                 const double2 *C = U + H2_BK * 128;
                 {   // segment 1: S[a][b] += U[q][a] C[q][b]   (one B fragment live at a time)
-                    const cfrag a1 = cfrag_of(U[R1 * 16]), a2 = cfrag_of(U[R2 * 16]);
+                    const cfrag a1 = cfrag_of(lds_frag(&U[R1 * 16])), a2 = cfrag_of(lds_frag(&U[R2 * 16]));
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) {
-                        const cfrag b = cfrag_of(C[c * 16]);
+                        const cfrag b = cfrag_of(lds_frag(&C[c * 16]));
                         if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
                         cmfma(acc2[c], a2, b);
                     }
                 }
                 if ((g_symmask >> (t / Tb)) & 1u) {   // segment 2: S[a][b] += C[q][a] U[q][b]   (same two panels)
-                    const cfrag a1 = cfrag_of(C[R1 * 16]), a2 = cfrag_of(C[R2 * 16]);
+                    const cfrag a1 = cfrag_of(lds_frag(&C[R1 * 16])), a2 = cfrag_of(lds_frag(&C[R2 * 16]));
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) {
-                        const cfrag b = cfrag_of(U[c * 16]);
+                        const cfrag b = cfrag_of(lds_frag(&U[c * 16]));
                         if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
                         cmfma(acc2[c], a2, b);
                     }
@@ -445,9 +455,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         {
             cfrag a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(Ua[i * 16]);
+            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(lds_frag(&Ua[i * 16]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(Cb[j * 16]);
+            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(lds_frag(&Cb[j * 16]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -456,9 +466,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         if ((g_symmask >> (t / Tb)) & 1u) {
             cfrag a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(Ca[i * 16]);
+            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(lds_frag(&Ca[i * 16]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(Ub[j * 16]);
+            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(lds_frag(&Ub[j * 16]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
