@@ -244,8 +244,8 @@ def main():
                     "traffic_note": "HBM bytes per launch from rocprofv3 PMC (profiles/traffic_latest.json), collected offline",
                     "avg_launch_ms": fam_out[dom]["ms_avg"],
                     "note": "achieved = ALGORITHMIC flop (8 per complex multiply-add) / HIP-event time; the kernel executes "
-                            "executed_mfma_tflops on the matrix pipe (3M complex product), ceiling measured 77.5 TFLOP/s",
-                    "mfma_ceiling_measured": 77.5,
+                            "executed_mfma_tflops on the matrix pipe (3M complex product), ceiling measured 78.1 TFLOP/s (tools/mfma_acc_probe.hip)",
+                    "mfma_ceiling_measured": 78.1,
                     "families": fam_out}
         res = {
             "metric": "DMET embedding-construction iteration (diag+bath+ERI-transform): ERI-transform TFLOP/s over the whole step",

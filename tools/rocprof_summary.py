@@ -39,9 +39,11 @@ def pmc(db):
     print()
 
 
-FAMILY = [("dgemm_tn_acc", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"),
-          ("philox_block", "philox"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"), ("jk_k_kernel", "jk_k"),
-          ("gemv2_kernel", "gemv2")]
+# first match wins: the multi-CU Jacobi solver must not be counted as the batched QL eigensolver, and only the LDS-DMA
+# contraction kernel is the "dgemm" of the ERI transform (dgemm_tn_acc_kernel also serves small Gram matrices)
+FAMILY = [("dgemm_tn_acc_dma_kernel", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"),
+          ("philox_block", "philox"), ("jacobi_eigh_kernel", "jacobi_eigh"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"),
+          ("jk_k_kernel", "jk_k"), ("gemv2_kernel", "gemv2")]
 
 
 def traffic_json(dbs, out):
@@ -50,15 +52,21 @@ def traffic_json(dbs, out):
     acc = {}
     for db in dbs:
         con = sqlite3.connect(db)
-        for n, cn, c, a in con.execute("select name, counter_name, count(*), avg(counter_value) from pmc_events "
-                                       "group by name, counter_name"):
+        per = {}
+        for n, cn, c, tot in con.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
+                                         "group by name, counter_name"):
             if cn not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             for key, fam in FAMILY:
                 if key in n:
-                    e = acc.setdefault(fam, {"launches_sampled": 0})
-                    e[cn + "_KiB_per_launch"] = a
-                    e["launches_sampled"] = max(e["launches_sampled"], c)
+                    e = per.setdefault((fam, cn), [0, 0.0])          # template variants of one family are pooled
+                    e[0] += c
+                    e[1] += tot
+                    break
+        for (fam, cn), (c, tot) in per.items():
+            e = acc.setdefault(fam, {"launches_sampled": 0})
+            e[cn + "_KiB_per_launch"] = tot / c
+            e["launches_sampled"] = max(e["launches_sampled"], c)
     for fam, e in acc.items():
         f = e.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024 * 2.0
         w = e.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
