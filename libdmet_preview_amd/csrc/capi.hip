@@ -88,7 +88,7 @@ int dmk_destroy(dmk_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &p : ctx->phases) (void)hipFree(p.dev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    for (int w = 0; w < 2; ++w)
+    for (int w = 0; w < 3; ++w)
         if (ctx->eri_ws[w]) (void)hipFree(ctx->eri_ws[w]);
     (void)hipEventDestroy(ctx->t0);
     (void)hipEventDestroy(ctx->t1);
@@ -601,6 +601,7 @@ struct dmk_eri {
     // block ring (dmk_eri_block_ring / dmk_eri_push_ring_slot): `group` AO-block buffers owned by the pipeline; blocks
     // written there are queued WITHOUT running step 1, and the flush runs ONE step-1 launch over all of them
     double2 *ring = nullptr;
+    size_t ring_bytes = 0;
     int ring_pending = 0;       // queued ring slots whose step 1 has not run yet (they are the first `ring_pending` slots)
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
@@ -893,11 +894,26 @@ int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out) {
     *nslots_out = 0;
     if (h->group <= 1) return DMK_OK;                 // generic path: no queue, use dmk_eri_push_block
     if (!h->ring) {
+        dmk_ctx *ctx = h->ctx;
         const size_t bytes = (size_t)h->group * h->naux * h->nao * h->nao * sizeof(double2);
-        if (hipMalloc(reinterpret_cast<void **>(&h->ring), bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            h->ring = nullptr;
-            return DMK_OK;                            // not fatal: the caller falls back to dmk_eri_push_block
+        if (ctx->eri_ws[2] && ctx->eri_ws_bytes[2] >= bytes) {          // parked by the previous pipeline
+            h->ring = reinterpret_cast<double2 *>(ctx->eri_ws[2]);
+            h->ring_bytes = ctx->eri_ws_bytes[2];
+            ctx->eri_ws[2] = nullptr;
+            ctx->eri_ws_bytes[2] = 0;
+        } else {
+            if (ctx->eri_ws[2]) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipFree(ctx->eri_ws[2]);
+                ctx->eri_ws[2] = nullptr;
+                ctx->eri_ws_bytes[2] = 0;
+            }
+            if (hipMalloc(reinterpret_cast<void **>(&h->ring), bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                h->ring = nullptr;
+                return DMK_OK;                        // not fatal: the caller falls back to dmk_eri_push_block
+            }
+            h->ring_bytes = bytes;
         }
     }
     *ring_out = h->ring;
@@ -996,7 +1012,14 @@ int dmk_eri_finish(dmk_eri *h) {
         }
         (void)hipStreamDestroy(h->copy_stream);
     }
-    if (h->ring) (void)hipFree(h->ring);
+    if (h->ring) {
+        if (!ctx->eri_ws[2]) {
+            ctx->eri_ws[2] = h->ring;
+            ctx->eri_ws_bytes[2] = h->ring_bytes;
+        } else {
+            (void)hipFree(h->ring);
+        }
+    }
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;

@@ -31,8 +31,8 @@ struct dmk_ctx {
     std::vector<Phase> phases;
     // workspace of the last ERI pipeline (plane set + Ut slots, several GB): kept across dmk_eri_finish /
     // dmk_eri_begin so that a self-consistency loop does not pay hipMalloc of it (~0.25 s) every iteration
-    void *eri_ws[2] = {nullptr, nullptr};
-    size_t eri_ws_bytes[2] = {0, 0};
+    void *eri_ws[3] = {nullptr, nullptr, nullptr};   // planes, Ut, AO-block ring: parked between pipelines
+    size_t eri_ws_bytes[3] = {0, 0, 0};
 };
 
 int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);

@@ -182,20 +182,29 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                 pbuf[t] = make_double2(pbuf[t].x + av.x, pbuf[t].y + av.y);
             }
             __syncthreads();
-            // (g) A22 -= v w^H + w v^H
-            const size_t mm = (size_t)m * m;
-            for (size_t idx = tid; idx < mm; idx += NT) {
-                const int i = (int)(idx / m), j = (int)(idx % m);
-                const double2 vi = vbuf[i], wi = pbuf[i], vj = vbuf[j], wj = pbuf[j];
-                // v_i conj(w_j) + w_i conj(v_j)
-                const double ur = vi.x * wj.x + vi.y * wj.y + wi.x * vj.x + wi.y * vj.y;
-                const double ui = vi.y * wj.x - vi.x * wj.y + wi.y * vj.x - wi.x * vj.y;
-                double2 *p = W + (size_t)(k + 1 + i) * n + (k + 1 + j);
-                double2 a = *p;
-                a.x -= ur;
-                a.y -= ui;
-                if (i == j) a.y = 0.0;
-                *p = a;
+            // (g) A22 -= v w^H + w v^H : one row per wave at a time, lanes along the row (coalesced, no index division);
+            // two rows in flight per wave
+            for (int i0 = wave; i0 < m; i0 += 2 * NW) {
+                const int i1 = i0 + NW;
+                const bool two = i1 < m;
+                const double2 vi0 = vbuf[i0], wi0 = pbuf[i0];
+                const double2 vi1 = two ? vbuf[i1] : make_double2(0.0, 0.0), wi1 = two ? pbuf[i1] : make_double2(0.0, 0.0);
+                double2 *r0 = W + (size_t)(k + 1 + i0) * n + (k + 1);
+                double2 *r1 = W + (size_t)(k + 1 + (two ? i1 : i0)) * n + (k + 1);
+                for (int j = lane; j < m; j += 64) {
+                    const double2 vj = vbuf[j], wj = pbuf[j];
+                    double2 a0 = r0[j], a1 = r1[j];
+                    a0.x -= vi0.x * wj.x + vi0.y * wj.y + wi0.x * vj.x + wi0.y * vj.y;
+                    a0.y -= vi0.y * wj.x - vi0.x * wj.y + wi0.y * vj.x - wi0.x * vj.y;
+                    if (j == i0) a0.y = 0.0;
+                    r0[j] = a0;
+                    if (two) {
+                        a1.x -= vi1.x * wj.x + vi1.y * wj.y + wi1.x * vj.x + wi1.y * vj.y;
+                        a1.y -= vi1.y * wj.x - vi1.x * wj.y + wi1.y * vj.x - wi1.x * vj.y;
+                        if (j == i1) a1.y = 0.0;
+                        r1[j] = a1;
+                    }
+                }
             }
         }
         __syncthreads();
