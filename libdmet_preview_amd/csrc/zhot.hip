@@ -340,16 +340,31 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             const int piece = wave + 4 * h;
             soff[h] = (long long)((piece & 7) >> 1) * nemb + d0 + (piece & 1) * 64 + lane;
         }
-        auto issue = [&](int tt) {
-            const int slot = tt / Tb, t = tt - slot * Tb;
-            double2 *st = lds + (tt % H2T_D) * H2T_STAGE;
-            const long long k0 = (long long)t * H2_BK * nemb;
-            const double2 *ub = Ubase + (long long)slot * g_slot_stride + k0;
-            const double2 *cb = H2_PICK_CJ(g, slot) + cj_off + k0;
-            glds16(ub + soff[0], lds_addr_of(st + (wave) * 64));            // pieces 0-3: U
-            glds16(ub + soff[1], lds_addr_of(st + (wave + 4) * 64));        // pieces 4-7: U
-            glds16(cb + soff[2], lds_addr_of(st + (wave + 8) * 64));        // pieces 8-11: C
-            glds16(cb + soff[3], lds_addr_of(st + (wave + 12) * 64));       // pieces 12-15: C
+        // running issue state (wave-uniform, SGPRs): no division and no kernel-argument load per K-tile
+        int is_t = 0, is_slot = 0, is_stage = 0;
+        const double2 *is_ub = Ubase, *is_cb = H2_PICK_CJ(g, 0) + cj_off;
+        // (spreading the four pieces of a tile over the MFMA stream of a K step, instead of this burst after the barrier,
+        // measured 2.5 % slower: the inline-asm DMA statements pin the compiler's MFMA / ds_read schedule)
+        auto issue_piece = [&](int h) {
+            double2 *st = lds + is_stage * H2T_STAGE;
+            glds16((h < 2 ? is_ub : is_cb) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+        };
+        auto issue_advance = [&]() {
+            is_stage = is_stage + 1 == H2T_D ? 0 : is_stage + 1;
+            if (++is_t == Tb) {
+                is_t = 0;
+                ++is_slot;
+                is_ub = Ubase + (long long)is_slot * g_slot_stride;
+                is_cb = H2_PICK_CJ(g, is_slot) + cj_off;
+            } else {
+                is_ub += H2_BK * nemb;
+                is_cb += H2_BK * nemb;
+            }
+        };
+        auto issue = [&]() {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) issue_piece(h);
+            issue_advance();
         };
         auto run = [&](auto tag) {
             constexpr int R1 = decltype(tag)::value;
@@ -359,17 +374,20 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             for (int c = 0; c <= R1; ++c) cacc_zero(acc1[c]);
 #pragma unroll
             for (int c = 0; c <= R2; ++c) cacc_zero(acc2[c]);
-            issue(0);
-            if (T > 1) issue(1);
-            if (T > 2) issue(2);
+            issue();
+            if (T > 1) issue();
+            if (T > 2) issue();
+            int c_t = 0, c_stage = 0;
+            unsigned c_sym = g_symmask & 1u, c_mask = g_symmask;
             for (int t = 0; t < T; ++t) {
                 const int later = T - 1 - t;
                 if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-                if (!(ZHOT_ABL & 1) && t + 3 < T) issue(t + 3);
-                const double2 *U = lds + (t % H2T_D) * H2T_STAGE + frag_k * 128 + frag_x;
+                if (!(ZHOT_ABL & 1) && t + 3 < T) issue();
+                const double2 *U = lds + c_stage * H2T_STAGE + frag_k * 128 + frag_x;
+                c_stage = c_stage + 1 == H2T_D ? 0 : c_stage + 1;
                 const double2 *C = U + H2_BK * 128;
                 {   // segment 1: S[a][b] += U[q][a] C[q][b]   (one B fragment live at a time)
                     const cfrag a1 = cfrag_of(lds_frag(&U[R1 * 16])), a2 = cfrag_of(lds_frag(&U[R2 * 16]));
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                         cmfma(acc2[c], a2, b);
                     }
                 }
-                if ((g_symmask >> (t / Tb)) & 1u) {   // segment 2: S[a][b] += C[q][a] U[q][b]   (same two panels)
+                if (c_sym) {   // segment 2: S[a][b] += C[q][a] U[q][b]   (same two panels)
                     const cfrag a1 = cfrag_of(lds_frag(&C[R1 * 16])), a2 = cfrag_of(lds_frag(&C[R2 * 16]));
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) {
@@ -388,6 +406,11 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                         if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
                         cmfma(acc2[c], a2, b);
                     }
+                }
+                if (++c_t == Tb) {
+                    c_t = 0;
+                    c_mask >>= 1;
+                    c_sym = c_mask & 1u;
                 }
             }
 #pragma unroll
@@ -426,30 +449,41 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         else { row = (piece - 16) >> 1; col = ((piece - 16) & 1) * 64; isC[h] = 0; }
         soff[h] = (long long)row * nemb + col + lane;
     }
-    auto issue = [&](int tt) {
-        const int slot = tt / Tb, t = tt - slot * Tb;
-        double2 *st = lds + (tt % H2S_D) * H2S_STAGE;
-        const long long k0 = (long long)t * H2_BK * nemb;
-        const double2 *ub = Ubase + (long long)slot * g_slot_stride + k0;
-        const double2 *cb = H2_PICK_CJ(g, slot) + cj_off + k0;
+    int is_t = 0, is_slot = 0, is_stage = 0;
+    const double2 *is_ub = Ubase, *is_cb = H2_PICK_CJ(g, 0) + cj_off;
+    auto issue = [&]() {
+        double2 *st = lds + is_stage * H2S_STAGE;
 #pragma unroll
         for (int h = 0; h < 6; ++h)
-            glds16((isC[h] ? cb : ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+            glds16((isC[h] ? is_cb : is_ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+        is_stage = is_stage + 1 == H2S_D ? 0 : is_stage + 1;
+        if (++is_t == Tb) {
+            is_t = 0;
+            ++is_slot;
+            is_ub = Ubase + (long long)is_slot * g_slot_stride;
+            is_cb = H2_PICK_CJ(g, is_slot) + cj_off;
+        } else {
+            is_ub += H2_BK * nemb;
+            is_cb += H2_BK * nemb;
+        }
     };
     cacc acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) cacc_zero(acc[i][j]);
-    issue(0);
-    if (T > 1) issue(1);
+    issue();
+    if (T > 1) issue();
+    int c_t = 0, c_stage = 0;
+    unsigned c_sym = g_symmask & 1u, c_mask = g_symmask;
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-        if (!(ZHOT_ABL & 1) && t + 2 < T) issue(t + 2);
-        const double2 *Ua = lds + (t % H2S_D) * H2S_STAGE + frag_k * 64 + wm * 32 + frag_x;
-        const double2 *Cb = lds + (t % H2S_D) * H2S_STAGE + 256 + frag_k * 128 + wn * 64 + frag_x;
+        if (!(ZHOT_ABL & 1) && t + 2 < T) issue();
+        const double2 *Ua = lds + c_stage * H2S_STAGE + frag_k * 64 + wm * 32 + frag_x;
+        const double2 *Cb = lds + c_stage * H2S_STAGE + 256 + frag_k * 128 + wn * 64 + frag_x;
+        c_stage = c_stage + 1 == H2S_D ? 0 : c_stage + 1;
         const double2 *Ca = Ua + 768;
         const double2 *Ub = Cb + 768;
         {
@@ -463,7 +497,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cmfma(acc[i][j], a[i], b[j]);
         }
-        if ((g_symmask >> (t / Tb)) & 1u) {
+        if (c_sym) {
             cfrag a[2], b[4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = cfrag_of(lds_frag(&Ca[i * 16]));
@@ -473,6 +507,11 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) cmfma(acc[i][j], a[i], b[j]);
+        }
+        if (++c_t == Tb) {
+            c_t = 0;
+            c_mask >>= 1;
+            c_sym = c_mask & 1u;
         }
     }
 #pragma unroll
