@@ -59,7 +59,34 @@ void run(const char *tag) {
     CK(hipFree(out));
 }
 
-int main() {
+template <int NA, int NB>
+void sustained(double seconds) {
+    // the same kernel launched back to back for `seconds`: does the rate hold under sustained load (power / clock management)?
+    const int blocks = 512 * 8, iters = 2000 / (NA * NB) * 40;
+    double *out;
+    CK(hipMalloc(&out, sizeof(double) * blocks * 256));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    double elapsed = 0;
+    int n = 0;
+    while (elapsed < seconds * 1e3) {
+        CK(hipEventRecord(e0));
+        k<NA, NB, 0><<<blocks, 256>>>(out, iters, 1.000001, 0.999999);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        elapsed += ms;
+        const double tf = (double)blocks * 4 * iters * NA * NB * 2048.0 / (ms * 1e-3) / 1e12;
+        if (n % 8 == 0) printf("sustained NA=%d NB=%d: launch %3d at %7.1f ms: %.1f ms per launch, %.2f TF\n", NA, NB, n, elapsed, ms, tf);
+        ++n;
+    }
+    CK(hipFree(out));
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) { sustained<3, 8>(atof(argv[1])); return 0; }
     run<4, 4, 0>("asm");
     run<4, 6, 0>("asm");
     run<3, 8, 0>("asm");
