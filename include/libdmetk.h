@@ -77,6 +77,11 @@ enum { DMK_FAM_DGEMM = 0, DMK_FAM_ZGEMM_HALF1 = 1, DMK_FAM_ZGEMM_HALF2 = 2,
 int dmk_profile(dmk_ctx *ctx, int enable);
 int dmk_profile_read(dmk_ctx *ctx, double *ms_host /*[DMK_FAM_COUNT]*/,
                      int64_t *launches_host /*[DMK_FAM_COUNT]*/, int reset);
+/* flop ISSUED to the f64 matrix pipe by each family since the last reset (tiles launched x MFMA instructions per
+ * tile x 512): the numerator of bench.py's roofline fraction.  Differs from the algorithmic count of SURVEY.md
+ * section 8d where a kernel restructures the arithmetic (3M complex product, tril-only step 2, symmetric
+ * contraction) or pads tiles.  Counted on every launch, independent of dmk_profile. */
+int dmk_profile_read_flops(dmk_ctx *ctx, double *flops_host /*[DMK_FAM_COUNT]*/, int reset);
 
 /* ------------------------------------------------------------------------- */
 /* a1 / a2 / a15 : k-point, cell and time-reversal bookkeeping (HOST, integer) */
@@ -163,6 +168,19 @@ int dmk_eigh_jacobi_real(dmk_ctx *ctx, int n, int batch, const double *A, const 
                          int *sweeps_out);
 int dmk_occ_density(dmk_ctx *ctx, int n, int batch, const void *Vt, const double *occ,
                     void *rho /* c128 batch x n x n */);
+/* a4: chemical potential and occupation numbers of `n` levels `ew` (device, any order; all spins and k-points of one
+ * particle-number sector) -- replaces routine/mfd.py:887-957 (assignocc, ncore = nvirt = 0 branches) and
+ * routine/ftsystem.py:24-105 (fermi_smearing_occ, find_mu) without the host sort.
+ *   beta = +inf: T = 0; nelec must be an integer 0 <= nelec <= n.  flags bit 0: mu0 is a preferred value, kept if it
+ *     separates nelec levels within the window thr_deg; otherwise mu = mid-point of the levels of rank nelec - 1 and
+ *     nelec (bit-identical to the sorted-array expression).  Levels below mu - thr_deg get 1, the remaining electrons
+ *     are spread evenly over [mu - thr_deg, mu + thr_deg].
+ *   beta finite: Fermi function 1 / (exp(beta (e - mu)) + 1) (0 beyond beta (e - mu) >= 100); flags bit 1: mu = mu0 is
+ *     fixed, else mu solves sum occ = nelec to the tolerance fit_tol (bracketed Newton on the device).
+ * occ: device, n doubles.  info_host[5]: mu, |sum occ - nelec| (0 at T = 0), electrons spread over the window, levels
+ * in the window, 0.  Synchronises the stream (the caller needs mu). */
+int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double nelec, double beta, double mu0, int flags,
+                   double thr_deg, double fit_tol, double *occ, double *info_host /*[5]*/);
 int dmk_transpose_c128(dmk_ctx *ctx, int rows, int cols, int batch, const void *in, void *out);
 
 /* ------------------------------------------------------------------------- */

@@ -41,6 +41,7 @@ PROTOTYPES = {
     "dmk_timer_stop": (c_int, [c_vp, P(c_dbl)]),
     "dmk_profile": (c_int, [c_vp, c_int]),
     "dmk_profile_read": (c_int, [c_vp, P(c_dbl), P(c_i64), c_int]),
+    "dmk_profile_read_flops": (c_int, [c_vp, P(c_dbl), c_int]),
     "dmk_kmesh_tables": (c_int, [_int3, c_vp, c_vp, c_vp]),
     "dmk_kconserv_table": (c_int, [_int3, c_vp]),
     "dmk_cell_add_table": (c_int, [_int3, c_int, c_vp]),
@@ -56,6 +57,7 @@ PROTOTYPES = {
     "dmk_eigh_batched_real": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmk_eigh_jacobi_real": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, P(c_int)]),
     "dmk_occ_density": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dmk_assign_occ": (c_int, [c_vp, c_i64, c_vp, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_vp, P(c_dbl)]),
     "dmk_transpose_c128": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "dmk_bath_svd": (c_int, [c_vp, _int3, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "dmk_bath_assemble": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
@@ -190,6 +192,12 @@ class Context(object):
         n = (c_i64 * len(FAMILIES))()
         self.check(lib.dmk_profile_read(self.h, ms, n, 1 if reset else 0))
         return {FAMILIES[i]: (ms[i], int(n[i])) for i in range(len(FAMILIES))}
+
+    def profile_read_flops(self, reset=True):
+        """Flop issued to the f64 matrix pipe per kernel family since the last reset (dmk_profile_read_flops)."""
+        f = (c_dbl * len(FAMILIES))()
+        self.check(lib.dmk_profile_read_flops(self.h, f, 1 if reset else 0))
+        return {FAMILIES[i]: float(f[i]) for i in range(len(FAMILIES))}
 
 
 class DevArray(object):

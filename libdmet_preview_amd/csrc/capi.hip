@@ -87,6 +87,7 @@ int dmk_destroy(dmk_ctx *ctx) {
     drain_pending(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &p : ctx->phases) (void)hipFree(p.dev);
+    for (auto &t : ctx->tile_tables) (void)hipFree(t.dev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (int w = 0; w < 3; ++w)
         if (ctx->eri_ws[w]) (void)hipFree(ctx->eri_ws[w]);
@@ -183,6 +184,14 @@ int dmk_profile_read(dmk_ctx *ctx, double *ms, int64_t *launches, int reset) {
         if (ms) ms[i] = ctx->fam_ms[i];
         if (launches) launches[i] = ctx->fam_launches[i];
         if (reset) { ctx->fam_ms[i] = 0; ctx->fam_launches[i] = 0; }
+    }
+    return DMK_OK;
+}
+int dmk_profile_read_flops(dmk_ctx *ctx, double *flops, int reset) {
+    if (!ctx) return DMK_ERR_INVALID;
+    for (int i = 0; i < DMK_FAM_COUNT; ++i) {
+        if (flops) flops[i] = ctx->fam_mfma_flops[i];
+        if (reset) ctx->fam_mfma_flops[i] = 0;
     }
     return DMK_OK;
 }

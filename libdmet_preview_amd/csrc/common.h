@@ -20,6 +20,7 @@ struct dmk_ctx {
     bool profile = false;
     double fam_ms[DMK_FAM_COUNT] = {0};
     int64_t fam_launches[DMK_FAM_COUNT] = {0};
+    double fam_mfma_flops[DMK_FAM_COUNT] = {0};   // flop ISSUED to the matrix pipe (tiles launched x MFMAs per tile x 512)
     struct Pending { int fam; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
@@ -33,6 +34,9 @@ struct dmk_ctx {
     // dmk_eri_begin so that a self-consistency loop does not pay hipMalloc of it (~0.25 s) every iteration
     void *eri_ws[3] = {nullptr, nullptr, nullptr};   // planes, Ut, AO-block ring: parked between pipelines
     size_t eri_ws_bytes[3] = {0, 0, 0};
+    // tile visiting orders of the contraction kernel (dgemm_tn.hip), one per (tiles_m, tiles_n, symm)
+    struct TileTable { int tiles_m, tiles_n, symm; unsigned count; unsigned *dev; };
+    std::vector<TileTable> tile_tables;
 };
 
 int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);
@@ -58,6 +62,9 @@ struct FamScope {
     dmk_ctx *ctx; int fam; hipEvent_t a = nullptr, b = nullptr;
     FamScope(dmk_ctx *c, int f);
     ~FamScope();
+    // flop this launch issues to the f64 matrix pipe (executed, not algorithmic: 3M complex products, padded tiles,
+    // the lower tile triangle of a symmetric contraction); read back by dmk_profile_read_flops
+    void mfma_flops(double f) { if (ctx) ctx->fam_mfma_flops[fam] += f; }
 };
 
 int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out);

@@ -20,6 +20,7 @@
 // 8*(K*(M+N) + 2*M*N) bytes.
 #include "common.h"
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -162,16 +163,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_kernel(
 //     after each barrier.  Two INDEPENDENT 256-thread workgroups per CU desynchronise by themselves;
 //   * read-modify-write of C in the epilogue costs 4-7 %: every C element has exactly one writer per
 //     launch (tiles are disjoint, launches are stream ordered), so a fire-and-forget f64 atomic gives
-//     the same deterministic sum without the HBM round trip.
+//     the same deterministic sum without the HBM round trip;
+//   * round 1 ran a 2-stage ring (BK = 16) with s_waitcnt vmcnt(0) in front of every K-tile -- exactly one
+//     tile in flight, the full L2 / HBM latency exposed once per tile -- and walked the lower tile triangle
+//     row by row: 64.8 TF executed, 62 GB of HBM traffic per launch against 18 GB algorithmic (PMC).
 // Hence: 128 x 128 tile, 4 waves (wave tile 64 x 64, 16 accumulators in 128 VGPRs, no AGPR traffic),
-// BK = 16, operands by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a 2-stage ring
-// (2 x 36 KiB -> 2 workgroups per CU), one counted s_waitcnt vmcnt + ONE raw s_barrier per K-tile.
-// LDS rows keep the 128-B-mod-256-B stride (144 doubles).  Out-of-range lanes re-read clamped valid
-// columns (only masked outputs see them), so every wave issues exactly 8 loads per tile.
-// Lab, random operands, N = 32896, K = 1600: 67.6 TFLOP/s (87 % of the measured MFMA ceiling).
-// Requires K % 16 == 0, even M, N, ldx, ldy, 16-B aligned bases; otherwise the kernel above runs.
-constexpr int GBK = 16, GD = 2;
-constexpr int G_STAGE = 2 * GBK * LDS_LD;      // doubles per stage: A[16][144] | B[16][144]
+// BK = 8, operands by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a FOUR-stage ring
+// (4 x 18 KiB -> 2 workgroups per CU) with up to three tiles in flight, retired by a counted
+// s_waitcnt vmcnt(8) + ONE raw s_barrier per K-tile.  LDS rows keep the 128-B-mod-256-B stride (144 doubles).
+// Out-of-range lanes re-read clamped valid columns (only masked outputs see them), so every wave issues
+// exactly 4 loads per tile.
+// Tile order: a host-built table (cached in the context per shape) walks 8 x 8 SUPER-BLOCKS of tiles; the 64
+// workgroups resident on one XCD (32 CUs x 2; xcd_remap hands each XCD a contiguous range of logical ids) are
+// then one super-block: they stream 8 + 8 operand panels through that XCD's L2 instead of 1 + 64.
+// Requires K % 8 == 0, even M, N, ldx, ldy, 16-B aligned bases; otherwise the kernel above runs.
+constexpr int GBK = 8, GD = 4;
+constexpr int G_STAGE = 2 * GBK * LDS_LD;      // doubles per stage: A[8][144] | B[8][144]
 
 // SYMM (X == Y, M == N): C is symmetric, so only tiles with tm >= tn are computed; an off-diagonal tile is
 // also added, transposed, to C[tn-tile][tm-tile] (still one writer per element).  Saves ~1/2 of the aa and bb
@@ -180,28 +187,12 @@ template <bool SYMM>
 __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
-    int tiles_m, int tiles_n, unsigned nblocks) {
+    const unsigned *__restrict__ tile_table, unsigned nblocks) {
     __shared__ __attribute__((aligned(16))) double lds[GD * G_STAGE];
 
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
-    int tm, tn;
-    if (SYMM) {
-        // lid -> (tm, tn), tm >= tn, row-major over the lower triangle
-        unsigned r = (unsigned)((sqrt(8.0 * (double)lid + 1.0) - 1.0) * 0.5);
-        while ((unsigned long long)r * (r + 1) / 2 > lid) --r;
-        while ((unsigned long long)(r + 1) * (r + 2) / 2 <= lid) ++r;
-        tm = (int)r;
-        tn = (int)(lid - (unsigned long long)r * (r + 1) / 2);
-    } else {
-        constexpr unsigned GROUP = 8;
-        const unsigned per_group = GROUP * (unsigned)tiles_n;
-        const unsigned g = lid / per_group;
-        const unsigned first_m = g * GROUP;
-        const unsigned gsize = min((unsigned)tiles_m - first_m, GROUP);
-        const unsigned in_g = lid - g * per_group;
-        tm = (int)(first_m + in_g % gsize);
-        tn = (int)(in_g / gsize);
-    }
+    const unsigned packed = tile_table[lid];
+    const int tm = (int)(packed >> 16), tn = (int)(packed & 0xffffu);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,17 +202,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
     int ca = m0 + 2 * lane, cb = n0 + 2 * lane;
     if (ca + 1 >= M) ca = M - 2;
     if (cb + 1 >= N) cb = N - 2;
-    const double *pA = X + ca, *pB = Y + cb;
-
-    auto issue = [&](int t) {           // wave w streams K rows 4w .. 4w+3 of both operands
-        double *st = lds + (t % GD) * G_STAGE;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = wave * 4 + r;
-            const int64_t kg = (int64_t)(t * GBK + k);
-            glds16(pA + kg * ldx, lds_addr_of(st + k * LDS_LD));
-            glds16(pB + kg * ldy, lds_addr_of(st + GBK * LDS_LD + k * LDS_LD));
-        }
+    // wave w streams K rows 2w, 2w+1 of both operands; running pointers advance one K-tile per issue
+    const double *pA = X + ca + (int64_t)(2 * wave) * ldx, *pB = Y + cb + (int64_t)(2 * wave) * ldy;
+    const int64_t stepA = (int64_t)GBK * ldx, stepB = (int64_t)GBK * ldy;
+    int is_stage = 0;
+    auto issue = [&]() {
+        double *st = lds + is_stage * G_STAGE + (2 * wave) * LDS_LD;
+        glds16(pA, lds_addr_of(st));
+        glds16(pA + ldx, lds_addr_of(st + LDS_LD));
+        glds16(pB, lds_addr_of(st + GBK * LDS_LD));
+        glds16(pB + ldy, lds_addr_of(st + GBK * LDS_LD + LDS_LD));
+        pA += stepA;
+        pB += stepB;
+        is_stage = is_stage + 1 == GD ? 0 : is_stage + 1;
     };
 
     d4_t acc[4][4];
@@ -231,13 +224,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
         for (int j = 0; j < 4; ++j) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
 
     const int T = K / GBK;
-    issue(0);
+    issue();
+    if (T > 1) issue();
+    if (T > 2) issue();
+    int c_stage = 0;
     for (int t = 0; t < T; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t has landed (nothing newer is in flight)
+        const int later = T - 1 - t;
+        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile t landed; t+1, t+2 may be in flight
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is done with tile t-1
-        if (t + 1 < T) issue(t + 1);                          // overwrite the stage tile t-1 lived in
-        const double *Ab = lds + (t % GD) * G_STAGE + wm * 64 + frag_x;
-        const double *Bb = lds + (t % GD) * G_STAGE + GBK * LDS_LD + wn * 64 + frag_x;
+        if (t + 3 < T) issue();                               // overwrite the stage tile t-1 lived in
+        const double *Ab = lds + c_stage * G_STAGE + wm * 64 + frag_x;
+        const double *Bb = lds + c_stage * G_STAGE + GBK * LDS_LD + wn * 64 + frag_x;
+        c_stage = c_stage + 1 == GD ? 0 : c_stage + 1;
 #pragma unroll
         for (int kk = 0; kk < GBK / 4; ++kk) {
             double a[4], b[4];
@@ -274,6 +274,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
 
 }  // namespace
 
+// Tile visiting order of the LDS-DMA kernel: 8 x 8 super-blocks of tiles, super-block rows walked in a serpentine
+// (the 8 B panels at a row end are reused by the next row), tiles inside a super-block column by column; SYMM keeps
+// tm >= tn only.  Packed (tm << 16 | tn); built once per shape and parked in the context.
+static const unsigned *dgemm_tile_table(dmk_ctx *ctx, int tiles_m, int tiles_n, bool symm, unsigned *count_out) {
+    for (auto &t : ctx->tile_tables)
+        if (t.tiles_m == tiles_m && t.tiles_n == tiles_n && t.symm == (int)symm) {
+            *count_out = t.count;
+            return t.dev;
+        }
+    int SB = 8;
+    if (const char *e = getenv("DMK_DGEMM_SUPER")) SB = atoi(e) > 0 ? atoi(e) : 8;     // ablation: 1 = plain row-major order
+    std::vector<unsigned> h;
+    const int sm = (tiles_m + SB - 1) / SB, sn = (tiles_n + SB - 1) / SB;
+    for (int Tm = 0; Tm < sm; ++Tm) {
+        const int ncol = symm ? Tm + 1 : sn;
+        for (int c = 0; c < ncol; ++c) {
+            const int Tn = (Tm & 1) ? ncol - 1 - c : c;
+            for (int jn = 0; jn < SB; ++jn)
+                for (int im = 0; im < SB; ++im) {
+                    const int tm = Tm * SB + im, tn = Tn * SB + jn;
+                    if (tm >= tiles_m || tn >= tiles_n || (symm && tn > tm)) continue;
+                    h.push_back(((unsigned)tm << 16) | (unsigned)tn);
+                }
+        }
+    }
+    unsigned *dev = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&dev), h.size() * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemcpy(dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(dev);
+        return nullptr;
+    }
+    ctx->tile_tables.push_back({tiles_m, tiles_n, (int)symm, (unsigned)h.size(), dev});
+    *count_out = (unsigned)h.size();
+    return dev;
+}
+
 int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
                         int64_t ldx, const double *Y, int64_t ldy, double *C, int64_t ldc) {
     if (M <= 0 || N <= 0 || K <= 0) return DMK_OK;
@@ -284,21 +320,26 @@ int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const d
                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
     static const bool dma_enabled = [] { const char *e = getenv("DMK_DGEMM_DMA"); return !(e && atoi(e) == 0); }();
-    if (dma_enabled && vec2 && (K % GBK) == 0 && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2) {
+    if (dma_enabled && vec2 && (K % GBK) == 0 && K >= GBK && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2 &&
+        tiles_m < 65536 && tiles_n < 65536) {
         static const bool symm_enabled = [] { const char *e = getenv("DMK_DGEMM_SYMM"); return !(e && atoi(e) == 0); }();
+        const bool symm = symm_enabled && X == Y && ldx == ldy && M == N && tiles_m >= 2;
+        unsigned count = 0;
+        const unsigned *table = dgemm_tile_table(ctx, tiles_m, tiles_n, symm, &count);
+        if (!table) return dmk_fail(ctx, DMK_ERR_NOMEM, "dgemm_tn: tile table allocation failed");
         FamScope fs(ctx, DMK_FAM_DGEMM);
-        if (symm_enabled && X == Y && ldx == ldy && M == N && tiles_m >= 2) {
-            const int64_t ntri = (int64_t)tiles_m * (tiles_m + 1) / 2;
-            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<true>, dim3((unsigned)ntri), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                               alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n, (unsigned)ntri);
-        } else {
-            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<false>, dim3((unsigned)nblocks), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                               alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n, (unsigned)nblocks);
-        }
+        fs.mfma_flops(2.0 * (double)count * BM * BN * (double)K);
+        if (symm)
+            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<true>, dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K,
+                               alpha, X, ldx, Y, ldy, C, ldc, table, count);
+        else
+            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<false>, dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K,
+                               alpha, X, ldx, Y, ldy, C, ldc, table, count);
         DMK_CHECK_LAUNCH(ctx);
         return DMK_OK;
     }
     FamScope fs(ctx, DMK_FAM_DGEMM);
+    fs.mfma_flops(2.0 * (double)nblocks * BM * BN * (double)(((K + BK - 1) / BK) * BK));
     if (vec2)
         hipLaunchKernelGGL(dgemm_tn_acc_kernel<true>, dim3((unsigned)nblocks), dim3(NTHREADS), 0,
                            ctx->stream, M, N, K, alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n);

@@ -346,6 +346,8 @@ int launch_cfg(dmk_ctx *ctx, ZArgs &a, const ZGemm &g, int fam) {
     if (nblocks > 0x7fffffffLL) return dmk_fail(ctx, DMK_ERR_INVALID, "zgemm: grid too large");
     a.nblocks = (unsigned)nblocks;
     FamScope fs(ctx, fam);
+    // upper bound: 16 x 16 blocks beyond the matrix edge are skipped inside a tile
+    fs.mfma_flops((M3 ? 6.0 : 8.0) * (double)nblocks * BM * BN * (double)(((g.K + 3) / 4) * 4) * (double)g.nseg);
     switch (g.epi) {
         case ZEPI_STORE:
             hipLaunchKernelGGL((zgemm_kernel<TM, TN, ZEPI_STORE, M3>), dim3(a.nblocks), dim3(NTHREADS), 0, ctx->stream, a);

@@ -556,6 +556,7 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     if ((unsigned long long)a.per_slot * (unsigned)nslot > 0x7fffffffull) return 0;
     a.nblocks = a.per_slot * (unsigned)nslot;
     FamScope fs(ctx, fam);
+    fs.mfma_flops((ZHOT_3M ? 6.0 : 8.0) * (double)a.nblocks * H1_BM * H1_BN * (double)K);
     if (conjB) hipLaunchKernelGGL(half1_kernel<true>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL(half1_kernel<false>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
@@ -656,6 +657,11 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.nblocks = (unsigned)(4 * nL * nspin);
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
+    {   // 136 of the 256 16 x 16 blocks per L and spin; a block with the time-reversal partner term runs two segments
+        double segs = 0.0;
+        for (int i = 0; i < nslot; ++i) segs += sym[i] ? 2.0 : 1.0;
+        fs.mfma_flops((ZHOT_3M ? 6.0 : 8.0) * 136.0 * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
+    }
     hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;

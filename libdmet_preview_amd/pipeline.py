@@ -110,18 +110,16 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
                                              sysm.d_Fock_k.offset((s * nk + k) * n * n, (n, n)).ptr, n * n * 16))
     d_w, d_Vt = mfd.eigh_dev(ctx, d_F, n, spin * nloc, sysm.d_vcor, nloc)
     t = _stage(ctx, timers, "diag", t)
-    ew_loc = d_w.get().reshape(spin, nloc, n)
-    if world > 1:
-        ew = np.zeros((spin, nk, n))
-        ew[:, kmine] = ew_loc
-        ew = dist.all_reduce_sum_numpy(ew)
+    if world == 1:
+        # occupations without leaving the device: no D2H of the eigenvalues, no host sort (csrc/occ.hip)
+        d_occ, mu, nerr = mfd.assignocc_dev(ctx, d_w, spin * nk * n * sysm.filling, np.inf)
     else:
-        ew = ew_loc
-    nelec = mfd.check_nelec(ew.size * sysm.filling, None)[0]
-    ew_sorted = np.sort(ew, axis=None, kind="mergesort")
-    mu0 = 0.5 * (ew_sorted[nelec - 1] + ew_sorted[nelec])
-    ewocc, mu, nerr = mfd.assignocc(ew, nelec, np.inf, mu0)
-    d_occ = ctx.to_device(np.ascontiguousarray(ewocc[:, kmine]).reshape(spin * nloc, n), np.float64)
+        ew = np.zeros((spin, nk, n))
+        ew[:, kmine] = d_w.get().reshape(spin, nloc, n)
+        d_all = ctx.to_device(dist.all_reduce_sum_numpy(ew))
+        d_occ_all, mu, nerr = mfd.assignocc_dev(ctx, d_all, spin * nk * n * sysm.filling, np.inf)
+        occ_all = d_occ_all.get()
+        d_occ = ctx.to_device(np.ascontiguousarray(occ_all[:, kmine]).reshape(spin * nloc, n), np.float64)
     t = _stage(ctx, timers, "occupations", t)
     d_rho = mfd.density_dev(ctx, d_Vt, d_occ, n, spin * nloc)
     t = _stage(ctx, timers, "density", t)
@@ -131,7 +129,7 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
     if dist.is_initialized():
         dist.all_reduce_sum_dev(d_rhoR)
         t = _stage(ctx, timers, "allreduce_rho", t)
-    return d_rhoR, {"mu": mu, "ew": ew, "occ": ewocc}
+    return d_rhoR, {"mu": mu, "ew": d_w, "occ": d_occ, "nerr": nerr}
 
 
 def bath_stage(ctx, sysm, d_rhoR, timers=None, tol_bath=1e-9):

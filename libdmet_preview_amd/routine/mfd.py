@@ -5,9 +5,8 @@ k-point diagonalisation, density build and k->R fold running on the MI355X throu
   DiagRHF / DiagUHF / DiagRHF_symm / DiagUHF_symm   mfd.py:33-108  -> dmk_eigh_batched (all k, s in one launch)
   DiagGHF[_symm] / DiagBdG[symm]                    mfd.py:591-641, 429-478 -> same kernel on (2 nlo) matrices
   HF                                                mfd.py:235-427 -> + dmk_occ_density + dmk_fold_k2R
-  assignocc / check_nelec                           mfd.py:860-957 (host: sort + scalar root find)
-
-Occupations stay on the host like the reference's brentq (SURVEY.md section 2.2 last row).
+  assignocc / check_nelec                           mfd.py:860-957 -> dmk_assign_occ (csrc/occ.hip: order statistics by
+                                                    bit-pattern bisection, bracketed Newton for the Fermi level; no sort)
 """
 import numpy as np
 
@@ -56,6 +55,8 @@ def _vcor_mat(vcor, nspin_needed):
     v = np.asarray(vcor.get(0, True))
     if v.ndim == 2:
         v = v[None]
+    if np.iscomplexobj(v) and max_abs(v.imag) > 0.0:
+        raise NotImplementedError("complex correlation potential: the batched eigensolver adds a real k-independent shift")
     return np.ascontiguousarray(v[:nspin_needed].real, dtype=np.float64)
 
 
@@ -204,229 +205,233 @@ def DiagBdGsymm(Fock, vcor, mu, lattice, **kwargs):
 
 
 # ---------------------------------------------------------------------------------------------
-# occupations (host)
+# a4: occupations (device: csrc/occ.hip)
 # ---------------------------------------------------------------------------------------------
 
+def _is_seq(x):
+    return isinstance(x, Iterable)
+
+
 def check_nelec(nelec, ncells=None, tol=1e-5):
-    nelec_round = int(np.round(nelec))
-    if abs(nelec - nelec_round) > tol:
-        log.warn("HF: nelec is rounded to integer nelec = %d (original %.2f)", nelec_round, nelec)
-    nelec = nelec_round
+    """Electron number as an integer -- complaining when the input is more than `tol` from one -- and the electrons per
+    cell (an int when that is integral within `tol`, else a float and a warning).  mfd.py:860-885."""
+    whole = int(np.round(nelec))
+    if abs(nelec - whole) > tol:
+        log.warn("HF: electron number %.6f is not an integer; using %d", nelec, whole)
     if ncells is None:
-        nelec_per_cell = None
+        return whole, None
+    share = whole / float(ncells)
+    if abs(share - np.round(share)) <= tol:
+        share = int(np.round(share))
     else:
-        nelec_per_cell = nelec / float(ncells)
-        if abs(nelec_per_cell - np.round(nelec_per_cell)) > tol:
-            log.warn("HF: nelec per cell (%.5f) is not an integer.", nelec_per_cell)
-        else:
-            nelec_per_cell = int(np.round(nelec_per_cell))
-    return nelec, nelec_per_cell
+        log.warn("HF: %.5f electrons per cell is not an integer.", share)
+    return whole, share
+
+
+def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, fit_tol=1e-12):
+    """Occupations of ALL levels in the device array `d_ew` (one particle-number sector) without leaving the GPU:
+    returns (device occupations, mu, nerr).  mu0=None at T = 0 means "no preferred level" (the frontier mid-point)."""
+    import ctypes as C
+    n = int(d_ew.size)
+    zero_t = not (beta < np.inf)
+    if zero_t:
+        nelec = check_nelec(nelec, None)[0]
+        if nelec > n:
+            raise IndexError("assignocc: %d electrons do not fit %d levels" % (nelec, n))
+        flags = 0 if mu0 is None else 1
+    else:
+        flags = 2 if fix_mu else 0
+    d_occ = ctx.empty(d_ew.shape, np.float64)
+    info = (C.c_double * 5)()
+    ctx.check(lib.dmk_assign_occ(ctx.h, n, d_ew.ptr, float(nelec), float(beta), 0.0 if mu0 is None else float(mu0), flags,
+                                 float(thr_deg), float(fit_tol), d_occ.ptr, info))
+    if zero_t and info[2] > 0:
+        log.warn("degenerate HOMO-LUMO: %d electrons shared by %d levels within %g of mu", int(info[2]), int(info[3]), thr_deg)
+    return d_occ, float(info[0]), float(info[1])
+
+
+def _assignocc_host(ew, nelec, beta, mu0, fix_mu, fit_tol, f_occ, ncore, nvirt):
+    """Finite-T occupations with a caller-supplied smearing function or frozen core / virtual levels (the branches
+    of mfd.py:905-924 the device kernel does not cover): stable order, root of the electron count, scatter back."""
+    frozen = {"ncore": ncore, "nvirt": nvirt} if (ncore or nvirt) else {}
+    order = np.argsort(ew, axis=None, kind="stable")
+    levels = ew.ravel()[order]
+    mu = mu0 if fix_mu else ftsystem.find_mu(nelec, levels, beta, mu0=mu0, f_occ=f_occ, tol=fit_tol, **frozen)
+    occ = np.empty(ew.size)
+    occ[order] = f_occ(mu, levels, beta, **frozen)
+    return occ.reshape(ew.shape), mu, abs(occ.sum() - nelec)
 
 
 def assignocc(ew, nelec, beta, mu0=0.0, fix_mu=False, thr_deg=1e-6, Sz=None, fit_tol=1e-12,
               f_occ=ftsystem.fermi_smearing_occ, ncore=0, nvirt=0):
-    """Occupation numbers of a mean field (mfd.py:887-957). nelec is per spin for RHF, total for UHF."""
-    ew = np.asarray(ew)
-    if (Sz is None) and (not isinstance(nelec, Iterable)):
-        if beta < np.inf:
-            if ncore == 0 and nvirt == 0:
-                ew_sorted = np.sort(ew, axis=None, kind="mergesort")
-                if fix_mu:
-                    mu = mu0
-                else:
-                    mu = ftsystem.find_mu(nelec, ew_sorted, beta, mu0=mu0, tol=fit_tol, f_occ=f_occ)
-                ewocc = f_occ(mu, ew, beta)
-                nerr = abs(np.sum(ewocc) - nelec)
-            else:
-                idx = np.argsort(ew, axis=None, kind="mergesort")
-                ew_sorted = ew.ravel()[idx]
-                idx_re = np.argsort(idx, kind="mergesort")
-                if fix_mu:
-                    mu = mu0
-                else:
-                    mu = ftsystem.find_mu(nelec, ew_sorted, beta, mu0=mu0, tol=fit_tol, f_occ=f_occ,
-                                          ncore=ncore, nvirt=nvirt)
-                ewocc = f_occ(mu, ew_sorted, beta, ncore=ncore, nvirt=nvirt)[idx_re]
-                ewocc = ewocc.reshape(ew.shape)
-                nerr = abs(np.sum(ewocc) - nelec)
-        else:
-            ew_sorted = np.sort(ew, axis=None, kind="mergesort")
-            nelec = check_nelec(nelec, None)[0]
-            if np.sum(ew < mu0 - thr_deg) <= nelec and np.sum(ew <= mu0 + thr_deg) >= nelec:
-                mu = mu0
-            else:
-                mu = 0.5 * (ew_sorted[nelec - 1] + ew_sorted[nelec])
-            ewocc = 1.0 * (ew < mu - thr_deg)
-            nremain_elec = nelec - np.sum(ewocc)
-            if nremain_elec > 0:
-                remain_orb = np.logical_and(ew <= mu + thr_deg, ew >= mu - thr_deg)
-                nremain_orb = np.sum(remain_orb)
-                log.warn("degenerate HOMO-LUMO, assign fractional occupation\n"
-                         "%d electrons assigned to %d orbitals", nremain_elec, nremain_orb)
-                ewocc += (float(nremain_elec) / nremain_orb) * remain_orb
-            nerr = 0.0
-    else:
-        spin = ew.shape[0]
-        assert spin == 2
-        if not isinstance(nelec, Iterable):
-            nelec = [(nelec + Sz) * 0.5, (nelec - Sz) * 0.5]
-        if not isinstance(mu0, Iterable):
-            mu0 = [mu0 for s in range(spin)]
-        ewocc = np.empty_like(ew)
-        mu = np.zeros((spin,))
-        nerr = np.zeros((spin,))
-        for s in range(2):
-            ewocc[s], mu[s], nerr[s] = assignocc(ew[s], nelec[s], beta, mu0[s], fix_mu=fix_mu, thr_deg=thr_deg,
-                                                 fit_tol=fit_tol, f_occ=f_occ, ncore=ncore, nvirt=nvirt)
-    return ewocc, mu, nerr
+    """Occupation numbers, chemical potential and electron-number error of a mean field (mfd.py:887-957): `nelec` is
+    per spin for one sector, or -- with `Sz` or a pair -- resolved into the two spin sectors, which are then treated
+    independently.  The standard cases (T = 0; Fermi smearing without frozen levels) run on the device
+    (dmk_assign_occ); only a custom `f_occ` or frozen levels use the host root finder."""
+    ew = np.asarray(ew, dtype=np.float64)
+    if Sz is not None or _is_seq(nelec):
+        if ew.shape[0] != 2:
+            raise AssertionError("spin-resolved occupations need ew[2, ...]")
+        targets = list(nelec) if _is_seq(nelec) else [0.5 * (nelec + Sz), 0.5 * (nelec - Sz)]
+        guesses = list(mu0) if _is_seq(mu0) else [mu0, mu0]
+        sector = [assignocc(ew[s], targets[s], beta, guesses[s], fix_mu=fix_mu, thr_deg=thr_deg, fit_tol=fit_tol,
+                            f_occ=f_occ, ncore=ncore, nvirt=nvirt) for s in (0, 1)]
+        return (np.stack([sector[0][0], sector[1][0]]), np.array([sector[0][1], sector[1][1]], dtype=float),
+                np.array([sector[0][2], sector[1][2]], dtype=float))
+    zero_t = not (beta < np.inf)
+    if not zero_t and (f_occ is not ftsystem.fermi_smearing_occ or ncore or nvirt):
+        return _assignocc_host(ew, nelec, beta, mu0, fix_mu, fit_tol, f_occ, ncore, nvirt)
+    ctx = get_ctx()
+    d_occ, mu, nerr = assignocc_dev(ctx, ctx.to_device(ew), nelec, beta, mu0=mu0, fix_mu=fix_mu, thr_deg=thr_deg,
+                                    fit_tol=fit_tol)
+    return d_occ.get(), mu, nerr
 
 
 # ---------------------------------------------------------------------------------------------
 # HF
 # ---------------------------------------------------------------------------------------------
 
-def _mu0_guess(ew_sorted, nelec):
+def _frontier_guess(levels_sorted, nelec):
+    """Mid-gap level for `nelec` electrons (band edges when the sector is empty or full)."""
     if nelec <= 0:
-        return ew_sorted[0]
-    elif nelec >= len(ew_sorted):
-        return ew_sorted[-1]
-    return 0.5 * (ew_sorted[nelec - 1] + ew_sorted[nelec])
+        return levels_sorted[0]
+    if nelec >= len(levels_sorted):
+        return levels_sorted[-1]
+    return 0.5 * (levels_sorted[nelec - 1] + levels_sorted[nelec])
+
+
+def _homo_lumo(levels_sorted, mu):
+    top = len(levels_sorted) - 1
+    h = max(int(np.searchsorted(levels_sorted, mu, side="right")) - 1, 0)
+    l = min(int(np.searchsorted(levels_sorted, mu, side="left")), top)
+    return levels_sorted[h], levels_sorted[l]
+
+
+def _later_pair_members(lattice, nkpts):
+    """(k, -k) for every k whose partner -k comes EARLIER in the list: the member that inherits conj(ev(-k))
+    in the *_symm variants (mfd.py:56-66)."""
+    done, out = set(), []
+    for k in range(nkpts):
+        mk = lattice.cell_pos2idx(-lattice.cell_idx2pos(k))
+        if mk in done:
+            out.append((k, mk))
+        else:
+            done.add(k)
+    return out
 
 
 def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, scf=False, use_hcore=None,
        **kwargs):
     """
-    RHF and UHF routine for lattice problems (mfd.py:235-427).
+    Restricted / unrestricted lattice mean field at fixed Fock matrix (mfd.py:235-427): all (spin, k) blocks are
+    diagonalised in one launch, the occupations and mu come from dmk_assign_occ, the density matrix and its k -> R
+    fold are built from the eigenvectors that never leave the device.
 
-    Returns rho (spin, ncells, nao, nao), mu, E (per cell, with vcor contribution) and, with
-    ires=True, a dict with keys gap, e, coef, nerr, rho_k, E0, E, mo_occ, homo, lumo.
-    kwargs: symm, fix_mu, tol_deg, nfrac.
+    Returns rho (spin, ncells, nao, nao), mu, E (per cell, with the vcor contribution) and, with ires=True, a dict
+    with keys gap, e, coef, nerr, rho_k, E0, E, mo_occ, homo, lumo.  kwargs: symm, fix_mu, tol_deg, nfrac.
     """
     log.eassert(beta >= 0, "beta cannot be negative")
     if scf:
         raise NotImplementedError("scf=True needs a PySCF KSCF object (out of scope of the HIP path)")
+    if vcor is not None and not vcor.islocal():
+        raise NotImplementedError("non-local vcor")
     if use_hcore is None:
         use_hcore = lattice.use_hcore_as_emb_ham
+    H1T = lattice.getH1(kspace=False)
     if use_hcore:
-        Fock = lattice.getH1(kspace=True)
-        FockT = H1T = lattice.getH1(kspace=False)
+        Fock, FockT = lattice.getH1(kspace=True), H1T
     else:
-        Fock = lattice.getFock(kspace=True)
-        FockT = lattice.getFock(kspace=False)
-        H1T = lattice.getH1(kspace=False)
-
-    ctx = get_ctx()
-    Fock = np.asarray(Fock)
-    symm = kwargs.get("symm", False)
-    if restricted:
-        log.info("Restricted Hartree-Fock")
-        if Fock.ndim == 3:
-            Fock = Fock[np.newaxis]
-        Fock = Fock[:1]
-        spin = 1
-    else:
-        log.info("Unrestricted Hartree-Fock")
-        if Fock.ndim == 3:
-            Fock = np.asarray((Fock, Fock))
-        Fock = Fock[:2]
-        spin = 2
+        Fock, FockT = lattice.getFock(kspace=True), lattice.getFock(kspace=False)
+    spin = 1 if restricted else 2
+    log.info("Restricted Hartree-Fock" if restricted else "Unrestricted Hartree-Fock")
+    Fock = add_spin_dim(np.asarray(Fock), spin)[:spin]
     nkpts, n = Fock.shape[-3], Fock.shape[-1]
-    kmesh = lattice.kmesh
-
-    # ---- diagonalisation: every (s, k) in one launch; eigenvectors stay on the device ------
-    d_F = ctx.to_device(Fock.reshape(spin * nkpts, n, n), np.complex128)
-    v = _vcor_mat(vcor, spin)
-    d_add = ctx.to_device(v) if v is not None else None
-    d_w, d_Vt = eigh_dev(ctx, d_F, n, spin * nkpts, d_add, nkpts)
-    ew = d_w.get().reshape(spin, nkpts, n)
-    if symm:
-        neg = [lattice.cell_pos2idx(-lattice.cell_idx2pos(i)) for i in range(nkpts)]
-        computed = set()
-        for i in range(nkpts):
-            if neg[i] in computed:
-                ew[:, i] = ew[:, neg[i]]
-            else:
-                computed.add(i)
-
-    # ---- occupancy (host) --------------------------------------------------------------------
-    if isinstance(filling, Iterable):
-        nelec = [ew.size * filling[0] * 0.5, ew.size * filling[1] * 0.5]
-        nelec[0], nelec[1] = check_nelec(nelec[0], None)[0], check_nelec(nelec[1], None)[0]
-        ew_sorted = [np.sort(ew[s], axis=None, kind="mergesort") for s in range(2)]
-        if mu0 is None:
-            mu0 = [_mu0_guess(ew_sorted[0], nelec[0]), _mu0_guess(ew_sorted[1], nelec[1])]
-    else:
-        nelec = ew.size * filling
-        nelec = check_nelec(nelec, None)[0]
-        ew_sorted = np.sort(ew, axis=None, kind="mergesort")
-        if mu0 is None:
-            mu0 = _mu0_guess(ew_sorted, nelec)
-
+    nlev = spin * nkpts * n
+    symm = bool(kwargs.get("symm", False))
     fix_mu = kwargs.get("fix_mu", False)
     tol_deg = kwargs.get("tol_deg", 1e-6)
     nfrac = kwargs.get("nfrac", None)
-    if nfrac is None:
-        ncore = nvirt = 0
-    else:
-        if restricted:
-            ncore = nelec - nfrac
-            nvirt = ew.size - (nelec + nfrac)
-        else:
-            ncore = (nelec // 2 - nfrac)
-            nvirt = ew.size // 2 - (nelec // 2 + nfrac)
-    ewocc, mu, nerr = assignocc(ew, nelec, beta, mu0, fix_mu=fix_mu, thr_deg=tol_deg, ncore=ncore, nvirt=nvirt)
+    ctx = get_ctx()
 
-    # ---- density matrix: rho_k = (ev occ) ev^H, rhoT = k2R(rho_k) --------------------------------
-    d_occ = ctx.to_device(ewocc.reshape(spin * nkpts, n), np.float64)
+    # ---- all (s, k) eigenproblems in one launch; eigenvectors stay on the device ----------------------------------
+    d_F = ctx.to_device(Fock.reshape(spin * nkpts, n, n), np.complex128)
+    v = _vcor_mat(vcor, spin)
+    d_w, d_Vt = eigh_dev(ctx, d_F, n, spin * nkpts, ctx.to_device(v) if v is not None else None, nkpts)
+    inherit = _later_pair_members(lattice, nkpts) if symm else []
+    for (k, mk) in inherit:                         # ew(k) := ew(-k) for the later member of each pair
+        for s in range(spin):
+            ctx.check(lib.dmk_memcpy_d2d(ctx.h, d_w.offset((s * nkpts + k) * n, (n,)).ptr,
+                                         d_w.offset((s * nkpts + mk) * n, (n,)).ptr, n * 8))
+    ew = d_w.get().reshape(spin, nkpts, n)
+
+    # ---- occupations on the device ----------------------------------------------------------------------------------
+    two_sectors = _is_seq(filling)
+    if two_sectors:
+        if spin != 2:
+            raise AssertionError("a filling per spin needs an unrestricted calculation")
+        nelec = [check_nelec(nlev * filling[s] * 0.5, None)[0] for s in (0, 1)]
+        ew_sorted = [np.sort(ew[s], axis=None, kind="stable") for s in (0, 1)]
+        if mu0 is None:
+            mu0 = [_frontier_guess(ew_sorted[s], nelec[s]) for s in (0, 1)]
+        frozen = (0, 0) if nfrac is None else (nelec[0] // 2 - nfrac, nlev // 2 - (nelec[0] // 2 + nfrac))
+    else:
+        nelec = check_nelec(nlev * filling, None)[0]
+        ew_sorted = np.sort(ew, axis=None, kind="stable")
+        if mu0 is None:
+            mu0 = _frontier_guess(ew_sorted, nelec)
+        if nfrac is None:
+            frozen = (0, 0)
+        elif restricted:
+            frozen = (nelec - nfrac, nlev - (nelec + nfrac))
+        else:
+            frozen = (nelec // 2 - nfrac, nlev // 2 - (nelec // 2 + nfrac))
+    if two_sectors or frozen != (0, 0):
+        ewocc, mu, nerr = assignocc(ew, nelec, beta, mu0, fix_mu=fix_mu, thr_deg=tol_deg, ncore=frozen[0], nvirt=frozen[1])
+        d_occ = ctx.to_device(ewocc.reshape(spin * nkpts, n), np.float64)
+    else:
+        d_occ, mu, nerr = assignocc_dev(ctx, d_w, nelec, beta, mu0=mu0, fix_mu=fix_mu, thr_deg=tol_deg)
+        ewocc = d_occ.get().reshape(spin, nkpts, n)
+
+    # ---- rho_k = (ev occ) ev^H, rhoT = k2R(rho_k) ----------------------------------------------------------------------
     d_rho = density_dev(ctx, d_Vt, d_occ, n, spin * nkpts)
+    for (k, mk) in inherit:
+        # ev(k) = conj(ev(-k)) and equal occupations: rho(k) = conj(rho(-k)) = rho(-k)^T (rho is Hermitian)
+        for s in range(spin):
+            ctx.check(lib.dmk_transpose_c128(ctx.h, n, n, 1, d_rho.offset((s * nkpts + mk) * n * n, (n, n)).ptr,
+                                             d_rho.offset((s * nkpts + k) * n * n, (n, n)).ptr))
     d_imax = ctx.zeros((1,), np.float64)
-    d_rhoT = fourier.fold_k2R_dev(d_rho.reshape(spin, nkpts, n * n), kmesh, spin, n * n, imag_max=d_imax)
+    d_rhoT = fourier.fold_k2R_dev(d_rho.reshape(spin, nkpts, n * n), lattice.kmesh, spin, n * n, imag_max=d_imax)
     rhoT = d_rhoT.get().reshape(spin, nkpts, n, n)
     imag = float(d_imax.get()[0])
     if imag > IMAG_DISCARD_TOL:
+        # the reference keeps the complex array in this case (system/fourier.py:168-177)
         log.warn("k2R: non-zero imaginary part: %15.8g", imag)
+        rhoT = fourier.FFTtoT(d_rho.get().reshape(spin, nkpts, n, n), lattice.kmesh, tol=IMAG_DISCARD_TOL)
 
-    # ---- energy -------------------------------------------------------------------------------
-    FockT = add_spin_dim(FockT, spin)
-    H1T = add_spin_dim(H1T, spin)
-    vcorT = None if vcor is None else np.asarray(vcor.get(0, kspace=False))
-    if vcor is not None and not vcor.islocal():
-        raise NotImplementedError("non-local vcor")
-    if spin == 1:
-        E0 = np.sum((FockT + H1T) * rhoT) + lattice.getH0()
-        E = E0 + (np.sum(vcorT[0] * rhoT[0, 0]) if vcorT is not None else 0.0)
-    else:
-        E0 = 0.5 * np.sum((FockT + H1T) * rhoT) + lattice.getH0()
-        E = E0 + (0.5 * np.sum(vcorT[0] * rhoT[0, 0] + vcorT[1] * rhoT[1, 0]) if vcorT is not None else 0.0)
+    # ---- energy per cell ------------------------------------------------------------------------------------------------
+    FockT, H1T = add_spin_dim(FockT, spin), add_spin_dim(H1T, spin)
+    weight = 1.0 if spin == 1 else 0.5
+    E0 = weight * np.sum((FockT + H1T) * rhoT) + lattice.getH0()
+    E = E0
+    if vcor is not None:
+        vcorT = np.asarray(vcor.get(0, kspace=False))
+        E = E0 + weight * sum(np.sum(vcorT[s] * rhoT[s, 0]) for s in range(spin))
     if max_abs(np.imag(E)) > IMAG_DISCARD_TOL:
         log.warn("E.imag = %e", np.imag(E))
     E = float(np.real(E))
+    if not ires:
+        return rhoT, mu, E
 
-    if ires:
-        rho = d_rho.get().reshape(spin, nkpts, n, n)
-        ev = _vt_to_ev(ctx, d_Vt, n, spin * nkpts).get().reshape(spin, nkpts, n, n)
-        if symm:
-            computed = set()
-            for i in range(nkpts):
-                if neg[i] in computed:
-                    ev[:, i] = ev[:, neg[i]].conj()
-                else:
-                    computed.add(i)
-        if isinstance(mu, Iterable):
-            homo, lumo = [], []
-            for s in range(2):
-                hi = max(np.searchsorted(ew_sorted[s], mu[s], side="right") - 1, 0)
-                li = min(np.searchsorted(ew_sorted[s], mu[s], side="left"), len(ew_sorted[s]) - 1)
-                homo.append(ew_sorted[s][hi])
-                lumo.append(ew_sorted[s][li])
-            gap = np.array((lumo[0] - homo[0], lumo[1] - homo[1]))
-            homo, lumo = tuple(homo), tuple(lumo)
-        else:
-            hi = max(np.searchsorted(ew_sorted, mu, side="right") - 1, 0)
-            li = min(np.searchsorted(ew_sorted, mu, side="left"), len(ew_sorted) - 1)
-            homo, lumo = ew_sorted[hi], ew_sorted[li]
-            gap = lumo - homo
-        res = {"gap": gap, "e": ew, "coef": ev, "nerr": nerr, "rho_k": rho, "E0": E0, "E": E,
-               "mo_occ": ewocc, "homo": homo, "lumo": lumo}
-        return rhoT, mu, E, res
-    return rhoT, mu, E
+    ev = _vt_to_ev(ctx, d_Vt, n, spin * nkpts).get().reshape(spin, nkpts, n, n)
+    for (k, mk) in inherit:
+        ev[:, k] = ev[:, mk].conj()
+    if _is_seq(mu):
+        edges = [_homo_lumo(ew_sorted[s], mu[s]) for s in (0, 1)]
+        homo, lumo = (edges[0][0], edges[1][0]), (edges[0][1], edges[1][1])
+        gap = np.array((lumo[0] - homo[0], lumo[1] - homo[1]))
+    else:
+        homo, lumo = _homo_lumo(ew_sorted, mu)
+        gap = lumo - homo
+    res = {"gap": gap, "e": ew, "coef": ev, "nerr": nerr, "rho_k": d_rho.get().reshape(spin, nkpts, n, n), "E0": E0, "E": E,
+           "mo_occ": ewocc, "homo": homo, "lumo": lumo}
+    return rhoT, mu, E, res

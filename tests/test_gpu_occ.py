@@ -1,0 +1,98 @@
+"""
+GPU parity of the device occupation assignment (csrc/occ.hip, dmk_assign_occ) against the oracle's restatement of
+the reference's assignocc / fermi_smearing_occ / find_mu (routine/mfd.py:887-957, routine/ftsystem.py:24-105).
+T = 0 results (mu, occupations) must be bit-identical (order statistics are exact); finite-T mu within the
+reference's brentq tolerance (1e-12) and occupations within 1e-10.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R
+
+
+@pytest.fixture(scope="module")
+def mfd():
+    from libdmet_preview_amd.routine import mfd
+    return mfd
+
+
+def _levels(seed, shape, degenerate=False):
+    rng = np.random.default_rng(seed)
+    e = rng.standard_normal(shape)
+    if degenerate:
+        flat = e.ravel()
+        order = np.argsort(flat)
+        n = flat.size // 2
+        flat[order[n - 2:n + 3]] = flat[order[n]]            # five-fold degenerate frontier
+        flat[order[n + 3]] = flat[order[n]] + 3e-7           # and one level inside the window
+    return e
+
+
+@pytest.mark.parametrize("shape,nelec,degenerate", [((2, 7, 9), 63, False), ((1, 216, 200), 21600, False), ((2, 5, 8), 40, True),
+                                                    ((2, 5, 8), 39, True), ((3, 4), 0, False), ((3, 4), 11, False), ((1, 1, 1), 0, False)])
+def test_zero_temperature_bit_exact(mfd, shape, nelec, degenerate):
+    ew = _levels(sum(shape) + nelec, shape, degenerate)
+    for mu0 in (0.0, None, 0.37):
+        ref_mu0 = mu0
+        if mu0 is None:                                      # "no preference" == the frontier mid-point the reference falls back to
+            srt = np.sort(ew, axis=None)
+            ref_mu0 = 0.5 * (srt[nelec - 1] + srt[nelec]) if 0 < nelec < ew.size else 1e300
+            if ref_mu0 == 1e300:
+                continue
+        occ_r, mu_r, _ = R.assignocc(ew, nelec, np.inf, mu0=ref_mu0, thr_deg=1e-6)
+        if mu0 is None:
+            from libdmet_preview_amd import _lib
+            ctx = _lib.get_ctx()
+            d_occ, mu, nerr = mfd.assignocc_dev(ctx, ctx.to_device(ew), nelec, np.inf, mu0=None)
+            occ = d_occ.get()
+        else:
+            occ, mu, nerr = mfd.assignocc(ew, nelec, np.inf, mu0=mu0, thr_deg=1e-6)
+        assert mu == mu_r, (mu0, mu, mu_r)
+        assert np.array_equal(occ, occ_r)
+        assert nerr == 0.0
+
+
+@pytest.mark.parametrize("beta", [3.0, 50.0, 2000.0])
+@pytest.mark.parametrize("nelec", [17.0, 31.5, 62.0])
+def test_fermi_smearing(mfd, beta, nelec):
+    ew = _levels(int(beta) + int(nelec), (2, 7, 9))
+    occ_r, mu_r, nerr_r = R.assignocc(ew, nelec, beta, mu0=0.0)
+    occ, mu, nerr = mfd.assignocc(ew, nelec, beta, mu0=0.0)
+    assert abs(mu - mu_r) < 2e-12 * (1 + abs(mu_r)), (mu, mu_r)
+    assert np.abs(occ - occ_r).max() < 1e-10
+    assert nerr < 1e-9 and abs(occ.sum() - nelec) < 1e-9
+    occ_f, mu_f, nerr_f = mfd.assignocc(ew, nelec, beta, mu0=0.123, fix_mu=True)
+    occ_fr, mu_fr, nerr_fr = R.assignocc(ew, nelec, beta, mu0=0.123, fix_mu=True)
+    assert mu_f == 0.123 and np.abs(occ_f - occ_fr).max() < 1e-14 and abs(nerr_f - nerr_fr) < 1e-10
+
+
+def test_spin_resolved_and_host_branches(mfd):
+    ew = _levels(5, (2, 6, 5))
+    for beta in (np.inf, 40.0):
+        ne = 30 if beta == np.inf else 30.0
+        o, m, e = mfd.assignocc(ew, ne, beta, mu0=0.0, Sz=2)
+        o_r, m_r, e_r = R.assignocc(ew, ne, beta, mu0=0.0, Sz=2)
+        assert np.abs(o - o_r).max() < 1e-10 and np.abs(m - m_r).max() < 1e-11 and np.abs(e - e_r).max() < 1e-9
+        o, m, e = mfd.assignocc(ew, [16, 14], beta, mu0=[0.0, 0.1])
+        o_r, m_r, e_r = R.assignocc(ew, [16, 14], beta, mu0=[0.0, 0.1])
+        assert np.abs(o - o_r).max() < 1e-10 and np.abs(m - m_r).max() < 1e-11
+    # frozen core / virtual levels and a caller-supplied smearing function take the host root finder
+    o, m, e = mfd.assignocc(ew[0], 12.0, 25.0, ncore=3, nvirt=4)
+    o_r, m_r, e_r = R.assignocc(ew[0], 12.0, 25.0, ncore=3, nvirt=4)
+    assert np.abs(o - o_r).max() < 1e-10 and abs(m - m_r) < 1e-10
+    from scipy.special import erfc
+    gauss = lambda mu, e, beta, ncore=0, nvirt=0: 0.5 * erfc((np.asarray(e) - mu) * beta)
+    o, m, e = mfd.assignocc(ew[0], 12.0, 25.0, f_occ=gauss)
+    o_r, m_r, e_r = R.assignocc(ew[0], 12.0, 25.0, f_occ=gauss)
+    assert np.abs(o - o_r).max() < 1e-10 and abs(m - m_r) < 1e-10
+
+
+def test_errors(mfd):
+    ew = _levels(1, (4, 4))
+    with pytest.raises(IndexError):
+        mfd.assignocc(ew, 17, np.inf)
+    from libdmet_preview_amd._lib import DmkError
+    with pytest.raises(DmkError):
+        mfd.assignocc(ew, 40.0, 10.0)             # more electrons than levels: no chemical potential
