@@ -77,11 +77,26 @@ def spawn_ranks(n):
 
 
 def host_threads(world):
+    """CPU threads this process may usefully run: the affinity mask, capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants a 16-CPU quota: more threads than that only time-slice and spin), split
+    over the ranks of the job."""
     n = os.cpu_count() or 1
     try:
         n = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / float(per) + 0.5)))
+        except Exception:
+            pass
     return max(1, n // max(1, world))
 
 

@@ -41,7 +41,24 @@ def lib():
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_set_threads.restype = None
         _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_set_threads(usable_cpus())
     return _lib
+
+
+def usable_cpus():
+    """Affinity mask capped by the cgroup CPU quota (a box may show 256 logical CPUs and grant 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def num_threads():

@@ -17,12 +17,25 @@ __global__ __launch_bounds__(256, 2) void k(double *out, int iters, double a0, d
     for (int i = 0; i < NA; ++i) a[i] = a0 + threadIdx.x * 1e-9 + i * 1e-3;
 #pragma unroll
     for (int j = 0; j < NB; ++j) b[j] = b0 - j * 1e-3;
+    if (MODE == 2) {
+        // operands with random mantissas and signs (what real data looks like to the multiplier array): does the
+        // sustained rate depend on the data (power management)?
+        unsigned long long h = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+        auto rnd = [&]() {
+            h ^= h >> 31; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
+            return __longlong_as_double((long long)((h & 0x800FFFFFFFFFFFFFull) | 0x3FE0000000000000ull));   // +-[0.5, 1)
+        };
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[i] = rnd();
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[j] = rnd();
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if (MODE == 0) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+                if (MODE == 0 || MODE == 2) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
                 else acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
             }
     }
@@ -59,7 +72,7 @@ void run(const char *tag) {
     CK(hipFree(out));
 }
 
-template <int NA, int NB>
+template <int NA, int NB, int MODE>
 void sustained(double seconds) {
     // the same kernel launched back to back for `seconds`: does the rate hold under sustained load (power / clock management)?
     const int blocks = 512 * 8, iters = 2000 / (NA * NB) * 40;
@@ -72,7 +85,7 @@ void sustained(double seconds) {
     int n = 0;
     while (elapsed < seconds * 1e3) {
         CK(hipEventRecord(e0));
-        k<NA, NB, 0><<<blocks, 256>>>(out, iters, 1.000001, 0.999999);
+        k<NA, NB, MODE><<<blocks, 256>>>(out, iters, 1.000001, 0.999999);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -86,12 +99,15 @@ void sustained(double seconds) {
 }
 
 int main(int argc, char **argv) {
-    if (argc > 1) { sustained<3, 8>(atof(argv[1])); return 0; }
+    if (argc > 2) { sustained<3, 8, 2>(atof(argv[1])); return 0; }
+    if (argc > 1) { sustained<3, 8, 0>(atof(argv[1])); return 0; }
     run<4, 4, 0>("asm");
     run<4, 6, 0>("asm");
     run<3, 8, 0>("asm");
     run<3, 9, 0>("asm");
     run<2, 4, 0>("asm");
+    run<4, 4, 2>("asm, random operands");
+    run<3, 8, 2>("asm, random operands");
     run<4, 4, 1>("intrinsic");
     run<3, 8, 1>("intrinsic");
     run<3, 9, 1>("intrinsic");
