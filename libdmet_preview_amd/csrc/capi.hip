@@ -88,6 +88,7 @@ int dmk_destroy(dmk_ctx *ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto &p : ctx->phases) (void)hipFree(p.dev);
     for (auto &t : ctx->tile_tables) (void)hipFree(t.dev);
+    for (auto &t : ctx->step2_tables) (void)hipFree(t.dev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     for (int w = 0; w < 3; ++w)
         if (ctx->eri_ws[w]) (void)hipFree(ctx->eri_ws[w]);
@@ -606,6 +607,7 @@ struct dmk_eri {
     // hot path: step-1 outputs of up to `group` consecutive AO blocks are queued and transformed by ONE
     // step-2 launch whose accumulators (and tril-pack epilogue) are shared by all of them
     int group = 1, pending = 0;
+    bool hot256 = false;      // step 2 by the nemb = 256 kernel (zhot.hip) instead of the table-driven one (zhot_tab.hip)
     int pend_kj[16], pend_sym[16], pend_ki[16];
     // block ring (dmk_eri_block_ring / dmk_eri_push_ring_slot): `group` AO-block buffers owned by the pipeline; blocks
     // written there are queued WITHOUT running step 1, and the flush runs ONE step-1 launch over all of them
@@ -643,11 +645,15 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         int v = atoi(e);
         if (v > 0 && v < naux) h->lchunk = v;
     }
-    if (half2_hot_usable(nao, nemb)) {
+    // grouped hot path (block queue, multi-slot launches of both half-transform steps): the specialised step-2 kernel
+    // for nemb = 256, the table-driven one for every other embedding dimension; only offered when the flattened step-1
+    // kernel covers the shape too, so a queued group can never be left without a kernel
+    h->hot256 = half2_hot_usable(nao, nemb) != 0;
+    if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(naux, nao, nemb)) {
         h->lchunk = naux;
         h->group = 8;
         if (const char *e = getenv("DMK_ERI_GROUP")) h->group = atoi(e);
-        h->group = std::max(1, std::min(h->group, half2_hot_maxslot()));
+        h->group = std::max(1, std::min(h->group, h->hot256 ? half2_hot_maxslot() : half2_tab_maxslot()));
     }
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
     // generic path: Ut is followed by the step-2 product P (lchunk x nemb x nemb) of the flattened kernel
@@ -722,9 +728,9 @@ static int eri_flush(dmk_eri *h) {
     const void *cj[16];
     for (int i = 0; i < h->pending; ++i)
         cj[i] = h->C + (size_t)h->pend_kj[i] * nao * nemb;
-    int rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->planes, naux, h->npair, naux,
-                              nao, nemb, h->spin, (long long)h->group * (long long)slot_elems,
-                              (long long)h->mesh.nk * nao * nemb, 2LL * naux * h->npair);
+    int rc = (h->hot256 ? launch_half2_hot : launch_half2_tab)(
+        ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->planes, naux, h->npair, naux, nao, nemb, h->spin,
+        (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb, 2LL * naux * h->npair);
     if (rc < 0) return rc;
     if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_flush: hot step-2 kernel unavailable for a queued block");
     h->pending = 0;

@@ -37,6 +37,9 @@ struct dmk_ctx {
     // tile visiting orders of the contraction kernel (dgemm_tn.hip), one per (tiles_m, tiles_n, symm)
     struct TileTable { int tiles_m, tiles_n, symm; unsigned count; unsigned *dev; };
     std::vector<TileTable> tile_tables;
+    // block-ownership tables of the general-nemb step-2 kernel (zhot_tab.hip), one per embedding dimension
+    struct StepTable { int nemb, nitems; double useful_blocks; int *dev; };
+    std::vector<StepTable> step2_tables;
 };
 
 int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);
@@ -178,3 +181,10 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);
 int half2_hot_usable(int nao, int nemb);
 int half2_hot_maxslot();
+int half1_hot_usable(int nL, int nao, int nemb);
+// step 2 for a general embedding dimension (zhot_tab.hip); same arguments and return convention as launch_half2_hot
+int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
+                     const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);
+int half2_tab_usable(int nao, int nemb);
+int half2_tab_maxslot();

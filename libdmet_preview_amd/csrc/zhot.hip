@@ -35,81 +35,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Ablation switches for tools/zhot_lab.hip only (product builds leave ZHOT_ABL at 0):
-//   1 = no LDS-DMA after the prologue, 2 = no epilogue, 4 = no barrier, 8 = no 3M operand sums, 16 = no LDS fragment reads (results wrong, timing only)
-#ifndef ZHOT_ABL
-#define ZHOT_ABL 0
-#endif
+#include "zhot_common.h"
 
 namespace {
-
-constexpr int HNT = 256;
-
-// Complex 16 x 16 x 4 tile step on the real f64 MFMA.
-//   ZHOT_3M = 1 (default): Karatsuba "3M" -- T1 += Ar Br, T2 += Ai Bi, T3 += (Ar+Ai)(Br+Bi); Re = T1 - T2,
-//     Im = T3 - T1 - T2.  25 % fewer MFMAs than 4M for 1.5x the accumulator registers; with LDS-DMA there are
-//     no staging registers left in these kernels and the 24 accumulator tiles of a wave fit (254 VGPRs, no
-//     spill).  Normwise backward stable; the parity tests hold it to the same 1e-8 / 1e-10 budgets.
-//   ZHOT_3M = 0: 4M (neg:[1,0,0] supplies the minus sign of Ai Bi).
-#ifndef ZHOT_3M
-#define ZHOT_3M 1
-#endif
-struct cfrag { double2 v; double s; };      // operand fragment and (3M) re + im
-struct cacc {
-    d4_t p, q;                               // 4M: (Re, Im)   3M: (T1, T2)
-#if ZHOT_3M
-    d4_t t;                                  // 3M: T3
-#endif
-};
-__device__ __forceinline__ void cacc_zero(cacc &c) {
-    c.p = d4_t{0.0, 0.0, 0.0, 0.0};
-    c.q = d4_t{0.0, 0.0, 0.0, 0.0};
-#if ZHOT_3M
-    c.t = d4_t{0.0, 0.0, 0.0, 0.0};
-#endif
-}
-// ablation 16: fragments come from a register pair filled once (no LDS reads in the loop; timing only)
-__device__ __forceinline__ double2 lds_frag(const double2 *p) {
-#if (ZHOT_ABL & 16)
-    double2 v;
-    asm volatile("; no lds read" : "=v"(v.x), "=v"(v.y) : "v"(p));
-    return v;
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ cfrag cfrag_of(double2 v) {
-    cfrag f;
-    f.v = v;
-    f.s = (ZHOT_ABL & 8) ? v.x : v.x + v.y;      // ablation 8: no VALU add (results wrong, timing only)
-    return f;
-}
-__device__ __forceinline__ void cmfma(cacc &c, const cfrag &a, const cfrag &b) {
-#if ZHOT_3M
-    c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.x, c.p, 0, 0, 0);
-    c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.y, c.q, 0, 0, 0);
-    c.t = __builtin_amdgcn_mfma_f64_16x16x4f64(a.s, b.s, c.t, 0, 0, 0);
-#else
-    c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.x, c.p, 0, 0, 0);
-    c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.y, c.q, 0, 0, 0);
-    c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.y, c.p, 0, 0, 1);
-    c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.x, c.q, 0, 0, 0);
-#endif
-}
-__device__ __forceinline__ double cacc_re(const cacc &c, int r) {
-#if ZHOT_3M
-    return c.p[r] - c.q[r];
-#else
-    return c.p[r];
-#endif
-}
-__device__ __forceinline__ double cacc_im(const cacc &c, int r) {
-#if ZHOT_3M
-    return (c.t[r] - c.p[r]) - c.q[r];
-#else
-    return c.q[r];
-#endif
-}
 
 // =============================================================================================
 // step 1: flattened M-blocks (batch L folded into M), tile 128 x 64, BK = 8, 3-stage ring (72 KiB)
@@ -207,8 +135,8 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile t landed; tile t+1 may be in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-        if (!(ZHOT_ABL & 1) && t + 2 < T) issue(t + 2);
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < T) issue(t + 2);
         const double2 *Ab = lds + (t % H1_D) * H1_STAGE + wm * 64 + frag_x;
         const double2 *Bb = lds + (t % H1_D) * H1_STAGE + H1_BK * H1_BM + wn * 32 + frag_x;
 #pragma unroll
@@ -230,15 +158,6 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     }
 
     // ---- epilogue: Ut[L][q][a] ---------------------------------------------------------------
-    if (ZHOT_ABL & 2) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) s += cacc_re(acc[i][j], 0) + cacc_im(acc[i][j], 1) + cacc_re(acc[i][j], 2) + cacc_im(acc[i][j], 3);
-        if (s == 12345.678) Osp[tid].x = s;
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int gb = tile_m * (H1_BM / 16) + wm * 4 + i;
@@ -296,22 +215,6 @@ struct H2Args {
      : (SLOT) == 4 ? (G).Cj[4] : (SLOT) == 5 ? (G).Cj[5] : (SLOT) == 6 ? (G).Cj[6] : (SLOT) == 7 ? (G).Cj[7]    \
      : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
      : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
-
-__device__ __forceinline__ void pack_acc(double *planes, long long naux, long long npair, int L, int row, int col,
-                                         double vr, double vi) {
-    if (ZHOT_ABL & 2) {
-        if (vr == 12345.678) planes[0] = vi;
-        return;
-    }
-    if (row >= col) {
-        const long long idx = (long long)row * (row + 1) / 2 + col;
-        double *pr = planes + (long long)L * npair + idx;
-        double *pi = planes + (naux + (long long)L) * npair + idx;
-        // single writer per address per launch -> deterministic; no load latency in the epilogue
-        unsafeAtomicAdd(pr, vr);
-        unsafeAtomicAdd(pi, vi);
-    }
-}
 
 __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     __shared__ __attribute__((aligned(16))) double2 lds[H2_LDS];
@@ -384,8 +287,8 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-                if (!(ZHOT_ABL & 1) && t + 3 < T) issue();
+                __builtin_amdgcn_s_barrier();
+                if (t + 3 < T) issue();
                 const double2 *U = lds + c_stage * H2T_STAGE + frag_k * 128 + frag_x;
                 c_stage = c_stage + 1 == H2T_D ? 0 : c_stage + 1;
                 const double2 *C = U + H2_BK * 128;
@@ -479,8 +382,8 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(ZHOT_ABL & 4)) __builtin_amdgcn_s_barrier();
-        if (!(ZHOT_ABL & 1) && t + 2 < T) issue();
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < T) issue();
         const double2 *Ua = lds + c_stage * H2S_STAGE + frag_k * 64 + wm * 32 + frag_x;
         const double2 *Cb = lds + c_stage * H2S_STAGE + 256 + frag_k * 128 + wn * 64 + frag_x;
         c_stage = c_stage + 1 == H2S_D ? 0 : c_stage + 1;
@@ -532,12 +435,17 @@ bool hot_enabled() {
 
 }  // namespace
 
+// shapes the flattened kernel covers when the flattened row count is nL x nao (step 1)
+int half1_hot_usable(int nL, int nao, int nemb) {
+    return hot_enabled() && (nao % H1_BK) == 0 && nao >= 2 * H1_BK && nemb >= 32 && (long long)nL * nao >= 4 * H1_BM;
+}
+
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
 static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out, int nL, int K, int mrows, int N, bool conjB,
                            int fam, int nspin = 1, long long b_spin_stride = 0, long long out_spin_stride = 0, int nslot = 1,
                            long long a_slot_stride = 0, long long out_slot_stride = 0, long long b_k_stride = 0,
                            const int *bk = nullptr) {
-    if (!hot_enabled() || (K % H1_BK) != 0 || K < 2 * H1_BK || N < 32 || (long long)nL * mrows < 4 * H1_BM) return 0;
+    if (!half1_hot_usable(nL, K, N) || (long long)nL * mrows < 4 * H1_BM) return 0;
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) return 0;
     H1Args a;
     a.Lpq = reinterpret_cast<const double2 *>(A);
@@ -556,7 +464,7 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     if ((unsigned long long)a.per_slot * (unsigned)nslot > 0x7fffffffull) return 0;
     a.nblocks = a.per_slot * (unsigned)nslot;
     FamScope fs(ctx, fam);
-    fs.mfma_flops((ZHOT_3M ? 6.0 : 8.0) * (double)a.nblocks * H1_BM * H1_BN * (double)K);
+    fs.mfma_flops(6.0 * (double)a.nblocks * H1_BM * H1_BN * (double)K);
     if (conjB) hipLaunchKernelGGL(half1_kernel<true>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL(half1_kernel<false>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
@@ -660,7 +568,7 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     {   // 136 of the 256 16 x 16 blocks per L and spin; a block with the time-reversal partner term runs two segments
         double segs = 0.0;
         for (int i = 0; i < nslot; ++i) segs += sym[i] ? 2.0 : 1.0;
-        fs.mfma_flops((ZHOT_3M ? 6.0 : 8.0) * 136.0 * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
+        fs.mfma_flops(6.0 * 136.0 * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
     }
     hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);

@@ -1,0 +1,354 @@
+// K6 hot step 2 for a GENERAL embedding dimension (any nemb >= 32; nemb == 256 keeps its specialised kernel in zhot.hip).
+//
+//   S_L[a][b] = sum_q Ut[L][q][a] C_j[q][b] (+ sum_q C_j[q][a] Ut[L][q][b]),  a >= b, tril-packed and ACCUMULATED
+//   into the Re / Im planes of Lij_s4              reference: basis_transform/eri_transform.py:368-378, 403-434
+//
+// The reference's r_e2 is shape agnostic; round 1 only had the LDS-DMA ring kernels for nemb = 256 and sent every
+// other embedding size (C4: nemb = 136) through the generic register-staged zgemm, one launch per AO block and spin
+// (0.1 - 0.3 ms launches: ramp-up / drain bound, 23 TF algorithmic).  This kernel keeps the structure that made the
+// 256 kernel fast -- operands by LDS-DMA into a 3-4 stage ring retired by counted s_waitcnt, ONE barrier per K step,
+// 3M complex product, two 256-thread workgroups per CU, the ring running straight through up to 16 queued AO blocks,
+// fire-and-forget atomics with one writer per plane element -- and replaces its hard-wired block ownership by a
+// host-built TABLE (cached in the context per nemb):
+//   * the lower triangle of the nb x nb grid of 16 x 16 blocks (nb = ceil(nemb / 16)) is cut along segments of 7
+//     blocks into diagonal TRIANGLES (<= 28 blocks, operand panels U[.][128], C[.][128]: 16 KiB per stage, 4 stages)
+//     and off-diagonal RECTANGLES of <= 4 x 7 blocks (panels Ua[.][64], Cb[.][128], Ca[.][64], Ub[.][128]: 24 KiB per
+//     stage, 3 stages) -- one workgroup per item and auxiliary index L;
+//   * inside an item every wave owns an explicit list of <= 8 blocks (an even row-major split of the item's blocks),
+//     read from the table into SGPRs; a block costs two (with the
+//     time-reversal partner four) fragment reads per K step instead of sharing them along a row -- 42 B/clk/CU of LDS
+//     bandwidth against 128 available -- in exchange for ONE code path for every shape.
+//   * embedding spaces of up to 12 blocks (nemb <= 192) use WIDE items instead: panels U[.][192], C[.][192] over the
+//     whole matrix (24 KiB per stage, 3 stages) and the triangle's blocks dealt out evenly -- no light workgroups.
+//   Block efficiency (useful blocks / 4 waves x longest list): nemb 136 -> 94 %, 200 -> 95 %, 272 -> 93 %.
+// Panels wider than the matrix re-read clamped valid columns; they only ever feed masked outputs.
+#include "common.h"
+#include <cstdlib>
+#include <vector>
+
+#include "zhot_common.h"
+
+namespace {
+
+constexpr int T_BK = 4;
+constexpr int T_MAXSLOT = 16;
+constexpr int T_ITEM = 48;                             // ints per table item
+constexpr int T_MAXBLK = 8;                            // accumulator tiles per wave (192 VGPRs + double-buffered fragments)
+constexpr int T_SEG = 7;                               // blocks per segment: a 7-wide triangle is 28 blocks = 4 waves x 7
+constexpr int TD_STAGE = T_BK * 256, TD_D = 4;         // diagonal item: U[4][128] | C[4][128]                        (16 KiB)
+constexpr int TR_STAGE = T_BK * 384, TR_D = 3;         // rectangle:     Ua[4][64] | Cb[4][128] | Ca[4][64] | Ub[4][128] (24 KiB)
+constexpr int TW_STAGE = T_BK * 384, TW_D = 3;         // wide item:     U[4][192] | C[4][192]  (whole matrix, nemb <= 192) (24 KiB)
+constexpr int T_WIDE_MAXNB = 12;
+static_assert(TW_STAGE == TR_STAGE && TW_D == TR_D, "wide items share the rectangle's ring geometry");
+constexpr int T_LDS = (TR_STAGE * TR_D > TD_STAGE * TD_D) ? TR_STAGE * TR_D : TD_STAGE * TD_D;
+
+struct H2TArgs {
+    const double2 *Ut;               // [nslot][nL][nao][nemb]
+    const double2 *Cj[T_MAXSLOT];    // [nao][nemb] of each queued block
+    unsigned symmask;
+    long long slot_stride;
+    double *planes;
+    long long naux, npair;
+    int nL, nao, nslot, nemb;
+    unsigned nblocks;
+    int nspin;
+    long long ut_spin_stride, cj_spin_stride, planes_spin_stride;
+    const int *table;                // nitems x T_ITEM: kind, R0, C0, nblk[4], pad, entries[4][8] = (row block << 8) | col block (local)
+    int nitems;
+};
+
+// kernel-argument arrays are only ever indexed by constants (see zhot.hip)
+#define T_PICK_CJ(G, SLOT)                                                                         \
+    ((SLOT) == 0 ? (G).Cj[0] : (SLOT) == 1 ? (G).Cj[1] : (SLOT) == 2 ? (G).Cj[2] : (SLOT) == 3 ? (G).Cj[3]      \
+     : (SLOT) == 4 ? (G).Cj[4] : (SLOT) == 5 ? (G).Cj[5] : (SLOT) == 6 ? (G).Cj[6] : (SLOT) == 7 ? (G).Cj[7]    \
+     : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
+     : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
+
+__global__ __launch_bounds__(HNT, 2) void half2_tab_kernel(const H2TArgs g) {
+    __shared__ __attribute__((aligned(16))) double2 lds[T_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frag_k = lane >> 4, frag_x = lane & 15;
+    const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
+    const int Lall = (int)(lid / (unsigned)g.nitems), item = (int)(lid - (unsigned)Lall * (unsigned)g.nitems);
+    const int sp = Lall >= g.nL ? 1 : 0;
+    const int L = Lall - sp * g.nL;
+    const long long nemb = g.nemb;
+    const int Tb = g.nao / T_BK;
+    const int T = Tb * g.nslot;
+    const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb;
+    double *const g_planes = g.planes + (long long)sp * g.planes_spin_stride;
+    const long long cj_off = (long long)sp * g.cj_spin_stride;
+    const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
+    const unsigned g_symmask = g.symmask;
+
+    // ---- this workgroup's item and this wave's block list (wave-uniform: SGPRs) ----------------------------------
+    const int *it = g.table + (long long)item * T_ITEM;
+    const int kind = __builtin_amdgcn_readfirstlane(it[0]);
+    const int R0 = __builtin_amdgcn_readfirstlane(it[1]), C0 = __builtin_amdgcn_readfirstlane(it[2]);
+    const int nblk = __builtin_amdgcn_readfirstlane(it[3 + wave]);
+    int ro[T_MAXBLK], co[T_MAXBLK];              // local element offsets of each block inside the row / column panels
+#pragma unroll
+    for (int i = 0; i < T_MAXBLK; ++i) {
+        const int e = __builtin_amdgcn_readfirstlane(it[8 + wave * T_MAXBLK + i]);
+        ro[i] = (e >> 8) * 16;
+        co[i] = (e & 255) * 16;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the table reads must not sit in the counted DMA ring
+
+    const int r0 = R0 * 16, c0 = C0 * 16;
+    auto clampcol = [&](int c) { return c < g.nemb ? c : g.nemb - 1; };
+
+    // The whole item, specialised on its kind and on the LENGTH of this wave's block list: with a static list length the
+    // K step is straight-line code (the compiler software-pipelines the fragment reads under the MFMAs) and the
+    // accumulators are exactly 24 NB registers.  (A single loop with `if (i < nblk)` around every block made hipcc spill
+    // 630 VGPRs once the reads were pipelined by hand, and left every block with an exposed ds_read round trip when
+    // they were not: 37 TF on the pipe at C4 shapes.)
+    auto run = [&](auto kindtag, auto nbtag) {
+        constexpr int KIND = decltype(kindtag)::value, NB = decltype(nbtag)::value;
+        constexpr int STAGE = KIND == 0 ? TD_STAGE : TR_STAGE, D = KIND == 0 ? TD_D : TR_D;      // TW_* == TR_*
+        constexpr int NP = KIND == 0 ? 4 : 6;                            // LDS-DMA pieces per wave and stage
+        // panel offsets inside a stage and panel widths (complex elements)
+        constexpr int PUA = 0, PCB = KIND == 0 ? 512 : KIND == 1 ? 256 : 768, PCA = KIND == 0 ? 512 : 768,
+                      PUB = KIND == 1 ? 1024 : 0;
+        constexpr int PWR = KIND == 0 ? 128 : KIND == 1 ? 64 : 192, PWC = KIND == 2 ? 192 : 128;
+
+        long long soff[NP];
+        int isC[NP];
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const int piece = wave + 4 * h;
+            int row, col;
+            if (KIND == 0) {
+                // 16 pieces of 64 complex: piece p < 8 -> U row p/2, half p%2 ; p >= 8 -> C likewise
+                row = (piece & 7) >> 1; col = r0 + (piece & 1) * 64 + lane; isC[h] = piece >= 8;
+            } else if (KIND == 2) {
+                // 24 pieces: piece p < 12 -> U row p/3, third p%3 ; p >= 12 -> C likewise (the whole matrix width)
+                const int q = piece >= 12 ? piece - 12 : piece;
+                row = q / 3; col = (q % 3) * 64 + lane; isC[h] = piece >= 12;
+            } else {
+                // 24 pieces: 0-3 Ua rows, 4-11 Cb (row*2+half), 12-15 Ca rows, 16-23 Ub (row*2+half)
+                if (piece < 4) { row = piece; col = r0 + lane; isC[h] = 0; }
+                else if (piece < 12) { row = (piece - 4) >> 1; col = c0 + ((piece - 4) & 1) * 64 + lane; isC[h] = 1; }
+                else if (piece < 16) { row = piece - 12; col = r0 + lane; isC[h] = 1; }
+                else { row = (piece - 16) >> 1; col = c0 + ((piece - 16) & 1) * 64 + lane; isC[h] = 0; }
+            }
+            soff[h] = (long long)row * nemb + clampcol(col);
+        }
+        int is_t = 0, is_slot = 0, is_stage = 0;
+        const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, 0) + cj_off;
+        auto issue = [&]() {
+            double2 *st = lds + is_stage * STAGE;
+#pragma unroll
+            for (int h = 0; h < NP; ++h) glds16((isC[h] ? is_cb : is_ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+            is_stage = is_stage + 1 == D ? 0 : is_stage + 1;
+            if (++is_t == Tb) {
+                is_t = 0;
+                ++is_slot;
+                is_ub = Ubase + (long long)is_slot * g_slot_stride;
+                is_cb = T_PICK_CJ(g, is_slot) + cj_off;
+            } else {
+                is_ub += T_BK * nemb;
+                is_cb += T_BK * nemb;
+            }
+        };
+
+        cacc acc[NB > 0 ? NB : 1];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) cacc_zero(acc[i]);
+
+        issue();
+        if (T > 1) issue();
+        if (D == 4 && T > 2) issue();
+        int c_t = 0, c_stage = 0;
+        unsigned c_sym = g_symmask & 1u, c_mask = g_symmask;
+        for (int t = 0; t < T; ++t) {
+            const int later = T - 1 - t;
+            if (D == 4) {
+                if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (later >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (t + D - 1 < T) issue();
+            const double2 *st = lds + c_stage * STAGE;
+            c_stage = c_stage + 1 == D ? 0 : c_stage + 1;
+            if (NB > 0) {
+                const double2 *rowU = st + PUA + frag_k * PWR + frag_x, *colC = st + PCB + frag_k * PWC + frag_x;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {                          // S[a][b] += U[q][a] C[q][b]
+                    const cfrag a = cfrag_of(lds_frag(rowU + ro[i])), b = cfrag_of(lds_frag(colC + co[i]));
+                    cmfma(acc[i], a, b);
+                }
+                if (c_sym) {
+                    const double2 *rowC = st + PCA + frag_k * PWR + frag_x, *colU = st + PUB + frag_k * PWC + frag_x;
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {                      // S[a][b] += C[q][a] U[q][b]
+                        const cfrag a = cfrag_of(lds_frag(rowC + ro[i])), b = cfrag_of(lds_frag(colU + co[i]));
+                        cmfma(acc[i], a, b);
+                    }
+                }
+            }
+            if (++c_t == Tb) {
+                c_t = 0;
+                c_mask >>= 1;
+                c_sym = c_mask & 1u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pack_acc(g_planes, g_naux, g_npair, L, r0 + ro[i] + frag_k + 4 * r, c0 + co[i] + frag_x, cacc_re(acc[i], r),
+                         cacc_im(acc[i], r), g.nemb);
+    };
+    auto by_len = [&](auto kindtag) {
+        switch (nblk) {
+            case 0: run(kindtag, std::integral_constant<int, 0>{}); break;
+            case 1: run(kindtag, std::integral_constant<int, 1>{}); break;
+            case 2: run(kindtag, std::integral_constant<int, 2>{}); break;
+            case 3: run(kindtag, std::integral_constant<int, 3>{}); break;
+            case 4: run(kindtag, std::integral_constant<int, 4>{}); break;
+            case 5: run(kindtag, std::integral_constant<int, 5>{}); break;
+            case 6: run(kindtag, std::integral_constant<int, 6>{}); break;
+            case 7: run(kindtag, std::integral_constant<int, 7>{}); break;
+            default: run(kindtag, std::integral_constant<int, 8>{}); break;
+        }
+    };
+    if (kind == 0) by_len(std::integral_constant<int, 0>{});
+    else if (kind == 1) by_len(std::integral_constant<int, 1>{});
+    else by_len(std::integral_constant<int, 2>{});
+}
+
+bool tab_enabled() {
+    static const bool on = [] { const char *e = getenv("DMK_ERI_HOT"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
+// Host side of the decomposition described at the top: items of the lower block triangle and the per-wave block lists.
+void build_table(int nemb, std::vector<int> &tab, double &useful_blocks, double &slots) {
+    const int nb = (nemb + 15) / 16;
+    tab.clear();
+    useful_blocks = slots = 0.0;
+    auto push_item = [&](int kind, int R0, int C0, const std::vector<std::pair<int, int>> lists[4]) {
+        const size_t base = tab.size();
+        tab.resize(base + T_ITEM, 0);
+        tab[base] = kind; tab[base + 1] = R0; tab[base + 2] = C0;
+        size_t longest = 0;
+        for (int w = 0; w < 4; ++w) {
+            tab[base + 3 + w] = (int)lists[w].size();
+            longest = std::max(longest, lists[w].size());
+            useful_blocks += (double)lists[w].size();
+            for (size_t i = 0; i < lists[w].size(); ++i)
+                tab[base + 8 + w * T_MAXBLK + i] = (lists[w][i].first << 8) | lists[w][i].second;
+        }
+        slots += 4.0 * (double)longest;
+    };
+    auto even_split = [](const std::vector<std::pair<int, int>> &all, std::vector<std::pair<int, int>> lists[4]) {
+        const size_t base = all.size() / 4, extra = all.size() % 4;
+        size_t pos = 0;
+        for (int w = 0; w < 4; ++w) {
+            const size_t n = base + ((size_t)w < extra ? 1 : 0);
+            lists[w].assign(all.begin() + pos, all.begin() + pos + n);
+            pos += n;
+        }
+    };
+    if (nb <= T_WIDE_MAXNB) {
+        // small embedding spaces: every workgroup sees the whole matrix width (panels U[.][192], C[.][192]), so the
+        // blocks of the lower triangle are simply dealt out evenly -- no light items (C4: 45 blocks -> 2 workgroups x 4
+        // waves x 5-6 blocks instead of a 28-block triangle plus a 14- and a 3-block item)
+        std::vector<std::pair<int, int>> all;
+        for (int r = 0; r < nb; ++r)
+            for (int c = 0; c <= r; ++c) all.push_back({r, c});
+        const int nwg = (int)((all.size() + 4 * T_MAXBLK - 1) / (4 * T_MAXBLK));
+        size_t pos = 0;
+        for (int wg = 0; wg < nwg; ++wg) {
+            const size_t n = all.size() / nwg + ((size_t)wg < all.size() % nwg ? 1 : 0);
+            std::vector<std::pair<int, int>> part(all.begin() + pos, all.begin() + pos + n), lists[4];
+            pos += n;
+            even_split(part, lists);
+            push_item(2, 0, 0, lists);
+        }
+        return;
+    }
+    for (int s0 = 0; s0 < nb; s0 += T_SEG) {
+        const int w = std::min(T_SEG, nb - s0);
+        {   // diagonal triangle of width w: w (w + 1) / 2 <= 28 blocks, row-major, cut evenly over the four waves
+            std::vector<std::pair<int, int>> all, lists[4];
+            for (int r = 0; r < w; ++r)
+                for (int c = 0; c <= r; ++c) all.push_back({r, c});
+            even_split(all, lists);
+            push_item(0, s0, s0, lists);
+        }
+        for (int t0 = 0; t0 < s0; t0 += T_SEG) {          // rectangles below the diagonal: rows of this segment x cols of segment t0
+            const int cw = T_SEG;                           // earlier segments are always full
+            for (int rh = 0; rh < w; rh += 4) {
+                const int rw = std::min(4, w - rh);
+                std::vector<std::pair<int, int>> all, lists[4];
+                for (int r = 0; r < rw; ++r)
+                    for (int c = 0; c < cw; ++c) all.push_back({r, c});
+                even_split(all, lists);
+                push_item(1, s0 + rh, t0, lists);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int half2_tab_usable(int nao, int nemb) {
+    return tab_enabled() && nemb >= 32 && nemb <= 4096 && (nao % T_BK) == 0 && nao >= 3 * T_BK;
+}
+int half2_tab_maxslot() { return T_MAXSLOT; }
+
+// Returns 1 if handled, 0 if the caller must use the generic kernel, < 0 on error.  Arguments as launch_half2_hot (zhot.hip).
+int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj, const int *sym,
+                     double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
+    if (!half2_tab_usable(nao, nemb) || nslot < 1 || nslot > T_MAXSLOT || nspin < 1 || nspin > 2) return 0;
+    if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
+    const dmk_ctx::StepTable *tb = nullptr;
+    for (auto &t : ctx->step2_tables)
+        if (t.nemb == nemb) tb = &t;
+    if (!tb) {
+        std::vector<int> h;
+        double useful, slots;
+        build_table(nemb, h, useful, slots);
+        int *dev = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&dev), h.size() * sizeof(int)) != hipSuccess)
+            return dmk_fail(ctx, DMK_ERR_NOMEM, "half2_tab: table allocation failed");
+        if (hipMemcpy(dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(dev);
+            return dmk_fail(ctx, DMK_ERR_HIP, "half2_tab: table upload failed");
+        }
+        ctx->step2_tables.push_back({nemb, (int)(h.size() / T_ITEM), useful, dev});
+        tb = &ctx->step2_tables.back();
+    }
+    H2TArgs a;
+    a.Ut = reinterpret_cast<const double2 *>(Ut);
+    a.symmask = 0;
+    double segs = 0.0;
+    for (int i = 0; i < T_MAXSLOT; ++i) {
+        a.Cj[i] = reinterpret_cast<const double2 *>(Cj[i < nslot ? i : 0]);
+        if (i < nslot && sym[i]) a.symmask |= 1u << i;
+        if (i < nslot) segs += sym[i] ? 2.0 : 1.0;
+        if (reinterpret_cast<uintptr_t>(a.Cj[i]) & 15) return 0;
+    }
+    a.slot_stride = slot_stride;
+    a.planes = planes; a.naux = naux; a.npair = npair;
+    a.nL = nL; a.nao = nao; a.nslot = nslot; a.nemb = nemb;
+    a.nspin = nspin;
+    a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
+    a.table = tb->dev; a.nitems = tb->nitems;
+    const unsigned long long nblocks = (unsigned long long)tb->nitems * (unsigned)nL * (unsigned)nspin;
+    if (nblocks > 0x7fffffffull) return 0;
+    a.nblocks = (unsigned)nblocks;
+    FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
+    fs.mfma_flops(6.0 * tb->useful_blocks * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
+    hipLaunchKernelGGL(half2_tab_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    DMK_CHECK_LAUNCH(ctx);
+    return 1;
+}

@@ -604,6 +604,46 @@ def test_hot_half_transform_planes(ctx, nao, naux, spin):
     eng.close()
 
 
+@pytest.mark.parametrize("nao,naux,nemb,spin", [(104, 19, 136, 1), (40, 24, 200, 2), (16, 40, 272, 2), (24, 30, 40, 1),
+                                                 (32, 20, 100, 2), (200, 8, 136, 2), (48, 16, 137, 1), (16, 64, 33, 2)])
+def test_tab_half_transform_planes(ctx, nao, naux, nemb, spin):
+    """General embedding dimension: the table-driven step-2 kernel (zhot_tab.hip) behind the same block queue as the
+    nemb = 256 kernels -- directly pushed blocks (step 1 per block, step 2 per group) and the ring feed (both steps per
+    group) -- against the oracle's r_e2 restatement, with and without the time-reversal partner term, 11 pushes =
+    one full group of 8 queued blocks + a group of 3.  nemb not a multiple of 16 exercises the clamped panels."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd._lib import lib
+    mesh = (2, 2, 1)
+    npair = nemb * (nemb + 1) // 2
+    rng = np.random.default_rng(nao + nemb)
+    Cemb = (rng.standard_normal((spin, 4, nao, nemb)) + 1j * rng.standard_normal((spin, 4, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Cemb)
+    pushes = [(1, 0, 1), (3, 2, 0), (0, 1, 1), (2, 3, 1), (0, 0, 0), (1, 1, 1), (2, 0, 0), (3, 1, 1), (0, 2, 1), (1, 3, 0), (2, 2, 1)]
+    ref = np.zeros((spin, naux, npair), dtype=np.complex128)
+    blocks = {}
+    for (i, j, sym) in pushes:
+        blocks[(i, j)] = R.df_block_philox(5, i, j, naux, nao)
+        Lij = R.transform_ao_to_emb(blocks[(i, j)].reshape(naux, -1), Cemb, i, j)
+        ref += R.pack_tril(Lij + Lij.transpose(0, 1, 3, 2) if sym else Lij)
+    scale = max(1.0, np.abs(ref).max())
+    for feed in ("push", "ring"):
+        eri_dev = ctx.zeros((spin * (spin + 1) // 2, 8, 8), np.float64)      # never contracted in this test
+        eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+        assert eng.ring_slots == 8                                           # the grouped hot path is active for this shape
+        ctx.check(lib.dmk_eri_begin_kL(eng.h, 1))
+        for n, (i, j, sym) in enumerate(pushes):
+            if feed == "push":
+                d_blk = ctx.to_device(blocks[(i, j)])
+                ctx.check(lib.dmk_eri_push_block(eng.h, i, j, sym, d_blk.ptr))
+            else:
+                eng.ring[n % eng.ring_slots].set(blocks[(i, j)])
+                ctx.check(lib.dmk_eri_push_ring_slot(eng.h, i, j, sym))
+        planes = eng.planes().get()
+        got = planes[:, 0] + 1j * planes[:, 1]
+        assert np.abs(got - ref).max() < 1e-11 * scale, (feed, np.abs(got - ref).max())
+        eng.close()
+
+
 @pytest.mark.parametrize("nao,naux,nemb,spin", [(40, 24, 256, 2), (10, 7, 12, 1), (24, 16, 40, 2)])
 def test_host_block_feed_matches_device_feed(ctx, nao, naux, nemb, spin):
     """dmk_eri_push_block_host (two pinned buffers, copy stream overlapped with the transform) against
