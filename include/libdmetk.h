@@ -230,7 +230,8 @@ typedef struct dmk_eri dmk_eri;
 /* C_ao_emb: spin x nk x nao x nemb c128, ALREADY scaled by nk^(-3/4)
  * (eri_transform.py:289-300).  eri_out: device f64 (spin*(spin+1)/2) x npair x
  * npair in (aa, ab, bb) order, accumulated into (caller zeroes it, so that
- * shards can be summed).  flags: bit0 = t_reversal_symm. */
+ * shards can be summed).  flags: bit0 = t_reversal_symm, bit1 = also accumulate the
+ * imaginary part of the contraction when bit0 is clear (dmk_eri_imag_norm). */
 int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, int spin,
                   int flags, const void *C_ao_emb, double *eri_out, dmk_eri **out);
 /* Start a momentum-transfer index kL (zeroes the Lij_s4 planes). */
@@ -270,6 +271,11 @@ int dmk_eri_finish(dmk_eri *h);
 /* ALGORITHMIC flop counters of the work pushed so far:
  * [0] half transform, [1] contraction. */
 int dmk_eri_flops(const dmk_eri *h, double flops_host[2]);
+/* Without time reversal (dmk_eri_begin flags bit 0 clear) and with flags bit 1 set, the pipeline also accumulates the
+ * IMAGINARY part of every contraction, Re_a^T Im_b - Im_a^T Re_b; this returns its max-abs so far -- the
+ * `eri_imag_norm = max_abs(eri.imag)` diagnostic of eri_transform.py:385-394 (compared with ERI_IMAG_TOL by the
+ * caller).  0 with time reversal. */
+int dmk_eri_imag_norm(dmk_eri *h, double *maxabs_host);
 
 /* Procedural DF block (synthetic configs): Philox4x32-10,
  * key (seed_lo, seed_hi), counter (e>>1 lo, e>>1 hi, ki, kj), e = (L*nao+p)*nao+q. */

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "dmk_eri_planes": (c_int, [c_vp, P(c_vp), P(c_i64)]),
     "dmk_eri_finish": (c_int, [c_vp]),
     "dmk_eri_flops": (c_int, [c_vp, P(c_dbl)]),
+    "dmk_eri_imag_norm": (c_int, [c_vp, P(c_dbl)]),
     "dmk_df_block_philox": (c_int, [c_vp, C.c_uint64, c_int, c_int, c_int, c_int, c_vp]),
     "dmk_eri_restore": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_dgemm_tn_acc": (c_int, [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_i64, c_vp, c_i64]),

@@ -607,6 +607,7 @@ struct dmk_eri {
     // hot path: step-1 outputs of up to `group` consecutive AO blocks are queued and transformed by ONE
     // step-2 launch whose accumulators (and tril-pack epilogue) are shared by all of them
     int group = 1, pending = 0;
+    double *imag = nullptr;   // flags & 2 (no time reversal): Im of the contraction, spin_pair x npair^2, for dmk_eri_imag_norm
     bool hot256 = false;      // step 2 by the nemb = 256 kernel (zhot.hip) instead of the table-driven one (zhot_tab.hip)
     int pend_kj[16], pend_sym[16], pend_ki[16];
     // block ring (dmk_eri_block_ring / dmk_eri_push_ring_slot): `group` AO-block buffers owned by the pipeline; blocks
@@ -636,6 +637,15 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     dmk_eri *h = new dmk_eri(ctx, mesh);
     h->nao = nao; h->naux = naux; h->nemb = nemb; h->spin = spin; h->tr = flags & 1;
     h->npair = (int64_t)nemb * (nemb + 1) / 2;
+    if ((flags & 2) && !h->tr) {
+        const size_t ib = (size_t)(spin == 2 ? 3 : 1) * h->npair * h->npair * sizeof(double);
+        if (hipMalloc(reinterpret_cast<void **>(&h->imag), ib) != hipSuccess ||
+            hipMemsetAsync(h->imag, 0, ib, ctx->stream) != hipSuccess) {
+            if (h->imag) (void)hipFree(h->imag);
+            delete h;
+            return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_begin: imaginary-part buffer allocation failed (%zu bytes)", ib);
+        }
+    }
     h->C = reinterpret_cast<const double2 *>(C_ao_emb);
     h->eri = eri_out;
     h->lchunk = naux;
@@ -684,6 +694,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     if (!h->planes || !h->Ut) {
         if (h->planes) (void)hipFree(h->planes);
         if (h->Ut) (void)hipFree(h->Ut);
+        if (h->imag) (void)hipFree(h->imag);
         delete h;
         return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_begin: workspace allocation failed (%zu + %zu bytes)", plane_bytes, ut_bytes);
     }
@@ -854,8 +865,55 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
         rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X1, np, X1, np, h->eri + (size_t)2 * np * np, np);
         if (rc) return rc;
     }
+    if (h->imag) {
+        // Im (L_a^H L_b) = Re_a^T Im_b - Im_a^T Re_b  (the part eri.real drops, eri_transform.py:385-394)
+        const int nb = h->spin == 2 ? 3 : 1;
+        for (int b = 0; b < nb; ++b) {
+            const double *A = (b == 2) ? X1 : X0, *B = (b == 0) ? X0 : X1;
+            const double *Are = A, *Aim = A + (size_t)h->naux * np, *Bre = B, *Bim = B + (size_t)h->naux * np;
+            double *Cb = h->imag + (size_t)b * np * np;
+            rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, h->naux, 1.0, Are, np, Bim, np, Cb, np);
+            if (rc) return rc;
+            rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, h->naux, -1.0, Aim, np, Bre, np, Cb, np);
+            if (rc) return rc;
+        }
+    }
     h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
     h->cur_kL = -1;
+    return DMK_OK;
+}
+
+namespace {
+__global__ void maxabs_kernel(long long n, const double *__restrict__ a, unsigned long long *__restrict__ out) {
+    double m = 0.0;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        m = fmax(m, fabs(a[t]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // |x| orders like its bits
+}
+}  // namespace
+
+int dmk_eri_imag_norm(dmk_eri *h, double *out) {
+    if (!h || !out) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    *out = 0.0;
+    if (!h->imag) return DMK_OK;                     // time reversal: the contraction is real by construction
+    void *scr;
+    int rc = dmk_scratch(ctx, 16, &scr);
+    if (rc) return rc;
+    DMK_HIP(ctx, hipMemsetAsync(scr, 0, 8, ctx->stream));
+    const long long n = (long long)(h->spin == 2 ? 3 : 1) * h->npair * h->npair;
+    {
+        FamScope fs(ctx, DMK_FAM_MISC);
+        hipLaunchKernelGGL(maxabs_kernel, dim3(4096), dim3(256), 0, ctx->stream, n, h->imag,
+                           reinterpret_cast<unsigned long long *>(scr));
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    unsigned long long bits = 0;
+    DMK_HIP(ctx, hipMemcpyAsync(&bits, scr, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, &bits, 8);
     return DMK_OK;
 }
 
@@ -1035,6 +1093,7 @@ int dmk_eri_finish(dmk_eri *h) {
             (void)hipFree(h->ring);
         }
     }
+    if (h->imag) (void)hipFree(h->imag);
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;

@@ -935,11 +935,68 @@ def gen_G13():
     print("G13 done")
 
 
+def gen_G15():
+    """ERI transform on k lists that are NOT the np.fft-ordered Gamma-centred mesh: a permuted mesh, and a shifted
+    Monkhorst-Pack mesh with `kscaled_center` (eri_transform.py:262-266), with and without time reversal; the
+    `ERI imaginary` diagnostic of the non-TR branch (eri_transform.py:385-394) is captured too."""
+    from oracle import restate
+    et = shim.patch_eri_transform()
+    from libdmet.system import fourier as rf
+    out = {}
+    mesh, nao, naux, nemb = (2, 2, 1), 6, 5, 8
+    nk = int(np.prod(mesh))
+    cell = shim.FakeCell(nao)
+    ks0 = np.asarray(rf.make_kpts_scaled(mesh), dtype=float)
+    W0 = synth.make_W0(mesh, naux, nao, seed=777)
+    perm = np.array([2, 0, 3, 1])
+    shift = np.array([0.25, 0.25, 0.0])
+    cases = {"perm": (ks0[perm], None), "shift": (ks0 + shift, shift), "shiftperm": ((ks0 + shift)[perm], shift)}
+    out["mesh"], out["W0"], out["perm"], out["shift"] = np.array(mesh), W0, perm, shift
+    for name, (ks, center) in cases.items():
+        kpts = cell.get_abs_kpts(ks)
+        blocks = restate.df_blocks_from_W0(W0, mesh, ks)
+        mydf = shim.FakeGDF(cell, kpts, lambda i, j, b=blocks: b[(i, j)], naux=naux, blockdim=3)
+        out[name + "/kpts_scaled"] = ks
+        for spin in (1, 2):
+            rng = np.random.default_rng(900 + spin)
+            C_ao_lo = rng.standard_normal((spin, nk, nao, nao)) + 1j * rng.standard_normal((spin, nk, nao, nao))
+            basis = rng.standard_normal((spin, nk, nao, nemb))
+            st = "%s/s%d" % (name, spin)
+            out[st + "/C_ao_lo"], out[st + "/basis"] = C_ao_lo, basis
+            for tr in (True, False):
+                seen = []
+                real_max_abs = et.max_abs
+
+                def spy(x, seen=seen, f=real_max_abs):
+                    v = f(x)
+                    seen.append(v)
+                    return v
+                et.max_abs = spy
+                try:
+                    e = et.get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=C_ao_lo, basis=basis, t_reversal_symm=tr,
+                                                kscaled_center=center, max_memory=1)
+                finally:
+                    et.max_abs = real_max_abs
+                out[st + "/eri_%s" % ("tr" if tr else "notr")] = e
+                if not tr:
+                    out[st + "/imag_norm"] = np.array(seen[-1])        # the last max_abs call is max_abs(eri.imag)
+                # the oracle restatement must reproduce the reference here too
+                r = restate.get_emb_eri_fast_gdf(mesh, ks, lambda i, j, b=blocks: b[(i, j)], naux, nao, C_ao_lo=C_ao_lo,
+                                                 basis=basis, t_reversal_symm=tr, kscaled_center=center,
+                                                 return_imag_norm=True)
+                assert np.abs(r[0] - e).max() < 1e-10 * np.abs(e).max(), (name, spin, tr)
+                if not tr:
+                    assert abs(r[1] - seen[-1]) < 1e-10 * max(1.0, seen[-1])
+            print("G15", st, "max|eri| %.3g  imag norm (no TR) %.3g" % (np.abs(e).max(), seen[-1]))
+    np.savez_compressed(os.path.join(GOLD, "G15_eri_kopts.npz"), **out)
+    print("G15 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15"]
     for g in which:
         globals()["gen_" + g]()
 

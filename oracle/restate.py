@@ -183,6 +183,31 @@ def tr_block_plan(kscaled, t_reversal_symm=True, tol=KPT_DIFF_TOL):
     return weights, plan
 
 
+def tr_block_plan_weights(kscaled, weights, tol=KPT_DIFF_TOL):
+    """tr_block_plan with the time-reversal weights supplied by the caller (the reference takes them from the k-points
+    as given, eri_transform.py:309, while conservation and the -k lookup use kscaled - kscaled_center, :262-266)."""
+    nk = len(kscaled)
+    plan = []
+    for kL in range(nk):
+        if weights[kL] <= 0:
+            continue
+        visited = np.zeros(nk, dtype=bool)
+        for i in range(nk):
+            if visited[i]:
+                continue
+            visited[i] = True
+            for j in range(nk):
+                kc = -kscaled[i] + kscaled[j] + kscaled[kL]
+                if max_abs(np.round(kc) - kc) > tol:
+                    continue
+                m = kpt_member(-kscaled[j], kscaled, tol=tol)
+                assert len(m) == 1
+                jm = int(m[0])
+                plan.append((kL, i, j, jm, bool(not visited[jm])))
+                visited[jm] = True
+    return plan
+
+
 def _task_location(n, size, task):
     """basis_transform/eri_transform_mpi.py:27-33."""
     neach, extras = divmod(n, size)
@@ -926,22 +951,25 @@ def make_C_ao_emb(kmesh, kpts_scaled, C_ao_lo=None, basis=None, unit_eri=False,
 def get_emb_eri_fast_gdf(kmesh, kpts_scaled, get_block, naux, nao, C_ao_lo=None,
                          basis=None, symmetry=4, C_ao_eo=None, unit_eri=False,
                          t_reversal_symm=True, kconserv_tol=KPT_DIFF_TOL, kL_list=None,
-                         restore_result=True):
+                         restore_result=True, kscaled_center=None, return_imag_norm=False):
     """
     basis_transform/eri_transform.py:235-399, in-core branch.
     get_block(i, j) -> (naux, nao, nao) complex128 plays the part of sr_loop.
     kL_list (optional) restricts the outer loop to a shard of irreducible kL, as
     basis_transform/eri_transform_mpi.py:151-157 does per MPI rank.
     """
-    kscaled = np.asarray(kpts_scaled, dtype=float)
-    nk = len(kscaled)
-    C_ao_emb = make_C_ao_emb(kmesh, kscaled, C_ao_lo=C_ao_lo, basis=basis,
+    kgiven = np.asarray(kpts_scaled, dtype=float)
+    nk = len(kgiven)
+    C_ao_emb = make_C_ao_emb(kmesh, kgiven, C_ao_lo=C_ao_lo, basis=basis,
                              unit_eri=unit_eri, C_ao_eo=C_ao_eo, nao=nao)
+    # eri_transform.py:262-266: the shift only enters momentum conservation and the -k lookup; the time-reversal weights
+    # (:309) and the R -> k phases (:289) use the k-points as given
+    kscaled = kgiven if kscaled_center is None else kgiven - np.asarray(kscaled_center, dtype=float)
     spin, _, _, nemb = C_ao_emb.shape
     npair = nemb * (nemb + 1) // 2
     res_shape = (spin * (spin + 1) // 2, npair, npair)
     if t_reversal_symm:
-        weights = get_weights_t_reversal(kscaled)
+        weights = get_weights_t_reversal(kgiven)
         eri = np.zeros(res_shape)
     else:
         weights = np.ones(nk, dtype=int)
@@ -979,6 +1007,8 @@ def get_emb_eri_fast_gdf(kmesh, kpts_scaled, get_block, naux, nao, C_ao_lo=None,
         eri = eri.real
     if restore_result:
         eri = eri_restore(eri, symmetry, nemb)
+    if return_imag_norm:
+        return eri, imag_norm
     return eri
 
 

@@ -770,3 +770,33 @@ def test_hot_contraction_big(ctx):
         ctx.check(lib.dmk_dgemm_tn_acc(ctx.h, N, K, 2.0, dX.ptr, dY.ptr, N, dC.ptr, N))
         ref = C0 + 2.0 * X.T @ Y
         assert np.abs(dC.get() - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("case", ["perm", "shift", "shiftperm"])
+@pytest.mark.parametrize("spin", [1, 2])
+def test_G15_eri_general_k_lists(ctx, golden, case, spin):
+    """get_emb_eri_fast_gdf on k lists that are not the np.fft-ordered Gamma-centred mesh -- a permuted list and a shifted
+    Monkhorst-Pack mesh with kscaled_center (eri_transform.py:262-266) -- against the reference-generated golden, with and
+    without time reversal, and the `ERI imaginary` diagnostic of the non-TR branch (eri_transform.py:385-394)."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd.system.lattice import _UnitCell
+    g = golden("G15_eri_kopts.npz")
+    mesh = tuple(int(x) for x in g["mesh"])
+    W0 = g["W0"]
+    naux, nao = W0.shape[0], W0.shape[2]
+    ks = g[case + "/kpts_scaled"]
+    center = None if case == "perm" else g["shift"]
+    blocks = R.df_blocks_from_W0(W0, mesh, ks)
+    cell = _UnitCell(nao)
+    mydf = et.GDFMemory(cell.get_abs_kpts(ks), blocks, naux=naux, cell=cell)
+    st = "%s/s%d" % (case, spin)
+    for tr in (True, False):
+        e = et.get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=g[st + "/C_ao_lo"], basis=g[st + "/basis"], t_reversal_symm=tr,
+                                    kscaled_center=center)
+        ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+        assert e.shape == ref.shape and np.abs(e - ref).max() < 1e-10 * np.abs(ref).max(), (tr, np.abs(e - ref).max())
+        if not tr:
+            im_ref = float(g[st + "/imag_norm"])
+            assert abs(et.get_emb_eri_fast_gdf.last_imag_norm - im_ref) < 1e-10 * im_ref
+    # the canonical mesh keeps its (zero) imaginary part: physical blocks, TR-symmetric orbitals
+    assert np.array_equal(et.get_weights_t_reversal(cell, cell.get_abs_kpts(ks)), R.get_weights_t_reversal(ks))

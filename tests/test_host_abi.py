@@ -151,3 +151,44 @@ def test_synthetic_hubbard_dispersion():
     kx = 2 * np.pi * np.arange(12) / 12
     exact2 = np.sort((-2 * np.cos(kx)[:, None] - 2 * np.cos(kx)[None, :]).ravel())
     assert np.abs(ew2 - exact2).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# general k lists: permuted order, shifted mesh with kscaled_center (eri_transform.py:262-266, 338-382)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mesh", [(2, 2, 1), (3, 2, 1), (4, 1, 1), (2, 2, 2)])
+@pytest.mark.parametrize("tr", [True, False])
+def test_general_plan_matches_reference_loop(mesh, tr):
+    """The vectorised host planner for arbitrary k lists against the restated reference loop: canonical order (where it
+    must also equal the integer-mesh plan of libdmetk), a permuted list and a shifted mesh with kscaled_center."""
+    from oracle import restate as R
+    ks0 = np.asarray(R.make_kpts_scaled(mesh), dtype=float)
+    nk = len(ks0)
+    rng = np.random.default_rng(nk)
+    perm = rng.permutation(nk)
+    shift = np.array([0.5 / mesh[0], 0.5 / mesh[1], 0.0])
+    for ks, center in ((ks0, None), (ks0[perm], None), (ks0 + shift, shift), ((ks0 + shift)[perm], shift)):
+        w, rec = et.general_plan(ks, center, tr)
+        kc = ks if center is None else ks - center
+        if tr:
+            w_ref = R.get_weights_t_reversal(ks)              # the weights use the k-points as given (eri_transform.py:309)
+            plan = R.tr_block_plan_weights(kc, w_ref)         # conservation / -k relative to the centre (:262-266)
+        else:
+            w_ref, plan = R.tr_block_plan(kc, False)
+        assert np.array_equal(w, w_ref)
+        assert [tuple(int(x) for x in r) for r in rec] == [(p[0], p[1], p[2], p[3], int(p[4])) for p in plan]
+    w, rec = et.general_plan(ks0, None, tr)
+    w_int, rec_int = et.eri_plan(mesh, tr)
+    assert np.array_equal(w, w_int) and np.array_equal(rec[:, :3], rec_int[:, :3]) and np.array_equal(rec[:, 4], rec_int[:, 4])
+
+
+def test_weights_t_reversal_general_lists():
+    from oracle import restate as R
+    from oracle import shim
+    cell = shim.FakeCell(3)
+    ks0 = np.asarray(R.make_kpts_scaled((3, 2, 1)), dtype=float)
+    perm = np.array([4, 0, 5, 2, 1, 3])
+    for ks in (ks0, ks0[perm], ks0 + np.array([0.25, 0.0, 0.0])):
+        got = et.get_weights_t_reversal(cell, cell.get_abs_kpts(ks))
+        assert np.array_equal(got, R.get_weights_t_reversal(ks))

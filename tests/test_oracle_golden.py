@@ -226,3 +226,25 @@ def test_philox_known_answer():
     assert [int(x[0]) for x in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
     b = R.df_block_philox(12345, 3, 7, 4, 5)
     assert b.shape == (4, 5, 5) and np.abs(b.real).max() <= 1 / np.sqrt(5) and abs(b.mean()) < 0.1
+
+
+@pytest.mark.parametrize("case", ["perm", "shift", "shiftperm"])
+@pytest.mark.parametrize("spin", [1, 2])
+def test_G15_eri_general_k_lists(golden, case, spin):
+    """Restatement == reference on a permuted k list and on a shifted mesh with kscaled_center, TR and non-TR, incl. the
+    imaginary-part diagnostic of the non-TR branch (eri_transform.py:262-266, 385-394)."""
+    g = golden("G15_eri_kopts.npz")
+    mesh = tuple(int(x) for x in g["mesh"])
+    W0 = g["W0"]
+    naux, nao = W0.shape[0], W0.shape[2]
+    ks = g[case + "/kpts_scaled"]
+    center = None if case == "perm" else g["shift"]
+    blocks = R.df_blocks_from_W0(W0, mesh, ks)
+    st = "%s/s%d" % (case, spin)
+    for tr in (True, False):
+        e, im = R.get_emb_eri_fast_gdf(mesh, ks, lambda i, j: blocks[(i, j)], naux, nao, C_ao_lo=g[st + "/C_ao_lo"],
+                                       basis=g[st + "/basis"], t_reversal_symm=tr, kscaled_center=center, return_imag_norm=True)
+        ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+        assert np.abs(e - ref).max() < 1e-10 * np.abs(ref).max()
+        if not tr:
+            assert abs(im - float(g[st + "/imag_norm"])) < 1e-10 * float(g[st + "/imag_norm"])
