@@ -168,23 +168,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_kernel(
 //     tile in flight, the full L2 / HBM latency exposed once per tile -- and walked the lower tile triangle
 //     row by row: 64.8 TF executed, 62 GB of HBM traffic per launch against 18 GB algorithmic (PMC).
 // Hence: 128 x 128 tile, 4 waves (wave tile 64 x 64, 16 accumulators in 128 VGPRs, no AGPR traffic),
-// BK = 8, operands by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a FOUR-stage ring
-// (4 x 18 KiB -> 2 workgroups per CU) with up to three tiles in flight, retired by a counted
-// s_waitcnt vmcnt(8) + ONE raw s_barrier per K-tile.  LDS rows keep the 128-B-mod-256-B stride (144 doubles).
+// BK = 8, operands by LDS-DMA (global_load_lds_dwordx4: no staging registers) into a THREE-stage ring with two tiles in
+// flight, retired by a counted s_waitcnt vmcnt(4) + ONE raw s_barrier per K-tile -- and THREE workgroups per CU: PMC on the
+// two-workgroup version showed the matrix pipe 88 % busy with every wave parked 9 % of its time at the barrier / LDS
+// round trip after it; a third wave per SIMD covers those gaps.  It fits because the kernel needs 162 VGPRs (<= 170) and
+// because the LDS rows are padded to 136 instead of 144 doubles (3 x 17 KiB x 3 workgroups = 153 KiB <= 160): that
+// stride costs a 2-way bank conflict on the fragment reads, which use < 15 % of the LDS bandwidth here.
 // Out-of-range lanes re-read clamped valid columns (only masked outputs see them), so every wave issues
 // exactly 4 loads per tile.
 // Tile order: a host-built table (cached in the context per shape) walks 8 x 8 SUPER-BLOCKS of tiles; the 64
 // workgroups resident on one XCD (32 CUs x 2; xcd_remap hands each XCD a contiguous range of logical ids) are
 // then one super-block: they stream 8 + 8 operand panels through that XCD's L2 instead of 1 + 64.
 // Requires K % 8 == 0, even M, N, ldx, ldy, 16-B aligned bases; otherwise the kernel above runs.
-constexpr int GBK = 8, GD = 4;
-constexpr int G_STAGE = 2 * GBK * LDS_LD;      // doubles per stage: A[8][144] | B[8][144]
+constexpr int GBK = 8, GD = 3;
+constexpr int G_LD = BM + 8;                   // 136 doubles: 17 KiB per stage, THREE workgroups per CU (see above)
+constexpr int G_STAGE = 2 * GBK * G_LD;        // doubles per stage: A[8][136] | B[8][136]
 
 // SYMM (X == Y, M == N): C is symmetric, so only tiles with tm >= tn are computed; an off-diagonal tile is
 // also added, transposed, to C[tn-tile][tm-tile] (still one writer per element).  Saves ~1/2 of the aa and bb
 // contractions, i.e. 1/3 of the UHF contraction work.
 template <bool SYMM>
-__global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
+__global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
     const unsigned *__restrict__ tile_table, unsigned nblocks) {
@@ -207,11 +211,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
     const int64_t stepA = (int64_t)GBK * ldx, stepB = (int64_t)GBK * ldy;
     int is_stage = 0;
     auto issue = [&]() {
-        double *st = lds + is_stage * G_STAGE + (2 * wave) * LDS_LD;
+        double *st = lds + is_stage * G_STAGE + (2 * wave) * G_LD;
         glds16(pA, lds_addr_of(st));
-        glds16(pA + ldx, lds_addr_of(st + LDS_LD));
-        glds16(pB, lds_addr_of(st + GBK * LDS_LD));
-        glds16(pB + ldy, lds_addr_of(st + GBK * LDS_LD + LDS_LD));
+        glds16(pA + ldx, lds_addr_of(st + G_LD));
+        glds16(pB, lds_addr_of(st + GBK * G_LD));
+        glds16(pB + ldy, lds_addr_of(st + GBK * G_LD + G_LD));
         pA += stepA;
         pB += stepB;
         is_stage = is_stage + 1 == GD ? 0 : is_stage + 1;
@@ -226,25 +230,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
     const int T = K / GBK;
     issue();
     if (T > 1) issue();
-    if (T > 2) issue();
     int c_stage = 0;
     for (int t = 0; t < T; ++t) {
-        const int later = T - 1 - t;
-        if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile t landed; t+1, t+2 may be in flight
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // tile t landed; t+1 may be in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is done with tile t-1
-        if (t + 3 < T) issue();                               // overwrite the stage tile t-1 lived in
+        if (t + 2 < T) issue();                               // overwrite the stage tile t-1 lived in
         const double *Ab = lds + c_stage * G_STAGE + wm * 64 + frag_x;
-        const double *Bb = lds + c_stage * G_STAGE + GBK * LDS_LD + wn * 64 + frag_x;
+        const double *Bb = lds + c_stage * G_STAGE + GBK * G_LD + wn * 64 + frag_x;
         c_stage = c_stage + 1 == GD ? 0 : c_stage + 1;
 #pragma unroll
         for (int kk = 0; kk < GBK / 4; ++kk) {
             double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = Ab[(kk * 4 + frag_k) * LDS_LD + i * 16];
+            for (int i = 0; i < 4; ++i) a[i] = Ab[(kk * 4 + frag_k) * G_LD + i * 16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bb[(kk * 4 + frag_k) * LDS_LD + j * 16];
+            for (int j = 0; j < 4; ++j) b[j] = Bb[(kk * 4 + frag_k) * G_LD + j * 16];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -271,26 +272,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void dgemm_tn_acc_dma_kernel(
         // mirrored tile C[n-tile][m-tile] += acc^T.  Straight from the accumulator layout a store instruction would touch
         // 16 rows of C with 4 scattered doubles each (measured: the symmetric launch ran 63 TF against 68 TF for the
         // rectangular one, 55 TF at K = 800); instead each wave transposes its 64 x 64 block through the now idle LDS ring
-        // (two 32-row halves, row stride 65 doubles: conflict-free both ways) and stores 2 rows x 32 contiguous doubles
-        // per instruction.
+        // (one 16-row block row at a time, row stride 65 doubles: conflict-free both ways) and stores 4 rows x 16
+        // contiguous doubles per instruction, the same pattern as the direct store.
         __syncthreads();                                        // every wave is done reading the last K-tile
-        double *tr = lds + wave * (32 * 65);
-        const int rr = lane & 31, cc = lane >> 5;
+        double *tr = lds + wave * (16 * 65);
+        const int rr = lane & 15, cc = lane >> 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int i = 0; i < 4; ++i) {                           // one 16-row block row of the wave tile at a time
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        tr[(i2 * 16 + frag_k + 4 * r) * 65 + j * 16 + frag_x] = alpha * acc[2 * h + i2][j][r];
+                for (int j = 0; j < 4; ++j) tr[(frag_k + 4 * r) * 65 + j * 16 + frag_x] = alpha * acc[i][j][r];
             // wave-private region: the LDS pipe returns a wave's own writes in order, no barrier needed
-            __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0)
-            const int row = m0 + wm * 64 + h * 32 + rr;         // contiguous along the mirrored row
+            const int row = m0 + wm * 64 + i * 16 + rr;         // contiguous along the mirrored row
 #pragma unroll 4
-            for (int it = 0; it < 32; ++it) {
-                const int c = 2 * it + cc;
+            for (int it = 0; it < 16; ++it) {
+                const int c = 4 * it + cc;
                 const int col = n0 + wn * 64 + c;
                 if (row < M && col < N) unsafeAtomicAdd(&C[(int64_t)col * ldc + row], tr[rr * 65 + c]);
             }
