@@ -659,6 +659,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     // for nemb = 256, the table-driven one for every other embedding dimension; only offered when the flattened step-1
     // kernel covers the shape too, so a queued group can never be left without a kernel
     h->hot256 = half2_hot_usable(nao, nemb) != 0;
+    if (const char *e = getenv("DMK_ERI_TAB256")) if (atoi(e) != 0) h->hot256 = false;      // route nemb = 256 through the table kernel
     if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(naux, nao, nemb)) {
         h->lchunk = naux;
         h->group = 8;

@@ -33,14 +33,21 @@ namespace {
 constexpr int T_BK = 4;
 constexpr int T_MAXSLOT = 16;
 constexpr int T_ITEM = 48;                             // ints per table item
-constexpr int T_MAXBLK = 8;                            // accumulator tiles per wave (192 VGPRs + double-buffered fragments)
-constexpr int T_SEG = 7;                               // blocks per segment: a 7-wide triangle is 28 blocks = 4 waves x 7
-constexpr int TD_STAGE = T_BK * 256, TD_D = 4;         // diagonal item: U[4][128] | C[4][128]                        (16 KiB)
-constexpr int TR_STAGE = T_BK * 384, TR_D = 3;         // rectangle:     Ua[4][64] | Cb[4][128] | Ca[4][64] | Ub[4][128] (24 KiB)
-constexpr int TW_STAGE = T_BK * 384, TW_D = 3;         // wide item:     U[4][192] | C[4][192]  (whole matrix, nemb <= 192) (24 KiB)
+constexpr int TD_STAGE = T_BK * 256;                   // diagonal item: U[4][128] | C[4][128]                          (16 KiB)
+constexpr int TR_STAGE = T_BK * 384;                   // rectangle:     Ua[4][64] | Cb[4][128] | Ca[4][64] | Ub[4][128] (24 KiB)
+                                                       // wide item:     U[4][192] | C[4][192] (whole matrix, nemb <= 192) (24 KiB)
 constexpr int T_WIDE_MAXNB = 12;
-static_assert(TW_STAGE == TR_STAGE && TW_D == TR_D, "wide items share the rectangle's ring geometry");
-constexpr int T_LDS = (TR_STAGE * TR_D > TD_STAGE * TD_D) ? TR_STAGE * TR_D : TD_STAGE * TD_D;
+
+// Two occupancy points of the same kernel:
+//   Cfg2: <= 8 accumulator tiles per wave (192 VGPRs + fragments), TWO workgroups per CU, rings of 4 / 3 stages (72 KiB);
+//   Cfg3: <= 5 accumulator tiles per wave (120 VGPRs + fragments; 6 spill at the 170-register limit), THREE workgroups per CU, rings of 3 / 2 stages (48 KiB) -- the
+//         third wave per SIMD covers the barrier / LDS round trips of the other two (the same lever that took the
+//         contraction kernel from 68 to 71 TF).
+struct Cfg2 { static constexpr int MAXBLK = 8, SEG = 7, OCC = 2, TD_D = 4, TR_D = 3; };
+struct Cfg3 { static constexpr int MAXBLK = 5, SEG = 5, OCC = 3, TD_D = 3, TR_D = 2; };
+template <class CFG> constexpr int lds_elems() {
+    return (TR_STAGE * CFG::TR_D > TD_STAGE * CFG::TD_D) ? TR_STAGE * CFG::TR_D : TD_STAGE * CFG::TD_D;
+}
 
 struct H2TArgs {
     const double2 *Ut;               // [nslot][nL][nao][nemb]
@@ -64,8 +71,10 @@ struct H2TArgs {
      : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
      : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
 
-__global__ __launch_bounds__(HNT, 2) void half2_tab_kernel(const H2TArgs g) {
-    __shared__ __attribute__((aligned(16))) double2 lds[T_LDS];
+template <class CFG>
+__global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs g) {
+    constexpr int T_MAXBLK = CFG::MAXBLK;
+    __shared__ __attribute__((aligned(16))) double2 lds[lds_elems<CFG>()];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frag_k = lane >> 4, frag_x = lane & 15;
@@ -106,14 +115,14 @@ __global__ __launch_bounds__(HNT, 2) void half2_tab_kernel(const H2TArgs g) {
     // they were not: 37 TF on the pipe at C4 shapes.)
     auto run = [&](auto kindtag, auto nbtag) {
         constexpr int KIND = decltype(kindtag)::value, NB = decltype(nbtag)::value;
-        constexpr int STAGE = KIND == 0 ? TD_STAGE : TR_STAGE, D = KIND == 0 ? TD_D : TR_D;      // TW_* == TR_*
+        constexpr int STAGE = KIND == 0 ? TD_STAGE : TR_STAGE, D = KIND == 0 ? CFG::TD_D : CFG::TR_D;   // wide == rectangle
         constexpr int NP = KIND == 0 ? 4 : 6;                            // LDS-DMA pieces per wave and stage
         // panel offsets inside a stage and panel widths (complex elements)
         constexpr int PUA = 0, PCB = KIND == 0 ? 512 : KIND == 1 ? 256 : 768, PCA = KIND == 0 ? 512 : 768,
                       PUB = KIND == 1 ? 1024 : 0;
         constexpr int PWR = KIND == 0 ? 128 : KIND == 1 ? 64 : 192, PWC = KIND == 2 ? 192 : 128;
 
-        long long soff[NP];
+        long long soff[NP];                                              // element offset inside one K step of the operand
         int isC[NP];
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
@@ -158,19 +167,22 @@ __global__ __launch_bounds__(HNT, 2) void half2_tab_kernel(const H2TArgs g) {
         for (int i = 0; i < NB; ++i) cacc_zero(acc[i]);
 
         issue();
-        if (T > 1) issue();
-        if (D == 4 && T > 2) issue();
+        if (D > 2 && T > 1) issue();
+        if (D > 3 && T > 2) issue();
         int c_t = 0, c_stage = 0;
         unsigned c_sym = g_symmask & 1u, c_mask = g_symmask;
         for (int t = 0; t < T; ++t) {
+            // tile t must have landed; up to D - 2 younger tiles (NP loads each) may still be in flight
             const int later = T - 1 - t;
-            if (D == 4) {
-                if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int young = later < D - 2 ? later : D - 2;
+            if (young == 2) {
+                if (NP == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else if (young == 1) {
+                if (NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
-                if (later >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
             if (t + D - 1 < T) issue();
@@ -206,16 +218,19 @@ __global__ __launch_bounds__(HNT, 2) void half2_tab_kernel(const H2TArgs g) {
                          cacc_im(acc[i], r), g.nemb);
     };
     auto by_len = [&](auto kindtag) {
+        auto go = [&](auto nbtag) {
+            if constexpr (decltype(nbtag)::value <= T_MAXBLK) run(kindtag, nbtag);
+        };
         switch (nblk) {
-            case 0: run(kindtag, std::integral_constant<int, 0>{}); break;
-            case 1: run(kindtag, std::integral_constant<int, 1>{}); break;
-            case 2: run(kindtag, std::integral_constant<int, 2>{}); break;
-            case 3: run(kindtag, std::integral_constant<int, 3>{}); break;
-            case 4: run(kindtag, std::integral_constant<int, 4>{}); break;
-            case 5: run(kindtag, std::integral_constant<int, 5>{}); break;
-            case 6: run(kindtag, std::integral_constant<int, 6>{}); break;
-            case 7: run(kindtag, std::integral_constant<int, 7>{}); break;
-            default: run(kindtag, std::integral_constant<int, 8>{}); break;
+            case 0: go(std::integral_constant<int, 0>{}); break;
+            case 1: go(std::integral_constant<int, 1>{}); break;
+            case 2: go(std::integral_constant<int, 2>{}); break;
+            case 3: go(std::integral_constant<int, 3>{}); break;
+            case 4: go(std::integral_constant<int, 4>{}); break;
+            case 5: go(std::integral_constant<int, 5>{}); break;
+            case 6: go(std::integral_constant<int, 6>{}); break;
+            case 7: go(std::integral_constant<int, 7>{}); break;
+            default: go(std::integral_constant<int, 8>{}); break;
         }
     };
     if (kind == 0) by_len(std::integral_constant<int, 0>{});
@@ -229,7 +244,7 @@ bool tab_enabled() {
 }
 
 // Host side of the decomposition described at the top: items of the lower block triangle and the per-wave block lists.
-void build_table(int nemb, std::vector<int> &tab, double &useful_blocks, double &slots) {
+void build_table(int nemb, int T_MAXBLK, int T_SEG, std::vector<int> &tab, double &useful_blocks, double &slots) {
     const int nb = (nemb + 15) / 16;
     tab.clear();
     useful_blocks = slots = 0.0;
@@ -310,13 +325,16 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
     if (!half2_tab_usable(nao, nemb) || nslot < 1 || nslot > T_MAXSLOT || nspin < 1 || nspin > 2) return 0;
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
+    // occupancy point: DMK_ERI_TAB_OCC = 2 | 3 (see Cfg2 / Cfg3)
+    static const int occ = [] { const char *e = getenv("DMK_ERI_TAB_OCC"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
     const dmk_ctx::StepTable *tb = nullptr;
     for (auto &t : ctx->step2_tables)
-        if (t.nemb == nemb) tb = &t;
+        if (t.nemb == nemb && t.cfg == occ) tb = &t;
     if (!tb) {
         std::vector<int> h;
         double useful, slots;
-        build_table(nemb, h, useful, slots);
+        if (occ == 2) build_table(nemb, Cfg2::MAXBLK, Cfg2::SEG, h, useful, slots);
+        else build_table(nemb, Cfg3::MAXBLK, Cfg3::SEG, h, useful, slots);
         int *dev = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&dev), h.size() * sizeof(int)) != hipSuccess)
             return dmk_fail(ctx, DMK_ERR_NOMEM, "half2_tab: table allocation failed");
@@ -324,7 +342,7 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
             (void)hipFree(dev);
             return dmk_fail(ctx, DMK_ERR_HIP, "half2_tab: table upload failed");
         }
-        ctx->step2_tables.push_back({nemb, (int)(h.size() / T_ITEM), useful, dev});
+        ctx->step2_tables.push_back({nemb, occ, (int)(h.size() / T_ITEM), useful, dev});
         tb = &ctx->step2_tables.back();
     }
     H2TArgs a;
@@ -348,7 +366,8 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.nblocks = (unsigned)nblocks;
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     fs.mfma_flops(6.0 * tb->useful_blocks * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
-    hipLaunchKernelGGL(half2_tab_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    if (occ == 2) hipLaunchKernelGGL(half2_tab_kernel<Cfg2>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(half2_tab_kernel<Cfg3>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }
