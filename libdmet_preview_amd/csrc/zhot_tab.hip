@@ -325,8 +325,12 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
     if (!half2_tab_usable(nao, nemb) || nslot < 1 || nslot > T_MAXSLOT || nspin < 1 || nspin > 2) return 0;
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
-    // occupancy point: DMK_ERI_TAB_OCC = 2 | 3 (see Cfg2 / Cfg3)
-    static const int occ = [] { const char *e = getenv("DMK_ERI_TAB_OCC"); const int v = e ? atoi(e) : 3; return v == 2 ? 2 : 3; }();
+    // occupancy point (see Cfg2 / Cfg3).  Measured (MI355X, executed TF of this kernel): the evenly dealt WIDE items of small
+    // embedding spaces gain from the third wave per SIMD (C4, nemb 136: 45.6 -> 54.8), the segment items of larger ones
+    // lose more from their shorter block lists than they gain (nemb 256 routed here: 56.9 vs 50.4; its specialised
+    // kernel: 66.5).  DMK_ERI_TAB_OCC = 2 | 3 overrides.
+    static const int occ_env = [] { const char *e = getenv("DMK_ERI_TAB_OCC"); return e ? atoi(e) : 0; }();
+    const int occ = (occ_env == 2 || occ_env == 3) ? occ_env : ((nemb + 15) / 16 <= T_WIDE_MAXNB ? 3 : 2);
     const dmk_ctx::StepTable *tb = nullptr;
     for (auto &t : ctx->step2_tables)
         if (t.nemb == nemb && t.cfg == occ) tb = &t;
