@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--max-blocks-per-kl", type=int, default=0, help="debug: truncate the i-loop (0 = all)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true", help="skip the sampled oracle check of the timed ERI")
+    p.add_argument("--parity-budget-s", type=float, default=150.0,
+                   help="host-time budget of the oracle check; if the estimate for the whole timed shard exceeds it (few host "
+                        "CPUs per rank), an UN-timed re-run of the first kL of every shard is checked instead, and the line says so")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--fit-iters", type=int, default=300,
                    help="MaxIter of the vcor fit measured after the timed steps (reference default 300, "
@@ -280,18 +283,30 @@ def main():
         tp = time.perf_counter()
         A = parity_sample(nemb)
         C_host = out["C_ao_emb"].get().reshape(sysm.spin, sysm.nk, sysm.nao, nemb)
-        ref, idx, _ = ES.eri_sample(sysm.mesh, sysm.df.seed, C_host, sysm.naux, A, kl_mine, max_blocks_per_kL=maxblk)
+        # cost of the oracle: the Philox regeneration of every visited block, ~0.16 core-seconds per C5 block
+        est = out["nblocks"] * 0.16 * (sysm.naux * sysm.nao ** 2 / (800.0 * 200 ** 2)) / threads
+        check_kl, check_dev, scope = kl_mine, eri_dev, "timed ERI"
+        if est > a.parity_budget_s:
+            keep = max(1, int(len(kl_mine) * a.parity_budget_s / est))
+            check_kl = kl_mine[:keep]
+            check_dev = ctx.zeros((spin_pair, npair, npair), np.float64)
+            pipeline.eri_stage(ctx, sysm, out["C_ao_emb"], nemb, check_dev, check_kl, {}, maxblk)
+            if distributed:
+                dist.all_reduce_sum_dev(check_dev)
+            scope = "UN-timed re-run (oracle budget %.0f s < %.0f s for the timed shard)" % (a.parity_budget_s, est)
+        ref, idx, _ = ES.eri_sample(sysm.mesh, sysm.df.seed, C_host, sysm.naux, A, check_kl, max_blocks_per_kL=maxblk)
         if distributed:
             ref = dist.all_reduce_sum_numpy(ref)
         if rank == 0:
-            got = np.stack([np.stack([eri_dev.offset((b * npair + int(r)) * npair, (npair,)).get()[idx] for r in idx])
+            got = np.stack([np.stack([check_dev.offset((b * npair + int(r)) * npair, (npair,)).get()[idx] for r in idx])
                             for b in range(spin_pair)])
             err = float(np.abs(got - ref).max())
             parity = {"parity_maxabs": err, "parity_ref_maxabs": float(np.abs(ref).max()),
                       "parity_entries": int(ref.size), "parity_orbitals": A, "parity_seconds": round(time.perf_counter() - tp, 2),
                       "parity_threads_per_rank": threads,
-                      "parity_scope": "timed ERI of all %d ranks: %d kL, all AO blocks, all %d auxiliary rows, %d sampled pair columns"
-                                      % (world, len(kl_mine) * world, sysm.naux, len(idx))}
+                      "parity_scope": "%s of all %d ranks: %d kL, all AO blocks, all %d auxiliary rows, %d sampled pair columns"
+                                      % (scope, world, len(check_kl) * world, sysm.naux, len(idx))}
+        del check_dev
 
     rc = 0
     if rank == 0:
