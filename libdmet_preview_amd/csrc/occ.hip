@@ -57,8 +57,27 @@ __device__ long long block_sum_i64(long long v, long long *sh) {
     return t;
 }
 
+constexpr int OCC_SMALL = 2048;      // spectra up to this size are ranked directly in LDS (model lattices: 12 - 150 levels)
+
 // element of rank k (0-based) in ascending order
 __device__ double kth_smallest(const double *__restrict__ e, long long n, long long k, long long *sh) {
+    if (n <= OCC_SMALL) {
+        // small spectra: every thread counts the elements ordered before its own (ties by index, like a stable sort) and
+        // the one whose count is k publishes itself -- two barriers instead of the 128 of the bit-pattern bisection
+        __shared__ double es[OCC_SMALL];
+        __shared__ double found;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += OCC_NT) es[i] = e[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += OCC_NT) {
+            const double x = es[i];
+            int before = 0;
+            for (int j = 0; j < n; ++j) before += (es[j] < x || (es[j] == x && j < i)) ? 1 : 0;
+            if (before == k) found = x;
+        }
+        __syncthreads();
+        return found;
+    }
     unsigned long long prefix = 0;
     for (int bit = 63; bit >= 0; --bit) {
         // among the keys that agree with `prefix` above `bit`, how many have this bit clear?
