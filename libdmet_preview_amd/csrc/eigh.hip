@@ -10,9 +10,9 @@
 //      p = tau A22 v, w = p - (tau/2)(p^H v) v, A22 -= v w^H + w v^H); the trailing block is
 //      kept as a full Hermitian matrix in HBM/L2 so that the matrix-vector product streams
 //      contiguous rows across the 64 lanes of a wave; reflectors are saved row-major.
-//   2. implicit-shift QL on the real tridiagonal (d, e): one lane runs the scalar recurrence
-//      of a sweep and leaves its Givens pairs in LDS, then all lanes apply the sweep to Z^T
-//      (row i of Z^T = eigenvector i of T, so a rotation touches two contiguous rows).
+//   2. eigenpairs of the real tridiagonal (d, e), parallel over the eigenvalues: block splitting,
+//      bisection on the Sturm count, inverse iteration with a pivoted tridiagonal elimination,
+//      Gram-Schmidt inside clusters of close eigenvalues (row i of Z^T = eigenvector i of T).
 //   3. rank sort (ascending, stable) and back-transformation y = H_0 ... H_{n-2} z, four
 //      eigenvectors per wave held in registers, reflector loads software-pipelined.
 //
@@ -22,9 +22,8 @@
 
 namespace {
 
-constexpr int NT = 320;          // five waves: during the QL phase four apply rotation sweeps while the fifth produces them
+constexpr int NT = 320;          // five waves per matrix
 constexpr int NW = NT / 64;
-constexpr int NC = NT - 64;      // consumer threads of the QL phase
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -47,10 +46,11 @@ struct EighArgs {
     double *Zt;             // batch x n x n
     double *d, *e;          // batch x n
     double2 *tau;           // batch x n
+    double *ws2;            // batch x 7 x n x n: lane-major scratch of the inverse iteration
     int *status;            // device flag, set to 1 on non-convergence
 };
 
-// LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2][2n] f64 | red[3*NW + 2] f64 | 16 ints | dl[n] | el[n]
+// LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2][2n] f64 | red[3*NW + 2] f64 | 16 ints | dl[n] | el[n] | colpart[NW][n] c128
 template <int R>
 __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     double *cs = reinterpret_cast<double *>(pbuf + n);
     double *red = cs + 4 * n;          // 3*NW + 2 doubles
     int *ired = reinterpret_cast<int *>(red + 3 * NW + 2);     // 16 ints
+    double2 *colpart = reinterpret_cast<double2 *>((reinterpret_cast<uintptr_t>(reinterpret_cast<double *>(ired + 16) + 2 * n) + 15) &
+                                                   ~static_cast<uintptr_t>(15));          // [NW][n] c128 (R <= 4 only), 16-B aligned
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,18 +146,66 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
         }
         __syncthreads();
         if (active) {
-            // (d) p = tau * A22 v   (one row per wave at a time; lanes along the row)
-            for (int i = wave; i < m; i += NW) {
-                const double2 *row = W + (size_t)(k + 1 + i) * n + (k + 1);
-                double sr = 0.0, si = 0.0;
-                for (int j = lane; j < m; j += 64) {
-                    const double2 a = row[j], v = vbuf[j];
-                    sr += a.x * v.x - a.y * v.y;
-                    si += a.x * v.y + a.y * v.x;
+            // (d) p = tau * A22 v.  Up to n = 256 only the UPPER triangle of the trailing block is read (and kept up to
+            // date): row i contributes a_ij v_j to y_i and conj(a_ij) v_i to y_j, j > i -- half the memory traffic of the
+            // full-matrix product, and the traffic is what 432 concurrent 200 x 200 problems are bound by (PMC: 38.8 GB per
+            // launch through HBM, the 691 MB of workspaces exceed the MALL).  The column contributions are accumulated in
+            // registers per wave (lane <-> column) and combined through LDS.
+            if constexpr (R <= 4) {
+                double2 colacc[R];
+#pragma unroll
+                for (int c = 0; c < R; ++c) colacc[c] = make_double2(0.0, 0.0);
+                for (int i = wave; i < m; i += NW) {
+                    const double2 *row = W + (size_t)(k + 1 + i) * n + (k + 1);
+                    const double2 vi = vbuf[i];
+                    double sr = 0.0, si = 0.0;
+#pragma unroll
+                    for (int c = 0; c < R; ++c) {
+                        const int j = lane + 64 * c;
+                        if (j >= i && j < m) {
+                            const double2 a = row[j], v = vbuf[j];
+                            sr += a.x * v.x - a.y * v.y;
+                            si += a.x * v.y + a.y * v.x;
+                            if (j > i) {                       // conj(a_ij) v_i
+                                colacc[c].x += a.x * vi.x + a.y * vi.y;
+                                colacc[c].y += a.x * vi.y - a.y * vi.x;
+                            }
+                        }
+                    }
+                    sr = wave_sum(sr);
+                    si = wave_sum(si);
+                    if (lane == 0) pbuf[i] = make_double2(sr, si);
                 }
-                sr = wave_sum(sr);
-                si = wave_sum(si);
-                if (lane == 0) pbuf[i] = cmul(tk, make_double2(sr, si));
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const int j = lane + 64 * c;
+                    if (j < m) colpart[(size_t)wave * n + j] = colacc[c];
+                }
+                __syncthreads();
+                for (int t = tid; t < m; t += NT) {
+                    double2 y = pbuf[t];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const double2 cpart = colpart[(size_t)w * n + t];
+                        y.x += cpart.x;
+                        y.y += cpart.y;
+                    }
+                    pbuf[t] = cmul(tk, y);
+                }
+            } else {
+                // full-matrix product for the large-n variant (one row per wave at a time; lanes along the row)
+                for (int i = wave; i < m; i += NW) {
+                    const double2 *row = W + (size_t)(k + 1 + i) * n + (k + 1);
+                    double sr = 0.0, si = 0.0;
+                    for (int j = lane; j < m; j += 64) {
+                        const double2 a = row[j], v = vbuf[j];
+                        sr += a.x * v.x - a.y * v.y;
+                        si += a.x * v.y + a.y * v.x;
+                    }
+                    sr = wave_sum(sr);
+                    si = wave_sum(si);
+                    if (lane == 0) pbuf[i] = cmul(tk, make_double2(sr, si));
+                }
             }
             __syncthreads();
             // (e) alpha2 = -1/2 tau (p^H v)
@@ -183,7 +233,7 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
             }
             __syncthreads();
             // (g) A22 -= v w^H + w v^H : one row per wave at a time, lanes along the row (coalesced, no index division);
-            // two rows in flight per wave
+            // two rows in flight per wave; up to n = 256 only the upper triangle (j >= i) is maintained
             for (int i0 = wave; i0 < m; i0 += 2 * NW) {
                 const int i1 = i0 + NW;
                 const bool two = i1 < m;
@@ -191,14 +241,18 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                 const double2 vi1 = two ? vbuf[i1] : make_double2(0.0, 0.0), wi1 = two ? pbuf[i1] : make_double2(0.0, 0.0);
                 double2 *r0 = W + (size_t)(k + 1 + i0) * n + (k + 1);
                 double2 *r1 = W + (size_t)(k + 1 + (two ? i1 : i0)) * n + (k + 1);
-                for (int j = lane; j < m; j += 64) {
+                const int jstart = (R <= 4) ? (i0 & ~63) + lane : lane;      // first 64-column chunk that reaches the diagonal
+                for (int j = jstart; j < m; j += 64) {
                     const double2 vj = vbuf[j], wj = pbuf[j];
-                    double2 a0 = r0[j], a1 = r1[j];
-                    a0.x -= vi0.x * wj.x + vi0.y * wj.y + wi0.x * vj.x + wi0.y * vj.y;
-                    a0.y -= vi0.y * wj.x - vi0.x * wj.y + wi0.y * vj.x - wi0.x * vj.y;
-                    if (j == i0) a0.y = 0.0;
-                    r0[j] = a0;
-                    if (two) {
+                    if (R > 4 || j >= i0) {
+                        double2 a0 = r0[j];
+                        a0.x -= vi0.x * wj.x + vi0.y * wj.y + wi0.x * vj.x + wi0.y * vj.y;
+                        a0.y -= vi0.y * wj.x - vi0.x * wj.y + wi0.y * vj.x - wi0.x * vj.y;
+                        if (j == i0) a0.y = 0.0;
+                        r0[j] = a0;
+                    }
+                    if (two && (R > 4 || j >= i1)) {
+                        double2 a1 = r1[j];
                         a1.x -= vi1.x * wj.x + vi1.y * wj.y + wi1.x * vj.x + wi1.y * vj.y;
                         a1.y -= vi1.y * wj.x - vi1.x * wj.y + wi1.y * vj.x - wi1.x * vj.y;
                         if (j == i1) a1.y = 0.0;
@@ -217,169 +271,206 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     __syncthreads();
 
     tphase[2] = wall_clock64();
-    // ---- phase 2: implicit QL, rotation sweeps applied to Zt ---------------------------------------
-    // e[i] couples i and i+1.  The sequential recurrence that generates a sweep (one lane) and the application of a
-    // sweep to Zt (all columns in parallel) only meet through the rotation list, so they run CONCURRENTLY: wave NW-1
-    // produces sweeps into a double-buffered list in LDS, waves 0..NW-2 consume them, each on its own columns
-    // (a sweep on a column only depends on the previous sweep on that column).  Hand-over is by sequence counters
-    // in LDS.  The tridiagonal (d, e) lives in LDS; the split point is found by a 64-wide ballot; a rotation
-    // costs one v_rsq_f64 + two Newton steps instead of a square root and two divisions; the sweep is applied with
-    // the row loads of eight rotations in flight.
+    // ---- phase 2: eigenpairs of the real tridiagonal T = (d, e) by bisection + inverse iteration ----------------------
+    // e[i] couples i and i+1.  Round 1 ran implicit-shift QL here: ~43 000 DEPENDENT rotations per 200 x 200 matrix, each
+    // applied to two rows of Z through L2 -- 9.2 ms of the 26 ms launch and the same latency chain for every matrix.  The
+    // work that replaces it is parallel over the EIGENVALUES (one lane each):
+    //   (a) T is cut into unreduced blocks at negligible couplings (1 x 1 blocks give their eigenpair exactly, and
+    //       eigenvectors of different blocks are orthogonal by support -- degeneracies ACROSS blocks cost nothing);
+    //   (b) the k-th eigenvalue of a block by bisection on the Sturm count (negative pivots of the LDL^T recurrence);
+    //   (c) its eigenvector by inverse iteration: Gaussian elimination with partial pivoting of the shifted tridiagonal
+    //       block (kept as three upper diagonals, the multipliers and the swap flags in a lane-major scratch), a hashed
+    //       pseudo-random start, three solves with rescaling, tiny pivots replaced by eps |T|;
+    //   (d) eigenvalues of one block closer than 1e-3 |T| form a cluster whose vectors are re-orthogonalised
+    //       (modified Gram-Schmidt, twice) by one wave per cluster -- independently iterated vectors of a (near-)degenerate
+    //       group span the right invariant subspace (different starts) but are not orthogonal to each other.
     {
-        volatile int *ctl = ired;                 // [0] sweeps published, [1] producer finished, [2..2+NW-2] consumer progress
-        int *meta = ired + 8;                     // [2][2] = (mm, cnt) per buffer
-        double *dl = reinterpret_cast<double *>(ired + 16);   // [n]
-        double *el = dl + n;                                  // [n]
+        double *dl = reinterpret_cast<double *>(ired + 16);   // [n] diagonal
+        double *el = dl + n;                                  // [n] couplings
+        int *bs = reinterpret_cast<int *>(cs);                // [n] first index of the block of i
+        int *be = bs + n;                                     // [n] one past its last index
+        double *lam = cs + n;                                 // [n] eigenvalue of lane j (ascending inside a block)
+        double *bnorm = cs + 2 * n;                           // [n] 1-norm of the block of i
+        double *ws = g.ws2 + (size_t)b * 7 * nn;              // seven [row][lane] arrays
+        const double eps = 2.220446049250313e-16;
+        double *e2 = reinterpret_cast<double *>(vbuf);        // [n] squared couplings (the reflector buffer is idle now)
         for (int t = tid; t < n; t += NT) {
             dl[t] = d[t];
-            el[t] = e[t];
+            el[t] = (t + 1 < n) ? e[t] : 0.0;
         }
-        if (tid < 16) ired[tid] = 0;
+        for (size_t idx = tid; idx < nn; idx += NT) Zt[idx] = 0.0;
         __syncthreads();
-        const double eps = 2.220446049250313e-16;
-        if (wave == NW - 1) {
-            // ---------------- producer ----------------
-            int k = 0;
-            bool fail = false;
-            for (int l = 0; l < n && !fail; ++l) {
-                int iter = 0;
-                while (true) {
-                    int mm = n - 1;
-                    for (int base = l; base < n - 1; base += 64) {
-                        const int mq = base + lane;
-                        bool small = false;
-                        if (mq < n - 1) small = fabs(el[mq]) <= eps * (fabs(dl[mq]) + fabs(dl[mq + 1]));
-                        const unsigned long long mask = __ballot(small);
-                        if (mask != 0ull) {
-                            mm = base + __ffsll((long long)mask) - 1;
-                            break;
-                        }
-                    }
-                    if (mm == l) break;
-                    // buffer k & 1 is free once every consumer has finished sweep k - 2
-                    if (k >= 2) {
-                        while (true) {
-                            int lowest = ctl[2];
-#pragma unroll
-                            for (int w = 1; w < NW - 1; ++w) lowest = min(lowest, ctl[2 + w]);
-                            if (lowest >= k - 1) break;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                    }
-                    double *csb = cs + (size_t)(k & 1) * 2 * n;
-                    if (lane == 0) {
-                        int cnt = 0;     // rotation q acts on rows (mm-1-q, mm-q)
-                        double gq = (dl[l + 1] - dl[l]) / (2.0 * el[l]);
-                        double r = sqrt(gq * gq + 1.0);
-                        gq = dl[mm] - dl[l] + el[l] / (gq + (gq >= 0.0 ? fabs(r) : -fabs(r)));
-                        double s = 1.0, c = 1.0, p = 0.0;
-                        int i = mm - 1;
-                        bool under = false;
-                        double d_hi = dl[mm];                          // d[i+1], untouched so far in this sweep
-                        double e_i = el[i], d_i = dl[i];
-                        for (; i >= l; --i) {
-                            const double f = s * e_i;
-                            const double bq = c * e_i;
-                            const double x = f * f + gq * gq;
-                            const int ip = i > l ? i - 1 : l;          // next iteration's (e, d), clamped: no branch
-                            const double e_nx = el[ip], d_nx = dl[ip];
-                            if (x == 0.0) {
-                                el[i + 1] = 0.0;
-                                dl[i + 1] = d_hi - p;
-                                el[mm] = 0.0;
-                                under = true;
-                                break;
-                            }
-                            double y = __builtin_amdgcn_rsq(x);
-                            y = y * (1.5 - 0.5 * x * y * y);
-                            y = y * (1.5 - 0.5 * x * y * y);
-                            r = x * y;
-                            r = r + 0.5 * y * fma(-r, r, x);           // sqrt(x) to the last bit or so
-                            el[i + 1] = r;
-                            s = f * y;
-                            c = gq * y;
-                            gq = d_hi - p;
-                            r = (d_i - gq) * s + 2.0 * c * bq;
-                            p = s * r;
-                            dl[i + 1] = gq + p;
-                            gq = c * r - bq;
-                            csb[2 * cnt] = c;
-                            csb[2 * cnt + 1] = s;
-                            ++cnt;
-                            d_hi = d_i;
-                            d_i = d_nx;
-                            e_i = e_nx;
-                        }
-                        if (!under) {
-                            dl[l] = d_hi - p;                          // d_hi == original d[l] here
-                            el[l] = gq;
-                            el[mm] = 0.0;
-                        }
-                        meta[2 * (k & 1)] = mm;
-                        meta[2 * (k & 1) + 1] = cnt;
-                    }
-                    __threadfence_block();
-                    ++k;
-                    if (lane == 0) ctl[0] = k;
-                    if (++iter > 80) {
-                        if (lane == 0) *g.status = 1;
-                        fail = true;
-                        break;
-                    }
-                }
-            }
-            __threadfence_block();
-            if (lane == 0) ctl[1] = 1;
-        } else {
-            // ---------------- consumers ----------------
-            int k = 0;
-            while (true) {
-                const int fin = ctl[1];
-                const int avail = ctl[0];
-                if (avail <= k) {
-                    if (fin) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                __threadfence_block();
-                const int mm = meta[2 * (k & 1)], cnt = meta[2 * (k & 1) + 1];
-                const double *csb = cs + (size_t)(k & 1) * 2 * n;
-                // rotation q on rows (i, i+1) of Zt with i = mm-1-q
-                for (int rcol = tid; rcol < n; rcol += NC) {
-                    double hi = Zt[(size_t)mm * n + rcol];
-                    double lo[8], nx[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) nx[u] = (u < cnt) ? Zt[(size_t)(mm - 1 - u) * n + rcol] : 0.0;
-                    for (int q0 = 0; q0 < cnt; q0 += 8) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) lo[u] = nx[u];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int q = q0 + 8 + u;
-                            nx[u] = (q < cnt) ? Zt[(size_t)(mm - 1 - q) * n + rcol] : 0.0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int q = q0 + u;
-                            if (q < cnt) {
-                                const double c = csb[2 * q], sn = csb[2 * q + 1];
-                                Zt[(size_t)(mm - q) * n + rcol] = sn * lo[u] + c * hi;
-                                hi = c * lo[u] - sn * hi;
-                            }
-                        }
-                    }
-                    Zt[(size_t)(mm - cnt) * n + rcol] = hi;
-                }
-                ++k;
-                __threadfence_block();
-                if (lane == 0) ctl[2 + wave] = k;
+        if (tid == 0) {
+            int s0 = 0;
+            for (int i = 0; i < n; ++i) {
+                const bool cut = (i == n - 1) || fabs(el[i]) <= eps * (fabs(dl[i]) + fabs(dl[i + 1]));
+                if (!cut) continue;
+                el[i] = 0.0;
+                double nrm = 0.0;
+                for (int q = s0; q <= i; ++q)
+                    nrm = fmax(nrm, fabs(dl[q]) + (q > s0 ? fabs(el[q - 1]) : 0.0) + (q < i ? fabs(el[q]) : 0.0));
+                for (int q = s0; q <= i; ++q) { bs[q] = s0; be[q] = i + 1; bnorm[q] = nrm; }
+                s0 = i + 1;
             }
         }
         __syncthreads();
-        for (int t = tid; t < n; t += NT) d[t] = dl[t];
+        for (int t = tid; t < n; t += NT) e2[t] = el[t] * el[t];
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) {
+            const int s0 = bs[j], t0 = be[j], m = t0 - s0, kk = j - s0;
+            if (m == 1) {
+                lam[j] = dl[s0];
+                Zt[(size_t)j * n + s0] = 1.0;
+                continue;
+            }
+            const double tn = bnorm[j];
+            // ---- (b) bisection: Gershgorin interval, count(x) = number of eigenvalues below x
+            double emax2 = 0.0, lo = dl[s0], hi = dl[s0];
+            for (int i = s0; i < t0; ++i) {
+                const double rad = (i > s0 ? fabs(el[i - 1]) : 0.0) + (i + 1 < t0 ? fabs(el[i]) : 0.0);
+                lo = fmin(lo, dl[i] - rad);
+                hi = fmax(hi, dl[i] + rad);
+                if (i + 1 < t0) emax2 = fmax(emax2, el[i] * el[i]);
+            }
+            const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax2);
+            lo -= 2.0 * eps * tn * m + 2.0 * pivmin;
+            hi += 2.0 * eps * tn * m + 2.0 * pivmin;
+            for (int it = 0; it < 200; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                int cnt = 0;
+                double q = dl[s0] - mid;
+                if (fabs(q) < pivmin) q = -pivmin;
+                cnt += q < 0.0 ? 1 : 0;
+#pragma unroll 4
+                for (int i = s0 + 1; i < t0; ++i) {
+                    // 1 / q from v_rcp_f64 and two Newton steps (the count only needs the SIGN of the pivots to be right
+                    // up to perturbations of a few ulp of |T|, which is the accuracy bisection delivers anyway)
+                    double r = __builtin_amdgcn_rcp(q);
+                    r = r * (2.0 - q * r);
+                    r = r * (2.0 - q * r);
+                    q = (dl[i] - mid) - e2[i - 1] * r;
+                    if (fabs(q) < pivmin) q = -pivmin;
+                    cnt += q < 0.0 ? 1 : 0;
+                }
+                if (cnt > kk) hi = mid; else lo = mid;
+                if (hi - lo <= eps * (fabs(lo) + fabs(hi)) + 2.0 * pivmin) break;
+            }
+            const double lm = 0.5 * (lo + hi);
+            lam[j] = lm;
+            // ---- (c) elimination with partial pivoting of T - lm I on rows s0 .. t0-1
+            double *U0 = ws + j, *U1 = U0 + nn, *U2 = U1 + nn, *Lm = U2 + nn, *Pv = Lm + nn, *x = Pv + nn;
+            const double pert = fmax(eps * tn, 1e-300);
+            {
+                double cd = dl[s0] - lm, cu = el[s0];
+                for (int i = s0; i + 1 < t0; ++i) {
+                    const double sub = el[i], nd = dl[i + 1] - lm, nu = (i + 2 < t0) ? el[i + 1] : 0.0;
+                    const size_t o = (size_t)i * n;
+                    if (fabs(cd) >= fabs(sub)) {
+                        if (fabs(cd) < pert) cd = cd >= 0.0 ? pert : -pert;
+                        const double mlt = sub / cd;
+                        U0[o] = cd; U1[o] = cu; U2[o] = 0.0; Lm[o] = mlt; Pv[o] = 0.0;
+                        cd = nd - mlt * cu;
+                        cu = nu;
+                    } else {
+                        const double mlt = cd / sub;
+                        U0[o] = sub; U1[o] = nd; U2[o] = nu; Lm[o] = mlt; Pv[o] = 1.0;
+                        cd = cu - mlt * nd;
+                        cu = -mlt * nu;
+                    }
+                }
+                if (fabs(cd) < pert) cd = cd >= 0.0 ? pert : -pert;
+                U0[(size_t)(t0 - 1) * n] = cd;
+            }
+            // start vector: hashed uniform numbers in (-1, 1), different for every matrix, eigenvalue and row
+            {
+                unsigned long long h = ((unsigned long long)b * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4Full);
+                for (int i = s0; i < t0; ++i) {
+                    h += 0x9E3779B97F4A7C15ull;
+                    unsigned long long z = h;
+                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                    z ^= z >> 31;
+                    x[(size_t)i * n] = (double)(long long)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+                }
+            }
+            // Each solve reads one array and writes another (forward x -> y, backward y -> x), so the loads of a pass do
+            // not alias its stores and the compiler may run several rows ahead of the recurrence; the scale of the next
+            // right-hand side (1 / max |x|) is gathered during the backward pass.
+            double xm = 0.0;
+            for (int i = s0; i < t0; ++i) xm = fmax(xm, fabs(x[(size_t)i * n]));
+            double *__restrict__ yv = x + nn;                  // second vector, lane-major like the others
+            for (int iter = 0; iter < 3; ++iter) {
+                const double sc = xm > 0.0 ? 1.0 / xm : 1.0;
+                // forward: row swaps and multipliers
+                double cur = x[(size_t)s0 * n] * sc;
+#pragma unroll 4
+                for (int i = s0; i + 1 < t0; ++i) {
+                    const size_t o = (size_t)i * n;
+                    double nxt = x[o + n] * sc;
+                    const double pv = Pv[o], ml = Lm[o];
+                    if (pv != 0.0) { const double tsw = cur; cur = nxt; nxt = tsw; }
+                    yv[o] = cur;
+                    cur = nxt - ml * cur;
+                }
+                yv[(size_t)(t0 - 1) * n] = cur;
+                // backward: three upper diagonals
+                double x1 = 0.0, x2 = 0.0;
+                xm = 0.0;
+#pragma unroll 4
+                for (int i = t0 - 1; i >= s0; --i) {
+                    const size_t o = (size_t)i * n;
+                    const double u0 = U0[o], u1 = U1[o], u2 = U2[o];
+                    double r = yv[o];
+                    if (i + 1 < t0) r -= u1 * x1 + u2 * x2;
+                    r /= u0;
+                    x[o] = r;
+                    xm = fmax(xm, fabs(r));
+                    x2 = x1;
+                    x1 = r;
+                }
+            }
+            double nr = 0.0;
+            const double sc = xm > 0.0 ? 1.0 / xm : 1.0;
+            for (int i = s0; i < t0; ++i) { const double v = x[(size_t)i * n] * sc; nr += v * v; }
+            const double inv = sc / sqrt(nr);
+            for (int i = s0; i < t0; ++i) Zt[(size_t)j * n + i] = x[(size_t)i * n] * inv;
+        }
+        __syncthreads();
+        // ---- (d) clusters: one wave each, members in ascending order
+        {
+            int cluster = -1;
+            for (int j = 0; j < n; ++j) {
+                const bool first = (j == bs[j]) || (lam[j] - lam[j - 1] > 1e-3 * bnorm[j]);
+                if (!first) continue;
+                ++cluster;
+                if (cluster % NW != wave) continue;
+                const int s0 = bs[j], t0 = be[j];
+                int last = j;
+                while (last + 1 < t0 && lam[last + 1] - lam[last] <= 1e-3 * bnorm[j]) ++last;
+                for (int q = j + 1; q <= last; ++q) {
+                    double *zq = Zt + (size_t)q * n;
+                    for (int pass = 0; pass < 2; ++pass)
+                        for (int p = j; p < q; ++p) {
+                            const double *zp = Zt + (size_t)p * n;
+                            double dot = 0.0;
+                            for (int i = s0 + lane; i < t0; i += 64) dot += zp[i] * zq[i];
+                            dot = wave_sum(dot);
+                            for (int i = s0 + lane; i < t0; i += 64) zq[i] -= dot * zp[i];
+                        }
+                    double nr = 0.0;
+                    for (int i = s0 + lane; i < t0; i += 64) nr += zq[i] * zq[i];
+                    nr = wave_sum(nr);
+                    const double inv = nr > 0.0 ? 1.0 / sqrt(nr) : 0.0;
+                    for (int i = s0 + lane; i < t0; i += 64) zq[i] *= inv;
+                }
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < n; t += NT) d[t] = lam[t];
         if (b == 0 && tid == 0) {
             long long *tp = reinterpret_cast<long long *>(g.status + 2);
-            tp[4] = 0; tp[5] = 0; tp[6] = 0; tp[7] = ctl[0];
+            tp[4] = 0; tp[5] = 0; tp[6] = 0; tp[7] = 0;
         }
     }
     __syncthreads();
@@ -474,7 +565,7 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     if (n <= 0 || batch <= 0) return DMK_OK;
     if (n > 1024) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh: n = %d exceeds the supported maximum of 1024", n);
     const size_t nn = (size_t)n * n;
-    const size_t per = nn * (16 + 16 + 8) + (size_t)n * (8 + 8 + 16);
+    const size_t per = nn * (16 + 16 + 8 + 56) + (size_t)n * (8 + 8 + 16);
     const size_t total = per * batch + 256;
     void *ws = nullptr;
     int rc = dmk_scratch(ctx, total, &ws);
@@ -489,11 +580,12 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     g.tau = reinterpret_cast<double2 *>(p); p += (size_t)n * 16 * batch;
     g.Zt = reinterpret_cast<double *>(p); p += nn * 8 * batch;
     g.d = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
-    g.e = reinterpret_cast<double *>(p);
+    g.e = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
+    g.ws2 = reinterpret_cast<double *>(p);
     DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
     // reflector rows are only partially written; clear so that masked lanes read zeros
     DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
-    const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64;
+    const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64 + (n <= 256 ? (size_t)NW * n * 16 + 16 : 0);
     {
         FamScope fs(ctx, DMK_FAM_EIGH);
         if (lds > 48 * 1024) {
@@ -514,9 +606,8 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     if (getenv("DMK_EIGH_TIMING")) {
         long long tp[8];
         DMK_HIP(ctx, hipMemcpy(tp, g.status + 2, sizeof(tp), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[eigh n=%d batch=%d] matrix 0: init %.3f ms, tridiag %.3f ms, QL %.3f ms (scalar %.3f, apply %.3f; %lld rotations in "
-                "%lld sweeps), sort+back %.3f ms\n", n, batch, tp[0] * 1e-5, tp[1] * 1e-5, tp[2] * 1e-5, tp[4] * 1e-5, tp[5] * 1e-5,
-                tp[6], tp[7], tp[3] * 1e-5);
+        fprintf(stderr, "[eigh n=%d batch=%d] matrix 0: init %.3f ms, tridiag %.3f ms, bisection + inverse iteration %.3f ms, sort+back %.3f ms\n",
+                n, batch, tp[0] * 1e-5, tp[1] * 1e-5, tp[2] * 1e-5, tp[3] * 1e-5);
     }
     return DMK_OK;
 }
