@@ -51,7 +51,7 @@ struct EighArgs {
 };
 
 // LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2][2n] f64 | red[3*NW + 2] f64 | 16 ints | dl[n] | el[n] | colpart[NW][n] c128
-template <int R>
+template <int R, int HR>
 __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = g.n;
@@ -155,26 +155,49 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                 double2 colacc[R];
 #pragma unroll
                 for (int c = 0; c < R; ++c) colacc[c] = make_double2(0.0, 0.0);
-                for (int i = wave; i < m; i += NW) {
-                    const double2 *row = W + (size_t)(k + 1 + i) * n + (k + 1);
-                    const double2 vi = vbuf[i];
-                    double sr = 0.0, si = 0.0;
+                // HR rows per wave and pass: all their loads are issued before the first reduction, otherwise every row pays
+                // its own L2 / HBM round trip (the loop was latency bound: 35 us per Householder step at m = 200).  HR = 4
+                // costs 136 VGPRs -- one workgroup per CU -- and is used when the batch fits one round anyway (64 x 136^2:
+                // 9.3 -> 4.5 ms); HR = 2 keeps two workgroups per CU for large batches (432 x 200^2: 13.8 vs 20.8 ms)
+                for (int ib = wave; ib < m; ib += HR * NW) {
+                    double2 a[HR][R];
 #pragma unroll
-                    for (int c = 0; c < R; ++c) {
-                        const int j = lane + 64 * c;
-                        if (j >= i && j < m) {
-                            const double2 a = row[j], v = vbuf[j];
-                            sr += a.x * v.x - a.y * v.y;
-                            si += a.x * v.y + a.y * v.x;
-                            if (j > i) {                       // conj(a_ij) v_i
-                                colacc[c].x += a.x * vi.x + a.y * vi.y;
-                                colacc[c].y += a.x * vi.y - a.y * vi.x;
+                    for (int u = 0; u < HR; ++u) {
+                        const int i = ib + u * NW;
+                        const double2 *row = W + (size_t)(k + 1 + (i < m ? i : 0)) * n + (k + 1);
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            const int j = lane + 64 * c;
+                            a[u][c] = (i < m && j >= i && j < m) ? row[j] : make_double2(0.0, 0.0);
+                        }
+                    }
+                    double sr[HR], si[HR];
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) {
+                        const int i = ib + u * NW;
+                        const double2 vi = vbuf[i < m ? i : 0];
+                        sr[u] = 0.0;
+                        si[u] = 0.0;
+#pragma unroll
+                        for (int c = 0; c < R; ++c) {
+                            const int j = lane + 64 * c;
+                            if (i < m && j >= i && j < m) {
+                                const double2 v = vbuf[j], av = a[u][c];
+                                sr[u] += av.x * v.x - av.y * v.y;
+                                si[u] += av.x * v.y + av.y * v.x;
+                                if (j > i) {                   // conj(a_ij) v_i
+                                    colacc[c].x += av.x * vi.x + av.y * vi.y;
+                                    colacc[c].y += av.x * vi.y - av.y * vi.x;
+                                }
                             }
                         }
                     }
-                    sr = wave_sum(sr);
-                    si = wave_sum(si);
-                    if (lane == 0) pbuf[i] = make_double2(sr, si);
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) {
+                        const int i = ib + u * NW;
+                        const double tr = wave_sum(sr[u]), ti = wave_sum(si[u]);
+                        if (lane == 0 && i < m) pbuf[i] = make_double2(tr, ti);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < R; ++c) {
@@ -588,15 +611,21 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64 + (n <= 256 ? (size_t)NW * n * 16 + 16 : 0);
     {
         FamScope fs(ctx, DMK_FAM_EIGH);
-        if (lds > 48 * 1024) {
-            const void *fn = n <= 64 ? reinterpret_cast<const void *>(eigh_kernel<1>)
-                             : n <= 256 ? reinterpret_cast<const void *>(eigh_kernel<4>)
-                                        : reinterpret_cast<const void *>(eigh_kernel<16>);
-            DMK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // HR (rows in flight per wave in the Householder matrix-vector product): see the kernel
+        const bool few = batch <= 256;
+        const void *fn = n <= 64 ? (few ? reinterpret_cast<const void *>(eigh_kernel<1, 4>) : reinterpret_cast<const void *>(eigh_kernel<1, 2>))
+                         : n <= 256 ? (few ? reinterpret_cast<const void *>(eigh_kernel<4, 4>) : reinterpret_cast<const void *>(eigh_kernel<4, 2>))
+                                    : reinterpret_cast<const void *>(eigh_kernel<16, 2>);
+        if (lds > 48 * 1024) DMK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (n <= 64) {
+            if (few) hipLaunchKernelGGL((eigh_kernel<1, 4>), dim3(batch), dim3(NT), lds, ctx->stream, g);
+            else hipLaunchKernelGGL((eigh_kernel<1, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
+        } else if (n <= 256) {
+            if (few) hipLaunchKernelGGL((eigh_kernel<4, 4>), dim3(batch), dim3(NT), lds, ctx->stream, g);
+            else hipLaunchKernelGGL((eigh_kernel<4, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
+        } else {
+            hipLaunchKernelGGL((eigh_kernel<16, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
         }
-        if (n <= 64) hipLaunchKernelGGL(eigh_kernel<1>, dim3(batch), dim3(NT), lds, ctx->stream, g);
-        else if (n <= 256) hipLaunchKernelGGL(eigh_kernel<4>, dim3(batch), dim3(NT), lds, ctx->stream, g);
-        else hipLaunchKernelGGL(eigh_kernel<16>, dim3(batch), dim3(NT), lds, ctx->stream, g);
         DMK_CHECK_LAUNCH(ctx);
     }
     int status = 0;
