@@ -204,6 +204,10 @@ struct H2Args {
     // throughput-bound in steady state, the extra epilogues cost more than the shorter drain saves.
     int nspin;
     long long ut_spin_stride, cj_spin_stride, planes_spin_stride;   // elements between the spin channels
+    // every queued block carries the time-reversal partner term: the 16 DIAGONAL 16 x 16 blocks then skip segment 2 and are
+    // completed as P + P^T in the epilogue (S_rr = U_r^T C_r + C_r^T U_r, and the second product is the transpose of the
+    // first): 256 instead of 272 block products per L, and triangle waves issue 16 per K step like the square ones
+    int fold_diag;
 };
 
 // Kernel-argument arrays must only be indexed with compile-time constants, and the argument struct must
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     const long long cj_off = (long long)sp * g.cj_spin_stride;
     const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
     const unsigned g_symmask = g.symmask;
+    const bool fold = g.fold_diag != 0;
 
     if (type >= 2) {
         // ---------------- diagonal triangle [d0, d0+128)^2 ----------------------------------------
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) {
                         const cfrag b = cfrag_of(lds_frag(&U[c * 16]));
-                        if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
-                        cmfma(acc2[c], a2, b);
+                        if (c < R1 || (c == R1 && !fold)) cmfma(acc1[c <= R1 ? c : 0], a1, b);
+                        if (c < R2 || !fold) cmfma(acc2[c], a2, b);
                     }
                 }
                 if (++c_t == Tb) {
@@ -315,6 +320,32 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                     c_mask >>= 1;
                     c_sym = c_mask & 1u;
                 }
+            }
+            if (fold) {
+                // diagonal blocks hold P = U_r^T C_r only: add P^T through a wave-private LDS tile (the ring is idle now)
+                __syncthreads();
+                double *tr = reinterpret_cast<double *>(lds) + wave * (2 * 16 * 17);
+                auto fold_block = [&](cacc &acc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tr[(frag_k + 4 * r) * 17 + frag_x] = cacc_re(acc, r);
+                        tr[272 + (frag_k + 4 * r) * 17 + frag_x] = cacc_im(acc, r);
+                    }
+                    double tre[4], tim[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                      // the LDS pipe keeps a wave's own accesses in order
+                        tre[r] = tr[frag_x * 17 + frag_k + 4 * r];
+                        tim[r] = tr[272 + frag_x * 17 + frag_k + 4 * r];
+                    }
+                    // fold into the T1 / T2 / T3 representation: Re += tre, Im += tim  (T1 += tre, T3 += tre + tim)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc.p[r] += tre[r];
+                        acc.t[r] += tre[r] + tim[r];
+                    }
+                };
+                fold_block(acc1[R1]);
+                fold_block(acc2[R2]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -564,11 +595,13 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.nspin = nspin;
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.nblocks = (unsigned)(4 * nL * nspin);
+    a.fold_diag = (a.symmask == (nslot >= 32 ? 0xffffffffu : ((1u << nslot) - 1u))) ? 1 : 0;
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
-    {   // 136 of the 256 16 x 16 blocks per L and spin; a block with the time-reversal partner term runs two segments
-        double segs = 0.0;
-        for (int i = 0; i < nslot; ++i) segs += sym[i] ? 2.0 : 1.0;
-        fs.mfma_flops(6.0 * 136.0 * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
+    {   // 136 of the 256 16 x 16 blocks per L and spin; a block with the time-reversal partner term runs a second segment
+        // (without the 16 diagonal blocks when the whole group is symmetrised: they are folded in the epilogue)
+        double blocks = 0.0;
+        for (int i = 0; i < nslot; ++i) blocks += 136.0 + (sym[i] ? (a.fold_diag ? 120.0 : 136.0) : 0.0);
+        fs.mfma_flops(6.0 * blocks * 256.0 * (double)nao * (double)nL * (double)nspin);
     }
     hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);

@@ -604,6 +604,33 @@ def test_hot_half_transform_planes(ctx, nao, naux, spin):
     eng.close()
 
 
+@pytest.mark.parametrize("nao,naux,spin", [(24, 80, 2), (200, 8, 1), (16, 130, 2)])
+def test_hot_half_transform_all_symmetrised_groups(ctx, nao, naux, spin):
+    """nemb = 256 with EVERY queued block carrying the time-reversal partner term (the usual case: 12 040 of the 12 152 C5
+    blocks): the diagonal 16 x 16 blocks then run one segment and are completed as P + P^T in the epilogue."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd._lib import lib
+    mesh, nemb = (2, 2, 1), 256
+    npair = nemb * (nemb + 1) // 2
+    rng = np.random.default_rng(nao + 1)
+    Cemb = (rng.standard_normal((spin, 4, nao, nemb)) + 1j * rng.standard_normal((spin, 4, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Cemb)
+    eri_dev = ctx.zeros((spin * (spin + 1) // 2, 8, 8), np.float64)
+    eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    ctx.check(lib.dmk_eri_begin_kL(eng.h, 1))
+    ref = np.zeros((spin, naux, npair), dtype=np.complex128)
+    for (i, j) in [(1, 0), (3, 2), (0, 1), (2, 3), (0, 0), (1, 1), (2, 0), (3, 1), (0, 2), (1, 3), (2, 2)]:
+        blk = R.df_block_philox(6, i, j, naux, nao)
+        d_blk = ctx.to_device(blk)                       # must outlive the call: the pipeline reads it asynchronously
+        ctx.check(lib.dmk_eri_push_block(eng.h, i, j, 1, d_blk.ptr))
+        Lij = R.transform_ao_to_emb(blk.reshape(naux, -1), Cemb, i, j)
+        ref += R.pack_tril(Lij + Lij.transpose(0, 1, 3, 2))
+    planes = eng.planes().get()
+    got = planes[:, 0] + 1j * planes[:, 1]
+    assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+    eng.close()
+
+
 @pytest.mark.parametrize("nao,naux,nemb,spin", [(104, 19, 136, 1), (40, 24, 200, 2), (16, 40, 272, 2), (24, 30, 40, 1),
                                                  (32, 20, 100, 2), (200, 8, 136, 2), (48, 16, 137, 1), (16, 64, 33, 2)])
 def test_tab_half_transform_planes(ctx, nao, naux, nemb, spin):
