@@ -133,6 +133,44 @@ class Context(object):
                                "there is no CPU fallback" % (device, rc))
         self.h = h
         self.device = int(device)
+        # Freed device blocks are parked here by size and handed out again instead of going through hipFree / hipMalloc
+        # (each a device synchronisation plus ~1 ms per few hundred MB): an embedding-construction iteration allocates the
+        # same two dozen temporaries every time.  One stream per context, so reuse is stream ordered.
+        self._pool = {}
+        self._pool_bytes = 0
+        self._pool_limit = int(float(os.environ.get("DMK_POOL_GB", "24")) * (1 << 30))
+
+    def _alloc(self, nbytes):
+        """(pointer, capacity) of a device block of at least nbytes."""
+        cap = (max(int(nbytes), 16) + 255) & ~255
+        stack = self._pool.get(cap)
+        if stack:
+            self._pool_bytes -= cap
+            return stack.pop(), cap
+        p = c_vp()
+        rc = lib.dmk_malloc(self.h, cap, C.byref(p))
+        if rc != 0 and self._pool_bytes:
+            self.trim()                                  # give the parked blocks back and retry once
+            rc = lib.dmk_malloc(self.h, cap, C.byref(p))
+        self.check(rc)
+        return p, cap
+
+    def _release(self, ptr, cap):
+        if not self.h:
+            return
+        if cap <= self._pool_limit - self._pool_bytes:
+            self._pool.setdefault(cap, []).append(ptr)
+            self._pool_bytes += cap
+        else:
+            lib.dmk_free(self.h, ptr)
+
+    def trim(self):
+        """Return every parked block to the driver."""
+        for stack in self._pool.values():
+            for ptr in stack:
+                lib.dmk_free(self.h, ptr)
+        self._pool = {}
+        self._pool_bytes = 0
 
     def check(self, rc):
         if rc != 0:
@@ -141,6 +179,7 @@ class Context(object):
 
     def close(self):
         if getattr(self, "h", None):
+            self.trim()
             lib.dmk_destroy(self.h)
             self.h = None
 
@@ -212,9 +251,7 @@ class DevArray(object):
         self.nbytes = self.size * self.dtype.itemsize
         self._keep = keepalive
         if ptr is None:
-            p = c_vp()
-            ctx.check(lib.dmk_malloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
-            self.ptr = p
+            self.ptr, self._cap = ctx._alloc(self.nbytes)
             self._own = True
         else:
             self.ptr = c_vp(int(ptr))
@@ -255,7 +292,7 @@ class DevArray(object):
 
     def free(self):
         if self._own and self.ptr and self.ctx.h:
-            lib.dmk_free(self.ctx.h, self.ptr)
+            self.ctx._release(self.ptr, self._cap)
         self.ptr = None
         self._own = False
 

@@ -602,8 +602,6 @@ struct dmk_eri {
     double2 *Ut = nullptr;      // lchunk x nao x nemb
     int lchunk;
     int use_3m = 1;       // Karatsuba complex product in the generic half transform (DMK_ERI_3M=0 restores 4M)
-    int flat2 = 0;        // DMK_ERI_FLAT2=1: step 2 of general nemb through the flattened hot kernel + a fold pass.  Measured at
-                          // C4 shapes (nao 104, nemb 136) the fold pass costs what the faster GEMM saves (0.31 vs 0.28 ms per block)
     // hot path: step-1 outputs of up to `group` consecutive AO blocks are queued and transformed by ONE
     // step-2 launch whose accumulators (and tril-pack epilogue) are shared by all of them
     int group = 1, pending = 0;
@@ -650,7 +648,6 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     h->eri = eri_out;
     h->lchunk = naux;
     if (const char *e = getenv("DMK_ERI_3M")) h->use_3m = atoi(e) != 0;
-    if (const char *e = getenv("DMK_ERI_FLAT2")) h->flat2 = atoi(e) != 0;
     if (const char *e = getenv("DMK_ERI_LCHUNK")) {
         int v = atoi(e);
         if (v > 0 && v < naux) h->lchunk = v;
@@ -667,9 +664,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         h->group = std::max(1, std::min(h->group, h->hot256 ? half2_hot_maxslot() : half2_tab_maxslot()));
     }
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
-    // generic path: Ut is followed by the step-2 product P (lchunk x nemb x nemb) of the flattened kernel
-    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1) +
-                            (h->group > 1 ? 0 : (size_t)h->lchunk * nemb * nemb * sizeof(double2));
+    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1);
     // reuse the workspace parked in the context by the previous pipeline when it is large enough
     const size_t want[2] = {plane_bytes, ut_bytes};
     void *got[2] = {nullptr, nullptr};
@@ -814,13 +809,6 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
                 if (rc) return rc;
             }
             // step 2: S[a][b] = sum_q Ut[L][q][a] Cj[q][b] (+ sum_q Cj[q][a] Ut[L][q][b]); tril-pack, accumulate
-            if (h->flat2) {
-                double2 *Pbuf = h->Ut + (size_t)h->lchunk * nao * nemb;
-                rc = launch_half2_flat(ctx, h->Ut, Cj, Pbuf, planes + (size_t)l0 * h->npair, naux, h->npair, nl, nao, nemb,
-                                       symmetrise ? 1 : 0);
-                if (rc < 0) return rc;
-                if (rc == 1) continue;
-            }
             ZGemm g2;
             g2.M = nemb; g2.N = nemb; g2.K = nao; g2.batch = nl; g2.nseg = symmetrise ? 2 : 1;
             g2.seg[0].A = h->Ut; g2.seg[0].lda = nemb; g2.seg[0].strideA = (int64_t)nao * nemb;

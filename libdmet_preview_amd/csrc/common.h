@@ -170,9 +170,6 @@ int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, i
 // hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin = 1,
                      long long ci_spin_stride = 0, long long ut_spin_stride = 0);
-// step 2 for a general nemb: flattened hot kernel into P (nL x nemb x nemb c128) + deterministic fold/pack into the planes
-int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
-                      int nL, int nao, int nemb, int sym);
 int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_stride, int nslot, const int *ki, const void *C,
                            void *Ut, long long ut_slot_stride, int nL, int nao, int nemb, int nspin, long long ci_spin_stride,
                            long long ut_spin_stride);

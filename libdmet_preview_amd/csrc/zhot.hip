@@ -518,62 +518,6 @@ int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_strid
                            nslot, a_slot_stride, ut_slot_stride, (long long)nao * nemb, ki);
 }
 
-// Step 2 for a general embedding dimension: P[L][a][b] = sum_q Ut[L][q][a] C_j[q][b] with the flattened kernel above
-// (Ut is K-major exactly like the AO block of step 1), then planes[L][pair(a,b)] += P[a][b] (+ P[b][a] when the
-// time-reversal partner is folded in, eri_transform.py:372-378) by fold_pack_kernel.  One writer per plane element:
-// deterministic.  Returns 0 if the shape is not covered.
-namespace {
-constexpr int FP_ROWS = 16;
-__global__ __launch_bounds__(256) void fold_pack_kernel(const double2 *__restrict__ P, double *__restrict__ planes, long long naux,
-                                                        long long npair, int nemb, int sym) {
-    __shared__ double2 strip[FP_ROWS][257];             // strip[al][b] = P[b][a0 + al]   (nemb <= 256 per pass)
-    const int L = blockIdx.y, a0 = blockIdx.x * FP_ROWS;
-    const double2 *PL = P + (long long)L * nemb * nemb;
-    double *re = planes + (long long)L * npair, *im = planes + (naux + L) * npair;
-    const int amax = min(a0 + FP_ROWS, nemb);
-    for (int b0 = 0; b0 < amax; b0 += 256) {            // only b <= a is needed
-        const int bw = min(256, amax - b0);
-        if (sym) {
-            for (int t = threadIdx.x; t < bw * FP_ROWS; t += 256) {
-                const int al = t % FP_ROWS, b = t / FP_ROWS;
-                const int a = a0 + al;
-                strip[al][b] = (a < nemb) ? PL[(long long)(b0 + b) * nemb + a] : make_double2(0.0, 0.0);
-            }
-            __syncthreads();
-        }
-        for (int al = 0; al < FP_ROWS; ++al) {
-            const int a = a0 + al;
-            if (a >= nemb) break;
-            for (int b = threadIdx.x; b < bw; b += 256) {
-                const int bg = b0 + b;
-                if (bg > a) break;
-                double2 v = PL[(long long)a * nemb + bg];
-                if (sym) {
-                    const double2 u = strip[al][b];
-                    v.x += u.x;
-                    v.y += u.y;
-                }
-                const long long pr = (long long)a * (a + 1) / 2 + bg;
-                re[pr] += v.x;
-                im[pr] += v.y;
-            }
-        }
-        if (sym) __syncthreads();
-    }
-}
-}  // namespace
-
-int launch_half2_flat(dmk_ctx *ctx, const void *Ut, const void *Cj, void *P, double *planes, long long naux, long long npair,
-                      int nL, int nao, int nemb, int sym) {
-    const int rc = launch_flat_hot(ctx, Ut, Cj, P, nL, nao, nemb, nemb, false, DMK_FAM_ZGEMM_HALF2);
-    if (rc <= 0) return rc;
-    FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
-    hipLaunchKernelGGL(fold_pack_kernel, dim3((nemb + FP_ROWS - 1) / FP_ROWS, nL), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const double2 *>(P), planes, naux, npair, nemb, sym);
-    DMK_CHECK_LAUNCH(ctx);
-    return 1;
-}
-
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
