@@ -38,7 +38,7 @@ struct dmk_ctx {
     struct TileTable { int tiles_m, tiles_n, symm; unsigned count; unsigned *dev; };
     std::vector<TileTable> tile_tables;
     // block-ownership tables of the general-nemb step-2 kernel (zhot_tab.hip), one per embedding dimension
-    struct StepTable { int nemb, cfg, nitems; double useful_blocks; int *dev; };
+    struct StepTable { int nemb, cfg, nitems; double useful_blocks, folded_blocks; int *dev; };
     std::vector<StepTable> step2_tables;
 };
 

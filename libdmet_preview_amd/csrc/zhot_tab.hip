@@ -60,6 +60,7 @@ struct H2TArgs {
     unsigned nblocks;
     int nspin;
     long long ut_spin_stride, cj_spin_stride, planes_spin_stride;
+    int fold_diag;                   // every queued block is symmetrised: diagonal blocks run one segment and are folded (zhot.hip)
     const int *table;                // nitems x T_ITEM: kind, R0, C0, nblk[4], pad, entries[4][8] = (row block << 8) | col block (local)
     int nitems;
 };
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
     const int kind = __builtin_amdgcn_readfirstlane(it[0]);
     const int R0 = __builtin_amdgcn_readfirstlane(it[1]), C0 = __builtin_amdgcn_readfirstlane(it[2]);
     const int nblk = __builtin_amdgcn_readfirstlane(it[3 + wave]);
+    // diagonal blocks of this wave (the host puts them LAST in its list): with `fold_diag` they skip segment 2
+    const int ndiag = g.fold_diag ? (__builtin_amdgcn_readfirstlane(it[7]) >> (8 * wave)) & 255 : 0;
+    const int nb2 = nblk - ndiag;
+    const bool wg_has_diag = g.fold_diag && __builtin_amdgcn_readfirstlane(it[7]) != 0;      // uniform over the workgroup
     int ro[T_MAXBLK], co[T_MAXBLK];              // local element offsets of each block inside the row / column panels
 #pragma unroll
     for (int i = 0; i < T_MAXBLK; ++i) {
@@ -199,8 +204,11 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                     const double2 *rowC = st + PCA + frag_k * PWR + frag_x, *colU = st + PUB + frag_k * PWC + frag_x;
 #pragma unroll
                     for (int i = 0; i < NB; ++i) {                      // S[a][b] += C[q][a] U[q][b]
-                        const cfrag a = cfrag_of(lds_frag(rowC + ro[i])), b = cfrag_of(lds_frag(colU + co[i]));
-                        cmfma(acc[i], a, b);
+                        // at most the last two blocks of a list are diagonal ones: only they carry a (uniform) branch
+                        if (i + 2 < NB || i < nb2) {
+                            const cfrag a = cfrag_of(lds_frag(rowC + ro[i])), b = cfrag_of(lds_frag(colU + co[i]));
+                            cmfma(acc[i], a, b);
+                        }
                     }
                 }
             }
@@ -208,6 +216,27 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                 c_t = 0;
                 c_mask >>= 1;
                 c_sym = c_mask & 1u;
+            }
+        }
+        if (wg_has_diag) {
+            // folded diagonal blocks hold P = U_r^T C_r only: add P^T through a wave-private LDS tile (the ring is idle now)
+            __syncthreads();
+            double *tr = reinterpret_cast<double *>(lds) + wave * (2 * 16 * 17);
+#pragma unroll
+            for (int i = (NB >= 2 ? NB - 2 : 0); i < NB; ++i) {
+                if (i >= nb2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        tr[(frag_k + 4 * r) * 17 + frag_x] = cacc_re(acc[i], r);
+                        tr[272 + (frag_k + 4 * r) * 17 + frag_x] = cacc_im(acc[i], r);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                  // the LDS pipe keeps a wave's own accesses in order
+                        const double tre = tr[frag_x * 17 + frag_k + 4 * r], tim = tr[272 + frag_x * 17 + frag_k + 4 * r];
+                        acc[i].p[r] += tre;                        // Re += tre, Im += tim in the (T1, T2, T3) representation
+                        acc[i].t[r] += tre + tim;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -244,16 +273,27 @@ bool tab_enabled() {
 }
 
 // Host side of the decomposition described at the top: items of the lower block triangle and the per-wave block lists.
-void build_table(int nemb, int T_MAXBLK, int T_SEG, std::vector<int> &tab, double &useful_blocks, double &slots) {
+void build_table(int nemb, int T_MAXBLK, int T_SEG, std::vector<int> &tab, double &useful_blocks, double &slots, double &folded) {
     const int nb = (nemb + 15) / 16;
     tab.clear();
-    useful_blocks = slots = 0.0;
-    auto push_item = [&](int kind, int R0, int C0, const std::vector<std::pair<int, int>> lists[4]) {
+    useful_blocks = slots = folded = 0.0;
+    auto push_item = [&](int kind, int R0, int C0, std::vector<std::pair<int, int>> lists[4]) {
         const size_t base = tab.size();
         tab.resize(base + T_ITEM, 0);
         tab[base] = kind; tab[base + 1] = R0; tab[base + 2] = C0;
         size_t longest = 0;
         for (int w = 0; w < 4; ++w) {
+            // diagonal blocks (same global block row and column) go last and are counted: they may skip segment 2
+            std::vector<std::pair<int, int>> ordered, diag;
+            for (auto &rc : lists[w]) ((kind != 1 && R0 + rc.first == C0 + rc.second) ? diag : ordered).push_back(rc);
+            if (diag.size() > 2) {                            // the kernel folds at most the last two blocks of a list
+                ordered.insert(ordered.end(), diag.begin(), diag.end() - 2);
+                diag.erase(diag.begin(), diag.end() - 2);
+            }
+            tab[base + 7] |= (int)diag.size() << (8 * w);
+            folded += (double)diag.size();
+            ordered.insert(ordered.end(), diag.begin(), diag.end());
+            lists[w] = ordered;
             tab[base + 3 + w] = (int)lists[w].size();
             longest = std::max(longest, lists[w].size());
             useful_blocks += (double)lists[w].size();
@@ -336,9 +376,9 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
         if (t.nemb == nemb && t.cfg == occ) tb = &t;
     if (!tb) {
         std::vector<int> h;
-        double useful, slots;
-        if (occ == 2) build_table(nemb, Cfg2::MAXBLK, Cfg2::SEG, h, useful, slots);
-        else build_table(nemb, Cfg3::MAXBLK, Cfg3::SEG, h, useful, slots);
+        double useful, slots, folded;
+        if (occ == 2) build_table(nemb, Cfg2::MAXBLK, Cfg2::SEG, h, useful, slots, folded);
+        else build_table(nemb, Cfg3::MAXBLK, Cfg3::SEG, h, useful, slots, folded);
         int *dev = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&dev), h.size() * sizeof(int)) != hipSuccess)
             return dmk_fail(ctx, DMK_ERR_NOMEM, "half2_tab: table allocation failed");
@@ -346,7 +386,7 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
             (void)hipFree(dev);
             return dmk_fail(ctx, DMK_ERR_HIP, "half2_tab: table upload failed");
         }
-        ctx->step2_tables.push_back({nemb, occ, (int)(h.size() / T_ITEM), useful, dev});
+        ctx->step2_tables.push_back({nemb, occ, (int)(h.size() / T_ITEM), useful, folded, dev});
         tb = &ctx->step2_tables.back();
     }
     H2TArgs a;
@@ -365,11 +405,14 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.nspin = nspin;
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.table = tb->dev; a.nitems = tb->nitems;
+    a.fold_diag = (a.symmask == (nslot >= 32 ? 0xffffffffu : ((1u << nslot) - 1u))) ? 1 : 0;
     const unsigned long long nblocks = (unsigned long long)tb->nitems * (unsigned)nL * (unsigned)nspin;
     if (nblocks > 0x7fffffffull) return 0;
     a.nblocks = (unsigned)nblocks;
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
-    fs.mfma_flops(6.0 * tb->useful_blocks * 256.0 * (double)nao * segs * (double)nL * (double)nspin);
+    // a symmetrised block runs a second segment -- without the folded diagonal blocks when the whole group is symmetrised
+    const double seg2 = (segs - (double)nslot) * (tb->useful_blocks - (a.fold_diag ? tb->folded_blocks : 0.0));
+    fs.mfma_flops(6.0 * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)nao * (double)nL * (double)nspin);
     if (occ == 2) hipLaunchKernelGGL(half2_tab_kernel<Cfg2>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL(half2_tab_kernel<Cfg3>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);

@@ -645,30 +645,32 @@ def test_tab_half_transform_planes(ctx, nao, naux, nemb, spin):
     rng = np.random.default_rng(nao + nemb)
     Cemb = (rng.standard_normal((spin, 4, nao, nemb)) + 1j * rng.standard_normal((spin, 4, nao, nemb))) / np.sqrt(nao)
     C_dev = ctx.to_device(Cemb)
-    pushes = [(1, 0, 1), (3, 2, 0), (0, 1, 1), (2, 3, 1), (0, 0, 0), (1, 1, 1), (2, 0, 0), (3, 1, 1), (0, 2, 1), (1, 3, 0), (2, 2, 1)]
-    ref = np.zeros((spin, naux, npair), dtype=np.complex128)
-    blocks = {}
-    for (i, j, sym) in pushes:
-        blocks[(i, j)] = R.df_block_philox(5, i, j, naux, nao)
-        Lij = R.transform_ao_to_emb(blocks[(i, j)].reshape(naux, -1), Cemb, i, j)
-        ref += R.pack_tril(Lij + Lij.transpose(0, 1, 3, 2) if sym else Lij)
-    scale = max(1.0, np.abs(ref).max())
-    for feed in ("push", "ring"):
-        eri_dev = ctx.zeros((spin * (spin + 1) // 2, 8, 8), np.float64)      # never contracted in this test
-        eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
-        assert eng.ring_slots == 8                                           # the grouped hot path is active for this shape
-        ctx.check(lib.dmk_eri_begin_kL(eng.h, 1))
-        for n, (i, j, sym) in enumerate(pushes):
-            if feed == "push":
-                d_blk = ctx.to_device(blocks[(i, j)])
-                ctx.check(lib.dmk_eri_push_block(eng.h, i, j, sym, d_blk.ptr))
-            else:
-                eng.ring[n % eng.ring_slots].set(blocks[(i, j)])
-                ctx.check(lib.dmk_eri_push_ring_slot(eng.h, i, j, sym))
-        planes = eng.planes().get()
-        got = planes[:, 0] + 1j * planes[:, 1]
-        assert np.abs(got - ref).max() < 1e-11 * scale, (feed, np.abs(got - ref).max())
-        eng.close()
+    mixed = [(1, 0, 1), (3, 2, 0), (0, 1, 1), (2, 3, 1), (0, 0, 0), (1, 1, 1), (2, 0, 0), (3, 1, 1), (0, 2, 1), (1, 3, 0), (2, 2, 1)]
+    # second pass: every block symmetrised (the usual case) -> the diagonal blocks are folded as P + P^T in the epilogue
+    for pushes in (mixed, [(i, j, 1) for (i, j, _) in mixed]):
+        ref = np.zeros((spin, naux, npair), dtype=np.complex128)
+        blocks = {}
+        for (i, j, sym) in pushes:
+            blocks[(i, j)] = R.df_block_philox(5, i, j, naux, nao)
+            Lij = R.transform_ao_to_emb(blocks[(i, j)].reshape(naux, -1), Cemb, i, j)
+            ref += R.pack_tril(Lij + Lij.transpose(0, 1, 3, 2) if sym else Lij)
+        scale = max(1.0, np.abs(ref).max())
+        for feed in ("push", "ring"):
+            eri_dev = ctx.zeros((spin * (spin + 1) // 2, 8, 8), np.float64)      # never contracted in this test
+            eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+            assert eng.ring_slots == 8                                           # the grouped hot path is active for this shape
+            ctx.check(lib.dmk_eri_begin_kL(eng.h, 1))
+            for n, (i, j, sym) in enumerate(pushes):
+                if feed == "push":
+                    d_blk = ctx.to_device(blocks[(i, j)])
+                    ctx.check(lib.dmk_eri_push_block(eng.h, i, j, sym, d_blk.ptr))
+                else:
+                    eng.ring[n % eng.ring_slots].set(blocks[(i, j)])
+                    ctx.check(lib.dmk_eri_push_ring_slot(eng.h, i, j, sym))
+            planes = eng.planes().get()
+            got = planes[:, 0] + 1j * planes[:, 1]
+            assert np.abs(got - ref).max() < 1e-11 * scale, (feed, np.abs(got - ref).max())
+            eng.close()
 
 
 @pytest.mark.parametrize("nao,naux,nemb,spin", [(40, 24, 256, 2), (10, 7, 12, 1), (24, 16, 40, 2)])
