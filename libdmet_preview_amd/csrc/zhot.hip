@@ -43,7 +43,6 @@ namespace {
 // step 1: flattened M-blocks (batch L folded into M), tile 128 x 64, BK = 8, 3-stage ring (72 KiB)
 // =============================================================================================
 constexpr int H1_BM = 128, H1_BN = 64, H1_BK = 8, H1_D = 3;
-constexpr int H1_STAGE = H1_BK * (H1_BM + H1_BN);     // double2 elements per stage (24 KiB)
 
 // out[L][m][n] = sum_k A[L][k][m] * op(B[k][n]),  op = conj (step 1: B = C_i) or identity (step 2 of general nemb: B = C_j).
 // A is K-major: element (k, m) of batch L at L * (nao * mrows) + k * mrows + m  (step 1: Lpq, mrows = nao; step 2: Ut,
@@ -74,11 +73,16 @@ struct H1Args {
      : (SLOT) == 8 ? (G).bk[8] : (SLOT) == 9 ? (G).bk[9] : (SLOT) == 10 ? (G).bk[10] : (SLOT) == 11 ? (G).bk[11] \
      : (SLOT) == 12 ? (G).bk[12] : (SLOT) == 13 ? (G).bk[13] : (SLOT) == 14 ? (G).bk[14] : (G).bk[15])
 
-template <bool CONJB>
-__global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
-    __shared__ __attribute__((aligned(16))) double2 lds[H1_D * H1_STAGE];
+// BM = 128 (wave tile 64 x 32, 8 accumulator tiles, two workgroups per CU) or BM = 64 (wave tile 32 x 32, 4 tiles, three
+// workgroups per CU)
+template <bool CONJB, int BM, int OCC>
+__global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
+    constexpr int MI = BM / 32;                          // 16-row blocks per wave
+    constexpr int AH = BM / 64;                          // 1 KiB pieces per K row of the A panel
+    constexpr int STAGE = H1_BK * (BM + H1_BN);
+    __shared__ __attribute__((aligned(16))) double2 lds[H1_D * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;            // 2 (M) x 2 (N) waves, wave tile 64 x 32
+    const int wm = wave >> 1, wn = wave & 1;            // 2 (M) x 2 (N) waves, wave tile (BM / 2) x 32
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
     const unsigned lid_all = xcd_remap(blockIdx.x, g.nblocks);
@@ -95,11 +99,11 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride + (long long)slot * g.out_slot_stride;
 
     // ---- per-lane LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB) ----
-    const double2 *srcA[2], *srcB;
+    const double2 *srcA[AH], *srcB;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < AH; ++h) {
         const int m = 64 * h + lane;
-        const int gb = tile_m * (H1_BM / 16) + (m >> 4);
+        const int gb = tile_m * (BM / 16) + (m >> 4);
         int L = gb / g.nblk;
         int q = (gb - L * g.nblk) * 16 + (m & 15);
         if (L >= g.nL) L = g.nL - 1;                    // clamped lanes only ever feed masked outputs
@@ -112,20 +116,20 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
         srcB = Bsp + col;
     }
     auto issue = [&](int t) {
-        double2 *st = lds + (t % H1_D) * H1_STAGE;
+        double2 *st = lds + (t % H1_D) * STAGE;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int k = wave * 2 + r;
             const long long kg = (long long)t * H1_BK + k;
-            glds16(srcA[0] + kg * mrows, lds_addr_of(st + k * H1_BM));
-            glds16(srcA[1] + kg * mrows, lds_addr_of(st + k * H1_BM + 64));
-            glds16(srcB + kg * nemb, lds_addr_of(st + H1_BK * H1_BM + k * H1_BN));
+#pragma unroll
+            for (int h = 0; h < AH; ++h) glds16(srcA[h] + kg * mrows, lds_addr_of(st + k * BM + 64 * h));
+            glds16(srcB + kg * nemb, lds_addr_of(st + H1_BK * BM + k * H1_BN));
         }
     };
 
-    cacc acc[4][2];
+    cacc acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) cacc_zero(acc[i][j]);
 
@@ -133,17 +137,21 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
     issue(0);
     if (T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
-        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile t landed; tile t+1 may be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 1 < T) {                                                     // tile t landed; tile t+1 may be in flight
+            if (AH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (t + 2 < T) issue(t + 2);
-        const double2 *Ab = lds + (t % H1_D) * H1_STAGE + wm * 64 + frag_x;
-        const double2 *Bb = lds + (t % H1_D) * H1_STAGE + H1_BK * H1_BM + wn * 32 + frag_x;
+        const double2 *Ab = lds + (t % H1_D) * STAGE + wm * (BM / 2) + frag_x;
+        const double2 *Bb = lds + (t % H1_D) * STAGE + H1_BK * BM + wn * 32 + frag_x;
 #pragma unroll
         for (int kk = 0; kk < H1_BK / 4; ++kk) {
-            cfrag a[4], b[2];
+            cfrag a[MI], b[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = cfrag_of(lds_frag(&Ab[(kk * 4 + frag_k) * H1_BM + i * 16]));
+            for (int i = 0; i < MI; ++i) a[i] = cfrag_of(lds_frag(&Ab[(kk * 4 + frag_k) * BM + i * 16]));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 double2 v = lds_frag(&Bb[(kk * 4 + frag_k) * H1_BN + j * 16]);
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
                 b[j] = cfrag_of(v);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) cmfma(acc[i][j], a[i], b[j]);
         }
@@ -159,8 +167,8 @@ __global__ __launch_bounds__(HNT, 2) void half1_kernel(const H1Args g) {
 
     // ---- epilogue: Ut[L][q][a] ---------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gb = tile_m * (H1_BM / 16) + wm * 4 + i;
+    for (int i = 0; i < MI; ++i) {
+        const int gb = tile_m * (BM / 16) + wm * MI + i;
         const int L = gb / g.nblk;
         if (L >= g.nL) continue;
         const int qb = (gb - L * g.nblk) * 16;
@@ -477,6 +485,7 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
                            long long a_slot_stride = 0, long long out_slot_stride = 0, long long b_k_stride = 0,
                            const int *bk = nullptr) {
     if (!half1_hot_usable(nL, K, N) || (long long)nL * mrows < 4 * H1_BM) return 0;
+    static const int bm = [] { const char *e = getenv("DMK_ERI_H1_BM"); return (e && atoi(e) == 64) ? 64 : 128; }();
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) return 0;
     H1Args a;
     a.Lpq = reinterpret_cast<const double2 *>(A);
@@ -485,7 +494,7 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     a.nL = nL; a.nao = K; a.nemb = N; a.mrows = mrows;
     a.nblk = (mrows + 15) / 16;
     const long long total_blk = (long long)nL * a.nblk;
-    a.tiles_m = (int)((total_blk + H1_BM / 16 - 1) / (H1_BM / 16));
+    a.tiles_m = (int)((total_blk + bm / 16 - 1) / (bm / 16));
     a.tiles_n = (N + H1_BN - 1) / H1_BN;
     a.nspin = nspin; a.b_spin_stride = b_spin_stride; a.out_spin_stride = out_spin_stride;
     if (nslot < 1 || nslot > 16) return 0;
@@ -495,9 +504,14 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     if ((unsigned long long)a.per_slot * (unsigned)nslot > 0x7fffffffull) return 0;
     a.nblocks = a.per_slot * (unsigned)nslot;
     FamScope fs(ctx, fam);
-    fs.mfma_flops(6.0 * (double)a.nblocks * H1_BM * H1_BN * (double)K);
-    if (conjB) hipLaunchKernelGGL(half1_kernel<true>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(half1_kernel<false>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    fs.mfma_flops(6.0 * (double)a.nblocks * bm * H1_BN * (double)K);
+    if (bm == 128) {
+        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 128, 2>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half1_kernel<false, 128, 2>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    } else {
+        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 64, 3>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half1_kernel<false, 64, 3>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    }
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }
