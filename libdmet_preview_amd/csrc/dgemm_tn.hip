@@ -212,10 +212,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int is_stage = 0;
     auto issue = [&]() {
         double *st = lds + is_stage * G_STAGE + (2 * wave) * G_LD;
-        glds16(pA, lds_addr_of(st));
-        glds16(pA + ldx, lds_addr_of(st + G_LD));
-        glds16(pB, lds_addr_of(st + GBK * G_LD));
-        glds16(pB + ldy, lds_addr_of(st + GBK * G_LD + G_LD));
+        glds16_x4(pA, pA + ldx, pB, pB + ldy, lds_addr_of(st), lds_addr_of(st + G_LD), lds_addr_of(st + GBK * G_LD),
+                  lds_addr_of(st + GBK * G_LD + G_LD));
         pA += stepA;
         pB += stepB;
         is_stage = is_stage + 1 == GD ? 0 : is_stage + 1;

@@ -117,13 +117,17 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     }
     auto issue = [&](int t) {
         double2 *st = lds + (t % H1_D) * STAGE;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int k = wave * 2 + r;
-            const long long kg = (long long)t * H1_BK + k;
-#pragma unroll
-            for (int h = 0; h < AH; ++h) glds16(srcA[h] + kg * mrows, lds_addr_of(st + k * BM + 64 * h));
-            glds16(srcB + kg * nemb, lds_addr_of(st + H1_BK * BM + k * H1_BN));
+        const int k0 = wave * 2;
+        const long long kg = (long long)t * H1_BK + k0;
+        if constexpr (AH == 2) {
+            glds16_x6(srcA[0] + kg * mrows, srcA[1] + kg * mrows, srcB + kg * nemb, srcA[0] + (kg + 1) * mrows,
+                      srcA[1] + (kg + 1) * mrows, srcB + (kg + 1) * nemb, lds_addr_of(st + k0 * BM), lds_addr_of(st + k0 * BM + 64),
+                      lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM), lds_addr_of(st + (k0 + 1) * BM + 64),
+                      lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
+        } else {
+            glds16_x4(srcA[0] + kg * mrows, srcB + kg * nemb, srcA[0] + (kg + 1) * mrows, srcB + (kg + 1) * nemb,
+                      lds_addr_of(st + k0 * BM), lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
+                      lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
         }
     };
 
@@ -259,12 +263,8 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         // running issue state (wave-uniform, SGPRs): no division and no kernel-argument load per K-tile
         int is_t = 0, is_slot = 0, is_stage = 0;
         const double2 *is_ub = Ubase, *is_cb = H2_PICK_CJ(g, 0) + cj_off;
-        // (spreading the four pieces of a tile over the MFMA stream of a K step, instead of this burst after the barrier,
+        // (spreading the four pieces of a tile over the MFMA stream of a K step, instead of a burst after the barrier,
         // measured 2.5 % slower: the inline-asm DMA statements pin the compiler's MFMA / ds_read schedule)
-        auto issue_piece = [&](int h) {
-            double2 *st = lds + is_stage * H2T_STAGE;
-            glds16((h < 2 ? is_ub : is_cb) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
-        };
         auto issue_advance = [&]() {
             is_stage = is_stage + 1 == H2T_D ? 0 : is_stage + 1;
             if (++is_t == Tb) {
@@ -278,8 +278,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             }
         };
         auto issue = [&]() {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) issue_piece(h);
+            double2 *st = lds + is_stage * H2T_STAGE;
+            glds16_x4(is_ub + soff[0], is_ub + soff[1], is_cb + soff[2], is_cb + soff[3], lds_addr_of(st + wave * 64),
+                      lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64));
             issue_advance();
         };
         auto run = [&](auto tag) {
@@ -395,9 +396,12 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     const double2 *is_ub = Ubase, *is_cb = H2_PICK_CJ(g, 0) + cj_off;
     auto issue = [&]() {
         double2 *st = lds + is_stage * H2S_STAGE;
+        const double2 *gp[6];
 #pragma unroll
-        for (int h = 0; h < 6; ++h)
-            glds16((isC[h] ? is_cb : is_ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+        for (int h = 0; h < 6; ++h) gp[h] = (isC[h] ? is_cb : is_ub) + soff[h];
+        glds16_x6(gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], lds_addr_of(st + wave * 64), lds_addr_of(st + (wave + 4) * 64),
+                  lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64), lds_addr_of(st + (wave + 16) * 64),
+                  lds_addr_of(st + (wave + 20) * 64));
         is_stage = is_stage + 1 == H2S_D ? 0 : is_stage + 1;
         if (++is_t == Tb) {
             is_t = 0;

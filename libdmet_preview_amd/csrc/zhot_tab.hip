@@ -153,8 +153,16 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
         const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, 0) + cj_off;
         auto issue = [&]() {
             double2 *st = lds + is_stage * STAGE;
+            const double2 *gp[NP];
 #pragma unroll
-            for (int h = 0; h < NP; ++h) glds16((isC[h] ? is_cb : is_ub) + soff[h], lds_addr_of(st + (wave + 4 * h) * 64));
+            for (int h = 0; h < NP; ++h) gp[h] = (isC[h] ? is_cb : is_ub) + soff[h];
+            if constexpr (NP == 4)
+                glds16_x4(gp[0], gp[1], gp[2], gp[3], lds_addr_of(st + wave * 64), lds_addr_of(st + (wave + 4) * 64),
+                          lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64));
+            else
+                glds16_x6(gp[0], gp[1], gp[2], gp[3], gp[NP - 2], gp[NP - 1], lds_addr_of(st + wave * 64),
+                          lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64),
+                          lds_addr_of(st + (wave + 16) * 64), lds_addr_of(st + (wave + 20) * 64));
             is_stage = is_stage + 1 == D ? 0 : is_stage + 1;
             if (++is_t == Tb) {
                 is_t = 0;
