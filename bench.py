@@ -285,6 +285,8 @@ def main():
         C_host = out["C_ao_emb"].get().reshape(sysm.spin, sysm.nk, sysm.nao, nemb)
         # cost of the oracle: the Philox regeneration of every visited block, ~0.16 core-seconds per C5 block
         est = out["nblocks"] * 0.16 * (sysm.naux * sysm.nao ** 2 / (800.0 * 200 ** 2)) / threads
+        if distributed:       # shards differ slightly in their block counts: every rank must take the same branch below
+            est = float(dist.all_reduce_sum_numpy(np.array([est]))[0]) / world
         check_kl, check_dev, scope = kl_mine, eri_dev, "timed ERI"
         if est > a.parity_budget_s:
             keep = max(1, int(len(kl_mine) * a.parity_budget_s / est))
