@@ -174,10 +174,19 @@ def main():
     if distributed:
         import torch
         import torch.distributed as td
+        # DMK_BENCH_BACKEND=gloo with DMK_BENCH_ONE_GPU=1 runs every rank on GPU 0 with host-staged exchanges: the whole
+        # multi-rank code path of this script (shards, exchanges, parity sum) on a 1-GPU box; never used for reported numbers
+        backend = os.environ.get("DMK_BENCH_BACKEND", "nccl")
+        if os.environ.get("DMK_BENCH_ONE_GPU", "0") == "1":
+            local = 0
+            os.environ["DMK_DEVICE"] = "0"
         if local >= torch.cuda.device_count():
             raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
         torch.cuda.set_device(local)
-        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend)
     from libdmet_preview_amd import _lib, pipeline, synth
     from libdmet_preview_amd.basis_transform import eri_transform as et
     from libdmet_preview_amd.parallel import dist
@@ -263,11 +272,9 @@ def main():
     if distributed:
         agg = dist.all_reduce_sum_numpy(np.array([flops, exec_mine]))
         flops_all, exec_all = float(agg[0]), float(agg[1])
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        import torch.distributed as td
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        slots = np.zeros(world)
+        slots[rank] = elapsed
+        elapsed = float(dist.all_reduce_sum_numpy(slots).max())         # max over ranks
     else:
         flops_all, exec_all = flops, exec_mine
 
