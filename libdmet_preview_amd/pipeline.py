@@ -156,7 +156,7 @@ def bath_stage(ctx, sysm, d_rhoR, timers=None, tol_bath=1e-9):
     return d_basis, nemb, sigmas
 
 
-def c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers=None):
+def c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers=None, return_basis_k=False):
     timers = {} if timers is None else timers
     n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
     t = time.perf_counter()
@@ -164,17 +164,18 @@ def c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers=None):
     d_C = bgemm_dev(ctx, "N", "N", n, nemb, n, spin * nk, sysm.d_C_ao_lo, n * n, d_bk, n * nemb,
                     alpha=1.0 / (nk ** 0.75)).reshape(spin, nk, n, nemb)
     _stage(ctx, timers, "c_ao_emb", t)
-    return d_C
+    return (d_C, d_bk) if return_basis_k else d_C     # the embedding-Hamiltonian stage folds with the same basis_k
 
 
-def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None):
+def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None, d_bk=None):
     """One-body part of the embedding Hamiltonian (slater.py:525-606, interacting bath, HF):
     H1 = basis^H fock basis - JK_emb(rdm1_emb, ERI), JK_core = H1 - hcore_emb.  Everything is replicated
     (every rank holds rho_R and, after the all-reduce, the ERI).  Returns host (spin, nemb, nemb) arrays."""
     timers = {} if timers is None else timers
     n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
     t = time.perf_counter()
-    d_bk = fourier.fold_R2k_dev(d_basis.reshape(spin, nk, n * nemb), sysm.mesh, spin, n * nemb)
+    if d_bk is None:
+        d_bk = fourier.fold_R2k_dev(d_basis.reshape(spin, nk, n * nemb), sysm.mesh, spin, n * nemb)
     d_rho_k = fourier.fold_R2k_dev(d_rhoR.reshape(spin, nk, n * n), sysm.mesh, spin, n * n)
 
     def fold(d_op_k):
@@ -280,7 +281,7 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
     d_basis, nemb, sigmas = bath_stage(ctx, sysm, d_rhoR, timers)
     out = {"rho_R": d_rhoR, "basis": d_basis, "nemb": nemb, "sigma": sigmas, "mu": mf["mu"], "timers": timers}
     if sysm.naux > 0:
-        d_C = c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers)
+        d_C, d_bk = c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers, return_basis_k=True)
         npair = nemb * (nemb + 1) // 2
         spin_pair = sysm.spin * (sysm.spin + 1) // 2
         if eri_dev is None:
@@ -292,5 +293,5 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
             _stage(ctx, timers, "allreduce_eri", t)
         out.update({"C_ao_emb": d_C, "eri": eri_dev, "nblocks": nblk, "flops_half": fh, "flops_contract": fc})
         if emb_ham:
-            out["emb_ham"] = emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers)
+            out["emb_ham"] = emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers, d_bk=d_bk)
     return out
