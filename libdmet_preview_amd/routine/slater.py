@@ -253,56 +253,60 @@ def _embHam2e(lattice, basis, vcor, local, int_bath=True, last_aabb=True, **kwar
 
 
 def _embHam1e(lattice, basis, vcor, H2_emb, int_bath=True, add_vcor=False, **kwargs):
-    """H1_emb and ovlp_emb (slater.py:525-680), Hartree-Fock branches; sets lattice.JK_core."""
-    for k in ("dft", "qsgw", "vxc_dc"):
-        if kwargs.get(k, False):
-            raise NotImplementedError("%s embedding Hamiltonian is outside the HIP path" % k)
+    """One-body part of the embedding Hamiltonian and the embedding overlap for Hartree-Fock mean fields
+    (reference behaviour: routine/slater.py:525-680); also leaves `lattice.JK_core` behind, like the reference.
+
+    Three regimes decide what the bare fold B^H fock B is corrected by:
+      interacting bath      -- the mean-field potential of the EMBEDDED density with the embedding ERI is taken out
+                               (it is double counted by the impurity solver), JK_core = H1 - hcore_emb;
+      bare bath, hcore      -- `use_hcore_as_emb_ham`: nothing to correct, no JK_core;
+      bare bath, Fock       -- the impurity-local JK (given as `JK_imp`, else rebuilt from the embedded density) is
+                               taken out.
+    A bare bath always carries the correlation potential; with `add_vcor` an interacting one does too (on the
+    environment only unless `fitting`).  Every fold (1/nk) Re sum_k B_k^H O_k B_k runs on the device."""
+    unsupported = [k for k in ("dft", "qsgw", "vxc_dc") if kwargs.get(k, False)]
+    if unsupported:
+        raise NotImplementedError("%s embedding Hamiltonian is outside the HIP path" % unsupported[0])
     spin = basis.shape[0]
     basis_k = lattice.R2k_basis(basis)
-    hcore_k = lattice.getH1(kspace=True)
-    fock_k = lattice.getFock(kspace=True)
-    ovlp_k = lattice.get_ovlp(kspace=True)
-    JK_imp = lattice.get_JK_imp()
-    if not isinstance(H2_emb, np.ndarray):
-        H2_emb = np.asarray(H2_emb["ccdd"])
+    fold = lambda op_k: transform_h1(op_k, basis_k)
+    eri = H2_emb if isinstance(H2_emb, np.ndarray) else np.asarray(H2_emb["ccdd"])
+    embedded_density = lambda: foldRho_k(lattice.rdm1_lo_k, basis_k)
 
-    hcore_emb = transform_h1(hcore_k, basis_k)
-    ovlp_emb = transform_h1(ovlp_k, basis_k)
-    if ovlp_emb.ndim == 3 and ovlp_emb.shape[0] == 1:
+    hcore_emb = fold(lattice.getH1(kspace=True))
+    ovlp_emb = fold(lattice.get_ovlp(kspace=True))
+    if ovlp_emb.ndim == 3 and len(ovlp_emb) == 1:
         ovlp_emb = ovlp_emb[0]
+    fock_k = lattice.getFock(kspace=True)
+    JK_imp = lattice.get_JK_imp()                      # read before any branch: the reference queries it up front
 
     if int_bath:
-        rdm1_emb = foldRho_k(lattice.rdm1_lo_k, basis_k)
         if not lattice.is_model:
             fock_k = lattice.hcore_lo_k + lattice.vhf_lo_k
-        H1 = transform_h1(fock_k, basis_k)
-        # subtract JK_emb = rho_kl [2 (ij||kl) - (il||jk)], all indices in the embedding basis
-        H1 -= get_veff(rdm1_emb, H2_emb)
+        H1 = fold(fock_k) - get_veff(embedded_density(), eri)
         lattice.JK_core = H1 - hcore_emb
+        with_vcor = add_vcor
+    elif lattice.use_hcore_as_emb_ham:
+        H1, lattice.JK_core, with_vcor = hcore_emb, None, True
     else:
-        add_vcor = True
-        if lattice.use_hcore_as_emb_ham:
-            H1 = hcore_emb
-            lattice.JK_core = None
+        if JK_imp is None:
+            local_jk = get_veff(embedded_density(), eri)
         else:
-            H1 = transform_h1(fock_k, basis_k)
-            if JK_imp is not None:
-                JK_imp = np.asarray(JK_imp)
-                if JK_imp.ndim == 2:
-                    JK_emb = np.asarray([transform_imp(basis[s], lattice, JK_imp) for s in range(spin)])
-                else:
-                    JK_emb = np.asarray([transform_imp(basis[s], lattice, JK_imp[s]) for s in range(spin)])
-            else:
-                JK_emb = get_veff(foldRho_k(lattice.rdm1_lo_k, basis_k), H2_emb)
-            H1 -= JK_emb
-            lattice.JK_core = H1 - hcore_emb
+            JK_imp = np.asarray(JK_imp)
+            per_spin = (lambda s: JK_imp) if JK_imp.ndim == 2 else (lambda s: JK_imp[s])
+            local_jk = np.asarray([transform_imp(basis[s], lattice, per_spin(s)) for s in range(spin)])
+        H1 = fold(fock_k) - local_jk
+        lattice.JK_core = H1 - hcore_emb
+        with_vcor = True
 
-    if add_vcor:
+    if with_vcor:
         log.eassert(vcor.islocal(), "nonlocal correlation potential cannot be treated in this routine")
+        on_impurity_too = bool(kwargs.get("fitting", False))
+        v = vcor.get()
         for s in range(spin):
-            H1[s] += transform_local(basis[s], lattice, vcor.get()[s])
-            if not "fitting" in kwargs or not kwargs["fitting"]:
-                H1[s] -= transform_imp(basis[s], lattice, vcor.get()[s])
+            H1[s] += transform_local(basis[s], lattice, v[s])
+            if not on_impurity_too:
+                H1[s] -= transform_imp(basis[s], lattice, v[s])
     return H1, ovlp_emb
 
 
