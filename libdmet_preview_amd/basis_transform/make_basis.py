@@ -47,29 +47,32 @@ def _result(x, *inputs):
     return x
 
 
+def _spin_stacks(*stacks):
+    """Bring (nk, ., .) / (spin, nk, ., .) stacks to a common leading spin axis (a single channel is repeated).
+    Returns the flattened (spin * nk, ., .) views, the spin count and whether ANY input carried a spin axis."""
+    stacks = [np.asarray(x) for x in stacks]
+    if any(x.ndim not in (3, 4) for x in stacks):
+        raise ValueError("expected (nkpts, n, m) or (spin, nkpts, n, m) arrays, got shapes %s" % ([x.shape for x in stacks],))
+    spin = get_spin_dim(stacks)
+    flat = []
+    for x in stacks:
+        x = add_spin_dim(x, spin)
+        flat.append(x.reshape((spin * x.shape[1],) + x.shape[2:]))
+    return flat, spin, any(x.ndim == 4 for x in stacks)
+
+
+def _unflatten(out, spin, keep_spin):
+    return out.reshape((spin, out.shape[0] // spin) + out.shape[1:]) if keep_spin else out
+
+
 def multiply_basis(C_ao_lo, C_lo_eo):
-    """C_ao_eo = C_ao_lo * C_lo_eo per (spin,) k-point."""
-    C_ao_lo = np.asarray(C_ao_lo)
-    C_lo_eo = np.asarray(C_lo_eo)
-    nkpts, nlo, neo = C_lo_eo.shape[-3:]
-    nao = C_ao_lo.shape[-2]
-    if C_ao_lo.ndim == 3 and C_lo_eo.ndim == 3:
-        return _result(_bgemm("N", "N", C_ao_lo, C_lo_eo), C_ao_lo, C_lo_eo)
-    if C_ao_lo.ndim == 3 and C_lo_eo.ndim == 4:
-        spin = C_lo_eo.shape[0]
-        C_ao_lo = add_spin_dim(C_ao_lo, spin)
-    elif C_ao_lo.ndim == 4 and C_lo_eo.ndim == 3:
-        spin = C_ao_lo.shape[0]
-        C_lo_eo = add_spin_dim(C_lo_eo, spin)
-    elif C_ao_lo.ndim == 4 and C_lo_eo.ndim == 4:
-        spin = max(C_ao_lo.shape[0], C_lo_eo.shape[0])
-        C_ao_lo = add_spin_dim(C_ao_lo, spin)
-        C_lo_eo = add_spin_dim(C_lo_eo, spin)
-    else:
+    """C_ao_eo[s, k] = C_ao_lo[s, k] C_lo_eo[s, k] (make_basis.py:923-962); either factor may omit the spin axis."""
+    try:
+        (A, B), spin, keep = _spin_stacks(C_ao_lo, C_lo_eo)
+    except ValueError:
         raise ValueError("invalid shape for multiply_basis: C_ao_lo shape %s, C_lo_eo shape: %s"
-                         % (C_ao_lo.shape, C_lo_eo.shape))
-    out = _bgemm("N", "N", C_ao_lo.reshape(spin * nkpts, nao, nlo), C_lo_eo.reshape(spin * nkpts, nlo, neo))
-    return _result(out.reshape(spin, nkpts, nao, neo), C_ao_lo, C_lo_eo)
+                         % (np.shape(C_ao_lo), np.shape(C_lo_eo)))
+    return _result(_unflatten(_bgemm("N", "N", A, B), spin, keep), C_ao_lo, C_lo_eo)
 
 
 def _triple(opL, L, Mid, opR, Rt):
@@ -91,67 +94,29 @@ def _triple(opL, L, Mid, opR, Rt):
 
 
 def transform_h1_to_lo(h_ao_ao, C_ao_lo):
-    r"""h^{LO} = C^{\dagger} h^{AO} C, with kpts."""
+    r"""h^{LO}[s, k] = C^{\dagger} h^{AO} C (make_basis.py:524-558).  A scalar (or one scalar per spin) stands for that
+    multiple of the all-ones matrix and is only broadcast."""
     h_ao_ao = np.asarray(h_ao_ao)
     C_ao_lo = np.asarray(C_ao_lo)
-    nkpts = C_ao_lo.shape[-3]
-    nlo = C_ao_lo.shape[-1]
-    res_type = np.result_type(h_ao_ao.dtype, C_ao_lo.dtype)
-    if h_ao_ao.ndim == 0:
-        return np.ones((nkpts, nlo, nlo), dtype=res_type) * h_ao_ao
-    elif h_ao_ao.ndim == 1:
-        spin = len(h_ao_ao)
-        h_lo_lo = np.ones((spin, nkpts, nlo, nlo), dtype=res_type)
-        for s in range(spin):
-            h_lo_lo[s] *= h_ao_ao[s]
-        return h_lo_lo
-    if C_ao_lo.ndim == 3 and h_ao_ao.ndim == 3:
-        return _result(_triple("C", C_ao_lo, h_ao_ao, "N", C_ao_lo), h_ao_ao, C_ao_lo)
-    spin = get_spin_dim((h_ao_ao, C_ao_lo))
-    h_ao_ao = add_spin_dim(h_ao_ao, spin)
-    C_ao_lo = add_spin_dim(C_ao_lo, spin)
-    assert h_ao_ao.ndim == C_ao_lo.ndim
-    nao = C_ao_lo.shape[-2]
-    Cf = C_ao_lo.reshape(spin * nkpts, nao, nlo)
-    out = _triple("C", Cf, h_ao_ao.reshape(spin * nkpts, nao, nao), "N", Cf)
-    return _result(out.reshape(spin, nkpts, nlo, nlo), h_ao_ao, C_ao_lo)
+    nkpts, nlo = C_ao_lo.shape[-3], C_ao_lo.shape[-1]
+    if h_ao_ao.ndim <= 1:
+        ones = np.ones((nkpts, nlo, nlo), dtype=np.result_type(h_ao_ao.dtype, C_ao_lo.dtype))
+        return ones * h_ao_ao if h_ao_ao.ndim == 0 else np.asarray([ones * x for x in h_ao_ao])
+    (H, Cf), spin, keep = _spin_stacks(h_ao_ao, C_ao_lo)
+    return _result(_unflatten(_triple("C", Cf, H, "N", Cf), spin, keep), h_ao_ao, C_ao_lo)
 
 
 def transform_rdm1_to_lo(dm_ao_ao, C_ao_lo, S_ao_ao):
-    r"""\gamma^{LO} = C^{-1} \gamma^{AO} (C^{-1})^{\dagger},  C^{-1} = C^{\dagger} S."""
-    dm_ao_ao = np.asarray(dm_ao_ao)
-    C_ao_lo = np.asarray(C_ao_lo)
-    S_ao_ao = np.asarray(S_ao_ao)
-    nkpts = C_ao_lo.shape[-3]
-    nlo = C_ao_lo.shape[-1]
-    nao = C_ao_lo.shape[-2]
-    if C_ao_lo.ndim == 3 and dm_ao_ao.ndim == 3:
-        Cinv = _bgemm("C", "N", C_ao_lo, S_ao_ao)
-        return _result(_triple("N", Cinv, dm_ao_ao, "C", Cinv), dm_ao_ao, C_ao_lo, S_ao_ao)
-    spin = get_spin_dim((dm_ao_ao, C_ao_lo))
-    dm_ao_ao = add_spin_dim(dm_ao_ao, spin)
-    C_ao_lo = add_spin_dim(C_ao_lo, spin)
-    assert dm_ao_ao.ndim == C_ao_lo.ndim
-    Cf = C_ao_lo.reshape(spin * nkpts, nao, nlo)
-    Sf = np.ascontiguousarray(np.broadcast_to(S_ao_ao[None], (spin,) + S_ao_ao.shape)).reshape(spin * nkpts, nao, nao)
+    r"""\gamma^{LO} = C^{-1} \gamma^{AO} (C^{-1})^{\dagger} with C^{-1} = C^{\dagger} S (make_basis.py:590-618); the overlap has
+    no spin axis."""
+    (D, Cf, Sf), spin, _ = _spin_stacks(dm_ao_ao, C_ao_lo, S_ao_ao)
+    keep = np.ndim(dm_ao_ao) == 4 or np.ndim(C_ao_lo) == 4
     Cinv = _bgemm("C", "N", Cf, Sf)
-    out = _triple("N", Cinv, dm_ao_ao.reshape(spin * nkpts, nao, nao), "C", Cinv)
-    return _result(out.reshape(spin, nkpts, nlo, nlo), dm_ao_ao, C_ao_lo, S_ao_ao)
+    return _result(_unflatten(_triple("N", Cinv, D, "C", Cinv), spin, keep), dm_ao_ao, C_ao_lo, S_ao_ao)
 
 
 def transform_rdm1_to_ao(dm_lo_lo, C_ao_lo):
-    r"""\gamma^{AO} = C \gamma^{LO} C^{\dagger}."""
-    dm_lo_lo = np.asarray(dm_lo_lo)
-    C_ao_lo = np.asarray(C_ao_lo)
-    nkpts = C_ao_lo.shape[-3]
-    nao = C_ao_lo.shape[-2]
-    nlo = C_ao_lo.shape[-1]
-    if C_ao_lo.ndim == 3 and dm_lo_lo.ndim == 3:
-        return _result(_triple("N", C_ao_lo, dm_lo_lo, "C", C_ao_lo), dm_lo_lo, C_ao_lo)
-    spin = get_spin_dim((dm_lo_lo, C_ao_lo))
-    dm_lo_lo = add_spin_dim(dm_lo_lo, spin)
-    C_ao_lo = add_spin_dim(C_ao_lo, spin)
-    assert dm_lo_lo.ndim == C_ao_lo.ndim
-    Cf = C_ao_lo.reshape(spin * nkpts, nao, nlo)
-    out = _triple("N", Cf, dm_lo_lo.reshape(spin * nkpts, nlo, nlo), "C", Cf)
-    return _result(out.reshape(spin, nkpts, nao, nao), dm_lo_lo, C_ao_lo)
+    r"""\gamma^{AO} = C \gamma^{LO} C^{\dagger} (make_basis.py:620-644)."""
+    (D, Cf), spin, keep = _spin_stacks(dm_lo_lo, C_ao_lo)
+    return _result(_unflatten(_triple("N", Cf, D, "C", Cf), spin, keep), dm_lo_lo, C_ao_lo)
+
