@@ -53,6 +53,10 @@ int dmk_init(int device, void *stream, dmk_ctx **out);
 int dmk_destroy(dmk_ctx *ctx);
 int dmk_set_stream(dmk_ctx *ctx, void *stream);
 int dmk_sync(dmk_ctx *ctx);
+/* Out-of-memory hook: called (with `user`) when a device allocation INSIDE the library fails, after the context stream
+ * has been drained; the allocation is retried once when it returns.  The host binding registers the release of its
+ * device-block cache here (libdmet_preview_amd/_lib.py Context.trim), memory the library cannot see otherwise. */
+int dmk_set_oom_hook(dmk_ctx *ctx, void (*hook)(void *user), void *user);
 const char *dmk_last_error(const dmk_ctx *ctx);
 const char *dmk_version(void);
 
@@ -276,6 +280,10 @@ int dmk_eri_flops(const dmk_eri *h, double flops_host[2]);
  * `eri_imag_norm = max_abs(eri.imag)` diagnostic of eri_transform.py:385-394 (compared with ERI_IMAG_TOL by the
  * caller).  0 with time reversal. */
 int dmk_eri_imag_norm(dmk_eri *h, double *maxabs_host);
+/* The accumulator dmk_eri_imag_norm reduces: device f64, (spin*(spin+1)/2) x npair x npair, NULL / 0 elements with time
+ * reversal.  A kL-sharded job sums it over ranks BEFORE taking the norm -- the imaginary parts of kL and -kL only cancel
+ * in the sum, as in the reference where max_abs(eri.imag) is taken after mpi.reduce (eri_transform_mpi.py:203-215). */
+int dmk_eri_imag_buffer(dmk_eri *h, double **imag_out, int64_t *elems_out);
 
 /* Procedural DF block (synthetic configs): Philox4x32-10,
  * key (seed_lo, seed_hi), counter (e>>1 lo, e>>1 hi, ki, kj), e = (L*nao+p)*nao+q. */

@@ -7,6 +7,7 @@ raises at import, and creating a context without a GPU raises RuntimeError.
 import ctypes as C
 import os
 import threading
+import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +30,7 @@ PROTOTYPES = {
     "dmk_destroy": (c_int, [c_vp]),
     "dmk_set_stream": (c_int, [c_vp, c_vp]),
     "dmk_sync": (c_int, [c_vp]),
+    "dmk_set_oom_hook": (c_int, [c_vp, c_vp, c_vp]),
     "dmk_last_error": (C.c_char_p, [c_vp]),
     "dmk_version": (C.c_char_p, []),
     "dmk_malloc": (c_int, [c_vp, c_sz, P(c_vp)]),
@@ -77,6 +79,7 @@ PROTOTYPES = {
     "dmk_eri_finish": (c_int, [c_vp]),
     "dmk_eri_flops": (c_int, [c_vp, P(c_dbl)]),
     "dmk_eri_imag_norm": (c_int, [c_vp, P(c_dbl)]),
+    "dmk_eri_imag_buffer": (c_int, [c_vp, P(c_vp), P(c_i64)]),
     "dmk_df_block_philox": (c_int, [c_vp, C.c_uint64, c_int, c_int, c_int, c_int, c_vp]),
     "dmk_eri_restore": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_dgemm_tn_acc": (c_int, [c_vp, c_int, c_int, c_dbl, c_vp, c_vp, c_i64, c_vp, c_i64]),
@@ -110,6 +113,9 @@ for _name, (_res, _args) in PROTOTYPES.items():
 FAMILIES = ["dgemm", "zgemm_half1", "zgemm_half2", "philox", "fold", "eigh", "bath", "zgemm_small", "misc", "jk", "fit"]
 
 
+_OOM_HOOK = C.CFUNCTYPE(None, c_vp)
+
+
 class DmkError(RuntimeError):
     pass
 
@@ -139,6 +145,11 @@ class Context(object):
         self._pool = {}
         self._pool_bytes = 0
         self._pool_limit = int(float(os.environ.get("DMK_POOL_GB", "24")) * (1 << 30))
+        # the library cannot see the parked blocks: before one of ITS allocations (ERI planes, Ut, rings, eigensolver scratch)
+        # is reported as out of memory it calls back here, and retries once
+        me = weakref.ref(self)
+        self._oom_cb = _OOM_HOOK(lambda _user: me() is not None and me().trim())
+        self.check(lib.dmk_set_oom_hook(self.h, C.cast(self._oom_cb, c_vp), None))
 
     def _alloc(self, nbytes):
         """(pointer, capacity) of a device block of at least nbytes."""
@@ -148,11 +159,7 @@ class Context(object):
             self._pool_bytes -= cap
             return stack.pop(), cap
         p = c_vp()
-        rc = lib.dmk_malloc(self.h, cap, C.byref(p))
-        if rc != 0 and self._pool_bytes:
-            self.trim()                                  # give the parked blocks back and retry once
-            rc = lib.dmk_malloc(self.h, cap, C.byref(p))
-        self.check(rc)
+        self.check(lib.dmk_malloc(self.h, cap, C.byref(p)))     # the library retries through the hook after trim()
         return p, cap
 
     def _release(self, ptr, cap):
@@ -180,6 +187,7 @@ class Context(object):
     def close(self):
         if getattr(self, "h", None):
             self.trim()
+            lib.dmk_set_oom_hook(self.h, None, None)
             lib.dmk_destroy(self.h)
             self.h = None
 
@@ -193,6 +201,10 @@ class Context(object):
         self.check(lib.dmk_sync(self.h))
 
     def set_stream(self, stream):
+        # parked blocks were released in the order of the OLD stream: drain it and hand them back to the driver, so that
+        # none of them can be given out again (and written on the new stream) while work on the old one still reads it
+        self.sync()
+        self.trim()
         self.check(lib.dmk_set_stream(self.h, c_vp(stream) if stream else None))
 
     # ---- device arrays ---------------------------------------------------------------

@@ -593,6 +593,15 @@ class EriEngine(object):
         self.ctx.check(lib.dmk_eri_imag_norm(self.h, C.byref(v)))
         return float(v.value)
 
+    def imag_buffer(self):
+        """Device accumulator behind `imag_norm` (spin_pair, npair, npair) f64, or None with time reversal."""
+        p, n = C.c_void_p(), C.c_int64()
+        self.ctx.check(lib.dmk_eri_imag_buffer(self.h, C.byref(p), C.byref(n)))
+        if not p.value:
+            return None
+        npair = self.nemb * (self.nemb + 1) // 2
+        return self.ctx.wrap(p.value, (int(n.value) // (npair * npair), npair, npair), np.float64, keepalive=self)
+
     def run_kL(self, kL, provider, user_of_mesh=None, max_blocks=None):
         ctx = self.ctx
         ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
@@ -805,9 +814,11 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
         if dist is not None and dist.is_initialized():
             dist.all_reduce_sum_dev(eri_dev)
         if not t_reversal_symm:
-            eri_imag_norm = eng.imag_norm()
             if dist is not None and dist.is_initialized():
-                eri_imag_norm = float(dist.all_reduce_sum_numpy(np.array([eri_imag_norm]))[0])      # upper bound over shards
+                # the imaginary parts of kL and -kL only cancel in the SUM over shards: reduce the accumulator first, then
+                # take the norm, as the reference does after mpi.reduce (eri_transform_mpi.py:203-215)
+                dist.all_reduce_sum_dev(eng.imag_buffer())
+            eri_imag_norm = eng.imag_norm()
             log.info("ERI imaginary = %s", eri_imag_norm)
             if eri_imag_norm > ERI_IMAG_TOL:
                 log.warn("ERI has imaginary part > %s (%s)", ERI_IMAG_TOL, eri_imag_norm)

@@ -472,7 +472,7 @@ int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath
     const size_t szB = (size_t)nenv * nbath, szS = (size_t)nbath * nbath;
     // separate allocation: the eigensolver below uses the context scratch
     double *wsd = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&wsd), (szB + (size_t)GB * szS + 3 * szS + nbath) * sizeof(double));
+    hipError_t e = dmk_dev_alloc(ctx, reinterpret_cast<void **>(&wsd), (szB + (size_t)GB * szS + 3 * szS + nbath) * sizeof(double));
     if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "bath_assemble: workspace allocation failed");
     double *B = wsd, *partial = B + szB, *S = partial + (size_t)GB * szS, *Vt = S + szS, *X = Vt + szS, *ev = X + szS;
     int rc = DMK_OK;

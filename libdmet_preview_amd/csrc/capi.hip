@@ -104,6 +104,13 @@ int dmk_set_stream(dmk_ctx *ctx, void *stream) {
     return DMK_OK;
 }
 
+int dmk_set_oom_hook(dmk_ctx *ctx, void (*hook)(void *), void *user) {
+    if (!ctx) return DMK_ERR_INVALID;
+    ctx->oom_hook = hook;
+    ctx->oom_user = user;
+    return DMK_OK;
+}
+
 int dmk_sync(dmk_ctx *ctx) {
     if (!ctx) return DMK_ERR_INVALID;
     DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -116,7 +123,7 @@ int dmk_malloc(dmk_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return DMK_ERR_INVALID;
     *out = nullptr;
     if (bytes == 0) return DMK_OK;
-    hipError_t e = hipMalloc(out, bytes);
+    hipError_t e = dmk_dev_alloc(ctx, out, bytes);
     if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     return DMK_OK;
 }
@@ -199,6 +206,17 @@ int dmk_profile_read_flops(dmk_ctx *ctx, double *flops, int reset) {
 
 }  // extern "C"
 
+hipError_t dmk_dev_alloc(dmk_ctx *ctx, void **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess || !ctx || !ctx->oom_hook) return e;
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(ctx->stream);      // parked blocks may still be read by queued work
+    ctx->oom_hook(ctx->oom_user);
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
+
 int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {
         if (ctx->scratch) {
@@ -207,7 +225,7 @@ int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out) {
             ctx->scratch = nullptr;
             ctx->scratch_bytes = 0;
         }
-        hipError_t e = hipMalloc(&ctx->scratch, bytes);
+        hipError_t e = dmk_dev_alloc(ctx, &ctx->scratch, bytes);
         if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "scratch hipMalloc(%zu) failed", bytes);
         ctx->scratch_bytes = bytes;
     }
@@ -637,7 +655,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     h->npair = (int64_t)nemb * (nemb + 1) / 2;
     if ((flags & 2) && !h->tr) {
         const size_t ib = (size_t)(spin == 2 ? 3 : 1) * h->npair * h->npair * sizeof(double);
-        if (hipMalloc(reinterpret_cast<void **>(&h->imag), ib) != hipSuccess ||
+        if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->imag), ib) != hipSuccess ||
             hipMemsetAsync(h->imag, 0, ib, ctx->stream) != hipSuccess) {
             if (h->imag) (void)hipFree(h->imag);
             delete h;
@@ -681,7 +699,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
                 ctx->eri_ws[w] = nullptr;
                 ctx->eri_ws_bytes[w] = 0;
             }
-            if (hipMalloc(&got[w], want[w]) != hipSuccess) got[w] = nullptr;
+            if (dmk_dev_alloc(ctx, &got[w], want[w]) != hipSuccess) got[w] = nullptr;
             h->ws_bytes[w] = want[w];
         }
     }
@@ -739,7 +757,25 @@ static int eri_flush(dmk_eri *h) {
         ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->planes, naux, h->npair, naux, nao, nemb, h->spin,
         (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb, 2LL * naux * h->npair);
     if (rc < 0) return rc;
-    if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_flush: hot step-2 kernel unavailable for a queued block");
+    if (rc == 0) {
+        // the grouped kernel declined (misaligned buffer, a table it cannot build): step 2 of every queued block through the
+        // generic c128 GEMM with the same tril-pack epilogue -- slower (one launch per block and spin), never wrong
+        for (int i = 0; i < h->pending; ++i)
+            for (int s = 0; s < h->spin; ++s) {
+                const double2 *ut = h->Ut + ((size_t)s * h->group + i) * slot_elems;
+                const double2 *Cj = h->C + ((size_t)s * h->mesh.nk + h->pend_kj[i]) * nao * nemb;
+                ZGemm g2;
+                g2.M = nemb; g2.N = nemb; g2.K = nao; g2.batch = naux; g2.nseg = h->pend_sym[i] ? 2 : 1;
+                g2.seg[0].A = ut; g2.seg[0].lda = nemb; g2.seg[0].strideA = (int64_t)nao * nemb;
+                g2.seg[0].B = Cj; g2.seg[0].ldb = nemb; g2.seg[0].strideB = 0;
+                g2.seg[1].A = Cj; g2.seg[1].lda = nemb; g2.seg[1].strideA = 0;
+                g2.seg[1].B = ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
+                g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
+                g2.planes = h->planes + (size_t)s * 2 * naux * h->npair; g2.naux = naux; g2.npair = h->npair;
+                int rg = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
+                if (rg) return rg;
+            }
+    }
     h->pending = 0;
     return DMK_OK;
 }
@@ -906,6 +942,13 @@ int dmk_eri_imag_norm(dmk_eri *h, double *out) {
     return DMK_OK;
 }
 
+int dmk_eri_imag_buffer(dmk_eri *h, double **imag_out, int64_t *elems_out) {
+    if (!h || !imag_out) return DMK_ERR_INVALID;
+    *imag_out = h->imag;
+    if (elems_out) *elems_out = h->imag ? (int64_t)(h->spin == 2 ? 3 : 1) * h->npair * h->npair : 0;
+    return DMK_OK;
+}
+
 namespace {
 __global__ void planes_sub_kernel(long long n, double *__restrict__ a, const double *__restrict__ b) {
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
@@ -970,7 +1013,7 @@ int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out) {
                 ctx->eri_ws[2] = nullptr;
                 ctx->eri_ws_bytes[2] = 0;
             }
-            if (hipMalloc(reinterpret_cast<void **>(&h->ring), bytes) != hipSuccess) {
+            if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->ring), bytes) != hipSuccess) {
                 (void)hipGetLastError();
                 h->ring = nullptr;
                 return DMK_OK;                        // not fatal: the caller falls back to dmk_eri_push_block
@@ -1024,7 +1067,7 @@ int dmk_eri_push_block_host(dmk_eri *h, int ki, int kj, int symmetrise, const vo
     if (!h->copy_stream) {
         DMK_HIP(ctx, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
-            DMK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&h->dstage[i]), bytes));
+            DMK_HIP(ctx, dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->dstage[i]), bytes));
             DMK_HIP(ctx, hipEventCreateWithFlags(&h->ev_copied[i], hipEventDisableTiming));
             DMK_HIP(ctx, hipEventCreateWithFlags(&h->ev_consumed[i], hipEventDisableTiming));
             DMK_HIP(ctx, hipEventRecord(h->ev_consumed[i], ctx->stream));

@@ -40,7 +40,14 @@ struct dmk_ctx {
     // block-ownership tables of the general-nemb step-2 kernel (zhot_tab.hip), one per embedding dimension
     struct StepTable { int nemb, cfg, nitems; double useful_blocks, folded_blocks; int *dev; };
     std::vector<StepTable> step2_tables;
+    // caller-side cache release (dmk_set_oom_hook): the host binding parks freed device blocks in a pool the library cannot
+    // see; before any allocation inside the library is reported as failed the hook is asked to give that memory back
+    void (*oom_hook)(void *) = nullptr;
+    void *oom_user = nullptr;
 };
+
+// hipMalloc with one retry after the out-of-memory hook; hipSuccess or the error of the second attempt
+hipError_t dmk_dev_alloc(dmk_ctx *ctx, void **out, size_t bytes);
 
 int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);
 

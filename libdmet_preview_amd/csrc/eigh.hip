@@ -32,6 +32,11 @@ __device__ __forceinline__ double2 cmulc(double2 a, double2 b) {   // conj(a) * 
     return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ double wave_sum(double v) { return dmk_wave_sum(v); }
+__device__ __forceinline__ double wave_max(double v) {          // cold path only (residual check)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 struct EighArgs {
     int n, batch;
@@ -47,7 +52,8 @@ struct EighArgs {
     double *d, *e;          // batch x n
     double2 *tau;           // batch x n
     double *ws2;            // batch x 7 x n x n: lane-major scratch of the inverse iteration
-    int *status;            // device flag, set to 1 on non-convergence
+    int *status;            // device flag: 2 = an eigenvector of the tridiagonal failed its residual check after the retries
+    int inject;             // fault injection (tests): every `inject`-th eigenvector is treated as failed and goes through the repair path
 };
 
 // LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2][2n] f64 | red[3*NW + 2] f64 | 16 ints | dl[n] | el[n] | colpart[NW][n] c128
@@ -339,6 +345,100 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
         __syncthreads();
         for (int t = tid; t < n; t += NT) e2[t] = el[t] * el[t];
         __syncthreads();
+        // ---- inverse iteration, one lane per eigenvector; the pieces are shared by the first pass and by the repair path ----
+        // (c1) elimination with partial pivoting of T - lm I on the rows of j's block (three upper diagonals, multipliers,
+        //      swap flags; tiny pivots replaced by eps |T|)
+        auto inv_factor = [&](const int j, const double lm) {
+            const int s0 = bs[j], t0 = be[j];
+            double *U0 = ws + j, *U1 = U0 + nn, *U2 = U1 + nn, *Lm = U2 + nn, *Pv = Lm + nn;
+            const double pert = fmax(eps * bnorm[j], 1e-300);
+            double cd = dl[s0] - lm, cu = el[s0];
+            for (int i = s0; i + 1 < t0; ++i) {
+                const double sub = el[i], nd = dl[i + 1] - lm, nu = (i + 2 < t0) ? el[i + 1] : 0.0;
+                const size_t o = (size_t)i * n;
+                if (fabs(cd) >= fabs(sub)) {
+                    if (fabs(cd) < pert) cd = cd >= 0.0 ? pert : -pert;
+                    const double mlt = sub / cd;
+                    U0[o] = cd; U1[o] = cu; U2[o] = 0.0; Lm[o] = mlt; Pv[o] = 0.0;
+                    cd = nd - mlt * cu;
+                    cu = nu;
+                } else {
+                    const double mlt = cd / sub;
+                    U0[o] = sub; U1[o] = nd; U2[o] = nu; Lm[o] = mlt; Pv[o] = 1.0;
+                    cd = cu - mlt * nd;
+                    cu = -mlt * nu;
+                }
+            }
+            if (fabs(cd) < pert) cd = cd >= 0.0 ? pert : -pert;
+            U0[(size_t)(t0 - 1) * n] = cd;
+        };
+        // (c2) start vector: hashed uniform numbers in (-1, 1), different for every matrix, eigenvalue, row and attempt
+        auto inv_seed = [&](const int j, const unsigned long long salt) {
+            const int s0 = bs[j], t0 = be[j];
+            double *x = ws + j + 5 * nn;
+            unsigned long long h = ((unsigned long long)b * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4Full) ^
+                                   (salt * 0xD6E8FEB86659FD93ull);
+            for (int i = s0; i < t0; ++i) {
+                h += 0x9E3779B97F4A7C15ull;
+                unsigned long long z = h;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                x[(size_t)i * n] = (double)(long long)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+            }
+        };
+        auto inv_xmax = [&](const int j) {
+            const int s0 = bs[j], t0 = be[j];
+            const double *x = ws + j + 5 * nn;
+            double xm = 0.0;
+            for (int i = s0; i < t0; ++i) xm = fmax(xm, fabs(x[(size_t)i * n]));
+            return xm;
+        };
+        // (c3) one solve (T - lm I) x_new = x / xm.  It reads one array and writes another (forward x -> y, backward y -> x), so
+        //      the loads of a pass do not alias its stores and the compiler may run several rows ahead of the recurrence; the
+        //      scale of the next right-hand side (max |x|) is gathered during the backward pass and returned.
+        auto inv_solve = [&](const int j, const double xm_in) {
+            const int s0 = bs[j], t0 = be[j];
+            const double *U0 = ws + j, *U1 = U0 + nn, *U2 = U1 + nn, *Lm = U2 + nn, *Pv = Lm + nn;
+            double *x = ws + j + 5 * nn;
+            double *__restrict__ yv = x + nn;                  // second vector, lane-major like the others
+            const double sc = xm_in > 0.0 ? 1.0 / xm_in : 1.0;
+            double cur = x[(size_t)s0 * n] * sc;
+#pragma unroll 4
+            for (int i = s0; i + 1 < t0; ++i) {                // forward: row swaps and multipliers
+                const size_t o = (size_t)i * n;
+                double nxt = x[o + n] * sc;
+                const double pv = Pv[o], ml = Lm[o];
+                if (pv != 0.0) { const double tsw = cur; cur = nxt; nxt = tsw; }
+                yv[o] = cur;
+                cur = nxt - ml * cur;
+            }
+            yv[(size_t)(t0 - 1) * n] = cur;
+            double x1 = 0.0, x2 = 0.0, xm = 0.0;
+#pragma unroll 4
+            for (int i = t0 - 1; i >= s0; --i) {               // backward: three upper diagonals
+                const size_t o = (size_t)i * n;
+                const double u0 = U0[o], u1 = U1[o], u2 = U2[o];
+                double r = yv[o];
+                if (i + 1 < t0) r -= u1 * x1 + u2 * x2;
+                r /= u0;
+                x[o] = r;
+                xm = fmax(xm, fabs(r));
+                x2 = x1;
+                x1 = r;
+            }
+            return xm;
+        };
+        // (c4) normalised copy into row j of Z^T
+        auto inv_store = [&](const int j, const double xm) {
+            const int s0 = bs[j], t0 = be[j];
+            const double *x = ws + j + 5 * nn;
+            double nr = 0.0;
+            const double sc = xm > 0.0 ? 1.0 / xm : 1.0;
+            for (int i = s0; i < t0; ++i) { const double v = x[(size_t)i * n] * sc; nr += v * v; }
+            const double inv = sc / sqrt(nr);
+            for (int i = s0; i < t0; ++i) Zt[(size_t)j * n + i] = x[(size_t)i * n] * inv;
+        };
         for (int j = tid; j < n; j += NT) {
             const int s0 = bs[j], t0 = be[j], m = t0 - s0, kk = j - s0;
             if (m == 1) {
@@ -381,83 +481,11 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
             }
             const double lm = 0.5 * (lo + hi);
             lam[j] = lm;
-            // ---- (c) elimination with partial pivoting of T - lm I on rows s0 .. t0-1
-            double *U0 = ws + j, *U1 = U0 + nn, *U2 = U1 + nn, *Lm = U2 + nn, *Pv = Lm + nn, *x = Pv + nn;
-            const double pert = fmax(eps * tn, 1e-300);
-            {
-                double cd = dl[s0] - lm, cu = el[s0];
-                for (int i = s0; i + 1 < t0; ++i) {
-                    const double sub = el[i], nd = dl[i + 1] - lm, nu = (i + 2 < t0) ? el[i + 1] : 0.0;
-                    const size_t o = (size_t)i * n;
-                    if (fabs(cd) >= fabs(sub)) {
-                        if (fabs(cd) < pert) cd = cd >= 0.0 ? pert : -pert;
-                        const double mlt = sub / cd;
-                        U0[o] = cd; U1[o] = cu; U2[o] = 0.0; Lm[o] = mlt; Pv[o] = 0.0;
-                        cd = nd - mlt * cu;
-                        cu = nu;
-                    } else {
-                        const double mlt = cd / sub;
-                        U0[o] = sub; U1[o] = nd; U2[o] = nu; Lm[o] = mlt; Pv[o] = 1.0;
-                        cd = cu - mlt * nd;
-                        cu = -mlt * nu;
-                    }
-                }
-                if (fabs(cd) < pert) cd = cd >= 0.0 ? pert : -pert;
-                U0[(size_t)(t0 - 1) * n] = cd;
-            }
-            // start vector: hashed uniform numbers in (-1, 1), different for every matrix, eigenvalue and row
-            {
-                unsigned long long h = ((unsigned long long)b * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(j + 1) * 0xC2B2AE3D27D4EB4Full);
-                for (int i = s0; i < t0; ++i) {
-                    h += 0x9E3779B97F4A7C15ull;
-                    unsigned long long z = h;
-                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-                    z ^= z >> 31;
-                    x[(size_t)i * n] = (double)(long long)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
-                }
-            }
-            // Each solve reads one array and writes another (forward x -> y, backward y -> x), so the loads of a pass do
-            // not alias its stores and the compiler may run several rows ahead of the recurrence; the scale of the next
-            // right-hand side (1 / max |x|) is gathered during the backward pass.
-            double xm = 0.0;
-            for (int i = s0; i < t0; ++i) xm = fmax(xm, fabs(x[(size_t)i * n]));
-            double *__restrict__ yv = x + nn;                  // second vector, lane-major like the others
-            for (int iter = 0; iter < 3; ++iter) {
-                const double sc = xm > 0.0 ? 1.0 / xm : 1.0;
-                // forward: row swaps and multipliers
-                double cur = x[(size_t)s0 * n] * sc;
-#pragma unroll 4
-                for (int i = s0; i + 1 < t0; ++i) {
-                    const size_t o = (size_t)i * n;
-                    double nxt = x[o + n] * sc;
-                    const double pv = Pv[o], ml = Lm[o];
-                    if (pv != 0.0) { const double tsw = cur; cur = nxt; nxt = tsw; }
-                    yv[o] = cur;
-                    cur = nxt - ml * cur;
-                }
-                yv[(size_t)(t0 - 1) * n] = cur;
-                // backward: three upper diagonals
-                double x1 = 0.0, x2 = 0.0;
-                xm = 0.0;
-#pragma unroll 4
-                for (int i = t0 - 1; i >= s0; --i) {
-                    const size_t o = (size_t)i * n;
-                    const double u0 = U0[o], u1 = U1[o], u2 = U2[o];
-                    double r = yv[o];
-                    if (i + 1 < t0) r -= u1 * x1 + u2 * x2;
-                    r /= u0;
-                    x[o] = r;
-                    xm = fmax(xm, fabs(r));
-                    x2 = x1;
-                    x1 = r;
-                }
-            }
-            double nr = 0.0;
-            const double sc = xm > 0.0 ? 1.0 / xm : 1.0;
-            for (int i = s0; i < t0; ++i) { const double v = x[(size_t)i * n] * sc; nr += v * v; }
-            const double inv = sc / sqrt(nr);
-            for (int i = s0; i < t0; ++i) Zt[(size_t)j * n + i] = x[(size_t)i * n] * inv;
+            inv_factor(j, lm);
+            inv_seed(j, 0ull);
+            double xm = inv_xmax(j);
+            for (int iter = 0; iter < 3; ++iter) xm = inv_solve(j, xm);
+            inv_store(j, xm);
         }
         __syncthreads();
         // ---- (d) clusters: one wave each, members in ascending order
@@ -487,6 +515,93 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                     const double inv = nr > 0.0 ? 1.0 / sqrt(nr) : 0.0;
                     for (int i = s0 + lane; i < t0; i += 64) zq[i] *= inv;
                 }
+            }
+        }
+        __syncthreads();
+        // ---- (e) acceptance test and repair.  Three fixed solves from a random start are enough for every spectrum met so
+        // far, but nothing above PROVES an eigenvector: an unlucky start, near-duplicate shifts inside one unreduced block or
+        // a vector annihilated by the cluster Gram-Schmidt would flow silently into rho, the bath and the vcor fit.  Every
+        // vector is therefore checked -- |T z - lam z|_inf <= 64 n eps |T| and |z| = 1 (NaN fails both) -- one wave per vector.
+        // A failed vector is rebuilt by wave 0 the way LAPACK's dstein does it: perturbed shift, fresh start, and the
+        // re-orthogonalisation against the accepted members of its cluster INSIDE the iteration; if that fails as well the
+        // launch reports DMK_ERR_NOCONV instead of returning a wrong basis.
+        int *bad = reinterpret_cast<int *>(pbuf);             // [n] (the Householder buffer is idle in this phase)
+        const double rtol = 64.0 * n * eps;
+        auto residual_ok = [&](const int j) {                 // wave-cooperative; every lane returns the verdict
+            const int s0 = bs[j], t0 = be[j];
+            if (t0 - s0 == 1) return true;
+            const double *z = Zt + (size_t)j * n;
+            const double lj = lam[j];
+            double r = 0.0, zn = 0.0;
+            for (int i = s0 + lane; i < t0; i += 64) {
+                const double zi = z[i];
+                double t = (dl[i] - lj) * zi;
+                if (i > s0) t += el[i - 1] * z[i - 1];
+                if (i + 1 < t0) t += el[i] * z[i + 1];
+                r = fmax(r, fabs(t));
+                if (!(fabs(t) <= 1.7e308)) r = 1.7e308;        // NaN / Inf: fmax would drop a NaN
+                zn += zi * zi;
+            }
+            r = wave_max(r);
+            zn = wave_sum(zn);
+            return r <= rtol * fmax(bnorm[j], 1e-300) && fabs(zn - 1.0) <= 1e-8;
+        };
+        for (int j = wave; j < n; j += NW) {
+            bool ok = residual_ok(j);
+            if (g.inject > 0 && (j % g.inject) == g.inject - 1) ok = false;
+            if (lane == 0) bad[j] = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int j = 0; j < n; ++j) {
+                if (!bad[j]) continue;
+                const int s0 = bs[j], t0 = be[j];
+                const double tn = bnorm[j], lj = lam[j];
+                double *zj = Zt + (size_t)j * n;
+                double *x = ws + j + 5 * nn;
+                bool fixed = false;
+                for (int attempt = 1; attempt <= 3 && !fixed; ++attempt) {
+                    double xm = 0.0;
+                    if (lane == 0) {
+                        inv_factor(j, lj + ((attempt & 1) ? 4.0 : -4.0) * attempt * eps * tn);
+                        inv_seed(j, (unsigned long long)attempt);
+                        xm = inv_xmax(j);
+                    }
+                    for (int iter = 0; iter < 5 && !fixed; ++iter) {
+                        if (lane == 0) {
+                            xm = inv_solve(j, xm);
+                            inv_store(j, xm);
+                        }
+                        __threadfence_block();
+                        // orthogonalise against the accepted vectors of j's cluster (twice), renormalise, feed back
+                        for (int pass = 0; pass < 2; ++pass)
+                            for (int p = s0; p < t0; ++p) {
+                                if (p == j || bad[p] || fabs(lam[p] - lj) > 1e-3 * tn) continue;
+                                const double *zp = Zt + (size_t)p * n;
+                                double dot = 0.0;
+                                for (int i = s0 + lane; i < t0; i += 64) dot += zp[i] * zj[i];
+                                dot = wave_sum(dot);
+                                for (int i = s0 + lane; i < t0; i += 64) zj[i] -= dot * zp[i];
+                            }
+                        double nr = 0.0;
+                        for (int i = s0 + lane; i < t0; i += 64) nr += zj[i] * zj[i];
+                        nr = wave_sum(nr);
+                        const double inv = nr > 0.0 ? 1.0 / sqrt(nr) : 0.0;
+                        for (int i = s0 + lane; i < t0; i += 64) {
+                            const double v = zj[i] * inv;
+                            zj[i] = v;
+                            x[(size_t)i * n] = v;
+                        }
+                        __threadfence_block();
+                        xm = 1.0;                                   // the fed-back vector has unit 2-norm: no rescaling needed
+                        fixed = iter >= 1 && residual_ok(j);
+                    }
+                }
+                if (lane == 0) {
+                    if (fixed) bad[j] = 0;
+                    else g.status[0] = 2;
+                }
+                __threadfence_block();
             }
         }
         __syncthreads();
@@ -597,6 +712,10 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     EighArgs g;
     g.n = n; g.batch = batch; g.A = A; g.a_real = a_real; g.add = add; g.add_group = add_group;
     g.w = w; g.Vt = Vt; g.v_real = v_real;
+    {   // fault injection for the repair path of the tridiagonal eigenvectors (tests/test_gpu_parity.py); never set in production
+        const char *inj = getenv("DMK_EIGH_INJECT");
+        g.inject = inj ? atoi(inj) : 0;
+    }
     g.status = reinterpret_cast<int *>(p); p += 256;
     g.W = reinterpret_cast<double2 *>(p); p += nn * 16 * batch;
     g.Vh = reinterpret_cast<double2 *>(p); p += nn * 16 * batch;
@@ -631,7 +750,9 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     int status = 0;
     DMK_HIP(ctx, hipMemcpyAsync(&status, g.status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (status != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "eigh: QL iteration did not converge");
+    if (status != 0)
+        return dmk_fail(ctx, DMK_ERR_NOCONV, "eigh: an eigenvector of the tridiagonal form failed the residual test |T z - lam z| <= 64 n eps |T| "
+                                            "after three repair attempts (n = %d, batch = %d; NaN / Inf in the input?)", n, batch);
     if (getenv("DMK_EIGH_TIMING")) {
         long long tp[8];
         DMK_HIP(ctx, hipMemcpy(tp, g.status + 2, sizeof(tp), hipMemcpyDeviceToHost));

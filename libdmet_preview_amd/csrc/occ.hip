@@ -57,6 +57,14 @@ __device__ long long block_sum_i64(long long v, long long *sh) {
     return t;
 }
 
+// number of levels that are NaN or +-Inf: such a spectrum has no order statistics (the reference fails at its sort / index
+// step); the kernels report status 2 instead of ranking the bit patterns
+__device__ long long count_nonfinite(const double *__restrict__ e, long long n, long long *sh) {
+    long long c = 0;
+    for (long long i = threadIdx.x; i < n; i += OCC_NT) c += (fabs(e[i]) <= 1.7976931348623157e308) ? 0 : 1;
+    return block_sum_i64(c, sh);
+}
+
 constexpr int OCC_SMALL = 2048;      // spectra up to this size are ranked directly in LDS (model lattices: 12 - 150 levels)
 
 // element of rank k (0-based) in ascending order
@@ -68,6 +76,7 @@ __device__ double kth_smallest(const double *__restrict__ e, long long n, long l
         __shared__ double found;
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += OCC_NT) es[i] = e[i];
+        if (threadIdx.x == 0) found = __longlong_as_double(0x7ff8000000000000ll);   // no thread matches (k out of range): NaN, never stale LDS
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += OCC_NT) {
             const double x = es[i];
@@ -114,6 +123,10 @@ __global__ __launch_bounds__(OCC_NT) void occ_zero_t_kernel(const OccArgs g) {
     __shared__ long long shi[OCC_NT / 64];
     const double *e = g.ew;
     const long long n = g.n, ne = (long long)g.nelec;
+    if (count_nonfinite(e, n, shi) != 0) {
+        if (threadIdx.x == 0) { g.out[0] = g.out[1] = g.out[2] = g.out[3] = 0.0; g.out[4] = 2.0; }
+        return;
+    }
     double mu = g.mu0;
     bool keep = false;
     if (g.has_mu0) {
@@ -161,6 +174,10 @@ __global__ __launch_bounds__(OCC_NT) void occ_fermi_kernel(const OccArgs g) {
     const double *e = g.ew;
     const long long n = g.n;
     const double beta = g.beta, target = g.nelec;
+    if (count_nonfinite(e, n, shi) != 0) {
+        if (threadIdx.x == 0) { g.out[0] = g.out[1] = g.out[2] = g.out[3] = 0.0; g.out[4] = 2.0; }
+        return;
+    }
     double mu = g.mu0, status = 0.0;
 
     auto count = [&](double x, double &slope) {       // N(x) - target and dN/dx
@@ -226,6 +243,8 @@ extern "C" int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double 
     if (n <= 0 || !ew || !occ || !info_host) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: bad arguments");
     const bool zero_t = !(beta < INFINITY);
     if (!zero_t && !(beta > 0.0)) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: beta must be positive");
+    if (!zero_t && !(flags & 2) && !(nelec >= 0.0 && nelec <= (double)n))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: %g electrons do not fit %lld levels", nelec, (long long)n);
     if (zero_t && (nelec < 0.0 || nelec > (double)n || nelec != std::floor(nelec)))
         return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: T = 0 needs an integer 0 <= nelec <= %lld levels", (long long)n);
     void *scratch;
@@ -245,6 +264,7 @@ extern "C" int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double 
     }
     DMK_HIP(ctx, hipMemcpyAsync(info_host, scratch, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (info_host[4] == 2.0) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: the eigenvalue list contains NaN / Inf");
     if (info_host[4] != 0.0) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: no chemical potential gives %g electrons", nelec);
     return DMK_OK;
 }

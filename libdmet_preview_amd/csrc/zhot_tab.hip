@@ -377,7 +377,10 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     // embedding spaces gain from the third wave per SIMD (C4, nemb 136: 45.6 -> 54.8), the segment items of larger ones
     // lose more from their shorter block lists than they gain (nemb 256 routed here: 56.9 vs 50.4; its specialised
     // kernel: 66.5).  DMK_ERI_TAB_OCC = 2 | 3 overrides.
-    static const int occ_env = [] { const char *e = getenv("DMK_ERI_TAB_OCC"); return e ? atoi(e) : 0; }();
+    // fault injection (tests): decline the launch so that the caller's generic fallback runs
+    if (const char *e = getenv("DMK_ERI_TAB_DECLINE")) if (atoi(e) != 0) return 0;
+    const char *occ_e = getenv("DMK_ERI_TAB_OCC");          // read per launch (a handful per second): tests toggle it
+    const int occ_env = occ_e ? atoi(occ_e) : 0;
     const int occ = (occ_env == 2 || occ_env == 3) ? occ_env : ((nemb + 15) / 16 <= T_WIDE_MAXNB ? 3 : 2);
     const dmk_ctx::StepTable *tb = nullptr;
     for (auto &t : ctx->step2_tables)
@@ -388,7 +391,7 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
         if (occ == 2) build_table(nemb, Cfg2::MAXBLK, Cfg2::SEG, h, useful, slots, folded);
         else build_table(nemb, Cfg3::MAXBLK, Cfg3::SEG, h, useful, slots, folded);
         int *dev = nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&dev), h.size() * sizeof(int)) != hipSuccess)
+        if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&dev), h.size() * sizeof(int)) != hipSuccess)
             return dmk_fail(ctx, DMK_ERR_NOMEM, "half2_tab: table allocation failed");
         if (hipMemcpy(dev, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
             (void)hipFree(dev);

@@ -97,3 +97,20 @@ def test_errors(mfd):
     from libdmet_preview_amd._lib import DmkError
     with pytest.raises(DmkError):
         mfd.assignocc(ew, 40.0, 10.0)             # more electrons than levels: no chemical potential
+
+
+@pytest.mark.parametrize("beta", [np.inf, 20.0])
+@pytest.mark.parametrize("shape", [(2, 3, 4), (1, 50, 60)])
+def test_nonfinite_levels_are_an_error(mfd, beta, shape):
+    """A NaN / Inf eigenvalue has no rank: the device assignment must fail loudly (the reference fails at its sort / index
+    step), in the small-spectrum LDS path and in the bit-pattern path."""
+    from libdmet_preview_amd import _lib
+    ctx = _lib.get_ctx()
+    ew = _levels(3, shape)
+    for bad in (np.nan, np.inf):
+        e = ew.copy()
+        e.ravel()[e.size // 3] = bad
+        with pytest.raises(_lib.DmkError):
+            mfd.assignocc_dev(ctx, ctx.to_device(e), e.size // 2, beta, mu0=None)
+    with pytest.raises(_lib.DmkError):                       # more electrons than levels at finite T
+        mfd.assignocc_dev(ctx, ctx.to_device(ew), ew.size + 1, 20.0, mu0=None)

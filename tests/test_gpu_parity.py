@@ -376,6 +376,57 @@ def test_eigh_degenerate_and_lower_triangle(ctx):
     assert np.abs(P - Q[:, :4] @ Q[:, :4].conj().T).max() < 1e-12
 
 
+def _wilkinson(m):
+    """W_{2m+1}^+ : diag |i - m|, unit couplings -- its upper eigenvalues come in pairs that agree to 1e-14."""
+    d = np.abs(np.arange(2 * m + 1) - m).astype(float)
+    return np.diag(d) + np.diag(np.ones(2 * m), 1) + np.diag(np.ones(2 * m), -1)
+
+
+def _glued(blocks, glue):
+    n = sum(b.shape[0] for b in blocks)
+    T = np.zeros((n, n))
+    o = 0
+    for b in blocks:
+        k = b.shape[0]
+        T[o:o + k, o:o + k] = b
+        if o + k < n:
+            T[o + k - 1, o + k] = T[o + k, o + k - 1] = glue
+        o += k
+    return T
+
+
+@pytest.mark.parametrize("inject", [0, 3])
+def test_eigh_clustered_tridiagonal(ctx, inject, monkeypatch):
+    """Exactly degenerate and tightly clustered spectra INSIDE one unreduced tridiagonal block (Wilkinson W21+, nine of
+    them glued by 1e-9: clusters of nine eigenvalues within 1e-9), where inverse iteration from independent starts does
+    not deliver orthogonal vectors by itself.  Every vector must pass the device's acceptance test (residual, norm);
+    with DMK_EIGH_INJECT every third vector is declared failed and rebuilt by the dstein-style repair path."""
+    from libdmet_preview_amd.routine import mfd
+    if inject:
+        monkeypatch.setenv("DMK_EIGH_INJECT", str(inject))
+    mats = [_wilkinson(10), _glued([_wilkinson(10)] * 9, 1e-9), _glued([_wilkinson(10)] * 4, 1e-13),
+            _glued([np.diag([1.0, 1.0, 1.0]) + 1e-7 * (np.eye(3, k=1) + np.eye(3, k=-1))] * 5, 1e-7)]
+    for T in mats:
+        n = T.shape[0]
+        dw, dVt = mfd.eigh_dev(ctx, ctx.to_device(T[None].astype(np.complex128)), n, 1)
+        w, V = dw.get()[0], dVt.get()[0].T
+        wr = np.linalg.eigvalsh(T)
+        scale = np.abs(wr).max()
+        assert np.abs(w - wr).max() < 1e-13 * scale * max(1, n / 10)
+        assert np.abs(V.conj().T @ V - np.eye(n)).max() < 1e-12 * max(1, n / 10)
+        assert np.abs(T @ V - V * w).max() < 1e-12 * scale * max(1, n / 10)
+
+
+def test_eigh_reports_garbage(ctx):
+    """A NaN in the input must surface as an error, not as a silently wrong basis."""
+    from libdmet_preview_amd.routine import mfd
+    from libdmet_preview_amd._lib import DmkError
+    A = np.eye(8, dtype=np.complex128) + 0.1 * np.eye(8, k=1) + 0.1 * np.eye(8, k=-1)
+    A[3, 3] = np.nan
+    with pytest.raises(DmkError):
+        mfd.eigh_dev(ctx, ctx.to_device(A[None]), 8, 1)
+
+
 def test_Diag_wrappers_vs_oracle(ctx):
     from libdmet_preview_amd.routine import mfd
     mesh, nlo = (3, 2, 1), 5
@@ -631,15 +682,24 @@ def test_hot_half_transform_all_symmetrised_groups(ctx, nao, naux, spin):
     eng.close()
 
 
-@pytest.mark.parametrize("nao,naux,nemb,spin", [(104, 19, 136, 1), (40, 24, 200, 2), (16, 40, 272, 2), (24, 30, 40, 1),
-                                                 (32, 20, 100, 2), (200, 8, 136, 2), (48, 16, 137, 1), (16, 64, 33, 2)])
-def test_tab_half_transform_planes(ctx, nao, naux, nemb, spin):
+@pytest.mark.parametrize("nao,naux,nemb,spin,env", [
+    (104, 19, 136, 1, {}), (40, 24, 200, 2, {}), (16, 40, 272, 2, {}), (24, 30, 40, 1, {}),
+    (32, 20, 100, 2, {}), (200, 8, 136, 2, {}), (48, 16, 137, 1, {}), (16, 64, 33, 2, {}),
+    # larger embedding spaces: four and more segments, large row / column offsets of the items
+    (24, 6, 400, 2, {}), (16, 5, 520, 1, {}), (16, 3, 1040, 1, {}),
+    # both occupancy points forced on both item kinds (segment items at 3 workgroups / CU, wide items at 2)
+    (16, 6, 272, 2, {"DMK_ERI_TAB_OCC": "3"}), (24, 6, 400, 1, {"DMK_ERI_TAB_OCC": "3"}), (32, 20, 100, 2, {"DMK_ERI_TAB_OCC": "2"}),
+    # the grouped kernel declines: eri_flush falls back to the generic step 2 for the queued blocks
+    (40, 8, 200, 2, {"DMK_ERI_TAB_DECLINE": "1"})])
+def test_tab_half_transform_planes(ctx, nao, naux, nemb, spin, env, monkeypatch):
     """General embedding dimension: the table-driven step-2 kernel (zhot_tab.hip) behind the same block queue as the
     nemb = 256 kernels -- directly pushed blocks (step 1 per block, step 2 per group) and the ring feed (both steps per
     group) -- against the oracle's r_e2 restatement, with and without the time-reversal partner term, 11 pushes =
     one full group of 8 queued blocks + a group of 3.  nemb not a multiple of 16 exercises the clamped panels."""
     from libdmet_preview_amd.basis_transform import eri_transform as et
     from libdmet_preview_amd._lib import lib
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     mesh = (2, 2, 1)
     npair = nemb * (nemb + 1) // 2
     rng = np.random.default_rng(nao + nemb)
