@@ -322,6 +322,12 @@ int dmk_bcs_assemble(dmk_ctx *ctx, int ncells, int n, int nval, const double *U,
  * routine/slater_helper.py:494-518 (unit2emb). */
 int dmk_pad_block_f64(dmk_ctx *ctx, int batch, int64_t r_in, int64_t c_in, const double *in, int64_t r_out,
                       int64_t c_out, double *out);
+/* Row gather (scatter = 0: out[r][:] = in[idx[r]][:]) or scatter (scatter = 1: out[idx[r]][:] = in[r][:]) of rows of
+ * `row_len` doubles (a complex row counts twice its length); idx is a DEVICE int32 array.  The k-sharded mean field of
+ * the multi-process path (routine/mfd_mpi.py:64-74 scatter_new / :93-94 gather_new): this rank's k rows of the resident
+ * Fock batch in one launch, and its eigenvalues placed into the all-k table that is summed over ranks. */
+int dmk_copy_rows_f64(dmk_ctx *ctx, int64_t nrows, int64_t row_len, const int32_t *idx_dev, const double *in, double *out,
+                      int scatter);
 
 /* ---- ERI x density -------------------------------------------------------
  * Coulomb / exchange matrices from one 4-fold packed ERI block E (npair x npair, leading dimension ld, device),

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "dmk_bcs_weight": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "dmk_bcs_assemble": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dmk_pad_block_f64": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
+    "dmk_copy_rows_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_int]),
     "dmk_jk_s4": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_dgemv2": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),

@@ -8,14 +8,19 @@
 //   :200-202  virtual-row projection + Loewdin (lo/lowdin.py:83-101),
 //   :212-213  scatter into C_lo_eo.
 //
-// SVD = Householder QR of the tall matrix (column at a time, every CU streams a row
-// slab; deterministic two-stage reductions, no atomics) + one-sided Jacobi SVD of the
-// small R factor in LDS (high relative accuracy for the singular values that are
-// compared with tol_bath = 1e-9; a Gram-matrix shortcut would square the condition
-// number) + application of Q to [U_r; 0].
+// SVD = Householder QR of the tall matrix + one-sided Jacobi SVD of the small R factor in LDS (high relative
+// accuracy for the singular values that are compared with tol_bath = 1e-9; a Gram-matrix shortcut would square the
+// condition number) + application of Q to [U_r; 0].
+// The QR is a TSQR (communication-avoiding, still Householder and backward stable): every workgroup factors its own row
+// slab entirely in LDS, the nb x nb R factors are stacked four at a time and factored again, level by level, until one
+// R is left; Q is never formed, its reflectors stay where the slabs / stacks were, and Q [U_r; 0] is applied down the
+// same tree.  ~12 launches per spin instead of the ~225 of the column-at-a-time version it replaces (kept below for
+// nb > 64), and the tall matrix is read and written a constant number of times.
 // Bound: HBM / launch latency: algorithmic bytes
 // 8*nenv*(nb + nbath).
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 int launch_eigh_public(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group,
                        double *w, void *Vt, int v_real);
@@ -153,6 +158,193 @@ __global__ __launch_bounds__(NT) void q_apply_kernel(int nrows, int nb, int nc, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TSQR building blocks.  Both kernels work on `m` consecutive rows [r0, r0 + m) of a row-major matrix with leading
+// dimension nb: a leaf's slab of the gathered matrix A, or -- tree levels -- four stacked nb x nb R factors of the level
+// below (block b of a stack occupies rows [b nb, (b + 1) nb), so a node's inputs are contiguous as well).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TS_MAXROWS = 256;      // rows per node: 8 waves x 32 register slots
+constexpr int TS_FANIN = 4;
+
+struct TsqrArgs {
+    int nb;                 // columns
+    int rows_total;         // rows of the whole matrix at this level
+    int rows_per_node;      // rows of a node (the last one may be shorter)
+    double *M;              // rows_total x nb: in = matrix, out = reflectors (unit diagonal implied) below / R on and above the diagonal
+    double *tau;            // nodes x nb
+    double *Rout;           // nodes x nb x nb, zero below the diagonal and beyond the node's rows (input of the next level)
+};
+
+__device__ __forceinline__ double lane_bcast(double v, int src) {      // src wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+constexpr int TS_NT = 512, TS_NW = TS_NT / 64;       // eight waves per node: rows are dealt round-robin to the waves
+
+// Householder QR of one node, the node's rows held in REGISTERS: lane <-> column (nb <= 64), wave w owns rows w, w + 8, ...
+// The first version kept the node in LDS and spent 12 us per column waiting on LDS round trips (0.68 ms per level at 224 x 56;
+// rocprof); here a column step is register arithmetic: column k is broadcast out of lane k with v_readlane and the scalar feeds
+// v_fma_f64 directly.  Two things keep the inner loops free of per-row conditions (the second version still spent 9 us per
+// column on exec-mask bookkeeping around every row):
+//   * a finished row is written out and its registers are cleared, so a zero row contributes nothing to any sum or update;
+//   * after every group of eight columns the slots are SHIFTED down by one (slot i <- slot i + 1), so the pivot row of column
+//     k = 8 g + c is always slot 0 of wave c -- a compile-time register, a wave-uniform owner.
+// One barrier per column: the per-wave partial sums and the pivot-row snapshot go through a double-buffered LDS slab (the
+// buffer of step k is last read in step k, and step k + 2 cannot write it before every wave passed the barrier of step k + 1).
+//   h_j = sum_{r >= k} a_rk a_rj (j >= k);  |x|^2 below the diagonal = h_k - a_kk^2 is NOT used -- g_k is summed without the
+//   pivot row;  tau, beta from g_k and a_kk;  a_rj -= tau (a_kj + inv g_j) v_r,  v = [1; a_rk inv];  reflector kept in column k.
+template <int RPT>
+__global__ __launch_bounds__(TS_NT) void tsqr_factor_kernel(const TsqrArgs g) {
+    __shared__ double part[2][TS_NW + 1][64];        // [buffer][wave | pivot-row snapshot][column]
+    __shared__ double taus[64];
+    const int nb = g.nb;
+    const int node = blockIdx.x;
+    const int r0 = node * g.rows_per_node;
+    const int m = min(g.rows_per_node, g.rows_total - r0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: keeps the owner tests scalar
+    const int j = lane;
+    double *Mrows = g.M + (size_t)r0 * nb;
+    double *R = g.Rout + (size_t)node * nb * nb;
+    double a[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = wave + TS_NW * i;
+        a[i] = (r < m && j < nb) ? Mrows[(size_t)r * nb + j] : 0.0;
+    }
+    if (threadIdx.x < 64) taus[threadIdx.x] = 0.0;
+    const int kmax = min(m, nb);
+    const int ngroups = (kmax + TS_NW - 1) / TS_NW;
+    for (int grp = 0; grp < ngroups; ++grp) {
+#pragma unroll
+        for (int c = 0; c < TS_NW; ++c) {
+            const int k = grp * TS_NW + c;
+            if (k >= kmax) break;                                  // uniform
+            const int buf = k & 1;
+            // ---- partial sums over this wave's live rows; slot 0 holds row 8 grp + wave: finished if wave < c, pivot if wave == c
+            double acc = 0.0;
+            if (wave == c) part[buf][TS_NW][j] = a[0];
+            else if (wave > c) acc = lane_bcast(a[0], k) * a[0];
+#pragma unroll
+            for (int i = 1; i < RPT; ++i) acc += lane_bcast(a[i], k) * a[i];
+            part[buf][wave][j] = acc;
+            __syncthreads();
+            double gj = 0.0, xnorm2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < TS_NW; ++w) {
+                gj += part[buf][w][j];
+                xnorm2 += part[buf][w][k];
+            }
+            const double alpha = part[buf][TS_NW][k];
+            double tau = 0.0, beta = alpha, inv = 0.0;
+            if (xnorm2 > 0.0) {
+                const double nrm = sqrt(alpha * alpha + xnorm2);
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                inv = 1.0 / (alpha - beta);
+            }
+            const double fac = (j > k) ? tau * (part[buf][TS_NW][j] + inv * gj) : 0.0;     // tau v^T a_j on the columns to update
+            const bool diag = (j == k);
+            if (wave == c) {                                       // pivot row: v = 1
+                a[0] = diag ? beta : a[0] - fac;
+            } else if (wave > c) {
+                const double vr = lane_bcast(a[0], k) * inv;
+                a[0] = diag ? vr : a[0] - fac * vr;
+            }
+#pragma unroll
+            for (int i = 1; i < RPT; ++i) {
+                const double vr = lane_bcast(a[i], k) * inv;
+                a[i] = diag ? vr : a[i] - fac * vr;
+            }
+            if (threadIdx.x == 0) taus[k] = tau;
+        }
+        // rows 8 grp .. 8 grp + 7 are final (R on and right of the diagonal, reflector entries left of it): write them out,
+        // then shift the slots so that the next group's pivot rows sit in slot 0 again
+        {
+            const int r = grp * TS_NW + wave;
+            if (r < m && j < nb) Mrows[(size_t)r * nb + j] = a[0];
+            if (r < nb && j < nb) R[(size_t)r * nb + j] = (r <= j && r < m) ? a[0] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i + 1 < RPT; ++i) a[i] = a[i + 1];
+        a[RPT - 1] = 0.0;
+    }
+    __syncthreads();
+    // rows that never became pivots (m > nb): slot i now holds row 8 (ngroups + i) + wave
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = (ngroups + i) * TS_NW + wave;
+        if (r < m && j < nb) Mrows[(size_t)r * nb + j] = a[i];
+        if (r < nb && j < nb) R[(size_t)r * nb + j] = 0.0;         // m < nb: rows of the R block beyond the node's rows
+    }
+    for (int t = threadIdx.x; t < nb; t += TS_NT) g.tau[(size_t)node * nb + t] = taus[t];
+}
+
+struct TsqrApplyArgs {
+    int nb, nc;
+    int rows_total, rows_per_node;
+    const double *V;        // rows_total x nb reflectors of this level (tsqr_factor_kernel's in-place output)
+    const double *tau;      // nodes x nb
+    const double *X;        // nodes x nb x nc: the node's input block (top rows of [X; 0])
+    double *Y;              // rows_total x nc: Q_node [X; 0]; a tree level writes the X blocks of the level below, a leaf rows of U
+};
+
+// Y = H_0 H_1 ... H_{kmax-1} [X; 0] for one node, Y in registers (lane <-> column of Y, nc <= 64; slot i of wave w <-> row
+// w + 8 i).  The reflector entries a wave needs in step k are one per lane (lane i keeps v_{w + 8 i, k}, zero above the
+// diagonal so that no row needs a condition): they come straight from global memory, fetched one step ahead, and are broadcast
+// with readlane.  One barrier per step (double-buffered partial sums, see the factor kernel).
+template <int RPT>
+__global__ __launch_bounds__(TS_NT) void tsqr_apply_kernel(const TsqrApplyArgs g) {
+    __shared__ double part[2][TS_NW][64];
+    const int nb = g.nb, nc = g.nc;
+    const int node = blockIdx.x;
+    const int r0 = node * g.rows_per_node;
+    const int m = min(g.rows_per_node, g.rows_total - r0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane;
+    const double *X = g.X + (size_t)node * nb * nc;
+    double y[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = wave + TS_NW * i;
+        y[i] = (r < m && r < nb && j < nc) ? X[(size_t)r * nc + j] : 0.0;
+    }
+    const int kmax = min(m, nb);
+    const int myrow = wave + TS_NW * lane;                       // the row whose reflector entries this lane carries (lane < RPT)
+    const bool carrier = lane < RPT && myrow < m;
+    const double *vcol = g.V + (size_t)(r0 + (carrier ? myrow : 0)) * nb;
+    double vnext = (carrier && kmax > 0) ? vcol[kmax - 1] : 0.0;
+    int buf = 0;                                                 // toggles per EXECUTED step (skipped steps have no barrier)
+    for (int k = kmax - 1; k >= 0; --k) {
+        double vmine = vnext;
+        if (myrow == k) vmine = 1.0;
+        if (myrow < k || !carrier) vmine = 0.0;
+        if (k > 0) vnext = carrier ? vcol[k - 1] : 0.0;
+        const double tau = g.tau[(size_t)node * nb + k];
+        if (tau == 0.0) continue;                               // uniform: H_k = I
+        buf ^= 1;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) acc += lane_bcast(vmine, i) * y[i];
+        part[buf][wave][j] = acc;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TS_NW; ++w) t += part[buf][w][j];
+        t *= tau;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) y[i] -= t * lane_bcast(vmine, i);
+    }
+    double *Yrows = g.Y + (size_t)r0 * nc;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = wave + TS_NW * i;
+        if (r < m && j < nc) Yrows[(size_t)r * nc + j] = y[i];
+    }
+}
+
 // One-sided Jacobi SVD of the upper-triangular R (top nb x nb of A).  One workgroup.
 // Output: sigma (descending), Utop (nb x nb row-major, column j <-> sigma[j]).
 // upper_only: the input is an R factor (entries below the diagonal are ignored).  Vt_out (optional):
@@ -234,6 +426,110 @@ __global__ __launch_bounds__(NT) void jacobi_svd_kernel(int nb, const double *__
         for (int i = 0; i < nb; ++i) Utop[(long long)i * nb + rk] = G[j * ld + i] * inv;
         if (Vt_out)
             for (int i = 0; i < nb; ++i) Vt_out[(long long)rk * nb + i] = V[j * ld + i];
+    }
+}
+
+// One-sided Jacobi SVD for nb <= 64 without right vectors (the bath's R factor): same rotations in the same round-robin
+// order as jacobi_svd_kernel, organised for latency.  Eight waves; a column is ONE element per lane, so a pair (p, q) is
+// two LDS reads per lane, three wave sums through the DPP crossbar (interleaved, no LDS) and the rotation in registers;
+// every wave loads all the pairs it owns in a round before it reduces any of them.  One barrier per round.
+// (rocprof on the first TSQR version: the general kernel took 4.4 ms at nb = 56 -- 42 % of the bath; this one ~0.2 ms.)
+constexpr int JF_NT = 1024, JF_NW = JF_NT / 64, JF_MAXP = 2;     // 32 pairs per round at most = 2 per wave
+// 1 / x and 1 / sqrt(x) from the hardware estimates + two Newton steps (full double accuracy for the normal range these
+// rotation parameters live in; an IEEE division / square root costs three times as many instructions)
+__device__ __forceinline__ double jf_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+}
+__device__ __forceinline__ double jf_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+__global__ __launch_bounds__(JF_NT) void jacobi_svd_fast_kernel(int nb, const double *__restrict__ A, int lda,
+                                                                double *__restrict__ sigma, double *__restrict__ Utop,
+                                                                int *__restrict__ status, int upper_only) {
+    __shared__ double G[64 * 65];             // column-major, column stride 65: G[j * 65 + i] = R[i][j]
+    __shared__ double nrm[64];
+    __shared__ int s_rot;
+    const int N = nb + (nb & 1), ld = 65;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int t = threadIdx.x; t < 64 * ld; t += JF_NT) {
+        const int j = t / ld, i = t % ld;
+        G[t] = (j < nb && i < nb && (!upper_only || i <= j)) ? A[(long long)i * lda + j] : 0.0;
+    }
+    if (threadIdx.x == 0) s_rot = 0;
+    __syncthreads();
+    const double eps2 = 2.220446049250313e-16 * 2.220446049250313e-16;
+    const int npairs = N / 2;
+    int sweep = 0;
+    for (; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int round = 0; round < N - 1; ++round) {
+            int pp[JF_MAXP], qq[JF_MAXP];
+            double gp[JF_MAXP], gq[JF_MAXP];
+#pragma unroll
+            for (int u = 0; u < JF_MAXP; ++u) {
+                const int pi = wave + JF_NW * u;
+                int p = -1, q = -1;
+                if (pi < npairs) {
+                    if (pi == 0) { p = N - 1; q = round; }
+                    else { p = (round + pi) % (N - 1); q = (round - pi + (N - 1)) % (N - 1); }
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    if (q >= nb) p = -1;          // padding column
+                }
+                pp[u] = p; qq[u] = q;
+                gp[u] = p >= 0 ? G[p * ld + lane] : 0.0;
+                gq[u] = p >= 0 ? G[q * ld + lane] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < JF_MAXP; ++u) {
+                if (pp[u] < 0) continue;          // uniform
+                const double a = wave_sum(gp[u] * gp[u]), b = wave_sum(gq[u] * gq[u]), c = wave_sum(gp[u] * gq[u]);
+                // rotate unless the pair is orthogonal to working precision: |c| <= eps sqrt(a b), tested without the root
+                if (c * c > eps2 * (a * b) && c != 0.0) {
+                    const double zeta = (b - a) * 0.5 * jf_rcp(c);
+                    const double az = fabs(zeta);
+                    double t;
+                    if (az > 1e150) t = 0.5 * jf_rcp(az);                       // 1 + zeta^2 would overflow
+                    else t = jf_rcp(az + (1.0 + zeta * zeta) * jf_rsqrt(1.0 + zeta * zeta));
+                    if (zeta < 0.0) t = -t;
+                    const double cs = jf_rsqrt(1.0 + t * t), sn = cs * t;
+                    G[pp[u] * ld + lane] = cs * gp[u] - sn * gq[u];
+                    G[qq[u] * ld + lane] = sn * gp[u] + cs * gq[u];
+                    rotated = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (rotated && lane == 0) atomicAdd(&s_rot, 1);
+        __syncthreads();
+        const int rot = s_rot;
+        __syncthreads();
+        if (threadIdx.x == 0) s_rot = 0;
+        if (rot == 0) break;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sweep >= 60) status[0] = 2;
+        status[1] = sweep + 1;
+    }
+    for (int j = wave; j < nb; j += JF_NW) {
+        const double v = G[j * ld + lane];
+        const double a = wave_sum(v * v);
+        if (lane == 0) nrm[j] = sqrt(a);
+    }
+    __syncthreads();
+    // ranks (descending, stable) and normalised columns: column j of G goes to column rank(j) of Utop
+    for (int j = wave; j < nb; j += JF_NW) {
+        const double sj = nrm[j];
+        int rk = 0;
+        for (int q = 0; q < nb; ++q) rk += (nrm[q] > sj || (nrm[q] == sj && q < j)) ? 1 : 0;
+        if (lane == 0) sigma[rk] = sj;
+        const double inv = sj > 0.0 ? 1.0 / sj : 0.0;
+        if (lane < nb) Utop[(long long)lane * nb + rk] = G[j * ld + lane] * inv;
     }
 }
 
@@ -336,6 +632,42 @@ __global__ __launch_bounds__(NT) void gram_partial_kernel(int nrows, int nc, con
         partial[(long long)blockIdx.x * nc * nc + t] = s;
     }
 }
+// the same partial Gram with the row slab staged through LDS in chunks of GRAM_CHUNK rows (nc <= 64): the version above reads
+// every B entry nc times from L2 (0.33 ms at 43144 x 56); here a chunk is read once, coalesced, and the nc^2 products run
+// out of LDS with lanes along j (conflict-free) and i broadcast
+constexpr int GRAM_CHUNK = 96;
+__global__ __launch_bounds__(NT) void gram_partial_lds_kernel(int nrows, int nc, const double *__restrict__ B,
+                                                              double *__restrict__ partial) {
+    __shared__ double Bs[GRAM_CHUNK * 65];
+    const int rows_per_blk = (nrows + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(nrows, r0 + rows_per_blk);
+    constexpr int EPT = 16;                          // entries per thread: 64 * 64 / 256
+    double acc[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) acc[u] = 0.0;
+    const int ld = nc + 1;
+    for (int c0 = r0; c0 < r1; c0 += GRAM_CHUNK) {
+        const int rows = min(GRAM_CHUNK, r1 - c0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < rows * nc; t += NT) Bs[(t / nc) * ld + (t % nc)] = B[(long long)c0 * nc + t];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = threadIdx.x + NT * u;
+            if (e < nc * nc) {
+                const int i = e / nc, j = e % nc;
+                double sacc = 0.0;
+                for (int r = 0; r < rows; ++r) sacc += Bs[r * ld + i] * Bs[r * ld + j];
+                acc[u] += sacc;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = threadIdx.x + NT * u;
+        if (e < nc * nc) partial[(long long)blockIdx.x * nc * nc + e] = acc[u];
+    }
+}
 __global__ void reduce_partials_kernel(int n, int nblk, const double *__restrict__ partial, double *__restrict__ out) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
         double s = 0.0;
@@ -351,6 +683,17 @@ __global__ void inv_sqrt_kernel(int n, const double *__restrict__ e, const doubl
         double s = 0.0;
         for (int m = 0; m < n; ++m)
             if (e[m] > tol) s += Vt[m * n + i] * Vt[m * n + j] / sqrt(e[m]);
+        X[t] = s;
+    }
+}
+// the same from eigenvectors stored as COLUMNS (U[i][m], the layout of jacobi_svd_fast_kernel)
+__global__ void inv_sqrt_cols_kernel(int n, const double *__restrict__ e, const double *__restrict__ U, double tol,
+                                     double *__restrict__ X) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * n; t += gridDim.x * blockDim.x) {
+        const int i = t / n, j = t % n;
+        double s = 0.0;
+        for (int m = 0; m < n; ++m)
+            if (e[m] > tol) s += U[i * n + m] * U[j * n + m] / sqrt(e[m]);
         X[t] = s;
     }
 }
@@ -394,6 +737,78 @@ int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1, c
     if (nb > 120) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: nb = %d exceeds the supported maximum of 120", nb);
     if (nenv < nb) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: needs nenv >= nb (tall matrix)");
     FamScope fs(ctx, DMK_FAM_BATH);
+    static const bool tsqr_enabled = [] { const char *e = getenv("DMK_BATH_TSQR"); return !(e && atoi(e) == 0); }();
+    if (tsqr_enabled && 4 * nb <= TS_MAXROWS) {
+        // ---- TSQR plan: leaves of m0 rows, then stacks of four R factors per node until one is left ----------------------
+        const int m0 = nenv <= TS_MAXROWS ? nenv : std::min(TS_MAXROWS, std::max(TS_FANIN * nb, (nenv + 255) / 256));
+        std::vector<int> nodes;                        // nodes[l] = workgroups of level l
+        nodes.push_back((nenv + m0 - 1) / m0);
+        while (nodes.back() > 1) nodes.push_back((nodes.back() + TS_FANIN - 1) / TS_FANIN);
+        const int L = (int)nodes.size();
+        size_t tot_nodes = 0;
+        for (int n : nodes) tot_nodes += (size_t)n;
+        // workspace (doubles): A | tau (all levels) | R stacks (output of every level) | X stacks (input of every level's apply) | status
+        const size_t szA = (size_t)nenv * nb, szBlk = (size_t)nb * nb;
+        void *ws = nullptr;
+        int rc = dmk_scratch(ctx, (szA + tot_nodes * nb + 2 * tot_nodes * szBlk + 8) * sizeof(double), &ws);
+        if (rc) return rc;
+        double *A = reinterpret_cast<double *>(ws);
+        double *tau = A + szA;
+        double *Rst = tau + tot_nodes * nb;
+        double *Xst = Rst + tot_nodes * szBlk;
+        int *status = reinterpret_cast<int *>(Xst + tot_nodes * szBlk);
+        std::vector<size_t> off(L + 1, 0);             // node offset of level l in tau / Rst / Xst
+        for (int l = 0; l < L; ++l) off[l + 1] = off[l] + (size_t)nodes[l];
+        DMK_HIP(ctx, hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
+        {
+            long long total = (long long)nenv * nb;
+            int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(gather_env_imp_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mesh[0], mesh[1], mesh[2], nlo,
+                               rdm1, env_idx, nenv, bath_col, nb, A);
+            DMK_CHECK_LAUNCH(ctx);
+        }
+        // up the tree: level l factors rows of (l == 0 ? A : the R stack written by level l - 1)
+        for (int l = 0; l < L; ++l) {
+            TsqrArgs a;
+            a.nb = nb;
+            a.rows_total = l == 0 ? nenv : nodes[l - 1] * nb;
+            a.rows_per_node = l == 0 ? m0 : TS_FANIN * nb;
+            a.M = l == 0 ? A : Rst + off[l - 1] * szBlk;
+            a.tau = tau + off[l] * nb;
+            a.Rout = Rst + off[l] * szBlk;
+            // register tile: 8 / 16 / 32 rows per thread (64 / 128 / 256 rows per node)
+            if (a.rows_per_node <= 64) hipLaunchKernelGGL(tsqr_factor_kernel<8>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
+            else if (a.rows_per_node <= 128) hipLaunchKernelGGL(tsqr_factor_kernel<16>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(tsqr_factor_kernel<32>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
+            DMK_CHECK_LAUNCH(ctx);
+        }
+        // SVD of the root R; its left singular vectors are the root's X block
+        double *Rroot = Rst + off[L - 1] * szBlk, *Xroot = Xst + off[L - 1] * szBlk;
+        hipLaunchKernelGGL(jacobi_svd_fast_kernel, dim3(1), dim3(JF_NT), 0, ctx->stream, nb, Rroot, nb, sigma, Xroot, status, 1);
+        DMK_CHECK_LAUNCH(ctx);
+        // down the tree: U = Q [U_r; 0]
+        for (int l = L - 1; l >= 0; --l) {
+            TsqrApplyArgs a;
+            a.nb = nb; a.nc = nb;
+            a.rows_total = l == 0 ? nenv : nodes[l - 1] * nb;
+            a.rows_per_node = l == 0 ? m0 : TS_FANIN * nb;
+            a.V = l == 0 ? A : Rst + off[l - 1] * szBlk;
+            a.tau = tau + off[l] * nb;
+            a.X = Xst + off[l] * szBlk;
+            a.Y = l == 0 ? U : Xst + off[l - 1] * szBlk;
+            if (a.rows_per_node <= 64) hipLaunchKernelGGL(tsqr_apply_kernel<8>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
+            else if (a.rows_per_node <= 128) hipLaunchKernelGGL(tsqr_apply_kernel<16>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(tsqr_apply_kernel<32>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
+            DMK_CHECK_LAUNCH(ctx);
+        }
+        int st[2] = {0, 0};
+        DMK_HIP(ctx, hipMemcpyAsync(st, status, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (st[0] != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "bath_svd: Jacobi SVD did not converge");
+        if (getenv("DMK_BATH_TIMING")) fprintf(stderr, "[bath_svd %d x %d] %d leaves of %d rows, %d levels, %d Jacobi sweeps\n", nenv, nb, nodes[0], m0, L, st[1]);
+        return DMK_OK;
+    }
+    // column-at-a-time Householder QR (nb > 64)
     // workspace: A (nenv x nb) | partial (MAXB x nb) | tau (nb) | rowk (nb) | Utop (nb x nb) | status
     const size_t szA = (size_t)nenv * nb, szP = (size_t)MAXB * nb;
     void *ws = nullptr;
@@ -470,30 +885,43 @@ int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath
     if (nbath == 0) return DMK_OK;
     const int GB = 128;
     const size_t szB = (size_t)nenv * nbath, szS = (size_t)nbath * nbath;
-    // separate allocation: the eigensolver below uses the context scratch
-    double *wsd = nullptr;
-    hipError_t e = dmk_dev_alloc(ctx, reinterpret_cast<void **>(&wsd), (szB + (size_t)GB * szS + 3 * szS + nbath) * sizeof(double));
-    if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "bath_assemble: workspace allocation failed");
+    // the context's SECOND scratch: the eigensolver below uses the first one (round 2 paid a hipMalloc / hipFree pair and a
+    // device synchronisation here on every call)
+    void *ws2 = nullptr;
+    int rc = dmk_scratch2(ctx, (szB + (size_t)GB * szS + 3 * szS + nbath + 2) * sizeof(double), &ws2);
+    if (rc) return rc;
+    double *wsd = reinterpret_cast<double *>(ws2);
     double *B = wsd, *partial = B + szB, *S = partial + (size_t)GB * szS, *Vt = S + szS, *X = Vt + szS, *ev = X + szS;
-    int rc = DMK_OK;
-    auto cleanup = [&]() { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(wsd); };
+    auto cleanup = [&]() {};
     {
         FamScope fs(ctx, DMK_FAM_BATH);
         const int blocks = (int)std::min<long long>(((long long)szB + 255) / 256, 4096);
         hipLaunchKernelGGL(mask_copy_kernel, dim3(blocks), dim3(256), 0, ctx->stream, nenv, nb, nbath, U, virt_mask,
                            orth ? 1 : 0, B);
         if (orth) {
-            hipLaunchKernelGGL(gram_partial_kernel, dim3(GB), dim3(NT), 0, ctx->stream, nenv, nbath, B, partial);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3(16), dim3(256), 0, ctx->stream, (int)szS, GB, partial, S);
+            if (nbath <= 64) hipLaunchKernelGGL(gram_partial_lds_kernel, dim3(GB), dim3(NT), 0, ctx->stream, nenv, nbath, B, partial);
+            else hipLaunchKernelGGL(gram_partial_kernel, dim3(GB), dim3(NT), 0, ctx->stream, nenv, nbath, B, partial);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(std::min<int>(64, (int)((szS + 255) / 256))), dim3(256), 0, ctx->stream, (int)szS,
+                               GB, partial, S);
         }
     }
-    if (orth) {
+    if (orth && nbath <= 64) {
+        // eigenpairs of the symmetric positive semi-definite metric: its singular vectors ARE its eigenvectors and the one-sided
+        // Jacobi kernel delivers them (with high relative accuracy for the small eigenvalues the 1e-14 cut looks at) in ~0.15 ms;
+        // the general batched eigensolver needs 0.55 ms for one 56 x 56 matrix (latency chain of its three phases).
+        // The kernel stores the vectors as COLUMNS of its output (here the `Vt` buffer): inv_sqrt_cols_kernel reads that layout.
+        FamScope fs(ctx, DMK_FAM_BATH);
+        int *st = reinterpret_cast<int *>(ev + nbath);
+        DMK_HIP(ctx, hipMemsetAsync(st, 0, 2 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(jacobi_svd_fast_kernel, dim3(1), dim3(JF_NT), 0, ctx->stream, nbath, S, nbath, ev, Vt, st, 0);
+        hipLaunchKernelGGL(inv_sqrt_cols_kernel, dim3(16), dim3(256), 0, ctx->stream, nbath, ev, Vt, 1e-14, X);
+    } else if (orth) {
         rc = launch_eigh_public(ctx, nbath, 1, S, 1, nullptr, 0, ev, Vt, 1);
         if (rc) { cleanup(); return rc; }
     }
     {
         FamScope fs(ctx, DMK_FAM_BATH);
-        if (orth)
+        if (orth && nbath > 64)
             hipLaunchKernelGGL(inv_sqrt_kernel, dim3(16), dim3(256), 0, ctx->stream, nbath, ev, Vt, 1e-14, X);
         const int blocks = (int)std::min<long long>(((long long)szB + 255) / 256, 4096);
         hipLaunchKernelGGL(scatter_bath_kernel, dim3(blocks), dim3(256), 0, ctx->stream, nenv, nbath, B,
@@ -502,6 +930,12 @@ int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath
     hipError_t le = hipGetLastError();
     cleanup();
     if (le != hipSuccess) return dmk_fail(ctx, DMK_ERR_HIP, "bath_assemble: launch failed: %s", hipGetErrorString(le));
+    if (orth && nbath <= 64) {
+        int st = 0;
+        DMK_HIP(ctx, hipMemcpyAsync(&st, ev + nbath, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (st != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "bath_assemble: Jacobi eigensolver of the Loewdin metric did not converge");
+    }
     return rc;
 }
 

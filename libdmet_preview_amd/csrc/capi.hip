@@ -90,6 +90,7 @@ int dmk_destroy(dmk_ctx *ctx) {
     for (auto &t : ctx->tile_tables) (void)hipFree(t.dev);
     for (auto &t : ctx->step2_tables) (void)hipFree(t.dev);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
     for (int w = 0; w < 3; ++w)
         if (ctx->eri_ws[w]) (void)hipFree(ctx->eri_ws[w]);
     (void)hipEventDestroy(ctx->t0);
@@ -230,6 +231,22 @@ int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out) {
         ctx->scratch_bytes = bytes;
     }
     *out = ctx->scratch;
+    return DMK_OK;
+}
+
+int dmk_scratch2(dmk_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch2_bytes) {
+        if (ctx->scratch2) {
+            DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            DMK_HIP(ctx, hipFree(ctx->scratch2));
+            ctx->scratch2 = nullptr;
+            ctx->scratch2_bytes = 0;
+        }
+        hipError_t e = dmk_dev_alloc(ctx, &ctx->scratch2, bytes);
+        if (e != hipSuccess) return dmk_fail(ctx, DMK_ERR_NOMEM, "scratch2 hipMalloc(%zu) failed", bytes);
+        ctx->scratch2_bytes = bytes;
+    }
+    *out = ctx->scratch2;
     return DMK_OK;
 }
 
@@ -1231,3 +1248,32 @@ int dmk_eri_restore(dmk_ctx *ctx, int nemb, int symmetry, const double *eri4, do
 }
 
 }  // extern "C"
+
+// ---- row gather / scatter (k-sharded mean field: this rank's k rows of the resident Fock batch; eigenvalues of a shard
+//      placed into the all-k table before the all-reduce) ------------------------------------------------------------
+namespace {
+__global__ void copy_rows_kernel(long long nrows, long long row_len, const int *__restrict__ idx, const double *__restrict__ in,
+                                 double *__restrict__ out, int scatter) {
+    const long long total = nrows * row_len;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t / row_len, c = t - r * row_len;
+        const long long far = (long long)idx[r] * row_len + c;
+        if (scatter) out[far] = in[t];
+        else out[t] = in[far];
+    }
+}
+}  // namespace
+
+extern "C" int dmk_copy_rows_f64(dmk_ctx *ctx, int64_t nrows, int64_t row_len, const int32_t *idx_dev, const double *in, double *out,
+                                 int scatter) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (nrows < 0 || row_len < 0 || !idx_dev || !in || !out) return dmk_fail(ctx, DMK_ERR_INVALID, "copy_rows: bad arguments");
+    if (nrows == 0 || row_len == 0) return DMK_OK;
+    const long long total = (long long)nrows * row_len;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 65536);
+    FamScope fs(ctx, DMK_FAM_MISC);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, ctx->stream, (long long)nrows, (long long)row_len, idx_dev, in, out,
+                       scatter ? 1 : 0);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}

@@ -27,6 +27,9 @@ struct dmk_ctx {
     // scratch owned by the context (grown on demand)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // second scratch for callers that run the eigensolver (which uses `scratch`) on data they keep alive across it
+    void *scratch2 = nullptr;
+    size_t scratch2_bytes = 0;
     // cached twiddle matrices for the folds (device), keyed by mesh + direction
     struct Phase { int mesh[3]; int dir; int nsub; std::vector<int32_t> subset; void *dev; };
     std::vector<Phase> phases;
@@ -78,6 +81,7 @@ struct FamScope {
 };
 
 int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out);
+int dmk_scratch2(dmk_ctx *ctx, size_t bytes, void **out);
 
 // XCD-aware, bijective remap of a 1-D block id: blocks that the dispatcher places on the
 // same XCD (id % 8) receive a contiguous range of logical ids, so that neighbouring tiles

@@ -101,25 +101,29 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
         d_F = sysm.d_Fock_k.reshape(spin * nk, n, n)
         nloc = nk
     else:
-        # gather this rank's k rows of the resident Fock (device-to-device)
+        # this rank's (spin, k) rows of the resident Fock batch: ONE gather launch (mfd_mpi.py:64-74 scatters them over MPI)
         nloc = len(kmine)
+        rows = np.asarray([s * nk + k for s in range(spin) for k in kmine], dtype=np.int32)
+        d_rows = ctx.to_device(rows)
         d_F = ctx.empty((spin * nloc, n, n), np.complex128)
-        for s in range(spin):
-            for a, k in enumerate(kmine):
-                ctx.check(lib.dmk_memcpy_d2d(ctx.h, d_F.offset((s * nloc + a) * n * n, (n, n)).ptr,
-                                             sysm.d_Fock_k.offset((s * nk + k) * n * n, (n, n)).ptr, n * n * 16))
+        ctx.check(lib.dmk_copy_rows_f64(ctx.h, len(rows), 2 * n * n, d_rows.ptr, sysm.d_Fock_k.ptr, d_F.ptr, 0))
     d_w, d_Vt = mfd.eigh_dev(ctx, d_F, n, spin * nloc, sysm.d_vcor, nloc)
     t = _stage(ctx, timers, "diag", t)
     if world == 1:
         # occupations without leaving the device: no D2H of the eigenvalues, no host sort (csrc/occ.hip)
+        d_w_all = d_w
         d_occ, mu, nerr = mfd.assignocc_dev(ctx, d_w, spin * nk * n * sysm.filling, np.inf)
+        d_occ_all = d_occ
     else:
-        ew = np.zeros((spin, nk, n))
-        ew[:, kmine] = d_w.get().reshape(spin, nloc, n)
-        d_all = ctx.to_device(dist.all_reduce_sum_numpy(ew))
-        d_occ_all, mu, nerr = mfd.assignocc_dev(ctx, d_all, spin * nk * n * sysm.filling, np.inf)
-        occ_all = d_occ_all.get()
-        d_occ = ctx.to_device(np.ascontiguousarray(occ_all[:, kmine]).reshape(spin * nloc, n), np.float64)
+        # every rank needs ALL eigenvalues for the Fermi level: the shards are scattered into a zeroed all-k table and summed
+        # over ranks on the device (mfd_mpi.py:93-94 gathers them through pickled MPI messages); the occupation kernel then
+        # runs replicated (one workgroup, 1.9 ms at C5) and the rank keeps its own rows -- nothing crosses PCIe
+        d_w_all = ctx.zeros((spin * nk, n), np.float64)
+        ctx.check(lib.dmk_copy_rows_f64(ctx.h, len(rows), n, d_rows.ptr, d_w.ptr, d_w_all.ptr, 1))
+        dist.all_reduce_sum_dev(d_w_all)
+        d_occ_all, mu, nerr = mfd.assignocc_dev(ctx, d_w_all, spin * nk * n * sysm.filling, np.inf)
+        d_occ = ctx.empty((spin * nloc, n), np.float64)
+        ctx.check(lib.dmk_copy_rows_f64(ctx.h, len(rows), n, d_rows.ptr, d_occ_all.ptr, d_occ.ptr, 0))
     t = _stage(ctx, timers, "occupations", t)
     d_rho = mfd.density_dev(ctx, d_Vt, d_occ, n, spin * nloc)
     t = _stage(ctx, timers, "density", t)
@@ -129,7 +133,7 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
     if dist.is_initialized():
         dist.all_reduce_sum_dev(d_rhoR)
         t = _stage(ctx, timers, "allreduce_rho", t)
-    return d_rhoR, {"mu": mu, "ew": d_w, "occ": d_occ, "nerr": nerr}
+    return d_rhoR, {"mu": mu, "ew": d_w_all, "occ": d_occ_all, "nerr": nerr}
 
 
 def bath_stage(ctx, sysm, d_rhoR, timers=None, tol_bath=1e-9):
@@ -279,7 +283,8 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
     timers = {} if timers is None else timers
     d_rhoR, mf = mean_field_stage(ctx, sysm, timers)
     d_basis, nemb, sigmas = bath_stage(ctx, sysm, d_rhoR, timers)
-    out = {"rho_R": d_rhoR, "basis": d_basis, "nemb": nemb, "sigma": sigmas, "mu": mf["mu"], "timers": timers}
+    out = {"rho_R": d_rhoR, "basis": d_basis, "nemb": nemb, "sigma": sigmas, "mu": mf["mu"], "ew": mf["ew"], "occ": mf["occ"],
+           "timers": timers}
     if sysm.naux > 0:
         d_C, d_bk = c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers, return_basis_k=True)
         npair = nemb * (nemb + 1) // 2

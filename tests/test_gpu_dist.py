@@ -106,3 +106,42 @@ def test_two_ranks_over_rccl_match_single_process():
         assert np.abs(res[r]["eri"] - single["eri"]).max() < 1e-11 * scale
         assert np.abs(res[r]["H1"] - single["H1"]).max() < 1e-9
     assert np.array_equal(res[0]["eri"], res[1]["eri"])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_script_two_ranks_gloo_one_gpu(scaling):
+    """bench.py ITSELF with two ranks (torch.distributed.run, gloo exchanges, both ranks on GPU 0): shards, k-sharded mean
+    field with the device-side eigenvalue exchange, kL-sharded ERI, the full-config pass after the timed steps (weak) or
+    the full config as the timed step (strong), the rank-summed oracle samples and the per-stage oracle check.  The JSON
+    line must carry the contract keys, every parity flag must be green and the exit status 0.  Workload C4-shaped but
+    small enough for a test (mesh 3x2x2: four weight-1 and four weight-2 kL)."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"DMK_BENCH_BACKEND": "gloo", "DMK_BENCH_ONE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                "DMK_BENCH_OVERRIDE": json.dumps({"mesh": [3, 2, 2], "nlo": 24, "naux": 16, "nval": 8, "spin": 2})})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "C3", "--kl-per-gpu", "1", "--scaling", scaling, "--fit-iters", "0", "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in res, key
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == scaling and res["dtype"] == "f64"
+    assert res["parity_ok"] is True and res["parity_maxabs"] <= 1e-8
+    assert res["parity_stages_ok"] is True and res["parity_occ_equal"] is True
+    assert res["roofline"]["bound"] == "mfma" and 0.0 < res["roofline"]["frac"] <= 1.0
+    assert res["cpu_baseline"]["kind"] == "port" and res["cpu_baseline"]["cores"] >= 1
+    if scaling == "weak":
+        assert res["full_config"]["parity_ok"] is True and res["full_config"]["n_gpus"] == 2
+        assert res["full_config_iteration_wall_s"] == res["full_config"]["iteration_wall_s"]
+    else:
+        assert "full_config" not in res and res["full_config_iteration_wall_s"] > 0

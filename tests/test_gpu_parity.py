@@ -686,11 +686,11 @@ def test_hot_half_transform_all_symmetrised_groups(ctx, nao, naux, spin):
     (104, 19, 136, 1, {}), (40, 24, 200, 2, {}), (16, 40, 272, 2, {}), (24, 30, 40, 1, {}),
     (32, 20, 100, 2, {}), (200, 8, 136, 2, {}), (48, 16, 137, 1, {}), (16, 64, 33, 2, {}),
     # larger embedding spaces: four and more segments, large row / column offsets of the items
-    (24, 6, 400, 2, {}), (16, 5, 520, 1, {}), (16, 3, 1040, 1, {}),
+    (24, 24, 400, 2, {}), (16, 33, 520, 1, {}), (16, 32, 1040, 1, {}),
     # both occupancy points forced on both item kinds (segment items at 3 workgroups / CU, wide items at 2)
-    (16, 6, 272, 2, {"DMK_ERI_TAB_OCC": "3"}), (24, 6, 400, 1, {"DMK_ERI_TAB_OCC": "3"}), (32, 20, 100, 2, {"DMK_ERI_TAB_OCC": "2"}),
+    (16, 40, 272, 2, {"DMK_ERI_TAB_OCC": "3"}), (24, 24, 400, 1, {"DMK_ERI_TAB_OCC": "3"}), (32, 20, 100, 2, {"DMK_ERI_TAB_OCC": "2"}),
     # the grouped kernel declines: eri_flush falls back to the generic step 2 for the queued blocks
-    (40, 8, 200, 2, {"DMK_ERI_TAB_DECLINE": "1"})])
+    (40, 16, 200, 2, {"DMK_ERI_TAB_DECLINE": "1"})])
 def test_tab_half_transform_planes(ctx, nao, naux, nemb, spin, env, monkeypatch):
     """General embedding dimension: the table-driven step-2 kernel (zhot_tab.hip) behind the same block queue as the
     nemb = 256 kernels -- directly pushed blocks (step 1 per block, step 2 per group) and the ring feed (both steps per

@@ -72,6 +72,18 @@ def traffic_json(dbs, out):
         w = e.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
         e["hbm_bytes_per_launch"] = f + w
         e["note"] = "FETCH_SIZE x2 (gfx950 counts 1/2 of a wide coalesced stream) + WRITE_SIZE, separate --pmc passes"
+    # provenance: bench.py reports `roofline.traffic` only while the kernel sources still are the ones these passes ran on
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import kernel_source_sha
+    try:
+        commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        commit = None
+    acc["_collected"] = {"kernel_source_sha": kernel_source_sha(), "commit": commit,
+                         "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
+                                "--no-cpu-baseline --no-parity --no-full-config --steps 1 --warmup 0; tools/rocprof_summary.py --traffic-json"}
     json.dump(acc, open(out, "w"), indent=1)
 
 
