@@ -222,9 +222,14 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def fetch_rows(eri_dev, spin_pair, npair, idx):
-    return np.stack([np.stack([eri_dev.offset((b * npair + int(r)) * npair, (npair,)).get()[idx] for r in idx])
-                     for b in range(spin_pair)])
+def fetch_rows(eri_dev, spin_pair, npair, idx, table=None):
+    """Sampled entries eri[b][P, Q], P, Q in idx.  `table`: ownership of a row-sharded ERI -- every rank contributes the rows
+    it owns and the sample is assembled over ranks (all ranks must call)."""
+    if table is None:
+        return np.stack([np.stack([eri_dev.offset((b * npair + int(r)) * npair, (npair,)).get()[idx] for r in idx])
+                         for b in range(spin_pair)])
+    from libdmet_preview_amd.parallel import dist
+    return dist.gather_rows_numpy(eri_dev, spin_pair, npair, idx, table)[:, :, idx]
 
 
 def main():
@@ -303,8 +308,9 @@ def main():
     def step(timers, kls):
         if eri_dev is not None:
             eri_dev.zero_()
-        return pipeline.iteration(ctx, sysm, eri_dev=eri_dev, kL_list=kls, timers=timers,
-                                  max_blocks_per_kL=maxblk, allreduce_eri=True)
+        # multi-rank: finished bands of ERI rows are reduced to their owners underneath the contraction, the sum stays row-sharded
+        return pipeline.iteration(ctx, sysm, eri_dev=eri_dev, kL_list=kls, timers=timers, max_blocks_per_kL=maxblk,
+                                  eri_exchange="row_sharded" if distributed else "none")
 
     def fence():
         ctx.sync()
@@ -359,8 +365,8 @@ def main():
     from oracle import eri_sample as ES                      # checker only
     pidx = np.asarray([p[2] for p in ES.sample_pairs(A)])
     got_timed = None
-    if not a.no_parity and rank == 0:
-        got_timed = fetch_rows(eri_dev, spin_pair, npair, pidx)
+    if not a.no_parity:
+        got_timed = fetch_rows(eri_dev, spin_pair, npair, pidx, out.get("eri_rows"))
 
     # ---- ONE pass over the full config (all irreducible kL over all ranks), timed on its own ---------------------------
     full = None
@@ -384,8 +390,8 @@ def main():
                 "eri_only_tflops": round(fl / world / max(ftimers.get("eri", 1e-9), 1e-9) / 1e12, 3),
                 "stage_seconds": {k: round(v, 5) for k, v in ftimers.items()}}
         out = fout
-        if not a.no_parity and rank == 0:
-            got_full = fetch_rows(eri_dev, spin_pair, npair, pidx)
+        if not a.no_parity:
+            got_full = fetch_rows(eri_dev, spin_pair, npair, pidx, fout.get("eri_rows"))
 
     # ---- oracle checks ---------------------------------------------------------------------------------------------------
     parity, stage_parity = None, None
@@ -423,10 +429,9 @@ def main():
             check_kl = kl_mine[:keep]
             check_dev = ctx.zeros((spin_pair, npair, npair), np.float64) if full is None else eri_dev
             check_dev.zero_()
-            pipeline.eri_stage(ctx, sysm, out["C_ao_emb"], nemb, check_dev, check_kl, {}, maxblk)
-            if distributed:
-                dist.all_reduce_sum_dev(check_dev)
-            check_got = fetch_rows(check_dev, spin_pair, npair, pidx) if rank == 0 else None
+            pipeline.eri_stage(ctx, sysm, out["C_ao_emb"], nemb, check_dev, check_kl, {}, maxblk,
+                               exchange="allreduce" if distributed else None)
+            check_got = fetch_rows(check_dev, spin_pair, npair, pidx)
             scope = "UN-timed re-run (oracle budget %.0f s < %.0f s for the timed shard)" % (a.parity_budget_s, est_timed)
         ref_t, idx, _ = ES.eri_sample(sysm.mesh, sysm.df.seed, C_host, sysm.naux, A, check_kl, max_blocks_per_kL=maxblk)
         assert np.array_equal(idx, pidx)
@@ -548,7 +553,9 @@ def main():
                                       n_mine, min(n_mine * world, n_irr) if a.scaling == "weak" else n_irr, n_irr, world, nblk_timed,
                                       "; + ONE pass over the whole config after the timed steps (full_config)" if full is not None else
                                       ("; the timed step IS the whole config" if timed_is_full else "")),
-                       "parallelism": "kL-sharded x%d, k-sharded diag, 1 all-reduce(rho_R) + 1 all-reduce(ERI)" % world},
+                       "parallelism": "kL-sharded x%d, k-sharded diag, all-reduce(ew) + all-reduce(rho_R); ERI: K-stacked contraction finished "
+                                      "band by band, every finished band of rows reduced to its owner underneath the remaining GEMMs "
+                                      "(row-sharded sum), all-reduce of the n x n J / K only" % world},
             "value_executed_mfma_tflops": round(exec_all / elapsed / 1e12, 3),
             "value_executed_frac_of_peak": round(exec_all / elapsed / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world), 4),
             "iteration_wall_s": round(elapsed / a.steps, 4),

@@ -60,6 +60,8 @@ int dmk_set_oom_hook(dmk_ctx *ctx, void (*hook)(void *user), void *user);
 const char *dmk_last_error(const dmk_ctx *ctx);
 const char *dmk_version(void);
 
+/* free / total device memory in bytes (hipMemGetInfo): sizes the plane stack of the ERI pipeline */
+int dmk_mem_info(dmk_ctx *ctx, size_t *free_bytes_host, size_t *total_bytes_host);
 int dmk_malloc(dmk_ctx *ctx, size_t bytes, void **out);
 int dmk_free(dmk_ctx *ctx, void *p);      /* drains the context stream first */
 int dmk_memset(dmk_ctx *ctx, void *p, int value, size_t bytes);
@@ -268,6 +270,22 @@ int dmk_eri_end_kL(dmk_eri *h, int weight);
 /* GSO (partial particle-hole) contraction of basis_transform/eri_transform.py:1252-1277 (_Lij_s4_to_eri_gso):
  * eri[0] += w [(a - b)^T (a - b)] over the Re (and, w = 2, Im) planes of the two flavours; needs spin = 2 at begin. */
 int dmk_eri_end_kL_gso(dmk_eri *h, int weight);
+
+/* Plane stack (deferred, K-stacked contraction).  By default every dmk_eri_end_kL contracts its kL at once
+ * (eri_transform.py:385-386 calls _Lij_s4_to_eri once per kL).  With a stack of `nslots_wanted` slots (each spin x 2 x naux x
+ * npair f64: 842 MB at C5) the planes of up to that many kL stay resident and dmk_eri_contract -- or a full stack, or
+ * dmk_eri_finish -- contracts them with ONE GEMM per weight class and spin block whose K runs over all of them: the 26 GB
+ * result is touched once instead of once per kL.  `nslots_granted` may be smaller than asked (memory).  Time-reversal
+ * pipelines only; call it before the first dmk_eri_begin_kL.  With a stack, k lists that are not the integer mesh must use
+ * dmk_eri_begin_kL_weighted (the slot region depends on the weight of the kL). */
+int dmk_eri_stack(dmk_eri *h, int nslots_wanted, int *nslots_granted);
+int dmk_eri_begin_kL_weighted(dmk_eri *h, int kL, int weight);
+/* Contract what is resident, restricted to the band [band_lo, band_hi) of 128-row tiles of the pair index (-1, -1: all;
+ * dmk_eri_bands gives their number).  Bands must be issued in increasing order; after band b the ROWS of band b of every
+ * spin block are complete, so a kL-sharded job can reduce them over its ranks while later bands are still being computed
+ * (eri_transform_mpi.py:203-210 reduces the whole array after the loop).  `done` != 0 empties the stack. */
+int dmk_eri_contract(dmk_eri *h, int band_lo, int band_hi, int done);
+int dmk_eri_bands(const dmk_eri *h, int *nbands, int *band_rows);
 /* Device pointers of the current kL's Lij_s4 planes (spin x 2 x naux x npair f64:
  * Re plane then Im plane) for inspection / tests. */
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out);
@@ -339,6 +357,11 @@ int dmk_copy_rows_f64(dmk_ctx *ctx, int64_t nrows, int64_t row_len, const int32_
  * (n x n) f64 row-major.  One streaming pass over E for J (both directions) and one for K; no atomics. */
 int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *dm_row, const double *dm_col,
               const double *dm_k, double *vj_row, double *vj_col, double *vk);
+/* The same restricted to the packed rows in `nranges` host ranges [lo, hi) (lo a multiple of 32): the outputs are the
+ * PARTIAL J / K of those rows.  A kL-sharded job keeps the summed ERI row-sharded over its ranks (the reference reduces the
+ * whole array to one rank, eri_transform_mpi.py:203-210) and sums only these n x n matrices. */
+int dmk_jk_s4_rows(dmk_ctx *ctx, int n, const double *eri, int64_t ld, int nranges, const int64_t *ranges_host,
+                   const double *dm_row, const double *dm_col, const double *dm_k, double *vj_row, double *vj_col, double *vk);
 /* 1-fold (n^4) or 8-fold (tril of npair x npair) ERI -> 4-fold (npair x npair): ao2mo.restore(4, .) at
  * solver/scf.py:311-321. */
 int dmk_eri_to_s4(dmk_ctx *ctx, int n, int from_symmetry, const double *in, double *out);

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "dmk_set_oom_hook": (c_int, [c_vp, c_vp, c_vp]),
     "dmk_last_error": (C.c_char_p, [c_vp]),
     "dmk_version": (C.c_char_p, []),
+    "dmk_mem_info": (c_int, [c_vp, P(c_sz), P(c_sz)]),
     "dmk_malloc": (c_int, [c_vp, c_sz, P(c_vp)]),
     "dmk_free": (c_int, [c_vp, c_vp]),
     "dmk_memset": (c_int, [c_vp, c_vp, c_int, c_sz]),
@@ -75,6 +76,10 @@ PROTOTYPES = {
     "dmk_host_free": (c_int, [c_vp, c_vp]),
     "dmk_eri_end_kL": (c_int, [c_vp, c_int]),
     "dmk_eri_end_kL_gso": (c_int, [c_vp, c_int]),
+    "dmk_eri_stack": (c_int, [c_vp, c_int, P(c_int)]),
+    "dmk_eri_begin_kL_weighted": (c_int, [c_vp, c_int, c_int]),
+    "dmk_eri_contract": (c_int, [c_vp, c_int, c_int, c_int]),
+    "dmk_eri_bands": (c_int, [c_vp, P(c_int), P(c_int)]),
     "dmk_eri_planes": (c_int, [c_vp, P(c_vp), P(c_i64)]),
     "dmk_eri_finish": (c_int, [c_vp]),
     "dmk_eri_flops": (c_int, [c_vp, P(c_dbl)]),
@@ -91,6 +96,7 @@ PROTOTYPES = {
     "dmk_pad_block_f64": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp]),
     "dmk_copy_rows_f64": (c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_int]),
     "dmk_jk_s4": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_jk_s4_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_dgemv2": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "dmk_dgemm_batched": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_i64, c_vp, c_i64,
@@ -140,6 +146,7 @@ class Context(object):
                                "there is no CPU fallback" % (device, rc))
         self.h = h
         self.device = int(device)
+        self.default_stream = not stream          # the legacy null stream: ordered with torch's default stream
         # Freed device blocks are parked here by size and handed out again instead of going through hipFree / hipMalloc
         # (each a device synchronisation plus ~1 ms per few hundred MB): an embedding-construction iteration allocates the
         # same two dozen temporaries every time.  One stream per context, so reuse is stream ordered.
@@ -201,12 +208,19 @@ class Context(object):
     def sync(self):
         self.check(lib.dmk_sync(self.h))
 
+    def mem_info(self):
+        """(free, total) bytes of HBM; blocks parked in this context's pool count as free."""
+        f, t = c_sz(), c_sz()
+        self.check(lib.dmk_mem_info(self.h, C.byref(f), C.byref(t)))
+        return int(f.value) + self._pool_bytes, int(t.value)
+
     def set_stream(self, stream):
         # parked blocks were released in the order of the OLD stream: drain it and hand them back to the driver, so that
         # none of them can be given out again (and written on the new stream) while work on the old one still reads it
         self.sync()
         self.trim()
         self.check(lib.dmk_set_stream(self.h, c_vp(stream) if stream else None))
+        self.default_stream = not stream
 
     # ---- device arrays ---------------------------------------------------------------
     def empty(self, shape, dtype):

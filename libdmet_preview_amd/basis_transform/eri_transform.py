@@ -18,6 +18,7 @@ The DF tensor is served by a *block provider* instead of PySCF's `_load3c` on an
 SURVEY.md section 8d generated on the device.
 """
 import ctypes as C
+import os
 import numpy as np
 
 from libdmet_preview_amd._lib import lib, mesh3, get_ctx, DevArray
@@ -570,6 +571,7 @@ class EriEngine(object):
                                     C.byref(h)))
         self.h = h
         self.weights, self.records = eri_plan(self.kmesh, self.tr) if plan is None else plan
+        self.nslots = 1
         self.block_buf = ctx.empty((self.naux, self.nao, self.nao), np.complex128)
         self.host_buf, self.host_slot = None, 0
         # block ring of the hot path: device-side producers write straight into the pipeline's queue slots and step 1
@@ -586,6 +588,37 @@ class EriEngine(object):
 
     def irreducible_kL(self):
         return [kL for kL in range(len(self.weights)) if self.weights[kL] > 0]
+
+    # ---- plane stack: deferred, K-stacked contraction (dmk_eri_stack) ---------------------------------------------------
+    def slot_bytes(self):
+        return self.spin * 2 * self.naux * (self.nemb * (self.nemb + 1) // 2) * 8
+
+    def set_stack(self, nslots=None, budget_gb=None, n_kL=None):
+        """Keep the planes of up to `nslots` kL resident and contract them together.  Without `nslots` the stack is sized
+        from a memory budget: DMK_ERI_STACK_GB (default 64) capped at half of the free HBM and at `n_kL` slots."""
+        if self.gso or not self.tr:
+            return 1
+        if nslots is None:
+            if budget_gb is None:
+                budget_gb = float(os.environ.get("DMK_ERI_STACK_GB", "64"))
+            free, _ = self.ctx.mem_info()
+            budget = min(budget_gb * (1 << 30), 0.5 * free)
+            nslots = int(budget // self.slot_bytes())
+            if n_kL is not None:
+                nslots = min(nslots, int(n_kL))
+        g = C.c_int(1)
+        self.ctx.check(lib.dmk_eri_stack(self.h, max(1, int(nslots)), C.byref(g)))
+        self.nslots = int(g.value)
+        return self.nslots
+
+    def nbands(self):
+        n, rows = C.c_int(), C.c_int()
+        self.ctx.check(lib.dmk_eri_bands(self.h, C.byref(n), C.byref(rows)))
+        return int(n.value), int(rows.value)
+
+    def contract(self, band_lo=-1, band_hi=-1, done=True):
+        """Contract the resident planes (a band of pair-index tiles, or everything); a no-op without a stack."""
+        self.ctx.check(lib.dmk_eri_contract(self.h, int(band_lo), int(band_hi), 1 if done else 0))
 
     def imag_norm(self):
         """max |Im eri| accumulated so far (track_imag engines; 0 with time reversal: the contraction is real)."""
@@ -604,7 +637,10 @@ class EriEngine(object):
 
     def run_kL(self, kL, provider, user_of_mesh=None, max_blocks=None):
         ctx = self.ctx
-        ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
+        if self.nslots > 1:
+            ctx.check(lib.dmk_eri_begin_kL_weighted(self.h, int(kL), int(self.weights[kL])))
+        else:
+            ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
         nblk = 0
         host_feed = hasattr(provider, "load_block_host")
         if host_feed and self.host_buf is None:
@@ -643,6 +679,7 @@ class EriEngine(object):
         nblk = 0
         for kL in todo:
             nblk += self.run_kL(kL, provider, user_of_mesh)
+        self.contract()                      # planes still waiting in the stack
         return nblk
 
     def flops(self):
@@ -810,6 +847,7 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
                 else:
                     from libdmet_preview_amd.basis_transform import eri_transform_mpi as _mpi
                     kL_list = [int(k) for k in _mpi.assign_workload(eng.weights, dist.world_size())[dist.rank()]]
+        eng.set_stack(n_kL=len(kL_list) if kL_list is not None else len(eng.irreducible_kL()))
         eng.run(mydf, kL_list=kL_list)
         if dist is not None and dist.is_initialized():
             dist.all_reduce_sum_dev(eri_dev)

@@ -105,6 +105,12 @@ int dmk_set_stream(dmk_ctx *ctx, void *stream) {
     return DMK_OK;
 }
 
+int dmk_mem_info(dmk_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+    if (!ctx || !free_bytes || !total_bytes) return DMK_ERR_INVALID;
+    DMK_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return DMK_OK;
+}
+
 int dmk_set_oom_hook(dmk_ctx *ctx, void (*hook)(void *), void *user) {
     if (!ctx) return DMK_ERR_INVALID;
     ctx->oom_hook = hook;
@@ -650,6 +656,13 @@ struct dmk_eri {
     int ring_pending = 0;       // queued ring slots whose step 1 has not run yet (they are the first `ring_pending` slots)
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
+    // plane STACK (dmk_eri_stack): nslots > 1 defers the contraction -- the planes of up to nslots kL stay resident, weight-2 kL
+    // fill slots from the front, weight-1 kL (only their Re halves are contracted) from the back, and one K-stacked GEMM per
+    // weight class and spin block contracts them all (dmk_eri_contract, or automatically when the stack is full / at finish)
+    int nslots = 1, n_w2 = 0, n_w1 = 0, cur_slot = 0, cur_weight = 1;
+    double *slot_planes(int slot, int spin_idx) const {
+        return planes + ((size_t)spin_idx * nslots + slot) * 2 * (size_t)naux * npair;
+    }
     // host feed (dmk_eri_push_block_host): two device staging blocks filled on a copy stream while the compute stream
     // transforms the other one; created on first use
     hipStream_t copy_stream = nullptr;
@@ -733,14 +746,43 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     return DMK_OK;
 }
 
-int dmk_eri_begin_kL(dmk_eri *h, int kL) {
-    if (!h) return DMK_ERR_INVALID;
+static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi);
+
+static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
     dmk_ctx *ctx = h->ctx;
     if (kL < 0 || kL >= h->mesh.nk) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin_kL: kL out of range");
     if (h->cur_kL >= 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_begin_kL: previous kL not ended");
-    DMK_HIP(ctx, hipMemsetAsync(h->planes, 0, (size_t)h->spin * 2 * h->naux * h->npair * sizeof(double), ctx->stream));
+    h->cur_slot = 0;
+    if (h->nslots > 1) {
+        if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin_kL: a plane stack needs the weight (1 or 2) of the kL");
+        if (h->n_w2 + h->n_w1 == h->nslots) {                 // stack full: contract everything that is resident
+            int rc = eri_contract_stack(h, -1, -1);
+            if (rc) return rc;
+            h->n_w2 = h->n_w1 = 0;
+        }
+        h->cur_slot = weight == 2 ? h->n_w2 : h->nslots - 1 - h->n_w1;
+        h->cur_weight = weight;
+    }
+    const size_t bytes = (size_t)2 * h->naux * h->npair * sizeof(double);
+    for (int s = 0; s < h->spin; ++s) DMK_HIP(ctx, hipMemsetAsync(h->slot_planes(h->cur_slot, s), 0, bytes, ctx->stream));
     h->cur_kL = kL;
     return DMK_OK;
+}
+
+int dmk_eri_begin_kL(dmk_eri *h, int kL) {
+    if (!h) return DMK_ERR_INVALID;
+    int weight = 1;
+    if (h->nslots > 1 && h->tr && kL >= 0 && kL < h->mesh.nk) {      // integer-mesh plan: the weight follows from the mesh
+        std::vector<int> w;
+        tr_weights(h->mesh, 1, w);
+        weight = w[kL];
+    }
+    return eri_begin_kL_impl(h, kL, weight);
+}
+
+int dmk_eri_begin_kL_weighted(dmk_eri *h, int kL, int weight) {
+    if (!h) return DMK_ERR_INVALID;
+    return eri_begin_kL_impl(h, kL, weight);
 }
 
 static int eri_ring_step1(dmk_eri *h) {
@@ -771,8 +813,9 @@ static int eri_flush(dmk_eri *h) {
     for (int i = 0; i < h->pending; ++i)
         cj[i] = h->C + (size_t)h->pend_kj[i] * nao * nemb;
     int rc = (h->hot256 ? launch_half2_hot : launch_half2_tab)(
-        ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->planes, naux, h->npair, naux, nao, nemb, h->spin,
-        (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb, 2LL * naux * h->npair);
+        ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair, naux, nao, nemb,
+        h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb,
+        (long long)h->nslots * 2LL * naux * h->npair);
     if (rc < 0) return rc;
     if (rc == 0) {
         // the grouped kernel declined (misaligned buffer, a table it cannot build): step 2 of every queued block through the
@@ -788,7 +831,7 @@ static int eri_flush(dmk_eri *h) {
                 g2.seg[1].A = Cj; g2.seg[1].lda = nemb; g2.seg[1].strideA = 0;
                 g2.seg[1].B = ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
                 g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
-                g2.planes = h->planes + (size_t)s * 2 * naux * h->npair; g2.naux = naux; g2.npair = h->npair;
+                g2.planes = h->slot_planes(h->cur_slot, s); g2.naux = naux; g2.npair = h->npair;
                 int rg = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
                 if (rg) return rg;
             }
@@ -845,7 +888,7 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
     for (int s = 0; s < h->spin; ++s) {
         const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
         const double2 *Cj = h->C + ((size_t)s * h->mesh.nk + kj) * nao * nemb;
-        double *planes = h->planes + (size_t)s * 2 * naux * h->npair;
+        double *planes = h->slot_planes(h->cur_slot, s);
         for (int l0 = 0; l0 < naux; l0 += h->lchunk) {
             const int nl = std::min(h->lchunk, naux - l0);
             // step 1: Ut[L][q][a] = sum_p Lpq[L][p][q] conj(Ci[p][a])
@@ -897,6 +940,17 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
         alpha = 1.0;
     }
     const int64_t np = h->npair;
+    if (h->nslots > 1) {
+        // deferred: the planes stay in their slot until the stack is contracted
+        if (!h->tr) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: the plane stack needs time-reversal symmetry");
+        if (weight != h->cur_weight)
+            return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: weight %d, but the slot was chosen for weight %d at begin_kL", weight,
+                            h->cur_weight);
+        if (weight == 2) h->n_w2 += 1; else h->n_w1 += 1;
+        h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
+        h->cur_kL = -1;
+        return DMK_OK;
+    }
     const double *X0 = h->planes;
     const double *X1 = h->planes + (size_t)2 * h->naux * np;
     int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
@@ -922,6 +976,81 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
     }
     h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
     h->cur_kL = -1;
+    return DMK_OK;
+}
+
+// One K-stacked GEMM per weight class and spin block over everything resident in the stack, restricted to the tile band
+// [band_lo, band_hi) of the pair index (-1: all).  Weight-2 slots are adjacent from the front: their Re and Im planes form one
+// contiguous K range.  Weight-1 slots sit at the back and only their Re halves enter: K segments of naux rows, one slot apart.
+static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
+    dmk_ctx *ctx = h->ctx;
+    const int64_t np = h->npair;
+    const int64_t slot_stride = 2LL * h->naux * np;
+    for (int w = 2; w >= 1; --w) {
+        const int n = w == 2 ? h->n_w2 : h->n_w1;
+        if (n == 0) continue;
+        const int first = w == 2 ? 0 : h->nslots - h->n_w1;
+        const int seg_rows = w == 2 ? 2 * h->naux : h->naux;
+        const int K = n * seg_rows;
+        const double *X0 = h->slot_planes(first, 0);
+        int rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X0, np, X0, np, h->eri, np, seg_rows, slot_stride,
+                                         slot_stride, band_lo, band_hi);
+        if (rc) return rc;
+        if (h->spin == 2) {
+            const double *X1 = h->slot_planes(first, 1);
+            rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X0, np, X1, np, h->eri + (size_t)np * np, np, seg_rows,
+                                         slot_stride, slot_stride, band_lo, band_hi);
+            if (rc) return rc;
+            rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X1, np, X1, np, h->eri + (size_t)2 * np * np, np,
+                                         seg_rows, slot_stride, slot_stride, band_lo, band_hi);
+            if (rc) return rc;
+        }
+    }
+    return DMK_OK;
+}
+
+int dmk_eri_stack(dmk_eri *h, int nslots_wanted, int *nslots_granted) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (nslots_wanted < 1) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_stack: needs at least one slot");
+    if (h->cur_kL >= 0 || h->n_w2 + h->n_w1 > 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_stack: a kL is in progress or the stack is not empty");
+    if ((h->imag || !h->tr) && nslots_wanted > 1) nslots_wanted = 1;          // the non-time-reversal branch contracts per kL
+    const size_t slot_bytes = (size_t)h->spin * 2 * h->naux * h->npair * sizeof(double);
+    int n = nslots_wanted;
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    while (true) {
+        if (h->ws_bytes[0] >= slot_bytes * n) break;                            // the buffer at hand is large enough
+        void *fresh = nullptr;
+        if (dmk_dev_alloc(ctx, &fresh, slot_bytes * n) == hipSuccess) {
+            (void)hipFree(h->planes);
+            h->planes = reinterpret_cast<double *>(fresh);
+            h->ws_bytes[0] = slot_bytes * n;
+            break;
+        }
+        if (n == 1) return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_stack: no memory for a single plane slot");
+        n = std::max(1, n / 2);
+    }
+    h->nslots = n;
+    if (nslots_granted) *nslots_granted = n;
+    return DMK_OK;
+}
+
+int dmk_eri_contract(dmk_eri *h, int band_lo, int band_hi, int done) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (h->cur_kL >= 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_contract: a kL is in progress");
+    if (h->nslots > 1) {
+        int rc = eri_contract_stack(h, band_lo, band_hi);
+        if (rc) return rc;
+        if (done) h->n_w2 = h->n_w1 = 0;
+    }
+    return DMK_OK;
+}
+
+int dmk_eri_bands(const dmk_eri *h, int *nbands, int *band_rows) {
+    if (!h || !nbands) return DMK_ERR_INVALID;
+    *nbands = (int)((h->npair + 127) / 128);
+    if (band_rows) *band_rows = 128;
     return DMK_OK;
 }
 
@@ -980,6 +1109,7 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
     dmk_ctx *ctx = h->ctx;
     if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: no kL in progress");
     if (h->spin != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: needs the two flavours (spin = 2)");
+    if (h->nslots > 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: not available with a plane stack");
     {
         int rcf = eri_flush(h);
         if (rcf) return rcf;
@@ -1070,6 +1200,7 @@ int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
         int rcf = eri_flush(h);      // queued blocks must land before anyone looks at the planes
         if (rcf) return rcf;
     }
+    if (h->nslots > 1) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_planes: with a plane stack the spin planes of a kL are not contiguous");
     *planes_out = h->planes;
     if (elems_out) *elems_out = (int64_t)h->spin * 2 * h->naux * h->npair;
     return DMK_OK;
@@ -1124,6 +1255,11 @@ int dmk_host_free(dmk_ctx *ctx, void *p) {
 int dmk_eri_finish(dmk_eri *h) {
     if (!h) return DMK_OK;
     dmk_ctx *ctx = h->ctx;
+    int rc_stack = DMK_OK;
+    if (h->nslots > 1 && h->cur_kL < 0 && h->n_w2 + h->n_w1 > 0) {           // planes still waiting for their contraction
+        rc_stack = eri_contract_stack(h, -1, -1);
+        h->n_w2 = h->n_w1 = 0;
+    }
     (void)hipStreamSynchronize(ctx->stream);
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
@@ -1154,7 +1290,7 @@ int dmk_eri_finish(dmk_eri *h) {
         }
     }
     delete h;
-    return DMK_OK;
+    return rc_stack;
 }
 
 int dmk_eri_flops(const dmk_eri *h, double f[2]) {

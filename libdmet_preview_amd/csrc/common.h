@@ -38,7 +38,7 @@ struct dmk_ctx {
     void *eri_ws[3] = {nullptr, nullptr, nullptr};   // planes, Ut, AO-block ring: parked between pipelines
     size_t eri_ws_bytes[3] = {0, 0, 0};
     // tile visiting orders of the contraction kernel (dgemm_tn.hip), one per (tiles_m, tiles_n, symm)
-    struct TileTable { int tiles_m, tiles_n, symm; unsigned count; unsigned *dev; };
+    struct TileTable { int tiles_m, tiles_n, symm, lo, hi; unsigned count; unsigned *dev; };
     std::vector<TileTable> tile_tables;
     // block-ownership tables of the general-nemb step-2 kernel (zhot_tab.hip), one per embedding dimension
     struct StepTable { int nemb, cfg, nitems; double useful_blocks, folded_blocks; int *dev; };
@@ -180,6 +180,10 @@ __device__ double dmk_wave_sum(double v);
 // C (M x N, ldc) += alpha * X^T Y;  X: K x M (ldx), Y: K x N (ldy)
 int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
                         int64_t ldx, const double *Y, int64_t ldy, double *C, int64_t ldc);
+// K as a stack of row segments and / or the output restricted to a band of 128-wide tiles (dgemm_tn.hip)
+int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X, int64_t ldx, const double *Y,
+                            int64_t ldy, double *C, int64_t ldc, int seg_rows, int64_t seg_stride_x, int64_t seg_stride_y,
+                            int band_lo, int band_hi);
 
 struct ZSeg {
     const void *A = nullptr;   // complex (or real if a_real) operand A

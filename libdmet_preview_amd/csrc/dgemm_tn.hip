@@ -19,6 +19,7 @@
 // Roofline: f64 MFMA: 2*K*M*N flop per call against
 // 8*(K*(M+N) + 2*M*N) bytes.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -191,7 +192,7 @@ template <bool SYMM>
 __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
-    const unsigned *__restrict__ tile_table, unsigned nblocks) {
+    const unsigned *__restrict__ tile_table, unsigned nblocks, int seg_tiles, int64_t jumpA, int64_t jumpB) {
     __shared__ __attribute__((aligned(16))) double lds[GD * G_STAGE];
 
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
@@ -210,12 +211,20 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     const double *pA = X + ca + (int64_t)(2 * wave) * ldx, *pB = Y + cb + (int64_t)(2 * wave) * ldy;
     const int64_t stepA = (int64_t)GBK * ldx, stepB = (int64_t)GBK * ldy;
     int is_stage = 0;
+    // K may be a stack of row SEGMENTS (the planes of several momentum transfers kL, or only their Re halves): after every
+    // `seg_tiles` K-tiles the running pointers hop over the gap to the next segment (wave-uniform counter: scalar ops)
+    int seg_left = seg_tiles;
     auto issue = [&]() {
         double *st = lds + is_stage * G_STAGE + (2 * wave) * G_LD;
         glds16_x4(pA, pA + ldx, pB, pB + ldy, lds_addr_of(st), lds_addr_of(st + G_LD), lds_addr_of(st + GBK * G_LD),
                   lds_addr_of(st + GBK * G_LD + G_LD));
         pA += stepA;
         pB += stepB;
+        if (--seg_left == 0) {
+            pA += jumpA;
+            pB += jumpB;
+            seg_left = seg_tiles;
+        }
         is_stage = is_stage + 1 == GD ? 0 : is_stage + 1;
     };
 
@@ -298,9 +307,13 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
 // Tile visiting order of the LDS-DMA kernel: 8 x 8 super-blocks of tiles, super-block rows walked in a serpentine
 // (the 8 B panels at a row end are reused by the next row), tiles inside a super-block column by column; SYMM keeps
 // tm >= tn only.  Packed (tm << 16 | tn); built once per shape and parked in the context.
-static const unsigned *dgemm_tile_table(dmk_ctx *ctx, int tiles_m, int tiles_n, bool symm, unsigned *count_out) {
+// [lo, hi): restriction to a band of tiles -- tile COLUMNS tn for the symmetric launch (its direct writes then cover the
+// lower part of that column band and its mirrored writes the rows of the band right of the diagonal: after the bands
+// 0 .. b have run, the ROWS of band b are complete), tile ROWS tm for the rectangular one.  (-1, -1) = everything.
+static const unsigned *dgemm_tile_table(dmk_ctx *ctx, int tiles_m, int tiles_n, bool symm, unsigned *count_out, int lo = -1,
+                                        int hi = -1) {
     for (auto &t : ctx->tile_tables)
-        if (t.tiles_m == tiles_m && t.tiles_n == tiles_n && t.symm == (int)symm) {
+        if (t.tiles_m == tiles_m && t.tiles_n == tiles_n && t.symm == (int)symm && t.lo == lo && t.hi == hi) {
             *count_out = t.count;
             return t.dev;
         }
@@ -316,57 +329,91 @@ static const unsigned *dgemm_tile_table(dmk_ctx *ctx, int tiles_m, int tiles_n, 
                 for (int im = 0; im < SB; ++im) {
                     const int tm = Tm * SB + im, tn = Tn * SB + jn;
                     if (tm >= tiles_m || tn >= tiles_n || (symm && tn > tm)) continue;
+                    if (lo >= 0 && ((symm ? tn : tm) < lo || (symm ? tn : tm) >= hi)) continue;
                     h.push_back(((unsigned)tm << 16) | (unsigned)tn);
                 }
         }
     }
     unsigned *dev = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&dev), h.size() * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemcpy(dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
+    if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&dev), std::max<size_t>(h.size(), 1) * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (!h.empty() && hipMemcpy(dev, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(dev);
         return nullptr;
     }
-    ctx->tile_tables.push_back({tiles_m, tiles_n, (int)symm, (unsigned)h.size(), dev});
+    ctx->tile_tables.push_back({tiles_m, tiles_n, (int)symm, lo, hi, (unsigned)h.size(), dev});
     *count_out = (unsigned)h.size();
     return dev;
 }
 
 int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
                         int64_t ldx, const double *Y, int64_t ldy, double *C, int64_t ldc) {
+    return launch_dgemm_tn_acc_seg(ctx, M, N, K, alpha, X, ldx, Y, ldy, C, ldc, 0, 0, 0, -1, -1);
+}
+
+// The same product with (i) K given as K / seg_rows row segments that start seg_stride_x / seg_stride_y ELEMENTS apart
+// (seg_rows = 0: one contiguous segment) and (ii) the output restricted to the tile band [band_lo, band_hi) (128-row /
+// 128-column tiles; -1: everything) -- see dgemm_tile_table.  The ERI pipeline stacks the planes of many kL along K and
+// finishes the contraction band by band so that finished rows can be reduced over ranks while later bands are computed.
+int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X, int64_t ldx, const double *Y,
+                            int64_t ldy, double *C, int64_t ldc, int seg_rows, int64_t seg_stride_x, int64_t seg_stride_y,
+                            int band_lo, int band_hi) {
     if (M <= 0 || N <= 0 || K <= 0) return DMK_OK;
+    if (seg_rows <= 0 || seg_rows >= K) { seg_rows = K; seg_stride_x = seg_stride_y = 0; }
+    if (K % seg_rows) return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_tn: K = %d is not a multiple of the segment length %d", K, seg_rows);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const int64_t nblocks = (int64_t)tiles_m * tiles_n;
     if (nblocks > 0x7fffffffLL) return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_tn: grid too large");
     const bool vec2 = ((ldx & 1) == 0) && ((ldy & 1) == 0) &&
                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+                      ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) && ((seg_stride_x & 1) == 0) && ((seg_stride_y & 1) == 0);
     static const bool dma_enabled = [] { const char *e = getenv("DMK_DGEMM_DMA"); return !(e && atoi(e) == 0); }();
-    if (dma_enabled && vec2 && (K % GBK) == 0 && K >= GBK && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2 &&
+    if (dma_enabled && vec2 && (seg_rows % GBK) == 0 && K >= GBK && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2 &&
         tiles_m < 65536 && tiles_n < 65536) {
         static const bool symm_enabled = [] { const char *e = getenv("DMK_DGEMM_SYMM"); return !(e && atoi(e) == 0); }();
-        const bool symm = symm_enabled && X == Y && ldx == ldy && M == N && tiles_m >= 2;
+        const bool symm = symm_enabled && X == Y && ldx == ldy && seg_stride_x == seg_stride_y && M == N && tiles_m >= 2;
         unsigned count = 0;
-        const unsigned *table = dgemm_tile_table(ctx, tiles_m, tiles_n, symm, &count);
+        const unsigned *table = dgemm_tile_table(ctx, tiles_m, tiles_n, symm, &count, band_lo, band_hi);
         if (!table) return dmk_fail(ctx, DMK_ERR_NOMEM, "dgemm_tn: tile table allocation failed");
+        if (count == 0) return DMK_OK;
+        const int seg_tiles = seg_rows / GBK;
+        const int64_t jumpA = seg_rows == K ? 0 : seg_stride_x - (int64_t)seg_rows * ldx;
+        const int64_t jumpB = seg_rows == K ? 0 : seg_stride_y - (int64_t)seg_rows * ldy;
         FamScope fs(ctx, DMK_FAM_DGEMM);
         fs.mfma_flops(2.0 * (double)count * BM * BN * (double)K);
         if (symm)
             hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<true>, dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                               alpha, X, ldx, Y, ldy, C, ldc, table, count);
+                               alpha, X, ldx, Y, ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB);
         else
             hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<false>, dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                               alpha, X, ldx, Y, ldy, C, ldc, table, count);
+                               alpha, X, ldx, Y, ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB);
         DMK_CHECK_LAUNCH(ctx);
         return DMK_OK;
     }
-    FamScope fs(ctx, DMK_FAM_DGEMM);
-    fs.mfma_flops(2.0 * (double)nblocks * BM * BN * (double)(((K + BK - 1) / BK) * BK));
-    if (vec2)
-        hipLaunchKernelGGL(dgemm_tn_acc_kernel<true>, dim3((unsigned)nblocks), dim3(NTHREADS), 0,
-                           ctx->stream, M, N, K, alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL(dgemm_tn_acc_kernel<false>, dim3((unsigned)nblocks), dim3(NTHREADS), 0,
-                           ctx->stream, M, N, K, alpha, X, ldx, Y, ldy, C, ldc, tiles_m, tiles_n);
-    DMK_CHECK_LAUNCH(ctx);
+    // register-staged kernel (odd sizes): one launch per segment; a band is a row range of C (no mirroring here, so every
+    // band writes its own rows over the full width)
+    int m_lo = 0, m_hi = M;
+    if (band_lo >= 0) {
+        m_lo = std::min(M, band_lo * BM);
+        m_hi = std::min(M, band_hi * BM);
+        if (m_hi <= m_lo) return DMK_OK;
+    }
+    const int Mb = m_hi - m_lo;
+    const int tiles_mb = (Mb + BM - 1) / BM;
+    const int64_t nb2 = (int64_t)tiles_mb * tiles_n;
+    const bool vec2b = vec2 && (m_lo % 2) == 0;
+    for (int k0 = 0, sidx = 0; k0 < K; k0 += seg_rows, ++sidx) {
+        const double *Xs = X + (seg_rows == K ? 0 : (int64_t)sidx * seg_stride_x) + m_lo;
+        const double *Ys = Y + (seg_rows == K ? 0 : (int64_t)sidx * seg_stride_y);
+        double *Cs = C + (int64_t)m_lo * ldc;
+        FamScope fs(ctx, DMK_FAM_DGEMM);
+        fs.mfma_flops(2.0 * (double)nb2 * BM * BN * (double)(((seg_rows + BK - 1) / BK) * BK));
+        if (vec2b)
+            hipLaunchKernelGGL(dgemm_tn_acc_kernel<true>, dim3((unsigned)nb2), dim3(NTHREADS), 0,
+                               ctx->stream, Mb, N, seg_rows, alpha, Xs, ldx, Ys, ldy, Cs, ldc, tiles_mb, tiles_n);
+        else
+            hipLaunchKernelGGL(dgemm_tn_acc_kernel<false>, dim3((unsigned)nb2), dim3(NTHREADS), 0,
+                               ctx->stream, Mb, N, seg_rows, alpha, Xs, ldx, Ys, ldy, Cs, ldc, tiles_mb, tiles_n);
+        DMK_CHECK_LAUNCH(ctx);
+    }
     return DMK_OK;
 }

@@ -52,10 +52,11 @@ __global__ void jk_unpack_kernel(int n, const double *__restrict__ y, double *__
 // yrow[r] = sum_c E[r][c] xrow[c]   (xrow != nullptr);   part[blk][c] = sum_{r in blk} E[r][c] xcol[r]   (xcol != nullptr)
 __global__ __launch_bounds__(NT) void jk_j_kernel(long long npair, const double *__restrict__ E, long long ld,
                                                   const double *__restrict__ xrow, const double *__restrict__ xcol,
-                                                  double *__restrict__ yrow, double *__restrict__ part) {
+                                                  double *__restrict__ yrow, double *__restrict__ part, int blk0) {
     __shared__ double red[NW][JRB];
     __shared__ double xc[JRB];
-    const long long r0 = (long long)blockIdx.x * JRB;
+    const long long rblk = (long long)blk0 + blockIdx.x;        // row block (blk0 > 0: a row range of a sharded ERI)
+    const long long r0 = rblk * JRB;
     const int nr = (int)((npair - r0) < JRB ? (npair - r0) : JRB);
     if (threadIdx.x < JRB) xc[threadIdx.x] = (xcol && threadIdx.x < nr) ? xcol[r0 + threadIdx.x] : 0.0;
     __syncthreads();
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(NT) void jk_j_kernel(long long npair, const double 
             racc[rr] = fma(v[rr], x1, racc[rr]);
             cacc = fma(v[rr], xc[rr], cacc);
         }
-        if (part) part[(long long)blockIdx.x * npair + c] = cacc;
+        if (part) part[rblk * npair + c] = cacc;
     }
     if (yrow) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,12 +121,12 @@ __global__ __launch_bounds__(NT) void jk_colsum_kernel(long long npair, int nblk
 template <int NM>
 __global__ __launch_bounds__(NT) void jk_k_kernel(int n, const double *__restrict__ E, long long ld,
                                                   const double *__restrict__ dm, double *__restrict__ Yi,
-                                                  double *__restrict__ Yj) {
+                                                  double *__restrict__ Yj, long long row0) {
     extern __shared__ double sh[];
     double *xi = sh, *xj = sh + n;                 // dm[i,:], dm[j,:]
     double *ai = sh + 2 * n, *aj = sh + 3 * n;     // row parts y[k] (one writer per k)
     double *red = sh + 4 * n;                      // [NW][2][n] mirrored parts per wave
-    const long long r = blockIdx.x;
+    const long long r = row0 + blockIdx.x;
     int i = (int)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
     while ((long long)(i + 1) * (i + 2) / 2 <= r) ++i;
     while ((long long)i * (i + 1) / 2 > r) --i;
@@ -263,14 +264,24 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" {
 
-int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *dm_row, const double *dm_col,
-              const double *dm_k, double *vj_row, double *vj_col, double *vk) {
+// Rows of the packed ERI that take part: nranges pairs [lo, hi) (lo a multiple of 32), or nranges = 0 for all of them.
+// With ranges the outputs are the PARTIAL J / K of those rows (a row-sharded ERI: every rank runs its own rows and the
+// small n x n results are summed over ranks).
+static int jk_s4_impl(dmk_ctx *ctx, int n, const double *eri, int64_t ld, int nranges, const int64_t *ranges, const double *dm_row,
+                      const double *dm_col, const double *dm_k, double *vj_row, double *vj_col, double *vk) {
     if (!ctx) return DMK_ERR_INVALID;
     const long long npair = (long long)n * (n + 1) / 2;
     if (n <= 0 || !eri || ld < npair) return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4: bad arguments");
     if ((dm_row && !vj_row) || (dm_col && !vj_col) || (dm_k && !vk))
         return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4: a density was given without its output matrix");
     if (dm_k && n > 512) return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4: exchange supports n <= 512 (got %d)", n);
+    const int64_t whole[2] = {0, npair};
+    const bool sharded = nranges > 0;
+    if (!sharded) { nranges = 1; ranges = whole; }
+    for (int q = 0; q < nranges; ++q)
+        if (ranges[2 * q] < 0 || ranges[2 * q + 1] > npair || ranges[2 * q] > ranges[2 * q + 1] || (ranges[2 * q] % JRB) != 0)
+            return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4: row range %d = [%lld, %lld) must lie in [0, %lld) and start on a multiple of %d", q,
+                            (long long)ranges[2 * q], (long long)ranges[2 * q + 1], npair, JRB);
     FamScope fs(ctx, DMK_FAM_JK);
     const int nblk = (int)((npair + JRB - 1) / JRB);
     // workspace carve
@@ -290,12 +301,21 @@ int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *
     double *Yj = reinterpret_cast<double *>(p);
     const int gsmall = (int)std::min<long long>((npair + 255) / 256, 4096);
     const int gsq = (int)std::min<long long>(((long long)n * n + 255) / 256, 4096);
+    if (sharded) {       // rows outside the ranges contribute zeros to the fixed-order reductions below
+        if (dm_row) DMK_HIP(ctx, hipMemsetAsync(yrow, 0, (size_t)npair * 8, ctx->stream));
+        if (dm_col) DMK_HIP(ctx, hipMemsetAsync(part, 0, (size_t)nblk * npair * 8, ctx->stream));
+        if (dm_k) DMK_HIP(ctx, hipMemsetAsync(Yi, 0, 2 * b_Y, ctx->stream));
+    }
     if (dm_row || dm_col) {
         if (dm_row) hipLaunchKernelGGL(jk_fold_dm_kernel, dim3(gsmall), dim3(256), 0, ctx->stream, n, dm_row, xrow);
         if (dm_col) hipLaunchKernelGGL(jk_fold_dm_kernel, dim3(gsmall), dim3(256), 0, ctx->stream, n, dm_col, xcol);
-        hipLaunchKernelGGL(jk_j_kernel, dim3(nblk), dim3(NT), 0, ctx->stream, npair, eri, (long long)ld,
-                           dm_row ? xrow : (const double *)nullptr, dm_col ? xcol : (const double *)nullptr,
-                           dm_row ? yrow : (double *)nullptr, dm_col ? part : (double *)nullptr);
+        for (int q = 0; q < nranges; ++q) {
+            const int b0 = (int)(ranges[2 * q] / JRB), b1 = (int)((ranges[2 * q + 1] + JRB - 1) / JRB);
+            if (b1 <= b0) continue;
+            hipLaunchKernelGGL(jk_j_kernel, dim3(b1 - b0), dim3(NT), 0, ctx->stream, npair, eri, (long long)ld,
+                               dm_row ? xrow : (const double *)nullptr, dm_col ? xcol : (const double *)nullptr,
+                               dm_row ? yrow : (double *)nullptr, dm_col ? part : (double *)nullptr, b0);
+        }
         DMK_CHECK_LAUNCH(ctx);
         if (dm_row) hipLaunchKernelGGL(jk_unpack_kernel, dim3(gsq), dim3(256), 0, ctx->stream, n, yrow, vj_row);
         if (dm_col) {
@@ -313,8 +333,10 @@ int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *
         if (lds > 48 * 1024)                                                                                     \
             DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(jk_k_kernel<NM>),                    \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
-        hipLaunchKernelGGL(jk_k_kernel<NM>, dim3((unsigned)npair), dim3(NT), lds, ctx->stream, n, eri,           \
-                           (long long)ld, dm_k, Yi, Yj);                                                         \
+        for (int q = 0; q < nranges; ++q)                                                                        \
+            if (ranges[2 * q + 1] > ranges[2 * q])                                                               \
+                hipLaunchKernelGGL(jk_k_kernel<NM>, dim3((unsigned)(ranges[2 * q + 1] - ranges[2 * q])), dim3(NT), lds, \
+                                   ctx->stream, n, eri, (long long)ld, dm_k, Yi, Yj, (long long)ranges[2 * q]);  \
     } while (0)
         if (nm <= 1) JK_K_LAUNCH(1);
         else if (nm <= 2) JK_K_LAUNCH(2);
@@ -326,6 +348,17 @@ int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *
         DMK_CHECK_LAUNCH(ctx);
     }
     return DMK_OK;
+}
+
+int dmk_jk_s4(dmk_ctx *ctx, int n, const double *eri, int64_t ld, const double *dm_row, const double *dm_col,
+              const double *dm_k, double *vj_row, double *vj_col, double *vk) {
+    return jk_s4_impl(ctx, n, eri, ld, 0, nullptr, dm_row, dm_col, dm_k, vj_row, vj_col, vk);
+}
+
+int dmk_jk_s4_rows(dmk_ctx *ctx, int n, const double *eri, int64_t ld, int nranges, const int64_t *ranges_host, const double *dm_row,
+                   const double *dm_col, const double *dm_k, double *vj_row, double *vj_col, double *vk) {
+    if (ctx && (nranges <= 0 || !ranges_host)) return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4_rows: needs at least one row range");
+    return jk_s4_impl(ctx, n, eri, ld, nranges, ranges_host, dm_row, dm_col, dm_k, vj_row, vj_col, vk);
 }
 
 int dmk_eri_to_s4(dmk_ctx *ctx, int n, int from_symmetry, const double *in, double *out) {

@@ -3,9 +3,14 @@ Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCC
 GPU box, "gloo" in CPU tests).  Replaces the mpi4pyscf collectives of the reference
 (basis_transform/eri_transform_mpi.py:203-210 `mpi.reduce_inplace(eri)`, routine/mfd_mpi.py:93-94).
 
-Only two exchanges exist on the path: the sum of the partial R-space density
-(138 MB at C5) and the sum of the kL-sharded embedding ERI (26 GB at C5), each ONE all-reduce after
-the local work -- never per kL, so the per-link-bound ring cost is paid once.
+Exchanges on the path:
+  * the eigenvalue table (0.7 MB) and the partial R-space density (138 MB at C5): one all-reduce each;
+  * the kL-sharded embedding ERI (26 GB at C5): the contraction of the resident plane stack is finished band by band of
+    the pair index and every finished band of rows is REDUCED TO ITS OWNER RANK while the next bands are still being
+    computed (`reduce_eri_bands`): (N-1)/N x 26 GB on the wire per step in total, hidden behind the contraction, and
+    the summed ERI stays ROW-SHARDED -- its consumer (J / K of the embedding Hamiltonian) streams row blocks anyway and
+    only its n x n results are summed.  `all_reduce_sum_dev` of the whole array remains for callers that ask for the
+    full tensor on every rank (get_emb_eri(use_mpi=True), like the reference's reduce to rank 0).
 """
 import numpy as np
 
@@ -82,6 +87,86 @@ def tensor_view(dev_array):
     t = torch.as_tensor(holder, device="cuda:%d" % dev_array.ctx.device)
     t._dmk_keep = dev_array
     return t
+
+
+class _Pending(object):
+    """Outstanding asynchronous reductions (keeps the aliased tensors alive until they are done)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, work, keep):
+        self.items.append((work, keep))
+
+    def wait(self):
+        for work, _ in self.items:
+            if work is not None:
+                work.wait()
+        self.items = []
+
+
+def reduce_rows_to(dev_rows, owner, pending):
+    """Sum the device block `dev_rows` over ranks INTO rank `owner` (other ranks keep their partial values).
+    RCCL: asynchronous on the process group's own stream, which waits for the work already queued on the library's
+    stream (the legacy default stream, ordered with torch's current stream) -- kernels launched afterwards overlap with
+    it.  gloo: staged through the host, synchronous."""
+    import torch
+    td = _td()
+    if td.get_backend() == "nccl":
+        if not dev_rows.ctx.default_stream:
+            dev_rows.ctx.sync()
+        t = tensor_view(dev_rows)
+        pending.add(td.reduce(t.view(-1), dst=owner, async_op=True), t)
+    else:
+        host = torch.from_numpy(dev_rows.get())
+        td.reduce(host, dst=owner)
+        if td.get_rank() == owner:
+            dev_rows.set(host.numpy())
+
+
+def reduce_eri_bands(eng, eri_dev, spin_pair, npair, bands_per_group=None):
+    """Finish the contraction of `eng`'s plane stack band by band and reduce every finished group of bands (all spin
+    blocks) to its owner while the next group is computed.  Returns the ownership table [(row_lo, row_hi, owner)] of
+    the pair rows; rows a rank does not own hold its partial sums only."""
+    import os
+    world, me = world_size(), rank()
+    nb, band_rows = eng.nbands()
+    if bands_per_group is None:          # 8 bands = 1024 pair rows = 270 MB per reduction at C5
+        bands_per_group = max(1, int(os.environ.get("DMK_ERI_BAND_GROUP", "8")))
+    pending = _Pending()
+    table = []
+    for gi, b0 in enumerate(range(0, nb, bands_per_group)):
+        b1 = min(nb, b0 + bands_per_group)
+        eng.contract(b0, b1, done=(b1 == nb))
+        owner = gi % world
+        lo, hi = b0 * band_rows, min(npair, b1 * band_rows)
+        table.append((lo, hi, owner))
+        if world > 1:
+            for blk in range(spin_pair):
+                reduce_rows_to(eri_dev.offset((blk * npair + lo) * npair, (hi - lo, npair)), owner, pending)
+    pending.wait()
+    if world > 1 and _td().get_backend() == "nccl":
+        import torch
+        torch.cuda.synchronize()
+    return table
+
+
+def owned_ranges(table, who=None):
+    who = rank() if who is None else who
+    return [(lo, hi) for (lo, hi, owner) in table if owner == who]
+
+
+def gather_rows_numpy(eri_dev, spin_pair, npair, rows, table):
+    """Host copy of the pair rows `rows` of every spin block of a row-sharded ERI, assembled over ranks:
+    (spin_pair, len(rows), npair) on every rank."""
+    me = rank()
+    out = np.zeros((spin_pair, len(rows), npair))
+    for i, r in enumerate(rows):
+        owner = next(o for (lo, hi, o) in table if lo <= r < hi)
+        if owner == me:
+            for b in range(spin_pair):
+                out[b, i] = eri_dev.offset((b * npair + int(r)) * npair, (npair,)).get()
+    return all_reduce_sum_numpy(out) if world_size() > 1 else out
 
 
 def barrier():

@@ -9,7 +9,10 @@ Device-resident embedding-construction iteration on synthetic k-sampled tensors:
 Inputs live in HBM before the iteration starts; only scalars and O(nk*nlo) vectors (eigenvalues,
 occupations, singular values) cross PCIe.  Multi-GPU (one process per GPU):
 k-points are sharded for the diag/density stage (+-k kept together) with ONE all-reduce of the
-partial rho_R, irreducible kL are sharded for the ERI stage with ONE all-reduce of the ERI.
+eigenvalue table and ONE of the partial rho_R; irreducible kL are sharded for the ERI stage, whose planes stay resident
+(K-stacked contraction) so that the final contraction can be finished band by band of the pair index with every finished
+band reduced to its owner rank underneath the remaining GEMMs; the summed ERI stays row-sharded and only the n x n J / K
+matrices of the embedding Hamiltonian are all-reduced.
 """
 import time
 import numpy as np
@@ -171,10 +174,12 @@ def c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers=None, return_basis_k=False):
     return (d_C, d_bk) if return_basis_k else d_C     # the embedding-Hamiltonian stage folds with the same basis_k
 
 
-def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None, d_bk=None):
+def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None, d_bk=None, eri_rows=None):
     """One-body part of the embedding Hamiltonian (slater.py:525-606, interacting bath, HF):
-    H1 = basis^H fock basis - JK_emb(rdm1_emb, ERI), JK_core = H1 - hcore_emb.  Everything is replicated
-    (every rank holds rho_R and, after the all-reduce, the ERI).  Returns host (spin, nemb, nemb) arrays."""
+    H1 = basis^H fock basis - JK_emb(rdm1_emb, ERI), JK_core = H1 - hcore_emb.  The one-body folds are replicated (every
+    rank holds rho_R and the basis).  `eri_rows` = ownership table of a ROW-SHARDED ERI (dist.reduce_eri_bands): every rank
+    streams only the pair rows it owns and the n x n partial J / K are summed over ranks; None = the whole ERI is local.
+    Returns host (spin, nemb, nemb) arrays."""
     timers = {} if timers is None else timers
     n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
     t = time.perf_counter()
@@ -194,16 +199,19 @@ def emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers=None, d_bk=N
     t = _stage(ctx, timers, "emb_h1", t)
     npair = nemb * (nemb + 1) // 2
     blk = lambda b: eri_dev.offset(b * npair * npair, (npair, npair))
+    mine = None if eri_rows is None else dist.owned_ranges(eri_rows)
     if spin == 1:
         d_dm = ctx.to_device(2.0 * rdm1_emb[0])                         # restricted: spin-traced density (slater.py:481)
-        vj, _, vk = scf.jk_dev(ctx, nemb, blk(0), d_dm, None, d_dm)
+        vj, _, vk = scf.jk_dev(ctx, nemb, blk(0), d_dm, None, d_dm, row_ranges=mine)
         veff = (vj.get() - 0.5 * vk.get())[None]
     else:
         d_dm = ctx.to_device(rdm1_emb)
         # the transform leaves the blocks in (aa, ab, bb) order (eri_transform.py:465-467)
-        (vj_s, vj_x), vk = scf.jk_blocks_dev(ctx, nemb, blk(0), blk(2), blk(1), d_dm)
+        (vj_s, vj_x), vk = scf.jk_blocks_dev(ctx, nemb, blk(0), blk(2), blk(1), d_dm, row_ranges=mine)
         vj = np.asarray([vj_s[0].get() + vj_x[0].get(), vj_s[1].get() + vj_x[1].get()])
         veff = vj - np.asarray([vk[0].get(), vk[1].get()])
+    if mine is not None:
+        veff = dist.all_reduce_sum_numpy(veff)                          # (spin, nemb, nemb): the only J / K data on the wire
     H1 = fock_emb - veff
     _stage(ctx, timers, "emb_jk", t)
     return {"H1": H1, "JK_core": H1 - hcore_emb, "rdm1_emb": rdm1_emb, "veff": veff, "fock_emb": fock_emb}
@@ -260,26 +268,43 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
             "dV_dparam_bytes": int(fit.d_dV.nbytes), "vcor": v}
 
 
-def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_blocks_per_kL=None):
-    """DF half transform + contraction over this rank's kL shard; returns (nblocks, flops_half, flops_contract)."""
+def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_blocks_per_kL=None, exchange=None):
+    """DF half transform + contraction over this rank's kL shard.  The planes of the shard stay resident (as many kL as the
+    DMK_ERI_STACK_GB budget holds) and are contracted together.  `exchange`: None (local result), "allreduce" (every rank gets
+    the whole sum) or "row_sharded" (finished bands of pair rows are reduced to their owners underneath the remaining
+    contraction, dist.reduce_eri_bands).  Returns (nblocks, flops_half, flops_contract, ownership table or None)."""
     timers = {} if timers is None else timers
     t = time.perf_counter()
     eng = et.EriEngine(ctx, sysm.mesh, sysm.nao, sysm.naux, nemb, sysm.spin, d_C, eri_dev, True)
+    rows = None
     try:
         todo = eng.irreducible_kL() if kL_list is None else list(kL_list)
+        eng.set_stack(n_kL=len(todo))
         nblk = 0
         for kL in todo:
             nblk += eng.run_kL(kL, sysm.df, max_blocks=max_blocks_per_kL)
         fh, fc = eng.flops()
-        _stage(ctx, timers, "eri", t)
+        if exchange == "row_sharded" and dist.is_initialized():
+            npair = nemb * (nemb + 1) // 2
+            rows = dist.reduce_eri_bands(eng, eri_dev, sysm.spin * (sysm.spin + 1) // 2, npair)
+            _stage(ctx, timers, "eri", t)
+        else:
+            eng.contract()
+            t = _stage(ctx, timers, "eri", t)
+            if exchange == "allreduce" and dist.is_initialized():
+                dist.all_reduce_sum_dev(eri_dev)
+                _stage(ctx, timers, "allreduce_eri", t)
     finally:
         eng.close()
-    return nblk, fh, fc
+    return nblk, fh, fc, rows
 
 
 def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per_kL=None, allreduce_eri=True,
-              emb_ham=True):
-    """One embedding-construction pass.  Returns a dict with the products and per-stage seconds."""
+              emb_ham=True, eri_exchange=None):
+    """One embedding-construction pass.  Returns a dict with the products and per-stage seconds.  `eri_exchange`: how the
+    kL-sharded ERI is summed over ranks -- "allreduce" (default when `allreduce_eri`), "row_sharded" or "none"."""
+    if eri_exchange is None:
+        eri_exchange = "allreduce" if allreduce_eri else "none"
     timers = {} if timers is None else timers
     d_rhoR, mf = mean_field_stage(ctx, sysm, timers)
     d_basis, nemb, sigmas = bath_stage(ctx, sysm, d_rhoR, timers)
@@ -291,12 +316,9 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
         spin_pair = sysm.spin * (sysm.spin + 1) // 2
         if eri_dev is None:
             eri_dev = ctx.zeros((spin_pair, npair, npair), np.float64)
-        nblk, fh, fc = eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list, timers, max_blocks_per_kL)
-        if allreduce_eri and dist.is_initialized():
-            t = time.perf_counter()
-            dist.all_reduce_sum_dev(eri_dev)
-            _stage(ctx, timers, "allreduce_eri", t)
-        out.update({"C_ao_emb": d_C, "eri": eri_dev, "nblocks": nblk, "flops_half": fh, "flops_contract": fc})
+        nblk, fh, fc, rows = eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list, timers, max_blocks_per_kL,
+                                       exchange=None if eri_exchange == "none" else eri_exchange)
+        out.update({"C_ao_emb": d_C, "eri": eri_dev, "nblocks": nblk, "flops_half": fh, "flops_contract": fc, "eri_rows": rows})
         if emb_ham:
-            out["emb_ham"] = emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers, d_bk=d_bk)
+            out["emb_ham"] = emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers, d_bk=d_bk, eri_rows=rows)
     return out

@@ -16,24 +16,35 @@ from libdmet_preview_amd._lib import lib, get_ctx
 from libdmet_preview_amd.system import integral
 
 
-def jk_dev(ctx, n, d_eri, d_dm_row=None, d_dm_col=None, d_dm_k=None, ld=None):
-    """One 4-fold block: returns device (vj_row, vj_col, vk), None where the density was not given."""
+def jk_dev(ctx, n, d_eri, d_dm_row=None, d_dm_col=None, d_dm_k=None, ld=None, row_ranges=None):
+    """One 4-fold block: returns device (vj_row, vj_col, vk), None where the density was not given.  `row_ranges`
+    ([(lo, hi)] of packed pair rows, lo a multiple of 32): the PARTIAL results of those rows of a row-sharded ERI -- the
+    caller sums them over ranks."""
     npair = n * (n + 1) // 2
     out = [ctx.empty((n, n), np.float64) if d is not None else None for d in (d_dm_row, d_dm_col, d_dm_k)]
     p = lambda a: a.ptr if a is not None else None
-    ctx.check(lib.dmk_jk_s4(ctx.h, int(n), d_eri.ptr, int(ld or npair), p(d_dm_row), p(d_dm_col), p(d_dm_k),
-                            p(out[0]), p(out[1]), p(out[2])))
+    if row_ranges is None:
+        ctx.check(lib.dmk_jk_s4(ctx.h, int(n), d_eri.ptr, int(ld or npair), p(d_dm_row), p(d_dm_col), p(d_dm_k),
+                                p(out[0]), p(out[1]), p(out[2])))
+    elif len(row_ranges) == 0:
+        for o in out:
+            if o is not None:
+                o.zero_()
+    else:
+        rr = np.ascontiguousarray(row_ranges, dtype=np.int64).reshape(-1, 2)
+        ctx.check(lib.dmk_jk_s4_rows(ctx.h, int(n), d_eri.ptr, int(ld or npair), len(rr), rr.ctypes.data, p(d_dm_row), p(d_dm_col),
+                                     p(d_dm_k), p(out[0]), p(out[1]), p(out[2])))
     return tuple(out)
 
 
-def jk_blocks_dev(ctx, n, d_aa, d_bb, d_ab, d_dm, with_j=True, with_k=True):
+def jk_blocks_dev(ctx, n, d_aa, d_bb, d_ab, d_dm, with_j=True, with_k=True, row_ranges=None):
     """UIHF J/K from the three device blocks and d_dm (2, n, n): ((vj00, vj11), (vj01, vj10)), (vk00, vk11)."""
     dma, dmb = d_dm.offset(0, (n, n)), d_dm.offset(n * n, (n, n))
-    vj00, _, vk00 = jk_dev(ctx, n, d_aa, dma if with_j else None, None, dma if with_k else None)
-    vj11, _, vk11 = jk_dev(ctx, n, d_bb, dmb if with_j else None, None, dmb if with_k else None)
+    vj00, _, vk00 = jk_dev(ctx, n, d_aa, dma if with_j else None, None, dma if with_k else None, row_ranges=row_ranges)
+    vj11, _, vk11 = jk_dev(ctx, n, d_bb, dmb if with_j else None, None, dmb if with_k else None, row_ranges=row_ranges)
     vj01 = vj10 = None
     if with_j:
-        vj01, vj10, _ = jk_dev(ctx, n, d_ab, dmb, dma, None)     # J a from b (rows), J b from a (columns)
+        vj01, vj10, _ = jk_dev(ctx, n, d_ab, dmb, dma, None, row_ranges=row_ranges)     # J a from b (rows), J b from a (columns)
     return ((vj00, vj11), (vj01, vj10)), (vk00, vk11)
 
 

@@ -13,27 +13,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(workload, dist_on, rank=0, world=1, over=None, device=0):
+def _run(workload, dist_on, rank=0, world=1, over=None, device=0, exchange="allreduce"):
     from libdmet_preview_amd import _lib, pipeline
     from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd.parallel import dist
     ctx = _lib.Context(device)
     _lib.set_ctx(ctx)
     sysm = pipeline.SyntheticSystem.from_workload(ctx, workload, **(over or {}))
     kl = et.assign_workload(sysm.mesh, world)[rank] if dist_on else None
-    out = pipeline.iteration(ctx, sysm, kL_list=kl, allreduce_eri=True, emb_ham=True)
+    out = pipeline.iteration(ctx, sysm, kL_list=kl, emb_ham=True, eri_exchange=exchange if dist_on else "none")
     ctx.sync()
     n, nk, spin, nemb = sysm.nlo, sysm.nk, sysm.spin, out["nemb"]
     B = out["basis"].get().reshape(spin, nk * n, nemb)
-    return {"eri": out["eri"].get(), "rho_R": out["rho_R"].get(), "proj_diag": np.einsum("spa,spa->sp", B, B),
-            "H1": np.asarray(out["emb_ham"]["H1"]), "nemb": nemb, "kl": kl,
+    eri = out["eri"].get()
+    table = out.get("eri_rows")
+    if table is not None:
+        # row-sharded sum: only the owner of a band of rows holds its total; assemble the whole array over ranks to compare
+        npair = nemb * (nemb + 1) // 2
+        eri = dist.gather_rows_numpy(out["eri"], eri.shape[0], npair, list(range(npair)), table)
+    return {"eri": eri, "rho_R": out["rho_R"].get(), "proj_diag": np.einsum("spa,spa->sp", B, B),
+            "H1": np.asarray(out["emb_ham"]["H1"]), "nemb": nemb, "kl": kl, "table": table,
             "stages": sorted(out["timers"].keys())}
 
 
-def _worker(rank, world, port, workload, over, q, backend="gloo"):
+def _worker(rank, world, port, workload, over, q, backend="gloo", exchange="allreduce"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["DMK_ERI_BAND_GROUP"] = "1"                 # one band per reduction: several owners even at test sizes
     import torch.distributed as td
     device = 0
     if backend == "nccl":
@@ -44,7 +52,7 @@ def _worker(rank, world, port, workload, over, q, backend="gloo"):
     else:
         td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _run(workload, True, rank, world, over, device=device)
+        res = _run(workload, True, rank, world, over, device=device, exchange=exchange)
         res["world_size"], res["backend"] = td.get_world_size(), td.get_backend()
         q.put((rank, res))
         td.barrier()
@@ -52,13 +60,17 @@ def _worker(rank, world, port, workload, over, q, backend="gloo"):
         td.destroy_process_group()
 
 
-@pytest.mark.parametrize("workload,over,world", [("C3", None, 2), ("C3", dict(mesh=(3, 2, 2), spin=2, nval=4, nlo=8, naux=12), 3)])
-def test_ranks_on_one_gpu_match_single_process(workload, over, world):
+@pytest.mark.parametrize("workload,over,world,exchange", [
+    ("C3", None, 2, "allreduce"), ("C3", dict(mesh=(3, 2, 2), spin=2, nval=4, nlo=8, naux=12), 3, "allreduce"),
+    # row-sharded sum: bands of ERI rows reduced to their owners, J / K from the owned rows, only n x n matrices all-reduced
+    ("C3", dict(mesh=(3, 2, 2), spin=2, nval=8, nlo=24, naux=16), 2, "row_sharded"),
+    ("C3", dict(mesh=(4, 2, 1), spin=1, nval=20, nlo=40, naux=8), 3, "row_sharded")])
+def test_ranks_on_one_gpu_match_single_process(workload, over, world, exchange):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = 29600 + (os.getpid() % 1500)
-    procs = [mpc.Process(target=_worker, args=(r, world, port, workload, over, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, workload, over, q, "gloo", exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)
@@ -68,7 +80,12 @@ def test_ranks_on_one_gpu_match_single_process(workload, over, world):
     single = _run(workload, False, over=over)
     allkl = sum((res[r]["kl"] for r in range(world)), [])
     assert len(allkl) == len(set(allkl))                                  # disjoint shards
-    assert "allreduce_rho" in res[0]["stages"] and "allreduce_eri" in res[0]["stages"]
+    assert "allreduce_rho" in res[0]["stages"]
+    if exchange == "allreduce":
+        assert "allreduce_eri" in res[0]["stages"] and res[0]["table"] is None
+    else:
+        owners = {o for (_, _, o) in res[0]["table"]}
+        assert res[0]["table"] == res[1]["table"] and owners <= set(range(world)) and len(owners) == min(world, len(res[0]["table"]))
     scale = np.abs(single["eri"]).max()
     for r in range(world):
         assert res[r]["nemb"] == single["nemb"]

@@ -113,3 +113,84 @@ def test_c5_meanfield_bath_full_size(ctx):
     assert res["parity_nbath_equal"] and res["parity_bath_frob"] <= 1e-10 and res["parity_basis_orth"] <= 1e-12, res
     assert res["parity_c_ao_emb_maxabs"] <= 1e-12, res
     assert res["parity_stages_ok"]
+
+
+@pytest.mark.parametrize("nao,naux,nemb,spin,nslots", [(16, 40, 256, 2, 3), (24, 16, 40, 1, 2), (10, 7, 12, 2, 4), (104, 24, 136, 1, 16)])
+def test_plane_stack_and_banded_contraction(ctx, nao, naux, nemb, spin, nslots):
+    """Deferred, K-stacked contraction (dmk_eri_stack): the planes of several kL stay resident -- weight-2 slots from the front,
+    weight-1 slots (Re halves only) from the back -- and one segmented-K GEMM per weight class and spin block contracts them;
+    a full stack flushes by itself; the final contraction run band by band (dmk_eri_contract) gives the same ERI and leaves
+    every finished band of rows complete.  Against the per-kL contraction of the same engine and the sampled oracle; hot
+    (nemb 256 / 136) and generic kernels (odd naux: the register-staged GEMM fallback with per-segment launches)."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh = (3, 2, 1)                                 # weights 1, 2, 0 mixed: 2 weight-1 and 2 weight-2 irreducible kL
+    nk = 6
+    npair = nemb * (nemb + 1) // 2
+    nblk = spin * (spin + 1) // 2
+    rng = np.random.default_rng(nao + nemb)
+    Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Ce)
+    df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=77)
+
+    def run(stack, banded):
+        eri_dev = ctx.zeros((nblk, npair, npair), np.float64)
+        eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+        snap = None
+        try:
+            kls = eng.irreducible_kL()
+            assert sorted(int(eng.weights[k]) for k in kls) == [1, 1, 2, 2]
+            if stack:
+                assert eng.set_stack(nslots=stack) == stack
+            for kL in kls:
+                eng.run_kL(kL, df)
+            if banded:
+                nb, rows = eng.nbands()
+                assert nb == (npair + rows - 1) // rows
+                for b in range(nb):
+                    eng.contract(b, b + 1, done=(b == nb - 1))
+                    if b == 0 and nb > 1:
+                        ctx.sync()
+                        snap = eri_dev.get()[:, :rows].copy()          # rows of band 0 must already be final
+            else:
+                eng.contract()
+            ctx.sync()
+            return eri_dev.get(), snap
+        finally:
+            eng.close()
+
+    ref, _ = run(0, False)
+    scale = np.abs(ref).max()
+    for stack, banded in ((nslots, False), (nslots, True), (2, True)):      # 2 slots < 4 kL: the stack flushes on its own in between
+        got, snap = run(stack, banded)
+        assert np.abs(got - ref).max() < 1e-11 * scale, (stack, banded, np.abs(got - ref).max(), scale)
+        if snap is not None:
+            assert np.abs(snap - ref[:, :snap.shape[1]]).max() < 1e-11 * scale
+    A = [0, 1, nemb // 2, nemb - 1]
+    want, idx, _ = ES.eri_sample(mesh, 77, Ce, naux, A, [int(k) for k in range(nk) if ES.plan_records(mesh)[0][k] > 0])
+    for b in range(nblk):
+        assert np.abs(ref[b][np.ix_(idx, idx)] - want[b]).max() < 1e-8
+
+
+def test_jk_row_ranges_add_up(ctx):
+    """dmk_jk_s4_rows: the J (both directions) and K of disjoint ranges of packed rows add up to the whole-ERI result -- the
+    embedding-Hamiltonian stage of a row-sharded ERI sums exactly these partial matrices over ranks."""
+    from libdmet_preview_amd.solver import scf
+    n = 72
+    npair = n * (n + 1) // 2
+    rng = np.random.default_rng(4)
+    E = rng.standard_normal((npair, npair))
+    dm = rng.standard_normal((2, n, n))
+    dE, d_dm = ctx.to_device(E), ctx.to_device(dm)
+    da, db = d_dm.offset(0, (n, n)), d_dm.offset(n * n, (n, n))
+    full = [x.get() for x in scf.jk_dev(ctx, n, dE, da, db, da)]
+    cuts = [0, 128, 1024, 1056, npair]
+    acc = [np.zeros((n, n)) for _ in range(3)]
+    for own in (0, 1):
+        ranges = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if i % 2 == own]
+        part = scf.jk_dev(ctx, n, dE, da, db, da, row_ranges=ranges)
+        for a_, p_ in zip(acc, part):
+            a_ += p_.get()
+    for a_, f_ in zip(acc, full):
+        assert np.abs(a_ - f_).max() < 1e-11 * np.abs(f_).max()
+    empty = scf.jk_dev(ctx, n, dE, da, None, da, row_ranges=[])
+    assert np.abs(empty[0].get()).max() == 0.0 and empty[1] is None
