@@ -125,3 +125,32 @@ def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, 
 
 
 vcor_zeros = VcorLocal
+
+
+# ---- driver layer (dmet/Hubbard.py:14-41, 1503): thin host wrappers over the device routines ------------------------------
+
+def HartreeFock(Lat, v, filling, mu0=None, beta=np.inf, ires=False, **kwargs):
+    """RHF / UHF lattice mean field of the DMET loop: `mfd.HF` with the spin symmetry of the correlation potential."""
+    from libdmet_preview_amd.routine.mfd import HF
+    if beta != np.inf:
+        log.info("using finite-T smearing for lattice, beta = %20.12f ", beta)
+    rho, mu, E, res = HF(Lat, v, filling, v.restricted, mu0=mu0, beta=beta, ires=True, **kwargs)
+    log.result("Chemical potential (mean-field) = %s", mu)
+    log.result("Energy per cell (mean-field) = %20.12f", E)
+    if ires or kwargs.get("full_return", False):
+        return rho, mu, res
+    return rho, mu
+
+
+def RHartreeFock(Lat, v, filling, mu0=None, beta=np.inf, ires=False, **kwargs):
+    log.eassert(v.restricted, "RHF routine requires vcor is restricted.")
+    return HartreeFock(Lat, v, filling, mu0=mu0, beta=beta, ires=ires, **kwargs)
+
+
+def FitVcor(rho, lattice, basis, vcor, beta, filling, MaxIter1=300, MaxIter2=0, **kwargs):
+    """dmet/Hubbard.py:1503 (`FitVcor = slater.FitVcorTwoStep`); resolved at call time so that it follows a rebound routine."""
+    from libdmet_preview_amd.routine import slater
+    return slater.FitVcorTwoStep(rho, lattice, basis, vcor, beta, filling, MaxIter1=MaxIter1, MaxIter2=MaxIter2, **kwargs)
+
+
+from libdmet_preview_amd.dmet.HubPhSymm import ConstructImpHam, basisMatching  # noqa: E402,F401

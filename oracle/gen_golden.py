@@ -992,11 +992,102 @@ def gen_G15():
     print("G15 done")
 
 
+def gen_G16():
+    """The reference's DRIVER layer as a chain, ab initio (dmet/Hubbard.py:14-37 HartreeFock, dmet/HubPhSymm.py:74-100
+    ConstructImpHam = slater.embBasis -> basisMatching -> slater.embHam, dmet/Hubbard.py:1503 FitVcor): a duck-typed ab-initio
+    lattice with an in-memory GDF, UHF (so that basisMatching and the H2[[0, 2, 1]] reorder of slater.py:461-462 fire), the
+    interacting bath (get_emb_eri through __embHam2e, no H2_given) AND the bare bath (get_unit_eri -> unit2emb), then the
+    two-step fit on the chain's own basis.  Everything executed is reference code; the PySCF primitives underneath are the
+    restatements of oracle/shim.py and `df.GDF` is pointed at the in-memory provider so that the reference's own
+    isinstance dispatch (eri_transform.py:68-94) takes its GDF branch."""
+    import types
+    from oracle import restate
+    et = shim.patch_eri_transform()
+    shim.patch_scf()
+    from libdmet.routine import slater
+    from libdmet.solver import scf as rscf
+    from libdmet.dmet import Hubbard as rdmet
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+
+    class _Other(object):
+        pass
+    et.df = types.SimpleNamespace(MDF=type("MDF", (_Other,), {}), GDF=shim.FakeGDF, FFTDF=type("FFTDF", (_Other,), {}),
+                                  AFTDF=type("AFTDF", (_Other,), {}))
+    out = {}
+    for name, mesh, nlo, naux, val in [("uhf_221", (2, 2, 1), 6, 5, [1, 2, 3]), ("uhf_311", (3, 1, 1), 5, 4, [0, 1, 2])]:
+        nk = int(np.prod(mesh))
+        spin = 2
+        rng = np.random.default_rng(1600 + nlo)
+        core = [i for i in range(nlo) if i < min(val)]
+        virt = [i for i in range(nlo) if i > max(val)]
+        L = _duck_lattice(mesh, nlo, val=val, virt=virt, core=core)
+        FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=160 + nlo)
+        Fk = synth.fold_R2k(FR, mesh)
+        HR = 0.6 * FR
+        Hk = synth.fold_R2k(HR, mesh)
+        SR = np.zeros((nk, nlo, nlo))
+        SR[0] = np.eye(nlo)
+        Sk = synth.fold_R2k(SR[None], mesh)[0]
+        L.fock_lo_k, L.fock_lo_R, L.hcore_lo_k, L.hcore_lo_R = Fk, FR, Hk, HR
+        L.vhf_lo_k, L.ovlp_lo_k = Fk - Hk, Sk
+        L.JK_imp = L.Ham = None
+        L.H0 = 0.75
+        # ab-initio side: AO = LO dimension, TR-symmetric C_ao_lo, real-space DF kernel
+        cell = shim.FakeCell(nlo)
+        cell.pbc_intor = True                                   # slater.py:449 picks the periodic branch on this attribute
+        from libdmet.system import fourier as rf
+        ks = rf.make_kpts_scaled(mesh)
+        kpts = cell.get_abs_kpts(ks)
+        W0 = 0.3 * synth.make_W0(mesh, naux, nlo, seed=1700 + nk)
+        blocks = synth.df_blocks_from_W0(W0, mesh)
+        L.cell = cell
+        L.df = shim.FakeGDF(cell, kpts, lambda i, j, b=blocks: b[i, j], naux=naux, blockdim=naux)
+        L.C_ao_lo = synth.make_C_ao_lo(mesh, nlo, nlo, spin=spin, seed=170 + nlo)
+        L.eri_symmetry = 4
+        # correlation potential: VcorLocal on the valence orbitals, seeded parameters
+        vc = rdmet.VcorLocal(False, False, nlo, idx_range=val)
+        p0 = 0.1 * rng.standard_normal(vc.length())
+        vc.update(p0)
+        rho, mu, res = rdmet.HartreeFock(L, vc, 0.5, mu0=None, beta=np.inf, ires=True)
+        L.rdm1_lo_k, L.rdm1_lo_R = res["rho_k"], rho
+        out[name + "/mesh"], out[name + "/val"] = np.array(mesh), np.array(val)
+        out[name + "/Fock_R"], out[name + "/H1_R"], out[name + "/W0"], out[name + "/C_ao_lo"] = FR, HR, W0, L.C_ao_lo
+        out[name + "/vcor_param"], out[name + "/vcor_value"] = p0, vc.get()
+        out[name + "/rho"], out[name + "/mu"], out[name + "/rho_k"] = rho, np.asarray(mu), res["rho_k"]
+        for tag, kw in [("ib", dict(int_bath=True)), ("nib", dict(int_bath=False))]:
+            L.JK_core = "unset"
+            ImpHam, H1e, basis = rdmet.ConstructImpHam(L, rho, vc, matching=True, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/basis"] = basis
+            out[key + "/H1"], out[key + "/H2"] = ImpHam.H1["cd"], np.asarray(ImpHam.H2["ccdd"])
+            out[key + "/H0"], out[key + "/ovlp"] = np.asarray(ImpHam.H0), np.asarray(ImpHam.ovlp)
+            if L.JK_core is not None and not isinstance(L.JK_core, str):
+                out[key + "/JK_core"] = np.asarray(L.JK_core)
+            assert ImpHam.H2["ccdd"].shape[0] == 3
+            if tag == "ib":
+                # slater.py:461-462: the solver order is (aa, bb, ab); the raw transform returns (aa, ab, bb)
+                raw = et.get_emb_eri_fast_gdf(cell, L.df, C_ao_lo=L.C_ao_lo, basis=basis, max_memory=1)
+                assert np.array_equal(raw[[0, 2, 1]], ImpHam.H2["ccdd"])
+                basis_ib = basis
+        # the chain's fit: target = embedded mean-field density of a hidden parameter vector (stands in for the solver)
+        from libdmet.routine import mfd
+        vt = rdmet.VcorLocal(False, False, nlo, idx_range=val)
+        vt.update(p0 + 0.05 * rng.standard_normal(vc.length()))
+        _, _, _, rt = mfd.HF(L, vt, 0.5, False, beta=np.inf, ires=True)
+        target = slater.foldRho_k(rt["rho_k"], L.R2k_basis(basis_ib))
+        out[name + "/fit_target"] = target
+        vfit, err_end = rdmet.FitVcor(target, L, basis_ib, vc, np.inf, 0.5, MaxIter1=40, MaxIter2=0)
+        out[name + "/fit_param"], out[name + "/fit_err"] = np.array(vfit.param), np.asarray(err_end)
+        print("G16", name, "H2 max %.3g, fit err %.3e" % (np.abs(out[name + "/ib/H2"]).max(), float(err_end)))
+    np.savez_compressed(os.path.join(GOLD, "G16_chain.npz"), **out)
+    print("G16 done")
+
+
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16"]
     for g in which:
         globals()["gen_" + g]()
 
