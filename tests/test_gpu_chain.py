@@ -75,7 +75,8 @@ def _rotate_h2(H2, T, nemb):
     for b, (s1, s2) in enumerate(pairs):
         full = R.restore(1, H2[b], nemb)
         full = np.einsum("ijkl,ia,jb,kc,ld->abcd", full, T[s1], T[s1], T[s2], T[s2], optimize=True)
-        out.append(R.restore(4, full, nemb))
+        ia, ib = np.tril_indices(nemb)
+        out.append(full[ia, ib][:, ia, ib])                      # back to the 4-fold packed form
     return np.asarray(out)
 
 
