@@ -286,6 +286,14 @@ int dmk_eri_begin_kL_weighted(dmk_eri *h, int kL, int weight);
  * (eri_transform_mpi.py:203-210 reduces the whole array after the loop).  `done` != 0 empties the stack. */
 int dmk_eri_contract(dmk_eri *h, int band_lo, int band_hi, int done);
 int dmk_eri_bands(const dmk_eri *h, int *nbands, int *band_rows);
+/* Out-of-core form (eri_transform.py:486-521 adds ERI_SLICE-row slabs of every kL to the file): rows [row_lo, row_hi) of every
+ * spin block of the contraction of the RESIDENT planes, accumulated into `out` ((spin_pair, rows, npair) f64, caller-zeroed)
+ * instead of into the pipeline's ERI -- the whole (spin_pair, npair, npair) tensor never has to fit HBM.  The caller empties
+ * the stack with dmk_eri_stack_clear when every slab has been taken and asks dmk_eri_stack_free_slots before a new kL
+ * (a full stack would otherwise be contracted into the pipeline's ERI). */
+int dmk_eri_contract_rows(dmk_eri *h, int64_t row_lo, int64_t row_hi, double *out);
+int dmk_eri_stack_clear(dmk_eri *h);
+int dmk_eri_stack_free_slots(const dmk_eri *h, int *free_slots);
 /* Device pointers of the current kL's Lij_s4 planes (spin x 2 x naux x npair f64:
  * Re plane then Im plane) for inspection / tests. */
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out);

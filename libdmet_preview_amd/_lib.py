@@ -80,6 +80,9 @@ PROTOTYPES = {
     "dmk_eri_begin_kL_weighted": (c_int, [c_vp, c_int, c_int]),
     "dmk_eri_contract": (c_int, [c_vp, c_int, c_int, c_int]),
     "dmk_eri_bands": (c_int, [c_vp, P(c_int), P(c_int)]),
+    "dmk_eri_contract_rows": (c_int, [c_vp, c_i64, c_i64, c_vp]),
+    "dmk_eri_stack_clear": (c_int, [c_vp]),
+    "dmk_eri_stack_free_slots": (c_int, [c_vp, P(c_int)]),
     "dmk_eri_planes": (c_int, [c_vp, P(c_vp), P(c_i64)]),
     "dmk_eri_finish": (c_int, [c_vp]),
     "dmk_eri_flops": (c_int, [c_vp, P(c_dbl)]),

@@ -616,6 +616,17 @@ class EriEngine(object):
         self.ctx.check(lib.dmk_eri_bands(self.h, C.byref(n), C.byref(rows)))
         return int(n.value), int(rows.value)
 
+    def stack_free(self):
+        n = C.c_int()
+        self.ctx.check(lib.dmk_eri_stack_free_slots(self.h, C.byref(n)))
+        return int(n.value)
+
+    def contract_rows_into(self, lo, hi, d_out):
+        self.ctx.check(lib.dmk_eri_contract_rows(self.h, int(lo), int(hi), d_out.ptr))
+
+    def stack_clear(self):
+        self.ctx.check(lib.dmk_eri_stack_clear(self.h))
+
     def contract(self, band_lo=-1, band_hi=-1, done=True):
         """Contract the resident planes (a band of pair-index tiles, or everything); a no-op without a stack."""
         self.ctx.check(lib.dmk_eri_contract(self.h, int(band_lo), int(band_hi), 1 if done else 0))
@@ -832,6 +843,9 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
     npair = nemb * (nemb + 1) // 2
     spin_pair = spin * (spin + 1) // 2
 
+    if not incore:
+        return _emb_eri_outcore(ctx, cell, mydf, kmesh, plan, C_dev, nao, naux, nemb, spin, fout, use_mpi)
+
     eri_dev = ctx.zeros((spin_pair, npair, npair), np.float64)
     eng = EriEngine(ctx, kmesh, nao, naux, nemb, spin, C_dev, eri_dev, t_reversal_symm, plan=plan,
                     track_imag=not t_reversal_symm)
@@ -865,15 +879,65 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
     finally:
         eng.close()
 
-    if not incore:
-        order = [0] if spin_pair == 1 else [0, 2, 1]
-        fn = fout if str(fout).endswith(".npy") else str(fout) + ".npy"
-        mm = np.lib.format.open_memmap(fn, mode="w+", dtype=np.float64, shape=eri.shape)
-        mm[:] = eri[order]
-        mm.flush()
-        return {"ccdd": mm}
     log.debug(1, "ERI restore")
     return eri_restore(eri, symmetry, nemb)
+
+
+
+
+OUTCORE_MAX_SLOTS = None      # cap of the plane stack of the out-of-core driver (tests force several flushes with it)
+
+
+def _emb_eri_outcore(ctx, cell, mydf, kmesh, plan, C_dev, nao, naux, nemb, spin, fout, use_mpi):
+    """incore=False (eri_transform.py:314-320, 486-521): the ERI is accumulated slab by slab of ERI_SLICE pair rows into a
+    file in the reference's out-of-core block order (aa, bb, ab); the (spin_pair, npair, npair) tensor is never held in HBM.
+    The planes of as many kL as the stack budget holds stay resident; when the stack is full (and at the end) every slab of
+    rows is contracted over all of them (dmk_eri_contract_rows), copied to the host and added to the file.  The file is
+    `fout` as .npy (h5py is not on the GPU box); returns {"ccdd": memmap}."""
+    npair = nemb * (nemb + 1) // 2
+    spin_pair = spin * (spin + 1) // 2
+    order = [0] if spin_pair == 1 else [0, 2, 1]
+    fn = fout if str(fout).endswith(".npy") else str(fout) + ".npy"
+    mm = np.lib.format.open_memmap(fn, mode="w+", dtype=np.float64, shape=(spin_pair, npair, npair))
+    mm[:] = 0.0
+    dummy = ctx.zeros((16,), np.float64)                     # the pipeline's own ERI is never written in this mode
+    eng = EriEngine(ctx, kmesh, nao, naux, nemb, spin, C_dev, dummy, True, plan=plan)
+    slab_rows = max(2, int(ERI_SLICE) & ~1)
+    try:
+        todo = eng.irreducible_kL()
+        if use_mpi:
+            from libdmet_preview_amd.parallel import dist
+            if dist.is_initialized() and dist.world_size() > 1:
+                raise NotImplementedError("out-of-core ERI with use_mpi: every rank would need its own file")
+        slab_bytes = spin_pair * slab_rows * npair * 8
+        free, _ = ctx.mem_info()
+        budget = max(0.0, 0.5 * free - slab_bytes)
+        nslots = max(2, min(len(todo), int(budget // eng.slot_bytes()), OUTCORE_MAX_SLOTS or len(todo)))
+        if eng.set_stack(nslots=nslots) < 2:
+            raise MemoryError("out-of-core ERI: not enough HBM for two plane slots")
+        d_slab = ctx.empty((spin_pair, slab_rows, npair), np.float64)
+
+        def flush():
+            for lo in range(0, npair, slab_rows):
+                hi = min(npair, lo + slab_rows)
+                view = d_slab if hi - lo == slab_rows else ctx.wrap(d_slab.address, (spin_pair, hi - lo, npair), np.float64,
+                                                                    keepalive=d_slab)
+                view.zero_()
+                eng.contract_rows_into(lo, hi, view)
+                part = view.get()
+                for dst, src in enumerate(order):
+                    mm[dst, lo:hi] += part[src]
+            eng.stack_clear()
+
+        for kL in todo:
+            if eng.stack_free() == 0:
+                flush()
+            eng.run_kL(kL, mydf)
+        flush()
+    finally:
+        eng.close()
+    mm.flush()
+    return {"ccdd": mm}
 
 
 get_emb_eri_fast = get_emb_eri_fast_gdf

@@ -1052,6 +1052,56 @@ int dmk_eri_contract(dmk_eri *h, int band_lo, int band_hi, int done) {
     return DMK_OK;
 }
 
+// Rows [row_lo, row_hi) of every spin block of the contraction of what is resident, ACCUMULATED into `out` ((spin_pair, rows,
+// npair) f64, caller-zeroed) instead of into the pipeline's ERI: the out-of-core form of _Lij_s4_to_eri
+// (eri_transform.py:486-521 adds ERI_SLICE-row slabs to the file): the full (spin_pair, npair, npair) tensor never has to fit HBM.
+int dmk_eri_contract_rows(dmk_eri *h, int64_t row_lo, int64_t row_hi, double *out) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    const int64_t np = h->npair;
+    if (h->cur_kL >= 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_contract_rows: a kL is in progress");
+    if (h->nslots <= 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_contract_rows: needs a plane stack (dmk_eri_stack)");
+    if (!out || row_lo < 0 || row_hi > np || row_lo >= row_hi || (row_lo & 1))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_contract_rows: bad row range [%lld, %lld) (row_lo must be even)", (long long)row_lo, (long long)row_hi);
+    const int rows = (int)(row_hi - row_lo);
+    const int64_t slot_stride = 2LL * h->naux * np;
+    const size_t blk = (size_t)rows * np;
+    for (int w = 2; w >= 1; --w) {
+        const int n = w == 2 ? h->n_w2 : h->n_w1;
+        if (n == 0) continue;
+        const int first = w == 2 ? 0 : h->nslots - h->n_w1;
+        const int seg_rows = w == 2 ? 2 * h->naux : h->naux;
+        const int K = n * seg_rows;
+        const double *X0 = h->slot_planes(first, 0);
+        int rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X0 + row_lo, np, X0, np, out, np, seg_rows, slot_stride,
+                                         slot_stride, -1, -1);
+        if (rc) return rc;
+        if (h->spin == 2) {
+            const double *X1 = h->slot_planes(first, 1);
+            rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X0 + row_lo, np, X1, np, out + blk, np, seg_rows, slot_stride,
+                                         slot_stride, -1, -1);
+            if (rc) return rc;
+            rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X1 + row_lo, np, X1, np, out + 2 * blk, np, seg_rows,
+                                         slot_stride, slot_stride, -1, -1);
+            if (rc) return rc;
+        }
+    }
+    return DMK_OK;
+}
+
+int dmk_eri_stack_clear(dmk_eri *h) {
+    if (!h) return DMK_ERR_INVALID;
+    if (h->cur_kL >= 0) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_stack_clear: a kL is in progress");
+    h->n_w2 = h->n_w1 = 0;
+    return DMK_OK;
+}
+
+int dmk_eri_stack_free_slots(const dmk_eri *h, int *free_slots) {
+    if (!h || !free_slots) return DMK_ERR_INVALID;
+    *free_slots = h->nslots > 1 ? h->nslots - h->n_w2 - h->n_w1 : 0;
+    return DMK_OK;
+}
+
 int dmk_eri_bands(const dmk_eri *h, int *nbands, int *band_rows) {
     if (!h || !nbands) return DMK_ERR_INVALID;
     *nbands = (int)((h->npair + 127) / 128);

@@ -701,7 +701,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
 int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group, double *w,
                 void *Vt, int v_real) {
     if (n <= 0 || batch <= 0) return DMK_OK;
-    if (n > 1024) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh: n = %d exceeds the supported maximum of 1024", n);
+    // one workgroup per matrix: the LDS carve (80 n bytes) and the per-lane column slices (64 R columns) bound n
+    if (n > 2000) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh: n = %d exceeds the supported maximum of 2000", n);
     const size_t nn = (size_t)n * n;
     const size_t per = nn * (16 + 16 + 8 + 56) + (size_t)n * (8 + 8 + 16);
     const size_t total = per * batch + 256;
@@ -734,7 +735,8 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
         const bool few = batch <= 256;
         const void *fn = n <= 64 ? (few ? reinterpret_cast<const void *>(eigh_kernel<1, 4>) : reinterpret_cast<const void *>(eigh_kernel<1, 2>))
                          : n <= 256 ? (few ? reinterpret_cast<const void *>(eigh_kernel<4, 4>) : reinterpret_cast<const void *>(eigh_kernel<4, 2>))
-                                    : reinterpret_cast<const void *>(eigh_kernel<16, 2>);
+                         : n <= 1024 ? reinterpret_cast<const void *>(eigh_kernel<16, 2>)
+                                     : reinterpret_cast<const void *>(eigh_kernel<32, 2>);
         if (lds > 48 * 1024) DMK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n <= 64) {
             if (few) hipLaunchKernelGGL((eigh_kernel<1, 4>), dim3(batch), dim3(NT), lds, ctx->stream, g);
@@ -742,8 +744,10 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
         } else if (n <= 256) {
             if (few) hipLaunchKernelGGL((eigh_kernel<4, 4>), dim3(batch), dim3(NT), lds, ctx->stream, g);
             else hipLaunchKernelGGL((eigh_kernel<4, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
-        } else {
+        } else if (n <= 1024) {
             hipLaunchKernelGGL((eigh_kernel<16, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
+        } else {
+            hipLaunchKernelGGL((eigh_kernel<32, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
         }
         DMK_CHECK_LAUNCH(ctx);
     }

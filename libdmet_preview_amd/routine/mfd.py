@@ -48,39 +48,84 @@ def _vt_to_ev(ctx, d_Vt, n, batch):
     return d_ev
 
 
+def _vcor_is_per_k(vcor):
+    """A correlation potential whose value depends on the k-point (routine/vcor.py:36-47: `value.ndim == 4`, set up by
+    VcorKpoints with `is_vcor_kpts`) or is complex: it cannot ride along as the kernel's shared real shift."""
+    if vcor is None:
+        return False
+    if getattr(vcor, "is_vcor_kpts", False) or np.ndim(getattr(vcor, "value", 0)) == 4:
+        return True
+    v = np.asarray(vcor.get(0, True))
+    return bool(np.iscomplexobj(v) and max_abs(v.imag) > 0.0)
+
+
 def _vcor_mat(vcor, nspin_needed):
-    """vcor.get(i, True): one (2|3, nlo, nlo) matrix for every k (routine/vcor.py:36-47)."""
+    """vcor.get(i, True) of a LOCAL real potential: one (2|3, nlo, nlo) matrix for every k (routine/vcor.py:36-47), added
+    inside the eigensolver as its shared real shift."""
     if vcor is None:
         return None
     v = np.asarray(vcor.get(0, True))
     if v.ndim == 2:
         v = v[None]
-    if np.iscomplexobj(v) and max_abs(v.imag) > 0.0:
-        raise NotImplementedError("complex correlation potential: the batched eigensolver adds a real k-independent shift")
     return np.ascontiguousarray(v[:nspin_needed].real, dtype=np.float64)
 
 
+def _fock_plus_vcor(Fock, vcor, spin):
+    """(Fock batch to upload, shared real shift or None).  Local real potentials stay separate (the kernel adds them, the
+    resident Fock batch is never rewritten); k-dependent or complex ones are added on the host before the upload, block
+    by block like the reference's `Fock[s, i] + vcor.get(i, True)[s]` (mfd.py:42-45, 77-83)."""
+    if not _vcor_is_per_k(vcor):
+        return Fock, _vcor_mat(vcor, spin)
+    F = np.array(Fock, dtype=np.complex128, copy=True)
+    for k in range(F.shape[1]):
+        vk = np.asarray(vcor.get(k, True))
+        if vk.ndim == 2:
+            vk = vk[None]
+        for s_ in range(spin):
+            F[s_, k] += vk[min(s_, vk.shape[0] - 1)] if spin == 1 else vk[s_]
+    return F, None
+
+
+def _pair_plan(neg):
+    """k / -k symmetry of the *_symm variants (mfd.py:56-66): the later member of a +-k pair is NOT diagonalised, it
+    inherits ew(-k) and conj(ev(-k)).  Returns (reps, src, inherits): the k that are diagonalised (in order), for every k
+    the position of its source in `reps`, and whether it inherits."""
+    reps, pos, src, inherits = [], {}, [], []
+    for k in range(len(neg)):
+        mk = int(neg[k])
+        if mk in pos:
+            src.append(pos[mk])
+            inherits.append(True)
+        else:
+            pos[k] = len(reps)
+            reps.append(k)
+            src.append(pos[k])
+            inherits.append(False)
+    return reps, np.asarray(src), np.asarray(inherits)
+
+
 def _diag(Fock, vcor, spin, symm_neg=None):
-    """Shared body of Diag*: returns ew (spin, nk, n), ev (spin, nk, n, n) as numpy (reference layout)."""
+    """Shared body of Diag*: returns ew (spin, nk, n), ev (spin, nk, n, n) as numpy (reference layout).  With `symm_neg`
+    only one member of every +-k pair goes to the device (half the eigenproblems, like the reference)."""
     ctx = get_ctx()
     Fock = np.asarray(Fock)
     nk, n = Fock.shape[-3], Fock.shape[-1]
-    d_F = ctx.to_device(Fock.reshape(spin * nk, n, n), np.complex128)
-    v = _vcor_mat(vcor, spin)
+    if symm_neg is None:
+        reps, src, inherits = list(range(nk)), np.arange(nk), np.zeros(nk, dtype=bool)
+    else:
+        reps, src, inherits = _pair_plan(symm_neg)
+    nrep = len(reps)
+    Fock, v = _fock_plus_vcor(Fock, vcor, spin)
+    Frep = Fock if nrep == nk else Fock[:, reps]
+    d_F = ctx.to_device(np.ascontiguousarray(Frep).reshape(spin * nrep, n, n), np.complex128)
     d_add = ctx.to_device(v) if v is not None else None
-    d_w, d_Vt = eigh_dev(ctx, d_F, n, spin * nk, d_add, nk)
-    ew = d_w.get().reshape(spin, nk, n)
-    ev = _vt_to_ev(ctx, d_Vt, n, spin * nk).get().reshape(spin, nk, n, n)
-    if symm_neg is not None:
-        # k / -k symmetry of the reference: the later member of a pair takes the conjugate (mfd.py:56-66)
-        computed = set()
-        for i in range(nk):
-            ni = int(symm_neg[i])
-            if ni in computed:
-                ew[:, i] = ew[:, ni]
-                ev[:, i] = ev[:, ni].conj()
-            else:
-                computed.add(i)
+    d_w, d_Vt = eigh_dev(ctx, d_F, n, spin * nrep, d_add, nrep)
+    ew = d_w.get().reshape(spin, nrep, n)
+    ev = _vt_to_ev(ctx, d_Vt, n, spin * nrep).get().reshape(spin, nrep, n, n)
+    if nrep == nk:
+        return ew, ev
+    ew, ev = ew[:, src], ev[:, src]
+    ev[:, inherits] = ev[:, inherits].conj()
     return ew, ev
 
 
@@ -120,19 +165,20 @@ def _diag_nambu(A, add, symm_lattice=None):
     """Batched eigh of (nk, m, m) complex matrices + one real (m, m) shift shared by all k; lower triangle only."""
     ctx = get_ctx()
     nk, m = A.shape[0], A.shape[-1]
-    d_A = ctx.to_device(A, np.complex128)
+    if symm_lattice is None:
+        reps, src, inherits = list(range(nk)), np.arange(nk), np.zeros(nk, dtype=bool)
+    else:
+        reps, src, inherits = _pair_plan([symm_lattice.cell_pos2idx(-symm_lattice.cell_idx2pos(i)) for i in range(nk)])
+    nrep = len(reps)
+    d_A = ctx.to_device(np.ascontiguousarray(A if nrep == nk else A[reps]), np.complex128)
     d_add = ctx.to_device(add[None], np.float64)
-    d_w, d_Vt = eigh_dev(ctx, d_A, m, nk, d_add, nk)
-    ew = d_w.get().reshape(nk, m)
-    ev = _vt_to_ev(ctx, d_Vt, m, nk).get().reshape(nk, m, m)
-    if symm_lattice is not None:
-        computed = set()
-        for i in range(nk):
-            ni = symm_lattice.cell_pos2idx(-symm_lattice.cell_idx2pos(i))
-            if ni in computed:
-                ew[i], ev[i] = ew[ni], ev[ni].conj()
-            else:
-                computed.add(i)
+    d_w, d_Vt = eigh_dev(ctx, d_A, m, nrep, d_add, nrep)
+    ew = d_w.get().reshape(nrep, m)
+    ev = _vt_to_ev(ctx, d_Vt, m, nrep).get().reshape(nrep, m, m)
+    if nrep == nk:
+        return ew, ev
+    ew, ev = ew[src], ev[src]
+    ev[inherits] = ev[inherits].conj()
     return ew, ev
 
 
@@ -353,15 +399,25 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
     nfrac = kwargs.get("nfrac", None)
     ctx = get_ctx()
 
-    # ---- all (s, k) eigenproblems in one launch; eigenvectors stay on the device ----------------------------------
-    d_F = ctx.to_device(Fock.reshape(spin * nkpts, n, n), np.complex128)
-    v = _vcor_mat(vcor, spin)
-    d_w, d_Vt = eigh_dev(ctx, d_F, n, spin * nkpts, ctx.to_device(v) if v is not None else None, nkpts)
+    # ---- all (s, k) eigenproblems in one launch; eigenvectors stay on the device.  symm: only ONE member of every +-k pair
+    #      is diagonalised (mfd.py:56-66); the later member takes ew(-k) and, further down, rho(k) = rho(-k)^T, ev(k) = conj ev(-k)
     inherit = _later_pair_members(lattice, nkpts) if symm else []
-    for (k, mk) in inherit:                         # ew(k) := ew(-k) for the later member of each pair
-        for s in range(spin):
-            ctx.check(lib.dmk_memcpy_d2d(ctx.h, d_w.offset((s * nkpts + k) * n, (n,)).ptr,
-                                         d_w.offset((s * nkpts + mk) * n, (n,)).ptr, n * 8))
+    if inherit:
+        reps, src, _ = _pair_plan([lattice.cell_pos2idx(-lattice.cell_idx2pos(k)) for k in range(nkpts)])
+    else:
+        reps, src = list(range(nkpts)), np.arange(nkpts)
+    nrep = len(reps)
+    full_of_rep = np.asarray([s_ * nrep + int(src[k]) for s_ in range(spin) for k in range(nkpts)], dtype=np.int32)
+    Fock_v, v = _fock_plus_vcor(Fock, vcor, spin)
+    Frep = Fock_v if nrep == nkpts else np.ascontiguousarray(Fock_v[:, reps])
+    d_F = ctx.to_device(np.ascontiguousarray(Frep).reshape(spin * nrep, n, n), np.complex128)
+    d_w_rep, d_Vt = eigh_dev(ctx, d_F, n, spin * nrep, ctx.to_device(v) if v is not None else None, nrep)
+    if nrep == nkpts:
+        d_w = d_w_rep
+    else:
+        d_src = ctx.to_device(full_of_rep)
+        d_w = ctx.empty((spin * nkpts, n), np.float64)
+        ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nkpts, n, d_src.ptr, d_w_rep.ptr, d_w.ptr, 0))
     ew = d_w.get().reshape(spin, nkpts, n)
 
     # ---- occupations on the device ----------------------------------------------------------------------------------
@@ -393,7 +449,15 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
         ewocc = d_occ.get().reshape(spin, nkpts, n)
 
     # ---- rho_k = (ev occ) ev^H, rhoT = k2R(rho_k) ----------------------------------------------------------------------
-    d_rho = density_dev(ctx, d_Vt, d_occ, n, spin * nkpts)
+    if nrep == nkpts:
+        d_rho = density_dev(ctx, d_Vt, d_occ, n, spin * nkpts)
+    else:
+        rep_rows = ctx.to_device(np.asarray([s_ * nkpts + k for s_ in range(spin) for k in reps], dtype=np.int32))
+        d_occ_rep = ctx.empty((spin * nrep, n), np.float64)
+        ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nrep, n, rep_rows.ptr, d_occ.ptr, d_occ_rep.ptr, 0))
+        d_rho_rep = density_dev(ctx, d_Vt, d_occ_rep, n, spin * nrep)
+        d_rho = ctx.empty((spin * nkpts, n, n), np.complex128)
+        ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nkpts, 2 * n * n, d_src.ptr, d_rho_rep.ptr, d_rho.ptr, 0))
     for (k, mk) in inherit:
         # ev(k) = conj(ev(-k)) and equal occupations: rho(k) = conj(rho(-k)) = rho(-k)^T (rho is Hermitian)
         for s in range(spin):
@@ -413,7 +477,15 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
     weight = 1.0 if spin == 1 else 0.5
     E0 = weight * np.sum((FockT + H1T) * rhoT) + lattice.getH0()
     E = E0
-    if vcor is not None:
+    if vcor is not None and getattr(vcor, "is_vcor_kpts", False):
+        # k-dependent potential: sum_k tr(v_k rho_k) (mfd.py:372-392)
+        rho_k_host = d_rho.get().reshape(spin, nkpts, n, n)
+        vcor_k = np.array([vcor.get(i, kspace=True) for i in range(nkpts)]).transpose(1, 0, 2, 3)
+        E = E0 + weight * np.einsum("skpq,skqp->", vcor_k[:spin], rho_k_host)
+    elif vcor is not None and not vcor.islocal():
+        vcorT = np.array([vcor.get(i, kspace=False) for i in range(nkpts)])
+        E = E0 + weight * sum(np.sum(vcorT[:, s] * rhoT[s]) for s in range(spin))
+    elif vcor is not None:
         vcorT = np.asarray(vcor.get(0, kspace=False))
         E = E0 + weight * sum(np.sum(vcorT[s] * rhoT[s, 0]) for s in range(spin))
     if max_abs(np.imag(E)) > IMAG_DISCARD_TOL:
@@ -422,7 +494,9 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
     if not ires:
         return rhoT, mu, E
 
-    ev = _vt_to_ev(ctx, d_Vt, n, spin * nkpts).get().reshape(spin, nkpts, n, n)
+    ev = _vt_to_ev(ctx, d_Vt, n, spin * nrep).get().reshape(spin, nrep, n, n)
+    if nrep != nkpts:
+        ev = ev[:, src]
     for (k, mk) in inherit:
         ev[:, k] = ev[:, mk].conj()
     if _is_seq(mu):

@@ -29,14 +29,40 @@ def _task_location(n, task=None, size=None):
     return loc0, loc0 + each + (1 if task < extra else 0)
 
 
-def get_kpairs_kidx(cell, kpts, tol=KPT_DIFF_TOL):
-    """[(i, j) | (i,)] with k_j = -k_i (i < j) in visiting order and the irreducible indices (mfd_mpi.py:33-54)."""
+def _minus_partner(cell, kpts, tol):
+    """partner[i] = position in the caller's list of -k_i (i itself at a time-reversal invariant point, -1 if the list
+    holds no such point).  The np.fft mesh and any permutation of it go through the integer mesh tables of libdmetk; any
+    other list (shifted meshes, subsets) through a tolerance search on the scaled coordinates."""
+    nk = len(kpts)
     kmesh, perm = _mesh_and_perm(cell, kpts, tol)
-    if perm is not None:
-        raise NotImplementedError("k-points must be in np.fft mesh order")
-    _, minus_k, w = fourier.kmesh_tables(kmesh)
-    kidx = np.where(w > 0)[0]
-    kpairs = [(int(i),) if int(minus_k[i]) == int(i) else (int(i), int(minus_k[i])) for i in kidx]
+    if kmesh is not None:
+        _, minus_k, _ = fourier.kmesh_tables(kmesh)
+        perm = np.arange(nk) if perm is None else np.asarray(perm)
+        where = np.empty(nk, dtype=int)
+        where[perm] = np.arange(nk)
+        return where[np.asarray(minus_k)[perm]]
+    ks = np.asarray(cell.get_scaled_kpts(kpts), dtype=float).reshape(nk, -1)
+    tot = ks[:, None, :] + ks[None, :, :]
+    hit = np.abs(tot - np.round(tot)).max(axis=2) < tol
+    return np.where(hit.any(axis=1), hit.argmax(axis=1), -1)
+
+
+def get_kpairs_kidx(cell, kpts, tol=KPT_DIFF_TOL):
+    """[(i, j) | (i,)] with k_j = -k_i (i < j) in visiting order and the irreducible indices (mfd_mpi.py:33-54), for any
+    ordering of the k list: a point is paired with its partner the first time either of them is visited."""
+    partner = _minus_partner(cell, kpts, tol)
+    taken = np.zeros(len(partner), dtype=bool)
+    kpairs = []
+    for i, j in enumerate(partner):
+        if taken[i]:
+            continue
+        taken[i] = True
+        if j > i and not taken[j]:
+            taken[j] = True
+            kpairs.append((int(i), int(j)))
+        else:
+            kpairs.append((int(i),))
+    kidx = np.asarray([p[0] for p in kpairs])
     return kpairs, kidx
 
 

@@ -140,8 +140,9 @@ def _get_emb_basis_eig(lattice, rdm1, **kwargs):
     if rdm1.ndim == 3:
         rdm1 = rdm1[np.newaxis]
     spin = rdm1.shape[0]
-    if nenv > 1024:
-        raise NotImplementedError("eig bath: env dimension %d exceeds the batched eigensolver limit" % nenv)
+    if nenv > 2000:
+        raise NotImplementedError("eig bath: env dimension %d exceeds the eigensolver limit of 2000 (one workgroup per matrix); "
+                                  "use the SVD flavour (kind='svd', the reference's default), which has no limit" % nenv)
     env_env = lattice.expand(rdm1)[:, env_idx][:, :, env_idx]
     ctx = get_ctx()
     d_A = ctx.to_device(env_env, np.float64)

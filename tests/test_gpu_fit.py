@@ -296,3 +296,45 @@ def test_eigh_jacobi_rejects(ctx):
         ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, 600, 1, d.ptr, None, d.ptr, d.ptr, None))
     with pytest.raises(DmkError):
         ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, 64, 200, d.ptr, None, d.ptr, d.ptr, None))
+
+
+def test_fit_c5_shape_objective_and_gradient_vs_oracle(ctx):
+    """The vcor fit at the C5 embedding shape (nlo 200, 56 valence orbitals -> nemb 256, UHF, VcorLocal on the valence
+    orbitals: 3192 parameters, dV_dparam 1.68 GB) on a small k-mesh: objective and analytic gradient of the device fit
+    against oracle/restate_fit.py at seeded parameter vectors.  bench.py measures this fit at the same shape; G9 pins only
+    small cases.  reference: routine/slater.py:1040-1154 (errfunc, gradfunc), :851-907 (get_dV_dparam)."""
+    from libdmet_preview_amd import pipeline
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.dmet import Hubbard
+    from libdmet_preview_amd.system.lattice import Lattice
+    mesh, nlo, nval, spin = (2, 2, 1), 200, 56, 2
+    sysm = pipeline.SyntheticSystem(ctx, mesh, nlo, 0, nval, spin, seed=5, name="fitC5")
+    d_rhoR, mf = pipeline.mean_field_stage(ctx, sysm)
+    d_basis, nemb, _ = pipeline.bath_stage(ctx, sysm, d_rhoR)
+    assert nemb == 256
+    nk = sysm.nk
+    basis = d_basis.get().reshape(spin, nk, nlo, nemb)
+    Fk = sysm.d_Fock_k.get().reshape(spin, nk, nlo, nlo)
+    Sk = np.asarray([np.eye(nlo)] * nk)
+    L = Lattice(nlo, mesh)
+    L.val_idx, L.virt_idx, L.core_idx = list(range(nval)), list(range(nval, nlo)), []
+    L.fock_lo_k = L.hcore_lo_k = Fk
+    rng = np.random.default_rng(9)
+    v = Hubbard.VcorLocal(False, False, nlo, idx_range=list(range(nval)))
+    assert v.length() == 3192
+    bk = R.R2k(basis, mesh)
+    rdm1_emb = np.asarray([np.einsum("kpa,kpq,kqb->ab", bk[s].conj(), R.R2k(d_rhoR.get().reshape(spin, nk, nlo, nlo), mesh)[s], bk[s]).real / nk
+                           for s in range(spin)])
+    ne = [int(round(np.trace(rdm1_emb[s]))) for s in range(spin)]
+    noise = 0.02 * rng.standard_normal(rdm1_emb.shape)
+    target = rdm1_emb + 0.5 * (noise + noise.transpose(0, 2, 1))
+    fit = slater.EmbFitDevice(ctx, target, L, basis, v, np.inf, ne, list(range(nemb)), [], Fk, Sk)
+    ov = F.VcorLocal(False, False, nlo, idx_range=list(range(nval)))
+    ref = F.EmbFit(target, mesh, basis, ov, np.inf, Fk, Sk, ne)
+    assert np.abs(fit.d_dV.get().reshape(ref.dV.shape) - ref.dV).max() < 1e-12
+    for scale in (0.0, 0.03):
+        p = scale * rng.standard_normal(3192)
+        e, e_ref = fit.errfunc(p), ref.errfunc(p)
+        assert abs(e - e_ref) < 1e-10, (scale, e, e_ref)
+        gq, g_ref = fit.gradfunc(p), ref.gradfunc(p)
+        assert np.abs(gq - g_ref).max() < 1e-8 * max(1.0, np.abs(g_ref).max()), (scale, np.abs(gq - g_ref).max())

@@ -234,6 +234,20 @@ def test_eri_outcore_matches_incore(ctx, golden, tmp_path):
     inc = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis)
     out = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, incore=False, fout=str(tmp_path / "H2"))
     assert np.abs(np.asarray(out["ccdd"]) - inc[[0, 2, 1]]).max() < 1e-12      # (aa, bb, ab) on disk
+    # slab by slab like the reference (eri_transform.py:486-521; its own test shrinks ERI_SLICE, test_eri_transform_gdf.py:62),
+    # with a plane stack of two slots so that the slabs are accumulated over several flushes
+    old = et.ERI_SLICE, et.OUTCORE_MAX_SLOTS
+    try:
+        et.ERI_SLICE, et.OUTCORE_MAX_SLOTS = 4, 2
+        out2 = et.get_emb_eri(cell, mydf, C_ao_lo=C, basis=basis, incore=False, fout=str(tmp_path / "H2b.npy"))
+        assert np.abs(np.asarray(out2["ccdd"]) - inc[[0, 2, 1]]).max() < 1e-12
+        mesh1, cell1, mydf1, st1 = _g6_setup(g, "mid221", 1)
+        inc1 = et.get_emb_eri(cell1, mydf1, C_ao_lo=g[st1 + "/C_ao_lo"], basis=g[st1 + "/basis"])
+        out1 = et.get_emb_eri(cell1, mydf1, C_ao_lo=g[st1 + "/C_ao_lo"], basis=g[st1 + "/basis"], incore=False,
+                              fout=str(tmp_path / "H2c"))
+        assert np.asarray(out1["ccdd"]).shape == inc1.shape and np.abs(np.asarray(out1["ccdd"]) - inc1).max() < 1e-12 * max(1.0, np.abs(inc1).max())
+    finally:
+        et.ERI_SLICE, et.OUTCORE_MAX_SLOTS = old
 
 
 def test_eri_sharded_sum(ctx, golden):
@@ -417,6 +431,24 @@ def test_eigh_clustered_tridiagonal(ctx, inject, monkeypatch):
         assert np.abs(T @ V - V * w).max() < 1e-12 * scale * max(1, n / 10)
 
 
+def test_eigh_above_1024(ctx):
+    """One real symmetric 1100 x 1100 matrix: the R = 32 column-slice variant behind the eig-flavoured bath of larger
+    model lattices (routine/slater.py:224-318 has no size limit; here n <= 2000, one workgroup per matrix)."""
+    from libdmet_preview_amd._lib import lib
+    n = 1100
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((n, n))
+    A = A + A.T
+    dA = ctx.to_device(A[None])
+    dw, dV = ctx.empty((1, n), np.float64), ctx.empty((1, n, n), np.float64)
+    ctx.check(lib.dmk_eigh_batched_real(ctx.h, n, 1, dA.ptr, dw.ptr, dV.ptr))
+    w, V = dw.get()[0], dV.get()[0].T
+    wr = np.linalg.eigvalsh(A)
+    assert np.abs(w - wr).max() < 1e-11 * np.abs(wr).max()
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-11
+    assert np.abs(A @ V - V * w).max() < 1e-10 * np.abs(wr).max()
+
+
 def test_eigh_reports_garbage(ctx):
     """A NaN in the input must surface as an error, not as a silently wrong basis."""
     from libdmet_preview_amd.routine import mfd
@@ -454,6 +486,52 @@ def test_Diag_wrappers_vs_oracle(ctx):
     assert np.abs(ew4 - R.DiagRHF_symm(Fk[0], None, mesh)[0]).max() < 1e-12
     ew5, _ = mfd.DiagUHF(Fk[0], None)                            # 3-d Fock promoted to two identical spins
     assert np.abs(ew5[0] - ew5[1]).max() == 0.0
+
+
+class _VcorK(object):
+    """k-dependent Hermitian correlation potential (routine/vcor.py:36-47: value.ndim == 4)."""
+    def __init__(self, value):
+        self.value, self.is_vcor_kpts = value, True
+
+    def islocal(self):
+        return False
+
+    is_local = islocal
+
+    def get(self, i=0, kspace=True):
+        return self.value[i]
+
+
+def test_k_dependent_complex_vcor(ctx):
+    """vcor.get(k, True) differing from k to k and complex Hermitian (reference: mfd.py:42-45, 77-83 add it per block; the
+    energy uses sum_k tr(v_k rho_k), mfd.py:372-392): added to the Fock batch before the upload."""
+    from libdmet_preview_amd.routine import mfd
+    mesh, nlo, spin = (3, 2, 1), 6, 2
+    nk = 6
+    FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=31)
+    Fk = R.R2k(FR, mesh)
+    rng = np.random.default_rng(5)
+    vR = 0.2 * synth.make_fock_R(mesh, nlo, spin=spin, seed=32)
+    vk = R.R2k(vR, mesh).transpose(1, 0, 2, 3)                     # (nk, spin, n, n): Hermitian, TR symmetric, complex
+    vc = _VcorK(np.ascontiguousarray(vk))
+    ew, ev = mfd.DiagUHF(Fk, vc)
+    for s in range(spin):
+        for k in range(nk):
+            H = Fk[s, k] + vk[k, s]
+            assert np.abs(ew[s, k] - np.linalg.eigvalsh(H)).max() < 1e-12
+            assert np.abs(H @ ev[s, k] - ev[s, k] * ew[s, k]).max() < 1e-11
+    L = _lattice(mesh, nlo)
+    L.set_Ham_lo(fock_lo_R=FR, hcore_lo_R=FR)
+    ew2, _ = mfd.DiagUHF_symm(Fk, vc, L)
+    assert np.abs(ew2 - ew).max() < 1e-12
+    rhoT, mu, E, res = mfd.HF(L, vc, 0.5, False, ires=True)
+    rho_k = res["rho_k"]
+    E0 = 0.5 * np.sum((FR + FR) * rhoT)
+    assert abs(res["E0"] - E0) < 1e-10
+    assert abs(E - (E0 + 0.5 * np.einsum("kspq,skqp->", vk, rho_k)).real) < 1e-10
+    for s in range(spin):
+        for k in range(nk):
+            assert np.abs(np.linalg.eigvalsh(rho_k[s, k]).round(8) % 1.0).max() < 1e-7       # projector at T = 0
 
 
 G3_CASES = ["rhf_611", "rhf_661", "uhf_411", "uhf_222_T", "rhf_331_T", "uhf_231_sz", "rhf_444"]
@@ -883,9 +961,18 @@ def test_G15_eri_general_k_lists(ctx, golden, case, spin):
         e = et.get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=g[st + "/C_ao_lo"], basis=g[st + "/basis"], t_reversal_symm=tr,
                                     kscaled_center=center)
         ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+        # |eri| reaches ~1e6 in this fixture, so 1e-10 RELATIVE is ~1e-4 absolute -- all that f64 accumulation in a different
+        # order can give at that magnitude; the north star's 1e-8 is an ABSOLUTE bound on O(1) integrals, checked below on
+        # the same problem rescaled to max |eri| = 1 (the transform is quadratic in the DF tensor)
         assert e.shape == ref.shape and np.abs(e - ref).max() < 1e-10 * np.abs(ref).max(), (tr, np.abs(e - ref).max())
         if not tr:
             im_ref = float(g[st + "/imag_norm"])
             assert abs(et.get_emb_eri_fast_gdf.last_imag_norm - im_ref) < 1e-10 * im_ref
+        if tr:
+            top = np.abs(ref).max()
+            unit_df = et.GDFMemory(cell.get_abs_kpts(ks), {ij: b / np.sqrt(top) for ij, b in blocks.items()}, naux=naux, cell=cell)
+            e1 = et.get_emb_eri_fast_gdf(cell, unit_df, C_ao_lo=g[st + "/C_ao_lo"], basis=g[st + "/basis"], t_reversal_symm=True,
+                                         kscaled_center=center)
+            assert np.abs(e1 - ref / top).max() < 1e-8
     # the canonical mesh keeps its (zero) imaginary part: physical blocks, TR-symmetric orbitals
     assert np.array_equal(et.get_weights_t_reversal(cell, cell.get_abs_kpts(ks)), R.get_weights_t_reversal(ks))

@@ -192,3 +192,20 @@ def test_weights_t_reversal_general_lists():
     for ks in (ks0, ks0[perm], ks0 + np.array([0.25, 0.0, 0.0])):
         got = et.get_weights_t_reversal(cell, cell.get_abs_kpts(ks))
         assert np.array_equal(got, R.get_weights_t_reversal(ks))
+
+
+@pytest.mark.parametrize("mesh", [(4, 4, 3), (3, 2, 1), (5, 1, 1), (2, 2, 2)])
+def test_kpairs_any_k_order(mesh):
+    """get_kpairs_kidx is order agnostic like the reference's double loop (routine/mfd_mpi.py:33-54): permuted mesh lists go
+    through the integer tables, shifted meshes / arbitrary lists through the tolerance search; both must reproduce the
+    oracle's restatement of the reference loop."""
+    from oracle import restate as R
+    from libdmet_preview_amd.routine import mfd_mpi
+    cell = type("Cell", (), {"get_scaled_kpts": staticmethod(lambda k: np.asarray(k))})()
+    ks = R.make_kpts_scaled(mesh)
+    rng = np.random.default_rng(sum(mesh))
+    for perm, shift in [(np.arange(len(ks)), 0.0), (rng.permutation(len(ks)), 0.0), (rng.permutation(len(ks)), np.array([0.1, 0.0, 0.0]))]:
+        k2 = ks[perm] + shift
+        kp, kidx = mfd_mpi.get_kpairs_kidx(cell, k2)
+        rp, ridx = R.get_kpairs_kidx(k2)
+        assert [tuple(int(y) for y in x) for x in rp] == kp and np.array_equal(kidx, ridx)
