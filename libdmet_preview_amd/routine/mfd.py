@@ -55,6 +55,8 @@ def _vcor_is_per_k(vcor):
         return False
     if getattr(vcor, "is_vcor_kpts", False) or np.ndim(getattr(vcor, "value", 0)) == 4:
         return True
+    if hasattr(vcor, "islocal") and not vcor.islocal():          # real-space non-local: get(k, True) differs from k to k
+        return True
     v = np.asarray(vcor.get(0, True))
     return bool(np.iscomplexobj(v) and max_abs(v.imag) > 0.0)
 
@@ -379,8 +381,6 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
     log.eassert(beta >= 0, "beta cannot be negative")
     if scf:
         raise NotImplementedError("scf=True needs a PySCF KSCF object (out of scope of the HIP path)")
-    if vcor is not None and not vcor.islocal():
-        raise NotImplementedError("non-local vcor")
     if use_hcore is None:
         use_hcore = lattice.use_hcore_as_emb_ham
     H1T = lattice.getH1(kspace=False)
