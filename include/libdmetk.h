@@ -203,6 +203,10 @@ int dmk_transpose_c128(dmk_ctx *ctx, int rows, int cols, int batch, const void *
 int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1,
                  const int32_t *env_idx, int nenv, const int32_t *bath_col, int nb,
                  double *sigma, double *U);
+/* The same for `batch` matrices that share the index maps and differ in the density (the spin channels: rdm1 of member b at
+ * rdm1 + b * rdm1_stride; sigma batch x nb; U batch x nenv x nb): one chain of launches for all of them. */
+int dmk_bath_svd_batched(dmk_ctx *ctx, const int mesh[3], int nlo, int batch, const double *rdm1, int64_t rdm1_stride,
+                         const int32_t *env_idx, int nenv, const int32_t *bath_col, int nb, double *sigma, double *U);
 /* B = U[:, :nbath]; if orth: B[virt_mask] = 0; B = B (B^T B)^{-1/2} (eigenvalues
  * <= 1e-14 dropped); then basis[imp_idx, :nimp] = I and
  * basis[env_idx, nimp:nimp+nbath] = B, basis: (ncells*nlo) x ncol_basis f64 (zeroed here). */

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "dmk_assign_occ": (c_int, [c_vp, c_i64, c_vp, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_vp, P(c_dbl)]),
     "dmk_transpose_c128": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "dmk_bath_svd": (c_int, [c_vp, _int3, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "dmk_bath_svd_batched": (c_int, [c_vp, _int3, c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "dmk_bath_assemble": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "dmk_zgemm_batched": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64]),
     "dmk_eri_begin": (c_int, [c_vp, _int3, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, P(c_vp)]),

@@ -36,7 +36,9 @@ __device__ __forceinline__ double wave_sum(double v) { return dmk_wave_sum(v); }
 // A[r][c] = big[env_idx[r]][bath_col[c]],  big[(R1,p),(R2,q)] = rdm1[R1 - R2][p][q]
 __global__ void gather_env_imp_kernel(int n0, int n1, int n2, int nlo, const double *__restrict__ rdm1,
                                       const int *__restrict__ env_idx, int nenv, const int *__restrict__ bath_col,
-                                      int nb, double *__restrict__ A) {
+                                      int nb, double *__restrict__ A, long long rdm1_bstride = 0, long long A_bstride = 0) {
+    rdm1 += (long long)blockIdx.y * rdm1_bstride;             // batch (spin channel) = blockIdx.y
+    A += (long long)blockIdx.y * A_bstride;
     const long long total = (long long)nenv * nb;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
@@ -174,6 +176,7 @@ struct TsqrArgs {
     double *M;              // rows_total x nb: in = matrix, out = reflectors (unit diagonal implied) below / R on and above the diagonal
     double *tau;            // nodes x nb
     double *Rout;           // nodes x nb x nb, zero below the diagonal and beyond the node's rows (input of the next level)
+    long long bstride;      // elements between the workspaces of consecutive batch members (blockIdx.y): M, tau and Rout all live in it
 };
 
 __device__ __forceinline__ double lane_bcast(double v, int src) {      // src wave-uniform
@@ -205,8 +208,9 @@ __global__ __launch_bounds__(TS_NT) void tsqr_factor_kernel(const TsqrArgs g) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // uniform: keeps the owner tests scalar
     const int j = lane;
-    double *Mrows = g.M + (size_t)r0 * nb;
-    double *R = g.Rout + (size_t)node * nb * nb;
+    const long long boff = (long long)blockIdx.y * g.bstride;
+    double *Mrows = g.M + boff + (size_t)r0 * nb;
+    double *R = g.Rout + boff + (size_t)node * nb * nb;
     double a[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(TS_NT) void tsqr_factor_kernel(const TsqrArgs g) {
         if (r < m && j < nb) Mrows[(size_t)r * nb + j] = a[i];
         if (r < nb && j < nb) R[(size_t)r * nb + j] = 0.0;         // m < nb: rows of the R block beyond the node's rows
     }
-    for (int t = threadIdx.x; t < nb; t += TS_NT) g.tau[(size_t)node * nb + t] = taus[t];
+    for (int t = threadIdx.x; t < nb; t += TS_NT) g.tau[boff + (size_t)node * nb + t] = taus[t];
 }
 
 struct TsqrApplyArgs {
@@ -288,6 +292,8 @@ struct TsqrApplyArgs {
     const double *tau;      // nodes x nb
     const double *X;        // nodes x nb x nc: the node's input block (top rows of [X; 0])
     double *Y;              // rows_total x nc: Q_node [X; 0]; a tree level writes the X blocks of the level below, a leaf rows of U
+    long long bstride;      // batch stride of the workspace (V, tau, X and the tree levels' Y)
+    long long y_bstride;    // batch stride of Y (the leaf level writes U: nenv x nc per batch member)
 };
 
 // Y = H_0 H_1 ... H_{kmax-1} [X; 0] for one node, Y in registers (lane <-> column of Y, nc <= 64; slot i of wave w <-> row
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(TS_NT) void tsqr_apply_kernel(const TsqrApplyArgs g
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane;
-    const double *X = g.X + (size_t)node * nb * nc;
+    const long long boff = (long long)blockIdx.y * g.bstride;
+    const double *X = g.X + boff + (size_t)node * nb * nc;
     double y[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(TS_NT) void tsqr_apply_kernel(const TsqrApplyArgs g
     const int kmax = min(m, nb);
     const int myrow = wave + TS_NW * lane;                       // the row whose reflector entries this lane carries (lane < RPT)
     const bool carrier = lane < RPT && myrow < m;
-    const double *vcol = g.V + (size_t)(r0 + (carrier ? myrow : 0)) * nb;
+    const double *vcol = g.V + boff + (size_t)(r0 + (carrier ? myrow : 0)) * nb;
     double vnext = (carrier && kmax > 0) ? vcol[kmax - 1] : 0.0;
     int buf = 0;                                                 // toggles per EXECUTED step (skipped steps have no barrier)
     for (int k = kmax - 1; k >= 0; --k) {
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(TS_NT) void tsqr_apply_kernel(const TsqrApplyArgs g
         if (myrow == k) vmine = 1.0;
         if (myrow < k || !carrier) vmine = 0.0;
         if (k > 0) vnext = carrier ? vcol[k - 1] : 0.0;
-        const double tau = g.tau[(size_t)node * nb + k];
+        const double tau = g.tau[boff + (size_t)node * nb + k];
         if (tau == 0.0) continue;                               // uniform: H_k = I
         buf ^= 1;
         double acc = 0.0;
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(TS_NT) void tsqr_apply_kernel(const TsqrApplyArgs g
 #pragma unroll
         for (int i = 0; i < RPT; ++i) y[i] -= t * lane_bcast(vmine, i);
     }
-    double *Yrows = g.Y + (size_t)r0 * nc;
+    double *Yrows = g.Y + (long long)blockIdx.y * g.y_bstride + (size_t)r0 * nc;
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int r = wave + TS_NW * i;
@@ -449,7 +456,13 @@ __device__ __forceinline__ double jf_rsqrt(double x) {
 }
 __global__ __launch_bounds__(JF_NT) void jacobi_svd_fast_kernel(int nb, const double *__restrict__ A, int lda,
                                                                 double *__restrict__ sigma, double *__restrict__ Utop,
-                                                                int *__restrict__ status, int upper_only) {
+                                                                int *__restrict__ status, int upper_only,
+                                                                long long a_bstride = 0, long long u_bstride = 0) {
+    // batch member = blockIdx.x: its matrix, its nb singular values, its vectors, its two status ints
+    A += (long long)blockIdx.x * a_bstride;
+    Utop += (long long)blockIdx.x * u_bstride;
+    sigma += (long long)blockIdx.x * nb;
+    status += 2 * blockIdx.x;
     __shared__ double G[64 * 65];             // column-major, column stride 65: G[j * 65 + i] = R[i][j]
     __shared__ double nrm[64];
     __shared__ int s_rot;
@@ -727,7 +740,116 @@ int nblocks_for(int nrows) {
 
 }  // namespace
 
+
+
+// TSQR path of dmk_bath_svd for `batch` matrices (the spin channels) that share the index maps: every launch carries the batch
+// in a grid dimension, so the dependent chain of ~12 launches is paid once.  Returns 1 if handled, 0 if the caller must use the
+// column-at-a-time path, < 0 on error.
+static int bath_svd_tsqr(dmk_ctx *ctx, const int mesh[3], int nlo, int batch, const double *rdm1, long long rdm1_bstride,
+                         const int32_t *env_idx, int nenv, const int32_t *bath_col, int nb, double *sigma, double *U) {
+    static const bool tsqr_enabled = [] { const char *e = getenv("DMK_BATH_TSQR"); return !(e && atoi(e) == 0); }();
+    if (!tsqr_enabled || 4 * nb > TS_MAXROWS) return 0;
+    // ---- TSQR plan: leaves of m0 rows, then stacks of four R factors per node until one is left ----------------------
+    const int m0 = nenv <= TS_MAXROWS ? nenv : std::min(TS_MAXROWS, std::max(TS_FANIN * nb, (nenv + 255) / 256));
+    std::vector<int> nodes;                        // nodes[l] = workgroups of level l
+    nodes.push_back((nenv + m0 - 1) / m0);
+    while (nodes.back() > 1) nodes.push_back((nodes.back() + TS_FANIN - 1) / TS_FANIN);
+    const int L = (int)nodes.size();
+    size_t tot_nodes = 0;
+    for (int n : nodes) tot_nodes += (size_t)n;
+    // workspace per batch member (doubles): A | tau (all levels) | R stacks (output of every level) | X stacks (input of every
+    // level's apply); then 2 status ints per member
+    const size_t szA = (size_t)nenv * nb, szBlk = (size_t)nb * nb;
+    const size_t per = szA + tot_nodes * nb + 2 * tot_nodes * szBlk;
+    void *ws = nullptr;
+    int rc = dmk_scratch(ctx, (per * batch + 2 * (size_t)batch + 8) * sizeof(double), &ws);
+    if (rc) return rc;
+    double *A = reinterpret_cast<double *>(ws);
+    double *tau = A + szA;
+    double *Rst = tau + tot_nodes * nb;
+    double *Xst = Rst + tot_nodes * szBlk;
+    int *status = reinterpret_cast<int *>(A + per * batch);
+    std::vector<size_t> off(L + 1, 0);             // node offset of level l in tau / Rst / Xst
+    for (int l = 0; l < L; ++l) off[l + 1] = off[l] + (size_t)nodes[l];
+    DMK_HIP(ctx, hipMemsetAsync(status, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
+    {
+        long long total = (long long)nenv * nb;
+        int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(gather_env_imp_kernel, dim3(blocks, batch), dim3(256), 0, ctx->stream, mesh[0], mesh[1], mesh[2], nlo,
+                           rdm1, env_idx, nenv, bath_col, nb, A, rdm1_bstride, (long long)per);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    // up the tree: level l factors rows of (l == 0 ? A : the R stack written by level l - 1)
+    for (int l = 0; l < L; ++l) {
+        TsqrArgs a;
+        a.nb = nb;
+        a.rows_total = l == 0 ? nenv : nodes[l - 1] * nb;
+        a.rows_per_node = l == 0 ? m0 : TS_FANIN * nb;
+        a.M = l == 0 ? A : Rst + off[l - 1] * szBlk;
+        a.tau = tau + off[l] * nb;
+        a.Rout = Rst + off[l] * szBlk;
+        a.bstride = (long long)per;
+        const dim3 grid(nodes[l], batch);
+        // register tile: 2 / 4 / 8 / 16 / 32 rows per thread (16 ... 256 rows per node)
+        if (a.rows_per_node <= 64) hipLaunchKernelGGL(tsqr_factor_kernel<8>, grid, dim3(TS_NT), 0, ctx->stream, a);
+        else if (a.rows_per_node <= 128) hipLaunchKernelGGL(tsqr_factor_kernel<16>, grid, dim3(TS_NT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(tsqr_factor_kernel<32>, grid, dim3(TS_NT), 0, ctx->stream, a);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    // SVD of the root R; its left singular vectors are the root's X block
+    double *Rroot = Rst + off[L - 1] * szBlk, *Xroot = Xst + off[L - 1] * szBlk;
+    hipLaunchKernelGGL(jacobi_svd_fast_kernel, dim3(batch), dim3(JF_NT), 0, ctx->stream, nb, Rroot, nb, sigma, Xroot, status, 1,
+                       (long long)per, (long long)per);
+    DMK_CHECK_LAUNCH(ctx);
+    // down the tree: U = Q [U_r; 0]
+    for (int l = L - 1; l >= 0; --l) {
+        TsqrApplyArgs a;
+        a.nb = nb; a.nc = nb;
+        a.rows_total = l == 0 ? nenv : nodes[l - 1] * nb;
+        a.rows_per_node = l == 0 ? m0 : TS_FANIN * nb;
+        a.V = l == 0 ? A : Rst + off[l - 1] * szBlk;
+        a.tau = tau + off[l] * nb;
+        a.X = Xst + off[l] * szBlk;
+        a.Y = l == 0 ? U : Xst + off[l - 1] * szBlk;
+        a.bstride = (long long)per;
+        a.y_bstride = l == 0 ? (long long)szA : (long long)per;
+        const dim3 grid(nodes[l], batch);
+        if (a.rows_per_node <= 64) hipLaunchKernelGGL(tsqr_apply_kernel<8>, grid, dim3(TS_NT), 0, ctx->stream, a);
+        else if (a.rows_per_node <= 128) hipLaunchKernelGGL(tsqr_apply_kernel<16>, grid, dim3(TS_NT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(tsqr_apply_kernel<32>, grid, dim3(TS_NT), 0, ctx->stream, a);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    std::vector<int> st(2 * (size_t)batch, 0);
+    DMK_HIP(ctx, hipMemcpyAsync(st.data(), status, st.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < batch; ++b)
+        if (st[2 * b] != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "bath_svd: Jacobi SVD did not converge");
+    if (getenv("DMK_BATH_TIMING"))
+        fprintf(stderr, "[bath_svd %d x (%d x %d)] %d leaves of %d rows, %d levels, %d Jacobi sweeps\n", batch, nenv, nb, nodes[0], m0, L, st[1]);
+    return 1;
+}
+
 extern "C" {
+
+int dmk_bath_svd_batched(dmk_ctx *ctx, const int mesh[3], int nlo, int batch, const double *rdm1, int64_t rdm1_stride,
+                         const int32_t *env_idx, int nenv, const int32_t *bath_col, int nb, double *sigma, double *U) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!mesh || nlo <= 0 || batch <= 0 || !rdm1 || !env_idx || !bath_col || nenv <= 0 || nb <= 0 || !sigma || !U)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: bad arguments");
+    if (nb > 120) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: nb = %d exceeds the supported maximum of 120", nb);
+    if (nenv < nb) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: needs nenv >= nb (tall matrix)");
+    {
+        FamScope fs(ctx, DMK_FAM_BATH);
+        int rc = bath_svd_tsqr(ctx, mesh, nlo, batch, rdm1, (long long)rdm1_stride, env_idx, nenv, bath_col, nb, sigma, U);
+        if (rc != 0) return rc < 0 ? rc : DMK_OK;
+    }
+    for (int b = 0; b < batch; ++b) {
+        int rc = dmk_bath_svd(ctx, mesh, nlo, rdm1 + (size_t)b * rdm1_stride, env_idx, nenv, bath_col, nb, sigma + (size_t)b * nb,
+                              U + (size_t)b * nenv * nb);
+        if (rc) return rc;
+    }
+    return DMK_OK;
+}
 
 int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1, const int32_t *env_idx, int nenv,
                  const int32_t *bath_col, int nb, double *sigma, double *U) {
@@ -737,76 +859,9 @@ int dmk_bath_svd(dmk_ctx *ctx, const int mesh[3], int nlo, const double *rdm1, c
     if (nb > 120) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: nb = %d exceeds the supported maximum of 120", nb);
     if (nenv < nb) return dmk_fail(ctx, DMK_ERR_INVALID, "bath_svd: needs nenv >= nb (tall matrix)");
     FamScope fs(ctx, DMK_FAM_BATH);
-    static const bool tsqr_enabled = [] { const char *e = getenv("DMK_BATH_TSQR"); return !(e && atoi(e) == 0); }();
-    if (tsqr_enabled && 4 * nb <= TS_MAXROWS) {
-        // ---- TSQR plan: leaves of m0 rows, then stacks of four R factors per node until one is left ----------------------
-        const int m0 = nenv <= TS_MAXROWS ? nenv : std::min(TS_MAXROWS, std::max(TS_FANIN * nb, (nenv + 255) / 256));
-        std::vector<int> nodes;                        // nodes[l] = workgroups of level l
-        nodes.push_back((nenv + m0 - 1) / m0);
-        while (nodes.back() > 1) nodes.push_back((nodes.back() + TS_FANIN - 1) / TS_FANIN);
-        const int L = (int)nodes.size();
-        size_t tot_nodes = 0;
-        for (int n : nodes) tot_nodes += (size_t)n;
-        // workspace (doubles): A | tau (all levels) | R stacks (output of every level) | X stacks (input of every level's apply) | status
-        const size_t szA = (size_t)nenv * nb, szBlk = (size_t)nb * nb;
-        void *ws = nullptr;
-        int rc = dmk_scratch(ctx, (szA + tot_nodes * nb + 2 * tot_nodes * szBlk + 8) * sizeof(double), &ws);
-        if (rc) return rc;
-        double *A = reinterpret_cast<double *>(ws);
-        double *tau = A + szA;
-        double *Rst = tau + tot_nodes * nb;
-        double *Xst = Rst + tot_nodes * szBlk;
-        int *status = reinterpret_cast<int *>(Xst + tot_nodes * szBlk);
-        std::vector<size_t> off(L + 1, 0);             // node offset of level l in tau / Rst / Xst
-        for (int l = 0; l < L; ++l) off[l + 1] = off[l] + (size_t)nodes[l];
-        DMK_HIP(ctx, hipMemsetAsync(status, 0, 2 * sizeof(int), ctx->stream));
-        {
-            long long total = (long long)nenv * nb;
-            int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-            hipLaunchKernelGGL(gather_env_imp_kernel, dim3(blocks), dim3(256), 0, ctx->stream, mesh[0], mesh[1], mesh[2], nlo,
-                               rdm1, env_idx, nenv, bath_col, nb, A);
-            DMK_CHECK_LAUNCH(ctx);
-        }
-        // up the tree: level l factors rows of (l == 0 ? A : the R stack written by level l - 1)
-        for (int l = 0; l < L; ++l) {
-            TsqrArgs a;
-            a.nb = nb;
-            a.rows_total = l == 0 ? nenv : nodes[l - 1] * nb;
-            a.rows_per_node = l == 0 ? m0 : TS_FANIN * nb;
-            a.M = l == 0 ? A : Rst + off[l - 1] * szBlk;
-            a.tau = tau + off[l] * nb;
-            a.Rout = Rst + off[l] * szBlk;
-            // register tile: 8 / 16 / 32 rows per thread (64 / 128 / 256 rows per node)
-            if (a.rows_per_node <= 64) hipLaunchKernelGGL(tsqr_factor_kernel<8>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
-            else if (a.rows_per_node <= 128) hipLaunchKernelGGL(tsqr_factor_kernel<16>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
-            else hipLaunchKernelGGL(tsqr_factor_kernel<32>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
-            DMK_CHECK_LAUNCH(ctx);
-        }
-        // SVD of the root R; its left singular vectors are the root's X block
-        double *Rroot = Rst + off[L - 1] * szBlk, *Xroot = Xst + off[L - 1] * szBlk;
-        hipLaunchKernelGGL(jacobi_svd_fast_kernel, dim3(1), dim3(JF_NT), 0, ctx->stream, nb, Rroot, nb, sigma, Xroot, status, 1);
-        DMK_CHECK_LAUNCH(ctx);
-        // down the tree: U = Q [U_r; 0]
-        for (int l = L - 1; l >= 0; --l) {
-            TsqrApplyArgs a;
-            a.nb = nb; a.nc = nb;
-            a.rows_total = l == 0 ? nenv : nodes[l - 1] * nb;
-            a.rows_per_node = l == 0 ? m0 : TS_FANIN * nb;
-            a.V = l == 0 ? A : Rst + off[l - 1] * szBlk;
-            a.tau = tau + off[l] * nb;
-            a.X = Xst + off[l] * szBlk;
-            a.Y = l == 0 ? U : Xst + off[l - 1] * szBlk;
-            if (a.rows_per_node <= 64) hipLaunchKernelGGL(tsqr_apply_kernel<8>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
-            else if (a.rows_per_node <= 128) hipLaunchKernelGGL(tsqr_apply_kernel<16>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
-            else hipLaunchKernelGGL(tsqr_apply_kernel<32>, dim3(nodes[l]), dim3(TS_NT), 0, ctx->stream, a);
-            DMK_CHECK_LAUNCH(ctx);
-        }
-        int st[2] = {0, 0};
-        DMK_HIP(ctx, hipMemcpyAsync(st, status, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (st[0] != 0) return dmk_fail(ctx, DMK_ERR_NOCONV, "bath_svd: Jacobi SVD did not converge");
-        if (getenv("DMK_BATH_TIMING")) fprintf(stderr, "[bath_svd %d x %d] %d leaves of %d rows, %d levels, %d Jacobi sweeps\n", nenv, nb, nodes[0], m0, L, st[1]);
-        return DMK_OK;
+    {
+        int rc = bath_svd_tsqr(ctx, mesh, nlo, 1, rdm1, 0, env_idx, nenv, bath_col, nb, sigma, U);
+        if (rc != 0) return rc < 0 ? rc : DMK_OK;
     }
     // column-at-a-time Householder QR (nb > 64)
     // workspace: A (nenv x nb) | partial (MAXB x nb) | tau (nb) | rowk (nb) | Utop (nb x nb) | status

@@ -146,13 +146,13 @@ def bath_stage(ctx, sysm, d_rhoR, timers=None, tol_bath=1e-9):
     nb, nenv, nimp = sysm.nval, len(sysm.env_idx), n
     t = time.perf_counter()
     svd, sigmas, nbaths = [], [], []
+    # both spin channels through ONE chain of launches (TSQR tree, Jacobi SVD of the two root R factors side by side)
+    d_sigma, d_U_all = slater.bath_svd_batched_dev(ctx, sysm.mesh, n, d_rhoR, spin, sysm.d_env, nenv, sysm.d_col, nb)
+    sig_all = d_sigma.get()
     for s in range(spin):
-        d_sigma, d_U = slater.bath_svd_dev(ctx, sysm.mesh, n, d_rhoR.offset(s * nk * n * n, (nk, n, n)), sysm.d_env,
-                                           nenv, sysm.d_col, nb)
-        sig = d_sigma.get()
-        svd.append(d_U)
-        sigmas.append(sig)
-        nbaths.append(int((sig >= tol_bath).sum()))
+        svd.append(d_U_all.offset(s * nenv * nb, (nenv, nb)))
+        sigmas.append(sig_all[s])
+        nbaths.append(int((sig_all[s] >= tol_bath).sum()))
     nbath_final = min([nb] + nbaths)          # nbath_final seed: len(imp_idx_bath) or nlo (slater.py:171,175)
     nemb = nimp + nbath_final
     d_basis = ctx.empty((spin, nk * n, nemb), np.float64)

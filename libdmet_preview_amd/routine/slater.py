@@ -69,6 +69,15 @@ def bath_svd_dev(ctx, kmesh, nlo, d_rdm1_s, d_env, nenv, d_col, nb):
     return d_sigma, d_U
 
 
+def bath_svd_batched_dev(ctx, kmesh, nlo, d_rdm1, spin, d_env, nenv, d_col, nb):
+    """All spin channels in one chain of launches: d_rdm1 (spin, ncells, nlo, nlo) -> sigma (spin, nb), U (spin, nenv, nb)."""
+    d_sigma = ctx.empty((spin, nb), np.float64)
+    d_U = ctx.empty((spin, nenv, nb), np.float64)
+    ctx.check(lib.dmk_bath_svd_batched(ctx.h, mesh3(kmesh), int(nlo), int(spin), d_rdm1.ptr, int(d_rdm1.size // spin), d_env.ptr,
+                                       int(nenv), d_col.ptr, int(nb), d_sigma.ptr, d_U.ptr))
+    return d_sigma, d_U
+
+
 def bath_assemble_dev(ctx, d_U, nenv, nb, nbath, d_virt, orth, d_env, d_imp, nimp, nsites, ncol, d_basis):
     ctx.check(lib.dmk_bath_assemble(ctx.h, d_U.ptr, int(nenv), int(nb), int(nbath), d_virt.ptr, 1 if orth else 0,
                                     d_env.ptr, d_imp.ptr, int(nimp), int(nsites), int(ncol), d_basis.ptr))
@@ -106,10 +115,11 @@ def _get_emb_basis_svd(lattice, rdm1, **kwargs):
     d_imp = ctx.to_device(np.asarray(imp_idx), np.int32)
     d_rdm1 = ctx.to_device(rdm1, np.float64)
     basis = np.zeros((spin, nsites, ncol))
+    d_sigma_all, d_U_all = bath_svd_batched_dev(ctx, lattice.kmesh, nlo, d_rdm1, spin, d_env, nenv, d_col, nb)
+    sigma_all = d_sigma_all.get()
     for s in range(spin):
-        d_sigma, d_U = bath_svd_dev(ctx, lattice.kmesh, nlo, d_rdm1.offset(s * ncells * nlo * nlo, (ncells, nlo, nlo)),
-                                    d_env, nenv, d_col, nb)
-        sigma = d_sigma.get()
+        d_U = d_U_all.offset(s * nenv * nb, (nenv, nb))
+        sigma = sigma_all[s]
         nbath_s = int((sigma >= tol_bath).sum()) if nbath is None else int(nbath)
         nzero = int(np.sum(np.abs(sigma[:nbath_s]) < tol_bath))
         log.debug(0, "Zero singular values number: %s", nzero)
