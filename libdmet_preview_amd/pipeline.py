@@ -246,6 +246,18 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
     gen.errfunc(p_true)
     target = gen.d_rho.get().reshape(spin, nemb, nemb)
     del gen
+    # (1) the reference's own stopping rules (fit.py:59: gtol 1e-3, ytol 1e-7, dx_tol 1e-7): what a DMET iteration would pay
+    ctx.sync()
+    t0 = time.perf_counter()
+    v_ref = Hubbard.VcorLocal(spin == 1, False, n, idx_range=sysm.val_idx)
+    v_ref, e0_ref, e1_ref = slater.FitVcorEmb(target, L, basis, v_ref, beta, MaxIter=MaxIter, nelec=nelec)
+    ctx.sync()
+    t_ref = time.perf_counter() - t0
+    fit_ref = slater.FitVcorEmb.last_fit
+    ref_counts = (int(fit_ref.nfev), int(fit_ref.ngev))
+    p_ref = v_ref.param.copy()
+    del fit_ref
+    # (2) run to convergence
     ctx.sync()
     t0 = time.perf_counter()
     v, e0, e1 = slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=MaxIter, nelec=nelec, gtol=gtol, ytol=ytol, dx_tol=dx_tol)
@@ -268,6 +280,8 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
     return {"nparam": int(v.length()), "nemb": int(nemb), "MaxIter": int(MaxIter), "err_begin": float(e0), "err_end": float(e1),
             "param_err_begin": float(np.abs(p_true).max()), "param_err_end": float(np.abs(p - p_true).max()),
             "seconds_total": t_total, "objective_evals": int(fit.nfev), "gradient_evals": int(fit.ngev),
+            "reference_tolerances": {"seconds_total": t_ref, "objective_evals": ref_counts[0], "gradient_evals": ref_counts[1],
+                                     "err_end": float(e1_ref), "param_err_end": float(np.abs(p_ref - p_true).max())},
             "ms_per_objective": 1e3 * t_err, "ms_per_objective_plus_gradient": 1e3 * t_grad,
             "dV_dparam_bytes": int(fit.d_dV.nbytes), "vcor": v,
             "err_reduction": float(e0 / max(e1, 1e-300)),
