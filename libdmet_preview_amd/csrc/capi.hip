@@ -986,10 +986,13 @@ static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
     dmk_ctx *ctx = h->ctx;
     const int64_t np = h->npair;
     const int64_t slot_stride = 2LL * h->naux * np;
-    // slots per launch.  One launch over ALL resident kL (K = 20 800 for 13 weight-2 kL at C5) measured 69.4 TF against 70.7 for
-    // one launch per kL: the tiles of a super-block drift apart along such a long K and stop sharing operand panels in their
-    // XCD's L2.  A few kL per launch keep the panels shared and still amortise the epilogue.
-    static const int kchunk = [] { const char *e = getenv("DMK_ERI_KCHUNK"); const int v = e ? atoi(e) : 2; return v > 0 ? v : 2; }();
+    // slots per launch.  Measured at C5 (13 weight-2 kL resident): 1, 2, 4 or all 13 kL per launch run at the same 69.3-69.6 TF on
+    // the matrix pipe -- the contraction is not sensitive to K -- but the HBM traffic is not the same: with K = 1600 the operand
+    // panels of the eight XCDs' super-blocks (8 x 16 panels x K x 128 x 8 B = 210 MB) still fit the 256 MB Infinity Cache and a
+    // launch fetches 31 GB; with K = 3200 they do not and it fetches 90 GB for twice the work (rocprofv3 FETCH_SIZE).  One kL per
+    // launch therefore stays the default; the stack is what lets the contraction be deferred, banded and overlapped with the
+    // exchange, not a way to lengthen K.
+    static const int kchunk = [] { const char *e = getenv("DMK_ERI_KCHUNK"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
     for (int w = 2; w >= 1; --w) {
         const int n = w == 2 ? h->n_w2 : h->n_w1;
         const int first = w == 2 ? 0 : h->nslots - h->n_w1;

@@ -141,11 +141,11 @@ def reduce_eri_bands(eng, eri_dev, spin_pair, npair, bands_per_group=None):
         owner = gi % world
         lo, hi = b0 * band_rows, min(npair, b1 * band_rows)
         table.append((lo, hi, owner))
-        if world > 1:
+        if is_initialized():           # also with ONE rank (DMK_FORCE_DIST=1): the same RCCL calls as on a multi-GPU node
             for blk in range(spin_pair):
                 reduce_rows_to(eri_dev.offset((blk * npair + lo) * npair, (hi - lo, npair)), owner, pending)
     pending.wait()
-    if world > 1 and _td().get_backend() == "nccl":
+    if is_initialized() and _td().get_backend() == "nccl":
         import torch
         torch.cuda.synchronize()
     return table
