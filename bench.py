@@ -205,6 +205,19 @@ def cpu_baseline(sysm, nemb, flops_half_full, flops_contract_full, budget_s, thr
             "extrapolated_eri_transform_s": round(total_s, 1), "kL_detail": detail}
 
 
+_JSON_FD = None
+
+
+def emit(res):
+    """The one JSON line, on the process's ORIGINAL stdout."""
+    line = (json.dumps(res) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def parity_sample(nemb):
     """Embedding orbitals whose pairs are checked: every workgroup type of the step-2 kernels and both ends."""
     cand = [0, 17, nemb // 2 - 1, nemb // 2, (3 * nemb) // 4 - 1, (3 * nemb) // 4, nemb - 1]
@@ -239,6 +252,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON of rank 0.  Native libraries write there too (RCCL prints a five-line version
+    # banner through C stdio when the process exits, i.e. AFTER anything Python printed): from here on file descriptor 1 is
+    # stderr for everybody, and the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    global _JSON_FD
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if "WORLD_SIZE" in os.environ and a.gpus != world:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; using %d ranks\n" % (a.gpus, world, world))
     os.environ.setdefault("DMK_DEVICE", str(local))
@@ -608,7 +628,7 @@ def main():
             cb["gpu_over_cpu"] = round(res["value"] / max(cb["value"], 1e-12), 1)
             res["cpu_baseline"] = cb
             res["vs_cpu_baseline"] = cb["gpu_over_cpu"]
-        print(json.dumps(res), flush=True)
+        emit(res)
     if distributed:
         import torch.distributed as td
         dist.barrier()           # rank 0 may still have been measuring the fit / CPU baseline: tear down together
@@ -666,7 +686,7 @@ def model_line(a, ctx, sysm, out, fam, timers, elapsed, world, rank, distributed
                                     % (spin * nk, n, n, len(sysm.env_idx), sysm.nval)}}
         if stage_parity is not None:
             res.update(stage_parity)
-        print(json.dumps(res), flush=True)
+        emit(res)
     else:
         rc = 0
     if distributed:

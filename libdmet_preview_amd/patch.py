@@ -56,6 +56,10 @@ _FUNCTIONS = [
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
     ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis"]),
     ("dmet.HubPhSymm", ["dmet.HubPhSymm"], ["basisMatching"]),
+    # driver layer: dmet/Hubbard.py:8 star-imports HubPhSymm, so it holds its own ConstructImpHam; it defines the RHF / UHF
+    # HartreeFock wrapper (:14-41) and FitVcor (:1503) itself
+    ("dmet.HubPhSymm", ["dmet.HubPhSymm", "dmet.Hubbard"], ["ConstructImpHam"]),
+    ("dmet.Hubbard", ["dmet.Hubbard"], ["HartreeFock", "RHartreeFock", "FitVcor"]),
     # Loewdin orthogonalisation (routine/slater.py imports lo.lowdin's vec_lowdin by name)
     ("lo.lowdin", ["lo.lowdin"], ["_lowdin", "_vec_lowdin", "vec_lowdin", "vec_lowdin_k"]),
     ("lo.lowdin", ["routine.slater"], ["vec_lowdin"]),
