@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     const int tm = (int)(packed >> 16), tn = (int)(packed & 0xffffu);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar LDS-DMA addressing
     const int wm = wave >> 1, wn = wave & 1;
     const int frag_k = lane >> 4, frag_x = lane & 15;
 

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     constexpr int AH = BM / 64;                          // 1 KiB pieces per K row of the A panel
     constexpr int STAGE = H1_BK * (BM + H1_BN);
     __shared__ __attribute__((aligned(16))) double2 lds[H1_D * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the LDS-DMA addressing scalar
     const int wm = wave >> 1, wn = wave & 1;            // 2 (M) x 2 (N) waves, wave tile (BM / 2) x 32
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
@@ -234,7 +234,7 @@ struct H2Args {
 
 __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     __shared__ __attribute__((aligned(16))) double2 lds[H2_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar LDS-DMA addressing
     const int frag_k = lane >> 4, frag_x = lane & 15;
     const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
     const int Lall = (int)(lid >> 2), type = (int)(lid & 3);
