@@ -50,16 +50,14 @@ def ConstructImpHam(Lat, rho, v, mu=None, afqmc=False, matching=True, local=True
         raise NotImplementedError("the AFQMC particle-hole rotation of the bath is outside the HIP path")
     log.result("Making embedding basis")
     basis = np.array(slater.embBasis(Lat, rho, local=local, **kwargs))
-    if matching and basis.shape[0] == 2:
+    unrestricted = basis.shape[0] == 2
+    if matching and unrestricted:
         log.result("Rotate bath orbitals to match alpha and beta basis")
         nimp = Lat.nimp
-        if local:
-            basis[:, :, :, nimp:] = basisMatching(basis[:, :, :, nimp:])
-        elif split:
-            basis[:, :, :, :nimp] = basisMatching(basis[:, :, :, :nimp])
-            basis[:, :, :, nimp:] = basisMatching(basis[:, :, :, nimp:])
-        else:
-            basis = basisMatching(basis)
+        # which column ranges are matched: the bath alone (local basis), impurity-like and bath-like halves separately, or all
+        ranges = [slice(nimp, None)] if local else ([slice(None, nimp), slice(nimp, None)] if split else [slice(None)])
+        for cols in ranges:
+            basis[..., cols] = basisMatching(basis[..., cols])
     log.result("Constructing impurity Hamiltonian")
-    ImpHam, H1e = slater.embHam(Lat, basis, v, local=local, **kwargs)
-    return ImpHam, H1e, basis
+    ham, h1e = slater.embHam(Lat, basis, v, local=local, **kwargs)
+    return ham, h1e, basis

@@ -106,13 +106,12 @@ class _VcorLocal(vcor.Vcor):
         return self.diag_idx
 
     def show(self):
-        vcor_mat = self.get()
-        string = "vcor\n"
-        string += "nao %d \n" % vcor_mat.shape[-1]
-        string += "idx range %s, length %s\n" % (self.idx_range, len(self.idx_range))
-        string += "res: %s, bogo: %s, bogo res: %s\n" % (self.restricted, self.bogoliubov, self.bogo_res)
-        string += str(vcor_mat[np.ix_(np.arange(vcor_mat.shape[0]), self.idx_range, self.idx_range)])
-        return string
+        """Human-readable summary: the parametrisation and the matrix blocks on the fitted orbitals."""
+        v = self.get()
+        fitted = v[np.ix_(np.arange(v.shape[0]), self.idx_range, self.idx_range)]
+        head = ["vcor", "nao %d" % v.shape[-1], "fitted orbitals %s (%d)" % (self.idx_range, len(self.idx_range)),
+                "restricted %s, bogoliubov %s (restricted pairing %s)" % (self.restricted, self.bogoliubov, self.bogo_res)]
+        return "\n".join(head + [str(fitted)])
 
 
 def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, v_idx=None, d_idx=None, ghf=False):
@@ -131,15 +130,13 @@ vcor_zeros = VcorLocal
 
 def HartreeFock(Lat, v, filling, mu0=None, beta=np.inf, ires=False, **kwargs):
     """RHF / UHF lattice mean field of the DMET loop: `mfd.HF` with the spin symmetry of the correlation potential."""
-    from libdmet_preview_amd.routine.mfd import HF
-    if beta != np.inf:
-        log.info("using finite-T smearing for lattice, beta = %20.12f ", beta)
-    rho, mu, E, res = HF(Lat, v, filling, v.restricted, mu0=mu0, beta=beta, ires=True, **kwargs)
-    log.result("Chemical potential (mean-field) = %s", mu)
-    log.result("Energy per cell (mean-field) = %20.12f", E)
-    if ires or kwargs.get("full_return", False):
-        return rho, mu, res
-    return rho, mu
+    from libdmet_preview_amd.routine import mfd
+    if np.isfinite(beta):
+        log.info("lattice mean field with Fermi smearing, beta = %.12g", beta)
+    rho, mu, energy, res = mfd.HF(Lat, v, filling, v.restricted, mu0=mu0, beta=beta, ires=True, **kwargs)
+    log.result("mean field: mu = %s, E per cell = %.12f, gap = %s", mu, energy, res["gap"])
+    want_details = ires or kwargs.get("full_return", False)
+    return (rho, mu, res) if want_details else (rho, mu)
 
 
 def RHartreeFock(Lat, v, filling, mu0=None, beta=np.inf, ires=False, **kwargs):

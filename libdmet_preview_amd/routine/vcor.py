@@ -28,10 +28,8 @@ def _abstract(name):
 
 class Vcor(object):
     def __init__(self):
-        self.param = None
-        self.value = None
-        self.local = True
-        self.is_vcor_kpts = False
+        self.param = self.value = None          # set by update() / assign()
+        self.local, self.is_vcor_kpts = True, False
 
     # --- parametrisation hooks (bound by the factories in dmet/Hubbard.py) ---------------------------------------
     evaluate = _abstract("evaluate")
@@ -39,6 +37,7 @@ class Vcor(object):
     length = _abstract("length")
 
     def update(self, param):
+        """Adopt a parameter vector and refresh the matrix value it stands for."""
         self.param = param
         self.value = self.evaluate()
 
