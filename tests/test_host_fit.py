@@ -59,7 +59,7 @@ def test_vcor_local(golden, tag, itag):
     w = Hubbard.VcorLocal(nscsites=5, idx_range=None if itag == "all" else [1, 3, 4], **VC[tag])
     w.assign(g[key + "/value"])
     assert np.abs(w.param - p).max() < 1e-14
-    assert "idx range" in w.show()
+    assert "fitted orbitals" in w.show() and "nao 5" in w.show()
 
 
 @pytest.mark.parametrize("kw", [dict(restricted=True, bogoliubov=False), dict(restricted=False, bogoliubov=False),
