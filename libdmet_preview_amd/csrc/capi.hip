@@ -648,7 +648,7 @@ struct dmk_eri {
     int group = 1, pending = 0;
     double *imag = nullptr;   // flags & 2 (no time reversal): Im of the contraction, spin_pair x npair^2, for dmk_eri_imag_norm
     bool hot256 = false;      // step 2 by the nemb = 256 kernel (zhot.hip) instead of the table-driven one (zhot_tab.hip)
-    int pend_kj[32], pend_sym[32], pend_ki[32];
+    int pend_kj[16], pend_sym[16], pend_ki[16];
     // block ring (dmk_eri_block_ring / dmk_eri_push_ring_slot): `group` AO-block buffers owned by the pipeline; blocks
     // written there are queued WITHOUT running step 1, and the flush runs ONE step-1 launch over all of them
     double2 *ring = nullptr;
@@ -708,8 +708,6 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(naux, nao, nemb)) {
         h->lchunk = naux;
         h->group = 8;
-        // table-driven step 2: several sub-groups of eight blocks per launch when that fills the last round of workgroups
-        if (!h->hot256) h->group = 8 * half2_tab_best_groups(naux, nemb, spin);
         if (const char *e = getenv("DMK_ERI_GROUP")) h->group = atoi(e);
         h->group = std::max(1, std::min(h->group, h->hot256 ? half2_hot_maxslot() : half2_tab_maxslot()));
     }
@@ -792,15 +790,11 @@ static int eri_ring_step1(dmk_eri *h) {
     if (h->ring_pending == 0) return DMK_OK;
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const size_t slot_elems = (size_t)naux * nao * nemb;
-    // the step-1 launch carries at most 16 blocks: larger queues (several sub-groups of the table-driven step 2) go in chunks
-    for (int s0 = 0; s0 < h->ring_pending; s0 += 16) {
-        const int ns = std::min(16, h->ring_pending - s0);
-        int rc = launch_half1_hot_multi(ctx, h->ring + (size_t)s0 * naux * nao * nao, (long long)naux * nao * nao, ns, h->pend_ki + s0, h->C,
-                                        h->Ut + (size_t)s0 * slot_elems, (long long)slot_elems, naux, nao, nemb, h->spin,
-                                        (long long)h->mesh.nk * nao * nemb, (long long)h->group * (long long)slot_elems);
-        if (rc < 0) return rc;
-        if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
-    }
+    int rc = launch_half1_hot_multi(ctx, h->ring, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->C, h->Ut,
+                                    (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * nao * nemb,
+                                    (long long)h->group * (long long)slot_elems);
+    if (rc < 0) return rc;
+    if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
     h->ring_pending = 0;
     return DMK_OK;
 }
@@ -815,7 +809,7 @@ static int eri_flush(dmk_eri *h) {
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const size_t slot_elems = (size_t)naux * nao * nemb;
     // one launch for both spin channels: C, Ut and the planes of spin 1 sit at constant offsets from those of spin 0
-    const void *cj[32];
+    const void *cj[16];
     for (int i = 0; i < h->pending; ++i)
         cj[i] = h->C + (size_t)h->pend_kj[i] * nao * nemb;
     int rc = (h->hot256 ? launch_half2_hot : launch_half2_tab)(

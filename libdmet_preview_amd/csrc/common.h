@@ -237,5 +237,3 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);
 int half2_tab_usable(int nao, int nemb);
 int half2_tab_maxslot();
-int half2_tab_subslots();
-int half2_tab_best_groups(int nL, int nemb, int nspin);

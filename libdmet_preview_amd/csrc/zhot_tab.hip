@@ -23,7 +23,6 @@
 //   Block efficiency (useful blocks / 4 waves x longest list): nemb 136 -> 94 %, 200 -> 95 %, 272 -> 93 %.
 // Panels wider than the matrix re-read clamped valid columns; they only ever feed masked outputs.
 #include "common.h"
-#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -32,7 +31,7 @@
 namespace {
 
 constexpr int T_BK = 4;
-constexpr int T_MAXSLOT = 32;                          // queued AO blocks per launch (up to four sub-groups of eight)
+constexpr int T_MAXSLOT = 16;
 constexpr int T_ITEM = 48;                             // ints per table item
 constexpr int TD_STAGE = T_BK * 256;                   // diagonal item: U[4][128] | C[4][128]                          (16 KiB)
 constexpr int TR_STAGE = T_BK * 384;                   // rectangle:     Ua[4][64] | Cb[4][128] | Ca[4][64] | Ub[4][128] (24 KiB)
@@ -64,12 +63,6 @@ struct H2TArgs {
     int fold_diag;                   // every queued block is symmetrised: diagonal blocks run one segment and are folded (zhot.hip)
     const int *table;                // nitems x T_ITEM: kind, R0, C0, nblk[4], pad, entries[4][8] = (row block << 8) | col block (local)
     int nitems;
-    // SUB-GROUPS: the queued blocks are cut into `nsub` runs of `sub_slots` consecutive slots and every (sub-group, L, item)
-    // is its own workgroup with its own accumulators.  All workgroups of a launch run equally long, so the launch pays
-    // ceil(units / resident slots) rounds: at C4 (416 L x 3 items = 1248 units on 768 slots) one group of eight blocks runs
-    // 2 rounds for 1.6 rounds of work; three groups in one launch run 5 rounds for 4.9.
-    int nsub, sub_slots;
-    unsigned units_per_sub;          // nitems * nL * nspin
 };
 
 // kernel-argument arrays are only ever indexed by constants (see zhot.hip)
@@ -77,11 +70,7 @@ struct H2TArgs {
     ((SLOT) == 0 ? (G).Cj[0] : (SLOT) == 1 ? (G).Cj[1] : (SLOT) == 2 ? (G).Cj[2] : (SLOT) == 3 ? (G).Cj[3]      \
      : (SLOT) == 4 ? (G).Cj[4] : (SLOT) == 5 ? (G).Cj[5] : (SLOT) == 6 ? (G).Cj[6] : (SLOT) == 7 ? (G).Cj[7]    \
      : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
-     : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (SLOT) == 15 ? (G).Cj[15]    \
-     : (SLOT) == 16 ? (G).Cj[16] : (SLOT) == 17 ? (G).Cj[17] : (SLOT) == 18 ? (G).Cj[18] : (SLOT) == 19 ? (G).Cj[19] \
-     : (SLOT) == 20 ? (G).Cj[20] : (SLOT) == 21 ? (G).Cj[21] : (SLOT) == 22 ? (G).Cj[22] : (SLOT) == 23 ? (G).Cj[23] \
-     : (SLOT) == 24 ? (G).Cj[24] : (SLOT) == 25 ? (G).Cj[25] : (SLOT) == 26 ? (G).Cj[26] : (SLOT) == 27 ? (G).Cj[27] \
-     : (SLOT) == 28 ? (G).Cj[28] : (SLOT) == 29 ? (G).Cj[29] : (SLOT) == 30 ? (G).Cj[30] : (G).Cj[31])
+     : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
 
 template <class CFG>
 __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs g) {
@@ -90,22 +79,18 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frag_k = lane >> 4, frag_x = lane & 15;
-    const unsigned lid_all = xcd_remap(blockIdx.x, g.nblocks);
-    const int sub = (int)(lid_all / g.units_per_sub);                   // sub-group of queued blocks this workgroup runs through
-    const unsigned lid = lid_all - (unsigned)sub * g.units_per_sub;
-    const int slot0 = sub * g.sub_slots;
-    const int my_slots = min(g.sub_slots, g.nslot - slot0);
+    const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
     const int Lall = (int)(lid / (unsigned)g.nitems), item = (int)(lid - (unsigned)Lall * (unsigned)g.nitems);
     const int sp = Lall >= g.nL ? 1 : 0;
     const int L = Lall - sp * g.nL;
     const long long nemb = g.nemb;
     const int Tb = g.nao / T_BK;
-    const int T = Tb * my_slots;
-    const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
-    const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb + (long long)slot0 * g_slot_stride;
+    const int T = Tb * g.nslot;
+    const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb;
     double *const g_planes = g.planes + (long long)sp * g.planes_spin_stride;
     const long long cj_off = (long long)sp * g.cj_spin_stride;
-    const unsigned g_symmask = g.symmask >> slot0;
+    const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
+    const unsigned g_symmask = g.symmask;
 
     // ---- this workgroup's item and this wave's block list (wave-uniform: SGPRs) ----------------------------------
     const int *it = g.table + (long long)item * T_ITEM;
@@ -113,10 +98,9 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
     const int R0 = __builtin_amdgcn_readfirstlane(it[1]), C0 = __builtin_amdgcn_readfirstlane(it[2]);
     const int nblk = __builtin_amdgcn_readfirstlane(it[3 + wave]);
     // diagonal blocks of this wave (the host puts them LAST in its list): with `fold_diag` they skip segment 2
-    const int fold_here = (g.fold_diag >> sub) & 1;          // bit per sub-group: every block of THIS run is symmetrised
-    const int ndiag = fold_here ? (__builtin_amdgcn_readfirstlane(it[7]) >> (8 * wave)) & 255 : 0;
+    const int ndiag = g.fold_diag ? (__builtin_amdgcn_readfirstlane(it[7]) >> (8 * wave)) & 255 : 0;
     const int nb2 = nblk - ndiag;
-    const bool wg_has_diag = fold_here && __builtin_amdgcn_readfirstlane(it[7]) != 0;      // uniform over the workgroup
+    const bool wg_has_diag = g.fold_diag && __builtin_amdgcn_readfirstlane(it[7]) != 0;      // uniform over the workgroup
     int ro[T_MAXBLK], co[T_MAXBLK];              // local element offsets of each block inside the row / column panels
 #pragma unroll
     for (int i = 0; i < T_MAXBLK; ++i) {
@@ -166,7 +150,7 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
             soff[h] = (long long)row * nemb + clampcol(col);
         }
         int is_t = 0, is_slot = 0, is_stage = 0;
-        const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, slot0) + cj_off;
+        const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, 0) + cj_off;
         auto issue = [&]() {
             double2 *st = lds + is_stage * STAGE;
             const double2 *gp[NP];
@@ -184,7 +168,7 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                 is_t = 0;
                 ++is_slot;
                 is_ub = Ubase + (long long)is_slot * g_slot_stride;
-                is_cb = T_PICK_CJ(g, slot0 + is_slot) + cj_off;
+                is_cb = T_PICK_CJ(g, is_slot) + cj_off;
             } else {
                 is_ub += T_BK * nemb;
                 is_cb += T_BK * nemb;
@@ -382,28 +366,6 @@ int half2_tab_usable(int nao, int nemb) {
     return tab_enabled() && nemb >= 32 && nemb <= 4096 && (nao % T_BK) == 0 && nao >= 3 * T_BK;
 }
 int half2_tab_maxslot() { return T_MAXSLOT; }
-int half2_tab_subslots() { return 8; }
-
-// How many sub-groups of eight blocks one launch should carry for (nL, nemb, nspin): the smallest count (<= 4) whose
-// workgroup count fills the last round of resident slots to 95 %, else the best of them.
-int half2_tab_best_groups(int nL, int nemb, int nspin) {
-    const int nb = (nemb + 15) / 16;
-    const int occ = nb <= T_WIDE_MAXNB ? 3 : 2;
-    const int maxblk = occ == 3 ? Cfg3::MAXBLK : Cfg2::MAXBLK, seg = occ == 3 ? Cfg3::SEG : Cfg2::SEG;
-    std::vector<int> h;
-    double useful, slots, folded;
-    build_table(nemb, maxblk, seg, h, useful, slots, folded);
-    const double units = (double)(h.size() / T_ITEM) * nL * nspin, resident = 256.0 * occ;
-    int best = 1;
-    double best_eff = 0.0;
-    for (int s = 1; s <= T_MAXSLOT / 8; ++s) {
-        const double rounds = std::ceil(units * s / resident);
-        const double eff = units * s / (rounds * resident);
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
-        if (eff >= 0.95) return s;
-    }
-    return best;
-}
 
 // Returns 1 if handled, 0 if the caller must use the generic kernel, < 0 on error.  Arguments as launch_half2_hot (zhot.hip).
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj, const int *sym,
@@ -454,26 +416,13 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.nspin = nspin;
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.table = tb->dev; a.nitems = tb->nitems;
-    const unsigned long long units = (unsigned long long)tb->nitems * (unsigned)nL * (unsigned)nspin;
-    a.sub_slots = half2_tab_subslots();
-    a.nsub = (nslot + a.sub_slots - 1) / a.sub_slots;
-    a.fold_diag = 0;                                          // bit per sub-group
-    double seg2 = 0.0;                                        // second-segment block products of the whole launch
-    for (int sg = 0; sg < a.nsub; ++sg) {
-        const int s0 = sg * a.sub_slots, s1 = std::min(nslot, s0 + a.sub_slots);
-        int nsym = 0;
-        for (int i = s0; i < s1; ++i) nsym += sym[i] ? 1 : 0;
-        const bool fold = nsym == s1 - s0;
-        if (fold) a.fold_diag |= 1 << sg;
-        seg2 += (double)nsym * (tb->useful_blocks - (fold ? tb->folded_blocks : 0.0));
-    }
-    a.units_per_sub = (unsigned)units;
-    const unsigned long long nblocks = units * (unsigned)a.nsub;
-    if (units > 0x7fffffffull || nblocks > 0x7fffffffull) return 0;
+    a.fold_diag = (a.symmask == (nslot >= 32 ? 0xffffffffu : ((1u << nslot) - 1u))) ? 1 : 0;
+    const unsigned long long nblocks = (unsigned long long)tb->nitems * (unsigned)nL * (unsigned)nspin;
+    if (nblocks > 0x7fffffffull) return 0;
     a.nblocks = (unsigned)nblocks;
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
-    // a symmetrised block runs a second segment -- without the folded diagonal blocks when its whole sub-group is symmetrised
-    (void)segs;
+    // a symmetrised block runs a second segment -- without the folded diagonal blocks when the whole group is symmetrised
+    const double seg2 = (segs - (double)nslot) * (tb->useful_blocks - (a.fold_diag ? tb->folded_blocks : 0.0));
     fs.mfma_flops(6.0 * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)nao * (double)nL * (double)nspin);
     if (occ == 2) hipLaunchKernelGGL(half2_tab_kernel<Cfg2>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL(half2_tab_kernel<Cfg3>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
