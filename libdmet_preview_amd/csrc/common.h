@@ -47,6 +47,9 @@ struct dmk_ctx {
     // see; before any allocation inside the library is reported as failed the hook is asked to give that memory back
     void (*oom_hook)(void *) = nullptr;
     void *oom_user = nullptr;
+    // warm-started eigensolver (jacobi_eigh.hip): bookkeeping of the refinement fast path
+    int refine_streak = 0, refine_skip = 0;
+    long long refine_ok = 0, refine_failed = 0;
 };
 
 // hipMalloc with one retry after the out-of-memory hook; hipSuccess or the error of the second attempt

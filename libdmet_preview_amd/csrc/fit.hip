@@ -102,60 +102,91 @@ __global__ __launch_bounds__(NT) void partsum_kernel(long long n, int nblk, cons
     if (wave == 0 && c < n) y[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// C[b] = alpha op(A[b]) op(B[b]) + beta C[b], row-major with leading dimensions; 64 x 64 tile, BK = 16
+// C[b] = alpha op(A[b]) op(B[b]) + beta C[b], row-major with leading dimensions, on v_mfma_f64_16x16x4_f64.
+// These are the small dense products of the fit (n = nemb, a few hundred) and of the basis rotations: a few MFLOP each, so
+// what counts is latency and the number of CUs reached, not operand reuse -- one 16 x 16 tile of C per wave (2 x 2 waves per
+// workgroup), operands straight from global memory (they are L2 resident), no LDS, no barrier.  The k index is permuted
+// identically in both operands: lane (x, q) owns k0 + 16 q .. + 15 of a 64-wide chunk and the t-th MFMA of the chunk contracts
+// element t of the four q groups, so a K-contiguous operand is read as 128 contiguous bytes per lane (8 x b128 when the rows
+// are 16-byte aligned) and the other kind as 16 row segments shared by 16 lanes.  The next chunk is in flight during the MFMAs.
 template <int TA, int TB>
 __global__ __launch_bounds__(NT) void dgemm_small_kernel(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                          long long lda, long long sA, const double *__restrict__ B,
                                                          long long ldb, long long sB, double beta, double *__restrict__ C,
                                                          long long ldc, long long sC) {
-    __shared__ double As[16][65], Bs[16][65];
     const int b = blockIdx.z;
     A += (long long)b * sA;
     B += (long long)b * sB;
     C += (long long)b * sC;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    double acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 32 + (wave >> 1) * 16, n0 = blockIdx.x * 32 + (wave & 1) * 16;
+    if (m0 >= M || n0 >= N) return;
+    const int am = m0 + x, bn = n0 + x;
+    const bool a_ok = am < M, b_ok = bn < N;
+    // K-contiguous operands: A when TA == 0 (row am), B when TB == 1 (row bn)
+    const bool a_vec = TA == 0 && ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool b_vec = TB == 1 && ((ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    const double *ap = TA ? A + (a_ok ? am : 0) : A + (long long)(a_ok ? am : 0) * lda;
+    const double *bp = TB ? B + (long long)(b_ok ? bn : 0) * ldb : B + (b_ok ? bn : 0);
+
+    auto load_contig = [&](const double *row, bool ok, bool vec, int k0, double (&r)[16]) {
+        if (ok && vec && k0 + 16 <= K) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = threadIdx.x + e * NT;                  // 1024 elements per operand tile
-            {
-                const int kk = TA ? idx / 64 : idx % 16, mm = TA ? idx % 64 : idx / 16;
-                const int m = m0 + mm, k = k0 + kk;
-                As[kk][mm] = (m < M && k < K) ? (TA ? A[(long long)k * lda + m] : A[(long long)m * lda + k]) : 0.0;
+            for (int t = 0; t < 8; ++t) {
+                const double2 v = *reinterpret_cast<const double2 *>(row + k0 + 2 * t);
+                r[2 * t] = v.x;
+                r[2 * t + 1] = v.y;
             }
-            {
-                const int kk = TB ? idx % 16 : idx / 64, nn = TB ? idx / 16 : idx % 64;
-                const int n = n0 + nn, k = k0 + kk;
-                Bs[kk][nn] = (n < N && k < K) ? (TB ? B[(long long)n * ldb + k] : B[(long long)k * ldb + n]) : 0.0;
-            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) r[t] = (ok && k0 + t < K) ? row[k0 + t] : 0.0;
         }
-        __syncthreads();
+    };
+    auto load_strided = [&](const double *col, long long ld, bool ok, int k0, double (&r)[16]) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double a[4], bb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bb[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
-        }
-        __syncthreads();
+        for (int t = 0; t < 16; ++t) r[t] = (ok && k0 + t < K) ? col[(long long)(k0 + t) * ld] : 0.0;
+    };
+    auto load_a = [&](int k0, double (&r)[16]) {
+        if (TA) load_strided(ap, lda, a_ok, k0, r); else load_contig(ap, a_ok, a_vec, k0, r);
+    };
+    auto load_b = [&](int k0, double (&r)[16]) {
+        if (TB) load_contig(bp, b_ok, b_vec, k0, r); else load_strided(bp, ldb, b_ok, k0, r);
+    };
+
+    d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+    double a[2][16], bb[2][16];
+    const int nchunk = (K + 63) / 64;
+    if (nchunk > 0) {
+        load_a(16 * q, a[0]);
+        load_b(16 * q, bb[0]);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < M && n < N) {
-                double *c = C + (long long)m * ldc + n;
-                *c = (beta == 0.0) ? alpha * acc[i][j] : alpha * acc[i][j] + beta * (*c);
-            }
+#pragma unroll 1
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 1 < nchunk) {
+            load_a((c + 1) * 64 + 16 * q, a[1]);
+            load_b((c + 1) * 64 + 16 * q, bb[1]);
         }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][t], bb[0][t], acc, 0, 0, 0);
+        if (c + 1 < nchunk) {
+            if (c + 2 < nchunk) {
+                load_a((c + 2) * 64 + 16 * q, a[0]);
+                load_b((c + 2) * 64 + 16 * q, bb[0]);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][t], bb[1][t], acc, 0, 0, 0);
+        }
+    }
+    // D layout: row = (lane >> 4) + 4 r, col = lane & 15
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + q + 4 * r;
+        if (row < M && bn < N) {
+            double *c = C + (long long)row * ldc + bn;
+            *c = (beta == 0.0) ? alpha * acc[r] : alpha * acc[r] + beta * (*c);
+        }
+    }
 }
 
 // packed lower triangle <-> full symmetric, batched
@@ -204,11 +235,17 @@ __global__ void ewise_kernel(int mode, long long nr, long long nc, const double 
 }
 
 // diff = a - b, sumsq = sum diff^2 ; one workgroup, fixed order
-__global__ __launch_bounds__(NT) void sub_sumsq_kernel(long long n, const double *__restrict__ a, const double *__restrict__ b,
-                                                       double *__restrict__ diff, double *__restrict__ sumsq) {
+// diff = a - b and its sum of squares in two launches: up to SS_BLOCKS workgroups leave one partial sum each (contiguous
+// slices, fixed partition), a single wave adds them in index order -- reproducible, and the 2 * nidx^2 residual entries of the
+// fit (131 072 at C5) no longer trickle through one workgroup (0.22 ms -> a few microseconds)
+constexpr int SS_BLOCKS = 64;
+__global__ __launch_bounds__(NT) void sub_sumsq_kernel(long long n, long long per_block, const double *__restrict__ a,
+                                                       const double *__restrict__ b, double *__restrict__ diff,
+                                                       double *__restrict__ part) {
     __shared__ double red[NW];
+    const long long t0 = (long long)blockIdx.x * per_block, t1 = (t0 + per_block < n) ? t0 + per_block : n;
     double s = 0.0;
-    for (long long t = threadIdx.x; t < n; t += NT) {
+    for (long long t = t0 + threadIdx.x; t < t1; t += NT) {
         const double d = a[t] - b[t];
         if (diff) diff[t] = d;
         s = fma(d, d, s);
@@ -216,7 +253,12 @@ __global__ __launch_bounds__(NT) void sub_sumsq_kernel(long long n, const double
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) sumsq[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void sumsq_final_kernel(int nblk, const double *__restrict__ part, double *__restrict__ sumsq) {
+    const double v = (int)threadIdx.x < nblk ? part[threadIdx.x] : 0.0;
+    const double s = wave_sum(v);
+    if (threadIdx.x == 0) sumsq[0] = s;
 }
 
 // dV[ip][pair(p,q)] = sum over the nonzeros (i, j, val) of parameter-spin entry ip of  val * G[(i,p),(j,q)]
@@ -284,7 +326,7 @@ int grid_for(long long total, int cap = 8192) { return (int)std::min<long long>(
 
 // C[b] = A[b] B[b] (row-major, contiguous) for the other translation units
 int launch_dgemm_small_nn(dmk_ctx *ctx, int M, int N, int K, int batch, const double *A, const double *B, double *C) {
-    const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    const dim3 grid((N + 31) / 32, (M + 31) / 32, batch);
     hipLaunchKernelGGL((dgemm_small_kernel<0, 0>), grid, dim3(NT), 0, ctx->stream, M, N, K, 1.0, A, (long long)K, (long long)M * K, B,
                        (long long)N, (long long)K * N, 0.0, C, (long long)N, (long long)M * N);
     DMK_CHECK_LAUNCH(ctx);
@@ -325,7 +367,7 @@ int dmk_dgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int b
         return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_batched: bad arguments");
     if (M == 0 || N == 0 || batch == 0) return DMK_OK;
     FamScope fs(ctx, DMK_FAM_FIT);
-    const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+    const dim3 grid((N + 31) / 32, (M + 31) / 32, batch);
 #define DG_LAUNCH(TA, TB)                                                                                             \
     hipLaunchKernelGGL((dgemm_small_kernel<TA, TB>), grid, dim3(NT), 0, ctx->stream, M, N, K, alpha, A, (long long)lda,    \
                        (long long)strideA, B, (long long)ldb, (long long)strideB, beta, C, (long long)ldc, (long long)strideC)
@@ -386,7 +428,14 @@ int dmk_sub_sumsq(dmk_ctx *ctx, int64_t n, const double *a, const double *b, dou
     if (!ctx) return DMK_ERR_INVALID;
     if (n < 0 || !a || !b || !sumsq_dev) return dmk_fail(ctx, DMK_ERR_INVALID, "sub_sumsq: bad arguments");
     FamScope fs(ctx, DMK_FAM_FIT);
-    hipLaunchKernelGGL(sub_sumsq_kernel, dim3(1), dim3(NT), 0, ctx->stream, (long long)n, a, b, diff, sumsq_dev);
+    const long long per_block = std::max<long long>(((n + SS_BLOCKS - 1) / SS_BLOCKS + NT - 1) / NT * NT, NT);
+    const int nblk = (int)std::max<long long>((n + per_block - 1) / per_block, 1);
+    void *ws = nullptr;
+    const int rc = dmk_scratch(ctx, SS_BLOCKS * sizeof(double), &ws);
+    if (rc) return rc;
+    double *part = static_cast<double *>(ws);
+    hipLaunchKernelGGL(sub_sumsq_kernel, dim3(nblk), dim3(NT), 0, ctx->stream, (long long)n, per_block, a, b, diff, part);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, ctx->stream, nblk, part, sumsq_dev);
     DMK_CHECK_LAUNCH(ctx);
     return DMK_OK;
 }

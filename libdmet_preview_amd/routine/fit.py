@@ -78,7 +78,8 @@ def minimize_SD(fn, x0, MaxIter=300, fgrad=None, callback=None, ytol=1e-7, gtol=
         h = 10 * g / y
         dx = h * 10 / (1 + np.sum(h * h))
         if callback is None:
-            phi = lambda step: fn(x - step * dx)
+            ray_fn = kwargs.get("ray_fn", None)
+            phi = ray_fn(x, -dx) if ray_fn is not None else (lambda step: fn(x - step * dx))
         else:
             ref_ = callback(x)
             phi = lambda step: fn(x - step * dx, ref_)
@@ -110,6 +111,7 @@ def _downhill(fn, x0, method, MaxIter, fgrad, callback, ytol, gtol, dx_tol, **kw
     init_step, min_step, xatol = kwargs.get("init_step", 1.0), kwargs.get("min_step", 0.1), kwargs.get("xatol", 1e-5)
     if fgrad is None:
         fgrad = _numeric_grad(fn, callback, eps, kwargs.get("diag_idx", None))
+    ray_fn = kwargs.get("ray_fn", None)
     f = lambda x: fn(np.copy(x))
     fp = lambda x: np.asarray(fgrad(np.copy(x)))
     xk = np.asarray(x0).flatten()
@@ -131,7 +133,9 @@ def _downhill(fn, x0, method, MaxIter, fgrad, callback, ytol, gtol, dx_tol, **kw
             pk = -np.dot(Hk, gfk)
         else:
             deltak = np.dot(gfk, gfk)
-        phi = lambda step: f(xk + step * pk)
+        # `ray_fn(x, p)` (optional, FitVcorEmb passes it): phi(t) = fn(x + t p) from an objective that is cheaper along
+        # a fixed ray (the potential is linear in the parameters: two passes over dV_dparam serve the whole search)
+        phi = ray_fn(xk, pk) if ray_fn is not None else (lambda step: f(xk + step * pk))
         alpha_k, new_fval = _line_search(phi, old_fval, steps, min_step, xatol)
         steps.append(alpha_k)
         dy = abs(new_fval - old_fval)

@@ -276,9 +276,10 @@ def check_nelec(nelec, ncells=None, tol=1e-5):
     return whole, share
 
 
-def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, fit_tol=1e-12):
+def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, fit_tol=1e-12, d_occ=None):
     """Occupations of ALL levels in the device array `d_ew` (one particle-number sector) without leaving the GPU:
-    returns (device occupations, mu, nerr).  mu0=None at T = 0 means "no preferred level" (the frontier mid-point)."""
+    returns (device occupations, mu, nerr).  mu0=None at T = 0 means "no preferred level" (the frontier mid-point).
+    `d_occ`: optional destination (same number of elements as d_ew)."""
     import ctypes as C
     n = int(d_ew.size)
     zero_t = not (beta < np.inf)
@@ -289,7 +290,8 @@ def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, 
         flags = 0 if mu0 is None else 1
     else:
         flags = 2 if fix_mu else 0
-    d_occ = ctx.empty(d_ew.shape, np.float64)
+    if d_occ is None:
+        d_occ = ctx.empty(d_ew.shape, np.float64)
     info = (C.c_double * 5)()
     ctx.check(lib.dmk_assign_occ(ctx.h, n, d_ew.ptr, float(nelec), float(beta), 0.0 if mu0 is None else float(mu0), flags,
                                  float(thr_deg), float(fit_tol), d_occ.ptr, info))

@@ -490,6 +490,7 @@ class EmbFitDevice(object):
         choice = os.environ.get("DMK_FIT_EIGH", eigh)
         self.use_jacobi = (choice == "jacobi") and nb <= 576 and spin * ((nb + 31) // 32) <= 256
         self._have_prev, self.sweeps = False, 0
+        self._ray = None
 
     # -- forward pass ------------------------------------------------------------------------------
     def _gemm(self, opA, opB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0):
@@ -497,15 +498,26 @@ class EmbFitDevice(object):
         ctx.check(lib.dmk_dgemm_batched(ctx.h, opA, opB, M, N, K, sp, alpha, A.ptr, lda, A.size // sp, B.ptr, ldb,
                                         B.size // sp, 0.0, C.ptr, ldc, C.size // sp))
 
-    def _forward(self, param):
+    def _vemb_into(self, param, d_out):
+        """d_out (spin, npair) = param . dV_dparam: one pass over the 1.7 GB (C5) table."""
+        ctx, spin = self.ctx, self.spin
+        param = np.ascontiguousarray(param, dtype=np.float64)
+        ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_param.ptr, param.ctypes.data, param.nbytes))
+        ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, None,
+                                 self.d_param.ptr, None, d_out.ptr))
+
+    def _forward(self, param, ray=None):
         param = np.ascontiguousarray(param, dtype=np.float64)
         key = param.tobytes()
         if key == self._key:
             return self._state
         ctx, spin, nb, nidx = self.ctx, self.spin, self.nb, self.nidx
-        ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_param.ptr, param.ctypes.data, param.nbytes))
-        ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, None,
-                                 self.d_param.ptr, None, self.d_vemb.ptr))
+        if ray is None:
+            self._vemb_into(param, self.d_vemb)
+        else:
+            d_v0, d_v1, t = ray                                   # V_emb(x + t p) = V_emb(x) + t V_emb(p)
+            ctx.check(lib.dmk_memcpy_d2d(ctx.h, self.d_vemb.ptr, d_v0.ptr, self.d_vemb.nbytes))
+            ctx.check(lib.dmk_axpy_f64(ctx.h, spin * self.npair, float(t), d_v1.ptr, self.d_vemb.ptr))
         ctx.check(lib.dmk_sym_unpack(ctx.h, nb, spin, self.d_vemb.ptr, self.d_H1.ptr, self.d_H.ptr))
         d_A = self.d_H
         if self.d_X is not None:
@@ -526,16 +538,30 @@ class EmbFitDevice(object):
             d_Vt = self.d_Vt
         else:
             d_Vt = self.d_Vp
-        ew = self.d_w.get()
-        if not self.fix_mu:
-            ne = self.nelec
-            mu = (0.5 * (ew[0][ne - 1] + ew[0][ne]) if spin == 1 else
-                  [0.5 * (ew[0][ne[0] - 1] + ew[0][ne[0]]), 0.5 * (ew[1][ne[1] - 1] + ew[1][ne[1]])])
+        if self.beta == np.inf:
+            # T = 0: occupations straight from the device eigenvalues, one particle-number sector per spin (the frontier
+            # mid-point the reference passes as mu0 is what dmk_assign_occ picks on its own); ew / occ stay in HBM and are
+            # only fetched when the gradient asks for them
+            ne = [self.nelec] if spin == 1 else list(self.nelec)
+            mu = []
+            for s in range(spin):
+                guess = None if not self.fix_mu else (self.mu0 if np.ndim(self.mu0) == 0 else self.mu0[s])
+                d_o, mu_s, _ = self._mfd.assignocc_dev(ctx, self.d_w.offset(s * nb, (nb,)), ne[s], self.beta, mu0=guess,
+                                                       thr_deg=self.tol_deg, d_occ=self.d_occ.offset(s * nb, (nb,)))
+                mu.append(mu_s)
+            mu = mu[0] if spin == 1 else np.asarray(mu)
+            ew = occ = None
         else:
-            mu = self.mu0
-        occ, mu, _ = self._mfd.assignocc(ew, self.nelec, self.beta, mu, fix_mu=self.fix_mu, thr_deg=self.tol_deg)
-        occ = np.ascontiguousarray(occ, dtype=np.float64)
-        ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_occ.ptr, occ.ctypes.data, occ.nbytes))
+            ew = self.d_w.get()
+            if not self.fix_mu:
+                ne = self.nelec
+                mu = (0.5 * (ew[0][ne - 1] + ew[0][ne]) if spin == 1 else
+                      [0.5 * (ew[0][ne[0] - 1] + ew[0][ne[0]]), 0.5 * (ew[1][ne[1] - 1] + ew[1][ne[1]])])
+            else:
+                mu = self.mu0
+            occ, mu, _ = self._mfd.assignocc(ew, self.nelec, self.beta, mu, fix_mu=self.fix_mu, thr_deg=self.tol_deg)
+            occ = np.ascontiguousarray(occ, dtype=np.float64)
+            ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_occ.ptr, occ.ctypes.data, occ.nbytes))
         ctx.check(lib.dmk_ewise_mul(ctx.h, 1, spin * nb, nb, d_Vt.ptr, self.d_occ.ptr, self.d_sc.ptr))
         self._gemm(1, 0, nb, nb, nb, d_Vt, nb, self.d_sc, nb, self.d_rho, nb)               # ev occ ev^T
         for s in range(spin):
@@ -552,6 +578,23 @@ class EmbFitDevice(object):
     def errfunc(self, param):
         self.nfev += 1
         return self._forward(param)[3] / sqrt(self.spin)
+
+    def errfunc_ray(self, x, p):
+        """phi(t) = errfunc(x + t p) for a line search: the embedding potential is LINEAR in the parameters, so the two
+        table passes V_emb(x), V_emb(p) are made once and every trial step is an axpy of spin * npair numbers (the pass over
+        dV_dparam was half of an objective evaluation at C5)."""
+        x, p = np.array(x, dtype=np.float64), np.array(p, dtype=np.float64)
+        if self._ray is None:
+            self._ray = (self.ctx.empty((self.spin, self.npair), np.float64), self.ctx.empty((self.spin, self.npair), np.float64))
+        d_v0, d_v1 = self._ray
+        self._vemb_into(x, d_v0)
+        self._vemb_into(p, d_v1)
+
+        def phi(t):
+            t = float(np.asarray(t).ravel()[0])                   # the Nelder-Mead fallback passes a 1-vector
+            self.nfev += 1
+            return self._forward(x + t * p, ray=(d_v0, d_v1, t))[3] / sqrt(self.spin)
+        return phi
 
     # -- gradient ----------------------------------------------------------------------------------
     def _kmat_dev(self, occ, mu):
@@ -570,6 +613,8 @@ class EmbFitDevice(object):
         self.ngev += 1
         ctx, spin, nb, nidx = self.ctx, self.spin, self.nb, self.nidx
         ew, occ, mu, val, d_Vt = self._forward(param)
+        if ew is None:                                                     # T = 0 forward pass: levels and occupations are in HBM
+            ew, occ = self.d_w.get(), self.d_occ.get()
         self._ew = ew
         ff = self._kmat_dev(occ, mu)
         for s in range(spin):                                              # C = ev[fit_idx]^T : (orbital m, fitted index a)
@@ -666,6 +711,8 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
     if kwargs.get("num_grad", False):
         log.warn("You are using numerical gradient...")
         gradfunc = None
+    if kwargs.get("ray_objective", True):
+        kwargs = dict(kwargs, ray_fn=fit.errfunc_ray)
     param, err_end, pattern, gnorm_res = minimize(errfunc, vcor.param, MaxIter, gradfunc, **kwargs)
     vcor.update(param)
     log.info("Minimizer converge pattern: %d ", pattern)

@@ -288,6 +288,64 @@ def test_eigh_jacobi(ctx, n, batch):
         assert sw2.value < sw.value
 
 
+@pytest.mark.parametrize("n,batch", [(7, 2), (33, 3), (100, 2), (256, 2), (300, 1)])
+@pytest.mark.parametrize("kind", ["random", "degenerate", "cluster"])
+def test_eigh_warm_refinement(ctx, n, batch, kind):
+    """Warm start of dmk_eigh_jacobi_real: the refinement fast path (sweeps_out == 0) and its fall-back to the sweeps both
+    return a basis that passes the same budgets as the cold solver, for perturbations from rounding size to O(1) rotations,
+    exactly repeated levels that the perturbation splits, and a tight cluster."""
+    import ctypes as C
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(7 * n + batch)
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    if kind == "random":
+        A = rng.standard_normal((batch, n, n))
+        A = A + A.transpose(0, 2, 1)
+    else:
+        lam = np.repeat(np.linspace(-3, 3, (n + 1) // 2), 2)[:n] if kind == "degenerate" else np.linspace(-3, 3, n)
+        if kind == "cluster":
+            lam[: max(n // 4, 2)] = -3 + 1e-7 * np.arange(max(n // 4, 2))
+        A = np.stack([Q @ np.diag(lam) @ Q.T] * batch)
+        A = 0.5 * (A + A.transpose(0, 2, 1))
+    dA, dw, dV = ctx.to_device(A), ctx.empty((batch, n), np.float64), ctx.empty((batch, n, n), np.float64)
+    sw = C.c_int()
+    ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, n, batch, dA.ptr, None, dw.ptr, dV.ptr, C.byref(sw)))
+    V0 = dV.get()
+    fast = 0
+    for eps in (0.0, 1e-9, 1e-6, 1e-4, 1e-2):
+        P = eps * rng.standard_normal((batch, n, n))
+        A2 = A + P + P.transpose(0, 2, 1)
+        dA2, dV0 = ctx.to_device(A2), ctx.to_device(V0)
+        ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, n, batch, dA2.ptr, dV0.ptr, dw.ptr, dV0.ptr, C.byref(sw)))   # output aliases V0
+        w, V = dw.get(), dV0.get()
+        fast += sw.value == 0
+        scale = max(1.0, np.abs(A2).max() * n ** 0.5)
+        for b in range(batch):
+            assert np.abs(w[b] - np.linalg.eigvalsh(A2[b])).max() < 1e-12 * scale, (kind, eps)
+            assert np.abs(V[b] @ V[b].T - np.eye(n)).max() < 1e-13, (kind, eps)
+            assert np.abs(V[b] @ A2[b] @ V[b].T - np.diag(w[b])).max() < 1e-12 * scale, (kind, eps)
+            assert (np.diff(w[b]) >= 0).all()
+    if kind == "random":
+        assert fast >= 3            # rounding-size and small perturbations of a generic matrix take the fast path
+
+
+def test_eigh_warm_refinement_nonfinite(ctx):
+    """A NaN in the matrix must not be accepted by the fast path (fmax would drop it): the call falls through to the
+    sweeps, which report no convergence."""
+    import ctypes as C
+    from libdmet_preview_amd._lib import lib, DmkError
+    n = 64
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((1, n, n))
+    A = A + A.transpose(0, 2, 1)
+    dA, dw, dV = ctx.to_device(A), ctx.empty((1, n), np.float64), ctx.empty((1, n, n), np.float64)
+    ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, n, 1, dA.ptr, None, dw.ptr, dV.ptr, None))
+    A[0, 5, 7] = A[0, 7, 5] = np.nan
+    dA2 = ctx.to_device(A)
+    with pytest.raises(DmkError):
+        ctx.check(lib.dmk_eigh_jacobi_real(ctx.h, n, 1, dA2.ptr, dV.ptr, dw.ptr, dV.ptr, None))
+
+
 def test_eigh_jacobi_rejects(ctx):
     import ctypes as C
     from libdmet_preview_amd._lib import lib, DmkError
