@@ -53,6 +53,9 @@ struct EighArgs {
     double2 *tau;           // batch x n
     double *ws2;            // batch x 7 x n x n: lane-major scratch of the inverse iteration
     int *status;            // device flag: 2 = an eigenvector of the tridiagonal failed its residual check after the retries
+    int *rank_out;          // batch x n: when set, phase 3 stops after the sort (w written, rank stored here) and the
+                            // back-transformation is done by backtransform_kernel (eigh_tridiag.hip)
+    int skip_tridiag;       // d, e, tau, Vh were produced by the CU-resident kernel (eigh_tridiag.hip): phases 0 and 1 are skipped
     int inject;             // fault injection (tests): every `inject`-th eigenvector is treated as failed and goes through the repair path
 };
 
@@ -81,6 +84,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
 
     long long tphase[5];
     tphase[0] = wall_clock64();
+    tphase[1] = tphase[0];
+    if (!g.skip_tridiag) {
     // ---- phase 0: W = Hermitian completion of the lower triangle (+ add), Zt = I ------------
     {
         const double *addm = g.add ? g.add + (size_t)(g.add_group > 0 ? b / g.add_group : 0) * nn : nullptr;
@@ -298,6 +303,7 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
         if (n >= 1) tau[n - 1] = make_double2(0.0, 0.0);
     }
     __syncthreads();
+    }   // !skip_tridiag
 
     tphase[2] = wall_clock64();
     // ---- phase 2: eigenpairs of the real tridiagonal T = (d, e) by bisection + inverse iteration ----------------------
@@ -626,8 +632,17 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
         }
         rank[j] = rk;
         g.w[(size_t)b * n + rk] = dj;
+        if (g.rank_out) g.rank_out[(size_t)b * n + j] = rk;
     }
     __syncthreads();
+    if (g.rank_out) {
+        if (b == 0 && tid == 0) {
+            long long *tp = reinterpret_cast<long long *>(g.status + 2);
+            tphase[4] = wall_clock64();
+            for (int q = 0; q < 4; ++q) tp[q] = tphase[q + 1] - tphase[q];
+        }
+        return;
+    }
 
     constexpr int E = (R <= 4) ? 4 : 1;
     for (int m0 = wave * E; m0 < n; m0 += NW * E) {
@@ -698,13 +713,19 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
     }
 }
 
+}  // namespace
+int launch_tridiag_resident(dmk_ctx *ctx, int n, int batch, const void *A, const double *add, int add_group, void *Vh, void *tau,
+                            double *d, double *e);
+int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const void *Vh, const void *tau, const int *rank, void *Vt);
+namespace {
+
 int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group, double *w,
                 void *Vt, int v_real) {
     if (n <= 0 || batch <= 0) return DMK_OK;
     // one workgroup per matrix: the LDS carve (80 n bytes) and the per-lane column slices (64 R columns) bound n
     if (n > 2000) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh: n = %d exceeds the supported maximum of 2000", n);
     const size_t nn = (size_t)n * n;
-    const size_t per = nn * (16 + 16 + 8 + 56) + (size_t)n * (8 + 8 + 16);
+    const size_t per = nn * (16 + 16 + 8 + 56) + (size_t)n * (8 + 8 + 16 + 8);
     const size_t total = per * batch + 256;
     void *ws = nullptr;
     int rc = dmk_scratch(ctx, total, &ws);
@@ -724,13 +745,25 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     g.Zt = reinterpret_cast<double *>(p); p += nn * 8 * batch;
     g.d = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
     g.e = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
-    g.ws2 = reinterpret_cast<double *>(p);
+    g.ws2 = reinterpret_cast<double *>(p); p += nn * 56 * batch;
+    int *rank_ws = reinterpret_cast<int *>(p);
     DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
+    g.skip_tridiag = 0;
+    g.rank_out = nullptr;
     // reflector rows are only partially written; clear so that masked lanes read zeros
     DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
     const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64 + (n <= 256 ? (size_t)NW * n * 16 + 16 : 0);
     {
         FamScope fs(ctx, DMK_FAM_EIGH);
+        // complex matrices of the north-star size: tridiagonalisation with the matrix resident in LDS + registers (one 512-thread
+        // workgroup per matrix, HBM read once); this kernel then only does the tridiagonal eigenpairs and the back-transformation
+        static const bool resident_on = !(getenv("DMK_EIGH_RESIDENT") && atoi(getenv("DMK_EIGH_RESIDENT")) == 0);
+        if (resident_on && !a_real && n > 64) {
+            const int rt = launch_tridiag_resident(ctx, n, batch, A, add, add_group, g.Vh, g.tau, g.d, g.e);
+            if (rt < 0) return rt;
+            g.skip_tridiag = rt;
+            if (rt && !v_real) g.rank_out = rank_ws;         // back-transformation by the lane-per-eigenvector kernel
+        }
         // HR (rows in flight per wave in the Householder matrix-vector product): see the kernel
         const bool few = batch <= 256;
         const void *fn = n <= 64 ? (few ? reinterpret_cast<const void *>(eigh_kernel<1, 4>) : reinterpret_cast<const void *>(eigh_kernel<1, 2>))
@@ -750,6 +783,10 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
             hipLaunchKernelGGL((eigh_kernel<32, 2>), dim3(batch), dim3(NT), lds, ctx->stream, g);
         }
         DMK_CHECK_LAUNCH(ctx);
+        if (g.rank_out) {
+            const int rb = launch_backtransform(ctx, n, batch, g.Zt, g.Vh, g.tau, g.rank_out, Vt);
+            if (rb < 0) return rb;
+        }
     }
     int status = 0;
     DMK_HIP(ctx, hipMemcpyAsync(&status, g.status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
