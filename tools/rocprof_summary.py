@@ -42,7 +42,8 @@ def pmc(db):
 # first match wins: the multi-CU Jacobi solver must not be counted as the batched QL eigensolver, and only the LDS-DMA
 # contraction kernel is the "dgemm" of the ERI transform (dgemm_tn_acc_kernel also serves small Gram matrices)
 FAMILY = [("dgemm_tn_acc_dma_kernel", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"), ("half2_tab_kernel", "zgemm_half2"),
-          ("philox_block", "philox"), ("jacobi_eigh_kernel", "jacobi_eigh"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"),
+          ("philox_block", "philox"), ("jacobi_eigh_kernel", "jacobi_eigh"), ("tridiag_resident_kernel", "eigh_tridiag"),
+          ("backtransform_kernel", "eigh_backtransform"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"),
           ("jk_k_kernel", "jk_k"), ("gemv2_kernel", "gemv2")]
 
 
