@@ -520,7 +520,9 @@ def main():
         coll = tinfo.get("_collected")
         coll = coll if isinstance(coll, dict) else {}
         sha_now, sha_rec = kernel_source_sha(), coll.get("kernel_source_sha")
-        fresh = sha_rec == sha_now
+        # ... and the workload whose launches were counted: bytes per launch of C5 launches say nothing about another shape
+        same_shape = coll.get("workload", "C5") == args.workload
+        fresh = sha_rec == sha_now and same_shape
         traffic = tinfo.get(dom, {}).get("hbm_bytes_per_launch") if fresh else None
         eri_sec = sum(fam_out[k]["ms_total"] for k in fam_flops if k in fam_out) * 1e-3
         roofline = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -528,8 +530,8 @@ def main():
                     "traffic_note": ("HBM bytes per launch from rocprofv3 PMC (profiles/traffic_latest.json: FETCH_SIZE x2 + WRITE_SIZE, "
                                      "separate --pmc passes), collected on commit %s, kernel sources %s"
                                      % (coll.get("commit"), sha_rec)) if fresh else
-                                    ("null: profiles/traffic_latest.json was collected on kernel sources %s, this run is %s"
-                                     % (sha_rec, sha_now)),
+                                    ("null: profiles/traffic_latest.json was collected on kernel sources %s and workload %s, this run "
+                                     "is %s on %s" % (sha_rec, coll.get("workload", "C5"), sha_now, args.workload)),
                     "avg_launch_ms": fam_out[dom]["ms_avg"],
                     "executed_gflop_per_launch": fam_out[dom]["executed_gflop_per_launch"],
                     "algorithmic_tflops": fam_out[dom]["algorithmic_tflops"],

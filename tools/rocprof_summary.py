@@ -82,7 +82,7 @@ def traffic_json(dbs, out):
         commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except Exception:
         commit = None
-    acc["_collected"] = {"kernel_source_sha": kernel_source_sha(), "commit": commit,
+    acc["_collected"] = {"kernel_source_sha": kernel_source_sha(), "commit": commit, "workload": "C5",
                          "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
                                 "--no-cpu-baseline --no-parity --no-full-config --steps 1 --warmup 0; tools/rocprof_summary.py --traffic-json"}
     json.dump(acc, open(out, "w"), indent=1)
