@@ -521,7 +521,7 @@ def main():
         coll = coll if isinstance(coll, dict) else {}
         sha_now, sha_rec = kernel_source_sha(), coll.get("kernel_source_sha")
         # ... and the workload whose launches were counted: bytes per launch of C5 launches say nothing about another shape
-        same_shape = coll.get("workload", "C5") == args.workload
+        same_shape = coll.get("workload", "C5") == a.workload
         fresh = sha_rec == sha_now and same_shape
         traffic = tinfo.get(dom, {}).get("hbm_bytes_per_launch") if fresh else None
         eri_sec = sum(fam_out[k]["ms_total"] for k in fam_flops if k in fam_out) * 1e-3
@@ -531,7 +531,7 @@ def main():
                                      "separate --pmc passes), collected on commit %s, kernel sources %s"
                                      % (coll.get("commit"), sha_rec)) if fresh else
                                     ("null: profiles/traffic_latest.json was collected on kernel sources %s and workload %s, this run "
-                                     "is %s on %s" % (sha_rec, coll.get("workload", "C5"), sha_now, args.workload)),
+                                     "is %s on %s" % (sha_rec, coll.get("workload", "C5"), sha_now, a.workload)),
                     "avg_launch_ms": fam_out[dom]["ms_avg"],
                     "executed_gflop_per_launch": fam_out[dom]["executed_gflop_per_launch"],
                     "algorithmic_tflops": fam_out[dom]["algorithmic_tflops"],
