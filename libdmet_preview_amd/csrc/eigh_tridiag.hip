@@ -354,6 +354,304 @@ __global__ __launch_bounds__(TD_NT, 1) void tridiag_resident_kernel(const TdArgs
 }
 
 
+// ---- K1a', tile layout: the same tridiagonalisation with the triangle as 16 x 16 tiles in MFMA ACCUMULATOR layout ---------------
+// The row-layout kernel above is bound by its own instruction stream (8 f64 FMAs per complex element and step on the VALU plus one
+// 64-lane reduction per row) while the matrix cores idle.  Here the lower triangle is 91 complex tiles (13 tile rows, n <= 208);
+// element (R, C) of a tile sits in lane C + 16 (R % 4), register R / 4 -- the D layout of v_mfma_f64_16x16x4_f64 -- so that
+//   * the rank-2 update A22 -= v w^H + w v^H is ONE MFMA per real tile: K = 4 = {v_r, v_i, w_r, w_i} (operands from three small LDS
+//     tables written once per step), no VALU work at all;
+//   * the row sums of the product are accumulated over the tiles of a row segment and reduced across 16 lanes once per FOUR rows
+//     (a transposed DPP reduction of eight values, 54 instructions per segment), the column sums across the four lane groups;
+//   * 72 tiles live in registers -- nine slots of 16 VGPRs per wave, runs of consecutive tiles of one tile row dealt to the waves
+//     so that every wave keeps work until the end (t3_tab, tools-generated) -- and the 19 tiles that retire first (tile rows
+//     0 .. 4 and the first tile of rows 5 .. 8) in LDS (ten register slots spill: 256 VGPRs + 196 B of scratch).
+// Both partial sums of a wave go into its own slice of `ypart` with LDS atomics (one writer per address and instruction, program
+// order within the wave: deterministic); four barriers per step.
+constexpr int T3_NT = 512, T3_NW = 8, T3_N = 208, T3_RS = 9, T3_LS = 3, T3_SL = T3_RS + T3_LS;
+
+struct T3Tab {
+    signed char I[T3_NW][T3_SL], J[T3_NW][T3_SL];
+    unsigned char last[T3_NW][T3_SL];          // the tile closes its row segment (flush the row sums)
+};
+__constant__ T3Tab t3_tab = {
+    {{ 5,  5, 10, 10, 10, 11, 11, 11, 11,  7, -1, -1},
+     { 6,  6,  9,  9,  9,  9,  9,  9,  9,  4,  3,  5},
+     { 5,  5,  5,  8,  8,  8,  8, 11, 11,  4,  1,  2},
+     { 7,  7,  7, 10, 10, 10, 10, 12, 12,  4,  6, -1},
+     { 6,  6,  9,  9,  9, 12, 12, 12, 12,  4,  2,  1},
+     { 8,  8,  8,  8, 11, 11, 11, 12, 12,  3,  4,  2},
+     { 7,  7,  7,  7, 12, 12, 12, 12, 12,  8, -1, -1},
+     { 6,  6, 10, 10, 10, 10, 11, 11, 11,  3,  3,  0}},
+    {{ 1,  2,  8,  9, 10,  3,  4,  5,  6,  0, -1, -1},
+     { 1,  2,  3,  4,  5,  6,  7,  8,  9,  1,  0,  0},
+     { 3,  4,  5,  1,  2,  3,  4, 10, 11,  2,  0,  0},
+     { 1,  2,  3,  4,  5,  6,  7,  9, 10,  0,  0, -1},
+     { 3,  4,  0,  1,  2,  5,  6,  7,  8,  4,  2,  1},
+     { 5,  6,  7,  8,  0,  1,  2,  3,  4,  3,  3,  1},
+     { 4,  5,  6,  7,  0,  1,  2, 11, 12,  0, -1, -1},
+     { 5,  6,  0,  1,  2,  3,  7,  8,  9,  2,  1,  0}},
+    {{ 0,  1,  0,  0,  1,  0,  0,  0,  1,  1,  0,  0},
+     { 0,  1,  0,  0,  0,  1,  0,  0,  1,  1,  1,  1},
+     { 0,  0,  1,  0,  0,  0,  1,  0,  1,  1,  1,  1},
+     { 0,  0,  1,  0,  0,  0,  1,  0,  1,  1,  1,  0},
+     { 0,  1,  0,  0,  1,  0,  0,  0,  1,  1,  1,  1},
+     { 0,  0,  0,  1,  0,  0,  1,  0,  1,  1,  1,  1},
+     { 0,  0,  0,  1,  0,  0,  1,  0,  1,  1,  0,  0},
+     { 0,  1,  0,  0,  0,  1,  0,  0,  1,  1,  1,  1}}};
+
+constexpr size_t T3_LDS = (size_t)T3_NW * T3_LS * 256 * 16        // LDS tiles [wave][slot][r][lane] c128
+                          + (size_t)(2 * T3_N + T3_N + T3_N + T3_NW * T3_N) * 16   // xbuf[2], pbuf, vbuf, ypart[8]
+                          + (size_t)3 * T3_N * 4 * 8;             // AR, AI, BB operand tables
+
+__global__ __launch_bounds__(T3_NT, 1) void tridiag_tiles_kernel(const TdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char td_smem[];
+    const int n = g.n, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = lane & 15, q = lane >> 4;
+    double2 *ltile = reinterpret_cast<double2 *>(td_smem);                 // [8][T3_LS][4][64]
+    double2 *xbuf = ltile + T3_NW * T3_LS * 256;                            // [2][T3_N]
+    double2 *pbuf = xbuf + 2 * T3_N;
+    double2 *vbuf = pbuf + T3_N;                                            // [T3_N] reflector of the step
+    double2 *ypart = vbuf + T3_N;                                           // [8][T3_N]
+    double *AR = reinterpret_cast<double *>(ypart + T3_NW * T3_N);          // [T3_N][4]
+    double *AI = AR + 4 * T3_N, *BB = AI + 4 * T3_N;
+    const size_t nn = (size_t)n * n;
+    const double2 *A = g.A + b * nn;
+    const double *addm = g.add ? g.add + (size_t)(g.add_group > 0 ? b / g.add_group : 0) * nn : nullptr;
+    double2 *Vh = g.Vh + b * nn;
+    double2 *tau = g.tau + (size_t)b * n;
+    double *d = g.d + (size_t)b * n, *e = g.e + (size_t)b * n;
+
+    auto load_a = [&](int i, int j) -> double2 {           // Hermitian element (i, j) from the lower triangle (+ add); zero padding
+        if (i >= n || j >= n) return make_double2(0.0, 0.0);
+        const int hi = i >= j ? i : j, lo = i >= j ? j : i;
+        double2 v = A[(size_t)hi * n + lo];
+        if (i < j) v.y = -v.y;
+        if (i == j) v.y = 0.0;
+        if (addm) v.x += addm[(size_t)hi * n + lo];
+        return v;
+    };
+    // this wave's tile list, read once (scalar registers; every later use is a compile-time slot index)
+    int tcode[T3_SL];                                      // I | J << 8 | last << 16, or -1
+#pragma unroll
+    for (int s = 0; s < T3_SL; ++s) {
+        const int I = t3_tab.I[w][s], J = t3_tab.J[w][s], L = t3_tab.last[w][s];
+        tcode[s] = __builtin_amdgcn_readfirstlane(I < 0 ? -1 : (I | (J << 8) | (L << 16)));
+    }
+#define T3_I(s) (tcode[s] < 0 ? -1 : (tcode[s] & 0xff))
+#define T3_J(s) (tcode[s] < 0 ? -1 : ((tcode[s] >> 8) & 0xff))
+#define T3_L(s) (tcode[s] >= 0 && ((tcode[s] >> 16) & 1))
+    d4_t tre[T3_RS], tim[T3_RS];
+#pragma unroll
+    for (int s = 0; s < T3_SL; ++s) {
+        const int I = T3_I(s), J = T3_J(s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double2 v = I >= 0 ? load_a(16 * I + q + 4 * r, 16 * J + C) : make_double2(0.0, 0.0);
+            if (s < T3_RS) { tre[s < T3_RS ? s : 0][r] = v.x; tim[s < T3_RS ? s : 0][r] = v.y; }
+            else ltile[((w * T3_LS + (s - T3_RS)) * 4 + r) * 64 + lane] = v;
+        }
+    }
+    for (int i = tid; i < 2 * T3_N; i += T3_NT) xbuf[i] = (i >= 1 && i < n) ? load_a(i, 0) : make_double2(0.0, 0.0);
+    for (int i = tid; i < T3_NW * T3_N; i += T3_NT) ypart[i] = make_double2(0.0, 0.0);
+    if (tid == 0) d[0] = load_a(0, 0).x;
+    __syncthreads();
+
+    for (int k = 0; k + 1 < n; ++k) {
+        const double2 *x = xbuf + (k & 1) * T3_N;
+        double2 *xn = xbuf + ((k + 1) & 1) * T3_N;
+        double part = 0.0;
+        for (int j = k + 2 + lane; j < n; j += 64) {
+            const double2 t = x[j];
+            part += t.x * t.x + t.y * t.y;
+        }
+        const double xnorm2 = dmk_wave_sum(part);
+        const double2 alpha = x[k + 1];
+        double2 tk = make_double2(0.0, 0.0), scale = make_double2(0.0, 0.0);
+        double beta = alpha.x;
+        if (!(xnorm2 == 0.0 && alpha.y == 0.0)) {
+            const double nrm = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xnorm2);
+            beta = alpha.x >= 0.0 ? -nrm : nrm;
+            tk = make_double2((beta - alpha.x) / beta, -alpha.y / beta);
+            const double dr = alpha.x - beta, di = alpha.y;
+            const double den = dr * dr + di * di;
+            scale = make_double2(dr / den, -di / den);
+        }
+        const bool active = !(tk.x == 0.0 && tk.y == 0.0);
+        // v_i: 1 at k + 1, x_i / (alpha - beta) below, 0 elsewhere -- once per step into LDS (the tiles read it ~25 times per wave)
+        if (tid < T3_N) {
+            double2 v = make_double2(0.0, 0.0);
+            if (tid == k + 1) v = make_double2(1.0, 0.0);
+            else if (tid > k + 1 && tid < n) v = td_cmul(x[tid], scale);
+            vbuf[tid] = v;
+        }
+        __syncthreads();
+        auto v_of = [&](int i) -> double2 { return vbuf[i]; };
+        if (w == (k & 7)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 64 * c + lane;
+                if (j > k && j < n) Vh[(size_t)k * n + j] = v_of(j);
+            }
+            if (lane == 0) {
+                tau[k] = tk;
+                e[k] = beta;
+            }
+        }
+        double2 *yw = ypart + w * T3_N;
+        if (active) {
+            // ---- p = tau A22 v ----
+            double2 racc[4], u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) racc[r] = make_double2(0.0, 0.0);
+            bool seg_open = false;
+#pragma unroll
+            for (int s = 0; s < T3_SL; ++s) {
+                const int I = T3_I(s), J = T3_J(s);
+                const bool live = I >= 0 && 16 * J + 15 > k && 16 * J < n && 16 * I < n;
+                if (live) {
+                    double2 T[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (s < T3_RS) T[r] = make_double2(tre[s < T3_RS ? s : 0][r], tim[s < T3_RS ? s : 0][r]);
+                        else T[r] = ltile[((w * T3_LS + (s - T3_RS)) * 4 + r) * 64 + lane];
+                    }
+                    if (!seg_open) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) u[r] = v_of(16 * I + q + 4 * r);
+                        seg_open = true;
+                    }
+                    const double2 vc = v_of(16 * J + C);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        racc[r].x = fma(T[r].x, vc.x, racc[r].x); racc[r].x = fma(-T[r].y, vc.y, racc[r].x);
+                        racc[r].y = fma(T[r].x, vc.y, racc[r].y); racc[r].y = fma(T[r].y, vc.x, racc[r].y);
+                    }
+                    if (I > J) {                           // Hermitian counterpart: y_col += conj(a) v_row
+                        double cr = 0.0, ci = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            cr = fma(T[r].x, u[r].x, cr); cr = fma(T[r].y, u[r].y, cr);
+                            ci = fma(T[r].x, u[r].y, ci); ci = fma(-T[r].y, u[r].x, ci);
+                        }
+                        const bool g1 = q & 1;             // lane groups 0 / 2 collect re, 1 / 3 im
+                        double val = (g1 ? ci : cr) + __shfl_xor(g1 ? cr : ci, 16, 64);
+                        val += __shfl_xor(val, 32, 64);
+                        if (q < 2) atomicAdd(reinterpret_cast<double *>(yw + 16 * J + C) + q, val);
+                    }
+                }
+                if (T3_L(s) && seg_open) {
+                    // eight values (four rows, re / im) over the 16 lanes of each lane group
+                    const bool b0 = lane & 1, b1 = lane & 2;
+                    double a_[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        a_[r] = (b0 ? racc[r].y : racc[r].x) + td_dpp<0xb1>(b0 ? racc[r].x : racc[r].y);      // quad_perm [1,0,3,2]
+                    double p0 = (b1 ? a_[1] : a_[0]) + td_dpp<0x4e>(b1 ? a_[0] : a_[1]);                         // quad_perm [2,3,0,1]
+                    double p1 = (b1 ? a_[3] : a_[2]) + td_dpp<0x4e>(b1 ? a_[2] : a_[3]);
+                    p0 += td_dpp<0x124>(p0); p0 += td_dpp<0x128>(p0);                                            // row_ror 4, 8
+                    p1 += td_dpp<0x124>(p1); p1 += td_dpp<0x128>(p1);
+                    // lane (b1, b0) of quad 0 holds row b1, of quad 1 row 2 + b1; component b0
+                    if (C < 8) {
+                        const int row = 16 * I + q + 4 * (((C >> 2) << 1) + (b1 ? 1 : 0));   // D layout: register r holds row q + 4 r
+                        atomicAdd(reinterpret_cast<double *>(yw + row) + (b0 ? 1 : 0), (C >> 2) ? p1 : p0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) racc[r] = make_double2(0.0, 0.0);
+                    seg_open = false;
+                }
+            }
+            __syncthreads();
+            if (tid < T3_N) {
+                double2 y = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int qq = 0; qq < T3_NW; ++qq) {
+                    const double2 o = ypart[qq * T3_N + tid];
+                    y.x += o.x;
+                    y.y += o.y;
+                    ypart[qq * T3_N + tid] = make_double2(0.0, 0.0);
+                }
+                pbuf[tid] = (tid > k && tid < n) ? td_cmul(tk, y) : make_double2(0.0, 0.0);
+            }
+            __syncthreads();
+            double pr = 0.0, pi = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 64 * c + lane;
+                if (j > k && j < n) {
+                    const double2 t = td_cmulc(pbuf[j], v_of(j));
+                    pr += t.x;
+                    pi += t.y;
+                }
+            }
+            pr = dmk_wave_sum(pr);
+            pi = dmk_wave_sum(pi);
+            double2 a2 = td_cmul(tk, make_double2(pr, pi));
+            a2.x *= -0.5;
+            a2.y *= -0.5;
+            if (tid < T3_N) {
+                const double2 v = v_of(tid), av = td_cmul(a2, v);
+                const double2 wv = make_double2(pbuf[tid].x + av.x, pbuf[tid].y + av.y);
+                double *ar = AR + 4 * tid, *ai = AI + 4 * tid, *bb = BB + 4 * tid;
+                ar[0] = -v.x; ar[1] = -v.y; ar[2] = -wv.x; ar[3] = -wv.y;      // Re(A) -= v_r w_r + v_i w_i + w_r v_r + w_i v_i
+                ai[0] = -v.y; ai[1] = v.x; ai[2] = -wv.y; ai[3] = wv.x;        // Im(A) -= v_i w_r - v_r w_i + w_i v_r - w_r v_i
+                bb[0] = wv.x; bb[1] = wv.y; bb[2] = v.x; bb[3] = v.y;
+            }
+            __syncthreads();
+        }
+        // ---- A22 -= v w^H + w v^H on the matrix cores; capture of column k + 1 and d[k + 1] ----
+        const int jn = k + 1, Jn = jn >> 4, Cn = jn & 15;
+#pragma unroll
+        for (int s = 0; s < T3_SL; ++s) {
+            const int I = T3_I(s), J = T3_J(s);
+            if (I >= 0 && 16 * J + 15 > k && 16 * J < n && 16 * I < n) {
+                d4_t re, im;
+                if (s < T3_RS) { re = tre[s < T3_RS ? s : 0]; im = tim[s < T3_RS ? s : 0]; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double2 t = ltile[((w * T3_LS + (s - T3_RS)) * 4 + r) * 64 + lane];
+                        re[r] = t.x;
+                        im[r] = t.y;
+                    }
+                }
+                if (active) {
+                    const double are = AR[4 * (16 * I + C) + q], aim = AI[4 * (16 * I + C) + q], bop = BB[4 * (16 * J + C) + q];
+                    re = __builtin_amdgcn_mfma_f64_16x16x4f64(are, bop, re, 0, 0, 0);
+                    im = __builtin_amdgcn_mfma_f64_16x16x4f64(aim, bop, im, 0, 0, 0);
+                    if (I == J) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (q + 4 * r == C) im[r] = 0.0;
+                    }
+                    if (s < T3_RS) { tre[s < T3_RS ? s : 0] = re; tim[s < T3_RS ? s : 0] = im; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ltile[((w * T3_LS + (s - T3_RS)) * 4 + r) * 64 + lane] = make_double2(re[r], im[r]);
+                    }
+                }
+                if (J == Jn && C == Cn) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * I + q + 4 * r;
+                        if (row > jn && row < n) xn[row] = make_double2(re[r], im[r]);
+                        else if (row == jn) d[jn] = re[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        e[n - 1] = 0.0;
+        tau[n - 1] = make_double2(0.0, 0.0);
+    }
+}
+
+#undef T3_I
+#undef T3_J
+#undef T3_L
+
 // ---- K1c: back-transformation y_m = H_0 ... H_{n-2} z_m, 16 eigenvectors per wave, components IN the lanes -------------------
 // Phase 3 of eigh.hip keeps four eigenvectors per wave with the lanes along the components: every reflector costs two wave
 // reductions per eigenvector (the dot product v^H y), 160 of its ~290 instructions.  Here lane l of a wave owns eigenvector
@@ -473,9 +771,14 @@ int launch_tridiag_resident(dmk_ctx *ctx, int n, int batch, const void *A, const
     if (!attr_set) {
         DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_resident_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)TD_LDS));
+        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_tiles_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(tridiag_resident_kernel, dim3(batch), dim3(TD_NT), TD_LDS, ctx->stream, g);
+    // read per call (tests run both layouts in one process): the tile layout is the default, DMK_EIGH_TILES=0 selects the row layout
+    const bool tiles_on = !(getenv("DMK_EIGH_TILES") && atoi(getenv("DMK_EIGH_TILES")) == 0);
+    if (tiles_on) hipLaunchKernelGGL(tridiag_tiles_kernel, dim3(batch), dim3(T3_NT), T3_LDS, ctx->stream, g);
+    else hipLaunchKernelGGL(tridiag_resident_kernel, dim3(batch), dim3(TD_NT), TD_LDS, ctx->stream, g);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }

@@ -354,6 +354,41 @@ def test_eri_properties_large(ctx):
 # K1 / K2: eigensolver, density, HF
 # ---------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("layout", ["tiles", "rows"])
+@pytest.mark.parametrize("n,batch", [(65, 3), (112, 2), (113, 2), (136, 5), (199, 2), (200, 7)])
+def test_eigh_resident_layouts(ctx, monkeypatch, n, batch, layout):
+    """The two CU-resident Householder layouts of the complex eigensolver for 64 < n <= 200 -- 16 x 16 tiles updated on the matrix
+    cores (default) and rows across the lanes (DMK_EIGH_TILES=0) -- against LAPACK, including a repeated level, a block-diagonal
+    matrix (zero reflectors inside the sweep) and the shared real shift matrix."""
+    from libdmet_preview_amd._lib import lib
+    if layout == "rows":
+        monkeypatch.setenv("DMK_EIGH_TILES", "0")
+    else:
+        monkeypatch.delenv("DMK_EIGH_TILES", raising=False)
+    rng = np.random.default_rng(n * 10 + batch)
+    A = rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))
+    A = A + A.conj().transpose(0, 2, 1)
+    A[0, :, 5] = A[0, :, 4]                                # a repeated row / column pair: one (near-)zero level split
+    A[0, 5, :] = A[0, 4, :]
+    A[0] = 0.5 * (A[0] + A[0].conj().T)
+    A[1, n // 2:, : n // 2] = 0.0                          # block diagonal
+    A[1, : n // 2, n // 2:] = 0.0
+    add = rng.standard_normal((n, n))
+    add = add + add.T
+    dA, dadd = ctx.to_device(A, np.complex128), ctx.to_device(add[None])
+    dw, dV = ctx.empty((batch, n), np.float64), ctx.empty((batch, n, n), np.complex128)
+    ctx.check(lib.dmk_eigh_batched(ctx.h, n, batch, dA.ptr, dadd.ptr, batch, dw.ptr, dV.ptr))
+    w, V = dw.get(), dV.get()
+    for b in range(batch):
+        M = A[b] + add
+        wr = np.linalg.eigvalsh(M)
+        scale = np.abs(wr).max()
+        assert np.abs(w[b] - wr).max() < 1e-12 * scale
+        Vb = V[b]                                           # rows = eigenvectors
+        assert np.abs(Vb.conj() @ Vb.T - np.eye(n)).max() < 1e-12
+        assert np.abs(Vb.conj() @ M @ Vb.T - np.diag(w[b])).max() < 1e-11 * scale
+
+
 @pytest.mark.parametrize("n,batch", [(1, 3), (2, 5), (3, 4), (10, 6), (33, 3), (64, 2), (65, 2), (200, 3)])
 def test_eigh_batched_random(ctx, n, batch):
     from libdmet_preview_amd.routine import mfd
