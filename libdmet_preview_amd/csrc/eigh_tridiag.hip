@@ -507,7 +507,10 @@ __global__ __launch_bounds__(T3_NT, 1) void tridiag_tiles_kernel(const TdArgs g)
             bool seg_open = false;
 #pragma unroll
             for (int s = 0; s < T3_SL; ++s) {
-                const int I = T3_I(s), J = T3_J(s);
+                int code = tcode[s];
+                asm volatile("" : "+s"(code));             // opaque: offsets derived from the tile coordinates are recomputed, not
+                const int I = code < 0 ? -1 : (code & 0xff), J = code < 0 ? -1 : ((code >> 8) & 0xff);   // hoisted and spilled
+                const bool last_of_seg = code >= 0 && ((code >> 16) & 1);
                 const bool live = I >= 0 && 16 * J + 15 > k && 16 * J < n && 16 * I < n;
                 if (live) {
                     double2 T[4];
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(T3_NT, 1) void tridiag_tiles_kernel(const TdArgs g)
                         if (q < 2) atomicAdd(reinterpret_cast<double *>(yw + 16 * J + C) + q, val);
                     }
                 }
-                if (T3_L(s) && seg_open) {
+                if (last_of_seg && seg_open) {
                     // eight values (four rows, re / im) over the 16 lanes of each lane group
                     const bool b0 = lane & 1, b1 = lane & 2;
                     double a_[4];
@@ -603,7 +606,9 @@ __global__ __launch_bounds__(T3_NT, 1) void tridiag_tiles_kernel(const TdArgs g)
         const int jn = k + 1, Jn = jn >> 4, Cn = jn & 15;
 #pragma unroll
         for (int s = 0; s < T3_SL; ++s) {
-            const int I = T3_I(s), J = T3_J(s);
+            int code = tcode[s];
+            asm volatile("" : "+s"(code));
+            const int I = code < 0 ? -1 : (code & 0xff), J = code < 0 ? -1 : ((code >> 8) & 0xff);
             if (I >= 0 && 16 * J + 15 > k && 16 * J < n && 16 * I < n) {
                 d4_t re, im;
                 if (s < T3_RS) { re = tre[s < T3_RS ? s : 0]; im = tim[s < T3_RS ? s : 0]; }
