@@ -490,7 +490,11 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
             inv_factor(j, lm);
             inv_seed(j, 0ull);
             double xm = inv_xmax(j);
-            for (int iter = 0; iter < 3; ++iter) xm = inv_solve(j, xm);
+            // two solves: the shift is an eigenvalue to rounding, so ONE step already leaves the eigenvector with relative error
+            // ~ eps |T| / gap and the second is the safety margin dstein's growth test usually stops at; every vector goes through
+            // the acceptance test of phase (e) below, which repairs the rare one that needed more (the third solve cost a quarter of
+            // the 5.9 GB this phase moves through its lane-major scratch)
+            for (int iter = 0; iter < 2; ++iter) xm = inv_solve(j, xm);
             inv_store(j, xm);
         }
         __syncthreads();
@@ -716,7 +720,8 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
 }  // namespace
 int launch_tridiag_resident(dmk_ctx *ctx, int n, int batch, const void *A, const double *add, int add_group, void *Vh, void *tau,
                             double *d, double *e);
-int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const void *Vh, const void *tau, const int *rank, void *Vt);
+int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const void *Vh, const void *tau, const int *rank, void *Vt,
+                         void *Tws);
 namespace {
 
 int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group, double *w,
@@ -750,8 +755,7 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
     g.skip_tridiag = 0;
     g.rank_out = nullptr;
-    // reflector rows are only partially written; clear so that masked lanes read zeros
-    DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
+
     const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64 + (n <= 256 ? (size_t)NW * n * 16 + 16 : 0);
     {
         FamScope fs(ctx, DMK_FAM_EIGH);
@@ -764,6 +768,9 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
             g.skip_tridiag = rt;
             if (rt && !v_real) g.rank_out = rank_ws;         // back-transformation by the lane-per-eigenvector kernel
         }
+        // single-kernel path: its reflector rows are only partially written; clear so that masked lanes read zeros (the resident
+        // kernels write complete rows)
+        if (!g.skip_tridiag) DMK_HIP(ctx, hipMemsetAsync(g.Vh, 0, nn * 16 * batch, ctx->stream));
         // HR (rows in flight per wave in the Householder matrix-vector product): see the kernel
         const bool few = batch <= 256;
         const void *fn = n <= 64 ? (few ? reinterpret_cast<const void *>(eigh_kernel<1, 4>) : reinterpret_cast<const void *>(eigh_kernel<1, 2>))
@@ -784,7 +791,7 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
         }
         DMK_CHECK_LAUNCH(ctx);
         if (g.rank_out) {
-            const int rb = launch_backtransform(ctx, n, batch, g.Zt, g.Vh, g.tau, g.rank_out, Vt);
+            const int rb = launch_backtransform(ctx, n, batch, g.Zt, g.Vh, g.tau, g.rank_out, Vt, g.W);   // W is idle on this path: T factors
             if (rb < 0) return rb;
         }
     }

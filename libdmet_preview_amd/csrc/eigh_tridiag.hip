@@ -137,7 +137,7 @@ __global__ __launch_bounds__(TD_NT, 1) void tridiag_resident_kernel(const TdArgs
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int j = 64 * c + lane;
-                if (j > k && j < n) Vh[(size_t)k * n + j] = vcol[c];
+                if (j < n) Vh[(size_t)k * n + j] = vcol[c];          // zeros up to the diagonal: the row is complete
             }
             if (lane == 0) {
                 tau[k] = tk;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(T3_NT, 1) void tridiag_tiles_kernel(const TdArgs g)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int j = 64 * c + lane;
-                if (j > k && j < n) Vh[(size_t)k * n + j] = v_of(j);
+                if (j < n) Vh[(size_t)k * n + j] = v_of(j);          // zeros up to the diagonal: the row is complete
             }
             if (lane == 0) {
                 tau[k] = tk;
@@ -762,6 +762,193 @@ __global__ __launch_bounds__(BT_NT, 1) void backtransform_kernel(const BtArgs g)
     }
 }
 
+// ---- K1d: blocked (compact WY) back-transformation on the matrix cores -------------------------------------------------------
+// Sixteen reflectors at a time: H_k0 ... H_k0+15 = I - V T V^H (T upper triangular, larft), so a block is applied as
+//     X = V^H Y,   X <- T X,   Y <- Y - V X
+// and with the register layout of K1c -- lane (e = l & 15, q = l >> 4) of a wave owns eigenvector e and, in register r of tile c,
+// component 16 c + q + 4 r -- every operand of the three products is already where v_mfma_f64_16x16x4_f64 wants it:
+//   * Y tile c IS an accumulator tile (rows = components, columns = eigenvectors), and register r' of tile c' is the B operand
+//     of the K chunk (components 4 t .. 4 t + 3, t = 4 c' + r') of X = V^H Y;
+//   * X comes out as an accumulator tile (rows = reflectors) whose register j is, in the same lane, the B operand of K chunk j
+//     (reflectors 4 j .. 4 j + 3) of T X and of V X: no cross-lane traffic at all;
+//   * the A operands (V^H, T, V) are read from LDS: the reflector block reflector-major with rows padded to 209 elements
+//     (conflict-free both along the reflectors and along the components), T padded to 17.
+// One LDS read per component and SIXTEEN reflectors instead of two per reflector; the T factors come from a small kernel.
+constexpr int WY_NB = 16, WY_LDV = 257, WY_NT = 64 * BT_NW, WY_NTILE = T3_N / 16;   // rows padded: conflict-free both ways, room for whole 64-lane DMA pieces
+
+struct WyArgs {
+    int n, batch, wgs_per_mat, nblk;
+    const double *Zt;
+    const double2 *Vh, *tau;
+    double2 *T;              // batch x nblk x 16 x 16
+    const int *rank;
+    double2 *Vt;
+};
+
+// T of every block of 16 reflectors (forward, columnwise: T_jj = tau_j, T(0:j, j) = -tau_j T(0:j, 0:j) (V(:, 0:j)^H v_j))
+__global__ __launch_bounds__(256) void wy_tfactor_kernel(const WyArgs g) {
+    __shared__ double2 gram[WY_NB][WY_NB + 1], Ts[WY_NB][WY_NB + 1];
+    __shared__ __attribute__((aligned(16))) double2 Vb[WY_NB][T3_N + 1];      // the block's reflector rows (one coalesced pass)
+    const int n = g.n, b = blockIdx.x / g.nblk, blk = blockIdx.x % g.nblk, k0 = WY_NB * blk;
+    const double2 *Vh = g.Vh + (size_t)b * n * n;
+    const double2 *tau = g.tau + (size_t)b * n;
+    {
+        double2 pre[WY_NB * T3_N / 256];                   // all thirteen loads of a thread in flight at once
+#pragma unroll
+        for (int u = 0; u < WY_NB * T3_N / 256; ++u) {
+            const int t = threadIdx.x + 256 * u, r = t / T3_N, i = t % T3_N, k = k0 + r;
+            pre[u] = (k + 1 < n && i > k && i < n) ? Vh[(size_t)k * n + i] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < WY_NB * T3_N / 256; ++u) {
+            const int t = threadIdx.x + 256 * u;
+            Vb[t / T3_N][t % T3_N] = pre[u];
+        }
+    }
+    __syncthreads();
+    const int a = threadIdx.x >> 4, c = threadIdx.x & 15;
+    double2 s = make_double2(0.0, 0.0);
+    const int kc = k0 + c;
+    if (a < c && kc + 1 < n) {                     // g_ac = v_a^H v_c; v_c is zero up to kc, one at kc + 1
+        for (int i = kc + 1; i < n; ++i) {
+            const double2 va = Vb[a][i], vc = Vb[c][i];
+            s.x = fma(va.x, vc.x, s.x); s.x = fma(va.y, vc.y, s.x);
+            s.y = fma(va.x, vc.y, s.y); s.y = fma(-va.y, vc.x, s.y);
+        }
+    }
+    gram[a][c] = s;
+    __syncthreads();
+    // row i of T depends only on its own earlier entries (T_ij = -tau_j sum_{l = i}^{j-1} T_il g_lj): one thread per row keeps
+    // the row in registers and walks the columns without a barrier
+    if (threadIdx.x < WY_NB) {
+        const int i = threadIdx.x;
+        double2 row[WY_NB];
+#pragma unroll
+        for (int j = 0; j < WY_NB; ++j) {
+            const int kj = k0 + j;
+            const double2 tj = (kj + 1 < n) ? tau[kj] : make_double2(0.0, 0.0);
+            double2 v = make_double2(0.0, 0.0);
+            if (j == i) v = tj;
+            else if (j > i) {
+                double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int l = 0; l < j; ++l) {
+                    if (l >= i) {
+                        const double2 t = td_cmul(row[l], gram[l][j]);
+                        acc.x += t.x;
+                        acc.y += t.y;
+                    }
+                }
+                const double2 r = td_cmul(tj, acc);
+                v = make_double2(-r.x, -r.y);
+            }
+            row[j] = v;
+            Ts[i][j] = v;
+        }
+    }
+    __syncthreads();
+    g.T[((size_t)b * g.nblk + blk) * 256 + threadIdx.x] = Ts[a][c];
+}
+
+__global__ __launch_bounds__(WY_NT, 1) void backtransform_wy_kernel(const WyArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char td_smem[];
+    double2 *Vs2 = reinterpret_cast<double2 *>(td_smem);                // [2][16][WY_LDV] reflector blocks, reflector-major, double buffered
+    double2 *Ts = Vs2 + 2 * WY_NB * WY_LDV;                             // [16][17]
+    const int n = g.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int e = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x / g.wgs_per_mat;
+    const int grp = (blockIdx.x % g.wgs_per_mat) * BT_NW + wave;
+    const bool live = 16 * grp < n;
+    const size_t nn = (size_t)n * n;
+    const int m = 16 * grp + e;
+    const double *Zt = g.Zt + b * nn;
+    const double2 *Vh = g.Vh + b * nn;
+    d4_t yr[WY_NTILE], yi[WY_NTILE];
+#pragma unroll
+    for (int c = 0; c < WY_NTILE; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * c + q + 4 * r;
+            yr[c][r] = (live && m < n && i < n) ? Zt[(size_t)m * n + i] : 0.0;
+            yi[c][r] = 0.0;
+        }
+    }
+    // Reflector block `blk` into buffer blk & 1 by LDS-DMA: 16 rows x 4 pieces of 64 entries, dealt to the waves.  Row k of Vh holds
+    // v_i for i > k and zeros up to the diagonal (the tridiagonalisation kernels write complete rows); lanes outside [0, n) and
+    // rows of reflectors that do not exist read Vh[0][0], which is such a zero.
+    auto stage = [&](int blk) {
+        double2 *dst = Vs2 + (blk & 1) * WY_NB * WY_LDV;
+        for (int p = wave; p < WY_NB * 4; p += BT_NW) {
+            const int r = p >> 2, i = 64 * (p & 3) + lane, k = WY_NB * blk + r;
+            const bool ok = k + 1 < n && i < n;
+            const double2 *src = ok ? Vh + (size_t)k * n + i : Vh;            // Vh[0][0]: zero (row 0 is written in full)
+            glds16(src, lds_addr_of(dst + r * WY_LDV + 64 * (p & 3)));
+        }
+    };
+    stage(g.nblk - 1);
+    for (int blk = g.nblk - 1; blk >= 0; --blk) {
+        const int k0 = WY_NB * blk;
+        const double2 *Vs = Vs2 + (blk & 1) * WY_NB * WY_LDV;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of block blk have landed
+        __syncthreads();                                   // ... everyone's; and block blk + 1 (other buffer, Ts) is no longer read
+        if (blk > 0) stage(blk - 1);                       // in flight underneath this block's products
+        if (tid < 256) Ts[(tid >> 4) * 17 + (tid & 15)] = g.T[((size_t)b * g.nblk + blk) * 256 + tid];
+        __syncthreads();
+        if (!live) continue;
+        const int c0 = (k0 + 1) >> 4;                      // first tile with a live component
+        // ---- X = V^H Y ----
+        d4_t xr = d4_t{0.0, 0.0, 0.0, 0.0}, xi = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < WY_NTILE; ++c) {
+            if (c >= c0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {              // K chunk: components 16 c + 4 r' ... no: components (16 c + q' + 4 r), q' = 0 .. 3
+                    const double2 v = Vs[e * WY_LDV + 16 * c + q + 4 * r];      // A: lane (reflector e, k = q) -> conj(V)[comp][e]
+                    xr = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, yr[c][r], xr, 0, 0, 0);
+                    xr = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, yi[c][r], xr, 0, 0, 0);
+                    xi = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, yi[c][r], xi, 0, 0, 0);
+                    xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, yr[c][r], xi, 0, 0, 0);
+                }
+            }
+        }
+        // ---- X <- T X ----
+        d4_t zr = d4_t{0.0, 0.0, 0.0, 0.0}, zi = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double2 tt = Ts[e * 17 + q + 4 * j];     // A: lane (row e, k = q) -> T[e][reflector of chunk j]
+            zr = __builtin_amdgcn_mfma_f64_16x16x4f64(tt.x, xr[j], zr, 0, 0, 0);
+            zr = __builtin_amdgcn_mfma_f64_16x16x4f64(-tt.y, xi[j], zr, 0, 0, 0);
+            zi = __builtin_amdgcn_mfma_f64_16x16x4f64(tt.x, xi[j], zi, 0, 0, 0);
+            zi = __builtin_amdgcn_mfma_f64_16x16x4f64(tt.y, xr[j], zi, 0, 0, 0);
+        }
+        // ---- Y <- Y - V X ----
+#pragma unroll
+        for (int c = 0; c < WY_NTILE; ++c) {
+            if (c >= c0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double2 v = Vs[(q + 4 * j) * WY_LDV + 16 * c + e];    // A: lane (component 16 c + e, k = q) -> V[comp][reflector]
+                    yr[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.x, zr[j], yr[c], 0, 0, 0);
+                    yr[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, zi[j], yr[c], 0, 0, 0);
+                    yi[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.x, zi[j], yi[c], 0, 0, 0);
+                    yi[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-v.y, zr[j], yi[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (live && m < n) {
+        double2 *out = g.Vt + b * nn + (size_t)g.rank[(size_t)b * n + m] * n;
+#pragma unroll
+        for (int c = 0; c < WY_NTILE; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * c + q + 4 * r;
+                if (i < n) out[i] = make_double2(yr[c][r], yi[c][r]);
+            }
+    }
+}
+
 }  // namespace
 
 // Tridiagonalise `batch` complex Hermitian n x n matrices (n <= 200) into (d, e, tau, Vh) in the layout phases 2 / 3 of
@@ -789,9 +976,32 @@ int launch_tridiag_resident(dmk_ctx *ctx, int n, int batch, const void *A, const
 }
 
 // Back-transformation of the tridiagonal eigenvectors Zt (rows) with the reflectors (Vh, tau) of launch_tridiag_resident /
-// eigh_kernel phase 1 into the rows rank[m] of Vt (c128).  n <= 200.  Returns 1 when launched, 0 when out of range.
-int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const void *Vh, const void *tau, const int *rank, void *Vt) {
+// eigh_kernel phase 1 into the rows rank[m] of Vt (c128).  n <= 200.  Tws: batch x ceil((n - 1) / 16) x 256 c128 of workspace for
+// the T factors of the blocked form (nullptr: one reflector at a time).  Returns 1 when launched, 0 when out of range.
+int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const void *Vh, const void *tau, const int *rank, void *Vt,
+                         void *Tws) {
     if (n < 2 || n > TD_NMAX || batch <= 0) return 0;
+    // read per call: the blocked form on the matrix cores is the default, DMK_EIGH_WY=0 applies the reflectors one at a time
+    const bool wy = Tws && !(getenv("DMK_EIGH_WY") && atoi(getenv("DMK_EIGH_WY")) == 0);
+    if (wy) {
+        WyArgs g;
+        g.n = n; g.batch = batch;
+        g.wgs_per_mat = ((n + 15) / 16 + BT_NW - 1) / BT_NW;
+        g.nblk = (n - 1 + WY_NB - 1) / WY_NB;
+        g.Zt = Zt; g.Vh = reinterpret_cast<const double2 *>(Vh); g.tau = reinterpret_cast<const double2 *>(tau);
+        g.T = reinterpret_cast<double2 *>(Tws); g.rank = rank; g.Vt = reinterpret_cast<double2 *>(Vt);
+        const size_t lds = (size_t)(2 * WY_NB * WY_LDV + WY_NB * 17) * sizeof(double2);
+        static bool attr_set = false;
+        if (!attr_set) {
+            DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(backtransform_wy_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wy_tfactor_kernel, dim3((unsigned)(batch * g.nblk)), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL(backtransform_wy_kernel, dim3((unsigned)(batch * g.wgs_per_mat)), dim3(WY_NT), lds, ctx->stream, g);
+        DMK_CHECK_LAUNCH(ctx);
+        return 1;
+    }
     BtArgs g;
     g.n = n; g.batch = batch;
     g.wgs_per_mat = ((n + 15) / 16 + BT_NW - 1) / BT_NW;

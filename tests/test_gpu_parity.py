@@ -354,17 +354,19 @@ def test_eri_properties_large(ctx):
 # K1 / K2: eigensolver, density, HF
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("layout", ["tiles", "rows"])
+@pytest.mark.parametrize("layout", ["tiles", "rows", "tiles_no_wy"])
 @pytest.mark.parametrize("n,batch", [(65, 3), (112, 2), (113, 2), (136, 5), (199, 2), (200, 7)])
 def test_eigh_resident_layouts(ctx, monkeypatch, n, batch, layout):
     """The two CU-resident Householder layouts of the complex eigensolver for 64 < n <= 200 -- 16 x 16 tiles updated on the matrix
     cores (default) and rows across the lanes (DMK_EIGH_TILES=0) -- against LAPACK, including a repeated level, a block-diagonal
     matrix (zero reflectors inside the sweep) and the shared real shift matrix."""
     from libdmet_preview_amd._lib import lib
+    monkeypatch.delenv("DMK_EIGH_TILES", raising=False)
+    monkeypatch.delenv("DMK_EIGH_WY", raising=False)
     if layout == "rows":
         monkeypatch.setenv("DMK_EIGH_TILES", "0")
-    else:
-        monkeypatch.delenv("DMK_EIGH_TILES", raising=False)
+    elif layout == "tiles_no_wy":
+        monkeypatch.setenv("DMK_EIGH_WY", "0")              # reflectors one at a time (K1c) instead of the blocked WY form
     rng = np.random.default_rng(n * 10 + batch)
     A = rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))
     A = A + A.conj().transpose(0, 2, 1)
