@@ -43,7 +43,8 @@ def pmc(db):
 # contraction kernel is the "dgemm" of the ERI transform (dgemm_tn_acc_kernel also serves small Gram matrices)
 FAMILY = [("dgemm_tn_acc_dma_kernel", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"), ("half2_tab_kernel", "zgemm_half2"),
           ("philox_block", "philox"), ("jacobi_eigh_kernel", "jacobi_eigh"), ("tridiag_resident_kernel", "eigh_tridiag"),
-          ("backtransform_kernel", "eigh_backtransform"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"),
+          ("tridiag_tiles_kernel", "eigh_tridiag"), ("backtransform_kernel", "eigh_backtransform"),
+          ("backtransform_wy_kernel", "eigh_backtransform"), ("wy_tfactor_kernel", "eigh_tfactor"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"),
           ("jk_k_kernel", "jk_k"), ("gemv2_kernel", "gemv2")]
 
 
