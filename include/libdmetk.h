@@ -153,7 +153,10 @@ int dmk_fold_k2R_complex(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batc
 /* and the loop rho[s,k] = (ev*occ) ev^H at routine/mfd.py:355-357             */
 /* ------------------------------------------------------------------------- */
 
-/* A: batch x n x n c128 (Hermitian; both triangles read).  add: optional n x n
+/* Complex batches with 64 < n <= 200 run as CU-resident kernels (csrc/eigh_tridiag.hip: tridiagonalisation with the
+ * matrix in LDS + registers and the rank-2 update on the matrix cores, compact-WY back-transformation); other shapes
+ * as one kernel per launch (csrc/eigh.hip).  DMK_ERR_NOCONV when an eigenvector fails its residual test (NaN / Inf).
+ * A: batch x n x n c128 (Hermitian; only the LOWER triangle is referenced).  add: optional n x n
  * f64 matrix added to every A (vcor.get(k, True)[s]), add_stride = 0 or n*n per
  * batch group (add_period matrices cycle with period `add_period` batches;
  * pass add=NULL for none).  w: batch x n ascending.  Vt: batch x n x n c128 with
@@ -169,7 +172,11 @@ int dmk_eigh_batched_real(dmk_ctx *ctx, int n, int batch, const double *A, doubl
  * one-sided Jacobi over several CUs (csrc/jacobi_eigh.hip).  A: batch x n x n f64, symmetric, FULL storage when V0 is
  * given (else only the lower triangle is read).  V0 (optional): batch x n x n, rows = approximate eigenvectors
  * (orthonormal) of a nearby matrix -- the warm start of the vcor-fit line search (routine/slater.py:1075, 1098).
- * w ascending, Vt rows = eigenvectors.  sweeps_out (optional): sweeps taken by the slowest matrix. */
+ * With V0 the call first refines that basis on the matrix cores (Newton-like correction V <- V + F V, a few n^3 products
+ * per pass; accepted only when the residual and the orthogonality of the returned basis were measured below
+ * 4 sqrt(n) eps |A| / 16 sqrt(n) eps) and falls back to the sweeps otherwise (DMK_EIGH_REFINE=0: sweeps only).
+ * w ascending, Vt rows = eigenvectors (Vt may alias V0).  sweeps_out (optional): sweeps taken by the slowest matrix,
+ * 0 when the refinement was accepted.  DMK_ERR_NOCONV for NaN / Inf input. */
 int dmk_eigh_jacobi_real(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt,
                          int *sweeps_out);
 int dmk_occ_density(dmk_ctx *ctx, int n, int batch, const void *Vt, const double *occ,
