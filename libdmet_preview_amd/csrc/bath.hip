@@ -457,7 +457,9 @@ __device__ __forceinline__ double jf_rsqrt(double x) {
 __global__ __launch_bounds__(JF_NT) void jacobi_svd_fast_kernel(int nb, const double *__restrict__ A, int lda,
                                                                 double *__restrict__ sigma, double *__restrict__ Utop,
                                                                 int *__restrict__ status, int upper_only,
-                                                                long long a_bstride = 0, long long u_bstride = 0) {
+                                                                long long a_bstride = 0, long long u_bstride = 0,
+                                                                const int *__restrict__ skip = nullptr) {
+    if (skip && skip[0]) return;              // the caller's shortcut already produced the result (lowdin_taylor_kernel)
     // batch member = blockIdx.x: its matrix, its nb singular values, its vectors, its two status ints
     A += (long long)blockIdx.x * a_bstride;
     Utop += (long long)blockIdx.x * u_bstride;
@@ -701,7 +703,8 @@ __global__ void inv_sqrt_kernel(int n, const double *__restrict__ e, const doubl
 }
 // the same from eigenvectors stored as COLUMNS (U[i][m], the layout of jacobi_svd_fast_kernel)
 __global__ void inv_sqrt_cols_kernel(int n, const double *__restrict__ e, const double *__restrict__ U, double tol,
-                                     double *__restrict__ X) {
+                                     double *__restrict__ X, const int *__restrict__ skip = nullptr) {
+    if (skip && skip[0]) return;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n * n; t += gridDim.x * blockDim.x) {
         const int i = t / n, j = t % n;
         double s = 0.0;
@@ -709,6 +712,37 @@ __global__ void inv_sqrt_cols_kernel(int n, const double *__restrict__ e, const 
             if (e[m] > tol) s += U[i * n + m] * U[j * n + m] / sqrt(e[m]);
         X[t] = s;
     }
+}
+// Loewdin factor of a metric that is the identity up to rounding -- the usual case: the bath vectors are columns of the SVD's
+// U.  With E = S - I and max|E| <= 1e-6, S^-1/2 = I - E/2 + 3/8 E^2 to 3e-19; the kernel then sets flag[0] = 1 and the Jacobi
+// eigensolver of the metric (1 ms of latency for a 56 x 56 matrix) and inv_sqrt_cols_kernel return at once.  Anything else
+// (rank-deficient or genuinely non-orthogonal vectors) leaves flag[0] = 0 and takes the eigendecomposition with its 1e-14 cut.
+__global__ __launch_bounds__(256) void lowdin_taylor_kernel(int n, const double *__restrict__ S, double *__restrict__ X,
+                                                            int *__restrict__ flag) {
+    __shared__ double E[64 * 65];
+    __shared__ double red[4];
+    double m = 0.0;
+    for (int t = threadIdx.x; t < n * n; t += 256) {
+        const int i = t / n, j = t % n;
+        const double e = S[t] - (i == j ? 1.0 : 0.0);
+        E[i * 65 + j] = e;
+        m = fmax(m, (fabs(e) <= 1.7e308) ? fabs(e) : 1.0);           // NaN / Inf: not near the identity
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const double emax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (emax > 1.0e-6) {
+        if (threadIdx.x == 0) flag[0] = 0;
+        return;
+    }
+    for (int t = threadIdx.x; t < n * n; t += 256) {
+        const int i = t / n, j = t % n;
+        double e2 = 0.0;
+        for (int k = 0; k < n; ++k) e2 = fma(E[i * 65 + k], E[k * 65 + j], e2);
+        X[t] = (i == j ? 1.0 : 0.0) - 0.5 * E[i * 65 + j] + 0.375 * e2;
+    }
+    if (threadIdx.x == 0) flag[0] = 1;
 }
 // basis[env_idx[r]][nimp + c] = sum_j B[r][j] X[j][c]   (or B itself when X == nullptr)
 __global__ void scatter_bath_kernel(int nenv, int nbath, const double *__restrict__ B, const double *__restrict__ X,
@@ -967,9 +1001,10 @@ int dmk_bath_assemble(dmk_ctx *ctx, const double *U, int nenv, int nb, int nbath
         // The kernel stores the vectors as COLUMNS of its output (here the `Vt` buffer): inv_sqrt_cols_kernel reads that layout.
         FamScope fs(ctx, DMK_FAM_BATH);
         int *st = reinterpret_cast<int *>(ev + nbath);
-        DMK_HIP(ctx, hipMemsetAsync(st, 0, 2 * sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(jacobi_svd_fast_kernel, dim3(1), dim3(JF_NT), 0, ctx->stream, nbath, S, nbath, ev, Vt, st, 0);
-        hipLaunchKernelGGL(inv_sqrt_cols_kernel, dim3(16), dim3(256), 0, ctx->stream, nbath, ev, Vt, 1e-14, X);
+        DMK_HIP(ctx, hipMemsetAsync(st, 0, 4 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(lowdin_taylor_kernel, dim3(1), dim3(256), 0, ctx->stream, nbath, S, X, st + 2);
+        hipLaunchKernelGGL(jacobi_svd_fast_kernel, dim3(1), dim3(JF_NT), 0, ctx->stream, nbath, S, nbath, ev, Vt, st, 0, 0LL, 0LL, st + 2);
+        hipLaunchKernelGGL(inv_sqrt_cols_kernel, dim3(16), dim3(256), 0, ctx->stream, nbath, ev, Vt, 1e-14, X, st + 2);
     } else if (orth) {
         rc = launch_eigh_public(ctx, nbath, 1, S, 1, nullptr, 0, ev, Vt, 1);
         if (rc) { cleanup(); return rc; }
