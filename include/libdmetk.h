@@ -190,8 +190,11 @@ int dmk_occ_density(dmk_ctx *ctx, int n, int batch, const void *Vt, const double
  *     are spread evenly over [mu - thr_deg, mu + thr_deg].
  *   beta finite: Fermi function 1 / (exp(beta (e - mu)) + 1) (0 beyond beta (e - mu) >= 100); flags bit 1: mu = mu0 is
  *     fixed, else mu solves sum occ = nelec to the tolerance fit_tol (bracketed Newton on the device).
+ *   flags bit 2: `ew` is in ascending order (the frontier levels are read, not searched; T = 0 only).
  * occ: device, n doubles.  info_host[5]: mu, |sum occ - nelec| (0 at T = 0), electrons spread over the window, levels
- * in the window, 0.  Synchronises the stream (the caller needs mu). */
+ * in the window, 0.  Synchronises the stream (the caller needs mu) -- unless info_host is NULL: then the call only
+ * enqueues the kernel (occupations in stream order, nothing read back, NaN / Inf input unreported: for callers whose
+ * eigensolver has already rejected it, e.g. the objective of the vcor fit). */
 int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double nelec, double beta, double mu0, int flags,
                    double thr_deg, double fit_tol, double *occ, double *info_host /*[5]*/);
 int dmk_transpose_c128(dmk_ctx *ctx, int rows, int cols, int batch, const void *in, void *out);

@@ -115,6 +115,7 @@ struct OccArgs {
     long long n;
     double nelec, beta, mu0, thr, tol;
     int has_mu0, fix_mu;
+    int sorted;         // the levels are in ascending order: rank k is e[k], no order-statistics search
     double *occ;
     double *out;        // [0] mu, [1] nerr, [2] electrons spread over the window, [3] levels in the window, [4] status
 };
@@ -141,8 +142,9 @@ __global__ __launch_bounds__(OCC_NT) void occ_zero_t_kernel(const OccArgs g) {
     }
     if (!keep) {
         // ranks ne - 1 and ne of the ascending order; rank -1 wraps to the largest level like the host indexing does
-        const double lo = kth_smallest(e, n, ne > 0 ? ne - 1 : n - 1, shi);
-        const double hi = kth_smallest(e, n, ne < n ? ne : n - 1, shi);
+        const long long klo = ne > 0 ? ne - 1 : n - 1, khi = ne < n ? ne : n - 1;
+        const double lo = g.sorted ? e[klo] : kth_smallest(e, n, klo, shi);
+        const double hi = g.sorted ? e[khi] : kth_smallest(e, n, khi, shi);
         mu = 0.5 * (lo + hi);
     }
     long long filled = 0, window = 0;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(OCC_NT) void occ_fermi_kernel(const OccArgs g) {
 extern "C" int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double nelec, double beta, double mu0, int flags,
                               double thr_deg, double fit_tol, double *occ, double *info_host) {
     if (!ctx) return DMK_ERR_INVALID;
-    if (n <= 0 || !ew || !occ || !info_host) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: bad arguments");
+    if (n <= 0 || !ew || !occ) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: bad arguments");
     const bool zero_t = !(beta < INFINITY);
     if (!zero_t && !(beta > 0.0)) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: beta must be positive");
     if (!zero_t && !(flags & 2) && !(nelec >= 0.0 && nelec <= (double)n))
@@ -255,6 +257,7 @@ extern "C" int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double 
     a.tol = fit_tol > 0.0 ? fit_tol : 1e-12;
     a.has_mu0 = (flags & 1) ? 1 : 0;
     a.fix_mu = (flags & 2) ? 1 : 0;
+    a.sorted = (flags & 4) ? 1 : 0;
     a.occ = occ; a.out = reinterpret_cast<double *>(scratch);
     {
         FamScope fs(ctx, DMK_FAM_MISC);
@@ -262,6 +265,7 @@ extern "C" int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double 
         else hipLaunchKernelGGL(occ_fermi_kernel, dim3(1), dim3(OCC_NT), 0, ctx->stream, a);
         DMK_CHECK_LAUNCH(ctx);
     }
+    if (!info_host) return DMK_OK;          // asynchronous use: occupations only, nothing is read back
     DMK_HIP(ctx, hipMemcpyAsync(info_host, scratch, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (info_host[4] == 2.0) return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: the eigenvalue list contains NaN / Inf");

@@ -276,10 +276,12 @@ def check_nelec(nelec, ncells=None, tol=1e-5):
     return whole, share
 
 
-def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, fit_tol=1e-12, d_occ=None):
+def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, fit_tol=1e-12, d_occ=None, ascending=False,
+                  sync=True):
     """Occupations of ALL levels in the device array `d_ew` (one particle-number sector) without leaving the GPU:
     returns (device occupations, mu, nerr).  mu0=None at T = 0 means "no preferred level" (the frontier mid-point).
-    `d_occ`: optional destination (same number of elements as d_ew)."""
+    `d_occ`: optional destination (same number of elements as d_ew).  `ascending`: the levels are sorted (T = 0: the frontier is
+    read, not searched).  `sync=False`: only enqueue the kernel -- mu and nerr come back as None, nothing is read from the device."""
     import ctypes as C
     n = int(d_ew.size)
     zero_t = not (beta < np.inf)
@@ -292,9 +294,13 @@ def assignocc_dev(ctx, d_ew, nelec, beta, mu0=None, fix_mu=False, thr_deg=1e-6, 
         flags = 2 if fix_mu else 0
     if d_occ is None:
         d_occ = ctx.empty(d_ew.shape, np.float64)
-    info = (C.c_double * 5)()
+    if ascending and zero_t:
+        flags |= 4
+    info = (C.c_double * 5)() if sync else None
     ctx.check(lib.dmk_assign_occ(ctx.h, n, d_ew.ptr, float(nelec), float(beta), 0.0 if mu0 is None else float(mu0), flags,
                                  float(thr_deg), float(fit_tol), d_occ.ptr, info))
+    if not sync:
+        return d_occ, None, None
     if zero_t and info[2] > 0:
         log.warn("degenerate HOMO-LUMO: %d electrons shared by %d levels within %g of mu", int(info[2]), int(info[3]), thr_deg)
     return d_occ, float(info[0]), float(info[1])

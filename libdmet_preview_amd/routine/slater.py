@@ -543,13 +543,13 @@ class EmbFitDevice(object):
             # mid-point the reference passes as mu0 is what dmk_assign_occ picks on its own); ew / occ stay in HBM and are
             # only fetched when the gradient asks for them
             ne = [self.nelec] if spin == 1 else list(self.nelec)
-            mu = []
             for s in range(spin):
                 guess = None if not self.fix_mu else (self.mu0 if np.ndim(self.mu0) == 0 else self.mu0[s])
-                d_o, mu_s, _ = self._mfd.assignocc_dev(ctx, self.d_w.offset(s * nb, (nb,)), ne[s], self.beta, mu0=guess,
-                                                       thr_deg=self.tol_deg, d_occ=self.d_occ.offset(s * nb, (nb,)))
-                mu.append(mu_s)
-            mu = mu[0] if spin == 1 else np.asarray(mu)
+                # the eigensolver returns each spin's levels ascending; nothing is read back (mu is not needed at T = 0 and the
+                # eigensolver has already rejected non-finite input)
+                self._mfd.assignocc_dev(ctx, self.d_w.offset(s * nb, (nb,)), ne[s], self.beta, mu0=guess, thr_deg=self.tol_deg,
+                                        d_occ=self.d_occ.offset(s * nb, (nb,)), ascending=True, sync=False)
+            mu = None
             ew = occ = None
         else:
             ew = self.d_w.get()

@@ -114,3 +114,21 @@ def test_nonfinite_levels_are_an_error(mfd, beta, shape):
             mfd.assignocc_dev(ctx, ctx.to_device(e), e.size // 2, beta, mu0=None)
     with pytest.raises(_lib.DmkError):                       # more electrons than levels at finite T
         mfd.assignocc_dev(ctx, ctx.to_device(ew), ew.size + 1, 20.0, mu0=None)
+
+
+def test_assign_occ_sorted_async(mfd):
+    """flags bit 2 (levels ascending: the frontier is read, not searched) and info_host = NULL (enqueue only) give the same
+    occupations as the synchronous search, including a degenerate frontier."""
+    from libdmet_preview_amd._lib import get_ctx
+    ctx = get_ctx()
+    rng = np.random.default_rng(11)
+    for n, ne, thr in ((256, 128, 1e-3), (57, 20, 1e-6), (8, 8, 1e-6), (8, 0, 1e-6)):
+        ew = np.sort(rng.standard_normal(n))
+        if 0 < ne < n:
+            ew[ne] = ew[ne - 1] + 1e-5 * (thr > 1e-4)           # a frontier pair inside / outside the window
+        d_ew = ctx.to_device(ew)
+        d_ref, mu, _ = mfd.assignocc_dev(ctx, d_ew, ne, np.inf, thr_deg=thr)
+        d_occ = ctx.empty((n,), np.float64)
+        out = mfd.assignocc_dev(ctx, d_ew, ne, np.inf, thr_deg=thr, d_occ=d_occ, ascending=True, sync=False)
+        assert out[1] is None and out[2] is None
+        assert np.array_equal(d_occ.get(), d_ref.get())
