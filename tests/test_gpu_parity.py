@@ -391,6 +391,36 @@ def test_eigh_resident_layouts(ctx, monkeypatch, n, batch, layout):
         assert np.abs(Vb.conj() @ M @ Vb.T - np.diag(w[b])).max() < 1e-11 * scale
 
 
+def test_eigh_resident_random_shapes(ctx):
+    """Randomised shapes 65 <= n <= 200 through the CU-resident eigensolver path: generic, massively degenerate (low rank + shift),
+    graded over twelve decades and banded matrices against LAPACK (tools/eigh_stress.py runs the longer version)."""
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(2026)
+    for trial in range(24):
+        n, batch, kind = int(rng.integers(65, 201)), int(rng.integers(1, 5)), trial % 4
+        A = rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))
+        A = A + A.conj().transpose(0, 2, 1)
+        if kind == 1:
+            u = rng.standard_normal((batch, n, 3)) + 1j * rng.standard_normal((batch, n, 3))
+            A = u @ u.conj().transpose(0, 2, 1) + 2.0 * np.eye(n)
+        elif kind == 2:
+            s = np.logspace(0, -12, n)
+            A = A * s[None, :, None] * s[None, None, :]
+        elif kind == 3:
+            A = np.triu(np.tril(A.real, 3), -3).astype(complex)
+            A = A + A.conj().transpose(0, 2, 1)
+        dA = ctx.to_device(A, np.complex128)
+        dw, dV = ctx.empty((batch, n), np.float64), ctx.empty((batch, n, n), np.complex128)
+        ctx.check(lib.dmk_eigh_batched(ctx.h, n, batch, dA.ptr, None, 0, dw.ptr, dV.ptr))
+        w, V = dw.get(), dV.get()
+        for b in range(batch):
+            wr = np.linalg.eigvalsh(A[b])
+            sc = np.abs(wr).max()
+            assert np.abs(w[b] - wr).max() < 1e-12 * sc, (trial, n, kind)
+            assert np.abs(V[b].conj() @ V[b].T - np.eye(n)).max() < 1e-11, (trial, n, kind)
+            assert np.abs(V[b].conj() @ A[b] @ V[b].T - np.diag(w[b])).max() < 1e-11 * sc, (trial, n, kind)
+
+
 @pytest.mark.parametrize("n,batch", [(1, 3), (2, 5), (3, 4), (10, 6), (33, 3), (64, 2), (65, 2), (200, 3)])
 def test_eigh_batched_random(ctx, n, batch):
     from libdmet_preview_amd.routine import mfd
