@@ -251,7 +251,10 @@ typedef struct dmk_eri dmk_eri;
  * (eri_transform.py:289-300).  eri_out: device f64 (spin*(spin+1)/2) x npair x
  * npair in (aa, ab, bb) order, accumulated into (caller zeroes it, so that
  * shards can be summed).  flags: bit0 = t_reversal_symm, bit1 = also accumulate the
- * imaginary part of the contraction when bit0 is clear (dmk_eri_imag_norm). */
+ * imaginary part of the contraction when bit0 is clear (dmk_eri_imag_norm), bit2 = ROWS-ONLY pipeline: eri_out is ignored
+ * (may be NULL), the planes are only taken through dmk_eri_contract_rows, and everything that would contract into an
+ * internal ERI (dmk_eri_end_kL without a stack, dmk_eri_contract, a full stack at dmk_eri_begin_kL) returns
+ * DMK_ERR_STATE; dmk_eri_finish drops planes still resident (eri_transform.py:486-521, the out-of-core branch). */
 int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, int spin,
                   int flags, const void *C_ao_emb, double *eri_out, dmk_eri **out);
 /* Start a momentum-transfer index kL (zeroes the Lij_s4 planes). */

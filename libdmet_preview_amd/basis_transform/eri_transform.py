@@ -552,9 +552,11 @@ class EriEngine(object):
     """Owns a dmk_eri pipeline: plan -> (begin_kL, push_block*, end_kL)* on one GPU."""
 
     def __init__(self, ctx, kmesh, nao, naux, nemb, spin, C_ao_emb_dev, eri_dev, t_reversal_symm=True, gso=False, plan=None,
-                 track_imag=False):
+                 track_imag=False, rows_only=False):
         """`plan` = (weights, records) of `general_plan` for k lists that are not the np.fft-ordered Gamma-centred mesh
         (then `kmesh` only carries the number of k-points, [nk, 1, 1]); default: the integer-mesh plan of libdmetk.
+        `rows_only`: a pipeline WITHOUT an ERI of its own (`eri_dev` may be None): its planes are only ever taken slab-wise
+        with `contract_rows_into`; every path that would contract into an internal ERI refuses instead (dmk_eri_begin flag 4).
         `track_imag`: without time reversal also accumulate the imaginary part of the contraction for the reference's
         `ERI imaginary` diagnostic (eri_transform.py:385-394)."""
         self.ctx = ctx
@@ -567,8 +569,8 @@ class EriEngine(object):
         h = C.c_void_p()
         self.track_imag = bool(track_imag) and not self.tr
         ctx.check(lib.dmk_eri_begin(ctx.h, mesh3(self.kmesh), self.nao, self.naux, self.nemb, self.spin,
-                                    (1 if self.tr else 0) | (2 if self.track_imag else 0), C_ao_emb_dev.ptr, eri_dev.ptr,
-                                    C.byref(h)))
+                                    (1 if self.tr else 0) | (2 if self.track_imag else 0) | (4 if rows_only else 0),
+                                    C_ao_emb_dev.ptr, None if eri_dev is None else eri_dev.ptr, C.byref(h)))
         self.h = h
         self.weights, self.records = eri_plan(self.kmesh, self.tr) if plan is None else plan
         self.nslots = 1
@@ -706,12 +708,15 @@ class EriEngine(object):
                              keepalive=self)
 
     def close(self):
+        rc = 0
         if getattr(self, "h", None):
-            lib.dmk_eri_finish(self.h)
+            rc = lib.dmk_eri_finish(self.h)          # contracts planes still waiting in the stack: that can fail
             self.h = None
         for b in (getattr(self, "host_buf", None) or []):
             b.free()
         self.host_buf = None
+        if rc:
+            self.ctx.check(rc)
 
     def __del__(self):
         try:
@@ -900,8 +905,8 @@ def _emb_eri_outcore(ctx, cell, mydf, kmesh, plan, C_dev, nao, naux, nemb, spin,
     fn = fout if str(fout).endswith(".npy") else str(fout) + ".npy"
     mm = np.lib.format.open_memmap(fn, mode="w+", dtype=np.float64, shape=(spin_pair, npair, npair))
     mm[:] = 0.0
-    dummy = ctx.zeros((16,), np.float64)                     # the pipeline's own ERI is never written in this mode
-    eng = EriEngine(ctx, kmesh, nao, naux, nemb, spin, C_dev, dummy, True, plan=plan)
+    # the pipeline has no ERI of its own in this mode: nothing (a full stack, an exception on the way out) can contract into one
+    eng = EriEngine(ctx, kmesh, nao, naux, nemb, spin, C_dev, None, True, plan=plan, rows_only=True)
     slab_rows = max(2, int(ERI_SLICE) & ~1)
     try:
         todo = eng.irreducible_kL()

@@ -714,7 +714,8 @@ __global__ void inv_sqrt_cols_kernel(int n, const double *__restrict__ e, const 
     }
 }
 // Loewdin factor of a metric that is the identity up to rounding -- the usual case: the bath vectors are columns of the SVD's
-// U.  With E = S - I and max|E| <= 1e-6, S^-1/2 = I - E/2 + 3/8 E^2 to 3e-19; the kernel then sets flag[0] = 1 and the Jacobi
+// U.  With E = S - I, S^-1/2 = I - E/2 + 3/8 E^2 - 5/16 E^3 ...; an element of E^3 is bounded by n^2 max|E|^3, so the shortcut is
+// taken when 5/16 n^2 max|E|^3 <= 2e-17 (n = 64: max|E| <= 2.5e-7; a U from the SVD has max|E| ~ 1e-15); the kernel then sets flag[0] = 1 and the Jacobi
 // eigensolver of the metric (1 ms of latency for a 56 x 56 matrix) and inv_sqrt_cols_kernel return at once.  Anything else
 // (rank-deficient or genuinely non-orthogonal vectors) leaves flag[0] = 0 and takes the eigendecomposition with its 1e-14 cut.
 __global__ __launch_bounds__(256) void lowdin_taylor_kernel(int n, const double *__restrict__ S, double *__restrict__ X,
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(256) void lowdin_taylor_kernel(int n, const double 
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     const double emax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-    if (emax > 1.0e-6) {
+    if (0.3125 * (double)n * (double)n * emax * emax * emax > 2.0e-17) {          // the dropped cubic term would be visible
         if (threadIdx.x == 0) flag[0] = 0;
         return;
     }

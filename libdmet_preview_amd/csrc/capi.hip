@@ -215,10 +215,20 @@ int dmk_profile_read_flops(dmk_ctx *ctx, double *flops, int reset) {
 
 hipError_t dmk_dev_alloc(dmk_ctx *ctx, void **out, size_t bytes) {
     hipError_t e = hipMalloc(out, bytes);
-    if (e == hipSuccess || !ctx || !ctx->oom_hook) return e;
+    if (e == hipSuccess || !ctx) return e;
+    bool parked = false;
+    for (int w = 0; w < 3; ++w) parked = parked || ctx->eri_ws[w] != nullptr;
+    if (!parked && !ctx->oom_hook) return e;
     (void)hipGetLastError();
     (void)hipStreamSynchronize(ctx->stream);      // parked blocks may still be read by queued work
-    ctx->oom_hook(ctx->oom_user);
+    // the workspaces the last ERI pipeline left in the context (plane stack: tens of GB) are only a cache
+    for (int w = 0; w < 3; ++w)
+        if (ctx->eri_ws[w]) {
+            (void)hipFree(ctx->eri_ws[w]);
+            ctx->eri_ws[w] = nullptr;
+            ctx->eri_ws_bytes[w] = 0;
+        }
+    if (ctx->oom_hook) ctx->oom_hook(ctx->oom_user);
     e = hipMalloc(out, bytes);
     if (e != hipSuccess) (void)hipGetLastError();
     return e;
@@ -678,7 +688,8 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     if (!ctx || !out) return DMK_ERR_INVALID;
     *out = nullptr;
     Mesh m(mesh);
-    if (!m.ok() || nao <= 0 || naux <= 0 || nemb <= 0 || (spin != 1 && spin != 2) || !C_ao_emb || !eri_out)
+    const bool no_out = (flags & 4) != 0;       // rows-only pipeline (dmk_eri_contract_rows): no ERI of its own
+    if (!m.ok() || nao <= 0 || naux <= 0 || nemb <= 0 || (spin != 1 && spin != 2) || !C_ao_emb || (!eri_out && !no_out))
         return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin: bad arguments");
     dmk_eri *h = new dmk_eri(ctx, mesh);
     h->nao = nao; h->naux = naux; h->nemb = nemb; h->spin = spin; h->tr = flags & 1;
@@ -693,7 +704,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         }
     }
     h->C = reinterpret_cast<const double2 *>(C_ao_emb);
-    h->eri = eri_out;
+    h->eri = no_out ? nullptr : eri_out;
     h->lchunk = naux;
     if (const char *e = getenv("DMK_ERI_3M")) h->use_3m = atoi(e) != 0;
     if (const char *e = getenv("DMK_ERI_LCHUNK")) {
@@ -756,6 +767,9 @@ static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
     if (h->nslots > 1) {
         if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin_kL: a plane stack needs the weight (1 or 2) of the kL");
         if (h->n_w2 + h->n_w1 == h->nslots) {                 // stack full: contract everything that is resident
+            if (!h->eri)
+                return dmk_fail(ctx, DMK_ERR_STATE, "eri_begin_kL: the plane stack is full and this pipeline has no ERI of its own "
+                                                    "(take the rows with dmk_eri_contract_rows, then dmk_eri_stack_clear)");
             int rc = eri_contract_stack(h, -1, -1);
             if (rc) return rc;
             h->n_w2 = h->n_w1 = 0;
@@ -951,6 +965,7 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
         h->cur_kL = -1;
         return DMK_OK;
     }
+    if (!h->eri) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: a pipeline without an ERI of its own needs a plane stack (dmk_eri_stack)");
     const double *X0 = h->planes;
     const double *X1 = h->planes + (size_t)2 * h->naux * np;
     int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
@@ -984,6 +999,7 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
 // contiguous K range.  Weight-1 slots sit at the back and only their Re halves enter: K segments of naux rows, one slot apart.
 static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
     dmk_ctx *ctx = h->ctx;
+    if (!h->eri) return dmk_fail(ctx, DMK_ERR_STATE, "eri contraction: this pipeline was opened without an ERI of its own (flags bit 2)");
     const int64_t np = h->npair;
     const int64_t slot_stride = 2LL * h->naux * np;
     // slots per launch.  Measured at C5 (13 weight-2 kL resident): 1, 2, 4 or all 13 kL per launch run at the same 69.3-69.6 TF on
@@ -1167,6 +1183,7 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
     dmk_ctx *ctx = h->ctx;
     if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: no kL in progress");
     if (h->spin != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: needs the two flavours (spin = 2)");
+    if (!h->eri) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: this pipeline has no ERI of its own");
     if (h->nslots > 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: not available with a plane stack");
     {
         int rcf = eri_flush(h);
@@ -1314,7 +1331,8 @@ int dmk_eri_finish(dmk_eri *h) {
     if (!h) return DMK_OK;
     dmk_ctx *ctx = h->ctx;
     int rc_stack = DMK_OK;
-    if (h->nslots > 1 && h->cur_kL < 0 && h->n_w2 + h->n_w1 > 0) {           // planes still waiting for their contraction
+    // planes still waiting for their contraction (a rows-only pipeline just drops them: its caller took the rows it wanted)
+    if (h->eri && h->nslots > 1 && h->cur_kL < 0 && h->n_w2 + h->n_w1 > 0) {
         rc_stack = eri_contract_stack(h, -1, -1);
         h->n_w2 = h->n_w1 = 0;
     }

@@ -959,14 +959,11 @@ int launch_tridiag_resident(dmk_ctx *ctx, int n, int batch, const void *A, const
     TdArgs g;
     g.n = n; g.batch = batch; g.A = reinterpret_cast<const double2 *>(A); g.add = add; g.add_group = add_group;
     g.Vh = reinterpret_cast<double2 *>(Vh); g.tau = reinterpret_cast<double2 *>(tau); g.d = d; g.e = e;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_resident_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)TD_LDS));
-        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_tiles_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
-        attr_set = true;
-    }
+    // per launch: the attribute belongs to the (function, device) pair and a process may hold contexts on several devices
+    DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_resident_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)TD_LDS));
+    DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tridiag_tiles_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS));
     // read per call (tests run both layouts in one process): the tile layout is the default, DMK_EIGH_TILES=0 selects the row layout
     const bool tiles_on = !(getenv("DMK_EIGH_TILES") && atoi(getenv("DMK_EIGH_TILES")) == 0);
     if (tiles_on) hipLaunchKernelGGL(tridiag_tiles_kernel, dim3(batch), dim3(T3_NT), T3_LDS, ctx->stream, g);
@@ -991,12 +988,8 @@ int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const
         g.Zt = Zt; g.Vh = reinterpret_cast<const double2 *>(Vh); g.tau = reinterpret_cast<const double2 *>(tau);
         g.T = reinterpret_cast<double2 *>(Tws); g.rank = rank; g.Vt = reinterpret_cast<double2 *>(Vt);
         const size_t lds = (size_t)(2 * WY_NB * WY_LDV + WY_NB * 17) * sizeof(double2);
-        static bool attr_set = false;
-        if (!attr_set) {
-            DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(backtransform_wy_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(backtransform_wy_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // per (function, device)
         hipLaunchKernelGGL(wy_tfactor_kernel, dim3((unsigned)(batch * g.nblk)), dim3(256), 0, ctx->stream, g);
         hipLaunchKernelGGL(backtransform_wy_kernel, dim3((unsigned)(batch * g.wgs_per_mat)), dim3(WY_NT), lds, ctx->stream, g);
         DMK_CHECK_LAUNCH(ctx);

@@ -279,9 +279,12 @@ static int jk_s4_impl(dmk_ctx *ctx, int n, const double *eri, int64_t ld, int nr
     const bool sharded = nranges > 0;
     if (!sharded) { nranges = 1; ranges = whole; }
     for (int q = 0; q < nranges; ++q)
-        if (ranges[2 * q] < 0 || ranges[2 * q + 1] > npair || ranges[2 * q] > ranges[2 * q + 1] || (ranges[2 * q] % JRB) != 0)
-            return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4: row range %d = [%lld, %lld) must lie in [0, %lld) and start on a multiple of %d", q,
-                            (long long)ranges[2 * q], (long long)ranges[2 * q + 1], npair, JRB);
+        // the J kernel works on whole JRB-row blocks: a range must start on one and end on one (or at npair), else the rows
+        // between `hi` and the end of its last block would be counted here AND by the owner of the next range
+        if (ranges[2 * q] < 0 || ranges[2 * q + 1] > npair || ranges[2 * q] > ranges[2 * q + 1] || (ranges[2 * q] % JRB) != 0 ||
+            ((ranges[2 * q + 1] % JRB) != 0 && ranges[2 * q + 1] != npair))
+            return dmk_fail(ctx, DMK_ERR_INVALID, "jk_s4: row range %d = [%lld, %lld) must lie in [0, %lld), start on a multiple of %d and "
+                            "end on one (or at the last row)", q, (long long)ranges[2 * q], (long long)ranges[2 * q + 1], npair, JRB);
     FamScope fs(ctx, DMK_FAM_JK);
     const int nblk = (int)((npair + JRB - 1) / JRB);
     // workspace carve

@@ -615,6 +615,19 @@ class EmbFitDevice(object):
         ew, occ, mu, val, d_Vt = self._forward(param)
         if ew is None:                                                     # T = 0 forward pass: levels and occupations are in HBM
             ew, occ = self.d_w.get(), self.d_occ.get()
+            # the forward pass enqueued dmk_assign_occ without reading its status back (flags bit 2: levels taken as sorted);
+            # here, where the levels are on the host anyway, the assumptions it ran on are checked once per gradient
+            lv = ew.reshape(spin, nb)
+            if not np.all(np.isfinite(lv)):
+                raise FloatingPointError("FitVcorEmb: non-finite embedding levels in the T = 0 forward pass")
+            if np.any(np.diff(lv, axis=1) < 0.0):
+                raise AssertionError("FitVcorEmb: the eigensolver returned unsorted levels; the T = 0 occupations assumed ascending order")
+            ne = [self.nelec] if spin == 1 else list(self.nelec)
+            for s in range(spin):
+                if 0 < ne[s] < nb and lv[s, ne[s]] - lv[s, ne[s] - 1] < self.tol_deg and not getattr(self, "_warned_deg", False):
+                    self._warned_deg = True                                # once per fit, like a summary of the reference's per-call warning
+                    log.warn("degenerate HOMO-LUMO in the embedding fit (spin %d): gap %g < %g", s,
+                             lv[s, ne[s]] - lv[s, ne[s] - 1], self.tol_deg)
         self._ew = ew
         ff = self._kmat_dev(occ, mu)
         for s in range(spin):                                              # C = ev[fit_idx]^T : (orbital m, fitted index a)
