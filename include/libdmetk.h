@@ -302,6 +302,14 @@ int dmk_eri_begin_kL_weighted(dmk_eri *h, int kL, int weight);
  * spin block are complete, so a kL-sharded job can reduce them over its ranks while later bands are still being computed
  * (eri_transform_mpi.py:203-210 reduces the whole array after the loop).  `done` != 0 empties the stack. */
 int dmk_eri_contract(dmk_eri *h, int band_lo, int band_hi, int done);
+/* Freivalds probe of the contraction (eri_transform.py:451-478): with a device vector x (npair f64) and a caller-zeroed
+ * yref ((spin*(spin+1)/2) x npair f64, blocks aa, ab, bb), every kL the pipeline contracts from now on also adds
+ * w X_a^T (X_b x) to yref[b] through two matrix-vector kernels that share nothing with the tiled GEMM (eri_probe.hip).
+ * After dmk_eri_finish / the last band, eri[b] x (dmk_dgemv2) must equal yref[b] to rounding: a check of EVERY tile row and
+ * column of the contraction for ~0.1 % of its time.  Per kL planes of a time-reversal pipeline (w = 2: Re and Im rows,
+ * w = 1: Re rows) or all 2 naux rows without time reversal; not available for the GSO contraction or a rows-only pipeline.
+ * x = yref = NULL switches it off.  Call it while no planes are resident. */
+int dmk_eri_probe(dmk_eri *h, const double *x, double *yref);
 int dmk_eri_bands(const dmk_eri *h, int *nbands, int *band_rows);
 /* Out-of-core form (eri_transform.py:486-521 adds ERI_SLICE-row slabs of every kL to the file): rows [row_lo, row_hi) of every
  * spin block of the contraction of the RESIDENT planes, accumulated into `out` ((spin_pair, rows, npair) f64, caller-zeroed)

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "dmk_eri_stack": (c_int, [c_vp, c_int, P(c_int)]),
     "dmk_eri_begin_kL_weighted": (c_int, [c_vp, c_int, c_int]),
     "dmk_eri_contract": (c_int, [c_vp, c_int, c_int, c_int]),
+    "dmk_eri_probe": (c_int, [c_vp, c_vp, c_vp]),
     "dmk_eri_bands": (c_int, [c_vp, P(c_int), P(c_int)]),
     "dmk_eri_contract_rows": (c_int, [c_vp, c_i64, c_i64, c_vp]),
     "dmk_eri_stack_clear": (c_int, [c_vp]),
@@ -151,6 +152,7 @@ class Context(object):
         self.h = h
         self.device = int(device)
         self.default_stream = not stream          # the legacy null stream: ordered with torch's default stream
+        self.stream_ptr = int(stream) if stream else 0
         # Freed device blocks are parked here by size and handed out again instead of going through hipFree / hipMalloc
         # (each a device synchronisation plus ~1 ms per few hundred MB): an embedding-construction iteration allocates the
         # same two dozen temporaries every time.  One stream per context, so reuse is stream ordered.
@@ -225,6 +227,7 @@ class Context(object):
         self.trim()
         self.check(lib.dmk_set_stream(self.h, c_vp(stream) if stream else None))
         self.default_stream = not stream
+        self.stream_ptr = int(stream) if stream else 0
 
     # ---- device arrays ---------------------------------------------------------------
     def empty(self, shape, dtype):

@@ -633,6 +633,13 @@ class EriEngine(object):
         """Contract the resident planes (a band of pair-index tiles, or everything); a no-op without a stack."""
         self.ctx.check(lib.dmk_eri_contract(self.h, int(band_lo), int(band_hi), 1 if done else 0))
 
+    def set_probe(self, d_x, d_yref):
+        """Freivalds probe of the contraction (dmk_eri_probe): every kL contracted from now on also adds w X_a^T (X_b x) to
+        `d_yref` ((spin_pair, npair) f64, caller-zeroed) through kernels independent of the tiled GEMM; afterwards
+        `probe_check(eri, x, yref)` compares eri[b] x with it.  None, None switches it off."""
+        self.ctx.check(lib.dmk_eri_probe(self.h, None if d_x is None else d_x.ptr, None if d_yref is None else d_yref.ptr))
+        self._probe = (d_x, d_yref)                       # keep the buffers alive while the library holds their addresses
+
     def imag_norm(self):
         """max |Im eri| accumulated so far (track_imag engines; 0 with time reversal: the contraction is real)."""
         v = C.c_double(0.0)
@@ -723,6 +730,16 @@ class EriEngine(object):
             self.close()
         except Exception:
             pass
+
+
+def eri_times_vector_dev(ctx, eri_dev, spin_pair, npair, d_x):
+    """y[b] = eri[b] x on the device (dmk_dgemv2 row dots: a streaming kernel, not the GEMM that produced eri): the left-hand side
+    of the contraction's Freivalds check.  Returns a device (spin_pair, npair) f64 array."""
+    d_y = ctx.empty((spin_pair, npair), np.float64)
+    for b in range(spin_pair):
+        ctx.check(lib.dmk_dgemv2(ctx.h, npair, npair, eri_dev.offset(b * npair * npair, (npair, npair)).ptr, npair, d_x.ptr, None,
+                                 d_y.offset(b * npair, (npair,)).ptr, None))
+    return d_y
 
 
 def make_C_ao_emb_dev(ctx, kmesh, C_ao_lo=None, basis=None, unit_eri=False, C_ao_eo=None, nao=None):

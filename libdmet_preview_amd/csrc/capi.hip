@@ -460,7 +460,8 @@ int dmk_assign_workload(const int mesh[3], int tr, int nranks, int rank, int32_t
 }  // extern "C"
 
 // =============================================================================================
-// a6 : folds (DFT as a complex GEMM against a cached twiddle matrix)
+// a6 : folds -- full meshes through fold.hip (fused mixed-radix pass); the DFT as a complex GEMM against a cached twiddle
+//      matrix below serves k subsets (multi-rank partial folds), axes longer than 16 and DMK_FOLD_FFT=0
 // =============================================================================================
 
 namespace {
@@ -536,6 +537,10 @@ int dmk_fold_R2k(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batch, const
     Mesh m(mesh);
     if (!m.ok() || ncol <= 0 || batch <= 0 || !in_R || !out_k || ncol > 0x7fffffffLL)
         return dmk_fail(ctx, DMK_ERR_INVALID, "fold_R2k: bad arguments");
+    {
+        int rf = launch_fold_fft(ctx, m.n, ncol, batch, in_R, in_is_complex ? 0 : 1, out_k, 0, 0, nullptr);
+        if (rf != 0) return rf < 0 ? rf : DMK_OK;
+    }
     void *P = nullptr;
     int rc = get_phase(ctx, m, nullptr, 0, &P);
     if (rc) return rc;
@@ -554,11 +559,15 @@ static int fold_k2R_impl(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batc
     Mesh m(mesh);
     if (!m.ok() || ncol <= 0 || batch <= 0 || !in_k || !out || ncol > 0x7fffffffLL || nsub < 0 || nsub > m.nk)
         return dmk_fail(ctx, DMK_ERR_INVALID, "fold_k2R: bad arguments");
+    if (imag_max) DMK_HIP(ctx, hipMemsetAsync(imag_max, 0, sizeof(double), ctx->stream));
+    if (!(subset && nsub > 0)) {                 // a full mesh: the fused mixed-radix kernel; a k subset is not a mesh
+        int rf = launch_fold_fft(ctx, m.n, ncol, batch, in_k, 0, out, real_out, 1, imag_max);
+        if (rf != 0) return rf < 0 ? rf : DMK_OK;
+    }
     void *P = nullptr;
     int rc = get_phase(ctx, m, subset, subset ? nsub : 0, &P);
     if (rc) return rc;
     const int kin = (subset && nsub > 0) ? nsub : m.nk;
-    if (imag_max) DMK_HIP(ctx, hipMemsetAsync(imag_max, 0, sizeof(double), ctx->stream));
     ZGemm g;
     g.M = m.nk; g.N = (int)ncol; g.K = kin; g.batch = batch; g.nseg = 1;
     // out[R] = (1/N) sum_k conj(P[k][R]) in[k]  ->  A[kdim=k][m=R] = conj(P[k][R])
@@ -678,6 +687,14 @@ struct dmk_eri {
     hipStream_t copy_stream = nullptr;
     double2 *dstage[2] = {nullptr, nullptr};
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    // sub-group plane copies of the table-driven step 2 (zhot_tab.hip H2TArgs): run p >= 1 of a launch accumulates into copy
+    // p - 1 ([spin][2 naux][npair] each); they are zeroed when a kL begins and added to its planes, in order, when it ends
+    double *sub_planes = nullptr;
+    int nsub_max = 1, sub_used = 1;
+    // Freivalds probe (dmk_eri_probe, eri_probe.hip): yref[b] += w X_a^T (X_b x) for every kL that is contracted
+    const double *probe_x = nullptr;
+    double *probe_y = nullptr;
+    bool probe_pending = false;      // planes entered the stack since the probe last ran over it
     dmk_eri(dmk_ctx *c, const int m[3]) : ctx(c), mesh(m) {}
 };
 
@@ -718,9 +735,10 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     if (const char *e = getenv("DMK_ERI_TAB256")) if (atoi(e) != 0) h->hot256 = false;      // route nemb = 256 through the table kernel
     if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(naux, nao, nemb)) {
         h->lchunk = naux;
-        h->group = 8;
+        h->group = h->hot256 ? 8 : 16;               // the table kernel cuts its queue into sub-group runs: a longer queue per launch
         if (const char *e = getenv("DMK_ERI_GROUP")) h->group = atoi(e);
         h->group = std::max(1, std::min(h->group, h->hot256 ? half2_hot_maxslot() : half2_tab_maxslot()));
+        if (!h->hot256) h->nsub_max = half2_tab_subgroups(ctx, naux, nao, nemb, spin, h->group, 4);
     }
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
     const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1);
@@ -753,11 +771,28 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         delete h;
         return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_begin: workspace allocation failed (%zu + %zu bytes)", plane_bytes, ut_bytes);
     }
+    if (h->nsub_max > 1) {
+        const size_t sb = (size_t)(h->nsub_max - 1) * spin * 2 * naux * h->npair * sizeof(double);
+        if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->sub_planes), sb) != hipSuccess) {
+            (void)hipGetLastError();
+            h->sub_planes = nullptr;                 // not fatal: one run per launch, as before
+            h->nsub_max = 1;
+        }
+    }
     *out = h;
     return DMK_OK;
 }
 
 static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi);
+
+// the probe's share of one plane slot (see dmk_eri_probe)
+static int eri_probe_slot(dmk_eri *h, int slot, int nrows, double w) {
+    void *tw = nullptr;
+    int rc = dmk_scratch(h->ctx, (size_t)4 * h->naux * sizeof(double), &tw);
+    if (rc) return rc;
+    return launch_eri_probe_slot(h->ctx, h->slot_planes(slot, 0), h->spin == 2 ? h->slot_planes(slot, 1) : nullptr, nrows, h->npair, w,
+                                 h->probe_x, h->probe_y, reinterpret_cast<double *>(tw));
+}
 
 static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
     dmk_ctx *ctx = h->ctx;
@@ -779,6 +814,8 @@ static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
     }
     const size_t bytes = (size_t)2 * h->naux * h->npair * sizeof(double);
     for (int s = 0; s < h->spin; ++s) DMK_HIP(ctx, hipMemsetAsync(h->slot_planes(h->cur_slot, s), 0, bytes, ctx->stream));
+    if (h->sub_planes) DMK_HIP(ctx, hipMemsetAsync(h->sub_planes, 0, bytes * h->spin * (h->nsub_max - 1), ctx->stream));
+    h->sub_used = 1;
     h->cur_kL = kL;
     return DMK_OK;
 }
@@ -826,10 +863,18 @@ static int eri_flush(dmk_eri *h) {
     const void *cj[16];
     for (int i = 0; i < h->pending; ++i)
         cj[i] = h->C + (size_t)h->pend_kj[i] * nao * nemb;
-    int rc = (h->hot256 ? launch_half2_hot : launch_half2_tab)(
-        ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair, naux, nao, nemb,
-        h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb,
-        (long long)h->nslots * 2LL * naux * h->npair);
+    int rc;
+    if (h->hot256) {
+        rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair,
+                              naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb,
+                              (long long)h->nslots * 2LL * naux * h->npair);
+    } else {
+        const int nsub = h->sub_planes ? half2_tab_subgroups(ctx, naux, nao, nemb, h->spin, h->pending, h->nsub_max) : 1;
+        rc = launch_half2_tab(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair,
+                              naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb,
+                              (long long)h->nslots * 2LL * naux * h->npair, nsub, h->sub_planes, (long long)h->spin * 2LL * naux * h->npair);
+        if (rc == 1) h->sub_used = std::max(h->sub_used, nsub);
+    }
     if (rc < 0) return rc;
     if (rc == 0) {
         // the grouped kernel declined (misaligned buffer, a table it cannot build): step 2 of every queued block through the
@@ -851,6 +896,32 @@ static int eri_flush(dmk_eri *h) {
             }
     }
     h->pending = 0;
+    return DMK_OK;
+}
+
+namespace {
+__global__ void planes_add_kernel(long long n, double *__restrict__ a, const double *__restrict__ b) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x)
+        a[t] += b[t];
+}
+}  // namespace
+
+// End of a kL: the sub-group copies (runs p >= 1 of the step-2 launches) are added to the kL's planes, copy by copy in a fixed
+// order -- the sum every plane element receives is the same whichever way the launches were cut.
+static int eri_fold_subplanes(dmk_eri *h, bool rezero = false) {
+    dmk_ctx *ctx = h->ctx;
+    if (!h->sub_planes || h->sub_used <= 1) return DMK_OK;
+    const long long n = 2LL * h->naux * h->npair;
+    for (int p = 1; p < h->sub_used; ++p)
+        for (int s = 0; s < h->spin; ++s) {
+            FamScope fs(ctx, DMK_FAM_MISC);
+            hipLaunchKernelGGL(planes_add_kernel, dim3(4096), dim3(256), 0, ctx->stream, n, h->slot_planes(h->cur_slot, s),
+                               h->sub_planes + ((size_t)(p - 1) * h->spin + s) * (size_t)n);
+            DMK_CHECK_LAUNCH(ctx);
+        }
+    // the kL goes on (dmk_eri_planes in the middle of one): what was just added must not be added again at its end
+    if (rezero) DMK_HIP(ctx, hipMemsetAsync(h->sub_planes, 0, (size_t)n * sizeof(double) * h->spin * (h->nsub_max - 1), ctx->stream));
+    h->sub_used = 1;
     return DMK_OK;
 }
 
@@ -942,6 +1013,8 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
     {
         int rcf = eri_flush(h);
         if (rcf) return rcf;
+        rcf = eri_fold_subplanes(h);
+        if (rcf) return rcf;
     }
     int K;
     double alpha;
@@ -961,11 +1034,16 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
             return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: weight %d, but the slot was chosen for weight %d at begin_kL", weight,
                             h->cur_weight);
         if (weight == 2) h->n_w2 += 1; else h->n_w1 += 1;
+        h->probe_pending = true;
         h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
         h->cur_kL = -1;
         return DMK_OK;
     }
     if (!h->eri) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: a pipeline without an ERI of its own needs a plane stack (dmk_eri_stack)");
+    if (h->probe_x) {
+        int rcp = eri_probe_slot(h, 0, K, alpha);
+        if (rcp) return rcp;
+    }
     const double *X0 = h->planes;
     const double *X1 = h->planes + (size_t)2 * h->naux * np;
     int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
@@ -1003,16 +1081,36 @@ static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
     const int64_t np = h->npair;
     const int64_t slot_stride = 2LL * h->naux * np;
     // slots per launch.  Measured at C5 (13 weight-2 kL resident): 1, 2, 4 or all 13 kL per launch run at the same 69.3-69.6 TF on
-    // the matrix pipe -- the contraction is not sensitive to K -- but the HBM traffic is not the same: with K = 1600 the operand
-    // panels of the eight XCDs' super-blocks (8 x 16 panels x K x 128 x 8 B = 210 MB) still fit the 256 MB Infinity Cache and a
-    // launch fetches 31 GB; with K = 3200 they do not and it fetches 90 GB for twice the work (rocprofv3 FETCH_SIZE).  One kL per
-    // launch therefore stays the default; the stack is what lets the contraction be deferred, banded and overlapped with the
-    // exchange, not a way to lengthen K.
-    static const int kchunk = [] { const char *e = getenv("DMK_ERI_KCHUNK"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+    // the matrix pipe -- there the contraction is not sensitive to K -- but the HBM traffic is not the same: with K = 1600 the
+    // operand panels of the eight XCDs' super-blocks (8 x 16 panels x K x 128 x 8 B = 210 MB) still fit the 256 MB Infinity Cache
+    // and a launch fetches 31 GB; with K = 3200 they do not and it fetches 90 GB for twice the work (rocprofv3 FETCH_SIZE).
+    // Small pair spaces are different: at C4 (npair 9316, K = 832 per kL) a tile's epilogue -- direct plus mirrored store of
+    // 128 x 128 doubles -- is a visible share of its 104 K-tiles: 1 / 2 / 4 kL per launch measured 56.6 / 63.8 / 66.4 TF on the
+    // pipe (round 4).  Rule: as many kL per launch (at most 4) as keep the panels of a launch inside the Infinity Cache --
+    // C5: 1 (as before), C4: 4.  DMK_ERI_KCHUNK overrides.
+    static const int kchunk_env = [] { const char *e = getenv("DMK_ERI_KCHUNK"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    auto kchunk_for = [&](int seg_rows) {
+        if (kchunk_env) return kchunk_env;
+        const double per_slot = (double)seg_rows * (double)std::min<int64_t>(np, 16384) * 8.0;
+        return std::max(1, std::min(4, (int)(268435456.0 / per_slot)));
+    };
+    if (h->probe_x && h->probe_pending) {
+        // once per resident plane set, however many bands the contraction is finished in
+        for (int i = 0; i < h->n_w2; ++i) {
+            int rc = eri_probe_slot(h, i, 2 * h->naux, 2.0);
+            if (rc) return rc;
+        }
+        for (int i = 0; i < h->n_w1; ++i) {
+            int rc = eri_probe_slot(h, h->nslots - h->n_w1 + i, h->naux, 1.0);
+            if (rc) return rc;
+        }
+        h->probe_pending = false;
+    }
     for (int w = 2; w >= 1; --w) {
         const int n = w == 2 ? h->n_w2 : h->n_w1;
         const int first = w == 2 ? 0 : h->nslots - h->n_w1;
         const int seg_rows = w == 2 ? 2 * h->naux : h->naux;
+        const int kchunk = kchunk_for(seg_rows);
         for (int s0 = 0; s0 < n; s0 += kchunk) {
             const int K = std::min(kchunk, n - s0) * seg_rows;
             const double *X0 = h->slot_planes(first + s0, 0);
@@ -1056,6 +1154,17 @@ int dmk_eri_stack(dmk_eri *h, int nslots_wanted, int *nslots_granted) {
     }
     h->nslots = n;
     if (nslots_granted) *nslots_granted = n;
+    return DMK_OK;
+}
+
+int dmk_eri_probe(dmk_eri *h, const double *x, double *yref) {
+    if (!h) return DMK_ERR_INVALID;
+    if ((x == nullptr) != (yref == nullptr)) return dmk_fail(h->ctx, DMK_ERR_INVALID, "eri_probe: x and yref go together (both NULL: off)");
+    if (x && !h->eri) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_probe: a rows-only pipeline contracts nothing to probe");
+    if (h->n_w2 + h->n_w1 > 0 || h->cur_kL >= 0) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_probe: set it before the first kL of a plane set");
+    h->probe_x = x;
+    h->probe_y = yref;
+    h->probe_pending = false;
     return DMK_OK;
 }
 
@@ -1184,9 +1293,12 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
     if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: no kL in progress");
     if (h->spin != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: needs the two flavours (spin = 2)");
     if (!h->eri) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: this pipeline has no ERI of its own");
+    if (h->probe_x) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: the contraction probe covers the spin-block contraction only");
     if (h->nslots > 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: not available with a plane stack");
     {
         int rcf = eri_flush(h);
+        if (rcf) return rcf;
+        rcf = eri_fold_subplanes(h);
         if (rcf) return rcf;
     }
     int K;
@@ -1274,6 +1386,10 @@ int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     {
         int rcf = eri_flush(h);      // queued blocks must land before anyone looks at the planes
         if (rcf) return rcf;
+        if (h->cur_kL >= 0) {
+            rcf = eri_fold_subplanes(h, true);
+            if (rcf) return rcf;
+        }
     }
     if (h->nslots > 1) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_planes: with a plane stack the spin planes of a kL are not contiguous");
     *planes_out = h->planes;
@@ -1355,6 +1471,7 @@ int dmk_eri_finish(dmk_eri *h) {
         }
     }
     if (h->imag) (void)hipFree(h->imag);
+    if (h->sub_planes) (void)hipFree(h->sub_planes);
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;

@@ -220,6 +220,14 @@ struct ZGemm {
 };
 int launch_zgemm(dmk_ctx *ctx, const ZGemm &g, int fam);
 
+// fused mixed-radix k <-> R fold of a full mesh (fold.hip): 1 = handled, 0 = use the DFT-GEMM, < 0 = error
+int launch_fold_fft(dmk_ctx *ctx, const int n[3], long long ncol, int batch, const void *in, int in_real, void *out, int out_real,
+                    int inverse, double *imag_max);
+
+// Freivalds probe of the contraction (eri_probe.hip)
+int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int nrows, long long npair, double w, const double *x,
+                          double *yref, double *twork);
+
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
 
 // hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
@@ -235,8 +243,12 @@ int half2_hot_usable(int nao, int nemb);
 int half2_hot_maxslot();
 int half1_hot_usable(int nL, int nao, int nemb);
 // step 2 for a general embedding dimension (zhot_tab.hip); same arguments and return convention as launch_half2_hot
+// nsub > 1: the queue is cut into nsub runs with one workgroup per (L, item, run); run p >= 1 accumulates into
+// planes_sub + (p - 1) * sub_stride ([spin][2 naux][npair] each), which the caller adds to `planes` afterwards
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
-                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int nsub = 1,
+                     double *planes_sub = nullptr, long long sub_stride = 0);
+int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int nslot, int max_sub);
 int half2_tab_usable(int nao, int nemb);
 int half2_tab_maxslot();

@@ -74,15 +74,23 @@ struct H1Args {
      : (SLOT) == 12 ? (G).bk[12] : (SLOT) == 13 ? (G).bk[13] : (SLOT) == 14 ? (G).bk[14] : (G).bk[15])
 
 // BM = 128 (wave tile 64 x 32, 8 accumulator tiles, two workgroups per CU) or BM = 64 (wave tile 32 x 32, 4 tiles, three
-// workgroups per CU)
-template <bool CONJB, int BM, int OCC>
+// workgroups per CU).  NARROW: the output tile is 48 instead of 64 columns wide -- the four waves are stacked along M
+// (wave tile BM / 4 x 48: 6 accumulator tiles at BM = 128) -- for embedding dimensions that three 48-column tiles cover
+// with less padding than 64-column ones (C4: nemb 136 -> 144 instead of 192 computed columns).  The B panel keeps its
+// 64-column LDS rows (lanes 48-63 of a piece land in the padding), so the LDS-DMA issue pattern is the same for both.
+// The M index is the FLAT row (L, q) -> L * mrows + q with no padding between batches: a 16-row block may straddle two L
+// (every lane carries its own source address, and Ut[L][q][:] is one contiguous array of nL * mrows rows).
+template <bool CONJB, int BM, int OCC, bool NARROW>
 __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
-    constexpr int MI = BM / 32;                          // 16-row blocks per wave
+    constexpr int MI = NARROW ? BM / 64 : BM / 32;       // 16-row blocks per wave
+    constexpr int NJ = NARROW ? 3 : 2;                   // 16-column blocks per wave
+    constexpr int BN = NARROW ? 48 : H1_BN;              // columns of the output tile
     constexpr int AH = BM / 64;                          // 1 KiB pieces per K row of the A panel
     constexpr int STAGE = H1_BK * (BM + H1_BN);
     __shared__ __attribute__((aligned(16))) double2 lds[H1_D * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the LDS-DMA addressing scalar
-    const int wm = wave >> 1, wn = wave & 1;            // 2 (M) x 2 (N) waves, wave tile (BM / 2) x 32
+    // 2 (M) x 2 (N) waves with wave tile (BM / 2) x 32, or 4 (M) x 1 waves with wave tile (BM / 4) x 48
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
     const unsigned lid_all = xcd_remap(blockIdx.x, g.nblocks);
@@ -92,8 +100,9 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     const int tile_m = (int)(lid / per_m);
     const unsigned rest = lid - (unsigned)tile_m * per_m;
     const int sp = (int)(rest / (unsigned)g.tiles_n), tile_n = (int)(rest - (unsigned)sp * (unsigned)g.tiles_n);
-    const int n0 = tile_n * H1_BN;
+    const int n0 = tile_n * BN;
     const long long nao = g.nao, nemb = g.nemb, mrows = g.mrows;
+    const long long rows_total = (long long)g.nL * mrows;
     const double2 *const Asl = g.Lpq + (long long)slot * g.a_slot_stride;
     const double2 *const Bsp = g.Ci + (long long)sp * g.b_spin_stride + (long long)H1_PICK_BK(g, slot) * g.b_k_stride;
     double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride + (long long)slot * g.out_slot_stride;
@@ -102,13 +111,10 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     const double2 *srcA[AH], *srcB;
 #pragma unroll
     for (int h = 0; h < AH; ++h) {
-        const int m = 64 * h + lane;
-        const int gb = tile_m * (BM / 16) + (m >> 4);
-        int L = gb / g.nblk;
-        int q = (gb - L * g.nblk) * 16 + (m & 15);
-        if (L >= g.nL) L = g.nL - 1;                    // clamped lanes only ever feed masked outputs
-        if (q >= g.mrows) q = g.mrows - 1;
-        srcA[h] = Asl + (long long)L * nao * mrows + q;
+        long long r = (long long)tile_m * BM + 64 * h + lane;
+        if (r >= rows_total) r = rows_total - 1;         // clamped lanes only ever feed masked outputs
+        const long long L = r / mrows, q = r - L * mrows;
+        srcA[h] = Asl + L * nao * mrows + q;
     }
     {
         int col = n0 + lane;
@@ -131,11 +137,11 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
         }
     };
 
-    cacc acc[MI][2];
+    cacc acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) cacc_zero(acc[i][j]);
+        for (int j = 0; j < NJ; ++j) cacc_zero(acc[i][j]);
 
     const int T = g.nao / H1_BK;
     issue(0);
@@ -149,15 +155,15 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
         }
         __builtin_amdgcn_s_barrier();
         if (t + 2 < T) issue(t + 2);
-        const double2 *Ab = lds + (t % H1_D) * STAGE + wm * (BM / 2) + frag_x;
+        const double2 *Ab = lds + (t % H1_D) * STAGE + wm * (MI * 16) + frag_x;
         const double2 *Bb = lds + (t % H1_D) * STAGE + H1_BK * BM + wn * 32 + frag_x;
 #pragma unroll
         for (int kk = 0; kk < H1_BK / 4; ++kk) {
-            cfrag a[MI], b[2];
+            cfrag a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[i] = cfrag_of(lds_frag(&Ab[(kk * 4 + frag_k) * BM + i * 16]));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 double2 v = lds_frag(&Bb[(kk * 4 + frag_k) * H1_BN + j * 16]);
                 if (CONJB) v.y = -v.y;                  // conj(C_i)
                 b[j] = cfrag_of(v);
@@ -165,24 +171,20 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) cmfma(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < NJ; ++j) cmfma(acc[i][j], a[i], b[j]);
         }
     }
 
-    // ---- epilogue: Ut[L][q][a] ---------------------------------------------------------------
+    // ---- epilogue: Ut[L][q][a] = row (L * mrows + q) of one contiguous (nL * mrows) x nemb array ----------------------
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int gb = tile_m * (BM / 16) + wm * MI + i;
-        const int L = gb / g.nblk;
-        if (L >= g.nL) continue;
-        const int qb = (gb - L * g.nblk) * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int q = qb + frag_k + 4 * r;
-            if (q >= g.mrows) continue;
-            double2 *row = Osp + ((long long)L * mrows + q) * nemb;
+            const long long rr = (long long)tile_m * BM + (wm * MI + i) * 16 + frag_k + 4 * r;
+            if (rr >= rows_total) continue;
+            double2 *row = Osp + rr * nemb;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int col = n0 + wn * 32 + j * 16 + frag_x;
                 if (col < g.nemb) row[col] = make_double2(cacc_re(acc[i][j], r), cacc_im(acc[i][j], r));
             }
@@ -497,9 +499,12 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     a.Ut = reinterpret_cast<double2 *>(out);
     a.nL = nL; a.nao = K; a.nemb = N; a.mrows = mrows;
     a.nblk = (mrows + 15) / 16;
-    const long long total_blk = (long long)nL * a.nblk;
-    a.tiles_m = (int)((total_blk + bm / 16 - 1) / (bm / 16));
-    a.tiles_n = (N + H1_BN - 1) / H1_BN;
+    a.tiles_m = (int)(((long long)nL * mrows + bm - 1) / bm);        // flat rows: no padding between the nL batches
+    // output tile width: 64 columns (2 x 2 waves) or 48 (4 x 1 waves), whichever pads N less; DMK_ERI_H1_BN = 64 | 48 overrides
+    int bn = (((N + 47) / 48) * 48 < ((N + 63) / 64) * 64) ? 48 : 64;
+    if (const char *e = getenv("DMK_ERI_H1_BN")) { const int v = atoi(e); if (v == 48 || v == 64) bn = v; }
+    if (bm != 128) bn = 64;
+    a.tiles_n = (N + bn - 1) / bn;
     a.nspin = nspin; a.b_spin_stride = b_spin_stride; a.out_spin_stride = out_spin_stride;
     if (nslot < 1 || nslot > 16) return 0;
     a.nslot = nslot; a.a_slot_stride = a_slot_stride; a.out_slot_stride = out_slot_stride; a.b_k_stride = b_k_stride;
@@ -508,13 +513,16 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     if ((unsigned long long)a.per_slot * (unsigned)nslot > 0x7fffffffull) return 0;
     a.nblocks = a.per_slot * (unsigned)nslot;
     FamScope fs(ctx, fam);
-    fs.mfma_flops(6.0 * (double)a.nblocks * bm * H1_BN * (double)K);
-    if (bm == 128) {
-        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 128, 2>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((half1_kernel<false, 128, 2>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    fs.mfma_flops(6.0 * (double)a.nblocks * bm * bn * (double)K);
+    if (bm == 128 && bn == 48) {
+        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 128, 2, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half1_kernel<false, 128, 2, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    } else if (bm == 128) {
+        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 128, 2, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half1_kernel<false, 128, 2, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     } else {
-        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 64, 3>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((half1_kernel<false, 64, 3>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 64, 3, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half1_kernel<false, 64, 3, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     }
     DMK_CHECK_LAUNCH(ctx);
     return 1;

@@ -23,6 +23,7 @@
 //   Block efficiency (useful blocks / 4 waves x longest list): nemb 136 -> 94 %, 200 -> 95 %, 272 -> 93 %.
 // Panels wider than the matrix re-read clamped valid columns; they only ever feed masked outputs.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -63,6 +64,15 @@ struct H2TArgs {
     int fold_diag;                   // every queued block is symmetrised: diagonal blocks run one segment and are folded (zhot.hip)
     const int *table;                // nitems x T_ITEM: kind, R0, C0, nblk[4], pad, entries[4][8] = (row block << 8) | col block (local)
     int nitems;
+    // SUB-GROUPS: the queue of nslot blocks is cut into nsub runs of sub_slots consecutive blocks; every (L, item) has one
+    // workgroup PER RUN, and run p >= 1 accumulates into its own copy of the planes (planes_sub + (p - 1) sub_stride) that the
+    // pipeline adds to the kL's planes in a fixed order when the kL ends -- still exactly one writer per plane element and
+    // launch.  nsub x more, nsub x shorter workgroups: a launch of 1.6 rounds of resident workgroups (C4: 1248 on 768
+    // slots, the last round 62 % full) becomes one of 6.5.
+    int nsub, sub_slots;
+    double *planes_sub;
+    long long sub_stride;
+    unsigned per_sub;                // workgroups per run = nitems * nL * nspin
 };
 
 // kernel-argument arrays are only ever indexed by constants (see zhot.hip)
@@ -79,18 +89,23 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frag_k = lane >> 4, frag_x = lane & 15;
-    const unsigned lid = xcd_remap(blockIdx.x, g.nblocks);
+    const unsigned lid_all = xcd_remap(blockIdx.x, g.nblocks);
+    const int sub = (int)(lid_all / g.per_sub);
+    const unsigned lid = lid_all - (unsigned)sub * g.per_sub;
     const int Lall = (int)(lid / (unsigned)g.nitems), item = (int)(lid - (unsigned)Lall * (unsigned)g.nitems);
     const int sp = Lall >= g.nL ? 1 : 0;
     const int L = Lall - sp * g.nL;
     const long long nemb = g.nemb;
     const int Tb = g.nao / T_BK;
-    const int T = Tb * g.nslot;
-    const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb;
-    double *const g_planes = g.planes + (long long)sp * g.planes_spin_stride;
-    const long long cj_off = (long long)sp * g.cj_spin_stride;
+    const int slot0 = sub * g.sub_slots;                                           // this run: queue slots [slot0, slot0 + nmine)
+    const int nmine = g.nslot - slot0 < g.sub_slots ? g.nslot - slot0 : g.sub_slots;
+    const int T = Tb * nmine;
     const long long g_naux = g.naux, g_npair = g.npair, g_slot_stride = g.slot_stride;
-    const unsigned g_symmask = g.symmask;
+    const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb + (long long)slot0 * g_slot_stride;
+    double *const g_planes = (sub == 0 ? g.planes + (long long)sp * g.planes_spin_stride
+                                       : g.planes_sub + (long long)(sub - 1) * g.sub_stride + (long long)sp * 2LL * g_naux * g_npair);
+    const long long cj_off = (long long)sp * g.cj_spin_stride;
+    const unsigned g_symmask = g.symmask >> slot0;
 
     // ---- this workgroup's item and this wave's block list (wave-uniform: SGPRs) ----------------------------------
     const int *it = g.table + (long long)item * T_ITEM;
@@ -149,8 +164,8 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
             }
             soff[h] = (long long)row * nemb + clampcol(col);
         }
-        int is_t = 0, is_slot = 0, is_stage = 0;
-        const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, 0) + cj_off;
+        int is_t = 0, is_slot = slot0, is_stage = 0;
+        const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, slot0) + cj_off;
         auto issue = [&]() {
             double2 *st = lds + is_stage * STAGE;
             const double2 *gp[NP];
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
             if (++is_t == Tb) {
                 is_t = 0;
                 ++is_slot;
-                is_ub = Ubase + (long long)is_slot * g_slot_stride;
+                is_ub = Ubase + (long long)(is_slot - slot0) * g_slot_stride;
                 is_cb = T_PICK_CJ(g, is_slot) + cj_off;
             } else {
                 is_ub += T_BK * nemb;
@@ -323,16 +338,38 @@ void build_table(int nemb, int T_MAXBLK, int T_SEG, std::vector<int> &tab, doubl
         // small embedding spaces: every workgroup sees the whole matrix width (panels U[.][192], C[.][192]), so the
         // blocks of the lower triangle are simply dealt out evenly -- no light items (C4: 45 blocks -> 2 workgroups x 4
         // waves x 5-6 blocks instead of a 28-block triangle plus a 14- and a 3-block item)
-        std::vector<std::pair<int, int>> all;
+        // Balanced in SEGMENTS, not in blocks: in an all-symmetrised group (the common case) an off-diagonal block runs two
+        // segments per K step and a folded diagonal block one, so an even split of the row-major block list left waves with
+        // 5 to 8 segments in one workgroup (C4: 81 useful of 92 occupied segment slots).  Diagonal blocks are dealt out first,
+        // one per wave, then every off-diagonal block goes to the wave with the lightest load (ties: fewer blocks): C4 ->
+        // nine waves of 3 + 1 blocks (7 segments) and three of 3 (6 segments), 81 of 84 slots; by block count (groups that
+        // are not all symmetrised) the same lists are 4, 4, 4, 3 per workgroup.
+        const int nblk_all = nb * (nb + 1) / 2;
+        const int nwg = (nblk_all + 4 * T_MAXBLK - 1) / (4 * T_MAXBLK);
+        const int nw = 4 * nwg;
+        std::vector<std::vector<std::pair<int, int>>> wl(nw);
+        std::vector<int> load(nw, 0);
+        for (int d = 0; d < nb; ++d) {                                // diagonal blocks round-robin
+            wl[d % nw].push_back({d, d});
+            load[d % nw] += 1;
+        }
         for (int r = 0; r < nb; ++r)
-            for (int c = 0; c <= r; ++c) all.push_back({r, c});
-        const int nwg = (int)((all.size() + 4 * T_MAXBLK - 1) / (4 * T_MAXBLK));
-        size_t pos = 0;
+            for (int c = 0; c < r; ++c) {
+                int best = -1;
+                for (int w = 0; w < nw; ++w) {
+                    if ((int)wl[w].size() >= T_MAXBLK) continue;
+                    if (best < 0 || load[w] < load[best] || (load[w] == load[best] && wl[w].size() < wl[best].size())) best = w;
+                }
+                wl[best].push_back({r, c});
+                load[best] += 2;
+            }
+        // workgroups of four waves with similar loads (a workgroup lasts as long as its heaviest wave)
+        std::vector<int> order(nw);
+        for (int w = 0; w < nw; ++w) order[w] = w;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
         for (int wg = 0; wg < nwg; ++wg) {
-            const size_t n = all.size() / nwg + ((size_t)wg < all.size() % nwg ? 1 : 0);
-            std::vector<std::pair<int, int>> part(all.begin() + pos, all.begin() + pos + n), lists[4];
-            pos += n;
-            even_split(part, lists);
+            std::vector<std::pair<int, int>> lists[4];
+            for (int w = 0; w < 4; ++w) lists[w] = wl[order[4 * wg + w]];
             push_item(2, 0, 0, lists);
         }
         return;
@@ -368,9 +405,26 @@ int half2_tab_usable(int nao, int nemb) {
 int half2_tab_maxslot() { return T_MAXSLOT; }
 
 // Returns 1 if handled, 0 if the caller must use the generic kernel, < 0 on error.  Arguments as launch_half2_hot (zhot.hip).
+// Sub-groups of a step-2 launch (see H2TArgs): how many runs the queue of `nslot` blocks should be cut into so that the launch
+// has at least ~6 rounds of resident workgroups; 1 when it already has, or when the queue is too short to cut.
+int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int nslot, int max_sub) {
+    (void)ctx; (void)nao;
+    if (const char *e = getenv("DMK_ERI_TAB_SUB")) { const int v = atoi(e); if (v >= 1) return std::min(std::min(v, max_sub), std::max(1, nslot / 2)); }
+    const int nb = (nemb + 15) / 16;
+    const int occ = nb <= T_WIDE_MAXNB ? 3 : 2;
+    const int maxblk = occ == 3 ? Cfg3::MAXBLK : Cfg2::MAXBLK;
+    // items per L: wide tables nwg, segment tables roughly the same count
+    const int nitems = std::max(1, (nb * (nb + 1) / 2 + 4 * maxblk - 1) / (4 * maxblk));
+    const double rounds = (double)nitems * nL * nspin / (256.0 * occ);
+    int p = 1;
+    while (p < max_sub && p * rounds < 6.0 && nslot / (p + 1) >= 2) ++p;
+    return p;
+}
+
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj, const int *sym,
                      double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
-                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int nsub,
+                     double *planes_sub, long long sub_stride) {
     if (!half2_tab_usable(nao, nemb) || nslot < 1 || nslot > T_MAXSLOT || nspin < 1 || nspin > 2) return 0;
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
     // occupancy point (see Cfg2 / Cfg3).  Measured (MI355X, executed TF of this kernel): the evenly dealt WIDE items of small
@@ -417,8 +471,14 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.table = tb->dev; a.nitems = tb->nitems;
     a.fold_diag = (a.symmask == (nslot >= 32 ? 0xffffffffu : ((1u << nslot) - 1u))) ? 1 : 0;
-    const unsigned long long nblocks = (unsigned long long)tb->nitems * (unsigned)nL * (unsigned)nspin;
+    if (nsub < 1 || !planes_sub) nsub = 1;
+    a.sub_slots = (nslot + nsub - 1) / nsub;
+    a.nsub = (nslot + a.sub_slots - 1) / a.sub_slots;                 // runs that actually hold blocks
+    a.planes_sub = planes_sub; a.sub_stride = sub_stride;
+    const unsigned long long per_sub = (unsigned long long)tb->nitems * (unsigned)nL * (unsigned)nspin;
+    const unsigned long long nblocks = per_sub * (unsigned)a.nsub;
     if (nblocks > 0x7fffffffull) return 0;
+    a.per_sub = (unsigned)per_sub;
     a.nblocks = (unsigned)nblocks;
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     // a symmetrised block runs a second segment -- without the folded diagonal blocks when the whole group is symmetrised

@@ -57,14 +57,14 @@ def all_reduce_sum_dev(dev_array):
     import torch
     td = _td()
     if td.get_backend() == "nccl":
-        dev_array.ctx.sync()
+        order_after_library(dev_array.ctx)
         t = tensor_view(dev_array)
         # large buffers in <= 2 GiB slices keep RCCL's staging bounded
         flat = t.view(-1)
         step = 1 << 28
         for o in range(0, flat.numel(), step):
-            td.all_reduce(flat[o:o + step])
-        torch.cuda.synchronize()
+            td.all_reduce(flat[o:o + step])          # synchronous op: the current stream waits for it on return
+        order_library_after_current(dev_array.ctx)
     else:
         host = dev_array.get()
         t = torch.from_numpy(host)
@@ -105,16 +105,49 @@ class _Pending(object):
         self.items = []
 
 
+def library_stream(ctx):
+    """The stream libdmetk launches on, as a torch stream: the device's legacy default stream, or the caller's stream
+    (Context(stream=...) / Context.set_stream) wrapped without taking ownership."""
+    import torch
+    if ctx.default_stream:
+        return torch.cuda.default_stream(ctx.device)
+    return torch.cuda.ExternalStream(ctx.stream_ptr, device=ctx.device)
+
+
+def order_after_library(ctx):
+    """Make torch's CURRENT stream wait for everything queued so far on the library's stream, through an explicit event
+    (no reliance on null-stream semantics, no host synchronisation).  A collective issued next is ordered after the kernels
+    that produced its input: ProcessGroupNCCL's own stream waits for the current stream at the call."""
+    import torch
+    lib_s, cur = library_stream(ctx), torch.cuda.current_stream(ctx.device)
+    if lib_s.cuda_stream == cur.cuda_stream:
+        return                                          # same queue: already ordered
+    ev = torch.cuda.Event()
+    ev.record(lib_s)
+    cur.wait_event(ev)
+
+
+def order_library_after_current(ctx):
+    """The reverse edge: the library's stream waits for what torch's current stream has queued (e.g. after Work.wait() has
+    made the current stream wait for a collective), so library kernels launched next see the reduced data."""
+    import torch
+    lib_s, cur = library_stream(ctx), torch.cuda.current_stream(ctx.device)
+    if lib_s.cuda_stream == cur.cuda_stream:
+        return
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    lib_s.wait_event(ev)
+
+
 def reduce_rows_to(dev_rows, owner, pending):
     """Sum the device block `dev_rows` over ranks INTO rank `owner` (other ranks keep their partial values).
-    RCCL: asynchronous on the process group's own stream, which waits for the work already queued on the library's
-    stream (the legacy default stream, ordered with torch's current stream) -- kernels launched afterwards overlap with
-    it.  gloo: staged through the host, synchronous."""
+    RCCL: asynchronous on the process group's own stream, ordered after the kernels already queued on the library's
+    stream by an explicit event (`order_after_library`) -- whichever stream the library runs on -- while kernels launched
+    afterwards overlap with it.  gloo: staged through the host, synchronous."""
     import torch
     td = _td()
     if td.get_backend() == "nccl":
-        if not dev_rows.ctx.default_stream:
-            dev_rows.ctx.sync()
+        order_after_library(dev_rows.ctx)
         t = tensor_view(dev_rows)
         pending.add(td.reduce(t.view(-1), dst=owner, async_op=True), t)
     else:
@@ -144,10 +177,9 @@ def reduce_eri_bands(eng, eri_dev, spin_pair, npair, bands_per_group=None):
         if is_initialized():           # also with ONE rank (DMK_FORCE_DIST=1): the same RCCL calls as on a multi-GPU node
             for blk in range(spin_pair):
                 reduce_rows_to(eri_dev.offset((blk * npair + lo) * npair, (hi - lo, npair)), owner, pending)
-    pending.wait()
+    pending.wait()                       # torch's current stream now waits for every reduction
     if is_initialized() and _td().get_backend() == "nccl":
-        import torch
-        torch.cuda.synchronize()
+        order_library_after_current(eri_dev.ctx)       # ... and so does whatever the library launches next (J / K on the owned rows)
     return table
 
 

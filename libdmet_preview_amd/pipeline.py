@@ -226,7 +226,8 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
     The stopping tolerances are TIGHTER than the reference's defaults (gtol 1e-3, ytol 1e-7, dx_tol 1e-7, fit.py:59): at
     those the synthetic problem stops after 5 gradient evaluations with the error barely changed, which measures the cost
     of 5 iterations and not of a fit; with these the CG runs until the density error has dropped by orders of magnitude
-    (the returned dict says how far).  Returns timings per evaluation; replicated work (every rank holds basis and target)."""
+    (the returned dict says how far).  Returns timings per evaluation.  Collective over the ranks of an initialised process
+    group: the dV_dparam table is sharded row-wise (slater.EmbFitDevice), the nemb x nemb algebra is replicated."""
     from libdmet_preview_amd.dmet import Hubbard
     from libdmet_preview_amd.system.lattice import Lattice
     n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
@@ -281,7 +282,11 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
             "param_err_begin": float(np.abs(p_true).max()), "param_err_end": float(np.abs(p - p_true).max()),
             "seconds_total": t_total, "objective_evals": int(fit.nfev), "gradient_evals": int(fit.ngev),
             "reference_tolerances": {"seconds_total": t_ref, "objective_evals": ref_counts[0], "gradient_evals": ref_counts[1],
-                                     "err_end": float(e1_ref), "param_err_end": float(np.abs(p_ref - p_true).max())},
+                                     "err_end": float(e1_ref), "param_err_end": float(np.abs(p_ref - p_true).max()),
+                                     "note": "UNCONVERGED: at the reference's default stopping rules this synthetic problem stops after "
+                                             "%d gradient evaluations with the error barely moved; it measures the cost of that many "
+                                             "evaluations, not of a fit, and is not part of any headline key" % ref_counts[1]},
+            "table_rows_per_rank": int(fit.nloc), "ranks": int(dist.world_size()),
             "ms_per_objective": 1e3 * t_err, "ms_per_objective_plus_gradient": 1e3 * t_grad,
             "dV_dparam_bytes": int(fit.d_dV.nbytes), "vcor": v,
             "err_reduction": float(e0 / max(e1, 1e-300)),
@@ -291,11 +296,11 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
                     "+ one eigh(nemb) per spin + nemb^3 algebra; objective + gradient = two passes"}
 
 
-def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_blocks_per_kL=None, exchange=None):
+def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_blocks_per_kL=None, exchange=None, probe=None):
     """DF half transform + contraction over this rank's kL shard.  The planes of the shard stay resident (as many kL as the
     DMK_ERI_STACK_GB budget holds) and are contracted together.  `exchange`: None (local result), "allreduce" (every rank gets
     the whole sum) or "row_sharded" (finished bands of pair rows are reduced to their owners underneath the remaining
-    contraction, dist.reduce_eri_bands).  Returns (nblocks, flops_half, flops_contract, ownership table or None)."""
+    contraction, dist.reduce_eri_bands).  `probe` = (d_x, d_yref): Freivalds probe of the contraction (EriEngine.set_probe).  Returns (nblocks, flops_half, flops_contract, ownership table or None)."""
     timers = {} if timers is None else timers
     t = time.perf_counter()
     eng = et.EriEngine(ctx, sysm.mesh, sysm.nao, sysm.naux, nemb, sysm.spin, d_C, eri_dev, True)
@@ -303,6 +308,8 @@ def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_bloc
     try:
         todo = eng.irreducible_kL() if kL_list is None else list(kL_list)
         eng.set_stack(n_kL=len(todo))
+        if probe is not None:
+            eng.set_probe(probe[0], probe[1])
         nblk = 0
         for kL in todo:
             nblk += eng.run_kL(kL, sysm.df, max_blocks=max_blocks_per_kL)
@@ -323,7 +330,7 @@ def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_bloc
 
 
 def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per_kL=None, allreduce_eri=True,
-              emb_ham=True, eri_exchange=None):
+              emb_ham=True, eri_exchange=None, eri_probe=None):
     """One embedding-construction pass.  Returns a dict with the products and per-stage seconds.  `eri_exchange`: how the
     kL-sharded ERI is summed over ranks -- "allreduce" (default when `allreduce_eri`), "row_sharded" or "none"."""
     if eri_exchange is None:
@@ -340,7 +347,7 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
         if eri_dev is None:
             eri_dev = ctx.zeros((spin_pair, npair, npair), np.float64)
         nblk, fh, fc, rows = eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list, timers, max_blocks_per_kL,
-                                       exchange=None if eri_exchange == "none" else eri_exchange)
+                                       exchange=None if eri_exchange == "none" else eri_exchange, probe=eri_probe)
         out.update({"C_ao_emb": d_C, "eri": eri_dev, "nblocks": nblk, "flops_half": fh, "flops_contract": fc, "eri_rows": rows})
         if emb_ham:
             out["emb_ham"] = emb_ham_stage(ctx, sysm, d_basis, nemb, d_rhoR, eri_dev, timers, d_bk=d_bk, eri_rows=rows)

@@ -355,9 +355,10 @@ embHam = get_emb_Ham
 # correlation-potential fit in the embedding space (routine/slater.py:851-1329)
 # ---------------------------------------------------------------------------------------------
 
-def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7):
+def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7, rows=None):
     """Device dV_dparam (nparam, spin, npair) f64, tril packed (slater.py:851-877 with transform_local_sparseH,
-    slater_helper.py:91-100): gathered from the cell Gram matrix of the basis rows that any parameter touches."""
+    slater_helper.py:91-100): gathered from the cell Gram matrix of the basis rows that any parameter touches.
+    `rows` = (p_lo, p_hi): only that range of parameters (a rank's shard of the table), shape (p_hi - p_lo, spin, npair)."""
     basis = np.asarray(basis, dtype=np.float64)
     spin, ncells, nlo, nb = basis.shape
     npair = nb * (nb + 1) // 2
@@ -373,12 +374,13 @@ def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7):
     used = np.unique(np.concatenate([nz[2], nz[3]])) if len(nz[0]) else np.zeros(0, dtype=int)
     pos = -np.ones(nlo, dtype=np.int64)
     pos[used] = np.arange(len(used))
-    d_dV = ctx.zeros((nparam, spin, npair), np.float64)
-    if len(used) == 0:
+    p_lo, p_hi = (0, nparam) if rows is None else (int(rows[0]), int(rows[1]))
+    d_dV = ctx.zeros((max(p_hi - p_lo, 1), spin, npair), np.float64)
+    if len(used) == 0 or p_hi <= p_lo:
         return d_dV
     m = len(used) * nb
     for s in range(spin):
-        sel = nz[1] == s
+        sel = (nz[1] == s) & (nz[0] >= p_lo) & (nz[0] < p_hi)
         ip, zi, zj, zv = nz[0][sel], pos[nz[2][sel]], pos[nz[3][sel]], vals[sel]
         if len(ip) == 0:
             continue
@@ -387,7 +389,7 @@ def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7):
         d_X = ctx.to_device(np.ascontiguousarray(basis[s][:, used, :]).reshape(ncells, m))
         d_G = ctx.zeros((m, m), np.float64)
         ctx.check(lib.dmk_dgemm_tn_acc(ctx.h, m, ncells, 1.0, d_X.ptr, d_X.ptr, m, d_G.ptr, m))
-        off = (ents.astype(np.int64) * spin + s) * npair
+        off = ((ents.astype(np.int64) - p_lo) * spin + s) * npair
         for e0 in range(0, len(ents), 32768):
             e1 = min(len(ents), e0 + 32768)
             sl = slice(ptr[e0], ptr[e1])
@@ -428,7 +430,7 @@ class EmbFitDevice(object):
     (ftsystem.py:151-213) are the same expression with different K."""
 
     def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, fock_k, ovlp_k, mu0=None,
-                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi"):
+                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi", shard=True):
         from libdmet_preview_amd.routine import mfd
         self._mfd = mfd
         self.ctx, self.vcor = ctx, vcor
@@ -460,7 +462,20 @@ class EmbFitDevice(object):
                 ctx.check(lib.dmk_ewise_mul(ctx.h, 1, nb, nb, d_V.ptr, d_sc.ptr, d_T.ptr))          # rows v_m / sqrt(w_m)
                 ctx.check(lib.dmk_dgemm_batched(ctx.h, 1, 0, nb, nb, nb, 1, 1.0, d_V.ptr, nb, nb * nb, d_T.ptr, nb, nb * nb,
                                                 0.0, self.d_X.offset(s * nb * nb, (nb, nb)).ptr, nb, nb * nb))
-        self.d_dV = get_dV_dparam_dev(ctx, vcor, basis)
+        # Rank-sharded table: rank r holds the rows [p_lo, p_hi) of dV_dparam (1.68 GB / N at C5), contracts its slice in both
+        # table passes and the small results are summed over ranks -- V_emb (spin x npair) after the column pass, the
+        # gradient slices after the row pass.  Everything else (eigh of nemb x nemb, densities) is replicated and, being
+        # deterministic on identical inputs, stays bit-identical across ranks.  The reference shards the gradient of its lattice
+        # fit over ranks the same way (routine/mfd_mpi.py:117-162 get_dw_dparam: local slice, then mpi reduce).
+        from libdmet_preview_amd.parallel import dist as _dist
+        self._dist = _dist if (shard and _dist.is_initialized() and _dist.world_size() > 1) else None
+        if self._dist is not None:
+            cuts = np.linspace(0, self.nparam, self._dist.world_size() + 1).astype(np.int64)
+            self.p_lo, self.p_hi = int(cuts[self._dist.rank()]), int(cuts[self._dist.rank() + 1])
+        else:
+            self.p_lo, self.p_hi = 0, self.nparam
+        self.nloc = self.p_hi - self.p_lo
+        self.d_dV = get_dV_dparam_dev(ctx, vcor, basis, rows=(self.p_lo, self.p_hi))
         # fitted entries: the imp x imp block and the det diagonal of rho[fit_idx, fit_idx] (slater.py:1012-1017)
         self.fit_idx = list(imp_idx) + list(det_idx)
         nimp, nidx = len(imp_idx), len(self.fit_idx)
@@ -477,12 +492,12 @@ class EmbFitDevice(object):
         self.d_fit = ctx.to_device(np.asarray(self.fit_idx, dtype=np.int32))
         # work arrays
         e = lambda *shape: ctx.empty(shape, np.float64)
-        self.d_param, self.d_vemb, self.d_H = e(self.nparam), e(spin, self.npair), e(spin, nb, nb)
+        self.d_param, self.d_vemb, self.d_H = e(max(self.nloc, 1)), e(spin, self.npair), e(spin, nb, nb)
         self.d_T, self.d_T2, self.d_w, self.d_Vp, self.d_Vt = e(spin, nb, nb), e(spin, nb, nb), e(spin, nb), e(spin, nb, nb), e(spin, nb, nb)
         self.d_occ, self.d_sc, self.d_rho = e(spin, nb), e(spin, nb, nb), e(spin, nb, nb)
         self.d_rfit, self.d_drho, self.d_ss = e(spin, nidx, nidx), e(spin, nidx, nidx), e(1)
         self.d_C, self.d_M1, self.d_K = e(spin, nb, nidx), e(spin, nb, nidx), e(spin, nb, nb)
-        self.d_dw, self.d_grad = e(spin, self.npair), e(self.nparam)
+        self.d_dw, self.d_grad = e(spin, self.npair), e(max(self.nloc, 1))
         self._key, self._state = None, None
         self.nfev = self.ngev = 0
         # eigensolver: "jacobi" (multi-CU, warm started: latency) or "ql" (batched Householder + QL); DMK_FIT_EIGH overrides
@@ -501,10 +516,15 @@ class EmbFitDevice(object):
     def _vemb_into(self, param, d_out):
         """d_out (spin, npair) = param . dV_dparam: one pass over the 1.7 GB (C5) table."""
         ctx, spin = self.ctx, self.spin
-        param = np.ascontiguousarray(param, dtype=np.float64)
-        ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_param.ptr, param.ctypes.data, param.nbytes))
-        ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, None,
-                                 self.d_param.ptr, None, d_out.ptr))
+        param = np.ascontiguousarray(np.asarray(param, dtype=np.float64)[self.p_lo:self.p_hi])
+        if self.nloc > 0:
+            ctx.check(lib.dmk_memcpy_h2d(ctx.h, self.d_param.ptr, param.ctypes.data, param.nbytes))
+            ctx.check(lib.dmk_dgemv2(ctx.h, self.nloc, spin * self.npair, self.d_dV.ptr, spin * self.npair, None,
+                                     self.d_param.ptr, None, d_out.ptr))
+        else:
+            d_out.zero_()
+        if self._dist is not None:
+            self._dist.all_reduce_sum_dev(d_out)                  # spin x npair doubles (0.5 MB at C5)
 
     def _forward(self, param, ray=None):
         param = np.ascontiguousarray(param, dtype=np.float64)
@@ -656,9 +676,16 @@ class EmbFitDevice(object):
                 dw_dmu = float(self.d_ss.get()[0]) * 2.0 * self.beta
                 ctx.check(lib.dmk_axpy_f64(ctx.h, nb * nb, dw_dmu / fsum, d_dm.ptr, self.d_sc.offset(s * nb * nb, (nb, nb)).ptr))
         ctx.check(lib.dmk_sym_fold(ctx.h, nb, spin, self.d_sc.ptr, self.d_dw.ptr))
-        ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, self.d_dw.ptr,
-                                 None, self.d_grad.ptr, None))
-        res = self.d_grad.get() / (2.0 * val * sqrt(spin))
+        if self.nloc > 0:
+            ctx.check(lib.dmk_dgemv2(ctx.h, self.nloc, spin * self.npair, self.d_dV.ptr, spin * self.npair, self.d_dw.ptr,
+                                     None, self.d_grad.ptr, None))
+        if self._dist is not None:
+            full = np.zeros(self.nparam)                           # every rank fills its slice; the sum is the whole gradient
+            if self.nloc > 0:
+                full[self.p_lo:self.p_hi] = self.d_grad.get()[:self.nloc]
+            res = self._dist.all_reduce_sum_numpy(full) / (2.0 * val * sqrt(spin))
+        else:
+            res = self.d_grad.get()[:self.nloc] / (2.0 * val * sqrt(spin))
         if self.remove_diag_grad:
             for s in range(spin):
                 d = self.vcor.diag_indices()[s]

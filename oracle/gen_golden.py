@@ -992,6 +992,95 @@ def gen_G15():
     print("G15 done")
 
 
+_G16_CASES = [("uhf_221", (2, 2, 1), 6, 5, [1, 2, 3]), ("uhf_311", (3, 1, 1), 5, 4, [0, 1, 2])]
+
+
+def _g16_case(out, et, slater, rdmet, name, mesh, nlo, naux, val, log=None):
+    """One case of the driver-layer chain (see gen_G16).  `log` (oracle/contract.Log): watch the lattice / vcor / df / cell
+    objects and file every attribute the reference's entry points read from them under the entry point's name (gen_G17)."""
+    nk = int(np.prod(mesh))
+    spin = 2
+    rng = np.random.default_rng(1600 + nlo)
+    core = [i for i in range(nlo) if i < min(val)]
+    virt = [i for i in range(nlo) if i > max(val)]
+    L = _duck_lattice(mesh, nlo, val=val, virt=virt, core=core)
+    FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=160 + nlo)
+    Fk = synth.fold_R2k(FR, mesh)
+    HR = 0.6 * FR
+    Hk = synth.fold_R2k(HR, mesh)
+    SR = np.zeros((nk, nlo, nlo))
+    SR[0] = np.eye(nlo)
+    Sk = synth.fold_R2k(SR[None], mesh)[0]
+    L.fock_lo_k, L.fock_lo_R, L.hcore_lo_k, L.hcore_lo_R = Fk, FR, Hk, HR
+    L.vhf_lo_k, L.ovlp_lo_k = Fk - Hk, Sk
+    L.JK_imp = L.Ham = None
+    L.H0 = 0.75
+    # ab-initio side: AO = LO dimension, TR-symmetric C_ao_lo, real-space DF kernel
+    cell = shim.FakeCell(nlo)
+    cell.pbc_intor = True                                   # slater.py:449 picks the periodic branch on this attribute
+    from libdmet.system import fourier as rf
+    ks = rf.make_kpts_scaled(mesh)
+    kpts = cell.get_abs_kpts(ks)
+    W0 = 0.3 * synth.make_W0(mesh, naux, nlo, seed=1700 + nk)
+    blocks = synth.df_blocks_from_W0(W0, mesh)
+    L.cell = cell
+    L.df = shim.FakeGDF(cell, kpts, lambda i, j, b=blocks: b[i, j], naux=naux, blockdim=naux)
+    L.C_ao_lo = synth.make_C_ao_lo(mesh, nlo, nlo, spin=spin, seed=170 + nlo)
+    L.eri_symmetry = 4
+    # correlation potential: VcorLocal on the valence orbitals, seeded parameters
+    vc = rdmet.VcorLocal(False, False, nlo, idx_range=val)
+    p0 = 0.1 * rng.standard_normal(vc.length())
+    vc.update(p0)
+    stage = (lambda s: None) if log is None else log.stage
+    if log is not None:
+        # G17: the objects the entry points are handed, watched for the attribute names read from outside
+        from oracle import contract
+        contract.watch(L, log, "lattice")
+        contract.watch(vc, log, "vcor")
+        contract.watch(L.df, log, "df")
+        contract.watch(cell, log, "cell")
+    stage("HartreeFock")
+    rho, mu, res = rdmet.HartreeFock(L, vc, 0.5, mu0=None, beta=np.inf, ires=True)
+    L.rdm1_lo_k, L.rdm1_lo_R = res["rho_k"], rho
+    out[name + "/mesh"], out[name + "/val"] = np.array(mesh), np.array(val)
+    out[name + "/Fock_R"], out[name + "/H1_R"], out[name + "/W0"], out[name + "/C_ao_lo"] = FR, HR, W0, L.C_ao_lo
+    out[name + "/vcor_param"], out[name + "/vcor_value"] = p0, vc.get()
+    out[name + "/rho"], out[name + "/mu"], out[name + "/rho_k"] = rho, np.asarray(mu), res["rho_k"]
+    for tag, kw in [("ib", dict(int_bath=True)), ("nib", dict(int_bath=False))]:
+        L.JK_core = "unset"
+        stage("ConstructImpHam_" + tag)
+        ImpHam, H1e, basis = rdmet.ConstructImpHam(L, rho, vc, matching=True, **kw)
+        stage("other")
+        key = "%s/%s" % (name, tag)
+        out[key + "/basis"] = basis
+        out[key + "/H1"], out[key + "/H2"] = ImpHam.H1["cd"], np.asarray(ImpHam.H2["ccdd"])
+        out[key + "/H0"], out[key + "/ovlp"] = np.asarray(ImpHam.H0), np.asarray(ImpHam.ovlp)
+        if L.JK_core is not None and not isinstance(L.JK_core, str):
+            out[key + "/JK_core"] = np.asarray(L.JK_core)
+        assert ImpHam.H2["ccdd"].shape[0] == 3
+        if tag == "ib":
+            # slater.py:461-462: the solver order is (aa, bb, ab); the raw transform returns (aa, ab, bb)
+            stage("get_emb_eri_fast_gdf")
+            raw = et.get_emb_eri_fast_gdf(cell, L.df, C_ao_lo=L.C_ao_lo, basis=basis, max_memory=1)
+            stage("other")
+            assert np.array_equal(raw[[0, 2, 1]], ImpHam.H2["ccdd"])
+            basis_ib = basis
+    # the chain's fit: target = embedded mean-field density of a hidden parameter vector (stands in for the solver)
+    from libdmet.routine import mfd
+    vt = rdmet.VcorLocal(False, False, nlo, idx_range=val)
+    vt.update(p0 + 0.05 * rng.standard_normal(vc.length()))
+    stage("HF")
+    _, _, _, rt = mfd.HF(L, vt, 0.5, False, beta=np.inf, ires=True)
+    stage("other")
+    target = slater.foldRho_k(rt["rho_k"], L.R2k_basis(basis_ib))
+    out[name + "/fit_target"] = target
+    stage("FitVcor")
+    vfit, err_end = rdmet.FitVcor(target, L, basis_ib, vc, np.inf, 0.5, MaxIter1=40, MaxIter2=0)
+    stage("other")
+    out[name + "/fit_param"], out[name + "/fit_err"] = np.array(vfit.param), np.asarray(err_end)
+    print("G16", name, "H2 max %.3g, fit err %.3e" % (np.abs(out[name + "/ib/H2"]).max(), float(err_end)))
+
+
 def gen_G16():
     """The reference's DRIVER layer as a chain, ab initio (dmet/Hubbard.py:14-37 HartreeFock, dmet/HubPhSymm.py:74-100
     ConstructImpHam = slater.embBasis -> basisMatching -> slater.embHam, dmet/Hubbard.py:1503 FitVcor): a duck-typed ab-initio
@@ -1014,80 +1103,64 @@ def gen_G16():
     et.df = types.SimpleNamespace(MDF=type("MDF", (_Other,), {}), GDF=shim.FakeGDF, FFTDF=type("FFTDF", (_Other,), {}),
                                   AFTDF=type("AFTDF", (_Other,), {}))
     out = {}
-    for name, mesh, nlo, naux, val in [("uhf_221", (2, 2, 1), 6, 5, [1, 2, 3]), ("uhf_311", (3, 1, 1), 5, 4, [0, 1, 2])]:
-        nk = int(np.prod(mesh))
-        spin = 2
-        rng = np.random.default_rng(1600 + nlo)
-        core = [i for i in range(nlo) if i < min(val)]
-        virt = [i for i in range(nlo) if i > max(val)]
-        L = _duck_lattice(mesh, nlo, val=val, virt=virt, core=core)
-        FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=160 + nlo)
-        Fk = synth.fold_R2k(FR, mesh)
-        HR = 0.6 * FR
-        Hk = synth.fold_R2k(HR, mesh)
-        SR = np.zeros((nk, nlo, nlo))
-        SR[0] = np.eye(nlo)
-        Sk = synth.fold_R2k(SR[None], mesh)[0]
-        L.fock_lo_k, L.fock_lo_R, L.hcore_lo_k, L.hcore_lo_R = Fk, FR, Hk, HR
-        L.vhf_lo_k, L.ovlp_lo_k = Fk - Hk, Sk
-        L.JK_imp = L.Ham = None
-        L.H0 = 0.75
-        # ab-initio side: AO = LO dimension, TR-symmetric C_ao_lo, real-space DF kernel
-        cell = shim.FakeCell(nlo)
-        cell.pbc_intor = True                                   # slater.py:449 picks the periodic branch on this attribute
-        from libdmet.system import fourier as rf
-        ks = rf.make_kpts_scaled(mesh)
-        kpts = cell.get_abs_kpts(ks)
-        W0 = 0.3 * synth.make_W0(mesh, naux, nlo, seed=1700 + nk)
-        blocks = synth.df_blocks_from_W0(W0, mesh)
-        L.cell = cell
-        L.df = shim.FakeGDF(cell, kpts, lambda i, j, b=blocks: b[i, j], naux=naux, blockdim=naux)
-        L.C_ao_lo = synth.make_C_ao_lo(mesh, nlo, nlo, spin=spin, seed=170 + nlo)
-        L.eri_symmetry = 4
-        # correlation potential: VcorLocal on the valence orbitals, seeded parameters
-        vc = rdmet.VcorLocal(False, False, nlo, idx_range=val)
-        p0 = 0.1 * rng.standard_normal(vc.length())
-        vc.update(p0)
-        rho, mu, res = rdmet.HartreeFock(L, vc, 0.5, mu0=None, beta=np.inf, ires=True)
-        L.rdm1_lo_k, L.rdm1_lo_R = res["rho_k"], rho
-        out[name + "/mesh"], out[name + "/val"] = np.array(mesh), np.array(val)
-        out[name + "/Fock_R"], out[name + "/H1_R"], out[name + "/W0"], out[name + "/C_ao_lo"] = FR, HR, W0, L.C_ao_lo
-        out[name + "/vcor_param"], out[name + "/vcor_value"] = p0, vc.get()
-        out[name + "/rho"], out[name + "/mu"], out[name + "/rho_k"] = rho, np.asarray(mu), res["rho_k"]
-        for tag, kw in [("ib", dict(int_bath=True)), ("nib", dict(int_bath=False))]:
-            L.JK_core = "unset"
-            ImpHam, H1e, basis = rdmet.ConstructImpHam(L, rho, vc, matching=True, **kw)
-            key = "%s/%s" % (name, tag)
-            out[key + "/basis"] = basis
-            out[key + "/H1"], out[key + "/H2"] = ImpHam.H1["cd"], np.asarray(ImpHam.H2["ccdd"])
-            out[key + "/H0"], out[key + "/ovlp"] = np.asarray(ImpHam.H0), np.asarray(ImpHam.ovlp)
-            if L.JK_core is not None and not isinstance(L.JK_core, str):
-                out[key + "/JK_core"] = np.asarray(L.JK_core)
-            assert ImpHam.H2["ccdd"].shape[0] == 3
-            if tag == "ib":
-                # slater.py:461-462: the solver order is (aa, bb, ab); the raw transform returns (aa, ab, bb)
-                raw = et.get_emb_eri_fast_gdf(cell, L.df, C_ao_lo=L.C_ao_lo, basis=basis, max_memory=1)
-                assert np.array_equal(raw[[0, 2, 1]], ImpHam.H2["ccdd"])
-                basis_ib = basis
-        # the chain's fit: target = embedded mean-field density of a hidden parameter vector (stands in for the solver)
-        from libdmet.routine import mfd
-        vt = rdmet.VcorLocal(False, False, nlo, idx_range=val)
-        vt.update(p0 + 0.05 * rng.standard_normal(vc.length()))
-        _, _, _, rt = mfd.HF(L, vt, 0.5, False, beta=np.inf, ires=True)
-        target = slater.foldRho_k(rt["rho_k"], L.R2k_basis(basis_ib))
-        out[name + "/fit_target"] = target
-        vfit, err_end = rdmet.FitVcor(target, L, basis_ib, vc, np.inf, 0.5, MaxIter1=40, MaxIter2=0)
-        out[name + "/fit_param"], out[name + "/fit_err"] = np.array(vfit.param), np.asarray(err_end)
-        print("G16", name, "H2 max %.3g, fit err %.3e" % (np.abs(out[name + "/ib/H2"]).max(), float(err_end)))
+    for name, mesh, nlo, naux, val in _G16_CASES:
+        _g16_case(out, et, slater, rdmet, name, mesh, nlo, naux, val)
     np.savez_compressed(os.path.join(GOLD, "G16_chain.npz"), **out)
     print("G16 done")
+
+
+def gen_G17():
+    """The duck-type CONTRACT of the entry points: the attribute and method names the reference's own
+    HartreeFock / ConstructImpHam / get_emb_eri_fast_gdf / HF / FitVcor read from the lattice, correlation-potential, GDF and
+    cell objects they are handed (oracle/contract.py recorder around the objects of the first G16 case while the unmodified
+    reference chain runs), plus every name those reference objects offer.  tests/test_gpu_chain.py records the same thing
+    around this package's mirror objects and compares."""
+    import types
+    from oracle import contract
+    et = shim.patch_eri_transform()
+    shim.patch_scf()
+    from libdmet.routine import slater
+    from libdmet.solver import scf as rscf
+    from libdmet.dmet import Hubbard as rdmet
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+
+    class _Other(object):
+        pass
+    et.df = types.SimpleNamespace(MDF=type("MDF", (_Other,), {}), GDF=shim.FakeGDF, FFTDF=type("FFTDF", (_Other,), {}),
+                                  AFTDF=type("AFTDF", (_Other,), {}))
+    log = contract.Log()
+    scratch = {}
+    name, mesh, nlo, naux, val = _G16_CASES[0]
+    _g16_case(scratch, et, slater, rdmet, name, mesh, nlo, naux, val, log=log)
+    # the watched run must not have changed a number: same chain, same golden
+    g16 = np.load(os.path.join(GOLD, "G16_chain.npz"))
+    for k, v in scratch.items():
+        assert np.array_equal(np.asarray(v), g16[k]), k
+    out = {}
+    for (stage, kind), names in sorted(log.reads.items()):
+        out["read/%s/%s" % (stage, kind)] = np.array(sorted(names))
+    # what the reference objects offer at all: fresh, unwatched instances of the same construction
+    L = _duck_lattice(mesh, nlo, val=val, virt=[i for i in range(nlo) if i > max(val)], core=[i for i in range(nlo) if i < min(val)])
+    for a in ("fock_lo_k", "fock_lo_R", "hcore_lo_k", "hcore_lo_R", "vhf_lo_k", "ovlp_lo_k", "JK_imp", "Ham", "JK_core", "cell", "df",
+              "C_ao_lo", "eri_symmetry", "rdm1_lo_k", "rdm1_lo_R"):
+        setattr(L, a, None)                      # the attributes a set_Ham'd ab-initio lattice carries (system/lattice.py:202-393)
+    vc = rdmet.VcorLocal(False, False, nlo, idx_range=val)
+    cell = shim.FakeCell(nlo)
+    cell.pbc_intor = True                        # a PySCF pbc cell has the method; slater.py:449 only asks whether it is there
+    gdf = shim.FakeGDF(cell, np.zeros((int(np.prod(mesh)), 3)), lambda i, j: None, naux=naux, blockdim=naux)
+    for kind, obj in (("lattice", L), ("vcor", vc), ("df", gdf), ("cell", cell)):
+        out["offered/" + kind] = np.array(contract.offered(obj))
+    np.savez_compressed(os.path.join(GOLD, "G17_contract.npz"), **out)
+    for kind in log.kinds():
+        print("G17", kind, sorted(log.names(kind)))
+    print("G17 done")
 
 
 def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17"]
     for g in which:
         globals()["gen_" + g]()
 

@@ -13,11 +13,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(workload, dist_on, rank=0, world=1, over=None, device=0, exchange="allreduce"):
+def _run(workload, dist_on, rank=0, world=1, over=None, device=0, exchange="allreduce", own_stream=False):
     from libdmet_preview_amd import _lib, pipeline
     from libdmet_preview_amd.basis_transform import eri_transform as et
     from libdmet_preview_amd.parallel import dist
-    ctx = _lib.Context(device)
+    keep = None
+    if own_stream:
+        # the library on a stream of the caller's (not the legacy default stream): the exchanges must order themselves
+        # against it through explicit events (dist.order_after_library), not through null-stream semantics
+        import torch
+        keep = torch.cuda.Stream(device)
+        ctx = _lib.Context(device, stream=keep.cuda_stream)
+        assert not ctx.default_stream and ctx.stream_ptr == keep.cuda_stream
+    else:
+        ctx = _lib.Context(device)
     _lib.set_ctx(ctx)
     sysm = pipeline.SyntheticSystem.from_workload(ctx, workload, **(over or {}))
     kl = et.assign_workload(sysm.mesh, world)[rank] if dist_on else None
@@ -36,7 +45,7 @@ def _run(workload, dist_on, rank=0, world=1, over=None, device=0, exchange="allr
             "stages": sorted(out["timers"].keys())}
 
 
-def _worker(rank, world, port, workload, over, q, backend="gloo", exchange="allreduce"):
+def _worker(rank, world, port, workload, over, q, backend="gloo", exchange="allreduce", own_stream=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -52,7 +61,7 @@ def _worker(rank, world, port, workload, over, q, backend="gloo", exchange="allr
     else:
         td.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _run(workload, True, rank, world, over, device=device, exchange=exchange)
+        res = _run(workload, True, rank, world, over, device=device, exchange=exchange, own_stream=own_stream)
         res["world_size"], res["backend"] = td.get_world_size(), td.get_backend()
         q.put((rank, res))
         td.barrier()
@@ -94,6 +103,35 @@ def test_ranks_on_one_gpu_match_single_process(workload, over, world, exchange):
         assert np.abs(res[r]["eri"] - single["eri"]).max() < 1e-11 * scale
         assert np.abs(res[r]["H1"] - single["H1"]).max() < 1e-9
     assert np.array_equal(res[0]["eri"], res[1]["eri"])                   # both ranks hold the same sum
+
+
+@pytest.mark.parametrize("exchange,own_stream", [("row_sharded", False), ("row_sharded", True), ("allreduce", True)])
+def test_one_rank_real_rccl_matches_local(exchange, own_stream):
+    """The RCCL code path itself on the 1-GPU box: ONE rank, backend "nccl", the whole iteration with the row-sharded exchange
+    (zero-copy tensor views of libdmetk buffers, asynchronous ncclReduce per band group on the process group's stream underneath
+    the remaining contraction launches, Work.wait, event edges between the library's stream and torch's, J / K from the owned
+    rows) or the whole-array all-reduce -- with the library on the legacy default stream and on a stream of its own
+    (Context(stream=...)).  A one-rank sum is the identity, so the result must equal the non-distributed pipeline bit for bit
+    where no reduction order changes, and to rounding elsewhere.  reference: eri_transform_mpi.py:151-223."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 32600 + (os.getpid() % 1500)
+    over = dict(mesh=(3, 2, 2), spin=2, nval=8, nlo=24, naux=16)
+    p = mpc.Process(target=_worker, args=(0, 1, port, "C3", over, q, "nccl", exchange, own_stream))
+    p.start()
+    _, res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    single = _run("C3", False, over=over)
+    assert res["world_size"] == 1 and res["backend"] == "nccl"
+    if exchange == "row_sharded":
+        assert res["table"] is not None and len(res["table"]) > 1 and {o for (_, _, o) in res["table"]} == {0}
+    scale = np.abs(single["eri"]).max()
+    assert res["nemb"] == single["nemb"]
+    assert np.abs(res["rho_R"] - single["rho_R"]).max() < 1e-12
+    assert np.abs(res["eri"] - single["eri"]).max() < 1e-11 * scale
+    assert np.abs(res["H1"] - single["H1"]).max() < 1e-9
 
 
 def test_two_ranks_over_rccl_match_single_process():
@@ -162,3 +200,54 @@ def test_bench_script_two_ranks_gloo_one_gpu(scaling):
         assert res["full_config_iteration_wall_s"] == res["full_config"]["iteration_wall_s"]
     else:
         assert "full_config" not in res and res["full_config_iteration_wall_s"] > 0
+
+
+def _fit_run(dist_on, device=0):
+    from libdmet_preview_amd import _lib, pipeline
+    ctx = _lib.Context(device)
+    _lib.set_ctx(ctx)
+    sysm = pipeline.SyntheticSystem.from_workload(ctx, "C3", mesh=(3, 2, 1), spin=2, nval=5, nlo=9, naux=6)
+    out = pipeline.iteration(ctx, sysm, emb_ham=True, eri_exchange="allreduce" if dist_on else "none")
+    fit = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], out["nemb"], out["emb_ham"]["rdm1_emb"], MaxIter=60)
+    return {"param": np.array(fit["vcor"].param), "err_end": fit["err_end"], "rows": fit["table_rows_per_rank"], "nparam": fit["nparam"],
+            "nfev": fit["objective_evals"], "ngev": fit["gradient_evals"]}
+
+
+def _fit_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _fit_run(True)))
+        td.barrier()
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_sharded_vcor_fit_matches_single_rank(world):
+    """FitVcorEmb with the dV_dparam table sharded row-wise over the ranks (every rank contracts its slice in both table passes;
+    V_emb and the gradient slices are summed over ranks; the nemb x nemb algebra is replicated): the fitted parameters equal the
+    single-rank fit to 1e-10, with the same number of objective and gradient evaluations -- the ranks stay in lock-step because
+    the summed quantities are bit-identical on all of them.  reference: routine/mfd_mpi.py:117-162 (local slice + reduce)."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 33900 + (os.getpid() % 1500)
+    procs = [mpc.Process(target=_fit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _fit_run(False)
+    assert single["rows"] == single["nparam"]
+    assert sum(res[r]["rows"] for r in range(world)) == single["nparam"] and max(res[r]["rows"] for r in range(world)) < single["nparam"]
+    for r in range(world):
+        assert np.abs(res[r]["param"] - single["param"]).max() < 1e-10, np.abs(res[r]["param"] - single["param"]).max()
+        assert abs(res[r]["err_end"] - single["err_end"]) < 1e-12
+        assert (res[r]["nfev"], res[r]["ngev"]) == (single["nfev"], single["ngev"])
+        assert np.array_equal(res[r]["param"], res[0]["param"])

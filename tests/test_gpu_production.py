@@ -38,6 +38,10 @@ def _run_and_check(ctx, mesh, nao, naux, nemb, spin, kL_list, A, seed, check_pla
     df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=seed + 1)
     eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
     ref_eri, idx, ref_planes = ES.eri_sample(mesh, seed + 1, Ce, naux, A, kL_list)
+    # Freivalds probe: the contraction is checked on ALL pair rows and columns, not only on the sampled ones
+    d_x = ctx.to_device(rng.uniform(-1.0, 1.0, npair))
+    d_yref = ctx.zeros((nblk, npair), np.float64)
+    eng.set_probe(d_x, d_yref)
     worst_p = 0.0
     try:
         for kL in kL_list:
@@ -57,6 +61,9 @@ def _run_and_check(ctx, mesh, nao, naux, nemb, spin, kL_list, A, seed, check_pla
             got = _eri_rows(eri_dev, b, npair, idx)[:, idx]
             err = np.abs(got - ref_eri[b]).max()
             assert err < 1e-8 and err < 1e-11 * np.abs(ref_eri).max(), (b, err, np.abs(ref_eri).max())
+        y, yref = et.eri_times_vector_dev(ctx, eri_dev, nblk, npair, d_x).get(), d_yref.get()
+        assert np.abs(yref).max() > 0
+        assert np.abs(y - yref).max() <= 1e-10 * max(1.0, np.abs(yref).max()), (np.abs(y - yref).max(), np.abs(yref).max())
         if nblk == 3:
             # aa and bb come from the symmetric (lower-tile-triangle + mirrored store) contraction: both halves present
             for b in (0, 2):
@@ -132,15 +139,19 @@ def test_plane_stack_and_banded_contraction(ctx, nao, naux, nemb, spin, nslots):
     C_dev = ctx.to_device(Ce)
     df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=77)
 
+    d_x = ctx.to_device(rng.uniform(-1.0, 1.0, npair))
+
     def run(stack, banded):
         eri_dev = ctx.zeros((nblk, npair, npair), np.float64)
         eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
         snap = None
+        d_yref = ctx.zeros((nblk, npair), np.float64)
         try:
             kls = eng.irreducible_kL()
             assert sorted(int(eng.weights[k]) for k in kls) == [1, 1, 2, 2]
             if stack:
                 assert eng.set_stack(nslots=stack) == stack
+            eng.set_probe(d_x, d_yref)                   # every contraction path (per kL, stacked, banded, self-flushing stack)
             for kL in kls:
                 eng.run_kL(kL, df)
             if banded:
@@ -154,6 +165,8 @@ def test_plane_stack_and_banded_contraction(ctx, nao, naux, nemb, spin, nslots):
             else:
                 eng.contract()
             ctx.sync()
+            y, yref = et.eri_times_vector_dev(ctx, eri_dev, nblk, npair, d_x).get(), d_yref.get()
+            assert np.abs(y - yref).max() <= 1e-10 * max(1.0, np.abs(yref).max()), (stack, banded, np.abs(y - yref).max())
             return eri_dev.get(), snap
         finally:
             eng.close()
@@ -194,3 +207,106 @@ def test_jk_row_ranges_add_up(ctx):
         assert np.abs(a_ - f_).max() < 1e-11 * np.abs(f_).max()
     empty = scf.jk_dev(ctx, n, dE, da, None, da, row_ranges=[])
     assert np.abs(empty[0].get()).max() == 0.0 and empty[1] is None
+
+
+def test_contraction_probe_detects_a_misplaced_tile(ctx):
+    """The Freivalds probe (dmk_eri_probe) is a real detector: after a correct contraction the residual is at rounding level;
+    moving ONE 128 x 128 tile of the ERI to a neighbouring position, zeroing one, or breaking the symmetry of one mirrored tile
+    makes it jump by many orders of magnitude, whichever tile row is hit.  reference: eri_transform.py:451-478."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, nk, nao, naux, nemb, spin = (2, 2, 1), 4, 16, 24, 64, 2
+    npair = nemb * (nemb + 1) // 2                          # 2080: 17 tile rows
+    rng = np.random.default_rng(5)
+    Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Ce)
+    df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=9)
+    eri_dev = ctx.zeros((3, npair, npair), np.float64)
+    d_x = ctx.to_device(rng.uniform(-1.0, 1.0, npair))
+    d_yref = ctx.zeros((3, npair), np.float64)
+    eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    try:
+        eng.set_stack(nslots=4)
+        eng.set_probe(d_x, d_yref)
+        for kL in eng.irreducible_kL():
+            eng.run_kL(kL, df)
+        eng.contract()
+        ctx.sync()
+    finally:
+        eng.close()
+    yref = d_yref.get()
+    resid = lambda: np.abs(et.eri_times_vector_dev(ctx, eri_dev, 3, npair, d_x).get() - yref).max()
+    clean = resid()
+    assert clean <= 1e-10 * max(1.0, np.abs(yref).max())
+    good = eri_dev.get()
+    scale = np.abs(good).max()
+    for blk, tr, tc in ((0, 0, 0), (1, 7, 3), (2, 16, 16), (0, 16, 0), (2, 5, 11)):
+        r0, c0 = 128 * tr, 128 * tc
+        r1, c1 = min(npair, r0 + 128), min(npair, c0 + 128)
+        bad = good.copy()
+        bad[blk, r0:r1, c0:c1] = 0.0                       # a tile the GEMM never wrote
+        eri_dev.set(bad)
+        assert resid() > 1e6 * max(clean, 1e-18) and resid() > 1e-6 * scale, (blk, tr, tc, resid(), clean)
+        bad = good.copy()
+        bad[blk, r0:r1, c0:c1] = good[blk, r0:r1, c0:c1][:, ::-1]      # right entries, wrong places inside the tile
+        eri_dev.set(bad)
+        assert resid() > 1e6 * max(clean, 1e-18), (blk, tr, tc)
+    eri_dev.set(good)
+    assert resid() == clean
+
+
+def test_rows_only_pipeline_refuses_to_contract_into_an_internal_eri(ctx):
+    """A pipeline opened without an ERI of its own (dmk_eri_begin flag 4, the out-of-core driver) must never launch a GEMM into
+    one: a full stack at begin_kL, an explicit contract and the probe are refused with an error, and finish() -- also on the
+    way out of an exception -- drops the resident planes instead of contracting them (round-3 advisor finding)."""
+    from libdmet_preview_amd import _lib
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, nk, nao, naux, nemb, spin = (3, 2, 1), 6, 10, 8, 12, 2
+    npair = nemb * (nemb + 1) // 2
+    rng = np.random.default_rng(1)
+    Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Ce)
+    df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=3)
+    eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, None, True, rows_only=True)
+    try:
+        assert eng.set_stack(nslots=2) == 2
+        kls = eng.irreducible_kL()
+        eng.run_kL(kls[0], df)
+        eng.run_kL(kls[1], df)
+        assert eng.stack_free() == 0
+        with pytest.raises(_lib.DmkError):
+            eng.run_kL(kls[2], df)                         # full stack: would have contracted into the (absent) ERI
+        with pytest.raises(_lib.DmkError):
+            eng.contract()
+        # the slab interface still works and agrees with an ordinary pipeline
+        d_slab = ctx.zeros((3, npair, npair), np.float64)
+        eng.contract_rows_into(0, npair, d_slab)
+        ctx.sync()
+        got = d_slab.get()
+    finally:
+        eng.close()                                        # planes still resident: dropped, no launch, no error
+    eri_dev = ctx.zeros((3, npair, npair), np.float64)
+    eng2 = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    try:
+        for kL in kls[:2]:
+            eng2.run_kL(kL, df)
+        ctx.sync()
+    finally:
+        eng2.close()
+    ref = eri_dev.get()
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_jk_row_ranges_must_end_on_a_block(ctx):
+    """dmk_jk_s4_rows: the J kernel works on whole 32-row blocks, so a range that ends inside a block (and not at the last row)
+    would make two owners count the same rows; the library rejects it instead of returning a silently wrong J."""
+    from libdmet_preview_amd import _lib
+    from libdmet_preview_amd.solver import scf
+    n = 24
+    npair = n * (n + 1) // 2                               # 300
+    rng = np.random.default_rng(2)
+    dE, d_dm = ctx.to_device(rng.standard_normal((npair, npair))), ctx.to_device(rng.standard_normal((n, n)))
+    with pytest.raises(_lib.DmkError):
+        scf.jk_dev(ctx, n, dE, d_dm, None, d_dm, row_ranges=[(0, 100)])
+    ok = scf.jk_dev(ctx, n, dE, d_dm, None, d_dm, row_ranges=[(0, 96), (96, npair)])
+    full = scf.jk_dev(ctx, n, dE, d_dm, None, d_dm)
+    assert np.abs(ok[0].get() - full[0].get()).max() <= 1e-12 * np.abs(full[0].get()).max()

@@ -48,8 +48,9 @@ FAMILY = [("dgemm_tn_acc_dma_kernel", "dgemm"), ("half1_kernel", "zgemm_half1"),
           ("jk_k_kernel", "jk_k"), ("gemv2_kernel", "gemv2")]
 
 
-def traffic_json(dbs, out):
-    """HBM bytes per launch per kernel family: FETCH_SIZE (x2 gfx950 correction for wide coalesced streams) + WRITE_SIZE."""
+def traffic_json(dbs, out, workload="C5", how=None):
+    """HBM bytes per launch per kernel family: FETCH_SIZE (x2 gfx950 correction for wide coalesced streams) + WRITE_SIZE.
+    The file holds one section per workload ({"workloads": {"C5": {...}, "C4": {...}}}); a run replaces only its own."""
     import json
     acc = {}
     for db in dbs:
@@ -83,16 +84,32 @@ def traffic_json(dbs, out):
         commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except Exception:
         commit = None
-    acc["_collected"] = {"kernel_source_sha": kernel_source_sha(), "commit": commit, "workload": "C5",
-                         "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
-                                "--no-cpu-baseline --no-parity --no-full-config --steps 1 --warmup 0; tools/rocprof_summary.py --traffic-json"}
-    json.dump(acc, open(out, "w"), indent=1)
+    acc["_collected"] = {"kernel_source_sha": kernel_source_sha(), "commit": commit, "workload": workload,
+                         "how": how or ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) -- python3 bench.py "
+                                        "--workload %s ... --steps 1 --warmup 0 --no-parity; tools/rocprof_summary.py --traffic-json"
+                                        % workload)}
+    doc = {"workloads": {}}
+    if os.path.exists(out):
+        try:
+            old = json.load(open(out))
+            if "workloads" in old:
+                doc = old
+            elif "_collected" in old:                       # round-3 layout: one flat section
+                doc["workloads"][old["_collected"].get("workload", "C5")] = old
+        except Exception:
+            pass
+    doc["workloads"][workload] = acc
+    json.dump(doc, open(out, "w"), indent=1)
 
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if args and args[0] == "--traffic-json":
-        traffic_json(args[2:], args[1])
+    if args and args[0] == "--traffic-json":             # --traffic-json OUT [--workload NAME] db ...
+        rest = args[2:]
+        wl = "C5"
+        if rest and rest[0] == "--workload":
+            wl, rest = rest[1], rest[2:]
+        traffic_json(rest, args[1], wl)
         sys.exit(0)
     stats(args[0])
     for d in args[1:]:
