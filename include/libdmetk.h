@@ -272,11 +272,18 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
  * rewritten as soon as the push that completes its group has returned (work is stream-ordered). */
 int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out);
 int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise);
+/* Transform the blocks queued so far NOW (one step-1 and one step-2 launch) instead of when the queue is full: a caller that
+ * knows how many blocks a kL has cuts them into launches of equal length (33 blocks: 11 + 11 + 11, not 16 + 16 + 1).  The next
+ * ring slot to fill is slot 0 again. */
+int dmk_eri_flush(dmk_eri *h);
 /* The same for an AO block in HOST memory (what sr_loop / _load3c hand over, eri_transform.py:195-227, 358-366): the
  * block is copied to one of two device staging blocks (`slot` 0 | 1) on a separate copy stream and transformed on the
  * compute stream as soon as it has landed, so the copy of block n+1 overlaps the transform of block n.  Returns
  * without waiting.  The host buffer may be refilled once dmk_eri_host_slot_wait(h, slot) has returned (use two pinned
- * buffers from dmk_host_alloc and alternate the slots; pageable memory works but copies synchronously). */
+ * buffers from dmk_host_alloc and alternate the slots; pageable memory works but copies synchronously).
+ * symmetrise: bit 0 as in dmk_eri_push_block; bit 1 = the buffer holds the block as STORED for the swapped pair (kj, ki)
+ * (a cderi container keeps only i >= j, eri_transform.py:213-224): it is conjugate-transposed on the device after the
+ * copy instead of by the host before it. */
 int dmk_eri_push_block_host(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq_host, int slot);
 int dmk_eri_host_slot_wait(dmk_eri *h, int slot);
 /* Page-locked host memory for the block feed. */

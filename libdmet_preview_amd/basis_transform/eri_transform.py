@@ -79,6 +79,26 @@ def _unpack_tril_hermi(p, n):
     return out
 
 
+_COPY_POOL = None
+
+
+def _parallel_copy(dst, src, min_bytes=32 << 20, threads=4):
+    """dst[...] = src for a large block, the rows split over a few threads (np.copyto releases the GIL): one core moves a 512 MB
+    C5 block into pinned memory at ~29 GB/s (measured, tools/host_feed_bench.py), slower than the 46 GB/s the PCIe copy behind it
+    sustains; four keep the host side ahead of the link."""
+    global _COPY_POOL
+    if dst.nbytes < min_bytes or dst.shape[0] < threads:
+        np.copyto(dst, src)
+        return
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _COPY_POOL = ThreadPoolExecutor(max_workers=threads)
+    cuts = np.linspace(0, dst.shape[0], threads + 1).astype(int)
+    jobs = [_COPY_POOL.submit(np.copyto, dst[cuts[t]:cuts[t + 1]], src[cuts[t]:cuts[t + 1]]) for t in range(threads)]
+    for j in jobs:
+        j.result()
+
+
 class CderiProvider(object):
     """DF blocks from a PySCF-style `cderi` container.
 
@@ -153,8 +173,38 @@ class CderiProvider(object):
     def load_block(self, ctx, i, j, out_dev):
         out_dev.set(self.get_block(i, j))
 
+    # dmk_eri_push_block_host conjugate-transposes a block uploaded for the swapped pair on the device (flag bit 1): the host
+    # side of a block is then ONE pass -- the stored segments copied (and widened) straight into the pinned buffer
+    host_swap_on_device = True
+
     def load_block_host(self, i, j, out):
-        out[...] = self.get_block(i, j)
+        """Fill the (pinned) host buffer `out` (naux, nao, nao) c128 with the block of pair (i, j) AS STORED and return True when
+        what is stored is the pair (j, i), i.e. the consumer still has to conjugate-transpose it (EriEngine passes that on to
+        dmk_eri_push_block_host).  Packed Gamma-type pairs (ki == kj) are unpacked on the host as before."""
+        nao = self.nao
+        if (i, j) in self.pair_of:
+            swap, p = False, self.pair_of[(i, j)]
+        elif (j, i) in self.pair_of:
+            swap, p = True, self.pair_of[(j, i)]
+        else:
+            raise KeyError("k-point pair (%d, %d) is not in the cderi container" % (i, j))
+        handles = self._segment_handles(p)
+        if np.shape(handles[0])[1] != nao * nao:              # lower-triangular packed (real at Gamma): rare, small
+            blk = self.get_block(i, j)
+            out[...] = blk
+            return False
+        flat = out.reshape(out.shape[0], nao * nao)
+        r = 0
+        for hnd in handles:
+            rows = np.shape(hnd)[0]
+            if hasattr(hnd, "read_direct") and getattr(hnd, "dtype", None) == flat.dtype:
+                hnd.read_direct(flat, dest_sel=np.s_[r:r + rows])          # h5py: straight into the pinned pages
+            else:
+                _parallel_copy(flat[r:r + rows], np.asarray(hnd))
+            r += rows
+        if r < flat.shape[0]:
+            flat[r:] = 0.0                                    # auxiliary-basis drop on some pairs
+        return swap
 
 
 def get_mask_kptij_lst(cell, kptij_lst, tol=KPT_DIFF_TOL):
@@ -666,6 +716,12 @@ class EriEngine(object):
         if host_feed and self.host_buf is None:
             from libdmet_preview_amd._lib import PinnedArray
             self.host_buf = [PinnedArray(ctx, (self.naux, self.nao, self.nao), np.complex128) for _ in range(2)]
+        # launches of EQUAL length: the queue holds ring_slots blocks, a kL of 36 blocks goes out as 12 + 12 + 12, not 16 + 16 + 4
+        ntot = len(self.by_kL[kL]) if max_blocks is None else min(len(self.by_kL[kL]), int(max_blocks))
+        per_launch = 0
+        if self.ring_slots and not host_feed and ntot > self.ring_slots:
+            launches = -(-ntot // self.ring_slots)
+            per_launch = -(-ntot // launches)
         for r in self.by_kL[kL]:
             i, j, sym = int(r[1]), int(r[2]), int(r[4])
             ui, uj = (i, j) if user_of_mesh is None else (int(user_of_mesh[i]), int(user_of_mesh[j]))
@@ -674,13 +730,17 @@ class EriEngine(object):
                 # copied and the previous block is being transformed (dmk_eri_push_block_host)
                 slot = self.host_slot
                 ctx.check(lib.dmk_eri_host_slot_wait(self.h, slot))
-                provider.load_block_host(ui, uj, self.host_buf[slot].a)
-                ctx.check(lib.dmk_eri_push_block_host(self.h, i, j, sym, self.host_buf[slot].ptr, slot))
+                swapped = provider.load_block_host(ui, uj, self.host_buf[slot].a)
+                flags = sym | (2 if (swapped is True and getattr(provider, "host_swap_on_device", False)) else 0)
+                ctx.check(lib.dmk_eri_push_block_host(self.h, i, j, flags, self.host_buf[slot].ptr, slot))
                 self.host_slot = 1 - slot
             elif self.ring_slots:
                 provider.load_block(ctx, ui, uj, self.ring[self.ring_pos])
                 ctx.check(lib.dmk_eri_push_ring_slot(self.h, i, j, sym))
                 self.ring_pos = (self.ring_pos + 1) % self.ring_slots
+                if per_launch and self.ring_pos == per_launch and per_launch < self.ring_slots:
+                    ctx.check(lib.dmk_eri_flush(self.h))
+                    self.ring_pos = 0
             else:
                 provider.load_block(ctx, ui, uj, self.block_buf)
                 ctx.check(lib.dmk_eri_push_block(self.h, i, j, sym, self.block_buf.ptr))

@@ -686,6 +686,7 @@ struct dmk_eri {
     // transforms the other one; created on first use
     hipStream_t copy_stream = nullptr;
     double2 *dstage[2] = {nullptr, nullptr};
+    double2 *tstage = nullptr;       // conjugate-transposed copy of a block uploaded for the swapped pair
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     // sub-group plane copies of the table-driven step 2 (zhot_tab.hip H2TArgs): run p >= 1 of a launch accumulates into copy
     // p - 1 ([spin][2 naux][npair] each); they are zeroed when a kL begins and added to its planes, in order, when it ends
@@ -738,7 +739,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         h->group = h->hot256 ? 8 : 16;               // the table kernel cuts its queue into sub-group runs: a longer queue per launch
         if (const char *e = getenv("DMK_ERI_GROUP")) h->group = atoi(e);
         h->group = std::max(1, std::min(h->group, h->hot256 ? half2_hot_maxslot() : half2_tab_maxslot()));
-        if (!h->hot256) h->nsub_max = half2_tab_subgroups(ctx, naux, nao, nemb, spin, h->group, 4);
+        if (!h->hot256) h->nsub_max = half2_tab_subgroups(ctx, naux, nao, nemb, spin, h->group, 4);      // 1 unless DMK_ERI_TAB_SUB asks
     }
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
     const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1);
@@ -1381,6 +1382,12 @@ int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise) {
     return DMK_OK;
 }
 
+int dmk_eri_flush(dmk_eri *h) {
+    if (!h) return DMK_ERR_INVALID;
+    if (h->cur_kL < 0) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_flush: no kL in progress");
+    return eri_flush(h);
+}
+
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     if (!h || !planes_out) return DMK_ERR_INVALID;
     {
@@ -1397,9 +1404,33 @@ int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
     return DMK_OK;
 }
 
+namespace {
+// out[b][c][r] = conj(in[b][r][c]): a block stored for the swapped k-point pair (kj, ki) becomes the block of (ki, kj)
+// (eri_transform.py:213-224 serves it as Lpq.conj().transpose(0, 2, 1) on the host: one more pass over 512 MB per block there)
+__global__ void conj_transpose_c128_kernel(int n, const double2 *__restrict__ in, double2 *__restrict__ out) {
+    __shared__ double2 tile[32][33];
+    const size_t boff = (size_t)blockIdx.z * n * n;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+        const int r = r0 + y, c = c0 + threadIdx.x;
+        if (r < n && c < n) tile[y][threadIdx.x] = in[boff + (size_t)r * n + c];
+    }
+    __syncthreads();
+    for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+        const int c = c0 + y, r = r0 + threadIdx.x;
+        if (r < n && c < n) {
+            const double2 v = tile[threadIdx.x][y];
+            out[boff + (size_t)c * n + r] = make_double2(v.x, -v.y);
+        }
+    }
+}
+}  // namespace
+
 int dmk_eri_push_block_host(dmk_eri *h, int ki, int kj, int symmetrise, const void *Lpq_host, int slot) {
     if (!h) return DMK_ERR_INVALID;
     dmk_ctx *ctx = h->ctx;
+    const bool swapped = (symmetrise & 2) != 0;        // the host buffer holds the block of the pair (kj, ki)
+    symmetrise &= 1;
     if (slot < 0 || slot > 1 || !Lpq_host) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_block_host: bad arguments");
     if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_block_host: no kL in progress");
     const size_t bytes = (size_t)h->naux * h->nao * h->nao * sizeof(double2);
@@ -1417,6 +1448,19 @@ int dmk_eri_push_block_host(dmk_eri *h, int ki, int kj, int symmetrise, const vo
     DMK_HIP(ctx, hipMemcpyAsync(h->dstage[slot], Lpq_host, bytes, hipMemcpyHostToDevice, h->copy_stream));
     DMK_HIP(ctx, hipEventRecord(h->ev_copied[slot], h->copy_stream));
     DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_copied[slot], 0));
+    if (swapped) {
+        // conjugate-transpose on the device into a third block; the staging slot is free again as soon as that kernel has run
+        if (!h->tstage) DMK_HIP(ctx, dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->tstage), bytes));
+        if (h->naux > 65535) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_block_host: naux too large for the device transpose");
+        {
+            FamScope fs(ctx, DMK_FAM_MISC);
+            dim3 grid((h->nao + 31) / 32, (h->nao + 31) / 32, h->naux), block(32, 8);
+            hipLaunchKernelGGL(conj_transpose_c128_kernel, grid, block, 0, ctx->stream, h->nao, h->dstage[slot], h->tstage);
+            DMK_CHECK_LAUNCH(ctx);
+        }
+        DMK_HIP(ctx, hipEventRecord(h->ev_consumed[slot], ctx->stream));
+        return dmk_eri_push_block(h, ki, kj, symmetrise, h->tstage);
+    }
     int rc = dmk_eri_push_block(h, ki, kj, symmetrise, h->dstage[slot]);
     if (rc) return rc;
     DMK_HIP(ctx, hipEventRecord(h->ev_consumed[slot], ctx->stream));
@@ -1461,6 +1505,7 @@ int dmk_eri_finish(dmk_eri *h) {
             (void)hipEventDestroy(h->ev_consumed[i]);
         }
         (void)hipStreamDestroy(h->copy_stream);
+        if (h->tstage) (void)hipFree(h->tstage);
     }
     if (h->ring) {
         if (!ctx->eri_ws[2]) {

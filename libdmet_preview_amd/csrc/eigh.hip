@@ -57,6 +57,8 @@ struct EighArgs {
                             // back-transformation is done by backtransform_kernel (eigh_tridiag.hip)
     int skip_tridiag;       // d, e, tau, Vh were produced by the CU-resident kernel (eigh_tridiag.hip): phases 0 and 1 are skipped
     int inject;             // fault injection (tests): every `inject`-th eigenvector is treated as failed and goes through the repair path
+    const int *only_flagged;   // batch ints or null: when set, a workgroup whose flag is 0 returns at once -- this launch is then the
+                               // REPAIR PASS behind tri_eigpairs_kernel (eigh_tripairs.hip), which flags the matrices it could not vouch for
 };
 
 // LDS carve (dynamic): vbuf[n] c128 | pbuf[n] c128 | cs[2][2n] f64 | red[3*NW + 2] f64 | 16 ints | dl[n] | el[n] | colpart[NW][n] c128
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(NT) void eigh_kernel(const EighArgs g) {
                                                    ~static_cast<uintptr_t>(15));          // [NW][n] c128 (R <= 4 only), 16-B aligned
 
     const int b = blockIdx.x;
+    if (g.only_flagged && g.only_flagged[b] == 0) return;      // uniform over the workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nn = (size_t)n * n;
     double2 *W = g.W + b * nn;
@@ -722,6 +725,8 @@ int launch_tridiag_resident(dmk_ctx *ctx, int n, int batch, const void *A, const
                             double *d, double *e);
 int launch_backtransform(dmk_ctx *ctx, int n, int batch, const double *Zt, const void *Vh, const void *tau, const int *rank, void *Vt,
                          void *Tws);
+int launch_tri_eigpairs(dmk_ctx *ctx, int n, int batch, const double *d, const double *e, double *Zt, double *w, int *rank_out,
+                        int *flags, int inject);
 namespace {
 
 int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const double *add, int add_group, double *w,
@@ -731,7 +736,7 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     if (n > 2000) return dmk_fail(ctx, DMK_ERR_INVALID, "eigh: n = %d exceeds the supported maximum of 2000", n);
     const size_t nn = (size_t)n * n;
     const size_t per = nn * (16 + 16 + 8 + 56) + (size_t)n * (8 + 8 + 16 + 8);
-    const size_t total = per * batch + 256;
+    const size_t total = per * batch + 256 + (size_t)batch * sizeof(int) + 256;
     void *ws = nullptr;
     int rc = dmk_scratch(ctx, total, &ws);
     if (rc) return rc;
@@ -751,10 +756,12 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
     g.d = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
     g.e = reinterpret_cast<double *>(p); p += (size_t)n * 8 * batch;
     g.ws2 = reinterpret_cast<double *>(p); p += nn * 56 * batch;
-    int *rank_ws = reinterpret_cast<int *>(p);
+    int *rank_ws = reinterpret_cast<int *>(p); p += (size_t)n * 8 * batch;
+    int *flag_ws = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(p) + 255) & ~static_cast<uintptr_t>(255));
     DMK_HIP(ctx, hipMemsetAsync(g.status, 0, sizeof(int), ctx->stream));
     g.skip_tridiag = 0;
     g.rank_out = nullptr;
+    g.only_flagged = nullptr;
 
     const size_t lds = (size_t)n * (16 + 16 + 32 + 16) + (3 * NW + 2) * 8 + 64 + 64 + (n <= 256 ? (size_t)NW * n * 16 + 16 : 0);
     {
@@ -767,6 +774,13 @@ int launch_eigh(dmk_ctx *ctx, int n, int batch, const void *A, int a_real, const
             if (rt < 0) return rt;
             g.skip_tridiag = rt;
             if (rt && !v_real) g.rank_out = rank_ws;         // back-transformation by the lane-per-eigenvector kernel
+            if (g.rank_out) {
+                // eigenpairs of the tridiagonal forms with every vector in LDS (eigh_tripairs.hip); the launch of eigh_kernel
+                // below then only repairs the matrices it flagged (normally none: 432 workgroups that return at once)
+                const int rp = launch_tri_eigpairs(ctx, n, batch, g.d, g.e, g.Zt, w, rank_ws, flag_ws, g.inject);
+                if (rp < 0) return rp;
+                if (rp) g.only_flagged = flag_ws;
+            }
         }
         // single-kernel path: its reflector rows are only partially written; clear so that masked lanes read zeros (the resident
         // kernels write complete rows)

@@ -335,10 +335,9 @@ void build_table(int nemb, int T_MAXBLK, int T_SEG, std::vector<int> &tab, doubl
         }
     };
     if (nb <= T_WIDE_MAXNB) {
-        // small embedding spaces: every workgroup sees the whole matrix width (panels U[.][192], C[.][192]), so the
-        // blocks of the lower triangle are simply dealt out evenly -- no light items (C4: 45 blocks -> 2 workgroups x 4
-        // waves x 5-6 blocks instead of a 28-block triangle plus a 14- and a 3-block item)
-        // Balanced in SEGMENTS, not in blocks: in an all-symmetrised group (the common case) an off-diagonal block runs two
+        // small embedding spaces: every workgroup sees the whole matrix width (panels U[.][192], C[.][192]), so any block can go
+        // to any wave -- no light items (C4: 45 blocks -> 3 workgroups x 4 waves instead of a 28-block triangle plus a 14- and
+        // a 3-block item).  Balanced in SEGMENTS, not in blocks: in an all-symmetrised group (the common case) an off-diagonal block runs two
         // segments per K step and a folded diagonal block one, so an even split of the row-major block list left waves with
         // 5 to 8 segments in one workgroup (C4: 81 useful of 92 occupied segment slots).  Diagonal blocks are dealt out first,
         // one per wave, then every off-diagonal block goes to the wave with the lightest load (ties: fewer blocks): C4 ->
@@ -408,17 +407,14 @@ int half2_tab_maxslot() { return T_MAXSLOT; }
 // Sub-groups of a step-2 launch (see H2TArgs): how many runs the queue of `nslot` blocks should be cut into so that the launch
 // has at least ~6 rounds of resident workgroups; 1 when it already has, or when the queue is too short to cut.
 int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int nslot, int max_sub) {
-    (void)ctx; (void)nao;
-    if (const char *e = getenv("DMK_ERI_TAB_SUB")) { const int v = atoi(e); if (v >= 1) return std::min(std::min(v, max_sub), std::max(1, nslot / 2)); }
-    const int nb = (nemb + 15) / 16;
-    const int occ = nb <= T_WIDE_MAXNB ? 3 : 2;
-    const int maxblk = occ == 3 ? Cfg3::MAXBLK : Cfg2::MAXBLK;
-    // items per L: wide tables nwg, segment tables roughly the same count
-    const int nitems = std::max(1, (nb * (nb + 1) / 2 + 4 * maxblk - 1) / (4 * maxblk));
-    const double rounds = (double)nitems * nL * nspin / (256.0 * occ);
+    (void)ctx; (void)nao; (void)nL; (void)nemb; (void)nspin;
+    // Measured at C4 (round 4, profiles/r04_*): 1 / 2 / 4 runs per launch = 1.438 / 1.425 / 1.443 ms per 16-block launch, and each
+    // extra run costs a pass over the planes when the kL ends -- the partial last round of workgroups is NOT what holds this
+    // kernel back.  One run per launch therefore stays the default; DMK_ERI_TAB_SUB = 2..4 cuts the queue for experiments on
+    // other shapes.
     int p = 1;
-    while (p < max_sub && p * rounds < 6.0 && nslot / (p + 1) >= 2) ++p;
-    return p;
+    if (const char *e = getenv("DMK_ERI_TAB_SUB")) p = atoi(e);
+    return std::max(1, std::min(std::min(p, max_sub), std::max(1, nslot / 2)));
 }
 
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj, const int *sym,

@@ -91,7 +91,11 @@ ALLOWED_EXTRA = {
 # The DF object is the one place where the duck types differ BY DESIGN: the reference pulls blocks through PySCF's
 # `sr_loop(mydf, ...)` on `mydf._cderi` (eri_transform.py:159-227), this package through the block-provider protocol of
 # INTEGRATION.md section 3 (`load_block` / `load_block_host`; `CderiProvider` adapts an object that carries `_cderi`).
-DF_PROVIDER_PROTOCOL = {"kpts", "naux", "load_block", "load_block_host", "nao", "cell", "blockdim", "_cderi", "max_memory"}
+# Capabilities PROBED with hasattr() and used only when present (the reference's objects lack them and take the documented
+# fallback): VcorLocal.grad_entries is this package's sparse description of vcor.gradient() (slater.get_dV_dparam_dev).
+OPTIONAL_PROBES = {"lattice": set(), "vcor": {"grad_entries"}, "cell": set()}
+DF_PROVIDER_PROTOCOL = {"kpts", "naux", "load_block", "load_block_host", "host_swap_on_device", "nao", "cell", "blockdim", "_cderi",
+                        "max_memory"}
 
 
 def _check_contract(log, g17):
@@ -112,8 +116,9 @@ def _check_contract(log, g17):
     except OSError:
         pass
     for kind in ("lattice", "vcor", "cell"):
-        mine = public(log.names(kind))
+        mine = public(log.names(kind)) - OPTIONAL_PROBES[kind]
         assert mine, kind                                              # the recorder saw the entry points at work
+        assert not (OPTIONAL_PROBES[kind] & offered[kind])             # a probe is optional only while the reference lacks it
         assert ALLOWED_EXTRA[kind] <= offered[kind], sorted(ALLOWED_EXTRA[kind] - offered[kind])
         missing = mine - offered[kind]
         assert not missing, "the reference's %s object has no attribute(s) %s that this package's entry points read" % (kind, sorted(missing))

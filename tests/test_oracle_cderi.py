@@ -64,6 +64,13 @@ def test_G13_reader_round_trip(golden, name):
                 want = R.transform_ao_to_emb(blocks[(i, j)].reshape(naux, nao * nao), C[None], i, j)[0]
                 assert np.abs(prov.get_block(i, j) - want).max() < 1e-12, (i, j)
                 assert np.abs(Cd.load_block(feri, nk, nlo, i, j) - want).max() < 1e-12, (i, j)
+                # host feed: ONE pass into the caller's (pinned) buffer, the block AS STORED; a pair kept as (j, i) is flagged
+                # so that dmk_eri_push_block_host conjugate-transposes it on the device
+                buf = np.full((naux, nlo, nlo), np.nan + 0j)
+                swapped = prov.load_block_host(i, j, buf)
+                got = buf.conj().transpose(0, 2, 1) if swapped else buf
+                assert np.abs(got - want).max() < 1e-12, (i, j, swapped)
+                assert swapped == ((i, j) not in prov.pair_of)
     # nested-dict containers (the form convert_eri_to_gdf returns without a file name) are read too
     nested = {"j3c-kptij": feri["j3c-kptij"], "j3c": {}}
     for k, v in feri.items():

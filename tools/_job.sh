@@ -1,12 +1,8 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04c; mkdir -p $O
-( time timeout 1500 python3 -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1
-tail -15 $O/pytest.log
-B="python3 bench.py --workload C4 --steps 3 --warmup 1 --fit-iters 0 --no-cpu-baseline --no-shard-pass"
-$B > $O/c4_new.json 2> $O/c4_new.err
-DMK_ERI_TAB_SUB=1 $B > $O/c4_sub1.json 2>> $O/c4_new.err
-DMK_ERI_TAB_SUB=2 $B > $O/c4_sub2.json 2>> $O/c4_new.err
-DMK_ERI_H1_BN=64 $B > $O/c4_bn64.json 2>> $O/c4_new.err
-DMK_ERI_GROUP=8 $B > $O/c4_g8.json 2>> $O/c4_new.err
-python3 bench.py --scaling weak --kl-per-gpu 2 --no-full-config --steps 2 --warmup 1 --fit-iters 0 --no-cpu-baseline --parity-budget-s 60 > $O/c5_quick.json 2> $O/c5_quick.err
-tail -c 300 $O/c5_quick.err
+O=gpurun_out/r04g; mkdir -p $O
+DMK_EIGH_DEBUG=1 python3 tools/eigh_bench.py > $O/eigh_bench_dbg.log 2>&1
+python3 tools/eigh_bench.py > $O/eigh_bench.log 2>&1
+grep -A1 "n=200" $O/eigh_bench_dbg.log | tail -4; cat $O/eigh_bench.log
+( time timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_fit.py tests/test_gpu_bcs.py -m gpu -x -q -k "eigh or Diag or HF or fit or bath or bcs" ) > $O/pytest.log 2>&1
+tail -5 $O/pytest.log
+python3 tools/eigh_stress.py > $O/eigh_stress.log 2>&1; tail -5 $O/eigh_stress.log

@@ -25,4 +25,11 @@ for n, batch, real in [(256, 2, True), (256, 2, False), (200, 432, False), (136,
     dt = (time.perf_counter() - t) / 3
     w = dw.get()
     wr = np.linalg.eigvalsh(A[0])
-    print("n=%d batch=%d %s: %.2f ms   (max |dw| %.1e)" % (n, batch, "real" if real else "c128", dt * 1e3, np.abs(w[0] - wr).max()), flush=True)
+    V = dV.get()                                             # row m = eigenvector m
+    res = orth = 0.0
+    for bi in (0, batch - 1):
+        X = V[bi].T                                          # row m of Vt = eigenvector m -> columns
+        res = max(res, np.abs(A[bi] @ X - X * w[bi]).max() / np.abs(w[bi]).max())
+        orth = max(orth, np.abs(X.conj().T @ X - np.eye(n)).max())
+    print("n=%d batch=%d %s: %.2f ms   (max |dw| %.1e, residual / |w| %.1e, orthogonality %.1e)"
+          % (n, batch, "real" if real else "c128", dt * 1e3, np.abs(w[0] - wr).max(), res, orth), flush=True)

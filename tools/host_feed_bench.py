@@ -5,6 +5,9 @@ PCIe-inclusive rate of the ERI transform: C5-shaped AO blo
      buffers are pre-filled, i.e. the provider's own read cost is excluded),
  (c) like (b) but every block is first copied by the CPU from pageable memory into the pinned buffer (what an HDF5
      reader that cannot read into pinned memory pays).
+ (d) through CderiProvider.load_block_host on a cderi-layout mapping ("j3c-kptij", "j3c/<pair>/0": only pairs i >= j stored, every
+     dataset served from one shared 512 MB array so that the box does not need 55 GB of host memory): the reader's single pass
+     into the pinned buffer + the device-side conjugate-transpose of blocks stored for the swapped pair.
 One irreducible kL with time-reversal weight 2 (all its blocks + the contraction).  usage: python tools/host_feed_bench.py
 """
 import json
@@ -47,8 +50,30 @@ def main():
         def load_block_host(self, i, j, out):
             np.copyto(out, pageable)
 
+    class SharedCderi(object):
+        """cderi-layout mapping whose every pair dataset is the same array (the layout and the read path are what is measured)."""
+        def __init__(self, kpts):
+            nkp = len(kpts)
+            self.kptij = np.asarray([(kpts[i], kpts[j]) for i in range(nkp) for j in range(i + 1)])
+            self.block = pageable.reshape(naux, nao * nao)
+
+        def __getitem__(self, key):
+            if key == "j3c-kptij":
+                return self.kptij
+            parts = key.split("/")
+            if len(parts) == 3 and parts[0] == "j3c" and parts[2] == "0" and int(parts[1]) < len(self.kptij):
+                return self.block
+            raise KeyError(key)
+
+    from libdmet_preview_amd.system import fourier
+    from libdmet_preview_amd.system.lattice import _UnitCell
+    kabs = _UnitCell(nao).get_abs_kpts(fourier.make_kpts_scaled(mesh))
+    cderi = et.CderiProvider(SharedCderi(kabs), kabs, nao)
+    swaps = sum(1 for r in eng.by_kL[kL] if (int(r[1]), int(r[2])) not in cderi.pair_of)
+
     res = {}
-    for name, prov in (("device_philox", Dev()), ("host_pinned_prefilled", HostPrefilled()), ("host_cpu_fill", HostMemcpy())):
+    for name, prov in (("device_philox", Dev()), ("host_pinned_prefilled", HostPrefilled()), ("host_cpu_fill", HostMemcpy()),
+                       ("host_cderi_provider", cderi)):
         if name != "device_philox" and eng.host_buf is not None:
             for b in eng.host_buf:
                 b.a[...] = pageable
@@ -69,6 +94,7 @@ def main():
                      "tflops": round(fl / dt / 1e12, 2),
                      "host_GBps": None if name == "device_philox" else round(n * block_bytes / dt / 1e9, 1)}
     eng.close()
+    res["host_cderi_provider"]["blocks_stored_for_the_swapped_pair"] = swaps
     print(json.dumps({"workload": "C5 blocks, one kL (w=2), %d blocks of %.0f MB" % (nblk, block_bytes / 1e6), "results": res}))
 
 
