@@ -660,6 +660,17 @@ def main():
                 hbm[k] = {"ms_per_step": round(ms_step, 4), "launches_per_step": round(fam_out[k]["launches"] / a.steps, 1),
                           "algorithmic_GB_per_step": round(by / 1e9, 4), "GBps": round(by / (ms_step * 1e-3) / 1e9, 1),
                           "frac_of_hbm_peak": round(by / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+        if fresh:
+            # measured HBM bytes of the same stages (rocprofv3 PMC, profiles/traffic_latest.json): traffic / algorithmic = re-reads
+            fam_bytes = lambda *ks: sum(tinfo.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in ks)
+            eb = fam_bytes("eigh_tridiag", "eigh_tripairs", "eigh", "eigh_tfactor", "eigh_backtransform")
+            if "eigh" in hbm and eb > 0:
+                hbm["eigh"]["pmc_traffic_GB_per_step"] = round(eb / 1e9, 3)
+                hbm["eigh"]["pmc_over_algorithmic"] = round(eb / alg["eigh"], 2)
+            fb = fam_bytes("fold_k2R")
+            if "fold" in hbm and fb > 0:
+                hbm["fold"]["k2R_pmc_traffic_GB_per_launch"] = round(fb / 1e9, 3)
+                hbm["fold"]["k2R_algorithmic_GB_per_launch"] = round((16.0 + 8.0) * spin * nk * n * n / 1e9, 3)
         roofline["hbm_stages"] = hbm
         n_mine = len(kl_mine)
         res = {

@@ -14,7 +14,8 @@
 //     (tools/mfma_f64_probe.hip: 77.5 TFLOP/s is reachable from registers);
 //   * operands therefore arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-4 stage ring, issued
 //     two to three K-tiles ahead and retired by a counted s_waitcnt vmcnt(N) + ONE raw s_barrier per
-//     K-tile; no staging registers, no scratch, so the counted waits are never drained by the compiler;
+//     K-tile; no staging registers and no scratch access INSIDE the K loops (half2_kernel spills 18 VGPRs = 28 B of scratch
+//     around its two K loops: kernel prologue / epilogue only), so the counted waits are never drained by the compiler;
 //   * 256-thread workgroups, TWO per CU: a 512-thread workgroup sharing a larger tile halves the L2
 //     bytes per flop but runs its two waves per SIMD in barrier lock-step and measured 10 % slower
 //     than two independent workgroups that desynchronise by themselves (tools/gemm_lab*.hip);
@@ -80,7 +81,11 @@ struct H1Args {
 // 64-column LDS rows (lanes 48-63 of a piece land in the padding), so the LDS-DMA issue pattern is the same for both.
 // The M index is the FLAT row (L, q) -> L * mrows + q with no padding between batches: a 16-row block may straddle two L
 // (every lane carries its own source address, and Ut[L][q][:] is one contiguous array of nL * mrows rows).
-template <bool CONJB, int BM, int OCC, bool NARROW>
+// LAB (tools/zhot_lab.hip only; the product instantiates LAB = 0, where every `if constexpr` below folds away): ablation bits that
+// remove one ingredient of the K loop at a time so that its share of the time can be MEASURED on the real kernel -- 1: no Ut
+// stores, 2: no LDS-DMA after the prologue (the ring keeps stale tiles), 4: no s_barrier.  Results of a LAB != 0 instantiation are
+// meaningless by construction.
+template <bool CONJB, int BM, int OCC, bool NARROW, int LAB = 0>
 __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     constexpr int MI = NARROW ? BM / 64 : BM / 32;       // 16-row blocks per wave
     constexpr int NJ = NARROW ? 3 : 2;                   // 16-column blocks per wave
@@ -153,8 +158,9 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < T) issue(t + 2);
+        if constexpr (!(LAB & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (LAB & 2) { if (t + 2 < T && g.nslot < 0) issue(t + 2); }
+        else { if (t + 2 < T) issue(t + 2); }
         const double2 *Ab = lds + (t % H1_D) * STAGE + wm * (MI * 16) + frag_x;
         const double2 *Bb = lds + (t % H1_D) * STAGE + H1_BK * BM + wn * 32 + frag_x;
 #pragma unroll
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
         for (int r = 0; r < 4; ++r) {
             const long long rr = (long long)tile_m * BM + (wm * MI + i) * 16 + frag_k + 4 * r;
             if (rr >= rows_total) continue;
+            if constexpr (LAB & 1) { if (g.nslot >= 0) continue; }
             double2 *row = Osp + rr * nemb;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -234,6 +241,9 @@ struct H2Args {
      : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
      : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
 
+// LAB: ablation bits of tools/zhot_lab.hip, as in half1_kernel (1: no plane atomics, 2: no LDS-DMA after the prologue, 4: no
+// s_barrier); the product instantiates LAB = 0.
+template <int LAB = 0>
 __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     __shared__ __attribute__((aligned(16))) double2 lds[H2_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar LDS-DMA addressing
@@ -303,8 +313,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 3 < T) issue();
+                if constexpr (!(LAB & 4)) __builtin_amdgcn_s_barrier();
+                if constexpr (LAB & 2) { if (t + 3 < T && g.nslot < 0) issue(); }
+                else { if (t + 3 < T) issue(); }
                 const double2 *U = lds + c_stage * H2T_STAGE + frag_k * 128 + frag_x;
                 c_stage = c_stage + 1 == H2T_D ? 0 : c_stage + 1;
                 const double2 *C = U + H2_BK * 128;
@@ -358,6 +369,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 fold_block(acc1[R1]);
                 fold_block(acc2[R2]);
             }
+            if constexpr (LAB & 1) { if (g.nslot >= 0) return; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row1 = d0 + R1 * 16 + frag_k + 4 * r, row2 = d0 + R2 * 16 + frag_k + 4 * r;
@@ -427,8 +439,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     for (int t = 0; t < T; ++t) {
         if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < T) issue();
+        if constexpr (!(LAB & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (LAB & 2) { if (t + 2 < T && g.nslot < 0) issue(); }
+        else { if (t + 2 < T) issue(); }
         const double2 *Ua = lds + c_stage * H2S_STAGE + frag_k * 64 + wm * 32 + frag_x;
         const double2 *Cb = lds + c_stage * H2S_STAGE + 256 + frag_k * 128 + wn * 64 + frag_x;
         c_stage = c_stage + 1 == H2S_D ? 0 : c_stage + 1;
@@ -462,6 +475,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             c_sym = c_mask & 1u;
         }
     }
+    if constexpr (LAB & 1) { if (g.nslot >= 0) return; }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -573,7 +587,7 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
         for (int i = 0; i < nslot; ++i) blocks += 136.0 + (sym[i] ? (a.fold_diag ? 120.0 : 136.0) : 0.0);
         fs.mfma_flops(6.0 * blocks * 256.0 * (double)nao * (double)nL * (double)nspin);
     }
-    hipLaunchKernelGGL(half2_kernel, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    hipLaunchKernelGGL(half2_kernel<0>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }

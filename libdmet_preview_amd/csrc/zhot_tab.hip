@@ -82,7 +82,9 @@ struct H2TArgs {
      : (SLOT) == 8 ? (G).Cj[8] : (SLOT) == 9 ? (G).Cj[9] : (SLOT) == 10 ? (G).Cj[10] : (SLOT) == 11 ? (G).Cj[11] \
      : (SLOT) == 12 ? (G).Cj[12] : (SLOT) == 13 ? (G).Cj[13] : (SLOT) == 14 ? (G).Cj[14] : (G).Cj[15])
 
-template <class CFG>
+// LAB: ablation bits of tools/zhot_lab.hip as in zhot.hip (1: no plane atomics, 2: no LDS-DMA after the prologue, 4: no
+// s_barrier); the product instantiates LAB = 0.
+template <class CFG, int LAB = 0>
 __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs g) {
     constexpr int T_MAXBLK = CFG::MAXBLK;
     __shared__ __attribute__((aligned(16))) double2 lds[lds_elems<CFG>()];
@@ -212,8 +214,9 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
-            if (t + D - 1 < T) issue();
+            if constexpr (!(LAB & 4)) __builtin_amdgcn_s_barrier();
+            if constexpr (LAB & 2) { if (t + D - 1 < T && g.nslot < 0) issue(); }
+            else { if (t + D - 1 < T) issue(); }
             const double2 *st = lds + c_stage * STAGE;
             c_stage = c_stage + 1 == D ? 0 : c_stage + 1;
             if (NB > 0) {
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                 }
             }
         }
+        if constexpr (LAB & 1) { if (g.nslot >= 0) return; }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
@@ -480,8 +484,8 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     // a symmetrised block runs a second segment -- without the folded diagonal blocks when the whole group is symmetrised
     const double seg2 = (segs - (double)nslot) * (tb->useful_blocks - (a.fold_diag ? tb->folded_blocks : 0.0));
     fs.mfma_flops(6.0 * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)nao * (double)nL * (double)nspin);
-    if (occ == 2) hipLaunchKernelGGL(half2_tab_kernel<Cfg2>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(half2_tab_kernel<Cfg3>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    if (occ == 2) hipLaunchKernelGGL((half2_tab_kernel<Cfg2, 0>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 0>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }

@@ -44,7 +44,8 @@ def pmc(db):
 FAMILY = [("dgemm_tn_acc_dma_kernel", "dgemm"), ("half1_kernel", "zgemm_half1"), ("half2_kernel", "zgemm_half2"), ("half2_tab_kernel", "zgemm_half2"),
           ("philox_block", "philox"), ("jacobi_eigh_kernel", "jacobi_eigh"), ("tridiag_resident_kernel", "eigh_tridiag"),
           ("tridiag_tiles_kernel", "eigh_tridiag"), ("backtransform_kernel", "eigh_backtransform"),
-          ("backtransform_wy_kernel", "eigh_backtransform"), ("wy_tfactor_kernel", "eigh_tfactor"), ("eigh_kernel", "eigh"), ("jk_j_kernel", "jk_j"),
+          ("backtransform_wy_kernel", "eigh_backtransform"), ("wy_tfactor_kernel", "eigh_tfactor"), ("tri_eigpairs_kernel", "eigh_tripairs"), ("eigh_kernel", "eigh"),
+          ("fold_fft_kernel<false, true, true>", "fold_k2R"), ("fold_fft_kernel", "fold_R2k"), ("jk_j_kernel", "jk_j"),
           ("jk_k_kernel", "jk_k"), ("gemv2_kernel", "gemv2")]
 
 
