@@ -231,22 +231,25 @@ def transform_local_grad(basis, lattice):
     return resA, resB, resD
 
 
-def get_dV_dparam(basis, lattice, vcor):
-    def sym_triu(a):
-        a = a + a.transpose((1, 0, 2, 3))
-        a[np.arange(a.shape[0]), np.arange(a.shape[1])] *= 0.5
-        return a[np.triu_indices(a.shape[0])]
+def _pair_symmetrised(t):
+    """(n, n, m, m) derivative tensor of a SYMMETRIC local block -> (n (n + 1) / 2, m, m): entry (i <= j) is the response to the
+    single parameter shared by elements (i, j) and (j, i), i.e. t[i, j] + t[j, i], and t[i, i] on the diagonal."""
+    iu, ju = np.triu_indices(t.shape[0])
+    both = t[iu, ju] + t[ju, iu]
+    both[iu == ju] *= 0.5
+    return both
 
+
+def get_dV_dparam(basis, lattice, vcor):
+    """dV_emb / dparam of the Nambu embedding potential (bcs_helper.py:390-428): parameters ordered as the upper triangles of the two
+    normal blocks followed by all elements of the pairing block; rows of the three stacked derivative tables follow that order."""
     nbasis = basis.shape[-1]
-    dV_dp = np.empty((vcor.length(), nbasis * 2, nbasis * 2))
-    resA, resB, resD = transform_local_grad(basis, lattice)
-    flat = lambda x: x.reshape((-1,) + x.shape[-2:])
-    dA = np.concatenate([sym_triu(resA[0][0]), sym_triu(resB[0][0]), flat(resD[0][0])], axis=0)
-    dB = np.concatenate([sym_triu(resA[0][1]), sym_triu(resB[0][1]), flat(resD[0][1])], axis=0)
-    dD = np.concatenate([sym_triu(resA[1]), sym_triu(resB[1]), flat(resD[1])], axis=0)
-    for ip in range(vcor.length()):
-        dV_dp[ip, :nbasis, :nbasis] = dA[ip]
-        dV_dp[ip, nbasis:, nbasis:] = -dB[ip]
-        dV_dp[ip, :nbasis, nbasis:] = dD[ip]
-        dV_dp[ip, nbasis:, :nbasis] = dD[ip].T
+    nparam = vcor.length()
+    (nA, pA, _), (nB, pB, _), (nD, pD, _) = transform_local_grad(basis, lattice)      # (normal [A, B], pairing, E0) per block kind
+    stack = lambda a, b, d: np.concatenate([_pair_symmetrised(a), _pair_symmetrised(b), d.reshape((-1,) + d.shape[-2:])], axis=0)
+    dA, dB, dD = stack(nA[0], nB[0], nD[0]), stack(nA[1], nB[1], nD[1]), stack(pA, pB, pD)
+    dV_dp = np.empty((nparam, nbasis * 2, nbasis * 2))
+    # Nambu layout: [[dA, dD], [dD^T, -dB]] for every parameter at once
+    dV_dp[:, :nbasis, :nbasis], dV_dp[:, nbasis:, nbasis:] = dA[:nparam], -dB[:nparam]
+    dV_dp[:, :nbasis, nbasis:], dV_dp[:, nbasis:, :nbasis] = dD[:nparam], dD[:nparam].transpose(0, 2, 1)
     return dV_dp

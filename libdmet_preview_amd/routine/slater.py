@@ -49,7 +49,10 @@ def get_emb_basis(lattice, rho=None, local=True, kind='svd', **kwargs):
     if rho is None:
         rho = lattice.rdm1_lo_R
     if not local:
-        raise NotImplementedError("non-local (particle-hole symmetric) bath is outside the HIP path")
+        # the reference calls `__embBasis_phsymm` here (slater.py:105-106), a name its module never defines: the branch raises
+        # NameError there; nothing to mirror
+        raise NotImplementedError("non-local (particle-hole symmetric) Slater bath: the reference's own branch calls an undefined "
+                                  "function (routine/slater.py:106); use routine.bcs.embBasis(local=False) for the quasiparticle bath")
     rho = np.asarray(rho).real
     if kind == 'svd':
         return _get_emb_basis_svd(lattice, rho, **kwargs)
