@@ -272,6 +272,15 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
  * rewritten as soon as the push that completes its group has returned (work is stream-ordered). */
 int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out);
 int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise);
+/* Producer side of the ring on a stream of its own (opt-in: DMK_ERI_GEN_STREAM=1 double-buffers the ring; otherwise the call hands
+ * out the single-buffered slot and the compute stream, i.e. the behaviour of dmk_eri_block_ring).  For the next
+ * queue slot (`slot` must be the number of blocks queued so far) this returns where to write the block and the HIP stream to
+ * launch the producer on -- the pipeline's second stream, on which the producers of group g + 1 (a generator kernel, a
+ * decompressor, a device-side format conversion) run while the compute stream still transforms group g.  The pipeline orders
+ * the two streams with events: the producer stream waits until step 1 of the group that last used the half has run, and step
+ * 1 of a group waits for the producers of that group.  Follow every fill with dmk_eri_push_ring_slot.  (The reference reads
+ * the next block from HDF5 while it transforms the current one only through h5py's prefetch, eri_transform.py:358-366.) */
+int dmk_eri_ring_slot(dmk_eri *h, int slot, void **ptr_out, void **stream_out);
 /* Transform the blocks queued so far NOW (one step-1 and one step-2 launch) instead of when the queue is full: a caller that
  * knows how many blocks a kL has cuts them into launches of equal length (33 blocks: 11 + 11 + 11, not 16 + 16 + 1).  The next
  * ring slot to fill is slot 0 again. */
@@ -345,6 +354,7 @@ int dmk_eri_imag_buffer(dmk_eri *h, double **imag_out, int64_t *elems_out);
 
 /* Procedural DF block (synthetic configs): Philox4x32-10,
  * key (seed_lo, seed_hi), counter (e>>1 lo, e>>1 hi, ki, kj), e = (L*nao+p)*nao+q. */
+int dmk_df_block_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
 int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao,
                         void *Lpq_out);
 

@@ -289,6 +289,11 @@ class GDFPhilox(object):
         ctx.check(lib.dmk_df_block_philox(ctx.h, C.c_uint64(self.seed), int(i), int(j), self.naux, self.nao,
                                           out_dev.ptr))
 
+    def load_block_on(self, ctx, i, j, out_ptr, stream):
+        """Producer form: generate the block at device address `out_ptr` on the HIP stream `stream` (the ERI pipeline's producer
+        stream, dmk_eri_ring_slot), so that generating group g + 1 overlaps the transform of group g."""
+        ctx.check(lib.dmk_df_block_philox_on(ctx.h, stream, C.c_uint64(self.seed), int(i), int(j), self.naux, self.nao, out_ptr))
+
 
 def _is_provider(mydf):
     return hasattr(mydf, "load_block") and hasattr(mydf, "kpts")
@@ -734,6 +739,16 @@ class EriEngine(object):
                 flags = sym | (2 if (swapped is True and getattr(provider, "host_swap_on_device", False)) else 0)
                 ctx.check(lib.dmk_eri_push_block_host(self.h, i, j, flags, self.host_buf[slot].ptr, slot))
                 self.host_slot = 1 - slot
+            elif self.ring_slots and hasattr(provider, "load_block_on"):
+                # device-side producer on the pipeline's second stream (double-buffered ring)
+                ptr, stream = C.c_void_p(), C.c_void_p()
+                ctx.check(lib.dmk_eri_ring_slot(self.h, self.ring_pos, C.byref(ptr), C.byref(stream)))
+                provider.load_block_on(ctx, ui, uj, ptr, stream)
+                ctx.check(lib.dmk_eri_push_ring_slot(self.h, i, j, sym))
+                self.ring_pos = (self.ring_pos + 1) % self.ring_slots
+                if per_launch and self.ring_pos == per_launch and per_launch < self.ring_slots:
+                    ctx.check(lib.dmk_eri_flush(self.h))
+                    self.ring_pos = 0
             elif self.ring_slots:
                 provider.load_block(ctx, ui, uj, self.ring[self.ring_pos])
                 ctx.check(lib.dmk_eri_push_ring_slot(self.h, i, j, sym))

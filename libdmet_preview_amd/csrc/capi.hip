@@ -24,7 +24,14 @@ int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...) {
 
 static thread_local std::string g_noctx_err;
 
-FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f) {
+FamScope::FamScope(dmk_ctx *c, int f, hipStream_t stream) : FamScope(c, f) {
+    // the delegated constructor recorded `a` on ctx->stream; a launch on another stream needs its events there
+    if (ctx && stream != ctx->stream) {
+        on = stream; on_set = true;
+        if (a) (void)hipEventRecord(a, stream);
+    }
+}
+FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f), on(nullptr) {
     if (ctx && ctx->profile) {
         auto get = [&]() {
             hipEvent_t e;
@@ -39,7 +46,7 @@ FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f) {
 }
 FamScope::~FamScope() {
     if (ctx && ctx->profile && a && b) {
-        (void)hipEventRecord(b, ctx->stream);
+        (void)hipEventRecord(b, on_set ? on : ctx->stream);
         ctx->pending.push_back({fam, a, b});
     }
 }
@@ -644,6 +651,12 @@ int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, i
     return launch_philox_block(ctx, seed, ki, kj, naux, nao, out);
 }
 
+int dmk_df_block_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (naux <= 0 || nao <= 0 || !out || ki < 0 || kj < 0) return dmk_fail(ctx, DMK_ERR_INVALID, "df_block_philox_on: bad arguments");
+    return launch_philox_block_on(ctx, reinterpret_cast<hipStream_t>(stream), seed, ki, kj, naux, nao, out);
+}
+
 }  // extern "C"
 
 // =============================================================================================
@@ -673,6 +686,17 @@ struct dmk_eri {
     double2 *ring = nullptr;
     size_t ring_bytes = 0;
     int ring_pending = 0;       // queued ring slots whose step 1 has not run yet (they are the first `ring_pending` slots)
+    // PRODUCER STREAM of the ring (dmk_eri_ring_slot): the ring is double buffered and device-side producers of group g + 1
+    // (a generator kernel, a decompressor) run on `gen_stream` while the compute stream transforms group g.  Ordering by events:
+    // ev_free[half] = step 1 of the group that last used that half has run (recorded on the compute stream; the producer stream
+    // waits on it before the first fill of the half), ev_gen[half] = the fills of the pending group (recorded on the producer
+    // stream after every fill; step 1 of that group waits on it).
+    hipStream_t gen_stream = nullptr;
+    hipEvent_t ev_gen[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    int ring_halves = 1;        // 2 when the ring is double buffered
+    int fill_half = 0;          // half of the pending group
+    int next_half = 0;          // half the next group of a ring_slot producer will fill
+    bool gen_pending = false;   // the pending group was (partly) filled on the producer stream
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
     // plane STACK (dmk_eri_stack): nslots > 1 defers the contraction -- the planes of up to nslots kL stay resident, weight-2 kL
@@ -842,12 +866,17 @@ static int eri_ring_step1(dmk_eri *h) {
     if (h->ring_pending == 0) return DMK_OK;
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const size_t slot_elems = (size_t)naux * nao * nemb;
-    int rc = launch_half1_hot_multi(ctx, h->ring, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->C, h->Ut,
+    const double2 *src = h->ring + (size_t)h->fill_half * h->group * naux * nao * nao;
+    if (h->gen_pending) DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_gen[h->fill_half], 0));      // the producers of this group
+    int rc = launch_half1_hot_multi(ctx, src, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->C, h->Ut,
                                     (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * nao * nemb,
                                     (long long)h->group * (long long)slot_elems);
     if (rc < 0) return rc;
     if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
+    if (h->ring_halves == 2) DMK_HIP(ctx, hipEventRecord(h->ev_free[h->fill_half], ctx->stream));           // the half may be refilled
     h->ring_pending = 0;
+    h->gen_pending = false;
+    h->fill_half = 0;                                  // a producer on the compute stream (no dmk_eri_ring_slot) always uses half 0
     return DMK_OK;
 }
 
@@ -1335,7 +1364,15 @@ int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out) {
     if (h->group <= 1) return DMK_OK;                 // generic path: no queue, use dmk_eri_push_block
     if (!h->ring) {
         dmk_ctx *ctx = h->ctx;
-        const size_t bytes = (size_t)h->group * h->naux * h->nao * h->nao * sizeof(double2);
+        {   // double buffering + producer stream only on request (DMK_ERI_GEN_STREAM=1).  Measured with the Philox generator as the
+            // producer (round 4): the overlap LOSES -- C4 258.7 -> 266.4 ms per step, C5 (4 kL) 1884 -> 1892 ms: the MFMA kernels
+            // occupy every CU, a concurrent generator only gets slots as their workgroups retire (a 17 us launch takes 95 us) and
+            // its 4 TB/s write burst slows the step-2 launch it overlaps by 5-15 %.  A producer that is NOT bandwidth-bound (a
+            // decompressor) may do better, so the path stays available and tested.
+            const char *e = getenv("DMK_ERI_GEN_STREAM");
+            h->ring_halves = (e && atoi(e) != 0) ? 2 : 1;
+        }
+        const size_t bytes = (size_t)h->ring_halves * h->group * h->naux * h->nao * h->nao * sizeof(double2);
         if (ctx->eri_ws[2] && ctx->eri_ws_bytes[2] >= bytes) {          // parked by the previous pipeline
             h->ring = reinterpret_cast<double2 *>(ctx->eri_ws[2]);
             h->ring_bytes = ctx->eri_ws_bytes[2];
@@ -1355,9 +1392,42 @@ int dmk_eri_block_ring(dmk_eri *h, void **ring_out, int *nslots_out) {
             }
             h->ring_bytes = bytes;
         }
+        if (h->ring_halves == 2 && !h->gen_stream) {
+            bool ok = hipStreamCreateWithFlags(&h->gen_stream, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 2 && ok; ++i)
+                ok = hipEventCreateWithFlags(&h->ev_gen[i], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) {                                // no second stream: single-buffered ring on the compute stream, as before
+                (void)hipGetLastError();
+                h->ring_halves = 1;
+            }
+        }
     }
     *ring_out = h->ring;
     *nslots_out = h->group;
+    return DMK_OK;
+}
+
+int dmk_eri_ring_slot(dmk_eri *h, int slot, void **ptr_out, void **stream_out) {
+    if (!h || !ptr_out || !stream_out) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (!h->ring || h->group <= 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_ring_slot: no block ring (dmk_eri_block_ring)");
+    if (slot != h->pending || slot >= h->group)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_ring_slot: slots are filled in order (next is %d, asked for %d)", h->pending, slot);
+    const size_t blk = (size_t)h->naux * h->nao * h->nao;
+    if (h->ring_halves < 2) {                          // single buffer: the producer shares the compute stream
+        *ptr_out = h->ring + (size_t)slot * blk;
+        *stream_out = reinterpret_cast<void *>(ctx->stream);
+        return DMK_OK;
+    }
+    if (slot == 0) {                                   // a new group: the other half; its last consumer must have run
+        h->fill_half = h->next_half;
+        h->next_half ^= 1;
+        DMK_HIP(ctx, hipStreamWaitEvent(h->gen_stream, h->ev_free[h->fill_half], 0));
+        h->gen_pending = true;
+    }
+    *ptr_out = h->ring + ((size_t)h->fill_half * h->group + slot) * blk;
+    *stream_out = reinterpret_cast<void *>(h->gen_stream);
     return DMK_OK;
 }
 
@@ -1376,6 +1446,7 @@ int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise) {
     h->pend_sym[slot] = symmetrise ? 1 : 0;
     h->pending += 1;
     h->ring_pending += 1;
+    if (h->gen_pending) DMK_HIP(ctx, hipEventRecord(h->ev_gen[h->fill_half], h->gen_stream));   // everything produced so far for this group
     h->flops_half += (double)h->spin * (8.0 * h->naux * (double)h->nao * h->nao * h->nemb +
                                         8.0 * h->naux * (double)h->nao * h->nemb * h->nemb);
     if (h->pending == h->group) return eri_flush(h);
@@ -1506,6 +1577,14 @@ int dmk_eri_finish(dmk_eri *h) {
         }
         (void)hipStreamDestroy(h->copy_stream);
         if (h->tstage) (void)hipFree(h->tstage);
+    }
+    if (h->gen_stream) {
+        (void)hipStreamSynchronize(h->gen_stream);
+        for (int i = 0; i < 2; ++i) {
+            if (h->ev_gen[i]) (void)hipEventDestroy(h->ev_gen[i]);
+            if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]);
+        }
+        (void)hipStreamDestroy(h->gen_stream);
     }
     if (h->ring) {
         if (!ctx->eri_ws[2]) {

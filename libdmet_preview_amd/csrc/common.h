@@ -76,7 +76,9 @@ int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...);
 // RAII bracket that (optionally) times one kernel family launch with HIP events.
 struct FamScope {
     dmk_ctx *ctx; int fam; hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t on; bool on_set = false;          // events go to ctx->stream unless the launch sits on another stream
     FamScope(dmk_ctx *c, int f);
+    FamScope(dmk_ctx *c, int f, hipStream_t stream);
     ~FamScope();
     // flop this launch issues to the f64 matrix pipe (executed, not algorithmic: 3M complex products, padded tiles,
     // the lower tile triangle of a symmetric contraction); read back by dmk_profile_read_flops
@@ -148,6 +150,46 @@ __device__ __forceinline__ void glds16_x6(const void *g0, const void *g1, const 
                  : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(g4), "v"(g5), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5)
                  : "memory");
 }
+// SADDR form of the same bursts: the source address of a piece is a wave-uniform 64-bit base in SGPRs plus a per-lane 32-bit byte
+// offset in ONE VGPR (`global_load_lds_dwordx4 voff, s[base:base+1]`).  The offsets of a ring kernel's pieces are loop invariant and
+// its running tile pointers are scalar, so a K step issues its LDS-DMA pieces WITHOUT any vector ALU work -- the per-piece 64-bit
+// v_add_co / v_addc (and the v_cndmask pair that picked the operand) of the per-lane-pointer form were 8-24 VALU instructions per
+// K step and wave in front of the MFMA stream.  `s_nop 4` opens the burst: a base that the compiler produced with v_readfirstlane
+// needs five wait states before a VMEM instruction may read it, and nothing pads hazards inside an asm statement.
+__device__ __forceinline__ void glds16s_x4(unsigned o0, unsigned o1, unsigned o2, unsigned o3, const void *s0, const void *s1,
+                                            const void *s2, const void *s3, unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+    unsigned keep;
+    b0 = __builtin_amdgcn_readfirstlane(b0); b1 = __builtin_amdgcn_readfirstlane(b1);
+    b2 = __builtin_amdgcn_readfirstlane(b2); b3 = __builtin_amdgcn_readfirstlane(b3);
+    asm volatile("s_mov_b32 %0, m0\n\ts_nop 4\n\t"
+                 "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %10\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+                 "s_mov_b32 m0, %11\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %7\n\t"
+                 "s_mov_b32 m0, %12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %8\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(b0), "s"(b1), "s"(b2), "s"(b3)
+                 : "memory");
+}
+__device__ __forceinline__ void glds16s_x6(unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned o4, unsigned o5, const void *s0,
+                                            const void *s1, const void *s2, const void *s3, const void *s4, const void *s5, unsigned b0,
+                                            unsigned b1, unsigned b2, unsigned b3, unsigned b4, unsigned b5) {
+    unsigned keep;
+    b0 = __builtin_amdgcn_readfirstlane(b0); b1 = __builtin_amdgcn_readfirstlane(b1); b2 = __builtin_amdgcn_readfirstlane(b2);
+    b3 = __builtin_amdgcn_readfirstlane(b3); b4 = __builtin_amdgcn_readfirstlane(b4); b5 = __builtin_amdgcn_readfirstlane(b5);
+    asm volatile("s_mov_b32 %0, m0\n\ts_nop 4\n\t"
+                 "s_mov_b32 m0, %13\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
+                 "s_mov_b32 m0, %14\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %8\n\t"
+                 "s_mov_b32 m0, %15\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
+                 "s_mov_b32 m0, %16\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %10\n\t"
+                 "s_mov_b32 m0, %17\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %11\n\t"
+                 "s_mov_b32 m0, %18\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %12\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(o5), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(b0),
+                   "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5)
+                 : "memory");
+}
 // Wave64 sum through the DPP crossbar (quad_perm, row_ror, row_bcast) instead of six ds_bpermute round trips:
 // every lane of the wave gets the total (read back from lane 63).  Fixed combination order: deterministic.
 // The whole wave must be active at the call.
@@ -175,6 +217,10 @@ __device__ void glds16(const void *gsrc, unsigned lds_base);
 __device__ void glds16_x4(const void *, const void *, const void *, const void *, unsigned, unsigned, unsigned, unsigned);
 __device__ void glds16_x6(const void *, const void *, const void *, const void *, const void *, const void *, unsigned, unsigned, unsigned,
                           unsigned, unsigned, unsigned);
+__device__ void glds16s_x4(unsigned, unsigned, unsigned, unsigned, const void *, const void *, const void *, const void *, unsigned,
+                           unsigned, unsigned, unsigned);
+__device__ void glds16s_x6(unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, const void *, const void *, const void *,
+                           const void *, const void *, const void *, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned);
 __device__ double dmk_wave_sum(double v);
 #endif
 
@@ -229,6 +275,7 @@ int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int 
                           double *yref, double *twork);
 
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
+int launch_philox_block_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
 
 // hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin = 1,

@@ -188,7 +188,9 @@ constexpr int G_STAGE = 2 * GBK * G_LD;        // doubles per stage: A[8][136] |
 // SYMM (X == Y, M == N): C is symmetric, so only tiles with tm >= tn are computed; an off-diagonal tile is
 // also added, transposed, to C[tn-tile][tm-tile] (still one writer per element).  Saves ~1/2 of the aa and bb
 // contractions, i.e. 1/3 of the UHF contraction work.
-template <bool SYMM>
+// SADDR: LDS-DMA pieces addressed as scalar row pointer + loop-invariant per-lane byte offset (common.h glds16s_x4) instead of
+// per-lane 64-bit pointers advanced with the vector ALU.
+template <bool SYMM, bool SADDR>
 __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
@@ -207,8 +209,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int ca = m0 + 2 * lane, cb = n0 + 2 * lane;
     if (ca + 1 >= M) ca = M - 2;
     if (cb + 1 >= N) cb = N - 2;
-    // wave w streams K rows 2w, 2w+1 of both operands; running pointers advance one K-tile per issue
-    const double *pA = X + ca + (int64_t)(2 * wave) * ldx, *pB = Y + cb + (int64_t)(2 * wave) * ldy;
+    // wave w streams K rows 2w, 2w+1 of both operands; SCALAR running row pointers advance one K-tile per issue, the per-lane
+    // part of an address is the loop-invariant column byte offset (common.h glds16s_x4: no vector ALU work per piece)
+    const unsigned voffA = (unsigned)ca * 8u, voffB = (unsigned)cb * 8u;
+    const double *pA = X + (SADDR ? 0 : ca) + (int64_t)(2 * wave) * ldx, *pB = Y + (SADDR ? 0 : cb) + (int64_t)(2 * wave) * ldy;
     const int64_t stepA = (int64_t)GBK * ldx, stepB = (int64_t)GBK * ldy;
     int is_stage = 0;
     // K may be a stack of row SEGMENTS (the planes of several momentum transfers kL, or only their Re halves): after every
@@ -216,8 +220,12 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int seg_left = seg_tiles;
     auto issue = [&]() {
         double *st = lds + is_stage * G_STAGE + (2 * wave) * G_LD;
-        glds16_x4(pA, pA + ldx, pB, pB + ldy, lds_addr_of(st), lds_addr_of(st + G_LD), lds_addr_of(st + GBK * G_LD),
-                  lds_addr_of(st + GBK * G_LD + G_LD));
+        if constexpr (SADDR)
+            glds16s_x4(voffA, voffA, voffB, voffB, pA, pA + ldx, pB, pB + ldy, lds_addr_of(st), lds_addr_of(st + G_LD),
+                       lds_addr_of(st + GBK * G_LD), lds_addr_of(st + GBK * G_LD + G_LD));
+        else
+            glds16_x4(pA, pA + ldx, pB, pB + ldy, lds_addr_of(st), lds_addr_of(st + G_LD), lds_addr_of(st + GBK * G_LD),
+                      lds_addr_of(st + GBK * G_LD + G_LD));
         pA += stepA;
         pB += stepB;
         if (--seg_left == 0) {
@@ -380,12 +388,17 @@ int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, con
         const int64_t jumpB = seg_rows == K ? 0 : seg_stride_y - (int64_t)seg_rows * ldy;
         FamScope fs(ctx, DMK_FAM_DGEMM);
         fs.mfma_flops(2.0 * (double)count * BM * BN * (double)K);
-        if (symm)
-            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<true>, dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                               alpha, X, ldx, Y, ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB);
-        else
-            hipLaunchKernelGGL(dgemm_tn_acc_dma_kernel<false>, dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K,
-                               alpha, X, ldx, Y, ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB);
+        // Measured (tools/contract_bench.py, round 4): the scalar-base form wins at the C5 size (N = 32896, K = 1600: symmetric
+        // 24.82 -> 24.51 ms, rectangular 48.57 -> 47.16 ms) and loses on small pair spaces (N = 9316: symmetric K = 832 1.42 -> 1.51 ms,
+        // K = 3328 4.71 -> 4.82 ms): chosen by N; DMK_DGEMM_SADDR = 0 | 1 overrides (read per launch: labs toggle it)
+        const char *se = getenv("DMK_DGEMM_SADDR");
+        const bool saddr = se ? atoi(se) != 0 : (N >= 16384);
+#define DGEMM_LAUNCH(SY, SA)                                                                                                  \
+        hipLaunchKernelGGL((dgemm_tn_acc_dma_kernel<SY, SA>), dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K, alpha, X, ldx, Y,   \
+                           ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB)
+        if (symm) { if (saddr) DGEMM_LAUNCH(true, true); else DGEMM_LAUNCH(true, false); }
+        else { if (saddr) DGEMM_LAUNCH(false, true); else DGEMM_LAUNCH(false, false); }
+#undef DGEMM_LAUNCH
         DMK_CHECK_LAUNCH(ctx);
         return DMK_OK;
     }

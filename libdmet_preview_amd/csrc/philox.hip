@@ -47,14 +47,19 @@ __global__ __launch_bounds__(256) void philox_block_kernel(uint32_t seed_lo, uin
 }  // namespace
 
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out) {
+    return launch_philox_block_on(ctx, ctx->stream, seed, ki, kj, naux, nao, out);
+}
+
+// the same launch on a stream of the caller's choice (the producer stream of the ERI pipeline's block ring)
+int launch_philox_block_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out) {
     const long long nelem = (long long)naux * nao * nao;
     if (nelem <= 0) return DMK_OK;
     const long long npairs = (nelem + 1) >> 1;
     long long blocks = (npairs + 255) / 256;
     if (blocks > 256LL * 32) blocks = 256LL * 32;
     const double scale = 1.0 / sqrt((double)nao);
-    FamScope fs(ctx, DMK_FAM_PHILOX);
-    hipLaunchKernelGGL(philox_block_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+    FamScope fs(ctx, DMK_FAM_PHILOX, stream);
+    hipLaunchKernelGGL(philox_block_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                        (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (uint32_t)ki, (uint32_t)kj, nelem,
                        scale, reinterpret_cast<double2 *>(out));
     DMK_CHECK_LAUNCH(ctx);

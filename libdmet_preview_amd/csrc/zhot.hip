@@ -14,8 +14,9 @@
 //     (tools/mfma_f64_probe.hip: 77.5 TFLOP/s is reachable from registers);
 //   * operands therefore arrive by LDS-DMA (global_load_lds_dwordx4) into a 3-4 stage ring, issued
 //     two to three K-tiles ahead and retired by a counted s_waitcnt vmcnt(N) + ONE raw s_barrier per
-//     K-tile; no staging registers and no scratch access INSIDE the K loops (half2_kernel spills 18 VGPRs = 28 B of scratch
-//     around its two K loops: kernel prologue / epilogue only), so the counted waits are never drained by the compiler;
+//     K-tile; no staging registers, no scratch (round 4: the LDS-DMA pieces are addressed as scalar tile base + one loop-invariant
+//     32-bit offset VGPR per piece, which removed half2_kernel's last 18 spilled VGPRs), so the counted waits are never drained
+//     by the compiler;
 //   * 256-thread workgroups, TWO per CU: a 512-thread workgroup sharing a larger tile halves the L2
 //     bytes per flop but runs its two waves per SIMD in barrier lock-step and measured 10 % slower
 //     than two independent workgroups that desynchronise by themselves (tools/gemm_lab*.hip);
@@ -112,33 +113,34 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     const double2 *const Bsp = g.Ci + (long long)sp * g.b_spin_stride + (long long)H1_PICK_BK(g, slot) * g.b_k_stride;
     double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride + (long long)slot * g.out_slot_stride;
 
-    // ---- per-lane LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB) ----
-    const double2 *srcA[AH], *srcB;
+    // ---- LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB).  Per lane only a loop-invariant byte
+    //      offset from the block's base (one VGPR per piece; a block is <= 512 MB); the K-row part of the address is scalar ----
+    unsigned voffA[AH], voffB;
 #pragma unroll
     for (int h = 0; h < AH; ++h) {
         long long r = (long long)tile_m * BM + 64 * h + lane;
         if (r >= rows_total) r = rows_total - 1;         // clamped lanes only ever feed masked outputs
         const long long L = r / mrows, q = r - L * mrows;
-        srcA[h] = Asl + L * nao * mrows + q;
+        voffA[h] = (unsigned)((L * nao * mrows + q) * 16);
     }
     {
         int col = n0 + lane;
         if (col >= g.nemb) col = g.nemb - 1;
-        srcB = Bsp + col;
+        voffB = (unsigned)(col * 16);
     }
     auto issue = [&](int t) {
         double2 *st = lds + (t % H1_D) * STAGE;
         const int k0 = wave * 2;
         const long long kg = (long long)t * H1_BK + k0;
+        const double2 *a0 = Asl + kg * mrows, *a1 = a0 + mrows, *b0 = Bsp + kg * nemb, *b1 = b0 + nemb;      // wave-uniform
         if constexpr (AH == 2) {
-            glds16_x6(srcA[0] + kg * mrows, srcA[1] + kg * mrows, srcB + kg * nemb, srcA[0] + (kg + 1) * mrows,
-                      srcA[1] + (kg + 1) * mrows, srcB + (kg + 1) * nemb, lds_addr_of(st + k0 * BM), lds_addr_of(st + k0 * BM + 64),
-                      lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM), lds_addr_of(st + (k0 + 1) * BM + 64),
-                      lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
+            glds16s_x6(voffA[0], voffA[1], voffB, voffA[0], voffA[1], voffB, a0, a0, b0, a1, a1, b1, lds_addr_of(st + k0 * BM),
+                       lds_addr_of(st + k0 * BM + 64), lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
+                       lds_addr_of(st + (k0 + 1) * BM + 64), lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
         } else {
-            glds16_x4(srcA[0] + kg * mrows, srcB + kg * nemb, srcA[0] + (kg + 1) * mrows, srcB + (kg + 1) * nemb,
-                      lds_addr_of(st + k0 * BM), lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
-                      lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
+            glds16s_x4(voffA[0], voffB, voffA[0], voffB, a0, b0, a1, b1, lds_addr_of(st + k0 * BM),
+                       lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
+                       lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
         }
     };
 
@@ -266,11 +268,11 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         // ---------------- diagonal triangle [d0, d0+128)^2 ----------------------------------------
         const int d0 = (type - 2) * 128;
         // stage = 16 pieces of 64 complex: piece p < 8 -> U row p/2, half p%2 ; p >= 8 -> C likewise; 4 pieces per wave
-        long long soff[4];
+        unsigned voff[4];                      // byte offset of this lane's 16 B inside a K-tile of the operand
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const int piece = wave + 4 * h;
-            soff[h] = (long long)((piece & 7) >> 1) * nemb + d0 + (piece & 1) * 64 + lane;
+            voff[h] = (unsigned)((((piece & 7) >> 1) * (int)nemb + d0 + (piece & 1) * 64 + lane) * 16);
         }
         // running issue state (wave-uniform, SGPRs): no division and no kernel-argument load per K-tile
         int is_t = 0, is_slot = 0, is_stage = 0;
@@ -291,8 +293,9 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         };
         auto issue = [&]() {
             double2 *st = lds + is_stage * H2T_STAGE;
-            glds16_x4(is_ub + soff[0], is_ub + soff[1], is_cb + soff[2], is_cb + soff[3], lds_addr_of(st + wave * 64),
-                      lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64));
+            // scalar tile bases + loop-invariant per-lane byte offsets: no vector ALU work per piece (common.h glds16s_x4)
+            glds16s_x4(voff[0], voff[1], voff[2], voff[3], is_ub, is_ub, is_cb, is_cb, lds_addr_of(st + wave * 64),
+                       lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64));
             issue_advance();
         };
         auto run = [&](auto tag) {
@@ -394,28 +397,26 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     const int r0 = 128 + 64 * type;
     const int wm = wave >> 1, wn = wave & 1;            // wave tile 32 x 64
     // stage = 24 pieces of 64 complex: 0-3 Ua rows, 4-11 Cb (row*2+half), 12-15 Ca rows, 16-23 Ub (row*2+half)
-    long long soff[6];
-    int isC[6];
+    unsigned voff[6];
 #pragma unroll
     for (int h = 0; h < 6; ++h) {
         const int piece = wave + 4 * h;
         int row, col;
-        if (piece < 4) { row = piece; col = r0; isC[h] = 0; }
-        else if (piece < 12) { row = (piece - 4) >> 1; col = ((piece - 4) & 1) * 64; isC[h] = 1; }
-        else if (piece < 16) { row = piece - 12; col = r0; isC[h] = 1; }
-        else { row = (piece - 16) >> 1; col = ((piece - 16) & 1) * 64; isC[h] = 0; }
-        soff[h] = (long long)row * nemb + col + lane;
+        if (piece < 4) { row = piece; col = r0; }
+        else if (piece < 12) { row = (piece - 4) >> 1; col = ((piece - 4) & 1) * 64; }
+        else if (piece < 16) { row = piece - 12; col = r0; }
+        else { row = (piece - 16) >> 1; col = ((piece - 16) & 1) * 64; }
+        voff[h] = (unsigned)((row * (int)nemb + col + lane) * 16);
     }
     int is_t = 0, is_slot = 0, is_stage = 0;
     const double2 *is_ub = Ubase, *is_cb = H2_PICK_CJ(g, 0) + cj_off;
     auto issue = [&]() {
         double2 *st = lds + is_stage * H2S_STAGE;
-        const double2 *gp[6];
-#pragma unroll
-        for (int h = 0; h < 6; ++h) gp[h] = (isC[h] ? is_cb : is_ub) + soff[h];
-        glds16_x6(gp[0], gp[1], gp[2], gp[3], gp[4], gp[5], lds_addr_of(st + wave * 64), lds_addr_of(st + (wave + 4) * 64),
-                  lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64), lds_addr_of(st + (wave + 16) * 64),
-                  lds_addr_of(st + (wave + 20) * 64));
+        // pieces wave + 4 h: h = 0 Ua, 1-2 Cb, 3 Ca, 4-5 Ub -- which operand a piece belongs to does not depend on the wave, so the
+        // bases are the two scalar tile pointers and the per-lane part is a loop-invariant byte offset (common.h glds16s_x6)
+        glds16s_x6(voff[0], voff[1], voff[2], voff[3], voff[4], voff[5], is_ub, is_cb, is_cb, is_cb, is_ub, is_ub, lds_addr_of(st + wave * 64),
+                   lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64),
+                   lds_addr_of(st + (wave + 16) * 64), lds_addr_of(st + (wave + 20) * 64));
         is_stage = is_stage + 1 == H2S_D ? 0 : is_stage + 1;
         if (++is_t == Tb) {
             is_t = 0;
@@ -496,7 +497,10 @@ bool hot_enabled() {
 
 // shapes the flattened kernel covers when the flattened row count is nL x nao (step 1)
 int half1_hot_usable(int nL, int nao, int nemb) {
-    return hot_enabled() && (nao % H1_BK) == 0 && nao >= 2 * H1_BK && nemb >= 32 && (long long)nL * nao >= 4 * H1_BM;
+    // the per-lane part of an LDS-DMA source address is a 32-bit byte offset from the block's base (glds16s): an AO block must stay
+    // below 4 GiB (C5: 512 MB); larger ones take the generic kernels
+    return hot_enabled() && (nao % H1_BK) == 0 && nao >= 2 * H1_BK && nemb >= 32 && (long long)nL * nao >= 4 * H1_BM &&
+           (long long)nL * nao * nao * 16 < (1LL << 32);
 }
 
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
@@ -505,6 +509,7 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
                            long long a_slot_stride = 0, long long out_slot_stride = 0, long long b_k_stride = 0,
                            const int *bk = nullptr) {
     if (!half1_hot_usable(nL, K, N) || (long long)nL * mrows < 4 * H1_BM) return 0;
+    if ((long long)nL * K * mrows * 16 >= (1LL << 32)) return 0;           // see half1_hot_usable
     static const int bm = [] { const char *e = getenv("DMK_ERI_H1_BM"); return (e && atoi(e) == 64) ? 64 : 128; }();
     if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) return 0;
     H1Args a;

@@ -144,42 +144,44 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                       PUB = KIND == 1 ? 1024 : 0;
         constexpr int PWR = KIND == 0 ? 128 : KIND == 1 ? 64 : 192, PWC = KIND == 2 ? 192 : 128;
 
-        long long soff[NP];                                              // element offset inside one K step of the operand
-        int isC[NP];
+        unsigned voff[NP];                                               // this lane's byte offset inside one K step of the operand
 #pragma unroll
         for (int h = 0; h < NP; ++h) {
             const int piece = wave + 4 * h;
             int row, col;
             if (KIND == 0) {
                 // 16 pieces of 64 complex: piece p < 8 -> U row p/2, half p%2 ; p >= 8 -> C likewise
-                row = (piece & 7) >> 1; col = r0 + (piece & 1) * 64 + lane; isC[h] = piece >= 8;
+                row = (piece & 7) >> 1; col = r0 + (piece & 1) * 64 + lane;
             } else if (KIND == 2) {
                 // 24 pieces: piece p < 12 -> U row p/3, third p%3 ; p >= 12 -> C likewise (the whole matrix width)
                 const int q = piece >= 12 ? piece - 12 : piece;
-                row = q / 3; col = (q % 3) * 64 + lane; isC[h] = piece >= 12;
+                row = q / 3; col = (q % 3) * 64 + lane;
             } else {
                 // 24 pieces: 0-3 Ua rows, 4-11 Cb (row*2+half), 12-15 Ca rows, 16-23 Ub (row*2+half)
-                if (piece < 4) { row = piece; col = r0 + lane; isC[h] = 0; }
-                else if (piece < 12) { row = (piece - 4) >> 1; col = c0 + ((piece - 4) & 1) * 64 + lane; isC[h] = 1; }
-                else if (piece < 16) { row = piece - 12; col = r0 + lane; isC[h] = 1; }
-                else { row = (piece - 16) >> 1; col = c0 + ((piece - 16) & 1) * 64 + lane; isC[h] = 0; }
+                if (piece < 4) { row = piece; col = r0 + lane; }
+                else if (piece < 12) { row = (piece - 4) >> 1; col = c0 + ((piece - 4) & 1) * 64 + lane; }
+                else if (piece < 16) { row = piece - 12; col = r0 + lane; }
+                else { row = (piece - 16) >> 1; col = c0 + ((piece - 16) & 1) * 64 + lane; }
             }
-            soff[h] = (long long)row * nemb + clampcol(col);
+            voff[h] = (unsigned)((row * (int)nemb + clampcol(col)) * 16);
         }
         int is_t = 0, is_slot = slot0, is_stage = 0;
         const double2 *is_ub = Ubase, *is_cb = T_PICK_CJ(g, slot0) + cj_off;
         auto issue = [&]() {
             double2 *st = lds + is_stage * STAGE;
-            const double2 *gp[NP];
-#pragma unroll
-            for (int h = 0; h < NP; ++h) gp[h] = (isC[h] ? is_cb : is_ub) + soff[h];
-            if constexpr (NP == 4)
-                glds16_x4(gp[0], gp[1], gp[2], gp[3], lds_addr_of(st + wave * 64), lds_addr_of(st + (wave + 4) * 64),
-                          lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64));
+            // which operand piece wave + 4 h belongs to depends on h only (diagonal: U U C C; rectangle: Ua Cb Cb Ca Ub Ub; wide:
+            // U U U C C C): scalar tile bases + loop-invariant per-lane byte offsets, no vector ALU work per piece (common.h)
+            if constexpr (KIND == 0)
+                glds16s_x4(voff[0], voff[1], voff[2], voff[3], is_ub, is_ub, is_cb, is_cb, lds_addr_of(st + wave * 64),
+                           lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64));
+            else if constexpr (KIND == 1)
+                glds16s_x6(voff[0], voff[1], voff[2], voff[3], voff[NP - 2], voff[NP - 1], is_ub, is_cb, is_cb, is_cb, is_ub, is_ub,
+                           lds_addr_of(st + wave * 64), lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64),
+                           lds_addr_of(st + (wave + 12) * 64), lds_addr_of(st + (wave + 16) * 64), lds_addr_of(st + (wave + 20) * 64));
             else
-                glds16_x6(gp[0], gp[1], gp[2], gp[3], gp[NP - 2], gp[NP - 1], lds_addr_of(st + wave * 64),
-                          lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64), lds_addr_of(st + (wave + 12) * 64),
-                          lds_addr_of(st + (wave + 16) * 64), lds_addr_of(st + (wave + 20) * 64));
+                glds16s_x6(voff[0], voff[1], voff[2], voff[3], voff[NP - 2], voff[NP - 1], is_ub, is_ub, is_ub, is_cb, is_cb, is_cb,
+                           lds_addr_of(st + wave * 64), lds_addr_of(st + (wave + 4) * 64), lds_addr_of(st + (wave + 8) * 64),
+                           lds_addr_of(st + (wave + 12) * 64), lds_addr_of(st + (wave + 16) * 64), lds_addr_of(st + (wave + 20) * 64));
             is_stage = is_stage + 1 == D ? 0 : is_stage + 1;
             if (++is_t == Tb) {
                 is_t = 0;

@@ -57,6 +57,29 @@ def test_dgemm_tn_acc(ctx, N, K):
     assert err < 1e-11 * max(1.0, np.abs(ref).max()), err
 
 
+@pytest.mark.parametrize("saddr", ["0", "1"])
+@pytest.mark.parametrize("N,K,rect", [(300, 800, False), (2080, 160, False), (1000, 120, True), (1282, 64, True)])
+def test_dgemm_tn_acc_both_dma_address_forms(ctx, N, K, rect, saddr):
+    """The LDS-DMA contraction in BOTH source-address forms -- per-lane 64-bit pointers and scalar row pointer + per-lane byte
+    offset (DMK_DGEMM_SADDR; the library picks by N, so small shapes would otherwise only ever see one of them) -- for the
+    symmetric launch (lower tile triangle + mirrored store) and the rectangular one, ragged edge tiles included."""
+    from libdmet_preview_amd._lib import lib
+    rng = np.random.default_rng(N + K)
+    X = rng.standard_normal((K, N))
+    Y = rng.standard_normal((K, N)) if rect else X
+    C0 = rng.standard_normal((N, N))
+    dX, dC = ctx.to_device(X), ctx.to_device(C0)
+    dY = ctx.to_device(Y) if rect else dX
+    os.environ["DMK_DGEMM_SADDR"] = saddr
+    try:
+        ctx.check(lib.dmk_dgemm_tn_acc(ctx.h, N, K, 0.5, dX.ptr, dY.ptr, N, dC.ptr, N))
+        got = dC.get()
+    finally:
+        del os.environ["DMK_DGEMM_SADDR"]
+    ref = C0 + 0.5 * X.T @ Y
+    assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
 def test_dgemm_tn_is_transpose_detecting(ctx):
     from libdmet_preview_amd._lib import lib
     rng = np.random.default_rng(5)

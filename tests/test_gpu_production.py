@@ -8,6 +8,7 @@ rows, reference visiting plan from the G1 golden).  Tolerance: the north star's 
 relative, which is what f64 accumulation in a different order gives).
 reference: basis_transform/eri_transform.py:338-382 (loop), 403-434 (half transform), 436-485 (contraction).
 """
+import os
 import numpy as np
 import pytest
 
@@ -310,3 +311,51 @@ def test_jk_row_ranges_must_end_on_a_block(ctx):
     ok = scf.jk_dev(ctx, n, dE, d_dm, None, d_dm, row_ranges=[(0, 96), (96, npair)])
     full = scf.jk_dev(ctx, n, dE, d_dm, None, d_dm)
     assert np.abs(ok[0].get() - full[0].get()).max() <= 1e-12 * np.abs(full[0].get()).max()
+
+
+@pytest.mark.parametrize("nao,naux,nemb,spin", [(104, 24, 136, 1), (16, 40, 256, 2)])
+def test_producer_stream_ring_is_bitwise_the_single_stream_result(ctx, nao, naux, nemb, spin):
+    """Device-side block producers on the pipeline's second stream (dmk_eri_ring_slot: double-buffered ring, the generator of group
+    g + 1 overlapping the transform of group g, ordered by events; opt-in with DMK_ERI_GEN_STREAM=1) against the default (single-buffered
+    ring on the compute stream): the same blocks in the same order, so the ERI must agree BIT FOR BIT -- a missing event edge (a block transformed before
+    it was generated, or overwritten before it was consumed) would show up as a different number.  Several kL, several groups per kL,
+    an explicit dmk_eri_flush in between (equal-length launches)."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, nk = (4, 3, 1), 12
+    npair = nemb * (nemb + 1) // 2
+    nblk = spin * (spin + 1) // 2
+    rng = np.random.default_rng(nao + naux)
+    Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    C_dev = ctx.to_device(Ce)
+    df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=41)
+    assert hasattr(df, "load_block_on")
+
+    def run(gen_stream):
+        os.environ["DMK_ERI_GEN_STREAM"] = "1" if gen_stream else "0"
+        try:
+            eri_dev = ctx.zeros((nblk, npair, npair), np.float64)
+            eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+            try:
+                assert eng.ring_slots > 0
+                kls = eng.irreducible_kL()
+                eng.set_stack(nslots=len(kls))
+                for rep in range(2):                       # the second pass reuses both halves of the ring
+                    for kL in kls:
+                        eng.run_kL(kL, df)
+                    eng.contract()
+                ctx.sync()
+                return eri_dev.get()
+            finally:
+                eng.close()
+        finally:
+            os.environ.pop("DMK_ERI_GEN_STREAM", None)
+
+    a = run(True)
+    b = run(False)
+    assert np.abs(a).max() > 0
+    assert np.array_equal(a, b)
+    # and against the oracle on a sample, so that "equal" is not "equally wrong"
+    A = [0, 1, nemb // 2, nemb - 1]
+    want, idx, _ = ES.eri_sample(mesh, 41, Ce, naux, A, [int(k) for k in range(nk) if ES.plan_records(mesh)[0][k] > 0])
+    for blk in range(nblk):
+        assert np.abs(a[blk][np.ix_(idx, idx)] - 2.0 * want[blk]).max() < 1e-8
