@@ -388,11 +388,14 @@ int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, con
         const int64_t jumpB = seg_rows == K ? 0 : seg_stride_y - (int64_t)seg_rows * ldy;
         FamScope fs(ctx, DMK_FAM_DGEMM);
         fs.mfma_flops(2.0 * (double)count * BM * BN * (double)K);
-        // Measured (tools/contract_bench.py, round 4): the scalar-base form wins at the C5 size (N = 32896, K = 1600: symmetric
-        // 24.82 -> 24.51 ms, rectangular 48.57 -> 47.16 ms) and loses on small pair spaces (N = 9316: symmetric K = 832 1.42 -> 1.51 ms,
-        // K = 3328 4.71 -> 4.82 ms): chosen by N; DMK_DGEMM_SADDR = 0 | 1 overrides (read per launch: labs toggle it)
+        // Measured (tools/contract_bench.py, rocprofv3 PMC; round 4): the scalar-base form is 1-3 % faster at the C5 size (N = 32896,
+        // K = 1600: symmetric 24.82 -> 24.51 ms, rectangular 48.57 -> 47.16 ms) but DOUBLES the launch's L2-miss traffic (FETCH_SIZE
+        // 22.1 -> 48.7 GB symmetric, 42.7 -> 82.0 GB rectangular; tools/fetch_probe.hip shows the counter reads both forms alike, so
+        // the re-reads are real: the workgroups of a super-block drift apart and lose their shared panels in L2), and it is slower
+        // on small pair spaces (N = 9316: symmetric K = 832 1.42 -> 1.51 ms).  The contraction therefore keeps per-lane pointers;
+        // DMK_DGEMM_SADDR=1 selects the scalar-base form (read per launch: labs and tests toggle it).
         const char *se = getenv("DMK_DGEMM_SADDR");
-        const bool saddr = se ? atoi(se) != 0 : (N >= 16384);
+        const bool saddr = se && atoi(se) != 0;
 #define DGEMM_LAUNCH(SY, SA)                                                                                                  \
         hipLaunchKernelGGL((dgemm_tn_acc_dma_kernel<SY, SA>), dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K, alpha, X, ldx, Y,   \
                            ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB)

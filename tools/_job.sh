@@ -1,10 +1,9 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04u; mkdir -p $O
+bash tools/prof_passes.sh r04p4 > gpurun_out/r04p4.log 2>&1
+tail -3 gpurun_out/r04p4.log
+O=gpurun_out/r04q4; mkdir -p $O
+cp gpurun_out/r04p4/traffic_latest.json profiles/traffic_latest.json
+python3 bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+python3 bench.py --workload C4 --steps 10 --warmup 2 > $O/bench_C4.json 2> $O/bench_C4.err
 ( time timeout 1500 python3 -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1
-tail -6 $O/pytest.log
-B4="python3 bench.py --workload C4 --steps 5 --warmup 1 --fit-iters 0 --no-cpu-baseline --no-shard-pass"
-$B4 > $O/c4_gen.json 2> $O/c4.err
-DMK_ERI_GEN_STREAM=0 $B4 > $O/c4_nogen.json 2>> $O/c4.err
-B5="python3 bench.py --scaling weak --kl-per-gpu 4 --no-full-config --steps 2 --warmup 1 --fit-iters 0 --no-cpu-baseline --parity-budget-s 100"
-$B5 > $O/c5_gen.json 2> $O/c5.err
-DMK_ERI_GEN_STREAM=0 $B5 > $O/c5_nogen.json 2>> $O/c5.err
+tail -5 $O/pytest.log
