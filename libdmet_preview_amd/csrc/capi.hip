@@ -598,12 +598,59 @@ int dmk_fold_k2R_complex(dmk_ctx *ctx, const int mesh[3], int64_t ncol, int batc
 // a9 / a10 : generic batched complex product
 // =============================================================================================
 
+namespace {
+// C[e] = alpha * sum_s part[s][e]: the reduction of a split-K product (fixed order: deterministic)
+__global__ void splitk_reduce_kernel(long long nelem, int nsplit, double alpha, const double2 *__restrict__ part, double2 *__restrict__ C) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (long long)gridDim.x * blockDim.x) {
+        double re = 0.0, im = 0.0;
+        for (int sidx = 0; sidx < nsplit; ++sidx) {
+            const double2 v = part[(long long)sidx * nelem + e];
+            re += v.x;
+            im += v.y;
+        }
+        C[e] = make_double2(alpha * re, alpha * im);
+    }
+}
+}  // namespace
+
 int dmk_zgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int batch, double alpha, const void *A,
                       int64_t strideA, const void *B, int64_t strideB, void *C, int64_t strideC) {
     if (!ctx) return DMK_ERR_INVALID;
     if (opA < 0 || opA > 2 || opB < 0 || opB > 2 || M < 0 || N < 0 || K < 0 || batch < 0)
         return dmk_fail(ctx, DMK_ERR_INVALID, "zgemm_batched: bad arguments");
     if (M == 0 || N == 0 || batch == 0) return DMK_OK;
+    // SPLIT-K for the long-K folds (1/nk) sum_k B_k^H T_k written as ONE product with K = nk * nlo (slater.py:682-704): at C5
+    // M = N = 256, K = 43 200, two spins -- 32 workgroups of 64 x 64 tiles on 256 CUs, 5.6 ms per call.  K is cut into `ns` equal
+    // chunks that become the batch of one launch per original batch element (partial products in the context's second scratch),
+    // then summed in a fixed order.  Only for K-major operands (op(A) = T | C, op(B) = N) and few, small output matrices.
+    if (opA != 0 && opB == 0 && K >= 4096 && batch <= 4 && (long long)M * N <= (1 << 18)) {
+        int ns = 0;
+        for (int cand = 128; cand >= 8; --cand)
+            if (K % cand == 0 && K / cand >= 128) { ns = cand; break; }
+        void *part = nullptr;
+        if (ns && dmk_scratch2(ctx, (size_t)ns * M * N * sizeof(double2), &part) == DMK_OK) {
+            const int kc = K / ns;
+            const long long nelem = (long long)M * N;
+            for (int b = 0; b < batch; ++b) {
+                ZGemm gs;
+                gs.M = M; gs.N = N; gs.K = kc; gs.batch = ns; gs.nseg = 1;
+                ZSeg &ss = gs.seg[0];
+                ss.A = reinterpret_cast<const double2 *>(A) + (long long)b * strideA; ss.a_kmajor = 1; ss.lda = M; ss.conjA = (opA == 2);
+                ss.strideA = (int64_t)kc * M;
+                ss.B = reinterpret_cast<const double2 *>(B) + (long long)b * strideB; ss.b_kmajor = 1; ss.ldb = N;
+                ss.strideB = (int64_t)kc * N;
+                gs.alpha = 1.0; gs.epi = ZEPI_STORE; gs.C = part; gs.ldc = N; gs.strideC = nelem;
+                int rc = launch_zgemm(ctx, gs, DMK_FAM_ZGEMM_SMALL);
+                if (rc) return rc;
+                FamScope fs(ctx, DMK_FAM_ZGEMM_SMALL);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>((nelem + 255) / 256, 1024)), dim3(256), 0,
+                                   ctx->stream, nelem, ns, alpha, reinterpret_cast<const double2 *>(part),
+                                   reinterpret_cast<double2 *>(C) + (long long)b * strideC);
+                DMK_CHECK_LAUNCH(ctx);
+            }
+            return DMK_OK;
+        }
+    }
     ZGemm g;
     g.M = M; g.N = N; g.K = K; g.batch = batch; g.nseg = 1;
     ZSeg &s = g.seg[0];

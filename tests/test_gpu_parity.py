@@ -96,6 +96,20 @@ def test_dgemm_tn_is_transpose_detecting(ctx):
 # generic complex batched product / basis algebra (a9, a10)
 # ---------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("opA,M,N,K,nb", [("C", 40, 24, 4320, 2), ("T", 72, 72, 8640, 1), ("C", 256, 256, 4096, 2), ("C", 16, 16, 4099, 3)])
+def test_zgemm_batched_long_k_split(ctx, opA, M, N, K, nb):
+    """The one-body folds (1/nk) sum_k B_k^H T_k are ONE product with K = nk * nlo (slater.py:682-704): few small output matrices
+    and a very long K, which dmk_zgemm_batched cuts into equal K chunks (a batch of partial products summed in a fixed order).
+    K = 4099 is prime: no equal split exists and the plain launch answers."""
+    from libdmet_preview_amd.basis_transform.make_basis import _bgemm
+    rng = np.random.default_rng(K + M)
+    a = rng.standard_normal((nb, K, M)) + 1j * rng.standard_normal((nb, K, M))
+    b = rng.standard_normal((nb, K, N)) + 1j * rng.standard_normal((nb, K, N))
+    ref = np.einsum("bkm,bkn->bmn", a.conj() if opA == "C" else a, b)
+    got = _bgemm(opA, "N", a, b)
+    assert np.abs(got - ref).max() < 1e-12 * K
+
+
 @pytest.mark.parametrize("opA", "NTC")
 @pytest.mark.parametrize("opB", "NTC")
 def test_zgemm_batched_ops(ctx, opA, opB):
