@@ -11,6 +11,7 @@
 //        -Wl,-rpath,'$ORIGIN/../libdmet_preview_amd' -o tools/zhot_lab            run: tools/zhot_lab
 #include "../libdmet_preview_amd/csrc/zhot.hip"
 #include "../libdmet_preview_amd/csrc/zhot_tab.hip"
+#include "zhot_half1p_lab.h"
 #include <cstdio>
 #include <vector>
 
@@ -75,6 +76,50 @@ int main() {
         printf("   LAB %2d  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", LABV, ms, f1 / ms * 1e-9, f1 / ms * 1e-9 / 78.6 * 100.0);  \
     }
     RUN1(0) RUN1(1) RUN1(2) RUN1(4) RUN1(3) RUN1(7)
+    int ncu = 256;
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+    printf("step 1, persistent (half1p_kernel<conj, 128, 2, wide>): %d workgroups walk the same %u tiles\n", 2 * ncu, a.nblocks);
+#define RUN1P(LABV)                                                                                                           \
+    {                                                                                                                           \
+        const float ms = time_ms([&] { hipLaunchKernelGGL((half1p_kernel<true, 128, 2, false, LABV>), dim3(2 * ncu), dim3(HNT), 0, 0, a); }); \
+        printf("   LAB %2d  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", LABV, ms, f1 / ms * 1e-9, f1 / ms * 1e-9 / 78.6 * 100.0);  \
+    }
+    RUN1P(0) RUN1P(8) RUN1P(16) RUN1P(32) RUN1P(64) RUN1P(1) RUN1P(2) RUN1P(4) RUN1P(3) RUN1P(7)
+    {   // ---- step 1 at C4: 16 queued blocks, naux 416, nao 104, nemb 136, one spin, 48-column tiles ---------------------------
+        const int nL4 = 416, nao4 = 104, nemb4 = 136, nslot4 = 16;
+        H1Args c = a;
+        c.nL = nL4; c.nao = nao4; c.nemb = nemb4; c.mrows = nao4; c.nblk = (nao4 + 15) / 16;
+        c.tiles_m = (int)(((long long)nL4 * nao4 + 127) / 128); c.tiles_n = (nemb4 + 47) / 48;
+        c.nspin = 1; c.b_spin_stride = 0; c.out_spin_stride = 0;
+        c.nslot = nslot4; c.a_slot_stride = (long long)nL4 * nao4 * nao4; c.out_slot_stride = (long long)nL4 * nao4 * nemb4;
+        c.b_k_stride = (long long)nao4 * nemb4;
+        c.per_slot = (unsigned)(c.tiles_m * c.tiles_n);
+        c.nblocks = c.per_slot * nslot4;
+        const double f4 = 6.0 * (double)c.nblocks * 128 * 48 * nao4;
+        printf("step 1 at C4 (<conj, 128, 2, narrow>): %u tiles, %.1f GFLOP issued per launch\n", c.nblocks, f4 * 1e-9);
+#define RUN4(KERNEL, GRID, LABV, TAG)                                                                                         \
+        {                                                                                                                       \
+            const float ms = time_ms([&] { hipLaunchKernelGGL((KERNEL<true, 128, 2, true, LABV>), dim3(GRID), dim3(HNT), 0, 0, c); }); \
+            printf("   %-10s LAB %2d  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", TAG, LABV, ms, f4 / ms * 1e-9, f4 / ms * 1e-9 / 78.6 * 100.0); \
+        }
+        RUN4(half1_kernel, c.nblocks, 0, "per tile") RUN4(half1_kernel, c.nblocks, 1, "per tile") RUN4(half1_kernel, c.nblocks, 2, "per tile")
+        RUN4(half1_kernel, c.nblocks, 7, "per tile")
+        RUN4(half1p_kernel, 2 * ncu, 0, "persistent") RUN4(half1p_kernel, 2 * ncu, 8, "persistent") RUN4(half1p_kernel, 2 * ncu, 16, "persistent") RUN4(half1p_kernel, 2 * ncu, 32, "persistent") RUN4(half1p_kernel, 2 * ncu, 64, "persistent") RUN4(half1p_kernel, 2 * ncu, 1, "persistent") RUN4(half1p_kernel, 2 * ncu, 2, "persistent")
+        RUN4(half1p_kernel, 2 * ncu, 7, "persistent")
+        {   // 64 x 48 tiles, three workgroups per CU
+            H1Args d = c;
+            d.tiles_m = (int)(((long long)nL4 * nao4 + 63) / 64);
+            d.per_slot = (unsigned)(d.tiles_m * d.tiles_n);
+            d.nblocks = d.per_slot * nslot4;
+            const double f5 = 6.0 * (double)d.nblocks * 64 * 48 * nao4;
+            for (int rep = 0; rep < 2; ++rep) {
+                const float ms = time_ms([&] { hipLaunchKernelGGL((half1_kernel<true, 64, 3, true, 0>), dim3(d.nblocks), dim3(HNT), 0, 0, d); });
+                printf("   64x48 occ3 LAB  0  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", ms, f5 / ms * 1e-9, f5 / ms * 1e-9 / 78.6 * 100.0);
+            }
+            const float ms7 = time_ms([&] { hipLaunchKernelGGL((half1_kernel<true, 64, 3, true, 7>), dim3(d.nblocks), dim3(HNT), 0, 0, d); });
+            printf("   64x48 occ3 LAB  7  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", ms7, f5 / ms7 * 1e-9, f5 / ms7 * 1e-9 / 78.6 * 100.0);
+        }
+    }
 
     // ---- step 2: as launch_half2_hot (all blocks symmetrised -> folded diagonal blocks) ------------------------------------
     H2Args h;
