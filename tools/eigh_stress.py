@@ -3,10 +3,11 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from libdmet_preview_amd import _lib
 from libdmet_preview_amd._lib import lib
 ctx = _lib.get_ctx()
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(os.environ.get('STRESS_SEED', '2026')))
+NMAX = int(os.environ.get('STRESS_NMAX', '200')); BMAX = int(os.environ.get('STRESS_BMAX', '5'))
 worst = [0, 0, 0]
-for trial in range(60):
-    n = int(rng.integers(65, 201)); batch = int(rng.integers(1, 6))
+for trial in range(int(os.environ.get('STRESS_TRIALS', '60'))):
+    n = int(rng.integers(2, NMAX + 1)); batch = int(rng.integers(1, BMAX + 1))
     kind = trial % 4
     A = rng.standard_normal((batch, n, n)) + 1j * rng.standard_normal((batch, n, n))
     A = A + A.conj().transpose(0, 2, 1)
