@@ -168,6 +168,20 @@ int main() {
             printf("   LAB %2d  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", LABV, ms, f3 / ms * 1e-9, f3 / ms * 1e-9 / 78.6 * 100.0); \
         }
         RUN3(0) RUN3(1) RUN3(2) RUN3(4) RUN3(3) RUN3(7)
+        // the same kernel with 2x / 4x / 8x the auxiliary rows per launch: what fusing the step-2 launches of several kL would give
+        // (1248 workgroups on 768 resident slots = 1.6 rounds -> 3.25 / 6.5 / 13)
+        for (int mult = 2; mult <= 8; mult *= 2) {
+            H2TArgs u = t;
+            u.nL = nL4 * mult; u.naux = u.nL;
+            u.per_sub = (unsigned)(u.nitems * u.nL); u.nblocks = u.per_sub;
+            if ((size_t)u.nL * nao4 * nemb4 * nslot4 > ut * nslot * nspin || (size_t)2 * u.nL * npair4 > (size_t)nspin * 2 * nL * npair) break;
+            u.slot_stride = (long long)u.nL * nao4 * nemb4;
+            const double fm = f3 * mult;
+            const float ms0 = time_ms([&] { hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 0>), dim3(u.nblocks), dim3(HNT), 0, 0, u); });
+            const float ms7 = time_ms([&] { hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 7>), dim3(u.nblocks), dim3(HNT), 0, 0, u); });
+            printf("   x%d rows (%u workgroups)  LAB 0 %8.3f ms %6.2f TF (%5.1f %%)   LAB 7 %8.3f ms %6.2f TF (%5.1f %%)\n", mult, u.nblocks,
+                   ms0, fm / ms0 * 1e-9, fm / ms0 * 1e-9 / 78.6 * 100.0, ms7, fm / ms7 * 1e-9, fm / ms7 * 1e-9 / 78.6 * 100.0);
+        }
     }
     return 0;
 }
