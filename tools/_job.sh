@@ -1,11 +1,2 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04x; mkdir -p $O
-( time timeout 1500 python3 -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1
-tail -5 $O/pytest.log
-python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-python3 - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r04x/bench_default.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['steps'], d['roofline']['frac'], d['roofline']['traffic'], d['parity_ok'], d['parity_stages_ok'], d['vcor_fit']['seconds_total'])
-PY
+python3 tools/diag_stage_probe.py C5 2>&1 | tail -8
