@@ -359,3 +359,29 @@ def test_producer_stream_ring_is_bitwise_the_single_stream_result(ctx, nao, naux
     want, idx, _ = ES.eri_sample(mesh, 41, Ce, naux, A, [int(k) for k in range(nk) if ES.plan_records(mesh)[0][k] > 0])
     for blk in range(nblk):
         assert np.abs(a[blk][np.ix_(idx, idx)] - 2.0 * want[blk]).max() < 1e-8
+
+
+def test_randomised_eri_campaign_short():
+    """tools/eri_stress.py with a fixed seed: 30 random systems (meshes with odd axes, dimensions on and off the tile sizes, one and two
+    spin channels, with and without time reversal, 4-fold and 1-fold results) through get_emb_eri against the oracle at 1e-8.  The long
+    campaign (850 systems, worst 1.1e-15) is profiles/r04_e_eri_stress.txt."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="30", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "eri_stress.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "eri stress ok: 30 systems" in run.stdout
+
+
+def test_randomised_mean_field_and_bath_campaign_short():
+    """tools/meanfield_stress.py with a fixed seed: 60 random lattices (odd and even mesh axes, 2 .. 72 orbitals per cell, restricted and
+    unrestricted, T = 0 and T > 0, random valence / virtual splits) through mfd.HF and slater.get_emb_basis against the oracle
+    (eigenvalues 1e-10, T = 0 occupations equal, rho 1e-9, bath projector 1e-9 where the singular values are clear of the cut-off).
+    The long campaign (1200 lattices) is profiles/r04_e_meanfield_stress.txt."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="60", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "meanfield_stress.py")], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "mean-field stress ok: 60 lattices" in run.stdout

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python3 tools/diag_stage_probe.py C5 2>&1 | tail -8
+python3 -m pytest tests/test_gpu_production.py -q -m gpu -k "randomised" 2>&1 | tail -5
