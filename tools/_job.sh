@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_gpu_production.py -q -m gpu -k "randomised" 2>&1 | tail -5
+O=gpurun_out/r04z; mkdir -p $O; rm -f $O/fit_stress.log
+for sd in 1 2 3 4 5 6 7 8 9 10; do STRESS_SEED=$sd STRESS_TRIALS=80 timeout 900 python3 tools/fit_stress.py >> $O/fit_stress.log 2>&1; echo "seed $sd rc $?" >> $O/fit_stress.log; done
+grep -v "WARNING\|^larger\|degenerate" $O/fit_stress.log | cut -c1-700 | tail -30
