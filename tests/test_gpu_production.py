@@ -398,3 +398,17 @@ def test_randomised_fit_campaign_short():
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "fit_stress.py")], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "fit stress ok: 30 embedding problems" in run.stdout
+
+
+def test_randomised_iteration_campaign_short():
+    """tools/iteration_stress.py with a fixed seed: 25 random systems through the WHOLE device-resident iteration (diag -> bath -> C_ao_emb
+    -> DF transform -> J / K -> H1_emb); ERI (1e-8), H1_emb / JK_core (1e-10), C_ao_emb (1e-12) against the oracle on the pipeline's own
+    intermediate products, the Freivalds probe, and a second pass bit-identical to the first.  The long campaign (600 systems) is
+    profiles/r04_e_iteration_stress.txt."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="25", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "iteration_stress.py")], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "iteration stress ok: 25 systems" in run.stdout
