@@ -390,14 +390,15 @@ def test_randomised_mean_field_and_bath_campaign_short():
 def test_randomised_fit_campaign_short():
     """tools/fit_stress.py with a fixed seed: 30 random embedding problems (random meshes, 3 .. 40 orbitals per cell, random valence counts,
     T = 0 and T > 0, full / impurity-only / impurity + bath-diagonal index sets, remove_diag_grad) through EmbFitDevice against
-    oracle/restate_fit.py: dV_dparam 1e-12, objective 1e-9, analytic gradient 1e-7.  The long campaign (800 problems, worst 7e-13) is
+    oracle/restate_fit.py: dV_dparam 1e-12, objective 1e-9, analytic gradient 1e-7; then 15 lattice-fit problems (FullFitDevice against
+    FullFit).  The long campaign (800 + 400 problems, worst 1e-12) is
     profiles/r04_e_fit_stress.txt."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="30", GRAFT_REPO_ROOT=root)
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "fit_stress.py")], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
-    assert "fit stress ok: 30 embedding problems" in run.stdout
+    assert "fit stress ok: 30 embedding problems" in run.stdout and "lattice-fit stress ok: 15 lattice problems" in run.stdout
 
 
 def test_randomised_iteration_campaign_short():

@@ -2,6 +2,7 @@
 table, streaming contraction, eigh(nemb), occupations, analytic gradient; reference routine/slater.py:1040-1154, ftsystem.py:151-213)
 against oracle/restate_fit.py on random embedding problems -- random meshes, 3 .. 40 orbitals per cell, random valence counts,
 T = 0 and T > 0, impurity-only / impurity + diagonal index sets, remove_diag_grad.
+A second loop does the same for the LATTICE fit (FullFitDevice against FullFit: objective at T = 0 and T > 0, analytic finite-T gradient).
     STRESS_SEED=1 STRESS_TRIALS=40 python tools/fit_stress.py          (test infrastructure: imports the oracle)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -73,5 +74,63 @@ for trial in range(trials):
         assert e_g < 1e-7, (trial, mesh, nlo, nval, beta, mode, rdg, scale, e_g)
         worst["err"], worst["grad"] = max(worst["err"], abs(e - e_ref)), max(worst["grad"], e_g)
     done += 1
+# ---- the LATTICE fit (FitVcorFull, slater.py:1352-1682): the whole lattice re-diagonalised per parameter vector ---------------------
+from libdmet_preview_amd import synth
+from libdmet_preview_amd.routine.mfd import check_nelec
+worst_full = {"err": 0.0, "grad": 0.0}
+done_full = 0
+for trial in range(max(1, trials // 2)):
+    mesh = tuple(int(x) for x in rng.choice([1, 2, 3, 4], size=3, p=[0.5, 0.3, 0.1, 0.1]))
+    nk = mesh[0] * mesh[1] * mesh[2]
+    if nk < 2:
+        mesh, nk = (2, 1, 1), 2
+    nlo = 2 * int(rng.integers(1, 13))
+    nval = int(rng.integers(1, nlo + 1))
+    spin, filling = 2, 0.5
+    beta = float(rng.uniform(5.0, 40.0)) if rng.random() < 0.7 else np.inf
+    sysm = pipeline.SyntheticSystem(ctx, mesh, nlo, 0, nval, spin, seed=int(rng.integers(1, 1 << 30)), name="fullfit_stress")
+    d_rhoR, mf = pipeline.mean_field_stage(ctx, sysm)
+    d_basis, nemb, sig = pipeline.bath_stage(ctx, sysm, d_rhoR)
+    basis = d_basis.get().reshape(spin, nk, nlo, nemb)
+    Fk = sysm.d_Fock_k.get().reshape(spin, nk, nlo, nlo)
+    L = Lattice(nlo, mesh)
+    L.set_Ham_lo(fock_lo_R=sysm.Fock_R)
+    L.val_idx, L.virt_idx, L.core_idx = list(range(nval)), list(range(nval, nlo)), []
+    v = Hubbard.VcorLocal(False, False, nlo)
+    ov = F.VcorLocal(False, False, nlo)
+    mode = int(rng.integers(0, 3))
+    if mode == 0 and True:
+        imp_idx, det_idx, ibf = list(range(nemb)), [], True                    # imp + bath fit: objective only (slater.py:1510-1512)
+        rho_k = R.R2k(d_rhoR.get().reshape(spin, nk, nlo, nlo), mesh)
+        bk = R.R2k(basis, mesh)
+        tgt = np.asarray([np.einsum("kpa,kpq,kqb->ab", bk[s].conj(), rho_k[s], bk[s]).real / nk for s in range(spin)])
+    else:
+        ibf = False
+        imp_idx, det_idx = (list(range(nlo)), []) if mode == 1 else ([], list(range(nlo)))
+        tgt = d_rhoR.get().reshape(spin, nk, nlo, nlo)[:, 0].copy()
+    noise = 0.02 * rng.standard_normal(tgt.shape)
+    target = tgt + 0.5 * (noise + noise.transpose(0, 2, 1))
+    nelec = check_nelec(spin * nk * nlo * filling)[0]
+    fit = slater.FullFitDevice(ctx, target, L, basis, v, beta, nelec, imp_idx, det_idx, ibf)
+    ref = F.FullFit(target, mesh, basis, ov, beta, Fk, filling, imp_idx=None if ibf else imp_idx, det_idx=None if ibf else det_idx)
+    for scale in (0.0, 0.05):
+        p = scale * rng.standard_normal(v.length())
+        if beta == np.inf:
+            # T = 0: only defined where the lattice frontier is not degenerate under this potential
+            ov.update(p)
+            vm = ov.get(0, True)
+            lv = np.sort(np.concatenate([np.linalg.eigvalsh(Fk[s, k] + vm[s]) for s in range(spin) for k in range(nk)]))
+            if lv[nelec] - lv[nelec - 1] < 1e-6:
+                continue
+        e, e_ref = fit.errfunc(p), ref.errfunc(p)
+        assert abs(e - e_ref) < 1e-9 * max(1.0, abs(e_ref)), ("full", trial, mesh, nlo, nval, beta, mode, scale, e, e_ref)
+        worst_full["err"] = max(worst_full["err"], abs(e - e_ref))
+        if beta != np.inf and not ibf:
+            g, g_ref = fit.gradfunc(p), ref.gradfunc_ft(p)
+            e_g = float(np.abs(g - g_ref).max()) / max(1.0, float(np.abs(g_ref).max()))
+            assert e_g < 1e-7, ("full", trial, mesh, nlo, nval, beta, mode, scale, e_g)
+            worst_full["grad"] = max(worst_full["grad"], e_g)
+    done_full += 1
+print("lattice-fit stress ok: %d lattice problems, worst |derr| %.1e, |dgrad| / max(1, |g|) %.1e" % (done_full, worst_full["err"], worst_full["grad"]))
 print("fit stress ok: %d embedding problems (%d skipped: empty or full channel) in %.0f s, worst |ddV| %.1e, |derr| %.1e, |dgrad| / max(1, |g|) %.1e"
       % (done, skipped, time.time() - t0, worst["dV"], worst["err"], worst["grad"]))
