@@ -13,7 +13,7 @@ import numpy as np
 
 from libdmet_preview_amd._lib import lib, get_ctx
 from libdmet_preview_amd.routine.bcs_helper import *          # noqa: F401,F403  (reference re-exports them)
-from libdmet_preview_amd.routine.slater import bath_svd_dev
+from libdmet_preview_amd.routine.slater import bath_svd_dev, complete_null_columns
 from libdmet_preview_amd.utils import logger as log
 
 
@@ -34,6 +34,7 @@ def emb_basis_proj_dev(ctx, kmesh, ncells, nscsites, val_idx, d_GRho):
     cols = np.asarray(list(val_idx) + [i + n for i in val_idx], dtype=np.int32)
     env = np.arange(2 * n, 2 * n * ncells, dtype=np.int32)
     d_sigma, d_U = bath_svd_dev(ctx, kmesh, 2 * n, d_GRho, ctx.to_device(env), nenv, ctx.to_device(cols), nb)
+    complete_null_columns(ctx, d_sigma.get().reshape(-1)[:nb], d_U, nenv, nb)     # bcs.py:46, 84: every column is kept
     d_w = ctx.empty((nb,), np.float64)
     ctx.check(lib.dmk_bcs_weight(ctx.h, ncells - 1, 2 * n, n, nb, d_U.ptr, d_w.ptr))
     w = d_w.get()

@@ -72,6 +72,39 @@ def bath_svd_dev(ctx, kmesh, nlo, d_rdm1_s, d_env, nenv, d_col, nb):
     return d_sigma, d_U
 
 
+def complete_null_columns(ctx, sigma, d_U, nenv, nb, ncheck=None):
+    """Where the reference keeps left singular vectors whatever their singular value -- every column in routine/bcs.py:46, 84, the first
+    `nbath` columns when the caller fixes `nbath` (routine/slater.py:177-186, with its "Zero singular value exists" warning) --
+    LAPACK returns an orthonormal completion for the singular values that vanish (an impurity that is not entangled with part of the
+    environment; a band that is full or empty at every k gives A = 0).  The device factorisation forms u_j = A v_j / sigma_j, which has
+    no direction there: such columns are replaced by an orthonormal completion (unit vectors orthogonalised against the columns kept,
+    twice), so that the embedding basis stays orthonormal.  Which completion is a matter of convention in the reference as well.
+    Rare and small: done on the host."""
+    sigma = np.asarray(sigma, dtype=float).reshape(-1)[:nb]
+    smax = float(sigma.max()) if nb else 0.0
+    ncheck = nb if ncheck is None else min(int(ncheck), nb)             # only the first `ncheck` columns are used by the caller
+    null = [j for j in range(ncheck) if not sigma[j] > 4.0 * nenv * np.finfo(float).eps * smax]
+    if not null or nenv < nb:
+        return
+    U = d_U.get().reshape(nenv, nb)
+    keep = [j for j in range(ncheck) if j not in null]
+    Q = U[:, keep].copy()
+    nxt = 0
+    for j in null:
+        while True:
+            e = np.zeros(nenv)
+            e[nxt] = 1.0
+            nxt += 1
+            for _ in range(2):
+                e -= Q @ (Q.T @ e)
+            nrm = np.linalg.norm(e)
+            if nrm > 0.5 or nxt >= nenv:
+                break
+        U[:, j] = e / nrm
+        Q = np.concatenate([Q, U[:, j:j + 1]], axis=1)
+    ctx.check(lib.dmk_memcpy_h2d(ctx.h, d_U.ptr, np.ascontiguousarray(U).ctypes.data, U.nbytes))
+
+
 def bath_svd_batched_dev(ctx, kmesh, nlo, d_rdm1, spin, d_env, nenv, d_col, nb):
     """All spin channels in one chain of launches: d_rdm1 (spin, ncells, nlo, nlo) -> sigma (spin, nb), U (spin, nenv, nb)."""
     d_sigma = ctx.empty((spin, nb), np.float64)
@@ -128,6 +161,7 @@ def _get_emb_basis_svd(lattice, rdm1, **kwargs):
         log.debug(0, "Zero singular values number: %s", nzero)
         if nzero > 0:
             log.warn("Zero singular value exists, \nthis may cause numerical instability.")
+            complete_null_columns(ctx, sigma, d_U, nenv, nb, ncheck=nbath_s)
         d_basis = ctx.empty((nsites, ncol), np.float64)
         bath_assemble_dev(ctx, d_U, nenv, nb, nbath_s, d_virt, orth, d_env, d_imp, nimp, nsites, ncol, d_basis)
         basis[s] = d_basis.get()

@@ -239,3 +239,32 @@ def test_unit2emb(ctx, golden):
     box = {"ccdd": np.array(g["u2e/in4"])}
     out = sh.unit2emb(box, neo)
     assert out is box and np.array_equal(box["ccdd"], g["u2e/out4"])
+
+
+def test_bcs_emb_basis_without_entanglement(ctx):
+    """A generalised density whose env x imp block vanishes (one band, full at every k: found by tools/bcs_stress.py) or is rank
+    deficient: the reference keeps all 2 nval left singular vectors and LAPACK completes the vanishing ones orthonormally
+    (bcs.py:46, 84-103); the device factorisation has no direction for them, the host binding completes them -- the embedding basis
+    must stay orthonormal, and the well-defined part must still be the oracle's."""
+    from libdmet_preview_amd.routine import bcs
+    mesh, n = (1, 1, 4), 1
+    L = _lattice(mesh, n, [0])
+    GRho = np.zeros((4, 2, 2))
+    GRho[0] = np.diag([1.0, 0.0])
+    b = bcs.embBasis(L, GRho)
+    assert b.shape == (2, 4, 2, 2)
+    for s in range(2):
+        a = b[s].reshape(-1, b.shape[-1])
+        assert np.abs(a.T @ a - np.eye(a.shape[1])).max() < 1e-12
+    # rank one: a single entangled direction, the second column is a completion
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal(6)
+    u /= np.linalg.norm(u)
+    A = 0.3 * np.outer(u, [0.8, 0.6])
+    GRho2 = np.zeros((4, 2, 2))
+    GRho2[0] = np.diag([0.6, 0.4])
+    GRho2[1:] = A.reshape(3, 2, 2)
+    Bd = bcs.embBasis(L, GRho2, only_return_bath=True)
+    a = Bd.reshape(-1, Bd.shape[-1])
+    assert np.abs(a.T @ a - np.eye(2)).max() < 1e-12
+    assert abs(abs(a[:, 0] @ u) - 1.0) < 1e-12                     # the entangled direction itself

@@ -1080,3 +1080,25 @@ def test_G15_eri_general_k_lists(ctx, golden, case, spin):
             assert np.abs(e1 - ref / top).max() < 1e-8
     # the canonical mesh keeps its (zero) imaginary part: physical blocks, TR-symmetric orbitals
     assert np.array_equal(et.get_weights_t_reversal(cell, cell.get_abs_kpts(ks)), R.get_weights_t_reversal(ks))
+
+
+def test_bath_with_fixed_nbath_beyond_the_rank(ctx):
+    """`nbath` fixed by the caller beyond the rank of the env x imp block (slater.py:177-186: the reference warns "Zero singular value
+    exists" and keeps LAPACK's orthonormal completion): the basis must stay orthonormal and its entangled part must be the oracle's."""
+    from libdmet_preview_amd.routine import slater
+    mesh, nlo = (1, 1, 3), 2
+    rng = np.random.default_rng(12)
+    u = rng.standard_normal(4)
+    u /= np.linalg.norm(u)
+    rdm1 = np.zeros((3, nlo, nlo))
+    rdm1[0] = np.diag([0.7, 0.3])
+    rdm1[1:] = (0.25 * np.outer(u, [0.6, 0.8])).reshape(2, nlo, nlo)           # rank one
+    L = _lattice(mesh, nlo, val=[0, 1], virt=[])
+    b = slater.get_emb_basis(L, rdm1, nbath=2, valence_bath=False)
+    assert b.shape[-1] == nlo + 2
+    B = b[0].reshape(-1, b.shape[-1])
+    assert np.abs(B.T @ B - np.eye(B.shape[1])).max() < 1e-12
+    assert abs(abs(B[nlo:, nlo] @ u) - 1.0) < 1e-12
+    ref = R.get_emb_basis(mesh, nlo, rdm1, imp_idx=[0, 1], val_idx=[0, 1], nbath=2, valence_bath=False)
+    Bref = ref[0].reshape(-1, ref.shape[-1])
+    assert abs(abs(Bref[nlo:, nlo] @ u) - 1.0) < 1e-12

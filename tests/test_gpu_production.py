@@ -413,3 +413,14 @@ def test_randomised_iteration_campaign_short():
                          timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "iteration stress ok: 25 systems" in run.stdout
+
+
+def test_randomised_bcs_campaign_short():
+    """tools/bcs_stress.py with a fixed seed: 60 random lattices through the BCS / Nambu twin (DiagBdG, bcs.embBasis, bcs_helper folds and
+    dV_dparam) against oracle/restate_bcs.py.  The long campaign (1000 lattices) is profiles/r04_e_bcs_stress.txt."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="60", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "bcs_stress.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "bcs stress ok: 60 lattices" in run.stdout
