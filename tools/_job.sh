@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_bcs.py tests/test_gpu_gso.py -q -m gpu -k "bath or bcs or gso or emb_basis" 2>&1 | tail -6
-STRESS_SEED=3 STRESS_TRIALS=100 python3 tools/meanfield_stress.py 2>&1 | grep "stress ok"
-STRESS_SEED=3 STRESS_TRIALS=100 python3 tools/bcs_stress.py 2>&1 | grep "stress ok"
+O=gpurun_out/r04z; mkdir -p $O; rm -f $O/ham_stress.log
+for sd in 1 2 3 4 5 6 7 8 9 10; do STRESS_SEED=$sd STRESS_TRIALS=150 timeout 900 python3 tools/ham_stress.py >> $O/ham_stress.log 2>&1; echo "seed $sd rc $?" >> $O/ham_stress.log; done
+grep "stress ok\|^seed\|Error" $O/ham_stress.log | cut -c1-300 | tail -22
