@@ -209,3 +209,16 @@ def test_kpairs_any_k_order(mesh):
         kp, kidx = mfd_mpi.get_kpairs_kidx(cell, k2)
         rp, ridx = R.get_kpairs_kidx(k2)
         assert [tuple(int(y) for y in x) for x in rp] == kp and np.array_equal(kidx, ridx)
+
+
+def test_randomised_ktable_campaign_short():
+    """tools/ktable_stress.py with a fixed seed: 10 random meshes (axes 1 .. 9), permuted and shifted k lists -- k-points, cells, -k table,
+    time-reversal weights, cell arithmetic, k-point membership, the visiting plans of the ERI double loop (integer planner and the planner
+    for arbitrary k lists), assign_workload and the +-k pairs, all BIT-IDENTICAL to the oracle's restatement of the reference's loops.
+    The long campaign (340 meshes, 2288 plans) is profiles/r04_e_ktable_stress.txt."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="10", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "ktable_stress.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "k-table stress ok: 10 meshes" in run.stdout
