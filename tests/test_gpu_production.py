@@ -427,13 +427,13 @@ def test_randomised_bcs_campaign_short():
 
 
 @pytest.mark.parametrize("tool,trials,needle", [("algebra_stress.py", 100, "algebra stress ok: 100 rounds"), ("ham_stress.py", 60, "ham stress ok: 60 lattices"),
-                                                ("cderi_stress.py", 40, "cderi stress ok: 40 DF tensors")])
+                                                ("cderi_stress.py", 40, "cderi stress ok: 40 DF tensors"), ("gso_stress.py", 50, "gso stress ok: 50 rounds")])
 def test_randomised_algebra_and_ham_campaigns_short(tool, trials, needle):
     """tools/algebra_stress.py (folds on meshes with axes 1 .. 7, basis algebra with every spin-dimension combination, eri_restore) and
     tools/ham_stress.py (J / K on every ERI format, one-body folds, get_emb_Ham with the reference's option combinations) with a fixed seed
     against the oracle; tools/cderi_stress.py (writer and reader of the cderi layout, ERI fed from the container through the host-feed
-    path).  The long campaigns (2000 rounds / 1500 lattices / 800 DF tensors, worst 8e-15) are profiles/r04_e_algebra_ham_stress.txt and
-    profiles/r04_e_cderi_stress.txt."""
+    path); tools/gso_stress.py (the GSO twins: spinless.get_emb_basis, get_emb_eri_gso).  The long campaigns (2000 rounds / 1500 lattices /
+    800 DF tensors / 1000 rounds, worst 6e-14) are profiles/r04_e_algebra_ham_stress.txt, r04_e_cderi_stress.txt, r04_e_gso_stress.txt."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS=str(trials), GRAFT_REPO_ROOT=root)
