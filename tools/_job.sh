@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04z; mkdir -p $O; rm -f $O/gso_stress.log
-for sd in 1 2 3 4 5 6 7 8 9 10; do STRESS_SEED=$sd STRESS_TRIALS=100 timeout 900 python3 tools/gso_stress.py >> $O/gso_stress.log 2>&1; echo "seed $sd rc $?" >> $O/gso_stress.log; done
-grep "stress ok\|^seed\|Error" $O/gso_stress.log | cut -c1-300 | tail -22
+O=gpurun_out/r04x; mkdir -p $O
+( time timeout 1800 python3 -m pytest tests -m gpu -x -q ) > $O/pytest3.log 2>&1
+tail -6 $O/pytest3.log
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
