@@ -440,3 +440,15 @@ def test_randomised_algebra_and_ham_campaigns_short(tool, trials, needle):
     run = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert needle in run.stdout
+
+
+def test_randomised_hot_kernel_campaign_short():
+    """tools/hot_stress.py with a fixed seed: 15 random production-like shapes (nao 16 .. 208, naux 32 .. 640, nemb 32 .. 320, one and two spin
+    channels) through the hot kernels -- whole kL through the block ring, planes and ERI on sampled orbital pairs against the sampled C
+    oracle, Freivalds probe on every pair row.  The long campaign (480 shapes) is profiles/r04_e_hot_stress.txt."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261002", STRESS_TRIALS="15", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "hot_stress.py")], env=env, capture_output=True, text=True, timeout=1200)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "hot stress ok: 15 shapes" in run.stdout

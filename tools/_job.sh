@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04x; mkdir -p $O
-( time timeout 1800 python3 -m pytest tests -m gpu -x -q ) > $O/pytest3.log 2>&1
-tail -6 $O/pytest3.log
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+O=gpurun_out/r04z; mkdir -p $O; rm -f $O/hot_stress.log
+for sd in 1 2 3 4 5 6 7 8; do STRESS_SEED=$sd STRESS_TRIALS=60 timeout 1200 python3 tools/hot_stress.py >> $O/hot_stress.log 2>&1; echo "seed $sd rc $?" >> $O/hot_stress.log; done
+grep "stress ok\|^seed\|Error\|assert" $O/hot_stress.log | cut -c1-400 | tail -24
