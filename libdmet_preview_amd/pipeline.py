@@ -106,6 +106,10 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
     else:
         # this rank's (spin, k) rows of the resident Fock batch: ONE gather launch (mfd_mpi.py:64-74 scatters them over MPI)
         nloc = len(kmine)
+        if nloc == 0:
+            # more ranks than +-k groups (a 2-point mesh on three ranks): this rank diagonalises nothing and only takes part in the
+            # sums (the reference's scatter hands such a rank an empty list as well, mfd_mpi.py:64-74)
+            return _mean_field_stage_idle(ctx, sysm, timers, t)
         rows = np.asarray([s * nk + k for s in range(spin) for k in kmine], dtype=np.int32)
         d_rows = ctx.to_device(rows)
         d_F = ctx.empty((spin * nloc, n, n), np.complex128)
@@ -136,6 +140,22 @@ def mean_field_stage(ctx, sysm, timers=None, tol_bath=1e-9):
     if dist.is_initialized():
         dist.all_reduce_sum_dev(d_rhoR)
         t = _stage(ctx, timers, "allreduce_rho", t)
+    return d_rhoR, {"mu": mu, "ew": d_w_all, "occ": d_occ_all, "nerr": nerr}
+
+
+def _mean_field_stage_idle(ctx, sysm, timers, t):
+    """mean_field_stage of a rank that owns no k-point: zeros into the two sums, the replicated occupation kernel, nothing else."""
+    n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
+    t = _stage(ctx, timers, "diag", t)
+    d_w_all = ctx.zeros((spin * nk, n), np.float64)
+    dist.all_reduce_sum_dev(d_w_all)
+    d_occ_all, mu, nerr = mfd.assignocc_dev(ctx, d_w_all, spin * nk * n * sysm.filling, np.inf)
+    t = _stage(ctx, timers, "occupations", t)
+    t = _stage(ctx, timers, "density", t)
+    d_rhoR = ctx.zeros((spin, nk, n * n), np.float64)
+    t = _stage(ctx, timers, "fold_k2R", t)
+    dist.all_reduce_sum_dev(d_rhoR)
+    _stage(ctx, timers, "allreduce_rho", t)
     return d_rhoR, {"mu": mu, "ew": d_w_all, "occ": d_occ_all, "nerr": nerr}
 
 

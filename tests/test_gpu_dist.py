@@ -73,7 +73,11 @@ def _worker(rank, world, port, workload, over, q, backend="gloo", exchange="allr
     ("C3", None, 2, "allreduce"), ("C3", dict(mesh=(3, 2, 2), spin=2, nval=4, nlo=8, naux=12), 3, "allreduce"),
     # row-sharded sum: bands of ERI rows reduced to their owners, J / K from the owned rows, only n x n matrices all-reduced
     ("C3", dict(mesh=(3, 2, 2), spin=2, nval=8, nlo=24, naux=16), 2, "row_sharded"),
-    ("C3", dict(mesh=(4, 2, 1), spin=1, nval=20, nlo=40, naux=8), 3, "row_sharded")])
+    ("C3", dict(mesh=(4, 2, 1), spin=1, nval=20, nlo=40, naux=8), 3, "row_sharded"),
+    # more ranks than +-k groups and than irreducible kL (found by tools/dist_stress.py): rank 2 owns no k-point and no kL and only
+    # takes part in the sums
+    ("C3", dict(mesh=(2, 1, 1), spin=2, nval=3, nlo=6, naux=8), 3, "row_sharded"),
+    ("C3", dict(mesh=(2, 1, 1), spin=1, nval=2, nlo=4, naux=5), 4, "allreduce")])
 def test_ranks_on_one_gpu_match_single_process(workload, over, world, exchange):
     import torch.multiprocessing as mp
     mpc = mp.get_context("spawn")
