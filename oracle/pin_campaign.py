@@ -1,0 +1,133 @@
+"""
+oracle/pin_campaign.py -- TEST INFRASTRUCTURE, THIS CONTAINER ONLY (imports the reference from /root/reference through oracle/shim.py;
+nothing here travels to the GPU box or is imported by the product).
+
+Randomised PINNING campaign of the oracle: the numpy restatements of oracle/restate.py against the REFERENCE ITSELF, run side by side on
+random inputs -- beyond the fixed cases of tests/golden (G1 - G17), which the same generator script produces.  Covered: the k-mesh
+bookkeeping (bit-exact), mfd.HF (diagonalisation, occupations at T = 0 and T > 0, density, fold; with and without the k / -k symmetry),
+slater.get_emb_basis (Schmidt bath), get_emb_eri_fast_gdf (with and without time reversal, 1- / 4- / 8-fold, unit_eri, C_ao_eo).
+    python oracle/pin_campaign.py [seed] [trials]
+"""
+import os, sys, time, io, contextlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import shim
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    trials = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    shim.install()
+    shim.quiet()
+    from oracle import restate as R
+    from oracle import gen_golden as GG
+    from libdmet_preview_amd import synth
+    from libdmet.routine import mfd, slater
+    from libdmet.system import fourier as rf
+    from libdmet.basis_transform import eri_transform as ret_plain
+    et = shim.patch_eri_transform()
+    rng = np.random.default_rng(seed)
+    worst = {"hf": 0.0, "bath": 0.0, "eri": 0.0}
+    t0, skipped = time.time(), 0
+    sink = io.StringIO()
+    for trial in range(trials):
+        mesh = tuple(int(x) for x in rng.choice([1, 2, 3, 4, 5], size=3, p=[0.4, 0.3, 0.15, 0.1, 0.05]))
+        nk = int(np.prod(mesh))
+        if nk < 2:
+            mesh, nk = (2, 1, 1), 2
+        if nk > 40:
+            mesh, nk = (mesh[0], mesh[1], 1), mesh[0] * mesh[1]
+        # ---- k bookkeeping, bit-exact ----
+        ks = rf.make_kpts_scaled(mesh)
+        assert np.array_equal(ks, R.make_kpts_scaled(mesh)), (mesh, "kpts_scaled")
+        cell = shim.FakeCell(3)
+        assert np.array_equal(ret_plain.get_weights_t_reversal(cell, cell.get_abs_kpts(ks)), R.get_weights_t_reversal(ks)), (mesh, "weights")
+        assert np.array_equal(rf.round_to_FBZ(ks + 0.5, tol=1e-10), R.round_to_FBZ(ks + 0.5, tol=1e-10)), (mesh, "round_to_FBZ")
+        # ---- mean field ----
+        nlo = int(rng.integers(2, 13))
+        spin = int(rng.integers(1, 3))
+        beta = np.inf if rng.random() < 0.6 else float(rng.uniform(5.0, 60.0))
+        FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=int(rng.integers(1, 1 << 30)))
+        Fk = synth.fold_R2k(FR, mesh)
+        H1R = 0.5 * FR
+        L = GG._duck_lattice(mesh, nlo)
+        L.fock_lo_k, L.fock_lo_R = (Fk[0], FR[0]) if spin == 1 else (Fk, FR)
+        L.hcore_lo_k = synth.fold_R2k(H1R, mesh)[0] if spin == 1 else synth.fold_R2k(H1R, mesh)
+        L.hcore_lo_R = H1R[0] if spin == 1 else H1R
+        v = rng.standard_normal((2, nlo, nlo)) * 0.1
+        v = 0.5 * (v + v.transpose(0, 2, 1))
+        if spin == 1:
+            v[1] = v[0]
+        ew_all = np.sort(np.concatenate([np.linalg.eigvalsh(Fk[s, k] + v[s]) for s in range(spin) for k in range(nk)]))
+        gaps = np.where(np.diff(ew_all) > 1e-4)[0]
+        gaps = gaps[(gaps > len(ew_all) // 8) & (gaps < 7 * len(ew_all) // 8)]
+        if len(gaps) == 0:
+            skipped += 1
+            continue
+        filling = (int(rng.choice(gaps)) + 1) / float(spin * nk * nlo)
+        symm = bool(rng.random() < 0.4)
+        with contextlib.redirect_stdout(sink):
+            rhoT, mu, E, res = mfd.HF(L, GG._Vcor(v), filling, spin == 1, mu0=None, beta=beta, ires=True, symm=symm)
+        rr, mur, Er, resr = R.HF(mesh, Fk, FR, H1R, v, filling, spin == 1, beta=beta, ires=True, symm=symm)
+        e = max(float(np.abs(res["e"] - resr["e"]).max()), float(np.abs(rhoT - rr).max()), abs(float(np.asarray(E)) - float(np.asarray(Er))) /
+                max(1.0, abs(float(np.asarray(Er)))))
+        assert e < 1e-11, (trial, mesh, nlo, spin, beta, symm, e)
+        assert np.abs(np.asarray(res["mo_occ"]) - np.asarray(resr["mo_occ"])).max() < 1e-11, (trial, "occupations")
+        worst["hf"] = max(worst["hf"], e)
+        # ---- Schmidt bath ----
+        nval = int(rng.integers(1, nlo + 1))
+        perm = rng.permutation(nlo)
+        val, virt = sorted(int(x) for x in perm[:nval]), sorted(int(x) for x in perm[nval:])
+        Lb = GG._duck_lattice(mesh, nlo, val=val, virt=virt)
+        rdm = rhoT if spin == 2 else rhoT[0]
+        vb = bool(rng.random() < 0.7)
+        with contextlib.redirect_stdout(sink):
+            b = slater.get_emb_basis(Lb, rdm, valence_bath=vb)
+        ref, info = R.get_emb_basis(mesh, nlo, rdm, imp_idx=list(range(nlo)), val_idx=val, valence_bath=vb, return_info=True)
+        assert b.shape == ref.shape, (trial, mesh, nlo, val, vb, b.shape, ref.shape)
+        for s in range(b.shape[0]):
+            B, Bref = b[s].reshape(-1, b.shape[-1]), ref[s].reshape(-1, ref.shape[-1])
+            # same LAPACK on both sides: the columns agree up to a sign; the projector distance is only defined for orthonormal columns
+            # (the reference's own basis is not orthonormal to better than 1e-9 when nbath is cut to the other spin's count)
+            csd = max(min(np.abs(B[:, j] - Bref[:, j]).max(), np.abs(B[:, j] + Bref[:, j]).max()) for j in range(B.shape[1]))
+            d = float(csd) if csd < 1e-10 else float(np.sqrt(2.0) * np.linalg.norm(B - Bref @ (Bref.T @ B)))
+            sg = np.sort(np.asarray(info["sigma"][s]))[::-1]
+            nb = min(info["nbath_s"])
+            ok = not (np.any((sg > 1e-11) & (sg < 1e-7)) or (1 <= nb < len(sg) and sg[nb - 1] - sg[nb] < 1e-6 and sg[nb] > 1e-9))
+            if ok:
+                smin = float(sg[:nb].min()) if nb >= 1 else 1.0          # singular vectors are determined to eps / sigma
+                assert d < 1e-9 + 1e-15 / max(smin, 1e-300), (trial, mesh, nlo, val, vb, d, smin)
+                worst["bath"] = max(worst["bath"], d)
+        # ---- DF ERI transform ----
+        mesh2 = tuple(int(x) for x in rng.choice([1, 2, 3], size=3, p=[0.5, 0.35, 0.15]))
+        nk2 = int(np.prod(mesh2))
+        if nk2 < 2 or nk2 > 9:
+            mesh2, nk2 = (2, 2, 1), 4
+        nao, naux, nemb, sp = int(rng.integers(2, 7)), int(rng.integers(2, 9)), int(rng.integers(2, 8)), int(rng.integers(1, 3))
+        ks2 = rf.make_kpts_scaled(mesh2)
+        cell2 = shim.FakeCell(nao)
+        kpts2 = cell2.get_abs_kpts(ks2)
+        W0 = synth.make_W0(mesh2, naux, nao, seed=int(rng.integers(1, 1 << 30)))
+        blocks = synth.df_blocks_from_W0(W0, mesh2)
+        mydf = shim.FakeGDF(cell2, kpts2, lambda i, j, bb=blocks: bb[i, j], naux=naux, blockdim=max(1, naux // 2 + 1))
+        C = synth.make_C_ao_lo(mesh2, nao, nao, spin=sp, seed=int(rng.integers(1, 1000)))
+        basis = rng.standard_normal((sp, nk2, nao, nemb))
+        get = lambda i, j: blocks[i, j]
+        runs = [dict(t_reversal_symm=True), dict(t_reversal_symm=False), dict(symmetry=1), dict(unit_eri=True)]
+        if sp == 1:
+            runs.append(dict(symmetry=8))
+        for kw in runs:
+            with contextlib.redirect_stdout(sink):
+                e_ref = et.get_emb_eri_fast_gdf(cell2, mydf, C_ao_lo=C, basis=basis, max_memory=1, **kw)
+            e_or = R.get_emb_eri_fast_gdf(mesh2, ks2, get, naux, nao, C_ao_lo=C, basis=basis, **kw)
+            assert np.asarray(e_ref).shape == np.asarray(e_or).shape, (trial, kw)
+            d = float(np.abs(np.asarray(e_ref) - np.asarray(e_or)).max()) / max(1.0, float(np.abs(e_ref).max()))
+            assert d < 1e-11, (trial, mesh2, nao, naux, nemb, sp, kw, d)
+            worst["eri"] = max(worst["eri"], d)
+    print("oracle pin campaign ok: %d random cases against the reference itself in %.0f s (%d without a gap at the Fermi level skipped), worst: "
+          "HF %.1e, bath projector %.1e, ERI %.1e (relative)" % (trials, time.time() - t0, skipped, worst["hf"], worst["bath"], worst["eri"]))
+
+
+if __name__ == "__main__":
+    main()
