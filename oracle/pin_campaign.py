@@ -125,6 +125,62 @@ def main():
             d = float(np.abs(np.asarray(e_ref) - np.asarray(e_or)).max()) / max(1.0, float(np.abs(e_ref).max()))
             assert d < 1e-11, (trial, mesh2, nao, naux, nemb, sp, kw, d)
             worst["eri"] = max(worst["eri"], d)
+    # ---- vcor fit in the embedding space: the reference's errfunc / gradfunc closures (captured by wrapping slater.minimize, as gen_G9
+    #      does) against oracle/restate_fit.py at random parameter vectors ----
+    from oracle import restate_fit as F
+    from libdmet.dmet import Hubbard
+    shim.patch_scf()
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    worst_fit, nfit = 0.0, 0
+    try:
+        for trial in range(max(1, trials // 3)):
+            mesh = tuple(int(x) for x in rng.choice([1, 2, 3, 4], size=3, p=[0.45, 0.3, 0.15, 0.1]))
+            if int(np.prod(mesh)) < 2:
+                mesh = (2, 1, 1)
+            nlo, spin = int(rng.integers(2, 8)), int(rng.integers(1, 3))
+            lo = int(rng.integers(0, nlo))
+            hi = int(rng.integers(lo, nlo))
+            val = list(range(lo, hi + 1))
+            with contextlib.redirect_stdout(sink):
+                L, FR, basis, target = GG._fit_case("x", mesh, nlo, spin, val, int(rng.integers(1, 1 << 20)))
+            nb = basis.shape[-1]
+            if nb <= nlo - lo or lo + len(val) >= nb:
+                continue                                    # no bath orbital, or ncore + nval electrons do not fit the embedding space:
+                                                            # the reference's own closure indexes out of bounds there (slater.py:1070)
+            Fk = R.R2k(FR, mesh)
+            Sk = np.asarray([np.eye(nlo, dtype=complex)] * basis.shape[1])
+            ncore = min(val)
+            nelec = ncore + len(val) if spin == 1 else [ncore + len(val)] * 2
+            runs = [(np.inf, dict()), (float(rng.uniform(8.0, 30.0)), dict()), (float(rng.uniform(8.0, 30.0)), dict(fix_mu=True, mu0=0.1)),
+                    (np.inf, dict(imp_fit=True)), (np.inf, dict(det=True)), (np.inf, dict(remove_diag_grad=True))]
+            beta, kw = runs[int(rng.integers(0, len(runs)))]
+            v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            with contextlib.redirect_stdout(sink):
+                slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=1, **kw)
+            ov = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            nimp = nlo - min(val)
+            imp_idx, det_idx = (list(range(nimp)), []) if kw.get("imp_fit") else (([], list(range(nimp))) if kw.get("det") else (None, None))
+            fit = F.EmbFit(target, mesh, basis, ov, beta, Fk if spin == 2 else Fk[0], Sk, nelec, imp_idx=imp_idx, det_idx=det_idx,
+                           mu0=kw.get("mu0"), fix_mu=kw.get("fix_mu", False), remove_diag_grad=kw.get("remove_diag_grad", False))
+            grad = fit.gradfunc if beta == np.inf else fit.gradfunc_ft
+            for _ in range(2):
+                p = 0.1 * rng.standard_normal(v.length())
+                with contextlib.redirect_stdout(sink):
+                    e_ref, g_ref = captured["fn"](p.copy()), captured["fgrad"](p.copy())
+                d = max(abs(fit.errfunc(p) - e_ref), float(np.abs(grad(p) - g_ref).max()) / max(1.0, float(np.abs(g_ref).max())))
+                assert d < 1e-9, ("fit", trial, mesh, nlo, spin, val, beta, kw, d)
+                worst_fit = max(worst_fit, d)
+            nfit += 1
+    finally:
+        slater.minimize = real_minimize
+    print("oracle pin campaign, fit: %d random embedding problems, errfunc / gradfunc closures of the reference against restate_fit.py: worst %.1e"
+          % (nfit, worst_fit))
     print("oracle pin campaign ok: %d random cases against the reference itself in %.0f s (%d without a gap at the Fermi level skipped), worst: "
           "HF %.1e, bath projector %.1e, ERI %.1e (relative)" % (trials, time.time() - t0, skipped, worst["hf"], worst["bath"], worst["eri"]))
 
