@@ -181,6 +181,153 @@ def main():
         slater.minimize = real_minimize
     print("oracle pin campaign, fit: %d random embedding problems, errfunc / gradfunc closures of the reference against restate_fit.py: worst %.1e"
           % (nfit, worst_fit))
+    # ---- exit of the path: the reference's get_emb_Ham / _get_jk / one-body folds against oracle/restate_ham.py ----
+    from oracle import restate_ham as H
+    from libdmet.routine import slater_helper as sh
+    from libdmet.solver import scf as rscf
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+    worst_ham, nham = 0.0, 0
+    for trial in range(max(1, trials // 3)):
+        mesh = tuple(int(x) for x in rng.choice([1, 2, 3, 4], size=3, p=[0.45, 0.3, 0.15, 0.1]))
+        nk = int(np.prod(mesh))
+        if nk < 2:
+            mesh, nk = (2, 1, 1), 2
+        nlo, spin = int(rng.integers(2, 8)), int(rng.integers(1, 3))
+        lo = int(rng.integers(0, nlo))
+        val = list(range(lo, int(rng.integers(lo, nlo)) + 1))
+        L = GG._duck_lattice(mesh, nlo, val=val, virt=[i for i in range(nlo) if i > max(val)], core=[i for i in range(nlo) if i < min(val)])
+        FR = synth.make_fock_R(mesh, nlo, spin=spin, seed=int(rng.integers(1, 1 << 30)))
+        Fk = synth.fold_R2k(FR, mesh)
+        HR = float(rng.uniform(0.3, 0.8)) * FR
+        Hk = synth.fold_R2k(HR, mesh)
+        SR = np.zeros((nk, nlo, nlo))
+        SR[0] = np.eye(nlo)
+        SR = SR + synth.make_fock_R(mesh, nlo, spin=1, seed=int(rng.integers(1, 1000)))[0] * 0.02
+        Sk = synth.fold_R2k(SR[None], mesh)[0]
+        sq = (lambda x: x[0]) if spin == 1 else (lambda x: x)
+        L.fock_lo_k, L.fock_lo_R, L.hcore_lo_k, L.hcore_lo_R = sq(Fk), sq(FR), sq(Hk), sq(HR)
+        L.vhf_lo_k, L.ovlp_lo_k, L.JK_imp, L.Ham, L.H0 = sq(Fk - Hk), Sk, None, None, 0.75
+        v = rng.standard_normal((2, nlo, nlo)) * 0.1
+        v = 0.5 * (v + v.transpose(0, 2, 1))
+        if spin == 1:
+            v[1] = v[0]
+        vc = GG._Vcor(v)
+        with contextlib.redirect_stdout(sink):
+            rhoT, mu, E, res = mfd.HF(L, vc, 0.5, spin == 1, beta=np.inf, ires=True)
+            L.rdm1_lo_k = res["rho_k"] * (2.0 if spin == 1 else 1.0)
+            L.rdm1_lo_R = rhoT
+            basis = slater.get_emb_basis(L, rhoT)
+        nb = basis.shape[-1]
+        H2 = GG._psd_eri(rng, nb, 7, spin)
+        JK2 = rng.standard_normal((nlo, nlo))
+        JK2 = JK2 + JK2.T
+        JK3 = np.asarray([JK2, 0.5 * JK2])[:spin]
+        runs = [dict(), dict(add_vcor=True), dict(add_vcor=True, fitting=True), dict(int_bath=False), dict(int_bath=False, JK_imp=JK2),
+                dict(int_bath=False, JK_imp=JK3), dict(int_bath=False, hcore=True)]
+        rdm1_k = L.rdm1_lo_k
+        for kw in runs:
+            kw = dict(kw)
+            okw = {k: w for k, w in kw.items() if k not in ("hcore",)}
+            if kw.get("hcore"):
+                okw["use_hcore_as_emb_ham"] = True
+            L.JK_imp = kw.pop("JK_imp", None)
+            L.use_hcore_as_emb_ham = kw.pop("hcore", False)
+            L.JK_core = "unset"
+            with contextlib.redirect_stdout(sink):
+                Himp, _ = slater.get_emb_Ham(L, basis, vc, H2_given=H2, **kw)
+            H1, ovlp, JKc = H.embHam1e(mesh, basis, H2, Hk, Fk, Sk, rdm1_k, vcor_mat=v, **okw)
+            d = max(float(np.abs(Himp.H1["cd"] - H1).max()), float(np.abs(np.asarray(Himp.ovlp) - ovlp).max()))
+            if JKc is not None:
+                d = max(d, float(np.abs(np.asarray(L.JK_core) - JKc).max()))
+            else:
+                assert L.JK_core is None
+            assert d < 1e-11 * max(1.0, float(np.abs(H1).max())), ("ham", trial, mesh, nlo, spin, val, sorted(okw), d)
+            worst_ham = max(worst_ham, d)
+        L.JK_imp, L.use_hcore_as_emb_ham = None, False
+        with contextlib.redirect_stdout(sink):
+            dm = slater.foldRho_k(L.rdm1_lo_k, L.R2k_basis(basis))
+            for eri in (H2, np.asarray([shim.restore(1, h, nb) for h in H2])):
+                vj, vk = rscf._get_jk(dm, eri)
+                oj, ok_ = H.get_jk(dm, eri)
+                d = max(float(np.abs(np.asarray(vj) - np.asarray(oj)).max()), float(np.abs(np.asarray(vk) - np.asarray(ok_)).max()))
+                assert d < 1e-11 * max(1.0, float(np.abs(np.asarray(oj)).max())), ("jk", trial, d)
+                worst_ham = max(worst_ham, d)
+            for s_ in range(spin):
+                for a, b in ((sh.transform_trans_inv(basis[s_], L, FR[s_]), H.transform_trans_inv(basis[s_], mesh, FR[s_])),
+                             (sh.transform_trans_inv(basis[s_], L, FR[s_], symmetric=False), H.transform_trans_inv(basis[s_], mesh, FR[s_], False)),
+                             (sh.transform_local(basis[s_], L, v[s_]), H.transform_local(basis[s_], v[s_])),
+                             (sh.transform_imp(basis[s_], L, v[s_]), H.transform_imp(basis[s_], v[s_])),
+                             (sh.transform_imp_env(basis[s_], L, FR[s_]), H.transform_imp_env(basis[s_], FR[s_]))):
+                    d = float(np.abs(a - b).max())
+                    assert d < 1e-11 * max(1.0, float(np.abs(b).max())), ("fold", trial, d)
+                    worst_ham = max(worst_ham, d)
+        nham += 1
+    print("oracle pin campaign, ham: %d random lattices, the reference's get_emb_Ham (7 option sets) / _get_jk / one-body folds against "
+          "restate_ham.py: worst %.1e" % (nham, worst_ham))
+    # ---- BCS / Nambu twin: the reference's DiagBdG / DiagGHF, bcs.embBasis and bcs_helper folds against oracle/restate_bcs.py ----
+    from oracle import restate_bcs as B
+    from libdmet.routine import bcs, bcs_helper as bh
+    from libdmet.system import lattice as rl
+    worst_bcs, nbcs = 0.0, 0
+    for trial in range(max(1, trials // 3)):
+        mesh = tuple(int(x) for x in rng.choice([1, 2, 3, 4], size=3, p=[0.45, 0.3, 0.15, 0.1]))
+        nk = int(np.prod(mesh))
+        if nk < 2:
+            mesh, nk = (3, 1, 1), 3
+        n = int(rng.integers(1, 8))
+        val = sorted(int(x) for x in rng.permutation(n)[: int(rng.integers(1, n + 1))])
+        L = GG._duck_lattice(mesh, n, val=val)
+        FR = synth.make_fock_R(mesh, n, spin=2, seed=int(rng.integers(1, 1 << 30)))
+        Fk = synth.fold_R2k(FR, mesh)
+        v = rng.standard_normal((3, n, n)) * 0.2
+        v[0], v[1] = 0.5 * (v[0] + v[0].T), 0.5 * (v[1] + v[1].T)
+        mu = float(rng.uniform(-0.4, 0.4))
+        vc = GG._Vcor(v)
+        with contextlib.redirect_stdout(sink):
+            ew, ev = mfd.DiagBdG(Fk, vc, mu)
+            ews, evs = mfd.DiagBdGsymm(Fk, vc, mu, L)
+        ewo, evo = B.DiagBdG(Fk, v, mu)
+        ewso, evso = B.DiagBdG(Fk, v, mu, kmesh=mesh)
+        d = max(float(np.abs(ew - ewo).max()), float(np.abs(ews - ewso).max()))
+        assert d < 1e-12, ("bdg", trial, mesh, n, d)
+        GRho_k = np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+        GRho = rl.FFTtoT(GRho_k, mesh)
+        D_R = synth.make_fock_R(mesh, n, spin=1, seed=int(rng.integers(1, 1000)))[0] * 0.3
+        GF_R = np.zeros((nk, 2 * n, 2 * n))
+        GF_R[:, :n, :n], GF_R[:, n:, n:], GF_R[:, :n, n:] = FR[0], -FR[1], D_R
+        GF_R[:, n:, :n] = rl.Lattice.transpose(L, D_R)
+        GFk = synth.fold_R2k(GF_R[None], mesh)[0]
+        with contextlib.redirect_stdout(sink):
+            gw, gv = mfd.DiagGHF(GFk, vc, mu)
+            gws, gvs = mfd.DiagGHF_symm(GFk, vc, mu, L)
+        d = max(d, float(np.abs(gw - B.DiagGHF(GFk, v, mu)[0]).max()), float(np.abs(gws - B.DiagGHF(GFk, v, mu, kmesh=mesh)[0]).max()))
+        assert d < 1e-12, ("ghf", trial, mesh, n, d)
+        with contextlib.redirect_stdout(sink):
+            basis = bcs.embBasis(L, GRho)
+        ob, osig, oB, ow = B.embBasis_proj(np.asarray(GRho).real, n, val)
+        assert basis.shape == ob.shape
+        csd = max(min(np.abs(basis.reshape(-1, basis.shape[-1])[:, j] - ob.reshape(-1, ob.shape[-1])[:, j]).max(),
+                      np.abs(basis.reshape(-1, basis.shape[-1])[:, j] + ob.reshape(-1, ob.shape[-1])[:, j]).max()) for j in range(basis.shape[-1]))
+        if np.sort(osig)[0] > 1e-7 and np.diff(np.sort(ow)).min(initial=1.0) > 1e-6:
+            assert csd < 1e-9, ("bcs basis", trial, mesh, n, val, csd)
+            d = max(d, float(csd))
+        H3 = np.asarray([FR[0], FR[1], D_R])
+        with contextlib.redirect_stdout(sink):
+            for fn, fo, Hm in ((bh.transform_trans_inv, B.transform_trans_inv, H3), (bh.transform_trans_inv, B.transform_trans_inv, FR),
+                               (bh.transform_local, B.transform_local, v), (bh.transform_imp, B.transform_imp, v),
+                               (bh.transform_imp_env, B.transform_imp_env, H3)):
+                (hA, hB), hD, e0 = fn(basis, L, Hm)
+                (rA, rB), rD, r0 = fo(basis, mesh, Hm)
+                df = max(float(np.abs(hA - rA).max()), float(np.abs(hB - rB).max()), float(np.abs(hD - rD).max()), abs(e0 - r0))
+                assert df < 1e-12 * max(1.0, float(np.abs(rA).max())), ("bcs fold", trial, df)
+                d = max(d, df)
+            dV = bh.get_dV_dparam(basis, L, vc)
+        d = max(d, float(np.abs(dV - B.get_dV_dparam(basis, vc.length())).max()))
+        assert d < 1e-9, ("bcs", trial, d)
+        worst_bcs = max(worst_bcs, d)
+        nbcs += 1
+    print("oracle pin campaign, bcs: %d random lattices, the reference's DiagBdG(symm) / DiagGHF(_symm) / bcs.embBasis / bcs_helper folds and "
+          "dV_dparam against restate_bcs.py: worst %.1e" % (nbcs, worst_bcs))
     print("oracle pin campaign ok: %d random cases against the reference itself in %.0f s (%d without a gap at the Fermi level skipped), worst: "
           "HF %.1e, bath projector %.1e, ERI %.1e (relative)" % (trials, time.time() - t0, skipped, worst["hf"], worst["bath"], worst["eri"]))
 
