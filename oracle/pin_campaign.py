@@ -328,6 +328,93 @@ def main():
         nbcs += 1
     print("oracle pin campaign, bcs: %d random lattices, the reference's DiagBdG(symm) / DiagGHF(_symm) / bcs.embBasis / bcs_helper folds and "
           "dV_dparam against restate_bcs.py: worst %.1e" % (nbcs, worst_bcs))
+    # ---- GSO twins and the cderi layout: the reference's spinless.get_emb_basis / get_emb_eri_gso against oracle/restate_gso.py, its
+    #      transform_gdf_to_lo (writer) and sr_loop (reader) against oracle/restate_cderi.py ----
+    from oracle import restate_gso as G
+    from oracle import restate_cderi as Cd
+    from libdmet.routine import spinless
+    worst_gso, worst_cd, ngso = 0.0, 0.0, 0
+    for trial in range(max(1, trials // 3)):
+        mesh = tuple(int(x) for x in rng.choice([1, 2, 3], size=3, p=[0.5, 0.35, 0.15]))
+        nk = int(np.prod(mesh))
+        if nk < 2 or nk > 9:
+            mesh, nk = (2, 2, 1), 4
+        # bath of a generalised density
+        n = int(rng.integers(2, 7))
+        lo = int(rng.integers(0, n))
+        val = list(range(lo, int(rng.integers(lo, n)) + 1))
+        FRb = synth.make_fock_R(mesh, n, spin=2, seed=int(rng.integers(1, 1 << 30)))
+        vb_ = rng.standard_normal((3, n, n)) * 0.2
+        vb_[0], vb_[1] = 0.5 * (vb_[0] + vb_[0].T), 0.5 * (vb_[1] + vb_[1].T)
+        ewo, evo = B.DiagBdG(synth.fold_R2k(FRb, mesh), vb_, float(rng.uniform(-0.3, 0.3)))
+        GRho = R.FFTtoT(np.einsum("kpm,km,kqm->kpq", evo, (ewo < 0).astype(float), evo.conj()), mesh).real
+        Lg = GG._duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        imp = val + [i for i in range(n) if i > max(val)]
+        for vbath in (True, False):
+            try:
+                ref, sigma, w = G.get_emb_basis_gso(GRho, n, val, imp, valence_bath=vbath)
+            except AssertionError:
+                continue                                        # odd nbath: the reference refuses as well (spinless.py:113)
+            with contextlib.redirect_stdout(sink):
+                b = spinless.get_emb_basis(Lg, GRho, valence_bath=vbath)
+            assert b.shape == ref.shape, ("gso bath", trial, b.shape, ref.shape)
+            nimp = 2 * len(imp)
+            sg = np.sort(sigma)[::-1]
+            nb = ref.shape[-1] - nimp
+            if nb >= 1 and sg[nb - 1] > 1e-7 and (nb == len(sg) or sg[nb] < 1e-11):
+                a2, r2 = b.reshape(-1, b.shape[-1])[:, nimp:], ref.reshape(-1, ref.shape[-1])[:, nimp:]
+                d = max(min(np.abs(a2[:, j] - r2[:, j]).max(), np.abs(a2[:, j] + r2[:, j]).max()) for j in range(nb))
+                if d > 1e-9:
+                    d = float(np.sqrt(2.0) * np.linalg.norm(r2 - a2 @ (a2.T @ r2)))
+                assert d < 1e-9, ("gso bath", trial, mesh, n, val, vbath, d)
+                worst_gso = max(worst_gso, float(d))
+        # GSO ERI and the cderi layout on a physical DF tensor
+        nao, naux, nemb, sp = int(rng.integers(2, 6)), int(rng.integers(2, 8)), int(rng.integers(2, 8)), int(rng.integers(1, 3))
+        ks2 = rf.make_kpts_scaled(mesh)
+        cell2 = shim.FakeCell(nao)
+        kpts2 = cell2.get_abs_kpts(ks2)
+        W0 = synth.make_W0(mesh, naux, nao, seed=int(rng.integers(1, 1 << 30)))
+        blocks = synth.df_blocks_from_W0(W0, mesh)
+        mydf = shim.FakeGDF(cell2, kpts2, lambda i, j, bb=blocks: bb[i, j], naux=naux, blockdim=max(1, naux // 2 + 1))
+        C = synth.make_C_ao_lo(mesh, nao, nao, spin=sp, seed=int(rng.integers(1, 1000)))
+        Cg = C[0] if sp == 1 else C
+        basis = rng.standard_normal((nk, 2 * nao, nemb))
+        get = lambda i, j: blocks[i, j]
+        for kw in (dict(t_reversal_symm=True), dict(t_reversal_symm=False), dict(symmetry=1), dict(unit_eri=True)):
+            with contextlib.redirect_stdout(sink):
+                e_ref = et.get_emb_eri_gso(cell2, mydf, C_ao_lo=Cg, basis=basis, max_memory=1, **kw)
+            e_or = G.get_emb_eri_gso(mesh, ks2, get, naux, nao, Cg, basis, **kw)
+            d = float(np.abs(np.asarray(e_ref) - np.asarray(e_or)).max()) / max(1.0, float(np.abs(e_ref).max()))
+            assert np.asarray(e_ref).shape == np.asarray(e_or).shape and d < 1e-11, ("gso eri", trial, mesh, nao, naux, nemb, sp, kw, d)
+            worst_gso = max(worst_gso, d)
+        class _H5Mod(object):
+            File = GG._FakeH5
+        et.h5py = _H5Mod
+
+        class _GDF(shim.FakeGDF):
+            def __init__(self, cell_, kpts_, bb=blocks, na=naux):
+                shim.FakeGDF.__init__(self, cell_, kpts_, lambda i, j: bb[i, j], naux=na, blockdim=na)
+                self.kpts_band, self._j_only = None, False
+        mydf2 = _GDF(cell2, kpts2)
+        src = "src_pin_%d_%d.h5" % (seed, trial)
+        GG._FakeH5(src, "w")["j3c-kptij"] = np.asarray([(ki, kpts2[j]) for i, ki in enumerate(kpts2) for j in range(i + 1)])
+        mydf2._cderi = src
+        nlo2 = int(rng.integers(max(1, nao - 1), nao + 1))
+        C2 = synth.make_C_ao_lo(mesh, nao, nlo2, spin=1, seed=int(rng.integers(1, 1000)))[0]
+        for tr in (True, False):
+            dst = "dst_pin_%d_%d_%d.h5" % (seed, trial, tr)
+            with contextlib.redirect_stdout(sink):
+                et.transform_gdf_to_lo(mydf2, C2, fname=dst, t_reversal_symm=tr)
+            f = GG._FakeH5.registry[dst]
+            ref, mask = Cd.transform_gdf_to_lo(get, ks2, kpts2, naux, C2, t_reversal_symm=tr)
+            assert sorted(f.keys()) == sorted(ref.keys()), ("cderi keys", trial, tr, sorted(f.keys()), sorted(ref.keys()))
+            for k in ref:
+                d = float(np.abs(np.asarray(f[k]) - ref[k]).max())
+                assert np.asarray(f[k]).shape == ref[k].shape and d < 1e-12, ("cderi", trial, k, d)
+                worst_cd = max(worst_cd, d)
+        ngso += 1
+    print("oracle pin campaign, gso / cderi: %d random cases, the reference's spinless.get_emb_basis / get_emb_eri_gso against restate_gso.py: worst %.1e; "
+          "its transform_gdf_to_lo against restate_cderi.py: worst %.1e" % (ngso, worst_gso, worst_cd))
     print("oracle pin campaign ok: %d random cases against the reference itself in %.0f s (%d without a gap at the Fermi level skipped), worst: "
           "HF %.1e, bath projector %.1e, ERI %.1e (relative)" % (trials, time.time() - t0, skipped, worst["hf"], worst["bath"], worst["eri"]))
 
