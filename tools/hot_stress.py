@@ -20,15 +20,16 @@ t0, worst, log = time.time(), 0.0, []
 for trial in range(trials):
     while True:
         mesh = [(2, 2, 1), (3, 1, 1), (2, 2, 2), (3, 2, 1), (4, 1, 1), (5, 1, 1)][int(rng.integers(0, 6))]
-        nao = 8 * int(rng.integers(2, 27))
-        naux = int(rng.integers(32, 641))
-        nemb = 256 if rng.random() < 0.33 else int(rng.integers(32, 321))
+        big = os.environ.get('STRESS_BIG') == '1'
+        nao = 8 * int(rng.integers(2, 33 if big else 27))
+        naux = int(rng.integers(32, 1201 if big else 641))
+        nemb = 256 if rng.random() < 0.33 else int(rng.integers(32, 449 if big else 321))
         spin = int(rng.integers(1, 3))
         npair = nemb * (nemb + 1) // 2
         nk = mesh[0] * mesh[1] * mesh[2]
         eri_gb = spin * (spin + 1) // 2 * npair * npair * 8 / 2 ** 30
         half_gflop = nk * naux * nao * nemb * (nao + nemb) * 8e-9 * spin * 2
-        if eri_gb < 40 and half_gflop < 6e3 and naux * nao >= 1024:
+        if eri_gb < (120 if big else 40) and half_gflop < (4e4 if big else 6e3) and naux * nao >= 1024:
             break
     w, by = ES.plan_records(mesh)
     kls = sorted(by)
