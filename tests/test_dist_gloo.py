@@ -46,12 +46,14 @@ def _worker(rank, world, port, out_q):
     td.destroy_process_group()
 
 
-def test_kl_shard_allreduce_world2():
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_kl_shard_allreduce_world2(world):
+    """world 5 > 4 irreducible kL: one rank owns no kL and only takes part in the sums."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
