@@ -225,4 +225,127 @@ __global__ __launch_bounds__(HNT, OCC) void half1p_kernel(const H1Args g) {
 }
 
 
+// LAB ONLY: half1_kernel (one workgroup per tile, the product form) with NONTEMPORAL Ut stores -- the only change.  A workgroup's slot is
+// released when its stores are acknowledged; the question is whether streaming stores shorten that.
+template <bool CONJB, int BM, int OCC, bool NARROW, int LAB = 0>
+__global__ __launch_bounds__(HNT, OCC) void half1nt_kernel(const H1Args g) {
+    constexpr int MI = NARROW ? BM / 64 : BM / 32;       // 16-row blocks per wave
+    constexpr int NJ = NARROW ? 3 : 2;                   // 16-column blocks per wave
+    constexpr int BN = NARROW ? 48 : H1_BN;              // columns of the output tile
+    constexpr int AH = BM / 64;                          // 1 KiB pieces per K row of the A panel
+    constexpr int STAGE = H1_BK * (BM + H1_BN);
+    __shared__ __attribute__((aligned(16))) double2 lds[H1_D * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the LDS-DMA addressing scalar
+    // 2 (M) x 2 (N) waves with wave tile (BM / 2) x 32, or 4 (M) x 1 waves with wave tile (BM / 4) x 48
+    const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
+    const int frag_k = lane >> 4, frag_x = lane & 15;
+
+    const unsigned lid_all = xcd_remap(blockIdx.x, g.nblocks);
+    const int slot = (int)(lid_all / g.per_slot);
+    const unsigned lid = lid_all - (unsigned)slot * g.per_slot;
+    const unsigned per_m = (unsigned)(g.tiles_n * g.nspin);
+    const int tile_m = (int)(lid / per_m);
+    const unsigned rest = lid - (unsigned)tile_m * per_m;
+    const int sp = (int)(rest / (unsigned)g.tiles_n), tile_n = (int)(rest - (unsigned)sp * (unsigned)g.tiles_n);
+    const int n0 = tile_n * BN;
+    const long long nao = g.nao, nemb = g.nemb, mrows = g.mrows;
+    const long long rows_total = (long long)g.nL * mrows;
+    const double2 *const Asl = g.Lpq + (long long)slot * g.a_slot_stride;
+    const double2 *const Bsp = g.Ci + (long long)sp * g.b_spin_stride + (long long)H1_PICK_BK(g, slot) * g.b_k_stride;
+    double2 *const Osp = g.Ut + (long long)sp * g.out_spin_stride + (long long)slot * g.out_slot_stride;
+
+    // ---- LDS-DMA sources: wave w streams K rows 2w, 2w+1 (A: 2 x 1 KiB per row, B: 1 KiB).  Per lane only a loop-invariant byte
+    //      offset from the block's base (one VGPR per piece; a block is <= 512 MB); the K-row part of the address is scalar ----
+    unsigned voffA[AH], voffB;
+#pragma unroll
+    for (int h = 0; h < AH; ++h) {
+        long long r = (long long)tile_m * BM + 64 * h + lane;
+        if (r >= rows_total) r = rows_total - 1;         // clamped lanes only ever feed masked outputs
+        const long long L = r / mrows, q = r - L * mrows;
+        voffA[h] = (unsigned)((L * nao * mrows + q) * 16);
+    }
+    {
+        int col = n0 + lane;
+        if (col >= g.nemb) col = g.nemb - 1;
+        voffB = (unsigned)(col * 16);
+    }
+    auto issue = [&](int t) {
+        double2 *st = lds + (t % H1_D) * STAGE;
+        const int k0 = wave * 2;
+        const long long kg = (long long)t * H1_BK + k0;
+        const double2 *a0 = Asl + kg * mrows, *a1 = a0 + mrows, *b0 = Bsp + kg * nemb, *b1 = b0 + nemb;      // wave-uniform
+        if constexpr (AH == 2) {
+            glds16s_x6(voffA[0], voffA[1], voffB, voffA[0], voffA[1], voffB, a0, a0, b0, a1, a1, b1, lds_addr_of(st + k0 * BM),
+                       lds_addr_of(st + k0 * BM + 64), lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
+                       lds_addr_of(st + (k0 + 1) * BM + 64), lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
+        } else {
+            glds16s_x4(voffA[0], voffB, voffA[0], voffB, a0, b0, a1, b1, lds_addr_of(st + k0 * BM),
+                       lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
+                       lds_addr_of(st + H1_BK * BM + (k0 + 1) * H1_BN));
+        }
+    };
+
+    cacc acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cacc_zero(acc[i][j]);
+
+    const int T = g.nao / H1_BK;
+    issue(0);
+    if (T > 1) issue(1);
+    for (int t = 0; t < T; ++t) {
+        if (t + 1 < T) {                                                     // tile t landed; tile t+1 may be in flight
+            if (AH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr (!(LAB & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (LAB & 2) { if (t + 2 < T && g.nslot < 0) issue(t + 2); }
+        else { if (t + 2 < T) issue(t + 2); }
+        const double2 *Ab = lds + (t % H1_D) * STAGE + wm * (MI * 16) + frag_x;
+        const double2 *Bb = lds + (t % H1_D) * STAGE + H1_BK * BM + wn * 32 + frag_x;
+#pragma unroll
+        for (int kk = 0; kk < H1_BK / 4; ++kk) {
+            cfrag a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = cfrag_of(lds_frag(&Ab[(kk * 4 + frag_k) * BM + i * 16]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                double2 v = lds_frag(&Bb[(kk * 4 + frag_k) * H1_BN + j * 16]);
+                if (CONJB) v.y = -v.y;                  // conj(C_i)
+                b[j] = cfrag_of(v);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) cmfma(acc[i][j], a[i], b[j]);
+        }
+    }
+
+    // ---- epilogue: Ut[L][q][a] = row (L * mrows + q) of one contiguous (nL * mrows) x nemb array ----------------------
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long rr = (long long)tile_m * BM + (wm * MI + i) * 16 + frag_k + 4 * r;
+            if (rr >= rows_total) continue;
+            if constexpr (LAB & 1) { if (g.nslot >= 0) continue; }
+            double2 *row = Osp + rr * nemb;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = n0 + wn * 32 + j * 16 + frag_x;
+                if (col < g.nemb) {
+                    h1_d2_t v;
+                    v.x = cacc_re(acc[i][j], r);
+                    v.y = cacc_im(acc[i][j], r);
+                    __builtin_nontemporal_store(v, reinterpret_cast<h1_d2_t *>(row + col));
+                }
+            }
+        }
+    }
+}
+
+
 }  // namespace

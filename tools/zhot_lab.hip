@@ -76,6 +76,12 @@ int main() {
         printf("   LAB %2d  %8.3f ms  %6.2f TF  (%5.1f %% of 78.6)\n", LABV, ms, f1 / ms * 1e-9, f1 / ms * 1e-9 / 78.6 * 100.0);  \
     }
     RUN1(0) RUN1(1) RUN1(2) RUN1(4) RUN1(3) RUN1(7)
+    {
+        const float ms = time_ms([&] { hipLaunchKernelGGL((half1nt_kernel<true, 128, 2, false, 0>), dim3(a.nblocks), dim3(HNT), 0, 0, a); }, 8);
+        const float ms0 = time_ms([&] { hipLaunchKernelGGL((half1_kernel<true, 128, 2, false, 0>), dim3(a.nblocks), dim3(HNT), 0, 0, a); }, 8);
+        printf("   nontemporal Ut stores (lab copy) %8.3f ms  %6.2f TF  (%5.1f %%)   against the product kernel in the same run %8.3f ms (%5.1f %%)\n", ms,
+               f1 / ms * 1e-9, f1 / ms * 1e-9 / 78.6 * 100.0, ms0, f1 / ms0 * 1e-9 / 78.6 * 100.0);
+    }
     int ncu = 256;
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
     printf("step 1, persistent (half1p_kernel<conj, 128, 2, wide>): %d workgroups walk the same %u tiles\n", 2 * ncu, a.nblocks);
