@@ -15,10 +15,12 @@ rank's share of the irreducible momentum transfers kL + embedding Hamiltonian.
 
   --scaling strong (default): every timed step IS the full config -- all 112 irreducible kL / 12 152 DF blocks of C5 -- sharded
                   over the N ranks by the reference's assign_workload rule: the config the metric is quoted on, at every N
-                  (N = 1: ~54 s per step; N = 8: 14 kL per GPU).  A step that long cannot be repeated 25 times inside the
-                  driver's window, so the number of timed steps is min(K, max(3, floor(--max-timed-s / step seconds))) and the
-                  warm-up is cut the same way (at least one); the line reports the counts that were run ("steps", "warmup")
-                  and the ones asked for ("steps_requested", "warmup_requested").  One extra pass over a 14-kL shard per GPU
+                  (N = 1: ~52 s per step; N = 8: 14 kL per GPU).  --steps K / --warmup W are honoured EXACTLY whenever the whole
+                  run (W + K steps, then the checks, the fit and the CPU baseline) fits --max-total-s (default 1500 s inside
+                  the driver's 1800 s window: 20 + 5 steps of 52 s do); only otherwise the timed steps are cut to
+                  min(K, max(3, floor(--max-timed-s / step seconds))) and the warm-up likewise (at least one).  The line reports
+                  the counts that were run ("steps", "warmup"), the ones asked for and why they differ ("steps_requested",
+                  "warmup_requested", "steps_note": top level AND inside "config").  One extra pass over a 14-kL shard per GPU
                   (the 8-GPU share) is reported under "shard_pass" as a secondary rate.
   --scaling weak: every GPU transforms --kl-per-gpu irreducible kL per step (14 = 112 / 8, so N = 8 is exactly the full C5
                   iteration); after the timed region ONE pass over the full config is reported under "full_config".
@@ -63,6 +65,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD MI355X FP64 matrix spec (= 256 CU x 4 SIM
                                  # measures 78.1 sustained on the box
 HBM_PEAK_GBPS = 8000.0
 PARITY_TOL = 1e-8                # north star: <= 1e-8 max-abs on the transformed ERI
+# where the DF blocks of the timed region come from, stated next to `value` (PCIe note)
+INPUT_NOTE = "device-generated (Philox) inside the timed region; host-fed blocks are PCIe-bound: est. 2.6x the step time at C5"
 
 
 def parse():
@@ -73,7 +77,11 @@ def parse():
     p.add_argument("--workload", default="C5")
     p.add_argument("--scaling", choices=("weak", "strong"), default="strong")
     p.add_argument("--max-timed-s", type=float, default=200.0,
-                   help="cap of the timed region: timed steps = min(--steps, max(3, floor(this / seconds of one step)))")
+                   help="cap of the timed region when the requested counts do not fit --max-total-s: timed steps = "
+                        "min(--steps, max(3, floor(this / seconds of one step)))")
+    p.add_argument("--max-total-s", type=float, default=1500.0,
+                   help="wall-clock this whole process may take (the driver's window is 1800 s): --steps / --warmup are honoured "
+                        "EXACTLY whenever warm-up + timed steps + the checks after them fit it")
     p.add_argument("--parity-seed", type=int, default=-1, help="seed of the sampled embedding orbitals (-1: from the clock)")
     p.add_argument("--no-shard-pass", action="store_true", help="strong scaling: skip the extra 14-kL-per-GPU pass")
     p.add_argument("--kl-per-gpu", type=int, default=14, help="weak scaling: irreducible kL transformed per GPU per step")
@@ -259,6 +267,7 @@ def fetch_rows(eri_dev, spin_pair, npair, idx, table=None):
 
 
 def main():
+    t_process_start = time.perf_counter()
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a.gpus))
@@ -397,9 +406,18 @@ def main():
         fence()
         t_w = max_over_ranks(time.perf_counter() - tw0)
         if not model:
-            # a whole-config step at N = 1 takes ~54 s: K = 20 of them do not fit the driver's window (see the module docstring)
-            nsteps = min(a.steps, max(3, int(a.max_timed_s // max(t_w, 1e-6))))
-            nwarm = min(a.warmup, max(1, int(0.3 * a.max_timed_s // max(t_w, 1e-6))))
+            # A whole-config step at N = 1 takes ~52 s.  The counts asked for are honoured EXACTLY whenever the rest of the
+            # warm-up, the timed steps and what follows them (shard pass, oracle checks within --parity-budget-s, fit, CPU
+            # baseline) fit --max-total-s; only otherwise are they cut to what fits --max-timed-s (never below 3 + 1)
+            after = 0.0 if a.no_parity else min(a.parity_budget_s, 130.0) + 20.0
+            after += (0.0 if a.no_cpu_baseline else a.cpu_seconds + 5.0) + (10.0 if a.fit_iters > 0 else 0.0) + 0.2 * t_w + 30.0
+            left = a.max_total_s - (time.perf_counter() - t_process_start) - after
+            if (a.steps + a.warmup - 1) * t_w * 1.03 > left:
+                nsteps = min(a.steps, max(3, int(a.max_timed_s // max(t_w, 1e-6))))
+                nwarm = min(a.warmup, max(1, int(0.3 * a.max_timed_s // max(t_w, 1e-6))))
+            if distributed:          # every rank must run the same counts
+                c = dist.all_reduce_sum_numpy(np.array([float(nsteps), float(nwarm)]) * (1.0 if rank == 0 else 0.0))
+                nsteps, nwarm = int(round(c[0])), int(round(c[1]))
         for _ in range(nwarm - 1):
             out = step({}, kl_mine)
     fence()
@@ -662,26 +680,30 @@ def main():
                           "frac_of_hbm_peak": round(by / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
         if fresh:
             # measured HBM bytes of the same stages (rocprofv3 PMC, profiles/traffic_latest.json): traffic / algorithmic = re-reads
-            fam_bytes = lambda *ks: sum(tinfo.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in ks)
+            # per STEP: a family's bytes per launch x its launches per step of the profiled run (older files: one launch per step)
+            fam_bytes = lambda *ks: sum(tinfo.get(k, {}).get("hbm_bytes_per_step", tinfo.get(k, {}).get("hbm_bytes_per_launch", 0.0))
+                                        for k in ks)
+            fam_launch_bytes = lambda *ks: sum(tinfo.get(k, {}).get("hbm_bytes_per_launch", 0.0) for k in ks)
             eb = fam_bytes("eigh_tridiag", "eigh_tripairs", "eigh", "eigh_tfactor", "eigh_backtransform")
             if "eigh" in hbm and eb > 0:
                 hbm["eigh"]["pmc_traffic_GB_per_step"] = round(eb / 1e9, 3)
                 hbm["eigh"]["pmc_over_algorithmic"] = round(eb / alg["eigh"], 2)
-            fb = fam_bytes("fold_k2R")
+            fb = fam_launch_bytes("fold_k2R")
             if "fold" in hbm and fb > 0:
                 hbm["fold"]["k2R_pmc_traffic_GB_per_launch"] = round(fb / 1e9, 3)
                 hbm["fold"]["k2R_algorithmic_GB_per_launch"] = round((16.0 + 8.0) * spin * nk * n * n / 1e9, 3)
         roofline["hbm_stages"] = hbm
         n_mine = len(kl_mine)
+        steps_note = "as requested" if (a.steps, a.warmup) == (a.steps_requested, a.warmup_requested) else \
+            "cut: %.0f s/step x (%d + %d) does not fit --max-total-s %g" % (elapsed / a.steps, a.steps_requested,
+                                                                            a.warmup_requested, a.max_total_s)
         res = {
             "metric": "DMET embedding-construction iteration (diag+bath+ERI-transform): ERI-transform algorithmic TFLOP/s over the whole step",
             "value": round(flops_all / elapsed / 1e12, 3),
             "unit": "TFLOP/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "steps_requested": a.steps_requested, "warmup_requested": a.warmup_requested,
-            "steps_note": None if (a.steps, a.warmup) == (a.steps_requested, a.warmup_requested) else
-                          "one step of this workload on %d GPU(s) takes %.1f s: timed steps = min(K, max(3, floor(%g s / step))), warm-up "
-                          "cut likewise (--max-timed-s)" % (world, elapsed / a.steps, a.max_timed_s),
+            "steps_note": steps_note, "input": INPUT_NOTE,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "vs_baseline_note": "null by contract: the reference publishes no number for this metric (BASELINE.md section 1); "
@@ -696,6 +718,8 @@ def main():
                                       ("; the timed step IS the whole config" if timed_is_full else "")),
                        "scaling_note": "strong: every timed step is the WHOLE config sharded over the ranks" if a.scaling == "strong"
                                        else "weak: --kl-per-gpu irreducible kL per GPU per step",
+                       "steps_requested": a.steps_requested, "warmup_requested": a.warmup_requested, "steps_note": steps_note,
+                       "input": INPUT_NOTE,
                        "parallelism": "kL-sharded x%d, k-sharded diag, all-reduce(ew) + all-reduce(rho_R); ERI: K-stacked contraction finished "
                                       "band by band, every finished band of rows reduced to its owner underneath the remaining GEMMs "
                                       "(row-sharded sum), all-reduce of the n x n J / K only" % world},

@@ -15,7 +15,11 @@ The DF tensor is served by a *block provider* instead of PySCF's `_load3c` on an
 (eri_transform.py:195-227): any object with `.kpts` (nk,3 absolute), `.naux` and
 `load_block(ctx, i, j, out_dev)` (fills a device (naux,nao,nao) c128 buffer with L^{(ki,kj)}).
 `GDFMemory` wraps host arrays / callables, `GDFPhilox` is the procedural synthetic tensor of
-SURVEY.md section 8d generated on the device.
+SURVEY.md section 8d generated on the device.  What the REFERENCE hands these entry points -- a
+`pyscf.pbc.df.GDF` object, i.e. something with `kpts`, `cell`, `blockdim`, `max_memory` and `_cderi` (the
+path of an HDF5 file, or an open container) and no provider methods -- is adapted by `resolve_df`:
+`CderiProvider` over the container (a path is opened with a lazily imported h5py), `feri` honoured like
+eri_transform.py:260-261.
 """
 import ctypes as C
 import os
@@ -118,6 +122,12 @@ class CderiProvider(object):
         for p, (ki, kj) in enumerate(kptij):
             self.pair_of[(find(ki), find(kj))] = p
         self.naux = max(self._pair_rows(p) for p in range(len(kptij)))
+        self._owned = None                            # a file resolve_df opened for this provider (closed by close())
+
+    def close(self):
+        f, self._owned = self._owned, None
+        if f is not None and hasattr(f, "close"):
+            f.close()
 
     def _get(self, key):
         f = self.feri
@@ -237,12 +247,21 @@ def transform_gdf_to_lo(mydf, C_ao_lo, fname=None, t_reversal_symm=True, cell=No
     time-reversed partner pair written as the conjugate.  The two products per pair run on the device
     (dmk_zgemm_batched over the auxiliary index).  Returns a CderiProvider over a dict (also saved to `fname` as .npz).
     """
+    cell = cell if cell is not None else getattr(mydf, "cell", None)
+    given = mydf
+    mydf = resolve_df(cell, given)
+    try:
+        return _transform_gdf_to_lo(mydf, C_ao_lo, fname, t_reversal_symm, cell)
+    finally:
+        _release_df(mydf, given)
+
+
+def _transform_gdf_to_lo(mydf, C_ao_lo, fname, t_reversal_symm, cell):
     ctx = get_ctx()
     C_ao_lo = np.asarray(C_ao_lo)
     nkpts, nao, nlo = C_ao_lo.shape
     kpts = np.asarray(mydf.kpts)
     assert nkpts == len(kpts)
-    cell = cell if cell is not None else getattr(mydf, "cell", None)
     naux = int(mydf.naux)
     kptij_lst = np.asarray([(kpts[i], kpts[j]) for i in range(nkpts) for j in range(i + 1)])
     pair_ij = [(i, j) for i in range(nkpts) for j in range(i + 1)]
@@ -299,6 +318,93 @@ def _is_provider(mydf):
     return hasattr(mydf, "load_block") and hasattr(mydf, "kpts")
 
 
+_NOT_GDF = ("MDF", "FFTDF", "AFTDF")      # the reference dispatches these to drivers that need PySCF grids (eri_transform.py:72-93)
+
+
+def _df_kind(mydf):
+    """'MDF' / 'FFTDF' / 'AFTDF' when the object's class (or a base) carries one of PySCF's other DF class names, else None.
+    The reference tests isinstance(mydf, df.MDF) BEFORE df.GDF because MDF derives from GDF (eri_transform.py:72-75)."""
+    names = [c.__name__ for c in type(mydf).__mro__]
+    for kind in _NOT_GDF:
+        if kind in names:
+            return kind
+    return None
+
+
+def _open_cderi(cderi):
+    """(container, file to close or None) for what a GDF object keeps in `_cderi`: a mapping with the HDF5 layout is used as
+    is, a path is opened read-only with h5py -- imported here, lazily: the GPU box of this build has no h5py, a user's has."""
+    if isinstance(cderi, (str, bytes, os.PathLike)):
+        path = os.fsdecode(cderi)
+        if path.endswith(".npz"):                     # the layout saved by transform_gdf_to_lo on a box without h5py
+            z = np.load(path)
+            return z, z
+        try:
+            import h5py
+        except ImportError:
+            raise NotImplementedError("HDF5 cderi files need h5py: pass a CderiProvider over the opened file / a mapping")
+        f = h5py.File(path, "r")
+        return f, f
+    if isinstance(cderi, np.ndarray):
+        raise NotImplementedError("an in-core cderi ndarray has no k-point pair table: pass GDFMemory(kpts, blocks)")
+    if hasattr(cderi, "__getitem__"):
+        return cderi, None
+    raise ValueError("Unknown DF type for embedding ERI construction.")
+
+
+def resolve_df(cell, mydf, feri=None, kpts=None):
+    """The block provider behind whatever the reference's callers pass as `mydf` (eri_transform.py:68-94 dispatch, :159-227
+    readers, :260-261 `feri`).
+
+      * a provider (`load_block` + `kpts`: GDFMemory, GDFPhilox, CderiProvider, a user's own) is returned as is;
+      * a GDF-shaped object -- `_cderi`, `kpts`, no provider methods, e.g. pyscf.pbc.df.GDF -- is wrapped in a
+        CderiProvider over its container; like the reference, `feri` only stands in while `mydf._cderi` is None
+        (and is stored there), and a GDF that has neither is asked to `build()` (sr_loop, :197-198);
+      * a bare container / path with `kpts` given is the MPI twin's (cell, cderi, kpts) form (eri_transform_mpi.py:57-62,
+        80-81);
+      * PySCF's MDF / FFTDF / AFTDF objects have their own drivers in the reference, outside this path: NotImplementedError;
+        anything else: the reference's ValueError("Unknown DF type ...").
+    A file this function opened is closed by `provider.close()` (the drivers do that when they are done)."""
+    if _is_provider(mydf):
+        return mydf
+    kind = _df_kind(mydf)
+    if kind is not None:
+        raise NotImplementedError("%s objects go through get_emb_eri_fast_%s in the reference (PySCF grids): outside the HIP "
+                                  "path, which covers Gaussian density fitting" % (kind, kind.lower().replace("df", "") or "fft"))
+    if hasattr(mydf, "_cderi") and hasattr(mydf, "kpts"):
+        if mydf._cderi is None and feri is not None:
+            mydf._cderi = feri                                        # eri_transform.py:260-261
+        if mydf._cderi is None and hasattr(mydf, "build"):
+            mydf.build()                                              # sr_loop, eri_transform.py:197-198
+        if mydf._cderi is None:
+            raise ValueError("the DF object has no _cderi and no feri was given")
+        cderi, kpts = mydf._cderi, mydf.kpts
+        cell = cell if cell is not None else getattr(mydf, "cell", None)
+    elif kpts is not None and not hasattr(mydf, "kpts"):
+        cderi = mydf
+    else:
+        raise ValueError("Unknown DF type for embedding ERI construction.")
+    if getattr(cell, "dimension", 3) == 2 and getattr(cell, "low_dim_ft_type", None) != "inf_vacuum":
+        raise NotImplementedError                                     # sr_loop, eri_transform.py:226-227
+    container, owned = _open_cderi(cderi)
+    try:
+        prov = CderiProvider(container, kpts, int(cell.nao_nr()), cell=cell)
+    except Exception:
+        if owned is not None and hasattr(owned, "close"):
+            owned.close()
+        raise
+    prov._owned = owned
+    prov.blockdim = getattr(mydf, "blockdim", 240)
+    prov.max_memory = getattr(mydf, "max_memory", 2000)
+    return prov
+
+
+def _release_df(prov, mydf):
+    """Close what resolve_df opened for `mydf` (nothing when the caller's own provider was used)."""
+    if prov is not mydf and hasattr(prov, "close"):
+        prov.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # small helpers with reference names
 # ---------------------------------------------------------------------------------------------
@@ -306,21 +412,21 @@ def _is_provider(mydf):
 def _as_cderi_provider(gdf):
     if isinstance(gdf, CderiProvider) or hasattr(gdf, "get_block"):
         return gdf
-    cderi = getattr(gdf, "_cderi", None)
-    if cderi is None or isinstance(cderi, str):
-        raise NotImplementedError("HDF5 cderi files need h5py: pass a CderiProvider over the opened file / a mapping")
-    return CderiProvider(cderi, gdf.kpts, gdf.cell.nao_nr(), cell=gdf.cell)
+    return resolve_df(getattr(gdf, "cell", None), gdf)
 
 
 def get_naoaux(gdf):
     """The maximum dimension of the auxiliary basis over the stored k-point pairs (eri_transform.py:159-193)."""
     prov = _as_cderi_provider(gdf)
-    if isinstance(prov, CderiProvider):
-        rows = [prov._pair_rows(p) for p in range(len(prov.kptij))]
-        if len(np.unique(rows)) != 1:
-            log.warn("aux basis drop may happened.")
-        return int(max(rows))
-    return int(prov.naux)
+    try:
+        if isinstance(prov, CderiProvider):
+            rows = [prov._pair_rows(p) for p in range(len(prov.kptij))]
+            if len(np.unique(rows)) != 1:
+                log.warn("aux basis drop may happened.")
+            return int(max(rows))
+        return int(prov.naux)
+    finally:
+        _release_df(prov, gdf)
 
 
 def sr_loop(gdf, kpti_kptj=np.zeros((2, 3)), max_memory=2000, compact=True, blksize=None):
@@ -332,6 +438,7 @@ def sr_loop(gdf, kpti_kptj=np.zeros((2, 3)), max_memory=2000, compact=True, blks
     find = lambda k: int(np.where(np.abs(kpts - k[None]).max(axis=1) < KPT_DIFF_TOL)[0][0])
     i, j = find(kpti), find(kptj)
     L = np.asarray(prov.get_block(i, j))
+    _release_df(prov, gdf)
     nao = L.shape[-1]
     L = L.reshape(L.shape[0], nao, nao)
     same = np.abs(kpti - kptj).max() < KPT_DIFF_TOL
@@ -886,8 +993,18 @@ def get_emb_eri(cell, mydf, C_ao_lo=None, basis=None, unit_eri=False, symmetry=4
                 max_memory=None, swap_idx=None, feri=None, kscaled_center=None, kconserv_tol=KPT_DIFF_TOL,
                 incore=True, fout="H2.h5", **kwargs):
     """Embedding ERIs with density fitting (see the reference docstring, eri_transform.py:44-67)."""
-    if not _is_provider(mydf):
-        raise ValueError("Unknown DF type for embedding ERI construction.")
+    kind = _df_kind(mydf)
+    if kind is not None or not (_is_provider(mydf) or (hasattr(mydf, "_cderi") and hasattr(mydf, "kpts"))):
+        resolve_df(cell, mydf, feri=feri)              # raises what the dispatch of eri_transform.py:72-90 has to raise
+    if kwargs.get("use_mpi", False) and not _is_provider(mydf):
+        # the reference's hand-over to the MPI twin (eri_transform.py:76-87): the container, not the object, crosses
+        from libdmet_preview_amd.basis_transform import eri_transform_mpi
+        if feri is None:
+            feri = mydf._cderi
+        return eri_transform_mpi.get_emb_eri_fast_gdf(mydf.cell, feri, kpts=mydf.kpts, C_ao_lo=C_ao_lo, basis=basis, feri=feri,
+                                                      kscaled_center=kscaled_center, symmetry=symmetry, max_memory=max_memory,
+                                                      kconserv_tol=kconserv_tol, unit_eri=unit_eri, swap_idx=swap_idx,
+                                                      t_reversal_symm=t_reversal_symm, incore=incore, fout=fout)
     return get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=C_ao_lo, basis=basis, feri=feri, kscaled_center=kscaled_center,
                                 symmetry=symmetry, max_memory=max_memory, kconserv_tol=kconserv_tol,
                                 unit_eri=unit_eri, swap_idx=swap_idx, t_reversal_symm=t_reversal_symm,
@@ -917,6 +1034,17 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
     """
     if not t_reversal_symm and not incore:
         raise NotImplementedError
+    given = mydf
+    mydf = resolve_df(cell, given, feri=feri)          # a pyscf-style GDF object -> CderiProvider over its _cderi (or feri)
+    try:
+        return _emb_eri_fast_gdf(cell, mydf, C_ao_lo, basis, kscaled_center, symmetry, C_ao_eo, kconserv_tol, unit_eri,
+                                 t_reversal_symm, incore, fout, use_mpi)
+    finally:
+        _release_df(mydf, given)
+
+
+def _emb_eri_fast_gdf(cell, mydf, C_ao_lo, basis, kscaled_center, symmetry, C_ao_eo, kconserv_tol, unit_eri, t_reversal_symm,
+                      incore, fout, use_mpi):
     ctx = get_ctx()
     nao = int(cell.nao_nr())
     kpts = mydf.kpts
@@ -1054,6 +1182,15 @@ def get_emb_eri_gso(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscaled_cen
         raise NotImplementedError("out-of-core GSO ERI is outside the HIP path")
     if basis_k is not None:
         raise NotImplementedError("pass the R-space basis; basis_k input is outside the HIP path")
+    given = mydf
+    mydf = resolve_df(cell, given, feri=feri)          # eri_transform.py:1127-1130: same `_cderi` / `feri` rule as the GDF driver
+    try:
+        return _emb_eri_gso(cell, mydf, C_ao_lo, basis, kscaled_center, symmetry, kconserv_tol, unit_eri, t_reversal_symm)
+    finally:
+        _release_df(mydf, given)
+
+
+def _emb_eri_gso(cell, mydf, C_ao_lo, basis, kscaled_center, symmetry, kconserv_tol, unit_eri, t_reversal_symm):
     ctx = get_ctx()
     nao = int(cell.nao_nr())
     kpts = mydf.kpts

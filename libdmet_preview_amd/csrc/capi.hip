@@ -24,14 +24,13 @@ int dmk_fail(dmk_ctx *ctx, int code, const char *fmt, ...) {
 
 static thread_local std::string g_noctx_err;
 
-FamScope::FamScope(dmk_ctx *c, int f, hipStream_t stream) : FamScope(c, f) {
-    // the delegated constructor recorded `a` on ctx->stream; a launch on another stream needs its events there
-    if (ctx && stream != ctx->stream) {
-        on = stream; on_set = true;
-        if (a) (void)hipEventRecord(a, stream);
-    }
+// `a` is recorded exactly once, on the stream the launch goes to (ctx->stream unless the caller names another one)
+FamScope::FamScope(dmk_ctx *c, int f, hipStream_t stream) : ctx(c), fam(f), on(stream) {
+    on_set = ctx && stream != ctx->stream;
+    begin();
 }
-FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f), on(nullptr) {
+FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f), on(nullptr) { begin(); }
+void FamScope::begin() {
     if (ctx && ctx->profile) {
         auto get = [&]() {
             hipEvent_t e;
@@ -40,7 +39,7 @@ FamScope::FamScope(dmk_ctx *c, int f) : ctx(c), fam(f), on(nullptr) {
             return e;
         };
         a = get(); b = get();
-        if (a) (void)hipEventRecord(a, ctx->stream);
+        if (a) (void)hipEventRecord(a, on_set ? on : ctx->stream);
     }
     if (ctx) ctx->fam_launches[fam] += 1;
 }

@@ -80,6 +80,7 @@ struct FamScope {
     FamScope(dmk_ctx *c, int f);
     FamScope(dmk_ctx *c, int f, hipStream_t stream);
     ~FamScope();
+    void begin();
     // flop this launch issues to the f64 matrix pipe (executed, not algorithmic: 3M complex products, padded tiles,
     // the lower tile triangle of a symmetric contraction); read back by dmk_profile_read_flops
     void mfma_flops(double f) { if (ctx) ctx->fam_mfma_flops[fam] += f; }

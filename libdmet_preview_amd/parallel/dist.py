@@ -73,6 +73,35 @@ def all_reduce_sum_dev(dev_array):
     return dev_array
 
 
+def broadcast_dev(dev_array, src=0):
+    """Overwrite a libdmetk device array on every rank with rank `src`'s copy (RCCL: zero-copy view; gloo: through the host)."""
+    if not is_initialized() or world_size() == 1:
+        return dev_array
+    import torch
+    td = _td()
+    if td.get_backend() == "nccl":
+        order_after_library(dev_array.ctx)
+        td.broadcast(tensor_view(dev_array).view(-1), src=src)
+        order_library_after_current(dev_array.ctx)
+    else:
+        t = torch.from_numpy(dev_array.get())
+        td.broadcast(t, src=src)
+        dev_array.set(t.numpy())
+    return dev_array
+
+
+def broadcast_numpy(x, src=0):
+    """Rank `src`'s host array on every rank (same shape / dtype everywhere)."""
+    if not is_initialized() or world_size() == 1:
+        return x
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(x).copy())
+    if _td().get_backend() == "nccl":
+        t = t.cuda()
+    _td().broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
 class _CudaArrayInterface(object):
     def __init__(self, ptr, shape, typestr):
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),

@@ -34,7 +34,11 @@ _FUNCTIONS = [
     ("routine.slater", ["routine.slater"],
      ["get_emb_basis", "embBasis", "get_emb_Ham", "embHam", "transform_h1", "foldRho", "foldRho_k", "get_veff",
       "get_dV_dparam", "FitVcorEmb", "FitVcorFull", "FitVcorTwoStep"]),
-    # the ERI transform; routine/slater.py:32-33 holds its own copy
+    # the ERI transform; routine/slater.py:32-33 holds its own copy.  The rebound functions take the reference's own
+    # argument -- a pyscf.pbc.df.GDF object (`_cderi` path / container, `kpts`, `cell`) -- and adapt it themselves
+    # (eri_transform.resolve_df); `use_mpi=True` goes to this package's eri_transform_mpi twin with the reference's
+    # (cell, cderi, kpts=...) hand-over (eri_transform.py:76-87), so libdmet.basis_transform.eri_transform_mpi (which needs
+    # mpi4pyscf to import at all) is never touched
     ("basis_transform.eri_transform", ["basis_transform.eri_transform", "basis_transform", "routine.slater"],
      ["get_emb_eri", "get_unit_eri"]),
     # spinless.py:518-538 imports get_emb_eri_gso lazily from the module; cderi layout helpers

@@ -72,6 +72,31 @@ def bath_svd_dev(ctx, kmesh, nlo, d_rdm1_s, d_env, nenv, d_col, nb):
     return d_sigma, d_U
 
 
+def orthonormal_completion(U, keep, null):
+    """Overwrite the columns `null` of U (nenv, nb) in place with unit vectors orthogonal to the columns `keep` and to each other
+    (host numpy; see complete_null_columns)."""
+    nenv = U.shape[0]
+    Q = U[:, keep].copy()
+    if Q.shape[1] + len(null) > nenv:
+        raise ValueError("complete_null_columns: %d kept + %d null columns do not fit %d environment rows"
+                         % (Q.shape[1], len(null), nenv))
+    for j in null:
+        # the unit vector that is furthest from span(Q): its residual norm^2 is 1 - |Q^T e_i|^2 = 1 - sum_c Q[i, c]^2, and the
+        # largest of them is >= (nenv - rank Q) / nenv > 0 -- no threshold to miss, no index to run past
+        resid = 1.0 - (Q * Q).sum(axis=1)
+        i = int(np.argmax(resid))
+        e = np.zeros(nenv)
+        e[i] = 1.0
+        for _ in range(2):
+            e -= Q @ (Q.T @ e)
+        nrm = float(np.linalg.norm(e))
+        if not nrm > 1e-8:
+            raise ValueError("complete_null_columns: no direction left outside the kept columns (residual %.1e)" % nrm)
+        U[:, j] = e / nrm
+        Q = np.concatenate([Q, U[:, j:j + 1]], axis=1)
+    return U
+
+
 def complete_null_columns(ctx, sigma, d_U, nenv, nb, ncheck=None):
     """Where the reference keeps left singular vectors whatever their singular value -- every column in routine/bcs.py:46, 84, the first
     `nbath` columns when the caller fixes `nbath` (routine/slater.py:177-186, with its "Zero singular value exists" warning) --
@@ -87,21 +112,7 @@ def complete_null_columns(ctx, sigma, d_U, nenv, nb, ncheck=None):
     if not null or nenv < nb:
         return
     U = d_U.get().reshape(nenv, nb)
-    keep = [j for j in range(ncheck) if j not in null]
-    Q = U[:, keep].copy()
-    nxt = 0
-    for j in null:
-        while True:
-            e = np.zeros(nenv)
-            e[nxt] = 1.0
-            nxt += 1
-            for _ in range(2):
-                e -= Q @ (Q.T @ e)
-            nrm = np.linalg.norm(e)
-            if nrm > 0.5 or nxt >= nenv:
-                break
-        U[:, j] = e / nrm
-        Q = np.concatenate([Q, U[:, j:j + 1]], axis=1)
+    orthonormal_completion(U, [j for j in range(ncheck) if j not in null], null)
     ctx.check(lib.dmk_memcpy_h2d(ctx.h, d_U.ptr, np.ascontiguousarray(U).ctypes.data, U.nbytes))
 
 
@@ -467,7 +478,7 @@ class EmbFitDevice(object):
     (ftsystem.py:151-213) are the same expression with different K."""
 
     def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, fock_k, ovlp_k, mu0=None,
-                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi", shard=True):
+                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi", shard=False):
         from libdmet_preview_amd.routine import mfd
         self._mfd = mfd
         self.ctx, self.vcor = ctx, vcor
@@ -499,7 +510,10 @@ class EmbFitDevice(object):
                 ctx.check(lib.dmk_ewise_mul(ctx.h, 1, nb, nb, d_V.ptr, d_sc.ptr, d_T.ptr))          # rows v_m / sqrt(w_m)
                 ctx.check(lib.dmk_dgemm_batched(ctx.h, 1, 0, nb, nb, nb, 1, 1.0, d_V.ptr, nb, nb * nb, d_T.ptr, nb, nb * nb,
                                                 0.0, self.d_X.offset(s * nb * nb, (nb, nb)).ptr, nb, nb * nb))
-        # Rank-sharded table: rank r holds the rows [p_lo, p_hi) of dV_dparam (1.68 GB / N at C5), contracts its slice in both
+        # Rank-sharded table, OPT-IN (`shard=True`; the reference's FitVcorEmb is purely local and so is the default here: a
+        # driver that fits on one rank and broadcasts the result must not find a collective inside).  With `shard=True` every
+        # evaluation is a COLLECTIVE -- all ranks of the process group have to run the same fit.
+        # Rank r holds the rows [p_lo, p_hi) of dV_dparam (1.68 GB / N at C5), contracts its slice in both
         # table passes and the small results are summed over ranks -- V_emb (spin x npair) after the column pass, the
         # gradient slices after the row pass.  Everything else (eigh of nemb x nemb, densities) is replicated and, being
         # deterministic on identical inputs, stays bit-identical across ranks.  The reference shards the gradient of its lattice
@@ -535,6 +549,13 @@ class EmbFitDevice(object):
         self.d_rfit, self.d_drho, self.d_ss = e(spin, nidx, nidx), e(spin, nidx, nidx), e(1)
         self.d_C, self.d_M1, self.d_K = e(spin, nb, nidx), e(spin, nb, nidx), e(spin, nb, nb)
         self.d_dw, self.d_grad = e(spin, self.npair), e(max(self.nloc, 1))
+        if self._dist is not None:
+            # lock-step by construction: the optimiser's decisions depend on f and the gradient only, which are deterministic
+            # functions of (embH1, X, target, summed V_emb) -- so rank 0's copies of those inputs replace every rank's own (a
+            # density that differs in the last bits between ranks could otherwise end a line search one evaluation apart and
+            # leave a rank waiting in an all-reduce)
+            for d in (self.d_H1, self.d_target) + ((self.d_X,) if self.d_X is not None else ()):
+                self._dist.broadcast_dev(d, src=0)
         self._key, self._state = None, None
         self.nfev = self.ngev = 0
         # eigensolver: "jacobi" (multi-CU, warm started: latency) or "ql" (batched Householder + QL); DMK_FIT_EIGH overrides
@@ -737,6 +758,9 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
     |rho_emb[vcor] - rho|_F / sqrt(spin) over the vcor parameters with an analytic gradient.
 
     Kwargs: ytol, gtol, dx_tol, method, mu0, fix_mu, num_grad, remove_diag_grad, nelec, tol_deg, vcor_mat.
+    `shard=True` (default False: local, like the reference) shards the dV_dparam table over the ranks of an initialised
+    torch.distributed group and makes the call COLLECTIVE: every rank must call it; rank 0's inputs (embedded Hamiltonian,
+    target density, starting parameters) are broadcast so that all ranks take identical optimiser decisions.
     Returns (vcor, err_begin, err_end).
     """
     for k in ("idem_fit", "P_act", "C_act", "use_drho_dparam", "return_drho_dparam", "test_grad"):
@@ -778,7 +802,9 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
     fit = EmbFitDevice(ctx, np.asarray(rho), lattice, basis, vcor, beta, nelec, imp_idx, det_idx, fock_k,
                        lattice.get_ovlp(kspace=True), mu0=kwargs.get("mu0", None), fix_mu=kwargs.get("fix_mu", False),
                        tol_deg=kwargs.get("tol_deg", 1e-3), remove_diag_grad=kwargs.get("remove_diag_grad", False),
-                       eigh=kwargs.get("eigh", "jacobi"))
+                       eigh=kwargs.get("eigh", "jacobi"), shard=bool(kwargs.pop("shard", False)))
+    if fit._dist is not None:
+        vcor.update(fit._dist.broadcast_numpy(np.asarray(vcor.param, dtype=np.float64), src=0))
     errfunc, gradfunc = fit.errfunc, fit.gradfunc
     err_begin = errfunc(vcor.param)
     if beta == np.inf:

@@ -109,6 +109,112 @@ def test_ranks_on_one_gpu_match_single_process(workload, over, world, exchange):
     assert np.array_equal(res[0]["eri"], res[1]["eri"])                   # both ranks hold the same sum
 
 
+def _run_light(workload, dist_on, rank=0, world=1, over=None, rows=48, seed=5):
+    """Like _run for FULL-SIZE configs: instead of the whole ERI (C4: 694 MB per rank through a queue) the result carries
+    `rows` sampled pair rows assembled from their owners and eri x for a seeded vector x (every row and column takes part),
+    plus rho_R, the bath projector diagonal, H1, the kL shard, the per-stage seconds and the bytes this rank put on the wire."""
+    from libdmet_preview_amd import _lib, pipeline
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    from libdmet_preview_amd.parallel import dist
+    ctx = _lib.Context(0)
+    _lib.set_ctx(ctx)
+    sysm = pipeline.SyntheticSystem.from_workload(ctx, workload, **(over or {}))
+    kl = et.assign_workload(sysm.mesh, world)[rank] if dist_on else None
+    out = pipeline.iteration(ctx, sysm, kL_list=kl, emb_ham=True, eri_exchange="row_sharded" if dist_on else "none")
+    ctx.sync()
+    n, nk, spin, nemb = sysm.nlo, sysm.nk, sysm.spin, out["nemb"]
+    npair, spin_pair = nemb * (nemb + 1) // 2, spin * (spin + 1) // 2
+    rng = np.random.default_rng(seed)
+    pick = np.sort(rng.choice(npair, size=rows, replace=False))
+    x = rng.uniform(-1.0, 1.0, npair)
+    y = et.eri_times_vector_dev(ctx, out["eri"], spin_pair, npair, ctx.to_device(x)).get()
+    table = out.get("eri_rows")
+    sent = 0
+    if table is not None:
+        keep = np.zeros_like(y)
+        for (lo, hi) in dist.owned_ranges(table):
+            keep[:, lo:hi] = y[:, lo:hi]
+        y = dist.all_reduce_sum_numpy(keep)
+        got = dist.gather_rows_numpy(out["eri"], spin_pair, npair, [int(r) for r in pick], table)
+        # bytes this rank contributes to the exchanges of a step: its partial of every ERI row band it does not own (reduce to
+        # the owner), rho_R and the eigenvalue table (all-reduce), the n x n J / K partials
+        sent = sum((hi - lo) for (lo, hi, o) in table if o != rank) * npair * 8 * spin_pair
+        sent += spin * nk * n * n * 8 + spin * nk * n * 8 + 3 * spin * nemb * nemb * 8
+    else:
+        got = np.stack([np.stack([out["eri"].offset((b * npair + int(r)) * npair, (npair,)).get() for r in pick])
+                        for b in range(spin_pair)])
+    B = out["basis"].get().reshape(spin, nk * n, nemb)
+    return {"rows": got, "eri_x": y, "rho_R": out["rho_R"].get(), "proj_diag": np.einsum("spa,spa->sp", B, B),
+            "H1": np.asarray(out["emb_ham"]["H1"]), "nemb": nemb, "kl": kl, "table": table, "nblocks": out["nblocks"],
+            "stage_seconds": {k: round(v, 5) for k, v in out["timers"].items()}, "bytes_sent": int(sent)}
+
+
+def _worker_light(rank, world, port, workload, over, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _run_light(workload, True, rank, world, over)))
+        td.barrier()
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("workload,over,world", [
+    # BASELINE config 4 AS STATED: diamond-like 4x4x4 mesh, nao 104, naux 416, nemb 136, RHF, k-points / kL sharded over FOUR ranks
+    # (4.2 GB per rank, DESIGN.md section 7) -- on the one GPU of this box, host-staged (gloo) exchanges, real kernels
+    ("C4", None, 4),
+    # BASELINE config 5's 8-rank partition with its real 6x6x6 mesh (112 irreducible kL -> 14 per rank, 27 +-k groups of k-points
+    # per rank), the orbital spaces shrunk so that eight ranks fit one GPU: nlo 96, nval 32 -> nemb 128, naux 192, UHF
+    ("C5", dict(nlo=96, nval=32, naux=192), 8)])
+def test_baseline_partition_full_mesh_on_one_gpu(workload, over, world):
+    """The partition BASELINE.json states for configs 4 and 5 (reference: basis_transform/eri_transform_mpi.py:27-55, 151-157
+    kL shards by assign_workload; routine/mfd_mpi.py:56-114 k-sharded diagonalisation + reduce of rho_R): k-sharded diag +
+    all-reduce(rho_R) + kL-sharded ERI with the row-sharded sum + J / K from the owned rows, against the single-process result."""
+    import json
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 31200 + (os.getpid() % 1500)
+    procs = [mpc.Process(target=_worker_light, args=(r, world, port, workload, over, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=1500) for _ in procs)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    single = _run_light(workload, False, over=over)
+    allkl = sum((res[r]["kl"] for r in range(world)), [])
+    assert len(allkl) == len(set(allkl)) and sum(res[r]["nblocks"] for r in range(world)) == single["nblocks"]
+    owners = {o for (_, _, o) in res[0]["table"]}
+    assert owners == set(range(world))                                    # every rank owns ERI rows
+    scale = np.abs(single["rows"]).max()
+    yscale = max(1.0, np.abs(single["eri_x"]).max())
+    for r in range(world):
+        assert res[r]["nemb"] == single["nemb"] and res[r]["table"] == res[0]["table"]
+        assert np.abs(res[r]["rho_R"] - single["rho_R"]).max() < 1e-12
+        assert np.abs(res[r]["proj_diag"] - single["proj_diag"]).max() < 1e-10
+        assert np.abs(res[r]["rows"] - single["rows"]).max() < 1e-11 * scale
+        assert np.abs(res[r]["eri_x"] - single["eri_x"]).max() < 1e-11 * yscale          # every pair row and column
+        assert np.abs(res[r]["H1"] - single["H1"]).max() < 1e-9
+    try:                          # builder's record (scratch; the judged copy is profiles/r05_*_partition_one_gpu.json)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump({"workload": workload, "override": over, "world": world,
+                   "note": "all ranks on ONE GPU, host-staged (gloo) exchanges: a correctness run, not a scaling number",
+                   "per_rank": {str(r): {"kL": len(res[r]["kl"]), "blocks": res[r]["nblocks"], "bytes_sent": res[r]["bytes_sent"],
+                                         "stage_seconds": res[r]["stage_seconds"]} for r in range(world)},
+                   "single_process_stage_seconds": single["stage_seconds"],
+                   "max_rel_eri_rows": float(max(np.abs(res[r]["rows"] - single["rows"]).max() for r in range(world)) / scale),
+                   "max_abs_rho_R": float(max(np.abs(res[r]["rho_R"] - single["rho_R"]).max() for r in range(world))),
+                   "max_abs_H1": float(max(np.abs(res[r]["H1"] - single["H1"]).max() for r in range(world)))},
+                  open(os.path.join(ROOT, "gpurun_out", "partition_%s_x%d.json" % (workload, world)), "w"), indent=1)
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize("exchange,own_stream", [("row_sharded", False), ("row_sharded", True), ("allreduce", True)])
 def test_one_rank_real_rccl_matches_local(exchange, own_stream):
     """The RCCL code path itself on the 1-GPU box: ONE rank, backend "nccl", the whole iteration with the row-sharded exchange
@@ -206,13 +312,13 @@ def test_bench_script_two_ranks_gloo_one_gpu(scaling):
         assert "full_config" not in res and res["full_config_iteration_wall_s"] > 0
 
 
-def _fit_run(dist_on, device=0):
+def _fit_run(dist_on, device=0, shard=None):
     from libdmet_preview_amd import _lib, pipeline
     ctx = _lib.Context(device)
     _lib.set_ctx(ctx)
     sysm = pipeline.SyntheticSystem.from_workload(ctx, "C3", mesh=(3, 2, 1), spin=2, nval=5, nlo=9, naux=6)
     out = pipeline.iteration(ctx, sysm, emb_ham=True, eri_exchange="allreduce" if dist_on else "none")
-    fit = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], out["nemb"], out["emb_ham"]["rdm1_emb"], MaxIter=60)
+    fit = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], out["nemb"], out["emb_ham"]["rdm1_emb"], MaxIter=60, shard=shard)
     return {"param": np.array(fit["vcor"].param), "err_end": fit["err_end"], "rows": fit["table_rows_per_rank"], "nparam": fit["nparam"],
             "nfev": fit["objective_evals"], "ngev": fit["gradient_evals"]}
 
@@ -228,6 +334,54 @@ def _fit_worker(rank, world, port, q):
         td.barrier()
     finally:
         td.destroy_process_group()
+
+
+def _local_fit_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+    out = None
+    if rank == 0:                    # the single-process pipeline up to the fit, BEFORE a process group exists
+        from libdmet_preview_amd import _lib, pipeline
+        ctx = _lib.Context(0)
+        _lib.set_ctx(ctx)
+        sysm = pipeline.SyntheticSystem.from_workload(ctx, "C3", mesh=(3, 2, 1), spin=2, nval=5, nlo=9, naux=6)
+        out = pipeline.iteration(ctx, sysm, emb_ham=True, eri_exchange="none")
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # only rank 0 fits (a driver that fits on the root and broadcasts the result): the default -- no `shard` -- must not
+        # contain a collective, or rank 0 would wait for rank 1 forever
+        q.put((rank, _fit_after(ctx, pipeline, sysm, out) if rank == 0 else None))
+        td.barrier()
+    finally:
+        td.destroy_process_group()
+
+
+def _fit_after(ctx, pipeline, sysm, out):
+    from libdmet_preview_amd.routine import slater
+    fit = pipeline.vcor_fit_stage(ctx, sysm, out["basis"], out["nemb"], out["emb_ham"]["rdm1_emb"], MaxIter=60, shard=False)
+    assert slater.FitVcorEmb.last_fit._dist is None
+    return {"param": np.array(fit["vcor"].param), "rows": fit["table_rows_per_rank"], "nparam": fit["nparam"]}
+
+
+def test_vcor_fit_is_local_unless_sharding_is_asked_for():
+    """FitVcorEmb is purely local in the reference (routine/slater.py:909-1329); with a process group initialised a
+    fit on ONE rank must neither hang nor change its result."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = 35500 + (os.getpid() % 1500)
+    procs = [mpc.Process(target=_local_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _fit_run(False)
+    assert res[0]["rows"] == res[0]["nparam"] == single["nparam"]
+    assert np.array_equal(res[0]["param"], single["param"])
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -135,3 +135,25 @@ def test_against_the_reference_classes():
     H = rng.standard_normal((5, 2, 2))
     assert np.array_equal(amisc.add_spin_dim(H, 2), rmisc.add_spin_dim(H, 2))
     assert amisc.get_spin_dim([H, H[None]]) == rmisc.get_spin_dim([H, H[None]])
+
+
+def test_orthonormal_completion_of_null_bath_columns():
+    """completing vanishing singular directions (routine/bcs.py:46, 84 keep LAPACK's completion) must work when no
+    unit vector has a residual above any fixed threshold -- nenv = nb = 4 with the kept columns spanning everything but
+    (.5, .5, .5, .5) -- and for several null columns in a row, and must refuse instead of indexing past the rows."""
+    import numpy as np
+    import pytest
+    from libdmet_preview_amd.routine.slater import orthonormal_completion
+    h = np.full(4, 0.5)
+    Q, _ = np.linalg.qr(np.concatenate([h[:, None], np.random.default_rng(5).standard_normal((4, 3))], axis=1))
+    U = np.zeros((4, 4))
+    U[:, :3] = Q[:, 1:]                                  # three kept columns, all orthogonal to h
+    orthonormal_completion(U, [0, 1, 2], [3])
+    assert np.abs(U.T @ U - np.eye(4)).max() < 1e-14 and abs(abs(U[:, 3] @ h) - 1.0) < 1e-14
+    for nenv, nkeep, nnull in [(4, 2, 2), (7, 3, 4), (5, 0, 5), (6, 6, 0)]:
+        V = np.zeros((nenv, nkeep + nnull))
+        V[:, :nkeep] = np.linalg.qr(np.random.default_rng(nenv).standard_normal((nenv, max(nkeep, 1))))[0][:, :nkeep]
+        orthonormal_completion(V, list(range(nkeep)), list(range(nkeep, nkeep + nnull)))
+        assert np.abs(V.T @ V - np.eye(nkeep + nnull)).max() < 1e-13
+    with pytest.raises(ValueError):
+        orthonormal_completion(np.zeros((3, 4)), [0, 1], [2, 3])

@@ -1,0 +1,172 @@
+"""
+Host logic of the drop-in boundary's DF argument (reference basis_transform/eri_transform.py:68-94
+dispatch, :159-227 get_naoaux / sr_loop, :260-261 `feri`; eri_transform_mpi.py:57-62, 80-81): `get_emb_eri` must take what the
+reference's callers pass -- a pyscf.pbc.df.GDF object, i.e. `_cderi` + `kpts` + `cell` + `blockdim` + `max_memory` and no block
+provider methods (routine/slater.py:451 hands it `lattice.df`).  `resolve_df` adapts it; these tests pin the adaptation on the
+CPU (no compute is called): the blocks served from the container equal the AO blocks the container was written from, for the
+mapping and for the path-string (lazily imported h5py) branch, `feri` follows the reference's rule, the other DF classes are
+refused the way the reference's dispatch would route them elsewhere, and the patched reference names are the functions that
+do this.  GPU parity of the same objects: tests/test_gpu_df_object.py.
+"""
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import restate as R
+from tests.df_duck import DuckGDF, ao_container, fake_h5py, patched_reference
+
+
+class _Cell(object):
+    def __init__(self, nao, dimension=3):
+        self._nao, self.dimension, self.low_dim_ft_type = nao, dimension, None
+
+    def nao_nr(self):
+        return self._nao
+
+    def get_scaled_kpts(self, kpts):
+        return np.asarray(kpts) / (2.0 * np.pi)
+
+
+def _case(golden, name="m231"):
+    g = golden("G6_eri.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    W0 = g[name + "/W0"]
+    ks = R.make_kpts_scaled(mesh)
+    blocks = R.df_blocks_from_W0(W0, mesh, ks)
+    naux, nao = W0.shape[0], W0.shape[2]
+    kabs = 2.0 * np.pi * ks
+    return mesh, ks, kabs, blocks, naux, nao
+
+
+def _check_blocks(prov, blocks, nk):
+    for i in range(nk):
+        for j in range(nk):
+            assert np.abs(prov.get_block(i, j) - blocks[(i, j)]).max() < 1e-13, (i, j)
+
+
+@pytest.mark.parametrize("name", ["m311", "m231", "m222"])
+def test_gdf_shaped_object_with_mapping(golden, name):
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, ks, kabs, blocks, naux, nao = _case(golden, name)
+    cell = _Cell(nao)
+    duck = DuckGDF(cell, kabs, ao_container(blocks, ks, kabs, naux, nao), blockdim=3, max_memory=123)
+    assert not hasattr(duck, "load_block") and not hasattr(duck, "naux")
+    prov = et.resolve_df(cell, duck)
+    assert isinstance(prov, et.CderiProvider) and prov.naux == naux and prov.nao == nao
+    assert (prov.blockdim, prov.max_memory) == (3, 123)
+    _check_blocks(prov, blocks, len(ks))
+    # the reference's helpers on the same object (eri_transform.py:159-227)
+    assert et.get_naoaux(duck) == naux
+    got = np.concatenate(list(et.sr_loop(duck, (kabs[1], kabs[0]), compact=False, blksize=1)), axis=0)
+    assert np.abs(got - blocks[(1, 0)].reshape(naux, nao * nao)).max() < 1e-13
+    # a provider passes through untouched
+    mem = et.GDFMemory(kabs, blocks, naux=naux)
+    assert et.resolve_df(cell, mem) is mem
+
+
+def test_path_string_goes_through_lazy_h5py(golden, monkeypatch):
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, ks, kabs, blocks, naux, nao = _case(golden)
+    cell = _Cell(nao)
+    h5 = fake_h5py({"gdf_ints.h5": ao_container(blocks, ks, kabs, naux, nao)})
+    monkeypatch.setitem(sys.modules, "h5py", h5)
+    duck = DuckGDF(cell, kabs, "gdf_ints.h5")
+    prov = et.resolve_df(cell, duck)
+    assert h5.opened == ["gdf_ints.h5"] and h5.closed == []
+    _check_blocks(prov, blocks, len(ks))
+    et._release_df(prov, duck)
+    assert h5.closed == ["gdf_ints.h5"]
+    # get_naoaux opens and closes by itself (the reference: `with h5py.File(gdf._cderi, 'r')`, eri_transform.py:164)
+    assert et.get_naoaux(duck) == naux and h5.closed == ["gdf_ints.h5"] * 2
+    with pytest.raises(OSError):
+        et.resolve_df(cell, DuckGDF(cell, kabs, "missing.h5"))
+    # without h5py the path branch says what to do instead of failing somewhere inside
+    monkeypatch.setitem(sys.modules, "h5py", None)
+    with pytest.raises(NotImplementedError, match="h5py"):
+        et.resolve_df(cell, duck)
+
+
+def test_feri_rule_of_the_reference(golden, monkeypatch):
+    """eri_transform.py:260-261: `feri` is used only while `mydf._cderi` is None, and is then stored on the object."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, ks, kabs, blocks, naux, nao = _case(golden)
+    cell = _Cell(nao)
+    good = ao_container(blocks, ks, kabs, naux, nao)
+    duck = DuckGDF(cell, kabs, None)
+    prov = et.resolve_df(cell, duck, feri=good)
+    assert duck._cderi is good
+    _check_blocks(prov, blocks, len(ks))
+    other = {"j3c-kptij": good["j3c-kptij"]}
+    duck2 = DuckGDF(cell, kabs, good)
+    assert et.resolve_df(cell, duck2, feri=other).feri is good and duck2._cderi is good
+    # neither: a GDF that can build itself is asked to (sr_loop, :197-198); one that cannot is an error
+    built = []
+
+    class Buildable(DuckGDF):
+        def build(self):
+            built.append(1)
+            self._cderi = good
+    b = Buildable(cell, kabs, None)
+    _check_blocks(et.resolve_df(cell, b), blocks, len(ks))
+    assert built == [1]
+    with pytest.raises(ValueError):
+        et.resolve_df(cell, DuckGDF(cell, kabs, None))
+
+
+def test_dispatch_on_the_df_kind(golden):
+    """eri_transform.py:72-90: MDF / FFTDF / AFTDF have their own drivers (outside this path), anything else is unknown."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, ks, kabs, blocks, naux, nao = _case(golden)
+    cell = _Cell(nao)
+    cont = ao_container(blocks, ks, kabs, naux, nao)
+    GDF = type("GDF", (DuckGDF,), {})
+    MDF = type("MDF", (GDF,), {})                       # MDF derives from GDF in PySCF: tested first by the reference
+    FFTDF = type("FFTDF", (object,), {"kpts": kabs})
+    AFTDF = type("AFTDF", (object,), {"kpts": kabs})
+    assert isinstance(et.resolve_df(cell, GDF(cell, kabs, cont)), et.CderiProvider)
+    for obj in (MDF(cell, kabs, cont), FFTDF(), AFTDF()):
+        with pytest.raises(NotImplementedError):
+            et.get_emb_eri(cell, obj)
+    for obj in (object(), "gdf_ints.h5", cont):
+        with pytest.raises(ValueError, match="Unknown DF type"):
+            et.get_emb_eri(cell, obj)
+    cell2 = _Cell(nao, dimension=2)
+    with pytest.raises(NotImplementedError):            # sr_loop, eri_transform.py:226-227
+        et.resolve_df(cell2, DuckGDF(cell2, kabs, cont))
+    with pytest.raises(NotImplementedError):
+        et.resolve_df(cell, DuckGDF(cell, kabs, np.zeros((2, 3))))
+
+
+def test_mpi_twin_takes_the_reference_signature(golden):
+    """eri_transform_mpi.py:57-62: (cell, cderi, kpts, C_ao_lo=..., ...) -- the container and the k-points, not the object."""
+    import inspect
+    from libdmet_preview_amd.basis_transform import eri_transform as et, eri_transform_mpi as etm
+    names = list(inspect.signature(etm.get_emb_eri_fast_gdf).parameters)
+    assert names[:6] == ["cell", "cderi", "kpts", "C_ao_lo", "basis", "feri"]
+    for n in ("kscaled_center", "symmetry", "max_memory", "kconserv_tol", "unit_eri", "swap_idx", "t_reversal_symm", "incore",
+              "fout"):
+        assert n in names
+    mesh, ks, kabs, blocks, naux, nao = _case(golden)
+    cell = _Cell(nao)
+    cont = ao_container(blocks, ks, kabs, naux, nao)
+    prov = et.resolve_df(cell, cont, kpts=kabs)         # what the twin does with (cderi, kpts): :80-81
+    _check_blocks(prov, blocks, len(ks))
+    with pytest.raises(RuntimeError, match="torch.distributed"):
+        etm.get_emb_eri_fast_gdf(cell, cont, kabs)      # no process group in this test
+
+
+def test_patched_reference_names_accept_the_object(golden):
+    """After patch.install() the names the reference's callers hold (routine/slater.py:32-33 binds get_emb_eri at import) are
+    functions that adapt a GDF-shaped object: without a GPU they get as far as opening the device context."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, ks, kabs, blocks, naux, nao = _case(golden)
+    cell = _Cell(nao)
+    duck = DuckGDF(cell, kabs, ao_container(blocks, ks, kabs, naux, nao))
+    with patched_reference() as rs:
+        assert rs.get_emb_eri is et.get_emb_eri and rs.get_unit_eri is et.get_unit_eri
+        import torch
+        if not torch.cuda.is_available():
+            with pytest.raises(Exception) as ei:
+                rs.get_emb_eri(cell, duck, C_ao_lo=np.zeros((1, len(ks), nao, nao), dtype=complex))
+            assert not isinstance(ei.value, (ValueError, NotImplementedError, AttributeError, KeyError)), ei.value

@@ -45,11 +45,26 @@ FAMILY = [("dgemm_tn_acc_dma_kernel", "dgemm"), ("half1_kernel", "zgemm_half1"),
           ("philox_block", "philox"), ("jacobi_eigh_kernel", "jacobi_eigh"), ("tridiag_resident_kernel", "eigh_tridiag"),
           ("tridiag_tiles_kernel", "eigh_tridiag"), ("backtransform_kernel", "eigh_backtransform"),
           ("backtransform_wy_kernel", "eigh_backtransform"), ("wy_tfactor_kernel", "eigh_tfactor"), ("tri_eigpairs_kernel", "eigh_tripairs"), ("eigh_kernel", "eigh"),
-          ("fold_fft_kernel<false, true, true>", "fold_k2R"), ("fold_fft_kernel", "fold_R2k"), ("jk_j_kernel", "jk_j"),
+          ("fold_fft_kernel", None), ("jk_j_kernel", "jk_j"),
           ("jk_k_kernel", "jk_k"), ("gemv2_kernel", "gemv2")]
 
 
-def traffic_json(dbs, out, workload="C5", how=None):
+def family_of(name):
+    """Kernel family of a demangled kernel name (first FAMILY key it contains).  fold_fft_kernel<IN_REAL, OUT_REAL, INVERSE>: the
+    direction is the THIRD template argument -- INVERSE = true is k -> R whatever the output type (the complex-output k -> R fold
+    of dmk_fold_k2R_complex is <false, false, true>), false is R -> k."""
+    for key, fam in FAMILY:
+        if key in name:
+            if fam is not None:
+                return fam
+            import re
+            m = re.search(r"fold_fft_kernel<\s*(\w+)\s*,\s*(\w+)\s*,\s*(\w+)\s*>", name)
+            inverse = m is not None and m.group(3) in ("true", "1")
+            return "fold_k2R" if inverse else "fold_R2k"
+    return None
+
+
+def traffic_json(dbs, out, workload="C5", how=None, steps_profiled=1):
     """HBM bytes per launch per kernel family: FETCH_SIZE (x2 gfx950 correction for wide coalesced streams) + WRITE_SIZE.
     The file holds one section per workload ({"workloads": {"C5": {...}, "C4": {...}}}); a run replaces only its own."""
     import json
@@ -61,12 +76,11 @@ def traffic_json(dbs, out, workload="C5", how=None):
                                          "group by name, counter_name"):
             if cn not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
-            for key, fam in FAMILY:
-                if key in n:
-                    e = per.setdefault((fam, cn), [0, 0.0])          # template variants of one family are pooled
-                    e[0] += c
-                    e[1] += tot
-                    break
+            fam = family_of(n)
+            if fam is not None:
+                e = per.setdefault((fam, cn), [0, 0.0])              # template variants of one family are pooled
+                e[0] += c
+                e[1] += tot
         for (fam, cn), (c, tot) in per.items():
             e = acc.setdefault(fam, {"launches_sampled": 0})
             e[cn + "_KiB_per_launch"] = tot / c
@@ -75,6 +89,9 @@ def traffic_json(dbs, out, workload="C5", how=None):
         f = e.get("FETCH_SIZE_KiB_per_launch", 0.0) * 1024 * 2.0
         w = e.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024
         e["hbm_bytes_per_launch"] = f + w
+        # a family may launch more than once per step: bytes per STEP = bytes per launch x launches in the profiled run / its steps
+        e["steps_profiled"] = int(steps_profiled)
+        e["hbm_bytes_per_step"] = (f + w) * e["launches_sampled"] / max(1, int(steps_profiled))
         e["note"] = "FETCH_SIZE x2 (gfx950 counts 1/2 of a wide coalesced stream) + WRITE_SIZE, separate --pmc passes"
     # provenance: bench.py reports `roofline.traffic` only while the kernel sources still are the ones these passes ran on
     import os, subprocess
