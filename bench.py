@@ -443,6 +443,24 @@ def main():
     a.steps_requested, a.warmup_requested = a.steps, a.warmup
     a.steps, a.warmup = nsteps, nwarm                        # from here on: the counts that were run
 
+    # ---- per-rank view of the timed region (N > 1): stage seconds, DF blocks and bytes put on the wire per step ------------
+    per_rank = None
+    if distributed:
+        keys = sorted(timers)
+        sl = np.zeros((world, len(keys) + 2))
+        sl[rank, :len(keys)] = [timers[k] / nsteps for k in keys]
+        sl[rank, len(keys)] = out["nblocks"]
+        n_, nk_, sp_ = sysm.nlo, sysm.nk, sysm.spin
+        sent = sp_ * nk_ * n_ * n_ * 8 + sp_ * nk_ * n_ * 8 + 3 * sp_ * nemb * nemb * 8        # rho_R, eigenvalue table, J / K partials
+        if out.get("eri_rows"):
+            sent += sum(hi - lo for (lo, hi, o) in out["eri_rows"] if o != rank) * npair * 8 * spin_pair   # partial row bands -> owners
+        sl[rank, len(keys) + 1] = sent
+        sl = dist.all_reduce_sum_numpy(sl)
+        per_rank = [{"rank": r, "kL": None, "blocks": int(sl[r, len(keys)]), "bytes_sent_per_step": int(sl[r, len(keys) + 1]),
+                     "stage_seconds_per_step": {k: round(float(sl[r, i]), 5) for i, k in enumerate(keys)}} for r in range(world)]
+        for r in range(world):
+            per_rank[r]["kL"] = len(et.assign_workload(sysm.mesh, world, True)[r]) if a.scaling == "strong" else len(kl_mine)
+
     fh_timed, fc_timed = out["flops_half"], out["flops_contract"]
     flops = (fh_timed + fc_timed) * a.steps
     exec_mine = sum(fam_exec.get(k, 0.0) for k in ("zgemm_half1", "zgemm_half2", "dgemm"))
@@ -739,6 +757,11 @@ def main():
             res["full_config_iteration_wall_s"] = round(elapsed / a.steps, 4)
         if shard is not None:
             res["shard_pass"] = shard
+        if per_rank is not None:
+            res["per_rank"] = per_rank
+            if os.environ.get("DMK_BENCH_ONE_GPU", "0") == "1":
+                res["one_gpu_note"] = ("ALL %d ranks on ONE GPU with host-staged (%s) exchanges: a correctness / partition run, "
+                                       "NOT a scaling number" % (world, os.environ.get("DMK_BENCH_BACKEND", "nccl")))
         if parity is not None:
             res.update(parity)
             res["parity_ok"] = bool(parity["parity_maxabs"] <= PARITY_TOL and parity["parity_freivalds_ok"])
