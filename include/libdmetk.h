@@ -458,6 +458,34 @@ int dmk_axpy_f64(dmk_ctx *ctx, int64_t n, double alpha, const double *x, double 
 int dmk_vcor_dV_dparam(dmk_ctx *ctx, int nent, int nb, const double *G, int64_t ldg, const int32_t *nz_ptr,
                        const int32_t *nz_i, const int32_t *nz_j, const double *nz_val, const int64_t *out_off, double *dV);
 
+/* The whole T = 0 objective of FitVcorEmb along a ray of the parameter space as ONE call (errfunc, routine/slater.py:1059-1124:
+ * V_emb = sum_p param_p dV_dparam_p is linear in the parameters, so a line search x + t p evaluates V_emb = v0 + t v1):
+ *   H = unpack(v0 + t v1 + H1)  ->  eigenpairs (warm refinement of the previous basis, enqueued without host read-back)
+ *   ->  T = 0 occupations of every spin channel (mfd.assignocc, routine/mfd.py:887-957)  ->  rho = ev occ ev^T on the fitted
+ *   block, W o rho - target, its sum of squares  ->  a pinned host record the call polls.
+ * All pointers are device pointers except nelec / mu0 (host, one per spin) and slot (pinned host, >= 256 bytes, dmk_host_alloc).
+ *   v0, v1, H1   (spin, npair) tril-packed; v1 NULL: V_emb = v0
+ *   H            (spin, nb, nb) work: the matrix that is diagonalised
+ *   Vp           (spin, nb, nb) in: eigenvector rows of the previous evaluation (the warm start); out: this evaluation's
+ *   w, occ       (spin, nb) out: levels ascending, occupations
+ *   fit_idx      (nidx) int32; W, target, drho (spin, nidx, nidx); work: >= 2112 doubles of device scratch owned by the caller
+ *   npass        refinement passes to enqueue (a pass that finds its matrix settled costs a few microseconds)
+ * *status: 0 ok -- *f2 = sum of squares (errfunc = sqrt(f2 / spin)); 1 the refinement did not verify its basis within npass
+ * passes: NOTHING of w / occ / drho is valid, Vp still holds the previous basis, the caller falls back to dmk_eigh_jacobi_real
+ * + the separate calls above; 2 non-finite levels.  *settle_pass: the measurement pass (0-based) that settled the slower matrix. */
+typedef struct {
+    int nb, spin, nidx, npass, has_mu0;
+    double t, tol_deg;
+    const double *v0, *v1, *H1;
+    double *H, *Vp, *w, *occ;
+    const double *nelec, *mu0;
+    const int32_t *fit_idx;
+    const double *W, *target;
+    double *drho, *work;
+    void *slot;
+} dmk_fit_args;
+int dmk_fit_objective(dmk_ctx *ctx, const dmk_fit_args *args, double *f2, int *status, int *settle_pass);
+
 #ifdef __cplusplus
 }
 #endif

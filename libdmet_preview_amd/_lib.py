@@ -118,7 +118,19 @@ PROTOTYPES = {
     "dmk_scatter2d_add_f64": (c_int, [c_vp, c_int, c_vp, c_vp, c_dbl, c_vp, c_i64, c_int]),
     "dmk_axpy_f64": (c_int, [c_vp, c_i64, c_dbl, c_vp, c_vp]),
     "dmk_vcor_dV_dparam": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_fit_objective": (c_int, [c_vp, c_vp, P(c_dbl), P(c_int), P(c_int)]),
 }
+
+
+class FitArgs(C.Structure):
+    """dmk_fit_args of include/libdmetk.h (the fused T = 0 objective of FitVcorEmb)."""
+    _fields_ = [("nb", c_int), ("spin", c_int), ("nidx", c_int), ("npass", c_int), ("has_mu0", c_int),
+                ("t", c_dbl), ("tol_deg", c_dbl),
+                ("v0", c_vp), ("v1", c_vp), ("H1", c_vp),
+                ("H", c_vp), ("Vp", c_vp), ("w", c_vp), ("occ", c_vp),
+                ("nelec", c_vp), ("mu0", c_vp),
+                ("fit_idx", c_vp), ("W", c_vp), ("target", c_vp),
+                ("drho", c_vp), ("work", c_vp), ("slot", c_vp)]
 
 for _name, (_res, _args) in PROTOTYPES.items():
     _f = getattr(lib, _name)          # AttributeError here = header / library mismatch: fail loudly

@@ -48,6 +48,7 @@ struct dmk_ctx {
     void (*oom_hook)(void *) = nullptr;
     void *oom_user = nullptr;
     // warm-started eigensolver (jacobi_eigh.hip): bookkeeping of the refinement fast path
+    unsigned long long fit_seq = 0;          // sequence number of the pinned result record of dmk_fit_objective
     int refine_streak = 0, refine_skip = 0;
     long long refine_ok = 0, refine_failed = 0;
 };
@@ -87,6 +88,12 @@ struct FamScope {
 };
 
 int dmk_scratch(dmk_ctx *ctx, size_t bytes, void **out);
+// occ.hip: T = 0 occupations of several spectra in one launch, nothing read back
+int dmk_assign_occ_zero_t_batch(dmk_ctx *ctx, int64_t n, int batch, const double *ew, const double *nelec_host,
+                                const double *mu0_host, int flags, double thr_deg, double *occ, double *info_dev);
+// jacobi_eigh.hip: warm Ogita-Aishima refinement, enqueued without any host read-back (used by dmk_fit_objective)
+int dmk_eigh_refine_enqueue(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int npass,
+                            int *verdict_dev);
 int dmk_scratch2(dmk_ctx *ctx, size_t bytes, void **out);
 
 // XCD-aware, bijective remap of a 1-D block id: blocks that the dispatcher places on the

@@ -322,6 +322,109 @@ __global__ void axpy_kernel(long long n, double alpha, const double *__restrict_
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int grid_for(long long total, int cap = 8192) { return (int)std::min<long long>((total + 255) / 256, cap); }
 
+// ---- fused T = 0 objective of the embedding fit (dmk_fit_objective) --------------------------------------------------------
+// full[b] = unpack(v0[b] + t v1[b] + H1[b]): the ray form of the embedding potential (V_emb is linear in the parameters) and the
+// fixed one-body part in one pass -- replaces a device copy, an axpy and sym_unpack
+__global__ void fit_ray_unpack_kernel(int n, int batch, const double *__restrict__ v0, const double *__restrict__ v1, double t,
+                                      const double *__restrict__ h1, double *__restrict__ full) {
+    const long long npair = (long long)n * (n + 1) / 2, total = (long long)n * n * batch;
+    for (long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * blockDim.x) {
+        const long long b = e0 / ((long long)n * n), e = e0 % ((long long)n * n);
+        const int i = (int)(e / n), j = (int)(e % n);
+        const int a = i > j ? i : j, c = i > j ? j : i;
+        const long long p = b * npair + (long long)a * (a + 1) / 2 + c;
+        const double v = v1 ? fma(t, v1[p], v0[p]) : v0[p];
+        full[e0] = v + h1[p];
+    }
+}
+
+// drho[s][a][b] = W[s][a][b] * sum_m occ[s][m] Vt[s][m][fit[a]] Vt[s][m][fit[b]] - target[s][a][b]  and per-workgroup partial
+// sums of drho^2: the density of the fitted block straight from the eigenvector rows (rho = ev occ ev^T restricted to the fitted
+// indices), the mask, the residual and its norm in ONE launch -- replaces ewise (scale), dgemm, 2 x gather, ewise (mask),
+// sub_sumsq.  One 16 x 16 tile per WORKGROUP on v_mfma_f64_16x16x4_f64; the four waves split the sum over the orbitals m
+// (wave w takes the 64-wide chunks w, w + 4, ...: one L2 round trip each at nb = 256) and their partial tiles are added through
+// LDS in a fixed order.  part[(s * gy + by) * gx + bx] = sum of squares over the workgroup's tile.
+__global__ __launch_bounds__(NT) void fit_rho_diff_kernel(int nb, int nidx, const double *__restrict__ Vt, const double *__restrict__ occ,
+                                                          const int *__restrict__ fit, const double *__restrict__ W,
+                                                          const double *__restrict__ target, double *__restrict__ drho,
+                                                          double *__restrict__ part) {
+    __shared__ double red[3][4][64];
+    const int s = blockIdx.z;
+    const double *V = Vt + (long long)s * nb * nb;
+    const double *oc = occ + (long long)s * nb;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int ia = m0 + x, ib = n0 + x;
+    const bool a_ok = ia < nidx, b_ok = ib < nidx;
+    const int ca = fit[a_ok ? ia : 0], cb = fit[b_ok ? ib : 0];
+    d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (nb + 63) / 64;
+#pragma unroll 1
+    for (int c = wave; c < nchunk; c += 4) {
+        double a[16], bb[16];
+        const int k0 = c * 64 + 16 * q;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int m = k0 + t;
+            const bool ok = m < nb;
+            const double *row = V + (long long)(ok ? m : 0) * nb;
+            a[t] = (ok && a_ok) ? row[ca] * oc[m] : 0.0;
+            bb[t] = (ok && b_ok) ? row[cb] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb[t], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    double ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = (acc[r] + red[0][r][lane]) + (red[1][r][lane] + red[2][r][lane]);
+        const int row = m0 + q + 4 * r;
+        if (row < nidx && ib < nidx) {
+            const long long o = ((long long)s * nidx + row) * nidx + ib;
+            const double d = v * W[o] - target[o];
+            drho[o] = d;
+            ss = fma(d, d, ss);
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) part[((long long)s * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = ss;
+}
+
+// The end of the chain: the partial sums in index order (fixed order: reproducible) -> sum of squares, on the device for the
+// gradient and, with the eigensolver's verdicts and the occupation status words, in a PINNED host record the caller polls:
+//   slot: [0] sum of squares, [1 .. 1 + 2 batch) verdicts (state, settling pass) as doubles, then batch occupation status words,
+//   last the sequence number, written LAST with system-scope release -- the host sees a complete record or the old sequence number.
+struct FitSlot { double f2; double verdict[8]; double occ_status[4]; double occ_spread[4]; unsigned long long seq; };
+__global__ __launch_bounds__(256) void fit_final_kernel(int npart, const double *__restrict__ part, double *__restrict__ sumsq_dev,
+                                                        int batch, const int *__restrict__ verdict, const double *__restrict__ occ_info,
+                                                        FitSlot *__restrict__ slot, unsigned long long seq) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < npart; i += 256) v += part[i];          // fixed assignment of terms to threads: reproducible
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double f2 = (red[0] + red[1]) + (red[2] + red[3]);
+        sumsq_dev[0] = f2;
+        slot->f2 = f2;
+        for (int i = 0; i < 2 * batch && i < 8; ++i) slot->verdict[i] = (double)verdict[i];
+        for (int i = 0; i < batch && i < 4; ++i) {
+            slot->occ_status[i] = occ_info[8 * i + 4];
+            slot->occ_spread[i] = occ_info[8 * i + 2];
+        }
+        __threadfence_system();
+        __hip_atomic_store(&slot->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace
 
 // C[b] = A[b] B[b] (row-major, contiguous) for the other translation units
@@ -485,6 +588,76 @@ int dmk_vcor_dV_dparam(dmk_ctx *ctx, int nent, int nb, const double *G, int64_t 
     hipLaunchKernelGGL(dv_dparam_kernel, dim3(grid_for(npair, 256), nent), dim3(256), 0, ctx->stream, nent, nb, (long long)ldg, G,
                        nz_ptr, nz_i, nz_j, nz_val, dV, reinterpret_cast<const long long *>(out_off));
     DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
+
+// ---- the whole T = 0 objective of FitVcorEmb as ONE call (routine/slater.py:1059-1124 errfunc) ------------------------------
+// V_emb = v0 + t v1 -> H = embH1 + V_emb -> eigenpairs (warm Ogita-Aishima refinement from the previous basis, ENQUEUED without a
+// host look at its verdict) -> T = 0 occupations of both spin channels (one launch) -> rho on the fitted block, residual, sum of
+// squares -> a pinned host record polled by the caller: ~15 launches issued back to back from C and ONE wait, where the Python
+// chain paid 7 - 20 us of interpreter time between 25 launches and two synchronising read-backs per evaluation.
+// Returns DMK_OK with *status = 0 (objective valid: *f2 = sum of squares, w / occ / Vp / drho hold this evaluation's levels,
+// occupations, eigenvector rows and residual for the gradient), 1 (the refinement did not verify every matrix within `npass`
+// passes -- nothing usable was produced, the caller falls back to the synchronous solver) or 2 (non-finite levels).
+int dmk_fit_objective(dmk_ctx *ctx, const dmk_fit_args *a, double *f2, int *status, int *settle_pass) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!a || !f2 || !status || a->nb <= 0 || a->spin < 1 || a->spin > 2 || a->nidx <= 0 || !a->v0 || !a->H1 || !a->H || !a->Vp ||
+        !a->w || !a->occ || !a->fit_idx || !a->W || !a->target || !a->drho || !a->work || !a->slot)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "fit_objective: bad arguments");
+    const int nb = a->nb, spin = a->spin, nidx = a->nidx;
+    FitSlot *slot = static_cast<FitSlot *>(a->slot);
+    // work: [0, 2048) partial sums | [2048] sum of squares | [2056, 2056 + 8 spin) occupation info | then 2 spin ints of verdicts
+    double *part = a->work, *ss_dev = a->work + 2048, *occ_info = a->work + 2056;
+    int *verdict = reinterpret_cast<int *>(a->work + 2056 + 8 * 4);
+    const int gx = (nidx + 15) / 16;
+    if (gx * gx * spin > 2048) return dmk_fail(ctx, DMK_ERR_INVALID, "fit_objective: %d fitted indices exceed the partial-sum table", nidx);
+    const unsigned long long seq = ++ctx->fit_seq;
+    {
+        FamScope fs(ctx, DMK_FAM_FIT);
+        hipLaunchKernelGGL(fit_ray_unpack_kernel, dim3(grid_for((long long)nb * nb * spin)), dim3(256), 0, ctx->stream, nb, spin,
+                           a->v0, a->v1, a->t, a->H1, a->H);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    int rc = dmk_eigh_refine_enqueue(ctx, nb, spin, a->H, a->Vp, a->w, a->Vp, a->npass, verdict);
+    if (rc) return rc;
+    rc = dmk_assign_occ_zero_t_batch(ctx, nb, spin, a->w, a->nelec, a->has_mu0 ? a->mu0 : nullptr, (a->has_mu0 ? 1 : 0) | 4,
+                                     a->tol_deg, a->occ, occ_info);
+    if (rc) return rc;
+    {
+        FamScope fs(ctx, DMK_FAM_FIT);
+        hipLaunchKernelGGL(fit_rho_diff_kernel, dim3(gx, gx, spin), dim3(NT), 0, ctx->stream, nb, nidx, a->Vp, a->occ, a->fit_idx, a->W,
+                           a->target, a->drho, part);
+        hipLaunchKernelGGL(fit_final_kernel, dim3(1), dim3(256), 0, ctx->stream, gx * gx * spin, part, ss_dev, spin, verdict, occ_info,
+                           slot, seq);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    // wait for the record: poll the pinned sequence number (the kernel releases it at system scope after the payload); a
+    // stream synchronisation is the fallback when polling is switched off or takes implausibly long
+    static const bool poll = !(getenv("DMK_FIT_POLL") && atoi(getenv("DMK_FIT_POLL")) == 0);
+    bool seen = false;
+    if (poll) {
+        volatile unsigned long long *ps = &slot->seq;
+        for (long spins = 0; spins < 200000000L; ++spins) {
+            if (__atomic_load_n(ps, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+    }
+    if (!seen) {
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq)
+            return dmk_fail(ctx, DMK_ERR_STATE, "fit_objective: the result record was not written");
+    }
+    *f2 = slot->f2;
+    int st = 0, worst_pass = 0;
+    for (int i = 0; i < spin; ++i) {
+        if ((int)slot->verdict[i] != 1 && (int)slot->verdict[i] != 3) st = 1;     // 1 verified, 3 settled by prediction
+        worst_pass = std::max(worst_pass, (int)slot->verdict[spin + i]);
+    }
+    if (st == 0)
+        for (int i = 0; i < spin; ++i)
+            if (slot->occ_status[i] != 0.0) st = 2;
+    *status = st;
+    if (settle_pass) *settle_pass = worst_pass;
     return DMK_OK;
 }
 

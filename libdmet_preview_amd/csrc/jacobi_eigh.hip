@@ -357,6 +357,7 @@ struct RfGemm {
     const double *A[2], *B[2], *Cadd[2];
     double *C[2];
     const int *state;
+    int pass;                // state 3 | (p << 8) ("settled by the update of pass p"): runs like state 0 in pass p, like state 1 later
     int run_mask;            // bit s set: matrices in state s take part
     int copy_mask;           // bit s set: matrices in state s get C = Cadd (the basis is carried to the other buffer)
     double *sq_part[2];      // optional [batch][nt16][nt16]: per-tile sums of squares for the norms of the analysis pass --
@@ -370,9 +371,15 @@ struct RfGemm {
 // contracts element t of the four q groups -- so NT operands are read as 128 contiguous bytes per lane.
 template <bool NN>
 __global__ __launch_bounds__(RF_T) void rf_gemm_kernel(RfGemm g) {
+    // One 16 x 16 tile of C per WORKGROUP, the four waves split K (wave w takes the 64-wide chunks w, w + 4, ...) and the
+    // partial tiles are added through LDS in the fixed order ((w0 + w1) + (w2 + w3)): at n = 256 every wave runs ONE chunk -- a
+    // single round trip to L2 and 16 MFMAs -- where the one-tile-per-wave form walked four chunks in sequence (11 us per
+    // launch, latency bound; round 5: these products are 2/3 of the vcor fit's kernel time).
+    __shared__ double part[3][4][64];
     const int n = g.n;
     const int prob = blockIdx.z / g.batch, mat = blockIdx.z % g.batch;
-    const int st = g.state ? g.state[mat] : 0;
+    int st = g.state ? g.state[mat] : 0;
+    if ((st & 0xff) == 3) st = ((st >> 8) == g.pass) ? 0 : 1;
     const bool run = (g.run_mask >> st) & 1, copy = (g.copy_mask >> st) & 1;
     if (!run && !copy) return;
     const size_t nn = (size_t)n * n;
@@ -381,15 +388,16 @@ __global__ __launch_bounds__(RF_T) void rf_gemm_kernel(RfGemm g) {
     double *C = g.C[prob] + mat * nn;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * 32 + (wave >> 1) * 16, n0 = blockIdx.x * 32 + (wave & 1) * 16;
-    if (m0 >= n || n0 >= n) return;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
     const bool symm = g.symm[prob] != 0;
     if (symm && m0 < n0) return;
     if (!run) {                                            // pass-through of a finished matrix
+        if (wave == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + q + 4 * r, col = n0 + x;
-            if (row < n && col < n) C[(size_t)row * n + col] = Cadd[(size_t)row * n + col];
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + q + 4 * r, col = n0 + x;
+                if (row < n && col < n) C[(size_t)row * n + col] = Cadd[(size_t)row * n + col];
+            }
         }
         return;
     }
@@ -418,27 +426,37 @@ __global__ __launch_bounds__(RF_T) void rf_gemm_kernel(RfGemm g) {
     };
 
     d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
-    double a[2][16], b[2][16];
     const int nchunk = (n + 63) / 64;
-    load_row16(arow, a_ok, 16 * q, a[0]);
-    if (NN) load_col16(brow, b_ok, 16 * q, b[0]); else load_row16(brow, b_ok, 16 * q, b[0]);
+    if (wave < nchunk) {
+        double a[2][16], b[2][16];
+        load_row16(arow, a_ok, wave * 64 + 16 * q, a[0]);
+        if (NN) load_col16(brow, b_ok, wave * 64 + 16 * q, b[0]); else load_row16(brow, b_ok, wave * 64 + 16 * q, b[0]);
 #pragma unroll 1
-    for (int c = 0; c < nchunk; c += 2) {
-        if (c + 1 < nchunk) {
-            load_row16(arow, a_ok, (c + 1) * 64 + 16 * q, a[1]);
-            if (NN) load_col16(brow, b_ok, (c + 1) * 64 + 16 * q, b[1]); else load_row16(brow, b_ok, (c + 1) * 64 + 16 * q, b[1]);
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][t], b[0][t], acc, 0, 0, 0);
-        if (c + 1 < nchunk) {
-            if (c + 2 < nchunk) {
-                load_row16(arow, a_ok, (c + 2) * 64 + 16 * q, a[0]);
-                if (NN) load_col16(brow, b_ok, (c + 2) * 64 + 16 * q, b[0]); else load_row16(brow, b_ok, (c + 2) * 64 + 16 * q, b[0]);
+        for (int c = wave; c < nchunk; c += 8) {
+            if (c + 4 < nchunk) {
+                load_row16(arow, a_ok, (c + 4) * 64 + 16 * q, a[1]);
+                if (NN) load_col16(brow, b_ok, (c + 4) * 64 + 16 * q, b[1]); else load_row16(brow, b_ok, (c + 4) * 64 + 16 * q, b[1]);
             }
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][t], b[1][t], acc, 0, 0, 0);
+            for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][t], b[0][t], acc, 0, 0, 0);
+            if (c + 4 < nchunk) {
+                if (c + 8 < nchunk) {
+                    load_row16(arow, a_ok, (c + 8) * 64 + 16 * q, a[0]);
+                    if (NN) load_col16(brow, b_ok, (c + 8) * 64 + 16 * q, b[0]); else load_row16(brow, b_ok, (c + 8) * 64 + 16 * q, b[0]);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][t], b[1][t], acc, 0, 0, 0);
+            }
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + q + 4 * r;
@@ -502,18 +520,33 @@ __global__ __launch_bounds__(1024) void rf_norm_kernel(int n, const double *__re
         const double bound = fmin(sqrt(f), gm);
         anorm[mat] = bound > 0.0 ? 1.015625 * bound : 1.0;
         state[mat] = 0;
+        state[gridDim.x + mat] = -1;              // settling pass: none yet
         arrive[mat] = 0;
     }
 }
 
 // Sorted, normalised output of a verified basis: w = l (ascending, stable), row rank(j) of Vt = v_j / |v_j|.
 // l_j = s_jj / g_jj are the Rayleigh quotients the analysis pass computed; |v_j|^2 = g_jj.  16 rows per workgroup.
+// ASYNCHRONOUS use (`state` given): the host has not looked at the verdicts -- a matrix whose state is not 1 (verified) is left
+// alone (w, Vt untouched) and every matrix's (state, settling pass) goes to `verdict_out` [2][batch] for the caller to read
+// together with whatever it enqueued behind this launch.
 __global__ __launch_bounds__(256) void rf_finish_kernel(int n, const double *__restrict__ V, const double *__restrict__ G,
                                                          const double *__restrict__ lam, double *__restrict__ w,
-                                                         double *__restrict__ Vt) {
+                                                         double *__restrict__ Vt, const int *__restrict__ state, int batch,
+                                                         int *__restrict__ verdict_out, int no_renorm) {
     extern __shared__ double ls[];               // [n]
     __shared__ int rank_s[16];
     const int mat = blockIdx.y, j0 = blockIdx.x * 16, tid = threadIdx.x;
+    const int st = state[mat] & 0xff;            // 1 verified, 3 settled by prediction (state 3 | pass << 8)
+    if (verdict_out) {
+        if (blockIdx.x == 0 && tid == 0) {
+            verdict_out[mat] = st;
+            verdict_out[batch + mat] = state[batch + mat];
+        }
+        if (st != 1 && st != 3) return;           // uniform over the workgroup
+    }
+    // V + F V is not the basis g_aa was measured on: a predicted state (3), and EVERY state of the fused analysis + update pass
+    const bool renorm = st != 3 && !no_renorm;
     const double *l = lam + (size_t)mat * n;
     for (int i = tid; i < n; i += 256) ls[i] = l[i];
     __syncthreads();
@@ -536,7 +569,7 @@ __global__ __launch_bounds__(256) void rf_finish_kernel(int n, const double *__r
         const int j = j0 + jr;
         if (j >= n) break;
         const int rk = rank_s[jr];
-        const double inrm = 1.0 / sqrt(G[base + (size_t)j * n + j]);
+        const double inrm = renorm ? 1.0 / sqrt(G[base + (size_t)j * n + j]) : 1.0;
         if ((tid & 63) == 0) w[(size_t)mat * n + rk] = ls[j];
         for (int i = tid & 63; i < n; i += 64) Vt[base + (size_t)rk * n + i] = V[base + (size_t)j * n + i] * inrm;
     }
@@ -551,14 +584,24 @@ struct RfAnalyse {
     unsigned *arrive;                // [batch] arrival counters (zero between launches)
     int *state;
     double tol;
+    int predict;                     // accept V + F V unmeasured when max|F| <= RF_PREDICT_F (see there)
 };
+
+// Settled BY PREDICTION (state 3 | pass << 8).  The correction is quadratically convergent: with every rotated pair's gap above
+// delta, V' = (I + F) V has errors c max|F|^2 with c = 0.49 - 0.54 measured over the fit's whole range of steps (max|F| 1e-4 ...
+// 3e-3 -> next pass 5e-9 ... 3e-6) -- so once a MEASURED max|F| is below 5e-8 the updated basis is good to 1.3e-15, ten times
+// inside the 4 sqrt(n) eps budget the verification itself applies, provided the pairs that are only re-orthogonalised (gap <=
+// delta) already meet that budget (m3).  Such a matrix skips the measurement pass that would confirm it -- four n^3 products,
+// a third of a fit evaluation; its Rayleigh quotients l = s_aa / g_aa are those of V (error O(F^2 |A|)), and the finish kernel
+// does not renormalise V' with the stale g_aa (V' is orthonormal to O(F^2) as it stands).  DMK_EIGH_PREDICT=0 switches it off.
+constexpr double RF_PREDICT_F = 5.0e-8;
 
 // One pass of the analysis, RF_SPLIT workgroups per matrix: each one forms l and delta for itself (the norms from the per-tile
 // sums of the product kernels, added in a fixed order, so all of them hold the same delta) and then a slice of F; the last workgroup of a matrix to arrive
 // folds the partial maxima (max is exact in any order) into the verdict.
 __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
     extern __shared__ double lam[];                // [n]
-    __shared__ double red[3][16];
+    __shared__ double red[4][16];
     __shared__ double delta_s;
     __shared__ int last_s;
     const int mat = blockIdx.x / RF_SPLIT, split = blockIdx.x % RF_SPLIT;
@@ -595,7 +638,7 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
     }
     __syncthreads();
     const double delta = delta_s;
-    double maxf = 0.0, maxres = 0.0, maxr = 0.0;
+    double maxf = 0.0, maxres = 0.0, maxr = 0.0, maxresc = 0.0;      // maxresc: residual of the pairs that are NOT rotated (gap <= delta)
     // rows of this workgroup: 16-row groups split, split + RF_SPLIT, ...; wave <-> row inside a group, lanes along b
     for (int a = split * 16 + wave; a < n; a += 16 * RF_SPLIT) {
         const double la = lam[a];
@@ -614,7 +657,12 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
                 const double gap = la - lam[b];
                 const double num = fma(la, r, sv);
                 maxres = (fabs(num) <= 1.7e308) ? fmax(maxres, fabs(num)) : INFINITY;     // NaN / Inf must not vanish in fmax
-                f = fabs(gap) > delta ? num * fast_rcp(gap) : 0.5 * r;
+                if (fabs(gap) > delta) {
+                    f = num * fast_rcp(gap);
+                } else {
+                    f = 0.5 * r;
+                    maxresc = fmax(maxresc, fabs(num));
+                }
             }
             maxr = (fabs(r) <= 1.7e308) ? fmax(maxr, fabs(r)) : INFINITY;
             maxf = fmax(maxf, fabs(f));
@@ -625,15 +673,18 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
         maxf = fmax(maxf, __shfl_xor(maxf, o, 64));
         maxres = fmax(maxres, __shfl_xor(maxres, o, 64));
         maxr = fmax(maxr, __shfl_xor(maxr, o, 64));
+        maxresc = fmax(maxresc, __shfl_xor(maxresc, o, 64));
     }
     __syncthreads();
-    if (lane == 0) { red[0][wave] = maxf; red[1][wave] = maxres; red[2][wave] = maxr; }
+    if (lane == 0) { red[0][wave] = maxf; red[1][wave] = maxres; red[2][wave] = maxr; red[3][wave] = maxresc; }
     __syncthreads();
     if (tid == 0) {
-        double m0 = 0.0, m1 = 0.0, m2 = 0.0;
-        for (int w = 0; w < 16; ++w) { m0 = fmax(m0, red[0][w]); m1 = fmax(m1, red[1][w]); m2 = fmax(m2, red[2][w]); }
+        double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            m0 = fmax(m0, red[0][w]); m1 = fmax(m1, red[1][w]); m2 = fmax(m2, red[2][w]); m3 = fmax(m3, red[3][w]);
+        }
         double *mine = g.part + ((size_t)mat * RF_SPLIT + split) * 4;
-        mine[0] = m0; mine[1] = m1; mine[2] = m2;
+        mine[0] = m0; mine[1] = m1; mine[2] = m2; mine[3] = m3;
         __threadfence();
         const unsigned before = atomicAdd(&g.arrive[mat], 1u);
         last_s = (before == RF_SPLIT - 1) ? 1 : 0;
@@ -641,7 +692,7 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
             __threadfence();
             for (int q = 0; q < RF_SPLIT; ++q) {
                 const volatile double *o = g.part + ((size_t)mat * RF_SPLIT + q) * 4;
-                m0 = fmax(m0, o[0]); m1 = fmax(m1, o[1]); m2 = fmax(m2, o[2]);
+                m0 = fmax(m0, o[0]); m1 = fmax(m1, o[1]); m2 = fmax(m2, o[2]); m3 = fmax(m3, o[3]);
             }
             const double an = g.anorm[mat];
             double *st = g.stats + ((size_t)mat * 8 + g.pass) * RF_STAT;
@@ -650,6 +701,7 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
             int verdict = 0;
             if (!finite) verdict = 2;
             else if (m1 <= g.tol * an && m2 <= 4.0 * g.tol) verdict = 1;      // this V is verified: residual and orthogonality
+            else if (g.predict && m0 <= RF_PREDICT_F && m3 <= g.tol * an) verdict = 3 | (g.pass << 8);
             else if (m0 > 0.125) verdict = 2;
             else if (g.pass >= 4) {
                 // a close pair is first only re-orthogonalised (gap < delta) and resolved one or two passes later, when delta
@@ -662,8 +714,203 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
             }
             if (verdict == 0 && g.last) verdict = 2;
             g.arrive[mat] = 0;
+            if (verdict != 0) g.state[g.batch + mat] = g.pass;       // the measurement pass that settled this matrix
             g.state[mat] = verdict;
         }
+    }
+}
+
+// ---- analysis + update of one refinement pass in ONE launch (round 5) ---------------------------------------------------------
+// rf_analyse_kernel writes F, a fourth product launch forms V + F V: two dependent launches per pass, 16 + 8 us at n = 256 where
+// the whole pass is 40.  Here a workgroup owns one 16 x 16 tile of the new basis: it forms the 16 rows of F it needs straight
+// into LDS (l from the diagonals of S and G, delta from the per-tile sums the product kernels left, every workgroup with the
+// same fixed-order sums -> the same delta), multiplies them with V on the matrix cores (the four waves split k) and adds the
+// old tile; the partial maxima of its F rows go to a table that the LAST workgroup of a matrix to arrive folds into the verdict.
+// The update is therefore applied in the pass that settles a matrix as well: V + F V of a VERIFIED V is the same basis to
+// O(max|F|^2), so nothing downstream renormalises with the g_aa of the measured V any more (rf_finish_kernel), and "settled by
+// prediction" (RF_PREDICT_F) needs no state of its own.
+struct RfUpdate {
+    int n, batch, pass, last, predict, ldf;
+    const double *S, *G, *anorm, *V;
+    double *Vnew, *lam, *stats, *part;     // part: [batch][tiles][4]
+    const double *sqS, *sqG;
+    unsigned *arrive;
+    int *state;
+    double tol;
+};
+
+__global__ __launch_bounds__(RF_T) void rf_update_kernel(RfUpdate g) {
+    extern __shared__ double dyn[];                 // lam[n] | Fs[16][ldf]
+    __shared__ double red4[4][4];
+    __shared__ double accp[3][4][64];
+    __shared__ double delta_s;
+    const int n = g.n, mat = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t nn = (size_t)n * n;
+    const double *__restrict__ V = g.V + mat * nn;
+    double *__restrict__ Vn = g.Vnew + mat * nn;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int x = lane & 15, q = lane >> 4;
+    if (g.state[mat] != 0) {                         // settled or failed earlier: the basis is carried to the other buffer
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + q + 4 * r, col = n0 + x;
+                if (row < n && col < n) Vn[(size_t)row * n + col] = V[(size_t)row * n + col];
+            }
+        }
+        return;
+    }
+    const double *__restrict__ S = g.S + mat * nn;
+    const double *__restrict__ G = g.G + mat * nn;
+    double *lam = dyn, *Fs = dyn + ((n + 1) & ~1);
+    const int ldf = g.ldf;
+    for (int i = tid; i < n; i += RF_T) {
+        const double l = S[(size_t)i * n + i] / G[(size_t)i * n + i];
+        lam[i] = l;
+        if (blockIdx.x == 0 && blockIdx.y == 0) g.lam[(size_t)mat * n + i] = l;
+    }
+    // |S - D|_F^2 and |R|_F^2 from the per-tile sums of the product kernels, in a fixed order (identical in every workgroup)
+    double ssd = 0.0, srr = 0.0;
+    {
+        const int nt16 = (n + 15) / 16;
+        const double *pS = g.sqS + (size_t)mat * nt16 * nt16, *pG = g.sqG + (size_t)mat * nt16 * nt16;
+        for (int t = tid; t < nt16 * nt16; t += RF_T) {
+            if (t / nt16 >= t % nt16) { ssd += pS[t]; srr += pG[t]; }
+        }
+    }
+    ssd = dmk_wave_sum(ssd);
+    srr = dmk_wave_sum(srr);
+    if (lane == 0) { red4[0][wave] = ssd; red4[1][wave] = srr; }
+    __syncthreads();
+    if (tid == 0) {
+        const double s0 = (red4[0][0] + red4[0][1]) + (red4[0][2] + red4[0][3]);
+        const double s1 = (red4[1][0] + red4[1][1]) + (red4[1][2] + red4[1][3]);
+        delta_s = fmax(2.0 * (sqrt(s0) + g.anorm[mat] * sqrt(s1)), 1.4901161193847656e-08 * g.anorm[mat]);
+    }
+    __syncthreads();
+    const double delta = delta_s;
+    // the 16 rows m0 .. m0 + 15 of F (all columns): wave <-> 4 rows, lanes along the columns
+    double maxf = 0.0, maxres = 0.0, maxr = 0.0, maxresc = 0.0;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int a = m0 + wave * 4 + rr;
+        double *frow = Fs + (size_t)(wave * 4 + rr) * ldf;
+        if (a >= n) {
+            for (int b = lane; b < n; b += 64) frow[b] = 0.0;
+            continue;
+        }
+        const double la = lam[a];
+#pragma unroll 4
+        for (int b = lane; b < n; b += 64) {
+            const double r = (a == b ? 1.0 : 0.0) - G[(size_t)a * n + b];
+            double f;
+            if (a == b) {
+                f = 0.5 * r;
+            } else {
+                const bool up_diag = (a >> 4) == (b >> 4) && a < b;          // see rf_analyse_kernel: one image of S per pair
+                const double sv = up_diag ? S[(size_t)b * n + a] : S[(size_t)a * n + b];
+                const double gap = la - lam[b];
+                const double num = fma(la, r, sv);
+                maxres = (fabs(num) <= 1.7e308) ? fmax(maxres, fabs(num)) : INFINITY;
+                if (fabs(gap) > delta) {
+                    f = num * fast_rcp(gap);
+                } else {
+                    f = 0.5 * r;
+                    maxresc = fmax(maxresc, fabs(num));
+                }
+            }
+            maxr = (fabs(r) <= 1.7e308) ? fmax(maxr, fabs(r)) : INFINITY;
+            maxf = fmax(maxf, fabs(f));
+            frow[b] = f;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        maxf = fmax(maxf, __shfl_xor(maxf, o, 64));
+        maxres = fmax(maxres, __shfl_xor(maxres, o, 64));
+        maxr = fmax(maxr, __shfl_xor(maxr, o, 64));
+        maxresc = fmax(maxresc, __shfl_xor(maxresc, o, 64));
+    }
+    if (lane == 0) { red4[0][wave] = maxf; red4[1][wave] = maxres; red4[2][wave] = maxr; red4[3][wave] = maxresc; }
+    __syncthreads();                                 // F rows and the maxima are in LDS
+    // V' tile = V tile + sum_k F[m0 + x][k] V[k][n0 + x']: A from LDS (rows of F), B strided from V; wave w takes chunks w, w + 4, ..
+    d4_t acc = d4_t{0.0, 0.0, 0.0, 0.0};
+    {
+        const int bn = n0 + x;
+        const bool b_ok = bn < n;
+        const double *fa = Fs + (size_t)x * ldf;
+        const double *bcol = V + (b_ok ? bn : 0);
+        const int nchunk = (n + 63) / 64;
+#pragma unroll 1
+        for (int c = wave; c < nchunk; c += 4) {
+            double a[16], b[16];
+            const int k0 = c * 64 + 16 * q;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int k = k0 + t;
+                a[t] = k < n ? fa[k] : 0.0;
+                b[t] = (b_ok && k < n) ? bcol[(size_t)k * n] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accp[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double v = (acc[r] + accp[0][r][lane]) + (accp[1][r][lane] + accp[2][r][lane]);
+        const int row = m0 + q + 4 * r, col = n0 + x;
+        if (row < n && col < n) Vn[(size_t)row * n + col] = V[(size_t)row * n + col] + v;
+    }
+    // verdict: partial maxima -> table, last workgroup of this matrix folds it (max is exact in any order)
+    const int ntile = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+    int is_last = 0;
+    if (lane == 0) {
+        double *mine = g.part + ((size_t)mat * ntile + me) * 4;
+        mine[0] = fmax(fmax(red4[0][0], red4[0][1]), fmax(red4[0][2], red4[0][3]));
+        mine[1] = fmax(fmax(red4[1][0], red4[1][1]), fmax(red4[1][2], red4[1][3]));
+        mine[2] = fmax(fmax(red4[2][0], red4[2][1]), fmax(red4[2][2], red4[2][3]));
+        mine[3] = fmax(fmax(red4[3][0], red4[3][1]), fmax(red4[3][2], red4[3][3]));
+        __threadfence();
+        const unsigned before = atomicAdd(&g.arrive[mat], 1u);
+        is_last = (before == (unsigned)ntile - 1u) ? 1 : 0;
+    }
+    is_last = __shfl(is_last, 0, 64);                // wave 0 only from here on
+    if (!is_last) return;
+    __threadfence();
+    double m0v = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    for (int t = lane; t < ntile; t += 64) {
+        const volatile double *o = g.part + ((size_t)mat * ntile + t) * 4;
+        m0v = fmax(m0v, o[0]); m1 = fmax(m1, o[1]); m2 = fmax(m2, o[2]); m3 = fmax(m3, o[3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        m0v = fmax(m0v, __shfl_xor(m0v, o, 64));
+        m1 = fmax(m1, __shfl_xor(m1, o, 64));
+        m2 = fmax(m2, __shfl_xor(m2, o, 64));
+        m3 = fmax(m3, __shfl_xor(m3, o, 64));
+    }
+    if (lane == 0) {
+        const double an = g.anorm[mat];
+        double *st = g.stats + ((size_t)mat * 8 + g.pass) * RF_STAT;
+        st[0] = m0v; st[1] = m1; st[2] = m2; st[3] = delta; st[4] = an;
+        const bool finite = (delta == delta) && (delta < 1.0e300) && (m1 < 1.0e300) && (m2 < 1.0e300);
+        int verdict = 0;
+        if (!finite) verdict = 2;
+        else if (m1 <= g.tol * an && m2 <= 4.0 * g.tol) verdict = 1;          // the measured V is verified (and was updated once more)
+        else if (g.predict && m0v <= RF_PREDICT_F && m3 <= g.tol * an) verdict = 3;   // settled by this update (RF_PREDICT_F)
+        else if (m0v > 0.125) verdict = 2;
+        else if (g.pass >= 4) {
+            const double prev = g.stats[((size_t)mat * 8 + g.pass - 2) * RF_STAT + 1];
+            if (m1 > 0.5 * prev) verdict = 2;                                 // stagnation: see rf_analyse_kernel
+        }
+        if (verdict == 0 && g.last) verdict = 2;
+        g.arrive[mat] = 0;
+        if (verdict != 0) g.state[g.batch + mat] = g.pass;
+        g.state[mat] = verdict;
     }
 }
 
@@ -673,14 +920,18 @@ int launch_dgemm_small_nn(dmk_ctx *ctx, int M, int N, int K, int batch, const do
 
 // Warm-start refinement driver: *ok = 1 when every matrix of the batch converged (w, Vt written), 0 when the caller has to run
 // the Jacobi sweeps (nothing written).  V0 may alias Vt.
+// `async_verdict` (device, [2][batch] ints) selects the ASYNCHRONOUS form used by the fused fit objective (dmk_fit_objective):
+// exactly `async_passes` passes are enqueued, nothing is read back, the finish launch writes w / Vt only for verified matrices
+// and leaves (state, settling pass) in `async_verdict`; *ok is then 1 and means "enqueued", not "converged".
 static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int *ok,
-                           int *passes_out) {
+                           int *passes_out, int *async_verdict = nullptr, int async_passes = 0) {
     *ok = 0;
     const size_t nn = (size_t)n * n;
     const size_t b_mat = ((nn * 8 * batch) + 255) & ~(size_t)255;
     const int nt16 = (n + 15) / 16;
-    const size_t b_small = (((size_t)batch * 8 * RF_STAT * 8) + (size_t)batch * n * 8 + (size_t)batch * RF_SPLIT * 32 +
-                            (size_t)2 * batch * nt16 * nt16 * 8 + (size_t)batch * 24 + 1023) & ~(size_t)255;
+    const size_t b_small = (((size_t)batch * 8 * RF_STAT * 8) + (size_t)batch * n * 8 +
+                            (size_t)batch * std::max(RF_SPLIT, nt16 * nt16) * 32 +
+                            (size_t)2 * batch * nt16 * nt16 * 8 + (size_t)batch * 32 + 1023) & ~(size_t)255;
     void *ws = nullptr;
     int rc = dmk_scratch(ctx, 6 * b_mat + b_small, &ws);
     if (rc) return rc;
@@ -695,13 +946,15 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
     double *stats = reinterpret_cast<double *>(p); p += (size_t)batch * 8 * RF_STAT * 8;
     double *lam = reinterpret_cast<double *>(p); p += (size_t)batch * n * 8;
     double *anorm = reinterpret_cast<double *>(p); p += (size_t)batch * 8;
-    double *part = reinterpret_cast<double *>(p); p += (size_t)batch * RF_SPLIT * 32;
+    const int ntile16 = nt16 * nt16;
+    double *part = reinterpret_cast<double *>(p); p += (size_t)batch * std::max(RF_SPLIT, ntile16) * 32;
     double *sqS = reinterpret_cast<double *>(p); p += (size_t)batch * nt16 * nt16 * 8;
     double *sqG = reinterpret_cast<double *>(p); p += (size_t)batch * nt16 * nt16 * 8;
-    int *state = reinterpret_cast<int *>(p); p += (size_t)batch * 4;
+    int *state = reinterpret_cast<int *>(p); p += (size_t)batch * 8;         // [2][batch]: verdict, settling pass
     unsigned *arrive = reinterpret_cast<unsigned *>(p);
     hipLaunchKernelGGL(rf_norm_kernel, dim3(batch), dim3(1024), 0, ctx->stream, n, A, anorm, state, arrive);
-    const dim3 tiles((n + 31) / 32, (n + 31) / 32, 1);
+    const dim3 tiles((n + 15) / 16, (n + 15) / 16, 1);             // one 16 x 16 tile per workgroup, K split over its waves
+    int cur = 0, pass = 0;
     auto gemm = [&](bool nn_mode, int nprob, const double *a0, const double *b0, const double *add0, double *c0, const double *a1,
                     const double *b1, double *c1, int run_mask, int copy_mask, bool masked, int symm0 = 0, int symm1 = 0) {
         RfGemm g;
@@ -712,21 +965,40 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
         g.n = n; g.batch = batch; g.nprob = nprob;
         g.A[0] = a0; g.B[0] = b0; g.Cadd[0] = add0; g.C[0] = c0;
         g.A[1] = a1; g.B[1] = b1; g.Cadd[1] = nullptr; g.C[1] = c1;
-        g.state = masked ? state : nullptr; g.run_mask = run_mask; g.copy_mask = copy_mask;
+        g.state = masked ? state : nullptr; g.run_mask = run_mask; g.copy_mask = copy_mask; g.pass = pass;
         const dim3 grid(tiles.x, tiles.y, (unsigned)(batch * nprob));
         if (nn_mode) hipLaunchKernelGGL(rf_gemm_kernel<true>, grid, dim3(RF_T), 0, ctx->stream, g);
         else hipLaunchKernelGGL(rf_gemm_kernel<false>, grid, dim3(RF_T), 0, ctx->stream, g);
     };
     const double tol = 4.0 * sqrt((double)n) * 2.220446049250313e-16;
+    static const bool predict_on = !(getenv("DMK_EIGH_PREDICT") && atoi(getenv("DMK_EIGH_PREDICT")) == 0);
     const double *Vc = V0;
-    int cur = 0, pass = 0;
     std::vector<int> st(batch);
+    static const bool fused_update = !(getenv("DMK_EIGH_FUSED_UPDATE") && atoi(getenv("DMK_EIGH_FUSED_UPDATE")) == 0);
+    const int ldf = ((n + 15) & ~15) + 2;                      // LDS row stride of the F rows (bank spread)
+    const size_t upd_lds = ((size_t)((n + 1) & ~1) + (size_t)16 * ldf) * sizeof(double);
+    const bool use_fused = fused_update && upd_lds <= 96 * 1024;
+    if (use_fused && upd_lds > 48 * 1024)
+        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)upd_lds));
     auto enqueue_pass = [&](bool last) {
         gemm(false, 2, Vc, A, nullptr, T1, Vc, Vc, G, 1 << 0, 0, true, 0, 1);      // T1 = V A (A symmetric), G = V V^T
         gemm(false, 1, T1, Vc, nullptr, S, nullptr, nullptr, nullptr, 1 << 0, 0, true, 1);   // S = T1 V^T
+        if (use_fused) {
+            RfUpdate u;
+            u.n = n; u.batch = batch; u.pass = pass; u.last = last ? 1 : 0; u.predict = predict_on ? 1 : 0; u.ldf = ldf;
+            u.S = S; u.G = G; u.anorm = anorm; u.V = Vc; u.Vnew = Vb[cur]; u.lam = lam; u.stats = stats; u.part = part;
+            u.sqS = sqS; u.sqG = sqG; u.arrive = arrive; u.state = state; u.tol = tol;
+            hipLaunchKernelGGL(rf_update_kernel, dim3(tiles.x, tiles.y, batch), dim3(RF_T), upd_lds, ctx->stream, u);
+            Vc = Vb[cur];
+            cur ^= 1;
+            ++pass;
+            return;
+        }
         RfAnalyse a;
         a.n = n; a.batch = batch; a.pass = pass; a.last = last ? 1 : 0;
         a.S = S; a.G = G; a.anorm = anorm; a.F = F; a.lam = lam; a.stats = stats; a.state = state; a.tol = tol;
+        a.predict = predict_on ? 1 : 0;
         a.part = part; a.arrive = arrive; a.sqS = sqS; a.sqG = sqG;
         hipLaunchKernelGGL(rf_analyse_kernel, dim3(batch * RF_SPLIT), dim3(1024), (size_t)n * 8, ctx->stream, a);
         gemm(true, 1, F, Vc, Vc, Vb[cur], nullptr, nullptr, nullptr, 1 << 0, (1 << 1) | (1 << 2), true);   // V + F V
@@ -739,10 +1011,20 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
         *good = true;
         for (int i = 0; i < batch; ++i) {
             if (st[i] == 0) done = false;
-            if (st[i] == 2) *good = false;
+            if ((st[i] & 0xff) == 2) *good = false;
         }
         return done;
     };
+    if (async_verdict) {
+        const int np = std::max(1, std::min(async_passes, 8));
+        for (int i = 0; i < np; ++i) enqueue_pass(i == 7);
+        hipLaunchKernelGGL(rf_finish_kernel, dim3((n + 15) / 16, batch), dim3(256), (size_t)n * 8, ctx->stream, n, Vc, G, lam, w, Vt,
+                           state, batch, async_verdict, use_fused ? 1 : 0);
+        DMK_CHECK_LAUNCH(ctx);
+        if (passes_out) *passes_out = pass;
+        *ok = 1;
+        return DMK_OK;
+    }
     bool good = true, done = false;
     const int plan[3] = {3, 4, 1};                 // passes before the first / second / third look at the verdict
     for (int round = 0; round < 3 && !done; ++round) {
@@ -766,10 +1048,22 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
             }
     }
     if (!done || !good) return DMK_OK;
-    hipLaunchKernelGGL(rf_finish_kernel, dim3((n + 15) / 16, batch), dim3(256), (size_t)n * 8, ctx->stream, n, Vc, G, lam, w, Vt);
+    hipLaunchKernelGGL(rf_finish_kernel, dim3((n + 15) / 16, batch), dim3(256), (size_t)n * 8, ctx->stream, n, Vc, G, lam, w, Vt,
+                       (const int *)state, batch, (int *)nullptr, use_fused ? 1 : 0);
     DMK_CHECK_LAUNCH(ctx);
     *ok = 1;
     return DMK_OK;
+}
+
+// Internal entry for csrc/fit.hip: warm refinement of `batch` n x n symmetric matrices from the basis V0, ENQUEUED only (see
+// eigh_refine_try).  verdict_dev [2][batch]: state (1 verified: w, Vt written; 0 not yet settled after `npass` passes; 2 failed)
+// and the measurement pass that settled it.
+int dmk_eigh_refine_enqueue(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int npass,
+                            int *verdict_dev) {
+    if (!ctx || n <= 0 || batch <= 0 || !A || !V0 || !w || !Vt || !verdict_dev) return DMK_ERR_INVALID;
+    FamScope fs(ctx, DMK_FAM_EIGH);
+    int ok = 0;
+    return eigh_refine_try(ctx, n, batch, A, V0, w, Vt, &ok, nullptr, verdict_dev, npass);
 }
 
 extern "C" {

@@ -19,225 +19,62 @@
 #include "common.h"
 #include <cmath>
 
+#include "occ_body.h"
+
 namespace {
 
-constexpr int OCC_NT = 1024;
+__global__ __launch_bounds__(OCC_NT) void occ_zero_t_kernel(const OccArgs g) { occ_zero_t_body(g); }
 
-__device__ __forceinline__ unsigned long long occ_key(double x) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double occ_val(unsigned long long k) {
-    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-
-// block-wide sums over OCC_NT threads; every thread receives the total (fixed combination order)
-__device__ double block_sum_f64(double v, double *sh) {
-    v = dmk_wave_sum(v);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[wave] = v;
-    __syncthreads();
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < OCC_NT / 64; ++w) t += sh[w];
-    return t;
-}
-__device__ long long block_sum_i64(long long v, long long *sh) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[wave] = v;
-    __syncthreads();
-    long long t = 0;
-#pragma unroll
-    for (int w = 0; w < OCC_NT / 64; ++w) t += sh[w];
-    return t;
-}
-
-// number of levels that are NaN or +-Inf: such a spectrum has no order statistics (the reference fails at its sort / index
-// step); the kernels report status 2 instead of ranking the bit patterns
-__device__ long long count_nonfinite(const double *__restrict__ e, long long n, long long *sh) {
-    long long c = 0;
-    for (long long i = threadIdx.x; i < n; i += OCC_NT) c += (fabs(e[i]) <= 1.7976931348623157e308) ? 0 : 1;
-    return block_sum_i64(c, sh);
-}
-
-constexpr int OCC_SMALL = 2048;      // spectra up to this size are ranked directly in LDS (model lattices: 12 - 150 levels)
-
-// element of rank k (0-based) in ascending order
-__device__ double kth_smallest(const double *__restrict__ e, long long n, long long k, long long *sh) {
-    if (n <= OCC_SMALL) {
-        // small spectra: every thread counts the elements ordered before its own (ties by index, like a stable sort) and
-        // the one whose count is k publishes itself -- two barriers instead of the 128 of the bit-pattern bisection
-        __shared__ double es[OCC_SMALL];
-        __shared__ double found;
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += OCC_NT) es[i] = e[i];
-        if (threadIdx.x == 0) found = __longlong_as_double(0x7ff8000000000000ll);   // no thread matches (k out of range): NaN, never stale LDS
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += OCC_NT) {
-            const double x = es[i];
-            int before = 0;
-            for (int j = 0; j < n; ++j) before += (es[j] < x || (es[j] == x && j < i)) ? 1 : 0;
-            if (before == k) found = x;
-        }
-        __syncthreads();
-        return found;
-    }
-    unsigned long long prefix = 0;
-    for (int bit = 63; bit >= 0; --bit) {
-        // among the keys that agree with `prefix` above `bit`, how many have this bit clear?
-        const unsigned long long hi_mask = bit == 63 ? 0ull : (~0ull << (bit + 1));
-        long long c = 0;
-        for (long long i = threadIdx.x; i < n; i += OCC_NT) {
-            const unsigned long long key = occ_key(e[i]);
-            c += ((key & hi_mask) == prefix && !((key >> bit) & 1ull)) ? 1 : 0;
-        }
-        c = block_sum_i64(c, sh);
-        if (k >= c) {
-            k -= c;
-            prefix |= 1ull << bit;
-        }
-    }
-    return occ_val(prefix);
-}
-
-__device__ __forceinline__ double fermi(double e, double mu, double beta) {
-    const double de = beta * (e - mu);
-    return de < 100.0 ? 1.0 / (exp(de) + 1.0) : 0.0;            // the reference's cut-off (ftsystem.py:43)
-}
-
-struct OccArgs {
-    const double *ew;
-    long long n;
-    double nelec, beta, mu0, thr, tol;
-    int has_mu0, fix_mu;
-    int sorted;         // the levels are in ascending order: rank k is e[k], no order-statistics search
-    double *occ;
-    double *out;        // [0] mu, [1] nerr, [2] electrons spread over the window, [3] levels in the window, [4] status
+// several independent spectra (the spin channels of an embedding problem) in ONE launch: workgroup b takes spectrum b
+constexpr int OCC_MAXBATCH = 8;
+struct OccBatchArgs {
+    OccArgs base;                         // ew / occ / out of spectrum 0; spectrum b at + b * n (ew, occ) and + 8 b (out)
+    double nelec[OCC_MAXBATCH], mu0[OCC_MAXBATCH];
 };
-
-__global__ __launch_bounds__(OCC_NT) void occ_zero_t_kernel(const OccArgs g) {
-    __shared__ long long shi[OCC_NT / 64];
-    const double *e = g.ew;
-    const long long n = g.n, ne = (long long)g.nelec;
-    if (count_nonfinite(e, n, shi) != 0) {
-        if (threadIdx.x == 0) { g.out[0] = g.out[1] = g.out[2] = g.out[3] = 0.0; g.out[4] = 2.0; }
-        return;
-    }
-    double mu = g.mu0;
-    bool keep = false;
-    if (g.has_mu0) {
-        long long below = 0, upto = 0;
-        for (long long i = threadIdx.x; i < n; i += OCC_NT) {
-            below += e[i] < g.mu0 - g.thr ? 1 : 0;
-            upto += e[i] <= g.mu0 + g.thr ? 1 : 0;
-        }
-        below = block_sum_i64(below, shi);
-        upto = block_sum_i64(upto, shi);
-        keep = below <= ne && upto >= ne;
-    }
-    if (!keep) {
-        // ranks ne - 1 and ne of the ascending order; rank -1 wraps to the largest level like the host indexing does
-        const long long klo = ne > 0 ? ne - 1 : n - 1, khi = ne < n ? ne : n - 1;
-        const double lo = g.sorted ? e[klo] : kth_smallest(e, n, klo, shi);
-        const double hi = g.sorted ? e[khi] : kth_smallest(e, n, khi, shi);
-        mu = 0.5 * (lo + hi);
-    }
-    long long filled = 0, window = 0;
-    for (long long i = threadIdx.x; i < n; i += OCC_NT) {
-        filled += e[i] < mu - g.thr ? 1 : 0;
-        window += (e[i] <= mu + g.thr && e[i] >= mu - g.thr) ? 1 : 0;
-    }
-    filled = block_sum_i64(filled, shi);
-    window = block_sum_i64(window, shi);
-    const long long remain = ne - filled;
-    const double share = (remain > 0 && window > 0) ? (double)remain / (double)window : 0.0;
-    for (long long i = threadIdx.x; i < n; i += OCC_NT) {
-        double o = e[i] < mu - g.thr ? 1.0 : 0.0;
-        if (remain > 0 && e[i] <= mu + g.thr && e[i] >= mu - g.thr) o += share;
-        g.occ[i] = o;
-    }
-    if (threadIdx.x == 0) {
-        g.out[0] = mu;
-        g.out[1] = 0.0;
-        g.out[2] = remain > 0 ? (double)remain : 0.0;
-        g.out[3] = remain > 0 ? (double)window : 0.0;
-        g.out[4] = 0.0;
-    }
+__global__ __launch_bounds__(OCC_NT) void occ_zero_t_batch_kernel(const OccBatchArgs gb) {
+    OccArgs g = gb.base;
+    const int b = blockIdx.x;
+    g.ew += (long long)b * g.n;
+    g.occ += (long long)b * g.n;
+    g.out += 8 * b;
+    // constant-index picks: a dynamically indexed kernel-argument array would be copied to scratch
+    double ne = gb.nelec[0], m0 = gb.mu0[0];
+#pragma unroll
+    for (int i = 1; i < OCC_MAXBATCH; ++i)
+        if (b == i) { ne = gb.nelec[i]; m0 = gb.mu0[i]; }
+    g.nelec = ne;
+    g.mu0 = m0;
+    occ_zero_t_body(g);
 }
 
-__global__ __launch_bounds__(OCC_NT) void occ_fermi_kernel(const OccArgs g) {
-    __shared__ long long shi[OCC_NT / 64];
-    __shared__ double shd[OCC_NT / 64];
-    const double *e = g.ew;
-    const long long n = g.n;
-    const double beta = g.beta, target = g.nelec;
-    if (count_nonfinite(e, n, shi) != 0) {
-        if (threadIdx.x == 0) { g.out[0] = g.out[1] = g.out[2] = g.out[3] = 0.0; g.out[4] = 2.0; }
-        return;
-    }
-    double mu = g.mu0, status = 0.0;
-
-    auto count = [&](double x, double &slope) {       // N(x) - target and dN/dx
-        double s = 0.0, d = 0.0;
-        for (long long i = threadIdx.x; i < n; i += OCC_NT) {
-            const double f = fermi(e[i], x, beta);
-            s += f;
-            d += f * (1.0 - f);
-        }
-        s = block_sum_f64(s, shd);
-        slope = beta * block_sum_f64(d, shd);
-        return s - target;
-    };
-
-    if (!g.fix_mu) {
-        const long long ni = llrint(target);
-        const long long rlo = ni - 1 < 0 ? 0 : (ni - 1 > n - 1 ? n - 1 : ni - 1), rhi = ni < 0 ? 0 : (ni > n - 1 ? n - 1 : ni);
-        const double width = 1.0 / beta;
-        double lo = kth_smallest(e, n, rlo, shi) - width;
-        double hi = kth_smallest(e, n, rhi, shi) + width;
-        double dummy, flo = count(lo, dummy), fhi = count(hi, dummy);
-        double grow = fmax(width, 1.0);
-        for (int it = 0; it < 80 && flo > 0.0; ++it) { lo -= grow; grow *= 2.0; flo = count(lo, dummy); }
-        grow = fmax(width, 1.0);
-        for (int it = 0; it < 80 && fhi < 0.0; ++it) { hi += grow; grow *= 2.0; fhi = count(hi, dummy); }
-        if (flo > 0.0 || fhi < 0.0) status = 1.0;          // no sign change: nelec outside (0, n)
-        double x = 0.5 * (lo + hi);
-        for (int it = 0; it < 200 && status == 0.0; ++it) {
-            double slope;
-            const double f = count(x, slope);
-            if (f == 0.0) break;
-            if (f < 0.0) lo = x; else hi = x;
-            double xn = slope > 0.0 ? x - f / slope : 0.5 * (lo + hi);
-            if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-            const double step = fabs(xn - x);
-            x = xn;
-            // Newton converges quadratically: once a step is below the tolerance the error is far below it
-            if (step <= 0.25 * g.tol * (1.0 + fabs(x)) || hi - lo <= 4.0e-16 * (1.0 + fabs(x))) break;
-        }
-        mu = x;
-    }
-    double s = 0.0;
-    for (long long i = threadIdx.x; i < n; i += OCC_NT) {
-        const double f = fermi(e[i], mu, beta);
-        g.occ[i] = f;
-        s += f;
-    }
-    s = block_sum_f64(s, shd);
-    if (threadIdx.x == 0) {
-        g.out[0] = mu;
-        g.out[1] = fabs(s - target);
-        g.out[2] = 0.0;
-        g.out[3] = 0.0;
-        g.out[4] = status;
-    }
-}
+__global__ __launch_bounds__(OCC_NT) void occ_fermi_kernel(const OccArgs g) { occ_fermi_body(g); }
 
 }  // namespace
+
+// T = 0 occupations of `batch` spectra of n levels each (ew, occ: [batch][n]) in one launch, nothing read back; info_dev
+// [batch][8] receives (mu, nerr, spread, window, status) per spectrum.  Internal (csrc/fit.hip: dmk_fit_objective).
+int dmk_assign_occ_zero_t_batch(dmk_ctx *ctx, int64_t n, int batch, const double *ew, const double *nelec_host,
+                                const double *mu0_host, int flags, double thr_deg, double *occ, double *info_dev) {
+    if (!ctx || n <= 0 || batch < 1 || batch > OCC_MAXBATCH || !ew || !occ || !nelec_host || !info_dev) return DMK_ERR_INVALID;
+    OccBatchArgs a;
+    a.base.ew = ew; a.base.n = n; a.base.nelec = 0.0; a.base.beta = INFINITY; a.base.mu0 = 0.0; a.base.thr = thr_deg;
+    a.base.tol = 1e-12;
+    a.base.has_mu0 = (flags & 1) ? 1 : 0;
+    a.base.fix_mu = (flags & 2) ? 1 : 0;
+    a.base.sorted = (flags & 4) ? 1 : 0;
+    a.base.occ = occ; a.base.out = info_dev;
+    for (int i = 0; i < OCC_MAXBATCH; ++i) {
+        a.nelec[i] = nelec_host[i < batch ? i : 0];
+        a.mu0[i] = mu0_host ? mu0_host[i < batch ? i : 0] : 0.0;
+        const double ne = a.nelec[i];
+        if (ne < 0.0 || ne > (double)n || ne != std::floor(ne))
+            return dmk_fail(ctx, DMK_ERR_INVALID, "assign_occ: T = 0 needs an integer 0 <= nelec <= %lld levels", (long long)n);
+    }
+    FamScope fs(ctx, DMK_FAM_MISC);
+    hipLaunchKernelGGL(occ_zero_t_batch_kernel, dim3(batch), dim3(OCC_NT), 0, ctx->stream, a);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
+}
 
 extern "C" int dmk_assign_occ(dmk_ctx *ctx, int64_t n, const double *ew, double nelec, double beta, double mu0, int flags,
                               double thr_deg, double fit_tol, double *occ, double *info_host) {

@@ -306,6 +306,9 @@ def vcor_fit_stage(ctx, sysm, d_basis, nemb, rdm1_emb, MaxIter=5, beta=np.inf, s
     return {"nparam": int(v.length()), "nemb": int(nemb), "MaxIter": int(MaxIter), "err_begin": float(e0), "err_end": float(e1),
             "param_err_begin": float(np.abs(p_true).max()), "param_err_end": float(np.abs(p - p_true).max()),
             "seconds_total": t_total, "objective_evals": int(fit.nfev), "gradient_evals": int(fit.ngev),
+            "fused_objective_calls": int(getattr(fit, "fused_calls", 0)), "fused_objective_fallbacks": int(getattr(fit, "fused_fallbacks", 0)),
+            "table_passes_saved": int(getattr(fit, "table_passes_saved", 0)), "on_ray_hits": list(getattr(fit, "on_ray_hits", [])),
+            "refinement_settle_pass_histogram": {str(k): int(n) for k, n in sorted(getattr(fit, "settle_hist", {}).items())},
             "reference_tolerances": {"seconds_total": t_ref, "objective_evals": ref_counts[0], "gradient_evals": ref_counts[1],
                                      "err_end": float(e1_ref), "param_err_end": float(np.abs(p_ref - p_true).max()),
                                      "note": "UNCONVERGED: at the reference's default stopping rules this synthetic problem stops after "

@@ -563,7 +563,59 @@ class EmbFitDevice(object):
         choice = os.environ.get("DMK_FIT_EIGH", eigh)
         self.use_jacobi = (choice == "jacobi") and nb <= 576 and spin * ((nb + 31) // 32) <= 256
         self._have_prev, self.sweeps = False, 0
-        self._ray = None
+        self._ray, self._ray_host = None, None
+        self.table_passes_saved = 0
+        self.on_ray_hits = [0, 0]                      # table passes saved at a gradient's forward pass / at the start of a ray
+        # fused native objective (dmk_fit_objective): T = 0, orthonormal embedding basis, warm eigensolver.  DMK_FIT_FUSED=0 keeps
+        # the chain of separate calls (which stays the path of the first evaluation, of finite T and of every fallback)
+        self._fused = None
+        self.fused_calls = self.fused_fallbacks = 0
+        self.settle_hist = {}                          # measurement pass that settled the refinement -> evaluations
+        if (self.beta == np.inf and self.d_X is None and self.use_jacobi and os.environ.get("DMK_FIT_FUSED", "1") != "0"
+                and ((nidx + 15) // 16) ** 2 * spin <= 2048):
+            self._fused_setup()
+
+    # -- fused native objective ----------------------------------------------------------------------
+    def _fused_setup(self):
+        from libdmet_preview_amd._lib import FitArgs, PinnedArray
+        ctx, spin, nb = self.ctx, self.spin, self.nb
+        ne = [self.nelec] if spin == 1 else list(self.nelec)
+        ne = [float(self._mfd.check_nelec(x, None)[0]) for x in ne]
+        self._f_nelec = (C.c_double * spin)(*ne)
+        mu = [0.0] * spin
+        if self.fix_mu:
+            mu = [float(self.mu0)] * spin if np.ndim(self.mu0) == 0 else [float(x) for x in self.mu0]
+        self._f_mu0 = (C.c_double * spin)(*mu)
+        self._f_work = ctx.zeros((4096,), np.float64)
+        self._f_slot = PinnedArray(ctx, (64,), np.float64)
+        self._f_slot.a[:] = 0.0
+        a = FitArgs()
+        a.nb, a.spin, a.nidx, a.npass, a.has_mu0 = nb, spin, self.nidx, 3, 1 if self.fix_mu else 0
+        a.tol_deg = float(self.tol_deg)
+        a.H1, a.H, a.Vp, a.w, a.occ = self.d_H1.ptr, self.d_H.ptr, self.d_Vp.ptr, self.d_w.ptr, self.d_occ.ptr
+        a.nelec, a.mu0 = C.cast(self._f_nelec, C.c_void_p), C.cast(self._f_mu0, C.c_void_p)
+        a.fit_idx, a.W, a.target = self.d_fit.ptr, self.d_W.ptr, self.d_target.ptr
+        a.drho, a.work, a.slot = self.d_drho.ptr, self._f_work.ptr, self._f_slot.ptr
+        self._fused = a
+        self._f_out = (C.c_double(), C.c_int(), C.c_int())
+
+    def _forward_fused(self, d_v0, d_v1, t):
+        """The whole objective in one library call (csrc/fit.hip dmk_fit_objective); None when the enqueued refinement did not
+        verify its basis (the caller then runs the chain of separate, synchronous calls)."""
+        a = self._fused
+        a.v0, a.v1, a.t = d_v0.ptr, (None if d_v1 is None else d_v1.ptr), float(t)
+        f2, st, sp = self._f_out
+        self.ctx.check(lib.dmk_fit_objective(self.ctx.h, C.byref(a), C.byref(f2), C.byref(st), C.byref(sp)))
+        self.fused_calls += 1
+        if st.value == 2:
+            raise FloatingPointError("FitVcorEmb: non-finite embedding levels in the T = 0 forward pass")
+        if st.value != 0:
+            self.fused_fallbacks += 1
+            a.npass = min(a.npass + 2, 8)
+            return None
+        self.settle_hist[sp.value] = self.settle_hist.get(sp.value, 0) + 1
+        a.npass = min(max(sp.value + 2, 2), 8)           # settled at measurement pass sp (0-based): one spare pass next time
+        return float(np.sqrt(f2.value))
 
     # -- forward pass ------------------------------------------------------------------------------
     def _gemm(self, opA, opB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0):
@@ -591,8 +643,20 @@ class EmbFitDevice(object):
             return self._state
         ctx, spin, nb, nidx = self.ctx, self.spin, self.nb, self.nidx
         if ray is None:
-            self._vemb_into(param, self.d_vemb)
-        else:
+            # a point of the current line-search ray (the gradient at the accepted step): V_emb from the ray, no table pass
+            t_on = self._on_ray(param)
+            if t_on is not None:
+                ray = self._ray[self._ray_cur] + (t_on,)
+                self.table_passes_saved += 1
+                self.on_ray_hits[0] += 1
+            else:
+                self._vemb_into(param, self.d_vemb)
+        if self._fused is not None and self._have_prev:
+            val = self._forward_fused(*((self.d_vemb, None, 0.0) if ray is None else ray))
+            if val is not None:
+                self._key, self._state = key, (None, None, None, val, self.d_Vp)
+                return self._state
+        if ray is not None:
             d_v0, d_v1, t = ray                                   # V_emb(x + t p) = V_emb(x) + t V_emb(p)
             ctx.check(lib.dmk_memcpy_d2d(ctx.h, self.d_vemb.ptr, d_v0.ptr, self.d_vemb.nbytes))
             ctx.check(lib.dmk_axpy_f64(ctx.h, spin * self.npair, float(t), d_v1.ptr, self.d_vemb.ptr))
@@ -657,20 +721,53 @@ class EmbFitDevice(object):
         self.nfev += 1
         return self._forward(param)[3] / sqrt(self.spin)
 
+    def _on_ray(self, param):
+        """t with param == x + t p BITWISE for the current line-search ray and a step t that was evaluated on it (the optimiser
+        forms its next point as xk + alpha_k pk from the arrays it handed to errfunc_ray and a step the search returned), else
+        None.  One vector operation: the candidate is the evaluated step closest to the quotient of the largest component."""
+        r = self._ray_host
+        if r is None or not r["ts"] or param.shape != r["x"].shape:
+            return None
+        i = r["imax"]
+        if r["p"][i] == 0.0:
+            return None
+        guess = (param[i] - r["x"][i]) / r["p"][i]
+        t = min(r["ts"], key=lambda u: abs(u - guess))
+        return t if np.array_equal(r["x"] + t * r["p"], param) else None
+
     def errfunc_ray(self, x, p):
         """phi(t) = errfunc(x + t p) for a line search: the embedding potential is LINEAR in the parameters, so the two
         table passes V_emb(x), V_emb(p) are made once and every trial step is an axpy of spin * npair numbers (the pass over
-        dV_dparam was half of an objective evaluation at C5)."""
+        dV_dparam was half of an objective evaluation at C5).  Round 5: when x itself lies on the PREVIOUS ray (x = x' + t p':
+        the CG / BFGS drivers step exactly that way), V_emb(x) = V_emb(x') + t V_emb(p') is an axpy too and only V_emb(p) costs
+        a table pass; every 16th ray takes the real pass so that the recursion cannot drift."""
         x, p = np.array(x, dtype=np.float64), np.array(p, dtype=np.float64)
         if self._ray is None:
-            self._ray = (self.ctx.empty((self.spin, self.npair), np.float64), self.ctx.empty((self.spin, self.npair), np.float64))
-        d_v0, d_v1 = self._ray
-        self._vemb_into(x, d_v0)
+            e = lambda: self.ctx.empty((self.spin, self.npair), np.float64)
+            self._ray = [(e(), e()), (e(), e())]
+            self._ray_cur, self._ray_age = 0, 0
+        t_prev = self._on_ray(x) if self._ray_age < 16 else None
+        old_v0, old_v1 = self._ray[self._ray_cur]
+        self._ray_cur ^= 1
+        d_v0, d_v1 = self._ray[self._ray_cur]
+        if t_prev is not None:
+            ctx = self.ctx
+            ctx.check(lib.dmk_memcpy_d2d(ctx.h, d_v0.ptr, old_v0.ptr, d_v0.nbytes))
+            ctx.check(lib.dmk_axpy_f64(ctx.h, self.spin * self.npair, float(t_prev), old_v1.ptr, d_v0.ptr))
+            self._ray_age += 1
+            self.table_passes_saved += 1
+            self.on_ray_hits[1] += 1
+        else:
+            self._vemb_into(x, d_v0)
+            self._ray_age = 0
         self._vemb_into(p, d_v1)
+        self._ray_host = {"x": x, "p": p, "ts": [], "imax": int(np.argmax(np.abs(p))) if p.size else 0}
+        ts = self._ray_host["ts"]
 
         def phi(t):
             t = float(np.asarray(t).ravel()[0])                   # the Nelder-Mead fallback passes a 1-vector
             self.nfev += 1
+            ts.append(t)
             return self._forward(x + t * p, ray=(d_v0, d_v1, t))[3] / sqrt(self.spin)
         return phi
 

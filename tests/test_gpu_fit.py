@@ -396,3 +396,28 @@ def test_fit_c5_shape_objective_and_gradient_vs_oracle(ctx):
         assert abs(e - e_ref) < 1e-10, (scale, e, e_ref)
         gq, g_ref = fit.gradfunc(p), ref.gradfunc(p)
         assert np.abs(gq - g_ref).max() < 1e-8 * max(1.0, np.abs(g_ref).max()), (scale, np.abs(gq - g_ref).max())
+    # the FUSED native objective (dmk_fit_objective: one call per evaluation) along a line-search ray: against the oracle, against
+    # the chain of separate calls on the same ray, and through its fall-back when the enqueued refinement cannot settle in time
+    assert fit._fused is not None and fit.fused_calls >= 1
+    x0, d = 0.03 * rng.standard_normal(3192), 2e-4 * rng.standard_normal(3192)     # line-search sized steps
+    phi = fit.errfunc_ray(x0, d)
+    ts = [0.0, 1.0, 0.37, 0.6, 0.52, 0.55]
+    phi(0.0)                                                                         # settle the basis at the start of the ray
+    fb0 = fit.fused_fallbacks
+    vals = [phi(t) for t in ts]
+    n_fused = fit.fused_calls
+    for t, e in zip(ts, vals):
+        assert abs(e - ref.errfunc(x0 + t * d)) < 1e-10, t
+    gq, g_ref = fit.gradfunc(x0 + ts[-1] * d), ref.gradfunc(x0 + ts[-1] * d)         # gradient from the fused forward's state
+    assert np.abs(gq - g_ref).max() < 1e-8 * max(1.0, np.abs(g_ref).max())
+    chain = slater.EmbFitDevice(ctx, target, L, basis, v, np.inf, ne, list(range(nemb)), [], Fk, Sk)
+    chain._fused = None                                                              # the separate-call path
+    phi_c = chain.errfunc_ray(x0, d)
+    assert max(abs(phi_c(t) - e) for t, e in zip(ts, vals)) < 1e-12
+    assert chain.fused_calls == 0 and fit.fused_fallbacks - fb0 <= 2, (fit.fused_fallbacks, fb0, fit._fused.npass)   # most took the fast path
+    # a big jump with ONE enqueued pass cannot verify: status 1 -> the synchronous solver takes over, same value
+    fit._fused.npass = 1
+    big = x0 + 4000.0 * d
+    e_big = fit.errfunc(big)
+    assert fit.fused_fallbacks >= 1 and abs(e_big - ref.errfunc(big)) < 1e-10
+    assert fit.fused_calls > n_fused
