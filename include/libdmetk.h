@@ -355,6 +355,10 @@ int dmk_eri_imag_buffer(dmk_eri *h, double **imag_out, int64_t *elems_out);
 /* Procedural DF block (synthetic configs): Philox4x32-10,
  * key (seed_lo, seed_hi), counter (e>>1 lo, e>>1 hi, ki, kj), e = (L*nao+p)*nao+q. */
 int dmk_df_block_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
+/* `nblk` blocks in one launch: block b = pair (ij[2b], ij[2b+1]) (host array) written at out + b * stride_bytes (device; the
+ * queue slots of dmk_eri_block_ring are spaced by the block size) on `stream`.  Same values as nblk calls of the above. */
+int dmk_df_blocks_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int nblk, const int32_t *ij, int naux, int nao, void *out,
+                            int64_t stride_bytes);
 int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao,
                         void *Lpq_out);
 
@@ -457,6 +461,27 @@ int dmk_axpy_f64(dmk_ctx *ctx, int64_t n, double alpha, const double *x, double 
  * Replaces the loop over transform_local_sparseH at slater.py:868-877 (slater_helper.py:91-100). */
 int dmk_vcor_dV_dparam(dmk_ctx *ctx, int nent, int nb, const double *G, int64_t ldg, const int32_t *nz_ptr,
                        const int32_t *nz_i, const int32_t *nz_j, const double *nz_val, const int64_t *out_off, double *dV);
+
+/* SMALL model lattices (Hubbard cells of <= 8 orbitals, spin * nk <= 256 blocks, nk <= 128): one mean-field step of routine/mfd.py
+ * HF() -- eigenpairs of every (spin, k) block of Fock_k (+ the shared real shift `add`, as dmk_eigh_batched), occupations and mu of
+ * ALL levels as one particle-number sector (flags / mu0 / thr_deg / fit_tol as dmk_assign_occ; beta = INFINITY: T = 0), rho_k =
+ * (ev occ) ev^H and its k -> R fold (real part; system/fourier.py:168-177) -- as ONE launch of one workgroup, nothing read back.
+ *   ew, occ (spin nk, n); Vt (spin nk, n, n) c128, ROW m = eigenvector m; rho_k (spin nk, n, n) c128; rho_R (spin, nk, n n) f64
+ *   info_dev[8]: mu, nerr, electrons spread over the degeneracy window, levels in it, status (0 ok / 1 no mu / 2 non-finite
+ *   levels), max |Im| of the folded density, Jacobi not converged (0 / 1)
+ * *handled = 0 (and nothing launched) when the shape is outside the limits: the caller then takes dmk_eigh_batched + dmk_assign_occ
+ * + dmk_occ_density + dmk_fold_k2R. */
+int dmk_small_meanfield(dmk_ctx *ctx, const int mesh[3], int n, int spin, const void *Fock_k, const double *add, int add_group,
+                        double nelec, double beta, double mu0, int flags, double thr_deg, double fit_tol, double *ew, double *occ,
+                        void *Vt, void *rho_k, double *rho_R, double *info_dev, int *handled);
+/* ... and the Schmidt bath of routine/slater.py:117-220 (_get_emb_basis_svd) for nb <= 8 bath columns as ONE launch: the env x imp
+ * block of the stripe rdm1 (index maps as dmk_bath_svd), Householder QR + one-sided Jacobi SVD, nbath_s = #(sigma >= tol_bath) per
+ * spin, virtual rows zeroed + Loewdin (orth) and the embedding basis [imp identity | bath] of every spin channel with
+ * ncol = nimp + min_s nbath_s columns, PACKED with leading dimension ncol in `basis` (room for nimp + nb columns required).
+ *   sigma (spin, nb); U (spin, nenv, nb) or NULL; iout_dev: [0] ncol, [1 + s] nbath_s, [1 + spin] SVD not converged (0 / 1). */
+int dmk_small_bath(dmk_ctx *ctx, const int mesh[3], int nlo, int spin, const double *rdm1, int64_t rdm1_stride, const int32_t *env_idx,
+                   int nenv, const int32_t *bath_col, int nb, const int32_t *virt_mask, int orth, const int32_t *imp_idx, int nimp,
+                   int nsites, double tol_bath, double *sigma, double *U, double *basis, int32_t *iout_dev, int *handled);
 
 /* The whole T = 0 objective of FitVcorEmb along a ray of the parameter space as ONE call (errfunc, routine/slater.py:1059-1124:
  * V_emb = sum_p param_p dV_dparam_p is linear in the parameters, so a line search x + t p evaluates V_emb = v0 + t v1):

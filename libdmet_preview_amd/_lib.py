@@ -118,7 +118,12 @@ PROTOTYPES = {
     "dmk_scatter2d_add_f64": (c_int, [c_vp, c_int, c_vp, c_vp, c_dbl, c_vp, c_i64, c_int]),
     "dmk_axpy_f64": (c_int, [c_vp, c_i64, c_dbl, c_vp, c_vp]),
     "dmk_vcor_dV_dparam": (c_int, [c_vp, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "dmk_df_blocks_philox_on": (c_int, [c_vp, c_vp, C.c_uint64, c_int, c_vp, c_int, c_int, c_vp, c_i64]),
     "dmk_fit_objective": (c_int, [c_vp, c_vp, P(c_dbl), P(c_int), P(c_int)]),
+    "dmk_small_meanfield": (c_int, [c_vp, P(c_int), c_int, c_int, c_vp, c_vp, c_int, c_dbl, c_dbl, c_dbl, c_int, c_dbl, c_dbl, c_vp,
+                                    c_vp, c_vp, c_vp, c_vp, c_vp, P(c_int)]),
+    "dmk_small_bath": (c_int, [c_vp, P(c_int), c_int, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int,
+                               c_dbl, c_vp, c_vp, c_vp, c_vp, P(c_int)]),
 }
 
 

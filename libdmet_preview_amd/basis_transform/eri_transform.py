@@ -313,6 +313,13 @@ class GDFPhilox(object):
         stream, dmk_eri_ring_slot), so that generating group g + 1 overlaps the transform of group g."""
         ctx.check(lib.dmk_df_block_philox_on(ctx.h, stream, C.c_uint64(self.seed), int(i), int(j), self.naux, self.nao, out_ptr))
 
+    def load_blocks_on(self, ctx, pairs, out_ptr, stride_bytes, stream):
+        """Several blocks in ONE launch: pair b of `pairs` at out_ptr + b * stride_bytes (consecutive queue slots of the block
+        ring).  At C4 sizes (72 MB blocks) a launch per block leaves a third of the generator's time in launch and ramp-up."""
+        ij = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+        ctx.check(lib.dmk_df_blocks_philox_on(ctx.h, stream, C.c_uint64(self.seed), len(ij), ij.ctypes.data_as(C.c_void_p), self.naux,
+                                              self.nao, out_ptr, int(stride_bytes)))
+
 
 def _is_provider(mydf):
     return hasattr(mydf, "load_block") and hasattr(mydf, "kpts")
@@ -834,7 +841,25 @@ class EriEngine(object):
         if self.ring_slots and not host_feed and ntot > self.ring_slots:
             launches = -(-ntot // self.ring_slots)
             per_launch = -(-ntot // launches)
-        for r in self.by_kL[kL]:
+        recs = self.by_kL[kL] if max_blocks is None else self.by_kL[kL][:int(max_blocks)]
+        if (self.ring_slots and not host_feed and hasattr(provider, "load_blocks_on") and self.ring_pos == 0
+                and os.environ.get("DMK_ERI_GEN_BATCH", "1") != "0"):
+            # device-side producer, one GENERATOR launch per group of queued blocks: the group's blocks go to consecutive ring slots
+            glen = per_launch if per_launch else self.ring_slots
+            for g0 in range(0, len(recs), glen):
+                grp = recs[g0:g0 + glen]
+                ptr, stream = C.c_void_p(), C.c_void_p()
+                ctx.check(lib.dmk_eri_ring_slot(self.h, 0, C.byref(ptr), C.byref(stream)))
+                pairs = [((int(r[1]), int(r[2])) if user_of_mesh is None else (int(user_of_mesh[int(r[1])]), int(user_of_mesh[int(r[2])])))
+                         for r in grp]
+                provider.load_blocks_on(ctx, pairs, ptr, self.block_buf.nbytes, stream)
+                for r in grp:
+                    ctx.check(lib.dmk_eri_push_ring_slot(self.h, int(r[1]), int(r[2]), int(r[4])))
+                nblk += len(grp)
+                if g0 + glen < len(recs):
+                    ctx.check(lib.dmk_eri_flush(self.h))       # the next group starts at slot 0 again
+            recs = []
+        for r in recs:
             i, j, sym = int(r[1]), int(r[2]), int(r[4])
             ui, uj = (i, j) if user_of_mesh is None else (int(user_of_mesh[i]), int(user_of_mesh[j]))
             if host_feed:

@@ -697,6 +697,16 @@ int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, i
     return launch_philox_block(ctx, seed, ki, kj, naux, nao, out);
 }
 
+int dmk_df_blocks_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int nblk, const int32_t *ij, int naux, int nao, void *out,
+                            int64_t stride_bytes) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (naux <= 0 || nao <= 0 || !out || !ij || nblk < 0 || stride_bytes < (int64_t)naux * nao * nao * 16 || (stride_bytes & 15))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "df_blocks_philox_on: bad arguments");
+    for (int b = 0; b < 2 * nblk; ++b)
+        if (ij[b] < 0) return dmk_fail(ctx, DMK_ERR_INVALID, "df_blocks_philox_on: negative k-point index");
+    return launch_philox_blocks_on(ctx, reinterpret_cast<hipStream_t>(stream), seed, nblk, ij, naux, nao, out, stride_bytes);
+}
+
 int dmk_df_block_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out) {
     if (!ctx) return DMK_ERR_INVALID;
     if (naux <= 0 || nao <= 0 || !out || ki < 0 || kj < 0) return dmk_fail(ctx, DMK_ERR_INVALID, "df_block_philox_on: bad arguments");

@@ -284,6 +284,8 @@ int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int 
 
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
 int launch_philox_block_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
+int launch_philox_blocks_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int nblk, const int *ij, int naux, int nao, void *out,
+                            long long stride_bytes);
 
 // hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin = 1,

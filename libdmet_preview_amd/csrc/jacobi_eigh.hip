@@ -350,7 +350,7 @@ __global__ void jacobi_symm_kernel(int n0, int batch, const double *__restrict__
 //           2 failed (|F| not small, no contraction, or unresolved cluster) -> the caller falls back to the Jacobi sweeps.
 constexpr int RF_T = 256;
 constexpr int RF_STAT = 8;
-constexpr int RF_SPLIT = 8;  // workgroups per matrix in the analysis pass   // doubles per (matrix, pass): max|F|, max|s + l r|, max|r|, delta, anorm
+constexpr int RF_SPLIT = 16;  // workgroups per matrix in the analysis pass   // doubles per (matrix, pass): max|F|, max|s + l r|, max|r|, delta, anorm
 
 struct RfGemm {
     int n, batch, nprob;
@@ -974,7 +974,10 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
     static const bool predict_on = !(getenv("DMK_EIGH_PREDICT") && atoi(getenv("DMK_EIGH_PREDICT")) == 0);
     const double *Vc = V0;
     std::vector<int> st(batch);
-    static const bool fused_update = !(getenv("DMK_EIGH_FUSED_UPDATE") && atoi(getenv("DMK_EIGH_FUSED_UPDATE")) == 0);
+    // measured (round 5, C5 fit: 2 x 256^2): the fused analysis + update launch takes 33 us where rf_analyse_kernel + the update
+    // product take 16 + 8 -- every one of the 16 column tiles of a row block recomputes the same 16 rows of F and pays the
+    // preamble (diagonals, per-tile sums) again; converged fit 0.98 s against 0.89 s.  Kept behind DMK_EIGH_FUSED_UPDATE=1.
+    static const bool fused_update = getenv("DMK_EIGH_FUSED_UPDATE") && atoi(getenv("DMK_EIGH_FUSED_UPDATE")) != 0;
     const int ldf = ((n + 15) & ~15) + 2;                      // LDS row stride of the F rows (bank spread)
     const size_t upd_lds = ((size_t)((n + 1) & ~1) + (size_t)16 * ldf) * sizeof(double);
     const bool use_fused = fused_update && upd_lds <= 96 * 1024;

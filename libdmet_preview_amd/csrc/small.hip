@@ -1,0 +1,573 @@
+// Small model lattices (BASELINE configs 1 - 2: Hubbard cells of a few sites on a k-mesh of a few dozen points): the mean-field
+// step and the Schmidt bath as ONE launch each.
+//
+//   small_meanfield_kernel   F_k + vcor -> eigenpairs of every (spin, k) block -> occupations / mu -> rho_k -> k -> R fold
+//                            reference: routine/mfd.py:33-108 (Diag*), :887-957 (assignocc), :352-360 (density + FFTtoT),
+//                            system/fourier.py:168-177 (k2R)
+//   small_bath_kernel        env x imp block of the stripe -> thin SVD -> bath count -> Loewdin -> embedding basis
+//                            reference: routine/slater.py:117-220 (_get_emb_basis_svd), lo/lowdin.py:83-101
+//
+// The general path runs these stages as ~10 dependent launches tuned for C4 / C5 sizes (batched Householder + bisection eigensolver,
+// TSQR + one-sided Jacobi SVD, ...): at 36 matrices of 4 x 4 every one of them is pure latency -- 0.21 ms of kernels and as much
+// again in launch gaps and stage synchronisations, where LAPACK on the host needs 0.23 ms (C1) / 2.8 ms (C2) for the whole step.
+// Here ONE workgroup does a stage: the matrices live in LDS (element-major, matrix index fastest: conflict-free), one thread per
+// (spin, k) block runs a cyclic complex Jacobi eigensolver, the occupation code is the same device function the stand-alone
+// kernels call (occ_body.h: bit-identical mu), the fold is a direct sum against exact per-axis twiddles, the bath is Householder QR
+// of the tall block (one fused reduction per column) + one-sided Jacobi on its nb x nb triangle -- no Gram-matrix shortcut, the
+// singular values keep the relative accuracy the sigma >= tol_bath count needs.
+// Limits (checked by the launchers, which return "not handled" so that the caller takes the general path): n <= 8 orbitals per
+// cell, nb <= 8 bath columns, spin * nk <= 256 blocks, nk <= 128, LDS carve-outs below.
+#include "common.h"
+#include <cmath>
+#include <algorithm>
+
+#include "occ_body.h"
+
+namespace {
+
+constexpr int SM_NT = OCC_NT;                  // the occupation bodies expect a workgroup of OCC_NT threads
+constexpr int SM_MAXN = 8;
+
+struct SmallMF {
+    int n, nmat, nk, spin, mstride;
+    int mesh[3];
+    const double2 *F;                          // [nmat][n][n] complex, row-major (lower triangle is used, like numpy's eigh)
+    const double *add;                         // optional real shift, [nmat / add_group][n][n]
+    int add_group;
+    OccArgs occ;                               // ew / occ / out point at the outputs (ew: [nmat][n], out: info[0..5))
+    int zero_t;
+    double2 *Vt;                               // [nmat][n][n]: ROW m = eigenvector m
+    double2 *rho_k;                            // [nmat][n][n]
+    double *rho_R;                             // [spin][nk][n*n]
+    double *info;                              // [0..5) occupation info, [5] max |Im| of the fold, [6] Jacobi sweeps not converged
+};
+
+__device__ __forceinline__ double block_max_f64(double v, double *sh) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < SM_NT / 64; ++w) t = fmax(t, sh[w]);
+    return t;
+}
+
+__global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g) {
+    extern __shared__ double dyn[];            // Hr | Hi | Vr | Vi, each [n*n][mstride]; then twiddles [3][128] complex
+    __shared__ double shd[SM_NT / 64];
+    const int n = g.n, nn = n * n, nmat = g.nmat, ms = g.mstride, tid = threadIdx.x;
+    double *Hr = dyn, *Hi = Hr + (size_t)nn * ms, *Vr = Hi + (size_t)nn * ms, *Vi = Vr + (size_t)nn * ms;
+    double2 *tw = reinterpret_cast<double2 *>(Vi + (size_t)nn * ms);
+    // exact per-axis twiddles e^{+2 pi i a / n_d}: quarter turns exact, the rest from sincospi of the reduced fraction
+    for (int t = tid; t < 3 * 128; t += SM_NT) {
+        const int d = t / 128, a = t % 128, nd = g.mesh[d];
+        double s = 0.0, c = 1.0;
+        if (a < nd) sincospi(2.0 * (double)a / (double)nd, &s, &c);
+        if (a < nd && (4 * a) % nd == 0) {         // multiples of a quarter turn
+            const int qt = (4 * a) / nd;
+            c = qt == 0 ? 1.0 : (qt == 2 ? -1.0 : 0.0);
+            s = qt == 1 ? 1.0 : (qt == 3 ? -1.0 : 0.0);
+        }
+        tw[t] = double2{c, s};
+    }
+    int notconv = 0;
+    if (tid < nmat) {
+        const int m = tid;
+        const double2 *F = g.F + (size_t)m * nn;
+        const double *ad = g.add ? g.add + (size_t)(m / g.add_group) * nn : nullptr;
+#define HR(i, j) Hr[(size_t)((i) * n + (j)) * ms + m]
+#define HI(i, j) Hi[(size_t)((i) * n + (j)) * ms + m]
+#define VR(i, j) Vr[(size_t)((i) * n + (j)) * ms + m]
+#define VI(i, j) Vi[(size_t)((i) * n + (j)) * ms + m]
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j <= i; ++j) {
+                const double2 f = F[i * n + j];
+                const double re = f.x + (ad ? ad[i * n + j] : 0.0), im = (i == j) ? 0.0 : f.y;
+                HR(i, j) = re; HI(i, j) = im;
+                HR(j, i) = re; HI(j, i) = -im;
+            }
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) { VR(i, j) = (i == j) ? 1.0 : 0.0; VI(i, j) = 0.0; }
+        // cyclic Jacobi on the Hermitian matrix: J = D R with D = diag(.., 1 (p), .., e^{-i phi} (q), ..), phi = arg h_pq, and R the
+        // real rotation that annihilates the (then real) pq element; H <- J^H H J, V <- V J
+        double scale = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) scale = fmax(scale, fmax(fabs(HR(i, j)), fabs(HI(i, j))));
+        int sweep = 0;
+        for (; sweep < 40; ++sweep) {
+            double off = 0.0;
+            for (int p = 0; p < n; ++p)
+                for (int q = p + 1; q < n; ++q) off = fmax(off, fmax(fabs(HR(p, q)), fabs(HI(p, q))));
+            if (!(off > 1.0e-17 * scale)) break;
+            for (int p = 0; p < n; ++p)
+                for (int q = p + 1; q < n; ++q) {
+                    const double ar = HR(p, q), ai = HI(p, q);
+                    const double mod = sqrt(ar * ar + ai * ai);
+                    if (!(mod > 1.0e-300) || !(mod > 1.0e-18 * scale)) continue;
+                    const double er = ar / mod, ei = ai / mod;               // e^{i phi}
+                    const double tau = (HR(q, q) - HR(p, p)) / (2.0 * mod);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    // J_pp = c, J_pq = s, J_qp = -s e^{-i phi}, J_qq = c e^{-i phi}
+                    const double jqp_r = -s * er, jqp_i = s * ei, jqq_r = c * er, jqq_i = -c * ei;
+                    for (int k = 0; k < n; ++k) {                            // columns: X[:, p], X[:, q] <- X J  (X = H and V)
+                        {
+                            const double xpr = HR(k, p), xpi = HI(k, p), xqr = HR(k, q), xqi = HI(k, q);
+                            HR(k, p) = c * xpr + (xqr * jqp_r - xqi * jqp_i);
+                            HI(k, p) = c * xpi + (xqr * jqp_i + xqi * jqp_r);
+                            HR(k, q) = s * xpr + (xqr * jqq_r - xqi * jqq_i);
+                            HI(k, q) = s * xpi + (xqr * jqq_i + xqi * jqq_r);
+                        }
+                        {
+                            const double xpr = VR(k, p), xpi = VI(k, p), xqr = VR(k, q), xqi = VI(k, q);
+                            VR(k, p) = c * xpr + (xqr * jqp_r - xqi * jqp_i);
+                            VI(k, p) = c * xpi + (xqr * jqp_i + xqi * jqp_r);
+                            VR(k, q) = s * xpr + (xqr * jqq_r - xqi * jqq_i);
+                            VI(k, q) = s * xpi + (xqr * jqq_i + xqi * jqq_r);
+                        }
+                    }
+                    for (int k = 0; k < n; ++k) {                            // rows: H[p, :], H[q, :] <- J^H H
+                        const double xpr = HR(p, k), xpi = HI(p, k), xqr = HR(q, k), xqi = HI(q, k);
+                        // conj(J_pp) = c, conj(J_qp) = (jqp_r, -jqp_i); conj(J_pq) = s, conj(J_qq) = (jqq_r, -jqq_i)
+                        HR(p, k) = c * xpr + (xqr * jqp_r + xqi * jqp_i);
+                        HI(p, k) = c * xpi + (xqi * jqp_r - xqr * jqp_i);
+                        HR(q, k) = s * xpr + (xqr * jqq_r + xqi * jqq_i);
+                        HI(q, k) = s * xpi + (xqi * jqq_r - xqr * jqq_i);
+                    }
+                    HR(p, q) = 0.0; HI(p, q) = 0.0; HR(q, p) = 0.0; HI(q, p) = 0.0;
+                    HI(p, p) = 0.0; HI(q, q) = 0.0;
+                }
+        }
+        if (sweep >= 40) notconv = 1;
+        // ascending order (stable selection sort: columns of V follow their eigenvalue); levels out
+        for (int a = 0; a < n; ++a) {
+            int best = a;
+            for (int b = a + 1; b < n; ++b)
+                if (HR(b, b) < HR(best, best)) best = b;
+            if (best != a) {
+                // rotate best down to a keeping the order of the others (stable)
+                for (int b = best; b > a; --b) {
+                    const double t0 = HR(b, b); HR(b, b) = HR(b - 1, b - 1); HR(b - 1, b - 1) = t0;
+                    for (int k = 0; k < n; ++k) {
+                        double t1 = VR(k, b); VR(k, b) = VR(k, b - 1); VR(k, b - 1) = t1;
+                        t1 = VI(k, b); VI(k, b) = VI(k, b - 1); VI(k, b - 1) = t1;
+                    }
+                }
+            }
+        }
+        for (int a = 0; a < n; ++a) const_cast<double *>(g.occ.ew)[(size_t)m * n + a] = HR(a, a);
+        for (int a = 0; a < n; ++a)
+            for (int i = 0; i < n; ++i) g.Vt[(size_t)m * nn + a * n + i] = double2{VR(i, a), VI(i, a)};
+    }
+    __threadfence();
+    __syncthreads();
+    // occupations of ALL levels (one particle-number sector), the very code of dmk_assign_occ
+    if (g.zero_t) occ_zero_t_body(g.occ);
+    else occ_fermi_body(g.occ);
+    __threadfence();
+    __syncthreads();
+    if (tid < nmat) {                          // rho_k = (V occ) V^H
+        const int m = tid;
+        const double *oc = g.occ.occ + (size_t)m * n;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                double re = 0.0, im = 0.0;
+                for (int l = 0; l < n; ++l) {
+                    const double o = oc[l];
+                    const double air = VR(i, l), aii = VI(i, l), bjr = VR(j, l), bji = VI(j, l);
+                    re += o * (air * bjr + aii * bji);                        // a conj(b)
+                    im += o * (aii * bjr - air * bji);
+                }
+                g.rho_k[(size_t)m * nn + i * n + j] = double2{re, im};
+            }
+    }
+#undef HR
+#undef HI
+#undef VR
+#undef VI
+    __threadfence();
+    __syncthreads();
+    // k -> R: rho_R[s][R][ij] = Re (1 / nk) sum_k e^{+2 pi i k.R} rho_k[s][k][ij]   (np.fft.ifftn over the mesh axes)
+    const int nk = g.nk, n1 = g.mesh[1], n2 = g.mesh[2];
+    const double inv = 1.0 / (double)nk;
+    double imax = 0.0;
+    for (int o = tid; o < g.spin * nk * nn; o += SM_NT) {
+        const int ij = o % nn, R = (o / nn) % nk, s = o / (nn * nk);
+        const int r0 = R / (n1 * n2), r1 = (R / n2) % n1, r2 = R % n2;
+        double re = 0.0, im = 0.0;
+        for (int k = 0; k < nk; ++k) {
+            const int k0 = k / (n1 * n2), k1 = (k / n2) % n1, k2 = k % n2;
+            const double2 w0 = tw[(k0 * r0) % g.mesh[0]], w1 = tw[128 + (k1 * r1) % n1], w2 = tw[256 + (k2 * r2) % n2];
+            const double ar = w0.x * w1.x - w0.y * w1.y, ai = w0.x * w1.y + w0.y * w1.x;
+            const double pr = ar * w2.x - ai * w2.y, pi = ar * w2.y + ai * w2.x;
+            const double2 v = g.rho_k[((size_t)s * nk + k) * nn + ij];
+            re += pr * v.x - pi * v.y;
+            im += pr * v.y + pi * v.x;
+        }
+        g.rho_R[o] = re * inv;
+        imax = fmax(imax, fabs(im * inv));
+    }
+    imax = block_max_f64(imax, shd);
+    const double nc = block_max_f64((double)notconv, shd);
+    if (tid == 0) { g.info[5] = imax; g.info[6] = nc; }
+}
+
+// ---- bath ---------------------------------------------------------------------------------------------------------------
+struct SmallBath {
+    int n0, n1, n2, nlo, spin, nenv, nb, nimp, nsites, orth, ncol_max;
+    double tol;
+    const double *rdm1;                        // [spin][nk][nlo][nlo] real stripe
+    long long rdm1_stride;
+    const int *env_idx, *bath_col, *virt_mask, *imp_idx;
+    double *sigma;                             // [spin][nb]
+    double *U;                                 // optional [spin][nenv][nb]
+    double *basis;                             // [spin][nsites][ncol], ncol = nimp + min_s nbath_s, PACKED with that leading dimension
+    int *iout;                                 // [0] ncol, [1 + s] nbath_s, [1 + spin] SVD sweeps not converged
+};
+
+constexpr int SB_MAXB = 8;
+
+// sum of `cnt` (<= SB_MAXB + 1) per-thread values over the workgroup, every thread receives all totals (fixed order)
+__device__ void block_sum_vec(double *v, int cnt, double *sh /* [SB_MAXB + 1][SM_NT / 64] */) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    for (int c = 0; c < cnt; ++c) {
+        const double s = dmk_wave_sum(v[c]);
+        if (lane == 0) sh[c * (SM_NT / 64) + wave] = s;
+    }
+    __syncthreads();
+    for (int c = 0; c < cnt; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < SM_NT / 64; ++w) t += sh[c * (SM_NT / 64) + w];
+        v[c] = t;
+    }
+}
+
+__global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
+    extern __shared__ double dyn[];            // A [spin][nenv][nb] (becomes Q-applied U) | R, Ur [spin][nb][nb] | tau [spin][nb] | X [nb][nb]
+    __shared__ double shv[(SB_MAXB + 1) * (SM_NT / 64)];
+    __shared__ int nbath_s[2];
+    __shared__ int bad_s;
+    const int nenv = g.nenv, nb = g.nb, tid = threadIdx.x, spin = g.spin;
+    double *Aall = dyn;
+    double *Rall = Aall + (size_t)spin * nenv * nb;
+    double *Uall = Rall + (size_t)spin * nb * nb;
+    double *tauall = Uall + (size_t)spin * nb * nb;
+    double *X = tauall + (size_t)spin * nb;
+    if (tid == 0) bad_s = 0;
+    for (int s = 0; s < spin; ++s) {
+        double *A = Aall + (size_t)s * nenv * nb, *Rm = Rall + (size_t)s * nb * nb, *Ur = Uall + (size_t)s * nb * nb;
+        double *tau = tauall + (size_t)s * nb;
+        const double *rd = g.rdm1 + (size_t)s * g.rdm1_stride;
+        // gather: A[r][c] = big[env_idx[r]][bath_col[c]], big[(R1, p), (R2, q)] = rdm1[R1 - R2][p][q]   (bath.hip)
+        for (int t = tid; t < nenv * nb; t += SM_NT) {
+            const int r = t / nb, c = t % nb;
+            const int e = g.env_idx[r], sc = g.bath_col[c];
+            const int R1 = e / g.nlo, p = e % g.nlo, R2 = sc / g.nlo, q = sc % g.nlo;
+            const int a0 = R1 / (g.n1 * g.n2), a1 = (R1 / g.n2) % g.n1, a2 = R1 % g.n2;
+            const int b0 = R2 / (g.n1 * g.n2), b1 = (R2 / g.n2) % g.n1, b2 = R2 % g.n2;
+            const int c0 = (a0 - b0 + g.n0) % g.n0, c1 = (a1 - b1 + g.n1) % g.n1, c2 = (a2 - b2 + g.n2) % g.n2;
+            const int Rd = (c0 * g.n1 + c1) * g.n2 + c2;
+            A[t] = rd[((size_t)Rd * g.nlo + p) * g.nlo + q];
+        }
+        __syncthreads();
+        // Householder QR, column by column: v = x + sign(x_j) |x| e_j (stored in place below the diagonal, v_j kept in `vj`),
+        // tau = 2 / (v.v); one fused reduction gives |x|^2, a second one the dots v . a_k of all later columns
+        for (int j = 0; j < nb && j < nenv; ++j) {
+            double acc[SB_MAXB + 1];
+            double nrm2 = 0.0;
+            for (int r = j + tid; r < nenv; r += SM_NT) nrm2 = fma(A[r * nb + j], A[r * nb + j], nrm2);
+            acc[0] = nrm2;
+            block_sum_vec(acc, 1, shv);
+            const double xn = sqrt(acc[0]);
+            const double xj = A[j * nb + j];
+            const double alpha = xj >= 0.0 ? -xn : xn;                     // R_jj
+            const double vj = xj - alpha;                                  // v_j (no cancellation)
+            const double vv = acc[0] - xj * xj + vj * vj;                  // v . v
+            const double tj = vv > 0.0 ? 2.0 / vv : 0.0;
+            // dots with the later columns
+            for (int k = 0; k <= SB_MAXB; ++k) acc[k] = 0.0;
+            for (int r = j + tid; r < nenv; r += SM_NT) {
+                const double vr = (r == j) ? vj : A[r * nb + j];
+                for (int k = j + 1; k < nb; ++k) acc[k - j - 1] = fma(vr, A[r * nb + k], acc[k - j - 1]);
+            }
+            block_sum_vec(acc, nb - j - 1, shv);
+            for (int r = j + tid; r < nenv; r += SM_NT) {
+                const double vr = (r == j) ? vj : A[r * nb + j];
+                for (int k = j + 1; k < nb; ++k) A[r * nb + k] -= tj * acc[k - j - 1] * vr;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                tau[j] = tj;
+                // the reflector stays below the diagonal scaled so that its j-th component is 1; R_jj replaces the diagonal
+                Rm[j * nb + j] = alpha;
+                for (int k = j + 1; k < nb; ++k) Rm[j * nb + k] = A[j * nb + k];
+                for (int k = 0; k < j; ++k) Rm[j * nb + k] = 0.0;
+                A[j * nb + j] = vj;                                        // keep v_j itself: H = I - tau v v^T with the stored v
+            }
+            __syncthreads();
+        }
+        // one-sided Jacobi SVD of the nb x nb triangle R = Ur diag(sigma) W^T: columns rotated until mutually orthogonal
+        if (tid == 0) {
+            const int k = nb < nenv ? nb : nenv;
+            for (int i = k; i < nb; ++i)
+                for (int c = 0; c < nb; ++c) Rm[i * nb + c] = 0.0;
+            double M[SB_MAXB * SB_MAXB];
+            for (int i = 0; i < nb * nb; ++i) M[i] = Rm[i];
+            int sweep = 0;
+            for (; sweep < 60; ++sweep) {
+                bool rotated = false;
+                for (int p = 0; p < nb; ++p)
+                    for (int q = p + 1; q < nb; ++q) {
+                        double al = 0.0, be = 0.0, ga = 0.0;
+                        for (int i = 0; i < nb; ++i) {
+                            al = fma(M[i * nb + p], M[i * nb + p], al);
+                            be = fma(M[i * nb + q], M[i * nb + q], be);
+                            ga = fma(M[i * nb + p], M[i * nb + q], ga);
+                        }
+                        if (!(fabs(ga) > 2.220446049250313e-16 * sqrt(al * be)) || ga == 0.0) continue;
+                        rotated = true;
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                        for (int i = 0; i < nb; ++i) {
+                            const double x = M[i * nb + p], y = M[i * nb + q];
+                            M[i * nb + p] = c * x - sn * y;
+                            M[i * nb + q] = sn * x + c * y;
+                        }
+                    }
+                if (!rotated) break;
+            }
+            if (sweep >= 60) bad_s = 1;
+            // sigma = column norms, descending (stable), Ur = normalised columns in that order
+            double sg[SB_MAXB];
+            int ord[SB_MAXB];
+            for (int c = 0; c < nb; ++c) {
+                double a = 0.0;
+                for (int i = 0; i < nb; ++i) a = fma(M[i * nb + c], M[i * nb + c], a);
+                sg[c] = sqrt(a);
+                ord[c] = c;
+            }
+            for (int a = 1; a < nb; ++a) {                                 // insertion sort, descending, stable
+                const int oa = ord[a];
+                int b = a - 1;
+                while (b >= 0 && sg[ord[b]] < sg[oa]) { ord[b + 1] = ord[b]; --b; }
+                ord[b + 1] = oa;
+            }
+            int cnt = 0;
+            for (int c = 0; c < nb; ++c) {
+                const double sv = sg[ord[c]];
+                g.sigma[s * nb + c] = sv;
+                if (sv >= g.tol) ++cnt;
+                const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
+                for (int i = 0; i < nb; ++i) Ur[i * nb + c] = M[i * nb + ord[c]] * inv;
+            }
+            nbath_s[s] = cnt;
+        }
+        __syncthreads();
+        // U = Q [Ur; 0]: the reflectors applied in reverse order to the rows of [Ur; 0] -- into the storage of A, whose reflector
+        // columns are consumed as they are applied (column j's reflector lives in A[j.., j])
+        // First move the reflectors out of the way: V[r][j] = A[r][j] (r >= j) is needed until step j; U overwrites A row-wise, so
+        // the reflector components are copied to registers per row batch instead -- simpler: keep a second array?  nenv * nb
+        // doubles more of LDS is affordable for the sizes this kernel accepts: Y lives behind X.
+        double *Y = X + nb * nb;                                           // [nenv][nb]
+        for (int t = tid; t < nenv * nb; t += SM_NT) {
+            const int r = t / nb, c = t % nb;
+            Y[t] = r < nb ? Ur[r * nb + c] : 0.0;
+        }
+        __syncthreads();
+        for (int j = (nb < nenv ? nb : nenv) - 1; j >= 0; --j) {
+            double acc[SB_MAXB + 1];
+            for (int k = 0; k < nb; ++k) acc[k] = 0.0;
+            for (int r = j + tid; r < nenv; r += SM_NT) {
+                const double vr = A[r * nb + j];
+                for (int k = 0; k < nb; ++k) acc[k] = fma(vr, Y[r * nb + k], acc[k]);
+            }
+            block_sum_vec(acc, nb, shv);
+            const double tj = tau[j];
+            for (int r = j + tid; r < nenv; r += SM_NT) {
+                const double vr = A[r * nb + j];
+                for (int k = 0; k < nb; ++k) Y[r * nb + k] -= tj * acc[k] * vr;
+            }
+            __syncthreads();
+        }
+        // U of this spin -> A's storage (the reflectors are no longer needed), and to global memory when asked for
+        for (int t = tid; t < nenv * nb; t += SM_NT) {
+            A[t] = Y[t];
+            if (g.U) g.U[(size_t)s * nenv * nb + t] = Y[t];
+        }
+        __syncthreads();
+    }
+    // ---- assemble: basis[s] = [ imp identity | env rows: B X ], B = U[:, :nbath_s] with virtual rows zeroed, X = (B^T B)^-1/2 ----
+    int nbf = nb;
+    for (int s = 0; s < spin; ++s) nbf = nbath_s[s] < nbf ? nbath_s[s] : nbf;
+    const int ncol = g.nimp + nbf;
+    for (size_t t = tid; t < (size_t)spin * g.nsites * ncol; t += SM_NT) g.basis[t] = 0.0;
+    __threadfence();
+    __syncthreads();
+    for (int s = 0; s < spin; ++s) {
+        double *A = Aall + (size_t)s * nenv * nb;
+        double *bs = g.basis + (size_t)s * g.nsites * ncol;
+        const int nbs = nbath_s[s];
+        for (int i = tid; i < g.nimp && i < ncol; i += SM_NT) bs[(size_t)g.imp_idx[i] * ncol + i] = 1.0;
+        if (nbs == 0) continue;
+        if (g.orth) {
+            for (int t = tid; t < nenv * nb; t += SM_NT)
+                if (g.virt_mask[t / nb]) A[t] = 0.0;
+            __syncthreads();
+            // metric S = B^T B (nbs x nbs), one fused reduction per row of S
+            for (int i = 0; i < nbs; ++i) {
+                double acc[SB_MAXB + 1];
+                for (int k = 0; k < nbs; ++k) acc[k] = 0.0;
+                for (int r = tid; r < nenv; r += SM_NT) {
+                    const double bi = A[r * nb + i];
+                    for (int k = 0; k < nbs; ++k) acc[k] = fma(bi, A[r * nb + k], acc[k]);
+                }
+                block_sum_vec(acc, nbs, shv);
+                if (tid == 0)
+                    for (int k = 0; k < nbs; ++k) X[i * nb + k] = acc[k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                // X = S^-1/2 = sum_{e_m > 1e-14} v_m v_m^T / sqrt(e_m) (lo/lowdin.py:83-91): cyclic Jacobi of the small metric
+                double Sm[SB_MAXB * SB_MAXB], Vm[SB_MAXB * SB_MAXB];
+                for (int i = 0; i < nbs; ++i)
+                    for (int k = 0; k < nbs; ++k) { Sm[i * nbs + k] = X[i * nb + k]; Vm[i * nbs + k] = (i == k) ? 1.0 : 0.0; }
+                for (int sweep = 0; sweep < 60; ++sweep) {
+                    double off = 0.0, dg = 0.0;
+                    for (int p = 0; p < nbs; ++p) {
+                        dg = fmax(dg, fabs(Sm[p * nbs + p]));
+                        for (int q = p + 1; q < nbs; ++q) off = fmax(off, fabs(Sm[p * nbs + q]));
+                    }
+                    if (!(off > 1.0e-17 * dg)) break;
+                    for (int p = 0; p < nbs; ++p)
+                        for (int q = p + 1; q < nbs; ++q) {
+                            const double apq = Sm[p * nbs + q];
+                            if (!(fabs(apq) > 1.0e-300)) continue;
+                            const double tau2 = (Sm[q * nbs + q] - Sm[p * nbs + p]) / (2.0 * apq);
+                            const double t = (tau2 >= 0.0 ? 1.0 : -1.0) / (fabs(tau2) + sqrt(1.0 + tau2 * tau2));
+                            const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+                            for (int k = 0; k < nbs; ++k) {
+                                const double x = Sm[k * nbs + p], y = Sm[k * nbs + q];
+                                Sm[k * nbs + p] = c * x - sn * y;
+                                Sm[k * nbs + q] = sn * x + c * y;
+                            }
+                            for (int k = 0; k < nbs; ++k) {
+                                const double x = Sm[p * nbs + k], y = Sm[q * nbs + k];
+                                Sm[p * nbs + k] = c * x - sn * y;
+                                Sm[q * nbs + k] = sn * x + c * y;
+                            }
+                            for (int k = 0; k < nbs; ++k) {
+                                const double x = Vm[k * nbs + p], y = Vm[k * nbs + q];
+                                Vm[k * nbs + p] = c * x - sn * y;
+                                Vm[k * nbs + q] = sn * x + c * y;
+                            }
+                        }
+                }
+                for (int i = 0; i < nbs; ++i)
+                    for (int k = 0; k < nbs; ++k) {
+                        double a = 0.0;
+                        for (int m = 0; m < nbs; ++m) {
+                            const double e = Sm[m * nbs + m];
+                            if (e > 1.0e-14) a += Vm[i * nbs + m] * Vm[k * nbs + m] / sqrt(e);
+                        }
+                        X[i * nb + k] = a;
+                    }
+            }
+            __syncthreads();
+        }
+        for (int t = tid; t < nenv * nbs; t += SM_NT) {
+            const int r = t / nbs, c = t % nbs;
+            double v;
+            if (g.orth) {
+                v = 0.0;
+                for (int j = 0; j < nbs; ++j) v += A[r * nb + j] * X[j * nb + c];
+            } else {
+                v = A[r * nb + c];
+            }
+            if (g.nimp + c < ncol) bs[(size_t)g.env_idx[r] * ncol + g.nimp + c] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        g.iout[0] = ncol;
+        for (int s = 0; s < spin; ++s) g.iout[1 + s] = nbath_s[s];
+        g.iout[1 + spin] = bad_s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmk_small_meanfield(dmk_ctx *ctx, const int mesh[3], int n, int spin, const void *Fock_k, const double *add, int add_group,
+                        double nelec, double beta, double mu0, int flags, double thr_deg, double fit_tol, double *ew, double *occ,
+                        void *Vt, void *rho_k, double *rho_R, double *info_dev, int *handled) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!handled || !mesh || !Fock_k || !ew || !occ || !Vt || !rho_k || !rho_R || !info_dev || n < 1 || spin < 1 || spin > 2)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: bad arguments");
+    *handled = 0;
+    const long long nk = (long long)mesh[0] * mesh[1] * mesh[2];
+    if (mesh[0] < 1 || mesh[1] < 1 || mesh[2] < 1) return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: bad mesh");
+    const long long nmat = spin * nk;
+    if (n > SM_MAXN || nmat > 256 || nk > 128 || mesh[0] > 128 || mesh[1] > 128 || mesh[2] > 128) return DMK_OK;
+    if (add && add_group < 1) return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: add_group must be positive");
+    const bool zero_t = !(beta < INFINITY);
+    const long long nlev = nmat * n;
+    if (zero_t && (nelec < 0.0 || nelec > (double)nlev || nelec != std::floor(nelec)))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: T = 0 needs an integer 0 <= nelec <= %lld levels", nlev);
+    if (!zero_t && !(beta > 0.0)) return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: beta must be positive");
+    SmallMF g;
+    g.n = n; g.nmat = (int)nmat; g.nk = (int)nk; g.spin = spin;
+    g.mstride = (int)nmat | 1;                                             // odd stride: element-major arrays stay conflict-free
+    g.mesh[0] = mesh[0]; g.mesh[1] = mesh[1]; g.mesh[2] = mesh[2];
+    g.F = static_cast<const double2 *>(Fock_k); g.add = add; g.add_group = add ? add_group : 1;
+    g.occ.ew = ew; g.occ.n = nlev; g.occ.nelec = nelec; g.occ.beta = beta; g.occ.mu0 = mu0; g.occ.thr = thr_deg;
+    g.occ.tol = fit_tol > 0.0 ? fit_tol : 1e-12;
+    g.occ.has_mu0 = (flags & 1) ? 1 : 0; g.occ.fix_mu = (flags & 2) ? 1 : 0; g.occ.sorted = 0;
+    g.occ.occ = occ; g.occ.out = info_dev;
+    g.zero_t = zero_t ? 1 : 0;
+    g.Vt = static_cast<double2 *>(Vt); g.rho_k = static_cast<double2 *>(rho_k); g.rho_R = rho_R; g.info = info_dev;
+    const size_t lds = ((size_t)4 * n * n * g.mstride + 2 * 3 * 128) * sizeof(double);
+    if (lds > 120 * 1024) return DMK_OK;
+    if (lds > 48 * 1024)
+        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(small_meanfield_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FamScope fs(ctx, DMK_FAM_EIGH);
+    hipLaunchKernelGGL(small_meanfield_kernel, dim3(1), dim3(SM_NT), lds, ctx->stream, g);
+    DMK_CHECK_LAUNCH(ctx);
+    *handled = 1;
+    return DMK_OK;
+}
+
+int dmk_small_bath(dmk_ctx *ctx, const int mesh[3], int nlo, int spin, const double *rdm1, int64_t rdm1_stride, const int32_t *env_idx,
+                   int nenv, const int32_t *bath_col, int nb, const int32_t *virt_mask, int orth, const int32_t *imp_idx, int nimp,
+                   int nsites, double tol_bath, double *sigma, double *U, double *basis, int32_t *iout_dev, int *handled) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (!handled || !mesh || !rdm1 || !env_idx || !bath_col || !imp_idx || !sigma || !basis || !iout_dev || nlo < 1 || spin < 1 ||
+        spin > 2 || nenv < 1 || nb < 1 || nimp < 0 || nsites < 1 || (orth && !virt_mask))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "small_bath: bad arguments");
+    *handled = 0;
+    if (nb > SB_MAXB) return DMK_OK;
+    const size_t lds = ((size_t)spin * nenv * nb + (size_t)2 * spin * nb * nb + (size_t)spin * nb + (size_t)nb * nb +
+                        (size_t)nenv * nb) * sizeof(double);
+    if (lds > 120 * 1024) return DMK_OK;
+    SmallBath g;
+    g.n0 = mesh[0]; g.n1 = mesh[1]; g.n2 = mesh[2]; g.nlo = nlo; g.spin = spin; g.nenv = nenv; g.nb = nb; g.nimp = nimp;
+    g.nsites = nsites; g.orth = orth ? 1 : 0; g.ncol_max = nimp + nb; g.tol = tol_bath;
+    g.rdm1 = rdm1; g.rdm1_stride = rdm1_stride; g.env_idx = env_idx; g.bath_col = bath_col; g.virt_mask = virt_mask;
+    g.imp_idx = imp_idx; g.sigma = sigma; g.U = U; g.basis = basis; g.iout = iout_dev;
+    if (lds > 48 * 1024)
+        DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(small_bath_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+    FamScope fs(ctx, DMK_FAM_BATH);
+    hipLaunchKernelGGL(small_bath_kernel, dim3(1), dim3(SM_NT), lds, ctx->stream, g);
+    DMK_CHECK_LAUNCH(ctx);
+    *handled = 1;
+    return DMK_OK;
+}
+
+}  // extern "C"

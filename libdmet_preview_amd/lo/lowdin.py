@@ -86,3 +86,37 @@ def vec_lowdin(C, S, f=None):
 
 
 vec_lowdin_k = vec_lowdin
+
+
+def _cano(s, tol=1e-12):
+    """Canonical orthogonalisation factor of a metric (lo/lowdin.py:138-143): eigenvectors with eigenvalue > tol, each divided
+    by sqrt(eigenvalue), as columns.  The eigenpairs come from the batched device eigensolver."""
+    s = np.asarray(s)
+    n = s.shape[-1]
+    ctx = get_ctx()
+    d_w, d_Vt = mfd.eigh_dev(ctx, ctx.to_device(s.reshape(1, n, n), np.complex128), n, 1)
+    e, Vt = d_w.get().reshape(n), d_Vt.get().reshape(n, n)
+    idx = e > tol
+    log.debug(2, "canonical orthogonalization eigenvals:\n%s", e)
+    X = Vt[idx].T / np.sqrt(e[idx])                                  # rows of Vt are the eigenvectors
+    return X if np.iscomplexobj(s) else np.ascontiguousarray(X.real)
+
+
+def _orth_cano(c, s, tol=1e-12, f=None):
+    """(c f) . _cano(c^H s c) (lo/lowdin.py:145-156); the two tall products run as device GEMMs."""
+    c = np.asarray(c)
+    ctx = get_ctx()
+    p, m = c.shape
+    d_C = ctx.to_device(c.reshape(1, p, m), np.complex128)
+    d_SC = d_C if s is None else bgemm_dev(ctx, "N", "N", p, m, p, 1, ctx.to_device(np.asarray(s).reshape(1, p, p), np.complex128),
+                                           p * p, d_C, p * m)
+    M = bgemm_dev(ctx, "C", "N", m, m, p, 1, d_C, p * m, d_SC, p * m).get().reshape(m, m)
+    real = not (np.iscomplexobj(c) or (s is not None and np.iscomplexobj(np.asarray(s))))
+    X = _cano(M.real if real else M, tol=tol)
+    k = X.shape[-1]
+    if k == 0:
+        return np.zeros((p, 0), dtype=c.dtype)
+    d_Cf = d_C if f is None else ctx.to_device((c * f).reshape(1, p, m), np.complex128)
+    out = bgemm_dev(ctx, "N", "N", p, k, m, 1, d_Cf, p * m, ctx.to_device(np.asarray(X).reshape(1, m, k), np.complex128), m * k)
+    out = out.get().reshape(p, k)
+    return np.ascontiguousarray(out.real) if real and (f is None or not np.iscomplexobj(f)) else out

@@ -183,6 +183,56 @@ def bath_stage(ctx, sysm, d_rhoR, timers=None, tol_bath=1e-9):
     return d_basis, nemb, sigmas
 
 
+def small_lattice_stages(ctx, sysm, timers=None, tol_bath=1e-9):
+    """Mean field + Schmidt bath of a SMALL model lattice (<= 8 orbitals per cell, spin * nk <= 256) as two launches and ONE
+    read-back (csrc/small.hip: dmk_small_meanfield, dmk_small_bath): the same products as mean_field_stage + bath_stage, or None
+    when the shape is outside the limits of the fused kernels (or DMK_SMALL=0).  reference: routine/mfd.py:235-360,
+    routine/slater.py:117-220."""
+    import ctypes as C
+    import os
+    if os.environ.get("DMK_SMALL", "1") == "0" or dist.world_size() > 1:
+        return None
+    n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
+    nb, nenv, nimp = sysm.nval, len(sysm.env_idx), n
+    if n > 8 or nb > 8 or spin * nk > 256 or nk > 128:
+        return None
+    timers = {} if timers is None else timers
+    t = time.perf_counter()
+    nelec = mfd.check_nelec(spin * nk * n * sysm.filling, None)[0]
+    d_w, d_occ = ctx.empty((spin * nk, n), np.float64), ctx.empty((spin * nk, n), np.float64)
+    d_Vt, d_rho = ctx.empty((spin * nk, n, n), np.complex128), ctx.empty((spin * nk, n, n), np.complex128)
+    d_rhoR = ctx.empty((spin, nk, n * n), np.float64)
+    # one small result record: info[8] | sigma[spin][nb] | (ncol, nbath_s.., flag) as int32
+    nrec = 8 + spin * nb + 2
+    d_rec = ctx.empty((nrec,), np.float64)
+    handled = C.c_int(0)
+    from libdmet_preview_amd._lib import mesh3
+    ctx.check(lib.dmk_small_meanfield(ctx.h, mesh3(sysm.mesh), n, spin, sysm.d_Fock_k.ptr, sysm.d_vcor.ptr if sysm.d_vcor is not None else None,
+                                      nk, float(nelec), float("inf"), 0.0, 0, 1e-6, 1e-12, d_w.ptr, d_occ.ptr, d_Vt.ptr, d_rho.ptr,
+                                      d_rhoR.ptr, d_rec.ptr, C.byref(handled)))
+    if not handled.value:
+        return None
+    d_basis_buf = ctx.empty((spin, nk * n, nimp + nb), np.float64)
+    d_sigma = d_rec.offset(8, (spin, nb))
+    d_iout = d_rec.offset(8 + spin * nb, (2,))
+    ctx.check(lib.dmk_small_bath(ctx.h, mesh3(sysm.mesh), n, spin, d_rhoR.ptr, nk * n * n, sysm.d_env.ptr, nenv, sysm.d_col.ptr, nb,
+                                 sysm.d_virt.ptr, 1, sysm.d_imp.ptr, nimp, nk * n, float(tol_bath), d_sigma.ptr, None, d_basis_buf.ptr,
+                                 d_iout.ptr, C.byref(handled)))
+    if not handled.value:
+        return None
+    rec = d_rec.get()                                   # the ONE synchronising read-back of the step
+    info, sig = rec[:8], rec[8:8 + spin * nb].reshape(spin, nb)
+    iout = rec[8 + spin * nb:].view(np.int32)
+    if info[4] != 0.0 or info[6] != 0.0 or iout[1 + spin] != 0:
+        raise RuntimeError("small-lattice step failed: occupation status %g, eigensolver flag %g, SVD flag %d"
+                           % (info[4], info[6], int(iout[1 + spin])))
+    nemb = int(iout[0])
+    d_basis = ctx.wrap(d_basis_buf.address, (spin, nk * n, nemb), np.float64, keepalive=d_basis_buf)
+    timers["small_step"] = timers.get("small_step", 0.0) + (time.perf_counter() - t)
+    mf = {"mu": float(info[0]), "ew": d_w, "occ": d_occ, "nerr": float(info[1]), "imag_max": float(info[5])}
+    return d_rhoR, mf, d_basis, nemb, [sig[s] for s in range(spin)]
+
+
 def c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers=None, return_basis_k=False):
     timers = {} if timers is None else timers
     n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
@@ -364,8 +414,12 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
     if eri_exchange is None:
         eri_exchange = "allreduce" if allreduce_eri else "none"
     timers = {} if timers is None else timers
-    d_rhoR, mf = mean_field_stage(ctx, sysm, timers)
-    d_basis, nemb, sigmas = bath_stage(ctx, sysm, d_rhoR, timers)
+    small = small_lattice_stages(ctx, sysm, timers)
+    if small is not None:
+        d_rhoR, mf, d_basis, nemb, sigmas = small
+    else:
+        d_rhoR, mf = mean_field_stage(ctx, sysm, timers)
+        d_basis, nemb, sigmas = bath_stage(ctx, sysm, d_rhoR, timers)
     out = {"rho_R": d_rhoR, "basis": d_basis, "nemb": nemb, "sigma": sigmas, "mu": mf["mu"], "ew": mf["ew"], "occ": mf["occ"],
            "timers": timers}
     if sysm.naux > 0:

@@ -185,15 +185,15 @@ def _diag_nambu(A, add, symm_lattice=None):
 
 
 def _ghf_shift(vcor, nao, mu):
-    """The k-independent part of mfd.py:597-608: vcor blocks (lower triangle convention) and -/+ mu."""
+    """The k-independent part of mfd.py:597-608: vcor blocks (lower triangle convention) and -/+ mu.  Complex (2 nao, 2 nao)
+    when the potential is complex, else real."""
     v = np.asarray(vcor.get(0, True))
-    if np.iscomplexobj(v) and max_abs(v.imag) > 0.0:
-        raise NotImplementedError("complex correlation potential is outside the HIP path")
-    v = v.real
-    add = np.zeros((2 * nao, 2 * nao))
+    cplx = np.iscomplexobj(v) and max_abs(v.imag) > 0.0
+    add = np.zeros((2 * nao, 2 * nao), dtype=np.complex128 if cplx else np.float64)
+    v = v if cplx else v.real
     add[:nao, :nao] = v[0]
     add[nao:, nao:] = v[1]
-    add[nao:, :nao] = v[2].T
+    add[nao:, :nao] = v[2].conj().T                       # only the lower triangle is read (mfd.py:600-603, eigh(lower=True))
     add[:nao, nao:] = v[2]
     if mu is not None:
         add[range(nao), range(nao)] -= mu
@@ -201,18 +201,28 @@ def _ghf_shift(vcor, nao, mu):
     return add
 
 
+def _diag_with_shift(A, add, symm_lattice=None):
+    """A real shift rides along as the eigensolver's shared shift; a COMPLEX one (a complex local correlation potential,
+    mfd.py:597-608 / 439-447) is added to every k block on the host before the upload -- the kernel reads the lower triangle,
+    like scipy's eigh(lower=True) in the reference."""
+    if np.iscomplexobj(add):
+        A = np.asarray(A, dtype=np.complex128) + add[None]
+        add = np.zeros(add.shape)
+    return _diag_nambu(A, add, symm_lattice=symm_lattice)
+
+
 def DiagGHF(GFock, vcor, mu, **kwargs):
     """mfd.py:591-610: generalised (spin-orbital) Fock, one eigh per k on the device."""
     GFock = np.asarray(GFock)
     nao = GFock.shape[-1] // 2
-    return _diag_nambu(GFock, _ghf_shift(vcor, nao, mu))
+    return _diag_with_shift(GFock, _ghf_shift(vcor, nao, mu))
 
 
 def DiagGHF_symm(GFock, vcor, mu, lattice, **kwargs):
     """mfd.py:612-641."""
     GFock = np.asarray(GFock)
     nao = GFock.shape[-1] // 2
-    return _diag_nambu(GFock, _ghf_shift(vcor, nao, mu), symm_lattice=lattice)
+    return _diag_with_shift(GFock, _ghf_shift(vcor, nao, mu), symm_lattice=lattice)
 
 
 def _bdg_matrix(Fock):
@@ -228,28 +238,28 @@ def _bdg_matrix(Fock):
 
 
 def _bdg_shift(vcor, n, mu):
+    """vcor and mu of mfd.py:439-447; complex when the potential is."""
     v = np.asarray(vcor.get(0, True))
-    if np.iscomplexobj(v) and max_abs(v.imag) > 0.0:
-        raise NotImplementedError("complex correlation potential is outside the HIP path")
-    v = v.real
-    add = np.zeros((2 * n, 2 * n))
+    cplx = np.iscomplexobj(v) and max_abs(v.imag) > 0.0
+    v = v if cplx else v.real
+    add = np.zeros((2 * n, 2 * n), dtype=np.complex128 if cplx else np.float64)
     add[:n, :n] = v[0] - mu * np.eye(n)
     add[n:, n:] = -v[1] + mu * np.eye(n)
     add[:n, n:] = v[2]
-    add[n:, :n] = v[2].T
+    add[n:, :n] = v[2].conj().T
     return add
 
 
 def DiagBdG(Fock, vcor, mu, **kwargs):
     """mfd.py:429-449."""
     A, n = _bdg_matrix(Fock)
-    return _diag_nambu(A, _bdg_shift(vcor, n, mu))
+    return _diag_with_shift(A, _bdg_shift(vcor, n, mu))
 
 
 def DiagBdGsymm(Fock, vcor, mu, lattice, **kwargs):
     """mfd.py:451-478."""
     A, n = _bdg_matrix(Fock)
-    return _diag_nambu(A, _bdg_shift(vcor, n, mu), symm_lattice=lattice)
+    return _diag_with_shift(A, _bdg_shift(vcor, n, mu), symm_lattice=lattice)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -376,6 +386,48 @@ def _later_pair_members(lattice, nkpts):
     return out
 
 
+def _hf_small(ctx, kmesh, Fock, vcor, spin, nkpts, n, nelec, beta, mu0, fix_mu, tol_deg):
+    """The mean-field step of a SMALL model lattice as one launch (dmk_small_meanfield: eigenpairs, occupations, rho_k, k -> R
+    fold) -- (d_w, d_occ, d_Vt, d_rho_k, d_rho_R, info[8]) or None when the shape / options are outside the fused kernel
+    (then HF runs the general chain).  DMK_SMALL=0 switches it off."""
+    import ctypes as C
+    import os
+    from libdmet_preview_amd._lib import mesh3
+    if os.environ.get("DMK_SMALL", "1") == "0" or n > 8 or spin * nkpts > 256 or nkpts > 128:
+        return None
+    if int(np.prod(kmesh)) != nkpts:
+        return None
+    Fock_v, v = _fock_plus_vcor(Fock, vcor, spin)
+    d_F = ctx.to_device(np.ascontiguousarray(Fock_v).reshape(spin * nkpts, n, n), np.complex128)
+    d_add = ctx.to_device(v) if v is not None else None
+    d_w, d_occ = ctx.empty((spin * nkpts, n), np.float64), ctx.empty((spin * nkpts, n), np.float64)
+    d_Vt, d_rho = ctx.empty((spin * nkpts, n, n), np.complex128), ctx.empty((spin * nkpts, n, n), np.complex128)
+    d_rhoT = ctx.empty((spin, nkpts, n * n), np.float64)
+    d_info = ctx.empty((8,), np.float64)
+    zero_t = not (beta < np.inf)
+    if zero_t:
+        if nelec > spin * nkpts * n:
+            raise IndexError("assignocc: %d electrons do not fit %d levels" % (nelec, spin * nkpts * n))
+        flags = 0 if mu0 is None else 1
+    else:
+        flags = 2 if fix_mu else 0
+    handled = C.c_int(0)
+    ctx.check(lib.dmk_small_meanfield(ctx.h, mesh3(kmesh), int(n), int(spin), d_F.ptr, d_add.ptr if d_add is not None else None,
+                                      int(nkpts), float(nelec), float(beta), 0.0 if mu0 is None else float(mu0), flags,
+                                      float(tol_deg), 1e-12, d_w.ptr, d_occ.ptr, d_Vt.ptr, d_rho.ptr, d_rhoT.ptr, d_info.ptr,
+                                      C.byref(handled)))
+    if not handled.value:
+        return None
+    info = d_info.get()
+    if info[4] == 2.0:
+        raise ValueError("assign_occ: the eigenvalue list contains NaN / Inf")
+    if info[4] != 0.0:
+        raise ValueError("assign_occ: no chemical potential gives %g electrons" % nelec)
+    if info[6] != 0.0:
+        raise RuntimeError("small-lattice eigensolver did not converge")
+    return d_w, d_occ, d_Vt, d_rho, d_rhoT, info
+
+
 def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, scf=False, use_hcore=None,
        **kwargs):
     """
@@ -407,78 +459,97 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
     nfrac = kwargs.get("nfrac", None)
     ctx = get_ctx()
 
-    # ---- all (s, k) eigenproblems in one launch; eigenvectors stay on the device.  symm: only ONE member of every +-k pair
-    #      is diagonalised (mfd.py:56-66); the later member takes ew(-k) and, further down, rho(k) = rho(-k)^T, ev(k) = conj ev(-k)
-    inherit = _later_pair_members(lattice, nkpts) if symm else []
-    if inherit:
-        reps, src, _ = _pair_plan([lattice.cell_pos2idx(-lattice.cell_idx2pos(k)) for k in range(nkpts)])
-    else:
-        reps, src = list(range(nkpts)), np.arange(nkpts)
-    nrep = len(reps)
-    full_of_rep = np.asarray([s_ * nrep + int(src[k]) for s_ in range(spin) for k in range(nkpts)], dtype=np.int32)
-    Fock_v, v = _fock_plus_vcor(Fock, vcor, spin)
-    Frep = Fock_v if nrep == nkpts else np.ascontiguousarray(Fock_v[:, reps])
-    d_F = ctx.to_device(np.ascontiguousarray(Frep).reshape(spin * nrep, n, n), np.complex128)
-    d_w_rep, d_Vt = eigh_dev(ctx, d_F, n, spin * nrep, ctx.to_device(v) if v is not None else None, nrep)
-    if nrep == nkpts:
-        d_w = d_w_rep
-    else:
-        d_src = ctx.to_device(full_of_rep)
-        d_w = ctx.empty((spin * nkpts, n), np.float64)
-        ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nkpts, n, d_src.ptr, d_w_rep.ptr, d_w.ptr, 0))
-    ew = d_w.get().reshape(spin, nkpts, n)
-
-    # ---- occupations on the device ----------------------------------------------------------------------------------
+    # ---- small model lattices: the whole chain below as ONE launch (csrc/small.hip) ------------------------------------------
     two_sectors = _is_seq(filling)
-    if two_sectors:
-        if spin != 2:
-            raise AssertionError("a filling per spin needs an unrestricted calculation")
-        nelec = [check_nelec(nlev * filling[s] * 0.5, None)[0] for s in (0, 1)]
-        ew_sorted = [np.sort(ew[s], axis=None, kind="stable") for s in (0, 1)]
-        if mu0 is None:
-            mu0 = [_frontier_guess(ew_sorted[s], nelec[s]) for s in (0, 1)]
-        frozen = (0, 0) if nfrac is None else (nelec[0] // 2 - nfrac, nlev // 2 - (nelec[0] // 2 + nfrac))
-    else:
-        nelec = check_nelec(nlev * filling, None)[0]
-        ew_sorted = np.sort(ew, axis=None, kind="stable")
-        if mu0 is None:
-            mu0 = _frontier_guess(ew_sorted, nelec)
-        if nfrac is None:
-            frozen = (0, 0)
-        elif restricted:
-            frozen = (nelec - nfrac, nlev - (nelec + nfrac))
-        else:
-            frozen = (nelec // 2 - nfrac, nlev // 2 - (nelec // 2 + nfrac))
-    if two_sectors or frozen != (0, 0):
-        ewocc, mu, nerr = assignocc(ew, nelec, beta, mu0, fix_mu=fix_mu, thr_deg=tol_deg, ncore=frozen[0], nvirt=frozen[1])
-        d_occ = ctx.to_device(ewocc.reshape(spin * nkpts, n), np.float64)
-    else:
-        d_occ, mu, nerr = assignocc_dev(ctx, d_w, nelec, beta, mu0=mu0, fix_mu=fix_mu, thr_deg=tol_deg)
+    small = None
+    if not symm and not two_sectors and nfrac is None:
+        small = _hf_small(ctx, lattice.kmesh, Fock, vcor, spin, nkpts, n, check_nelec(nlev * filling, None)[0], beta, mu0, fix_mu, tol_deg)
+    if small is not None:
+        d_w, d_occ, d_Vt, d_rho, d_rhoT, info = small
+        nrep, src, inherit = nkpts, np.arange(nkpts), []
+        ew = d_w.get().reshape(spin, nkpts, n)
         ewocc = d_occ.get().reshape(spin, nkpts, n)
+        mu, nerr = float(info[0]), float(info[1])
+        ew_sorted = np.sort(ew, axis=None, kind="stable")
+        if beta == np.inf and info[2] > 0:
+            log.warn("degenerate HOMO-LUMO: %d electrons shared by %d levels within %g of mu", int(info[2]), int(info[3]), tol_deg)
+        rhoT = d_rhoT.get().reshape(spin, nkpts, n, n)
+        if float(info[5]) > IMAG_DISCARD_TOL:
+            log.warn("k2R: non-zero imaginary part: %15.8g", float(info[5]))
+            rhoT = fourier.FFTtoT(d_rho.get().reshape(spin, nkpts, n, n), lattice.kmesh, tol=IMAG_DISCARD_TOL)
+    if small is None:
+        # ---- all (s, k) eigenproblems in one launch; eigenvectors stay on the device.  symm: only ONE member of every +-k pair
+        #      is diagonalised (mfd.py:56-66); the later member takes ew(-k) and, further down, rho(k) = rho(-k)^T, ev(k) = conj ev(-k)
+        inherit = _later_pair_members(lattice, nkpts) if symm else []
+        if inherit:
+            reps, src, _ = _pair_plan([lattice.cell_pos2idx(-lattice.cell_idx2pos(k)) for k in range(nkpts)])
+        else:
+            reps, src = list(range(nkpts)), np.arange(nkpts)
+        nrep = len(reps)
+        full_of_rep = np.asarray([s_ * nrep + int(src[k]) for s_ in range(spin) for k in range(nkpts)], dtype=np.int32)
+        Fock_v, v = _fock_plus_vcor(Fock, vcor, spin)
+        Frep = Fock_v if nrep == nkpts else np.ascontiguousarray(Fock_v[:, reps])
+        d_F = ctx.to_device(np.ascontiguousarray(Frep).reshape(spin * nrep, n, n), np.complex128)
+        d_w_rep, d_Vt = eigh_dev(ctx, d_F, n, spin * nrep, ctx.to_device(v) if v is not None else None, nrep)
+        if nrep == nkpts:
+            d_w = d_w_rep
+        else:
+            d_src = ctx.to_device(full_of_rep)
+            d_w = ctx.empty((spin * nkpts, n), np.float64)
+            ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nkpts, n, d_src.ptr, d_w_rep.ptr, d_w.ptr, 0))
+        ew = d_w.get().reshape(spin, nkpts, n)
 
-    # ---- rho_k = (ev occ) ev^H, rhoT = k2R(rho_k) ----------------------------------------------------------------------
-    if nrep == nkpts:
-        d_rho = density_dev(ctx, d_Vt, d_occ, n, spin * nkpts)
-    else:
-        rep_rows = ctx.to_device(np.asarray([s_ * nkpts + k for s_ in range(spin) for k in reps], dtype=np.int32))
-        d_occ_rep = ctx.empty((spin * nrep, n), np.float64)
-        ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nrep, n, rep_rows.ptr, d_occ.ptr, d_occ_rep.ptr, 0))
-        d_rho_rep = density_dev(ctx, d_Vt, d_occ_rep, n, spin * nrep)
-        d_rho = ctx.empty((spin * nkpts, n, n), np.complex128)
-        ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nkpts, 2 * n * n, d_src.ptr, d_rho_rep.ptr, d_rho.ptr, 0))
-    for (k, mk) in inherit:
-        # ev(k) = conj(ev(-k)) and equal occupations: rho(k) = conj(rho(-k)) = rho(-k)^T (rho is Hermitian)
-        for s in range(spin):
-            ctx.check(lib.dmk_transpose_c128(ctx.h, n, n, 1, d_rho.offset((s * nkpts + mk) * n * n, (n, n)).ptr,
-                                             d_rho.offset((s * nkpts + k) * n * n, (n, n)).ptr))
-    d_imax = ctx.zeros((1,), np.float64)
-    d_rhoT = fourier.fold_k2R_dev(d_rho.reshape(spin, nkpts, n * n), lattice.kmesh, spin, n * n, imag_max=d_imax)
-    rhoT = d_rhoT.get().reshape(spin, nkpts, n, n)
-    imag = float(d_imax.get()[0])
-    if imag > IMAG_DISCARD_TOL:
-        # the reference keeps the complex array in this case (system/fourier.py:168-177)
-        log.warn("k2R: non-zero imaginary part: %15.8g", imag)
-        rhoT = fourier.FFTtoT(d_rho.get().reshape(spin, nkpts, n, n), lattice.kmesh, tol=IMAG_DISCARD_TOL)
+        # ---- occupations on the device ----------------------------------------------------------------------------------
+        two_sectors = _is_seq(filling)
+        if two_sectors:
+            if spin != 2:
+                raise AssertionError("a filling per spin needs an unrestricted calculation")
+            nelec = [check_nelec(nlev * filling[s] * 0.5, None)[0] for s in (0, 1)]
+            ew_sorted = [np.sort(ew[s], axis=None, kind="stable") for s in (0, 1)]
+            if mu0 is None:
+                mu0 = [_frontier_guess(ew_sorted[s], nelec[s]) for s in (0, 1)]
+            frozen = (0, 0) if nfrac is None else (nelec[0] // 2 - nfrac, nlev // 2 - (nelec[0] // 2 + nfrac))
+        else:
+            nelec = check_nelec(nlev * filling, None)[0]
+            ew_sorted = np.sort(ew, axis=None, kind="stable")
+            if mu0 is None:
+                mu0 = _frontier_guess(ew_sorted, nelec)
+            if nfrac is None:
+                frozen = (0, 0)
+            elif restricted:
+                frozen = (nelec - nfrac, nlev - (nelec + nfrac))
+            else:
+                frozen = (nelec // 2 - nfrac, nlev // 2 - (nelec // 2 + nfrac))
+        if two_sectors or frozen != (0, 0):
+            ewocc, mu, nerr = assignocc(ew, nelec, beta, mu0, fix_mu=fix_mu, thr_deg=tol_deg, ncore=frozen[0], nvirt=frozen[1])
+            d_occ = ctx.to_device(ewocc.reshape(spin * nkpts, n), np.float64)
+        else:
+            d_occ, mu, nerr = assignocc_dev(ctx, d_w, nelec, beta, mu0=mu0, fix_mu=fix_mu, thr_deg=tol_deg)
+            ewocc = d_occ.get().reshape(spin, nkpts, n)
+
+        # ---- rho_k = (ev occ) ev^H, rhoT = k2R(rho_k) ----------------------------------------------------------------------
+        if nrep == nkpts:
+            d_rho = density_dev(ctx, d_Vt, d_occ, n, spin * nkpts)
+        else:
+            rep_rows = ctx.to_device(np.asarray([s_ * nkpts + k for s_ in range(spin) for k in reps], dtype=np.int32))
+            d_occ_rep = ctx.empty((spin * nrep, n), np.float64)
+            ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nrep, n, rep_rows.ptr, d_occ.ptr, d_occ_rep.ptr, 0))
+            d_rho_rep = density_dev(ctx, d_Vt, d_occ_rep, n, spin * nrep)
+            d_rho = ctx.empty((spin * nkpts, n, n), np.complex128)
+            ctx.check(lib.dmk_copy_rows_f64(ctx.h, spin * nkpts, 2 * n * n, d_src.ptr, d_rho_rep.ptr, d_rho.ptr, 0))
+        for (k, mk) in inherit:
+            # ev(k) = conj(ev(-k)) and equal occupations: rho(k) = conj(rho(-k)) = rho(-k)^T (rho is Hermitian)
+            for s in range(spin):
+                ctx.check(lib.dmk_transpose_c128(ctx.h, n, n, 1, d_rho.offset((s * nkpts + mk) * n * n, (n, n)).ptr,
+                                                 d_rho.offset((s * nkpts + k) * n * n, (n, n)).ptr))
+        d_imax = ctx.zeros((1,), np.float64)
+        d_rhoT = fourier.fold_k2R_dev(d_rho.reshape(spin, nkpts, n * n), lattice.kmesh, spin, n * n, imag_max=d_imax)
+        rhoT = d_rhoT.get().reshape(spin, nkpts, n, n)
+        imag = float(d_imax.get()[0])
+        if imag > IMAG_DISCARD_TOL:
+            # the reference keeps the complex array in this case (system/fourier.py:168-177)
+            log.warn("k2R: non-zero imaginary part: %15.8g", imag)
+            rhoT = fourier.FFTtoT(d_rho.get().reshape(spin, nkpts, n, n), lattice.kmesh, tol=IMAG_DISCARD_TOL)
 
     # ---- energy per cell ------------------------------------------------------------------------------------------------
     FockT, H1T = add_spin_dim(FockT, spin), add_spin_dim(H1T, spin)

@@ -563,7 +563,7 @@ class EmbFitDevice(object):
         choice = os.environ.get("DMK_FIT_EIGH", eigh)
         self.use_jacobi = (choice == "jacobi") and nb <= 576 and spin * ((nb + 31) // 32) <= 256
         self._have_prev, self.sweeps = False, 0
-        self._ray, self._ray_host = None, None
+        self._ray, self._ray_host, self._ray_serial = None, None, 0
         self.table_passes_saved = 0
         self.on_ray_hits = [0, 0]                      # table passes saved at a gradient's forward pass / at the start of a ray
         # fused native objective (dmk_fit_objective): T = 0, orthonormal embedding basis, warm eigensolver.  DMK_FIT_FUSED=0 keeps
@@ -637,8 +637,11 @@ class EmbFitDevice(object):
             self._dist.all_reduce_sum_dev(d_out)                  # spin x npair doubles (0.5 MB at C5)
 
     def _forward(self, param, ray=None):
-        param = np.ascontiguousarray(param, dtype=np.float64)
-        key = param.tobytes()
+        if ray is not None and param is None:
+            key = ("ray", id(ray[0]), self._ray_serial, ray[2])     # a trial step of the current ray: no host vector is formed
+        else:
+            param = np.ascontiguousarray(param, dtype=np.float64)
+            key = param.tobytes()
         if key == self._key:
             return self._state
         ctx, spin, nb, nidx = self.ctx, self.spin, self.nb, self.nidx
@@ -647,6 +650,9 @@ class EmbFitDevice(object):
             t_on = self._on_ray(param)
             if t_on is not None:
                 ray = self._ray[self._ray_cur] + (t_on,)
+                key = ("ray", id(ray[0]), self._ray_serial, t_on)
+                if key == self._key:                                    # the accepted step was the last one evaluated
+                    return self._state
                 self.table_passes_saved += 1
                 self.on_ray_hits[0] += 1
             else:
@@ -762,13 +768,15 @@ class EmbFitDevice(object):
             self._ray_age = 0
         self._vemb_into(p, d_v1)
         self._ray_host = {"x": x, "p": p, "ts": [], "imax": int(np.argmax(np.abs(p))) if p.size else 0}
+        self._ray_serial += 1
         ts = self._ray_host["ts"]
+        inv = 1.0 / sqrt(self.spin)
 
         def phi(t):
             t = float(np.asarray(t).ravel()[0])                   # the Nelder-Mead fallback passes a 1-vector
             self.nfev += 1
             ts.append(t)
-            return self._forward(x + t * p, ray=(d_v0, d_v1, t))[3] / sqrt(self.spin)
+            return self._forward(None, ray=(d_v0, d_v1, t))[3] * inv
         return phi
 
     # -- gradient ----------------------------------------------------------------------------------

@@ -26,15 +26,116 @@ def get_emb_basis(lattice, GRho, local=True, kind='svd', **kwargs):
     if not local:
         raise NotImplementedError
     if kwargs.get("bath_opt", False):
-        raise NotImplementedError("bath_opt is outside the HIP path")
+        raise NotImplementedError("bath_opt (scipy brentq over full-lattice eigendecompositions, spinless.py:277-349) is outside "
+                                  "the HIP path")
     if kind == 'svd':
         return _get_emb_basis_svd(lattice, np.asarray(GRho).real, **kwargs)
-    elif kind in ('eig', 'ph'):
-        raise NotImplementedError("GSO bath kind %s is outside the HIP path" % kind)
+    elif kind == 'eig':
+        return _get_emb_basis_eig(lattice, np.asarray(GRho).real, **kwargs)
+    elif kind == 'ph':
+        return _get_emb_basis_ph(lattice, np.asarray(GRho).real, **kwargs)
     raise ValueError("get_emb_basis: Unknown kind %s" % kind)
 
 
 embBasis = get_emb_basis
+
+
+def _gso_index_sets(lattice, valence_bath):
+    """imp / bath / env index sets of the generalised lattice with 2 nlo orbitals per cell (spinless.py:86-106)."""
+    ncells, nlo = lattice.ncells, lattice.nscsites
+    nso = nlo * 2
+    val_idx = list(lattice.val_idx) + [i + nlo for i in lattice.val_idx]
+    imp_idx = list(lattice.imp_idx) + [i + nlo for i in lattice.imp_idx]
+    imp_idx_bath = val_idx if valence_bath else imp_idx
+    bath_set, imp_set = set(imp_idx_bath), set(imp_idx)
+    env_idx = np.asarray([i for i in range(ncells * nso) if i not in bath_set], dtype=np.int32)
+    virt_mask = np.asarray([i in imp_set for i in env_idx], dtype=np.int32)
+    return imp_idx, imp_idx_bath, env_idx, virt_mask
+
+
+def _order_by_particle_character(ctx, d_basis, ncells, nso, nlo, nimp, nbath):
+    """Bath columns ordered by their weight on the alpha rows, descending, stable (spinless.py:147-154): returns the host basis."""
+    ncol = nimp + nbath
+    d_w = ctx.empty((ncol,), np.float64)
+    ctx.check(lib.dmk_bcs_weight(ctx.h, ncells, nso, nlo, ncol, d_basis.ptr, d_w.ptr))
+    w = d_w.get()[nimp:]
+    order = np.argsort(w, kind='mergesort')[::-1]
+    w1 = w[order]
+    if nbath > 0:
+        wA, wB = w1[:nbath // 2], 1.0 - w1[nbath // 2:]
+        log.debug(0, "particle character:\nspin A max %.2f min %.2f mean %.2f\nspin B max %.2f min %.2f mean %.2f",
+                  np.max(wA), np.min(wA), np.average(wA), np.max(wB), np.min(wB), np.average(wB))
+    basis = d_basis.get()
+    basis[:, nimp:] = basis[:, nimp + order]
+    return basis
+
+
+def _get_emb_basis_eig(lattice, rdm1, **kwargs):
+    """GSO bath from the eigenvectors of the env-env block of the generalised density matrix whose eigenvalues are neither 0
+    nor 1 (routine/spinless.py:166-275): one real symmetric eigenproblem of the environment dimension on the device
+    (dmk_eigh_batched_real: model sizes, one workgroup per matrix), then the virtual projection + Loewdin + scatter of the SVD
+    flavour (dmk_bath_assemble) and the particle-character ordering."""
+    valence_bath = kwargs.get("valence_bath", True)
+    tol_bath = kwargs.get("tol_bath", 1e-9)
+    if not kwargs.get("orth", True):
+        raise NotImplementedError
+    if kwargs.get("localize_bath", None) is not None:
+        raise NotImplementedError("localize_bath is outside the HIP path")
+    ncells, nlo = lattice.ncells, lattice.nscsites
+    nso = nlo * 2
+    imp_idx, imp_idx_bath, env_idx, virt_mask = _gso_index_sets(lattice, valence_bath)
+    nimp, nenv = len(imp_idx), len(env_idx)
+    rdm1 = np.ascontiguousarray(rdm1, dtype=np.float64)
+    assert rdm1.shape == (ncells, nso, nso)
+    if nenv > 2000:
+        raise NotImplementedError("eig bath: env dimension %d exceeds the eigensolver limit of 2000 (one workgroup per matrix); "
+                                  "use kind='svd' (the reference's default), which has no limit" % nenv)
+    env_env = lattice.expand(rdm1)[env_idx][:, env_idx]
+    ctx = get_ctx()
+    d_w, d_Vt = ctx.empty((1, nenv), np.float64), ctx.empty((1, nenv, nenv), np.float64)
+    ctx.check(lib.dmk_eigh_batched_real(ctx.h, nenv, 1, ctx.to_device(env_env, np.float64).ptr, d_w.ptr, d_Vt.ptr))
+    ew, Vt = d_w.get().reshape(nenv), d_Vt.get().reshape(nenv, nenv)
+    keep = [i for i, e in enumerate(ew) if abs(e) > tol_bath and abs(1 - e) > tol_bath]
+    log.debug(0, "dm eigenvalues:\n%s", ew[keep])
+    nbath = len(keep)
+    log.eassert(nbath % 2 == 0, "nbath (%s) should be even in GSO.", nbath)
+    ncol = nimp + nbath
+    d_env, d_virt = ctx.to_device(env_idx), ctx.to_device(virt_mask)
+    d_imp = ctx.to_device(np.asarray(imp_idx, dtype=np.int32))
+    d_basis = ctx.empty((ncells * nso, ncol), np.float64)
+    d_U = ctx.to_device(np.ascontiguousarray(Vt[keep].T) if nbath else np.zeros((nenv, 1)), np.float64)
+    bath_assemble_dev(ctx, d_U, nenv, max(nbath, 1), nbath, d_virt, True, d_env, d_imp, nimp, ncells * nso, ncol, d_basis)
+    basis = _order_by_particle_character(ctx, d_basis, ncells, nso, nlo, nimp, nbath)
+    log.debug(0, "nimp : %d", nimp)
+    log.debug(0, "nbath: %d", nbath)
+    return basis.reshape(ncells, nso, ncol)
+
+
+def _get_emb_basis_ph(lattice, rdm1, **kwargs):
+    """GSO bath from the particle and hole projections of the bath columns plus the local virtual orbitals, canonically
+    orthogonalised (routine/spinless.py:351-423, lo/lowdin.py:138-156); the overlap and the final product are device GEMMs."""
+    from libdmet_preview_amd.lo.lowdin import _orth_cano
+    valence_bath = kwargs.get("valence_bath", True)
+    tol_bath = kwargs.get("tol_bath", 1e-9)
+    ncells, nlo = lattice.ncells, lattice.nscsites
+    nso = nlo * 2
+    imp_idx, imp_idx_bath, env_idx, virt_mask = _gso_index_sets(lattice, valence_bath)
+    virt_idx = [int(i) for i, v in zip(env_idx, virt_mask) if v]
+    rdm1_p = np.asarray(rdm1, dtype=np.float64)
+    assert rdm1_p.shape == (ncells, nso, nso)
+    bath_p = rdm1_p.reshape(ncells * nso, nso)[:, imp_idx_bath]
+    rdm1_h = -rdm1_p
+    rdm1_h[0, range(nso), range(nso)] += 1.0
+    bath_h = rdm1_h.reshape(ncells * nso, nso)[:, imp_idx_bath]
+    nval, nvirt = len(imp_idx_bath) * 2, len(virt_idx)
+    nbasis = nval + nvirt
+    basis = np.zeros((ncells * nso, nbasis))
+    basis[virt_idx, range(nbasis - nvirt, nbasis)] = 1.0
+    basis[:, :nval // 2] = bath_p
+    basis[:, nval // 2:nval] = bath_h
+    basis = _orth_cano(basis, s=None, tol=tol_bath)
+    log.debug(0, "nimp + nbath: %d", nbasis)
+    return basis.reshape(ncells, nso, -1)
 
 
 def _get_emb_basis_svd(lattice, rdm1, **kwargs):

@@ -1160,9 +1160,49 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18"]
     for g in which:
         globals()["gen_" + g]()
+
+
+def gen_G18():
+    """Branches the round-4 review listed as refused: a COMPLEX local correlation potential in DiagGHF(_symm) / DiagBdG(symm)
+    (routine/mfd.py:429-478, 591-641) and the 'eig' / 'ph' flavours of the GSO bath (routine/spinless.py:166-275, 351-423) --
+    the reference's own functions under the shim on the lattices of G7."""
+    from libdmet.routine import mfd, spinless
+    from libdmet.system import lattice as rl
+    g7 = np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        nk = int(np.prod(mesh))
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        rng = np.random.default_rng(4000 + n)
+        FR = g7[name + "/Fock_R"]
+        Fk = synth.fold_R2k(FR, mesh)
+        v = (rng.standard_normal((3, n, n)) + 1j * rng.standard_normal((3, n, n))) * 0.2
+        v[0] = 0.5 * (v[0] + v[0].conj().T)
+        v[1] = 0.5 * (v[1] + v[1].conj().T)
+        mu = 0.21
+        vc = _Vcor(v)
+        out[name + "/vcor_complex"], out[name + "/mu"] = v, np.asarray(mu)
+        proj = lambda ew, ev: np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+        ew, ev = mfd.DiagBdG(Fk, vc, mu)
+        ews, evs = mfd.DiagBdGsymm(Fk, vc, mu, L)
+        out[name + "/bdg_ew"], out[name + "/bdg_GRho_k"] = ew, proj(ew, ev)
+        out[name + "/bdg_symm_ew"], out[name + "/bdg_symm_GRho_k"] = ews, proj(ews, evs)
+        GFk = synth.fold_R2k(g7[name + "/GFock_R"][None], mesh)[0]
+        gw, gv = mfd.DiagGHF(GFk, vc, mu)
+        gws, gvs = mfd.DiagGHF_symm(GFk, vc, mu, L)
+        gw0, gv0 = mfd.DiagGHF(GFk, vc, None)
+        out[name + "/ghf_ew"], out[name + "/ghf_symm_ew"], out[name + "/ghf_nomu_ew"] = gw, gws, gw0
+        out[name + "/ghf_rho_k"], out[name + "/ghf_symm_rho_k"] = proj(gw, gv), proj(gws, gvs)
+        # GSO bath flavours on the generalised density matrix of G7
+        GRho = g7[name + "/GRho"]
+        for kind in ("eig", "ph"):
+            for vb in (True, False):
+                out["%s/gso_%s_%s" % (name, kind, "val" if vb else "full")] = spinless.get_emb_basis(L, GRho, kind=kind, valence_bath=vb)
+    np.savez_compressed(os.path.join(GOLD, "G18_branches.npz"), **out)
+    print("G18 done")
 
 
 if __name__ == "__main__":

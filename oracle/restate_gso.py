@@ -3,6 +3,9 @@ oracle/restate_gso.py -- CPU restatement (numpy) of the generalised-spin-orbital
 SURVEY.md section 8(f) rank 4:
 
   spinless._get_emb_basis_svd     routine/spinless.py:58-163     Schmidt bath of the generalised density matrix
+  spinless._get_emb_basis_eig     routine/spinless.py:166-275    ... from the eigenvectors of the env-env block
+  spinless._get_emb_basis_ph      routine/spinless.py:351-423    ... particle / hole projections, canonical orthogonalisation
+                                                                 (both pinned by tests/golden/G18_branches.npz, gen_G18)
   eri_transform.get_emb_eri_gso   basis_transform/eri_transform.py:1104-1250
   _Lij_s4_to_eri_gso              basis_transform/eri_transform.py:1252-1310  (aaaa + bbbb - aabb - bbaa)
 
@@ -48,6 +51,73 @@ def get_emb_basis_gso(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1
     basis[imp2, :nimp] = np.eye(nimp)
     basis[env, nimp:] = B[:, order]
     return basis.reshape(ncells, nso, nimp + nbath), sigma, w
+
+
+def _gso_index_sets(ncells, nlo, val_idx, imp_idx, valence_bath):
+    """The index bookkeeping shared by the three bath flavours (routine/spinless.py:86-106, 196-216, 376-398)."""
+    nso = 2 * nlo
+    val2 = list(val_idx) + [i + nlo for i in val_idx]
+    imp2 = list(imp_idx) + [i + nlo for i in imp_idx]
+    bath_cols = val2 if valence_bath else imp2
+    env, virt, alpha, virt_idx = [], [], [], []
+    for R in range(ncells):
+        for s in range(2):
+            for i in range(nlo):
+                idx = R * nso + s * nlo + i
+                if idx not in bath_cols:
+                    env.append(idx)
+                    virt.append(idx in imp2)
+                    if idx in imp2:
+                        virt_idx.append(idx)
+                    alpha.append(s == 0)
+    return imp2, bath_cols, env, np.asarray(virt, dtype=bool), np.asarray(alpha, dtype=bool), virt_idx
+
+
+def get_emb_basis_gso_eig(kmesh, rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9):
+    """routine/spinless.py:166-275 (kind = 'eig', orth = True): eigenvectors of the env-env block of the generalised density
+    matrix whose eigenvalues are neither 0 nor 1 (lattice.expand restated by CellArith.expand)."""
+    rdm1 = np.asarray(rdm1)
+    ncells, nso, _ = rdm1.shape
+    imp2, bath_cols, env, virt, alpha, _ = _gso_index_sets(ncells, nlo, val_idx, imp_idx, valence_bath)
+    nimp = len(imp2)
+    from oracle.restate import CellArith
+    big = CellArith(kmesh).expand(rdm1[None])[0]                                                       # lattice.expand
+    ew, ev = la.eigh(big[env][:, env])
+    keep = [i for i, e in enumerate(ew) if abs(e) > tol_bath and abs(1 - e) > tol_bath]
+    B = ev[:, keep].copy()
+    nbath = B.shape[-1]
+    assert nbath % 2 == 0
+    B[virt] = 0.0
+    B = vec_lowdin(B)
+    w = np.einsum("ai,ai->i", B[alpha], B[alpha])
+    order = np.argsort(w, kind="mergesort")[::-1]
+    basis = np.zeros((ncells * nso, nimp + nbath))
+    basis[imp2, :nimp] = np.eye(nimp)
+    basis[env, nimp:] = B[:, order]
+    return basis.reshape(ncells, nso, nimp + nbath), ew[keep]
+
+
+def get_emb_basis_gso_ph(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9):
+    """routine/spinless.py:351-423 (kind = 'ph'): particle and hole projections of the bath columns plus the local virtuals,
+    canonically orthogonalised (lo/lowdin.py:138-148: eigenvectors of the overlap above tol / sqrt(eigenvalue))."""
+    rdm1 = np.asarray(rdm1)
+    ncells, nso, _ = rdm1.shape
+    imp2, bath_cols, env, virt, alpha, virt_idx = _gso_index_sets(ncells, nlo, val_idx, imp_idx, valence_bath)
+    bath_p = rdm1.reshape(ncells * nso, nso)[:, bath_cols]
+    rdm1_h = -rdm1.copy()
+    rdm1_h[0, range(nso), range(nso)] += 1.0
+    bath_h = rdm1_h.reshape(ncells * nso, nso)[:, bath_cols]
+    nval = len(bath_cols) * 2
+    nvirt = len(virt_idx)
+    nbasis = nval + nvirt
+    basis = np.zeros((ncells * nso, nbasis))
+    basis[virt_idx, range(nbasis - nvirt, nbasis)] = 1.0
+    basis[:, :nval // 2] = bath_p
+    basis[:, nval // 2:nval] = bath_h
+    e, v = la.eigh(basis.conj().T @ basis)
+    idx = e > tol_bath
+    out = basis @ (v[:, idx] / np.sqrt(e[idx]))
+    return out.reshape(ncells, nso, -1), e
 
 
 def Lij_s4_to_eri_gso(Lij_s4, eri, weight=1, t_reversal_symm=False):

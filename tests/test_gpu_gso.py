@@ -39,8 +39,22 @@ def test_gso_bath(ctx, golden, name, n, val):
         a2, r2 = b.reshape(-1, b.shape[-1])[:, nimp:], ref.reshape(-1, ref.shape[-1])[:, nimp:]
         assert np.sqrt(2.0) * np.linalg.norm(r2 - a2 @ (a2.T @ r2)) < 1e-10        # projector, gauge free
     assert spinless.embBasis is spinless.get_emb_basis
+    # the 'eig' and 'ph' flavours (routine/spinless.py:166-275, 351-423) against what the reference's own functions returned (G18)
+    g18 = golden("G18_branches.npz")
+    span = lambda a, r: np.abs(a.reshape(-1, a.shape[-1]) @ a.reshape(-1, a.shape[-1]).T
+                               - r.reshape(-1, r.shape[-1]) @ r.reshape(-1, r.shape[-1]).T).max()
+    for vb, tag in ((True, "val"), (False, "full")):
+        be = spinless.get_emb_basis(L, GRho, kind="eig", valence_bath=vb)
+        ref = g18["%s/gso_eig_%s" % (name, tag)]
+        assert be.shape == ref.shape and np.array_equal(be[..., :nimp], ref[..., :nimp])
+        assert span(be[..., nimp:], ref[..., nimp:]) < 1e-10
+        bp = spinless.get_emb_basis(L, GRho, kind="ph", valence_bath=vb)
+        refp = g18["%s/gso_ph_%s" % (name, tag)]
+        assert bp.shape == refp.shape and span(bp, refp) < 1e-10
+        Bm = bp.reshape(-1, bp.shape[-1])
+        assert np.abs(Bm.T @ Bm - np.eye(Bm.shape[-1])).max() < 1e-10
     with pytest.raises(NotImplementedError):
-        spinless.get_emb_basis(L, GRho, kind="eig")
+        spinless.get_emb_basis(L, GRho, bath_opt=True)
     with pytest.raises(ValueError):
         spinless.get_emb_basis(L, GRho, kind="nope")
 

@@ -1,0 +1,123 @@
+"""
+GPU parity of the fused SMALL-LATTICE kernels (csrc/small.hip: dmk_small_meanfield, dmk_small_bath; BASELINE configs 1 - 2): the
+mean-field step (eigenpairs of every (spin, k) block, occupations / mu, rho_k, k -> R fold) and the Schmidt bath (env x imp block,
+thin SVD, bath count, Loewdin, embedding basis) as ONE launch each, against
+  * the oracle's restatement of the reference chain (oracle/stage_check.py: routine/mfd.py:235-360 HF, routine/slater.py:117-220
+    _get_emb_basis_svd) on the same seeded lattices,
+  * the general device path (DMK_SMALL=0: batched eigensolver, dmk_assign_occ, density, fold, TSQR + Jacobi SVD, assemble),
+  * the reference's own HF results (golden G3) through the mirror entry point mfd.HF, which now takes the fused kernel for small cells.
+Tolerances: eigenvalues / rho 1e-12, occupations equal, bath projector 1e-10 (north star: 1e-10 Frobenius on the embedding basis).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import stage_check as SC                     # the checker
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from libdmet_preview_amd import _lib
+    return _lib.get_ctx()
+
+
+def _pipeline_products(ctx, sysm, small):
+    from libdmet_preview_amd import pipeline
+    old = os.environ.get("DMK_SMALL")
+    os.environ["DMK_SMALL"] = "1" if small else "0"
+    try:
+        out = pipeline.iteration(ctx, sysm, emb_ham=False)
+    finally:
+        if old is None:
+            os.environ.pop("DMK_SMALL", None)
+        else:
+            os.environ["DMK_SMALL"] = old
+    n, nk, spin, nemb = sysm.nlo, sysm.nk, sysm.spin, out["nemb"]
+    return {"ew": out["ew"].get().reshape(spin, nk, n), "occ": out["occ"].get().reshape(spin, nk, n), "mu": out["mu"],
+            "rho_R": out["rho_R"].get().reshape(spin, nk, n, n), "basis": out["basis"].get().reshape(spin, nk, n, nemb),
+            "sigma": np.asarray(out["sigma"]), "timers": out["timers"]}
+
+
+CASES = [("C1", {}), ("C2", {}),
+         ("C2", dict(mesh=(4, 3, 1), nlo=3, nval=3, spin=2)), ("C2", dict(mesh=(5, 1, 1), nlo=8, nval=8, spin=1)),
+         ("C2", dict(mesh=(2, 2, 2), nlo=5, nval=4, spin=2)), ("C2", dict(mesh=(3, 3, 3), nlo=2, nval=2, spin=2)),
+         ("C2", dict(mesh=(7, 2, 1), nlo=6, nval=3, spin=1)), ("C2", dict(mesh=(1, 1, 1), nlo=4, nval=2, spin=1)),
+         ("C2", dict(mesh=(2, 1, 1), nlo=1, nval=1, spin=2))]
+
+
+@pytest.mark.parametrize("workload,over", CASES)
+def test_small_lattice_step_vs_oracle_and_general_path(ctx, workload, over):
+    from libdmet_preview_amd import pipeline
+    sysm = pipeline.SyntheticSystem.from_workload(ctx, workload, **over)
+    got = _pipeline_products(ctx, sysm, small=True)
+    assert "small_step" in got["timers"], "the fused small-lattice kernels did not run"
+    gen = _pipeline_products(ctx, sysm, small=False)
+    assert "small_step" not in gen["timers"]
+    ref = SC.reference_chain(sysm.mesh, sysm.Fock_R, sysm.vcor, sysm.filling, sysm.restricted, sysm.imp_idx, sysm.val_idx)
+    spin = sysm.spin
+    for other, tag in ((ref, "oracle"), (gen, "general")):
+        assert np.abs(got["ew"] - other["ew"]).max() < 1e-12, tag
+        assert np.array_equal(got["occ"], other["occ"]), tag
+        assert np.abs(got["rho_R"] - other["rho_R"]).max() < 1e-12, tag
+        assert got["basis"].shape == other["basis"].shape, tag
+        for s in range(spin):
+            assert SC.projector_distance(got["basis"][s], other["basis"][s]) < 1e-10, tag
+    assert abs(got["mu"] - ref["mu"]) < 1e-12
+    assert np.abs(np.sort(got["sigma"], axis=-1) - np.sort(np.asarray(gen["sigma"]), axis=-1)).max() < 1e-12
+    B = got["basis"].reshape(spin, -1, got["basis"].shape[-1])
+    if sysm.nk > 1:                      # (a single cell's environment is its own virtual orbitals: every bath vector is projected out)
+        for s in range(spin):
+            assert np.abs(B[s].T @ B[s] - np.eye(B.shape[-1])).max() < 1e-12       # orthonormal embedding basis
+
+
+def test_small_limits_fall_back(ctx):
+    """Outside the limits of the fused kernels (here 9 orbitals per cell) the pipeline takes the general path."""
+    from libdmet_preview_amd import pipeline
+    sysm = pipeline.SyntheticSystem.from_workload(ctx, "C2", mesh=(3, 2, 1), nlo=9, nval=4, spin=1)
+    got = _pipeline_products(ctx, sysm, small=True)
+    assert "small_step" not in got["timers"] and "diag" in got["timers"]
+
+
+@pytest.mark.parametrize("beta", [np.inf, 20.0])
+def test_hf_entry_point_takes_the_small_kernel(ctx, beta):
+    """mfd.HF on a small cell: fused kernel vs the general chain (DMK_SMALL=0), T = 0 and finite T -- rho, mu, E equal to rounding."""
+    from libdmet_preview_amd.routine import mfd
+    from libdmet_preview_amd.system.lattice import Lattice
+    from libdmet_preview_amd import synth
+    from libdmet_preview_amd.dmet import Hubbard
+    mesh, n = (4, 2, 1), 4
+    rng = np.random.default_rng(31)
+    nk = int(np.prod(mesh))
+    FR = rng.standard_normal((2, nk, n, n)) * 0.3
+    # translation invariant Hermitian operator: F[-R] = F[R]^T
+    from libdmet_preview_amd.system import fourier
+    _, minus, _ = fourier.kmesh_tables(mesh)
+    for s in range(2):
+        for R in range(nk):
+            if int(minus[R]) >= R:
+                FR[s, int(minus[R])] = FR[s, R].T
+        for R in range(nk):
+            if int(minus[R]) == R:
+                FR[s, R] = 0.5 * (FR[s, R] + FR[s, R].T)
+    L = Lattice(n, mesh)
+    L.val_idx, L.virt_idx, L.core_idx = list(range(n)), [], []
+    Fk = synth.fold_R2k(FR, mesh)
+    L.fock_lo_k = L.hcore_lo_k = Fk
+    L.fock_lo_R = L.hcore_lo_R = FR
+    L.H0, L.is_model, L.use_hcore_as_emb_ham = 0.0, True, False
+    vc = Hubbard.VcorLocal(False, False, n)
+    vc.update(0.1 * rng.standard_normal(vc.length()))
+    res = {}
+    for small in ("1", "0"):
+        os.environ["DMK_SMALL"] = small
+        try:
+            res[small] = mfd.HF(L, vc, 0.5, False, beta=beta, ires=True)
+        finally:
+            os.environ.pop("DMK_SMALL", None)
+    a, b = res["1"], res["0"]
+    assert np.abs(a[0] - b[0]).max() < 1e-12 and abs(a[1] - b[1]) < 1e-10 and abs(a[2] - b[2]) < 1e-11
+    assert np.abs(a[3]["e"] - b[3]["e"]).max() < 1e-12 and np.abs(a[3]["rho_k"] - b[3]["rho_k"]).max() < 1e-12
+    assert np.abs(a[3]["mo_occ"] - b[3]["mo_occ"]).max() < 1e-10

@@ -129,3 +129,26 @@ def test_G7_unit2emb(golden):
     assert np.array_equal(B.reorder_spin_blocks(x), x[[0, 2, 1]])
     with pytest.raises(ValueError):
         B.unit2emb(np.zeros((1, 2, 2, 2)), neo)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_G18_complex_vcor_in_bdg_and_ghf(golden, name):
+    """A COMPLEX local correlation potential (routine/mfd.py:439-447, 597-608): the restatement against the reference's own
+    DiagBdG(symm) / DiagGHF(_symm) (golden G18, gen_G18)."""
+    g7, g = golden("G7_bcs.npz"), golden("G18_branches.npz")
+    mesh, FR, Fk, _, _, val = _case(g7, name)
+    v, mu = g[name + "/vcor_complex"], float(g[name + "/mu"])
+    for symm in (False, True):
+        ew, ev = B.DiagBdG(Fk, v, mu, kmesh=mesh if symm else None)
+        t = "bdg_symm" if symm else "bdg"
+        assert np.abs(ew - g["%s/%s_ew" % (name, t)]).max() < 1e-11
+        rho = np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+        assert np.abs(rho - g["%s/%s_GRho_k" % (name, t)]).max() < 1e-10
+    GFk = R.FFTtoK(g7[name + "/GFock_R"], mesh)
+    for symm, mu_ in ((False, mu), (True, mu), (False, None)):
+        ew, ev = B.DiagGHF(GFk, v, mu_, kmesh=mesh if symm else None)
+        t = "ghf_symm" if symm else ("ghf" if mu_ is not None else "ghf_nomu")
+        assert np.abs(ew - g["%s/%s_ew" % (name, t)]).max() < 1e-11
+        if mu_ is not None:
+            rho = np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
+            assert np.abs(rho - g["%s/%s_rho_k" % (name, t)]).max() < 1e-10

@@ -52,3 +52,35 @@ def test_G12_gso_eri(golden, name):
             assert np.abs(e - g[st + "/" + key]).max() < 1e-10 * max(1.0, np.abs(e).max())
         assert np.abs(G.get_emb_eri_gso(mesh, ks, get, naux, nao, C, basis, symmetry=1) - g[st + "/eri_s1"]).max() < 1e-10
         assert np.abs(G.get_emb_eri_gso(mesh, ks, get, naux, nao, C, basis, unit_eri=True) - g[st + "/eri_unit"]).max() < 1e-10
+
+
+# ---- golden G18 (gen_G18): the 'eig' / 'ph' flavours of the GSO bath --------------------------------------------------------
+G18_CASES = [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]
+
+
+def _same_span(a, b, tol):
+    """Two column sets span the same space (bases differ by a rotation inside degenerate groups)."""
+    a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    assert a.shape == b.shape
+    return np.abs(a @ a.T - b @ b.T).max() < tol
+
+
+@pytest.mark.parametrize("name,mesh,n,val", G18_CASES)
+def test_G18_gso_eig_and_ph_bath(golden, name, mesh, n, val):
+    """routine/spinless.py:166-275 ('eig') and :351-423 ('ph') against what the reference's own functions returned."""
+    from oracle import restate_gso as G
+    g, g7 = golden("G18_branches.npz"), golden("G7_bcs.npz")
+    GRho = g7[name + "/GRho"]
+    imp = list(val) + [i for i in range(n) if i > max(val)]                      # Lattice.imp_idx = val + virt (system/lattice.py:119-120)
+    for vb, tag in ((True, "val"), (False, "full")):
+        be, _ = G.get_emb_basis_gso_eig(mesh, GRho, n, val, imp, valence_bath=vb)
+        ref = g["%s/gso_eig_%s" % (name, tag)]
+        assert be.shape == ref.shape
+        nimp = 2 * len(imp)
+        assert np.array_equal(be[..., :nimp], ref[..., :nimp])                     # impurity columns: the identity block
+        assert _same_span(be[..., nimp:], ref[..., nimp:], 1e-10)
+        bp, _ = G.get_emb_basis_gso_ph(GRho, n, val, imp, valence_bath=vb)
+        refp = g["%s/gso_ph_%s" % (name, tag)]
+        assert bp.shape == refp.shape and _same_span(bp, refp, 1e-10)
+        B = bp.reshape(-1, bp.shape[-1])
+        assert np.abs(B.T @ B - np.eye(B.shape[-1])).max() < 1e-10
