@@ -467,8 +467,9 @@ int dmk_vcor_dV_dparam(dmk_ctx *ctx, int nent, int nb, const double *G, int64_t 
  * ALL levels as one particle-number sector (flags / mu0 / thr_deg / fit_tol as dmk_assign_occ; beta = INFINITY: T = 0), rho_k =
  * (ev occ) ev^H and its k -> R fold (real part; system/fourier.py:168-177) -- as ONE launch of one workgroup, nothing read back.
  *   ew, occ (spin nk, n); Vt (spin nk, n, n) c128, ROW m = eigenvector m; rho_k (spin nk, n, n) c128; rho_R (spin, nk, n n) f64
- *   info_dev[8]: mu, nerr, electrons spread over the degeneracy window, levels in it, status (0 ok / 1 no mu / 2 non-finite
- *   levels), max |Im| of the folded density, Jacobi not converged (0 / 1)
+ *   info_dev[12]: mu, nerr, electrons spread over the degeneracy window, levels in it, status (0 ok / 1 no mu / 2 non-finite
+ *   levels), max |Im| of the folded density, Jacobi not converged (0 / 1), Jacobi sweeps, then four phase clocks in
+ *   microseconds (eigensolver, occupations, density, fold)
  * *handled = 0 (and nothing launched) when the shape is outside the limits: the caller then takes dmk_eigh_batched + dmk_assign_occ
  * + dmk_occ_density + dmk_fold_k2R. */
 int dmk_small_meanfield(dmk_ctx *ctx, const int mesh[3], int n, int spin, const void *Fock_k, const double *add, int add_group,

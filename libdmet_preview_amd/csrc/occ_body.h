@@ -73,20 +73,51 @@ __device__ double kth_smallest(const double *__restrict__ e, long long n, long l
         __syncthreads();
         return found;
     }
+    // Large spectra (C5: 86 400 levels): radix select on the order-preserving bit pattern, ELEVEN bits per pass -- a 2048-bin
+    // histogram in LDS of the keys that agree with the digits found so far, a workgroup scan to the bin that holds rank k.  Six
+    // passes over the keys instead of the 64 of a bit-by-bit bisection (1.84 ms at C5, round 4); exact like it: the result is the
+    // very element a stable sort puts at rank k.
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned wave_tot[OCC_NT / 64];
+    __shared__ unsigned long long pick_prefix;
+    __shared__ long long pick_k;
     unsigned long long prefix = 0;
-    for (int bit = 63; bit >= 0; --bit) {
-        // among the keys that agree with `prefix` above `bit`, how many have this bit clear?
-        const unsigned long long hi_mask = bit == 63 ? 0ull : (~0ull << (bit + 1));
-        long long c = 0;
-        for (long long i = threadIdx.x; i < n; i += OCC_NT) {
+    int decided = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    while (decided < 64) {
+        const int bits = (64 - decided) >= 11 ? 11 : (64 - decided);
+        const int shift = 64 - decided - bits, nbins = 1 << bits;
+        __syncthreads();
+        for (int b = tid; b < 2048; b += OCC_NT) hist[b] = 0u;
+        __syncthreads();
+        for (long long i = tid; i < n; i += OCC_NT) {
             const unsigned long long key = occ_key(e[i]);
-            c += ((key & hi_mask) == prefix && !((key >> bit) & 1ull)) ? 1 : 0;
+            if (decided == 0 || (key >> (64 - decided)) == prefix) atomicAdd(&hist[(unsigned)((key >> shift) & (unsigned long long)(nbins - 1))], 1u);
         }
-        c = block_sum_i64(c, sh);
-        if (k >= c) {
-            k -= c;
-            prefix |= 1ull << bit;
+        __syncthreads();
+        // thread t owns bins 2t, 2t + 1; inclusive scan of the per-thread counts over the workgroup
+        const unsigned c0 = hist[2 * tid], c1 = hist[2 * tid + 1];
+        const unsigned mine = c0 + c1;
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
         }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned before = 0u;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        const long long excl = (long long)before + (long long)(incl - mine);
+        if (mine > 0u && k >= excl && k < excl + (long long)mine) {       // exactly one thread: counts are non-negative, k < total
+            const bool first = k < excl + (long long)c0;
+            pick_prefix = (prefix << bits) | (unsigned long long)(2 * tid + (first ? 0 : 1));
+            pick_k = first ? k - excl : k - excl - (long long)c0;
+        }
+        __syncthreads();
+        prefix = pick_prefix;
+        k = pick_k;
+        decided += bits;
     }
     return occ_val(prefix);
 }

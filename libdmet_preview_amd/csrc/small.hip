@@ -16,7 +16,7 @@
 // of the tall block (one fused reduction per column) + one-sided Jacobi on its nb x nb triangle -- no Gram-matrix shortcut, the
 // singular values keep the relative accuracy the sigma >= tol_bath count needs.
 // Limits (checked by the launchers, which return "not handled" so that the caller takes the general path): n <= 8 orbitals per
-// cell, nb <= 8 bath columns, spin * nk <= 256 blocks, nk <= 128, LDS carve-outs below.
+// cell, nb <= 8 bath columns, spin * nk <= 128 blocks (eight lanes per block), LDS carve-outs below.
 #include "common.h"
 #include <cmath>
 #include <algorithm>
@@ -39,8 +39,24 @@ struct SmallMF {
     double2 *Vt;                               // [nmat][n][n]: ROW m = eigenvector m
     double2 *rho_k;                            // [nmat][n][n]
     double *rho_R;                             // [spin][nk][n*n]
-    double *info;                              // [0..5) occupation info, [5] max |Im| of the fold, [6] Jacobi sweeps not converged
+    double *info;                              // [0..5) occupation info, [5] max |Im| of the fold, [6] Jacobi not converged, [7] sweeps
 };
+
+// hardware estimates + two Newton steps (v_rcp_f64 / v_rsq_f64 are good to ~2^-26; two steps square that twice: <= 1 ulp).  The
+// libm sqrt / division of the rotation parameters were two thirds of the eigensolver phase at n = 4 (seven of them in a
+// dependent chain per rotation).
+__device__ __forceinline__ double sm_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+__device__ __forceinline__ double sm_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
 
 __device__ __forceinline__ double block_max_f64(double v, double *sh) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -55,7 +71,7 @@ __device__ __forceinline__ double block_max_f64(double v, double *sh) {
 }
 
 __global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g) {
-    extern __shared__ double dyn[];            // Hr | Hi | Vr | Vi, each [n*n][mstride]; then twiddles [3][128] complex
+    extern __shared__ double dyn[];            // Hr | Hi | Vr | Vi, each [n*n][mstride]; twiddles [3][128] complex; ranks [nmat][8] int
     __shared__ double shd[SM_NT / 64];
     const int n = g.n, nn = n * n, nmat = g.nmat, ms = g.mstride, tid = threadIdx.x;
     double *Hr = dyn, *Hi = Hr + (size_t)nn * ms, *Vr = Hi + (size_t)nn * ms, *Vi = Vr + (size_t)nn * ms;
@@ -72,116 +88,139 @@ __global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g)
         }
         tw[t] = double2{c, s};
     }
-    int notconv = 0;
-    if (tid < nmat) {
-        const int m = tid;
-        const double2 *F = g.F + (size_t)m * nn;
-        const double *ad = g.add ? g.add + (size_t)(m / g.add_group) * nn : nullptr;
+    int notconv = 0, nsweep = 0;
+    const long long clk0 = wall_clock64();       // phase clocks of thread 0 (100 MHz) -> info[8..12], for the builder's profile
+    long long clk1 = clk0, clk2 = clk0, clk3 = clk0, clk4 = clk0;
+    // EIGHT lanes per matrix (lane r <-> row r in the column phase of a rotation, column r in the row phase): the loads and stores
+    // of a phase are independent across the lanes of a matrix and issue together; lanes of one matrix sit in one wave, so the LDS
+    // pipe keeps a phase's stores ahead of the next phase's loads (one thread per matrix walked ~160 dependent LDS accesses per
+    // rotation: 110 us for 36 matrices of 4 x 4).
+    const int m = tid >> 3, r = tid & 7;
+    const bool mat_ok = m < nmat, act = mat_ok && r < n;
 #define HR(i, j) Hr[(size_t)((i) * n + (j)) * ms + m]
 #define HI(i, j) Hi[(size_t)((i) * n + (j)) * ms + m]
 #define VR(i, j) Vr[(size_t)((i) * n + (j)) * ms + m]
 #define VI(i, j) Vi[(size_t)((i) * n + (j)) * ms + m]
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j <= i; ++j) {
+    int *rk = reinterpret_cast<int *>(tw + 3 * 128);          // [nmat][8]: sorted position of eigenpair l
+    if (mat_ok) {
+        const double2 *F = g.F + (size_t)m * nn;
+        const double *ad = g.add ? g.add + (size_t)(m / g.add_group) * nn : nullptr;
+        if (act) {
+            const int i = r;
+            for (int j = 0; j <= i; ++j) {                    // lower triangle of row i and its mirror image
                 const double2 f = F[i * n + j];
                 const double re = f.x + (ad ? ad[i * n + j] : 0.0), im = (i == j) ? 0.0 : f.y;
                 HR(i, j) = re; HI(i, j) = im;
                 HR(j, i) = re; HI(j, i) = -im;
             }
-        for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) { VR(i, j) = (i == j) ? 1.0 : 0.0; VI(i, j) = 0.0; }
-        // cyclic Jacobi on the Hermitian matrix: J = D R with D = diag(.., 1 (p), .., e^{-i phi} (q), ..), phi = arg h_pq, and R the
-        // real rotation that annihilates the (then real) pq element; H <- J^H H J, V <- V J
+        }
+        // max over the 8 lanes of a matrix
+        auto gmax = [&](double v) {
+            v = fmax(v, __shfl_xor(v, 1, 64));
+            v = fmax(v, __shfl_xor(v, 2, 64));
+            v = fmax(v, __shfl_xor(v, 4, 64));
+            return v;
+        };
         double scale = 0.0;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) scale = fmax(scale, fmax(fabs(HR(i, j)), fabs(HI(i, j))));
+        if (act)
+            for (int j = 0; j < n; ++j) scale = fmax(scale, fmax(fabs(HR(r, j)), fabs(HI(r, j))));
+        scale = gmax(scale);
         int sweep = 0;
         for (; sweep < 40; ++sweep) {
             double off = 0.0;
-            for (int p = 0; p < n; ++p)
-                for (int q = p + 1; q < n; ++q) off = fmax(off, fmax(fabs(HR(p, q)), fabs(HI(p, q))));
-            if (!(off > 1.0e-17 * scale)) break;
+            if (act)
+                for (int q = r + 1; q < n; ++q) off = fmax(off, fmax(fabs(HR(r, q)), fabs(HI(r, q))));
+            off = gmax(off);
+            if (!(off > 5.6e-17 * scale)) break;           // 2^-54: half an ulp of the largest element
             for (int p = 0; p < n; ++p)
                 for (int q = p + 1; q < n; ++q) {
-                    const double ar = HR(p, q), ai = HI(p, q);
-                    const double mod = sqrt(ar * ar + ai * ai);
-                    if (!(mod > 1.0e-300) || !(mod > 1.0e-18 * scale)) continue;
-                    const double er = ar / mod, ei = ai / mod;               // e^{i phi}
-                    const double tau = (HR(q, q) - HR(p, p)) / (2.0 * mod);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    // cyclic Jacobi on the Hermitian matrix: J = D R with D = diag(.., 1 (p), .., e^{-i phi} (q), ..), phi = arg h_pq,
+                    // R the real rotation that annihilates the (then real) pq element; H <- J^H H J, V <- V J
+                    const double ar = HR(p, q), ai = HI(p, q);                 // broadcast reads: every lane forms the same J
+                    const double mod2 = ar * ar + ai * ai;
+                    if (!(mod2 > 1.0e-290) || !(mod2 > 1.0e-34 * scale * scale)) continue;
+                    const double imod = sm_rsqrt(mod2);                      // 1 / |h_pq|
+                    const double er = ar * imod, ei = ai * imod;             // e^{i phi}
+                    const double tau = 0.5 * (HR(q, q) - HR(p, p)) * imod;
+                    const double rt = 1.0 + tau * tau;
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) * sm_rcp(fabs(tau) + rt * sm_rsqrt(rt));
+                    const double c = sm_rsqrt(1.0 + t * t), sn = t * c;
                     // J_pp = c, J_pq = s, J_qp = -s e^{-i phi}, J_qq = c e^{-i phi}
-                    const double jqp_r = -s * er, jqp_i = s * ei, jqq_r = c * er, jqq_i = -c * ei;
-                    for (int k = 0; k < n; ++k) {                            // columns: X[:, p], X[:, q] <- X J  (X = H and V)
+                    const double jqp_r = -sn * er, jqp_i = sn * ei, jqq_r = c * er, jqq_i = -c * ei;
+                    if (act) {                                               // columns: X[r, p], X[r, q] <- (X J)[r, .]  (X = H and V)
+                        const int k = r;
                         {
                             const double xpr = HR(k, p), xpi = HI(k, p), xqr = HR(k, q), xqi = HI(k, q);
                             HR(k, p) = c * xpr + (xqr * jqp_r - xqi * jqp_i);
                             HI(k, p) = c * xpi + (xqr * jqp_i + xqi * jqp_r);
-                            HR(k, q) = s * xpr + (xqr * jqq_r - xqi * jqq_i);
-                            HI(k, q) = s * xpi + (xqr * jqq_i + xqi * jqq_r);
+                            HR(k, q) = sn * xpr + (xqr * jqq_r - xqi * jqq_i);
+                            HI(k, q) = sn * xpi + (xqr * jqq_i + xqi * jqq_r);
                         }
                         {
                             const double xpr = VR(k, p), xpi = VI(k, p), xqr = VR(k, q), xqi = VI(k, q);
                             VR(k, p) = c * xpr + (xqr * jqp_r - xqi * jqp_i);
                             VI(k, p) = c * xpi + (xqr * jqp_i + xqi * jqp_r);
-                            VR(k, q) = s * xpr + (xqr * jqq_r - xqi * jqq_i);
-                            VI(k, q) = s * xpi + (xqr * jqq_i + xqi * jqq_r);
+                            VR(k, q) = sn * xpr + (xqr * jqq_r - xqi * jqq_i);
+                            VI(k, q) = sn * xpi + (xqr * jqq_i + xqi * jqq_r);
                         }
                     }
-                    for (int k = 0; k < n; ++k) {                            // rows: H[p, :], H[q, :] <- J^H H
+                    if (act) {                                               // rows: H[p, r], H[q, r] <- (J^H H)[., r]
+                        const int k = r;
                         const double xpr = HR(p, k), xpi = HI(p, k), xqr = HR(q, k), xqi = HI(q, k);
                         // conj(J_pp) = c, conj(J_qp) = (jqp_r, -jqp_i); conj(J_pq) = s, conj(J_qq) = (jqq_r, -jqq_i)
-                        HR(p, k) = c * xpr + (xqr * jqp_r + xqi * jqp_i);
-                        HI(p, k) = c * xpi + (xqi * jqp_r - xqr * jqp_i);
-                        HR(q, k) = s * xpr + (xqr * jqq_r + xqi * jqq_i);
-                        HI(q, k) = s * xpi + (xqi * jqq_r - xqr * jqq_i);
+                        double npr = c * xpr + (xqr * jqp_r + xqi * jqp_i);
+                        double npi = c * xpi + (xqi * jqp_r - xqr * jqp_i);
+                        double nqr = sn * xpr + (xqr * jqq_r + xqi * jqq_i);
+                        double nqi = sn * xpi + (xqi * jqq_r - xqr * jqq_i);
+                        if (k == q) { npr = 0.0; npi = 0.0; nqi = 0.0; }    // the annihilated element and the real diagonal
+                        if (k == p) { nqr = 0.0; nqi = 0.0; npi = 0.0; }
+                        HR(p, k) = npr; HI(p, k) = npi;
+                        HR(q, k) = nqr; HI(q, k) = nqi;
                     }
-                    HR(p, q) = 0.0; HI(p, q) = 0.0; HR(q, p) = 0.0; HI(q, p) = 0.0;
-                    HI(p, p) = 0.0; HI(q, q) = 0.0;
                 }
         }
         if (sweep >= 40) notconv = 1;
-        // ascending order (stable selection sort: columns of V follow their eigenvalue); levels out
-        for (int a = 0; a < n; ++a) {
-            int best = a;
-            for (int b = a + 1; b < n; ++b)
-                if (HR(b, b) < HR(best, best)) best = b;
-            if (best != a) {
-                // rotate best down to a keeping the order of the others (stable)
-                for (int b = best; b > a; --b) {
-                    const double t0 = HR(b, b); HR(b, b) = HR(b - 1, b - 1); HR(b - 1, b - 1) = t0;
-                    for (int k = 0; k < n; ++k) {
-                        double t1 = VR(k, b); VR(k, b) = VR(k, b - 1); VR(k, b - 1) = t1;
-                        t1 = VI(k, b); VI(k, b) = VI(k, b - 1); VI(k, b - 1) = t1;
-                    }
-                }
+        nsweep = sweep;
+        // ascending order, stable: lane a ranks eigenvalue a (ties by index); levels and eigenvector rows go to their sorted place
+        if (act) {
+            const int a0 = r;
+            const double la = HR(a0, a0);
+            int rank = 0;
+            for (int b = 0; b < n; ++b) {
+                const double lb = HR(b, b);
+                rank += (lb < la || (lb == la && b < a0)) ? 1 : 0;
             }
+            rk[m * 8 + a0] = rank;
+            const_cast<double *>(g.occ.ew)[(size_t)m * n + rank] = la;
+            for (int i = 0; i < n; ++i) g.Vt[(size_t)m * nn + rank * n + i] = double2{VR(i, a0), VI(i, a0)};
         }
-        for (int a = 0; a < n; ++a) const_cast<double *>(g.occ.ew)[(size_t)m * n + a] = HR(a, a);
-        for (int a = 0; a < n; ++a)
-            for (int i = 0; i < n; ++i) g.Vt[(size_t)m * nn + a * n + i] = double2{VR(i, a), VI(i, a)};
     }
     __threadfence();
     __syncthreads();
+    clk1 = wall_clock64();
     // occupations of ALL levels (one particle-number sector), the very code of dmk_assign_occ
     if (g.zero_t) occ_zero_t_body(g.occ);
     else occ_fermi_body(g.occ);
     __threadfence();
     __syncthreads();
-    if (tid < nmat) {                          // rho_k = (V occ) V^H
-        const int m = tid;
+    clk2 = wall_clock64();
+    // rho_k also stays in LDS for the fold (the H arrays are free now: 2 nn ms doubles >= nmat nn complex numbers)
+    double2 *rl = reinterpret_cast<double2 *>(Hr);
+    if (act) {                                 // rho_k = (V occ) V^H: lane r forms row r
         const double *oc = g.occ.occ + (size_t)m * n;
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) {
-                double re = 0.0, im = 0.0;
-                for (int l = 0; l < n; ++l) {
-                    const double o = oc[l];
-                    const double air = VR(i, l), aii = VI(i, l), bjr = VR(j, l), bji = VI(j, l);
-                    re += o * (air * bjr + aii * bji);                        // a conj(b)
-                    im += o * (aii * bjr - air * bji);
-                }
-                g.rho_k[(size_t)m * nn + i * n + j] = double2{re, im};
+        const int i = r;
+        for (int j = 0; j < n; ++j) {
+            double re = 0.0, im = 0.0;
+            for (int l = 0; l < n; ++l) {
+                const double o = oc[rk[m * 8 + l]];
+                const double air = VR(i, l), aii = VI(i, l), bjr = VR(j, l), bji = VI(j, l);
+                re += o * (air * bjr + aii * bji);                            // a conj(b)
+                im += o * (aii * bjr - air * bji);
             }
+            g.rho_k[(size_t)m * nn + i * n + j] = double2{re, im};
+            rl[(size_t)m * nn + i * n + j] = double2{re, im};
+        }
     }
 #undef HR
 #undef HI
@@ -189,6 +228,7 @@ __global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g)
 #undef VI
     __threadfence();
     __syncthreads();
+    clk3 = wall_clock64();
     // k -> R: rho_R[s][R][ij] = Re (1 / nk) sum_k e^{+2 pi i k.R} rho_k[s][k][ij]   (np.fft.ifftn over the mesh axes)
     const int nk = g.nk, n1 = g.mesh[1], n2 = g.mesh[2];
     const double inv = 1.0 / (double)nk;
@@ -196,22 +236,44 @@ __global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g)
     for (int o = tid; o < g.spin * nk * nn; o += SM_NT) {
         const int ij = o % nn, R = (o / nn) % nk, s = o / (nn * nk);
         const int r0 = R / (n1 * n2), r1 = (R / n2) % n1, r2 = R % n2;
+        const int n0 = g.mesh[0];
         double re = 0.0, im = 0.0;
-        for (int k = 0; k < nk; ++k) {
-            const int k0 = k / (n1 * n2), k1 = (k / n2) % n1, k2 = k % n2;
-            const double2 w0 = tw[(k0 * r0) % g.mesh[0]], w1 = tw[128 + (k1 * r1) % n1], w2 = tw[256 + (k2 * r2) % n2];
-            const double ar = w0.x * w1.x - w0.y * w1.y, ai = w0.x * w1.y + w0.y * w1.x;
-            const double pr = ar * w2.x - ai * w2.y, pi = ar * w2.y + ai * w2.x;
-            const double2 v = g.rho_k[((size_t)s * nk + k) * nn + ij];
-            re += pr * v.x - pi * v.y;
-            im += pr * v.y + pi * v.x;
+        // k = (k0 n1 + k1) n2 + k2 walked as three nested loops: the twiddle indices (k_d r_d) mod n_d advance by r_d with a
+        // conditional wrap -- no integer division inside (six of them per term made this loop two thirds of the kernel at C2)
+        const double2 *v = rl + (size_t)s * nk * nn + ij;
+        int i0 = 0;
+        for (int k0 = 0; k0 < n0; ++k0) {
+            const double2 w0 = tw[i0];
+            int i1 = 0;
+            for (int k1 = 0; k1 < n1; ++k1) {
+                const double2 w1 = tw[128 + i1];
+                const double ar = w0.x * w1.x - w0.y * w1.y, ai = w0.x * w1.y + w0.y * w1.x;
+                int i2 = 0;
+                for (int k2 = 0; k2 < n2; ++k2) {
+                    const double2 w2 = tw[256 + i2];
+                    const double pr = ar * w2.x - ai * w2.y, pi = ar * w2.y + ai * w2.x;
+                    const double2 x = *v;
+                    re += pr * x.x - pi * x.y;
+                    im += pr * x.y + pi * x.x;
+                    v += nn;
+                    i2 += r2; if (i2 >= n2) i2 -= n2;
+                }
+                i1 += r1; if (i1 >= n1) i1 -= n1;
+            }
+            i0 += r0; if (i0 >= n0) i0 -= n0;
         }
         g.rho_R[o] = re * inv;
         imax = fmax(imax, fabs(im * inv));
     }
     imax = block_max_f64(imax, shd);
     const double nc = block_max_f64((double)notconv, shd);
-    if (tid == 0) { g.info[5] = imax; g.info[6] = nc; }
+    const double ns = block_max_f64((double)nsweep, shd);
+    clk4 = wall_clock64();
+    if (tid == 0) {
+        g.info[5] = imax; g.info[6] = nc; g.info[7] = ns;
+        g.info[8] = 0.01 * (double)(clk1 - clk0); g.info[9] = 0.01 * (double)(clk2 - clk1);      // us: eigensolver, occupations,
+        g.info[10] = 0.01 * (double)(clk3 - clk2); g.info[11] = 0.01 * (double)(clk4 - clk3);    // density, fold
+    }
 }
 
 // ---- bath ---------------------------------------------------------------------------------------------------------------
@@ -228,29 +290,73 @@ struct SmallBath {
 };
 
 constexpr int SB_MAXB = 8;
+constexpr int SB_NT = 256;                     // tall matrices of a few hundred rows: four waves keep the reductions short
 
 // sum of `cnt` (<= SB_MAXB + 1) per-thread values over the workgroup, every thread receives all totals (fixed order)
-__device__ void block_sum_vec(double *v, int cnt, double *sh /* [SB_MAXB + 1][SM_NT / 64] */) {
+__device__ void block_sum_vec(double *v, int cnt, double *sh /* [SB_MAXB + 1][SB_NT / 64] */) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
     for (int c = 0; c < cnt; ++c) {
         const double s = dmk_wave_sum(v[c]);
-        if (lane == 0) sh[c * (SM_NT / 64) + wave] = s;
+        if (lane == 0) sh[c * (SB_NT / 64) + wave] = s;
     }
     __syncthreads();
     for (int c = 0; c < cnt; ++c) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < SM_NT / 64; ++w) t += sh[c * (SM_NT / 64) + w];
+        for (int w = 0; w < SB_NT / 64; ++w) t += sh[c * (SB_NT / 64) + w];
         v[c] = t;
     }
 }
 
-__global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
+// One-sided (Hestenes) Jacobi on the columns of the nb x nb matrix M (LDS, row-major), run by ONE wave: lane i owns row i, the
+// three sums of a column pair are 8-lane shuffle reductions, so a pair costs two LDS reads, nine shuffles and two writes where a
+// single thread walked ~20 dependent LDS accesses.  On return the columns are mutually orthogonal: their norms are the singular
+// values, the normalised columns the left singular vectors (for a symmetric positive semi-definite M: eigenvalues / eigenvectors).
+// Returns the number of sweeps, 60 = not converged.  Call with all 64 lanes of the wave.
+__device__ int wave_onesided_jacobi(double *M, int nb) {
+    const int i = threadIdx.x & 63;
+    const bool on = i < nb;
+    // The eight lanes of a group must take the SAME decision and apply the SAME rotation: the sums are butterflies of products
+    // rounded on their own (__dmul_rn: a fused multiply-add of a lane's own product into its partner's would round differently in
+    // the two lanes of a pair) and lane 0's totals are broadcast to the group.
+    auto sum8 = [&](double v) {
+        v = __dadd_rn(v, __shfl_xor(v, 1, 64));
+        v = __dadd_rn(v, __shfl_xor(v, 2, 64));
+        v = __dadd_rn(v, __shfl_xor(v, 4, 64));
+        return __shfl(v, i & ~7, 64);
+    };
+    int sweep = 0;
+    for (; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < nb; ++p)
+            for (int q = p + 1; q < nb; ++q) {
+                const double x = on ? M[i * nb + p] : 0.0, y = on ? M[i * nb + q] : 0.0;
+                const double al = sum8(__dmul_rn(x, x)), be = sum8(__dmul_rn(y, y)), ga = sum8(__dmul_rn(x, y));
+                if (!(fabs(ga) > 2.220446049250313e-16 * sqrt(al * be)) || ga == 0.0) continue;     // uniform over the wave
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                if (on) {
+                    M[i * nb + p] = c * x - sn * y;
+                    M[i * nb + q] = sn * x + c * y;
+                }
+            }
+        if (!rotated) break;
+    }
+    return sweep;
+}
+
+__global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
     extern __shared__ double dyn[];            // A [spin][nenv][nb] (becomes Q-applied U) | R, Ur [spin][nb][nb] | tau [spin][nb] | X [nb][nb]
-    __shared__ double shv[(SB_MAXB + 1) * (SM_NT / 64)];
+    __shared__ double shv[(SB_MAXB + 1) * (SB_NT / 64)];
     __shared__ int nbath_s[2];
     __shared__ int bad_s;
+    // work arrays of the single-thread sections (nb x nb problems): LDS, not per-thread arrays -- those live in scratch memory,
+    // where every access of the serial Jacobi loops is a round trip to L2
+    __shared__ double Ms[SB_MAXB * SB_MAXB], Ws[SB_MAXB * SB_MAXB], sgs[SB_MAXB];
+    __shared__ int ords[SB_MAXB];
     const int nenv = g.nenv, nb = g.nb, tid = threadIdx.x, spin = g.spin;
     double *Aall = dyn;
     double *Rall = Aall + (size_t)spin * nenv * nb;
@@ -263,7 +369,7 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
         double *tau = tauall + (size_t)s * nb;
         const double *rd = g.rdm1 + (size_t)s * g.rdm1_stride;
         // gather: A[r][c] = big[env_idx[r]][bath_col[c]], big[(R1, p), (R2, q)] = rdm1[R1 - R2][p][q]   (bath.hip)
-        for (int t = tid; t < nenv * nb; t += SM_NT) {
+        for (int t = tid; t < nenv * nb; t += SB_NT) {
             const int r = t / nb, c = t % nb;
             const int e = g.env_idx[r], sc = g.bath_col[c];
             const int R1 = e / g.nlo, p = e % g.nlo, R2 = sc / g.nlo, q = sc % g.nlo;
@@ -279,7 +385,7 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
         for (int j = 0; j < nb && j < nenv; ++j) {
             double acc[SB_MAXB + 1];
             double nrm2 = 0.0;
-            for (int r = j + tid; r < nenv; r += SM_NT) nrm2 = fma(A[r * nb + j], A[r * nb + j], nrm2);
+            for (int r = j + tid; r < nenv; r += SB_NT) nrm2 = fma(A[r * nb + j], A[r * nb + j], nrm2);
             acc[0] = nrm2;
             block_sum_vec(acc, 1, shv);
             const double xn = sqrt(acc[0]);
@@ -290,12 +396,12 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
             const double tj = vv > 0.0 ? 2.0 / vv : 0.0;
             // dots with the later columns
             for (int k = 0; k <= SB_MAXB; ++k) acc[k] = 0.0;
-            for (int r = j + tid; r < nenv; r += SM_NT) {
+            for (int r = j + tid; r < nenv; r += SB_NT) {
                 const double vr = (r == j) ? vj : A[r * nb + j];
                 for (int k = j + 1; k < nb; ++k) acc[k - j - 1] = fma(vr, A[r * nb + k], acc[k - j - 1]);
             }
             block_sum_vec(acc, nb - j - 1, shv);
-            for (int r = j + tid; r < nenv; r += SM_NT) {
+            for (int r = j + tid; r < nenv; r += SB_NT) {
                 const double vr = (r == j) ? vj : A[r * nb + j];
                 for (int k = j + 1; k < nb; ++k) A[r * nb + k] -= tj * acc[k - j - 1] * vr;
             }
@@ -311,61 +417,36 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
             __syncthreads();
         }
         // one-sided Jacobi SVD of the nb x nb triangle R = Ur diag(sigma) W^T: columns rotated until mutually orthogonal
-        if (tid == 0) {
+        if (tid < 64) {
             const int k = nb < nenv ? nb : nenv;
-            for (int i = k; i < nb; ++i)
-                for (int c = 0; c < nb; ++c) Rm[i * nb + c] = 0.0;
-            double M[SB_MAXB * SB_MAXB];
-            for (int i = 0; i < nb * nb; ++i) M[i] = Rm[i];
-            int sweep = 0;
-            for (; sweep < 60; ++sweep) {
-                bool rotated = false;
-                for (int p = 0; p < nb; ++p)
-                    for (int q = p + 1; q < nb; ++q) {
-                        double al = 0.0, be = 0.0, ga = 0.0;
-                        for (int i = 0; i < nb; ++i) {
-                            al = fma(M[i * nb + p], M[i * nb + p], al);
-                            be = fma(M[i * nb + q], M[i * nb + q], be);
-                            ga = fma(M[i * nb + p], M[i * nb + q], ga);
-                        }
-                        if (!(fabs(ga) > 2.220446049250313e-16 * sqrt(al * be)) || ga == 0.0) continue;
-                        rotated = true;
-                        const double zeta = (be - al) / (2.0 * ga);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                        for (int i = 0; i < nb; ++i) {
-                            const double x = M[i * nb + p], y = M[i * nb + q];
-                            M[i * nb + p] = c * x - sn * y;
-                            M[i * nb + q] = sn * x + c * y;
-                        }
-                    }
-                if (!rotated) break;
+            double *M = Ms;
+            for (int e = tid; e < nb * nb; e += 64) M[e] = (e / nb) < k ? Rm[e] : 0.0;
+            const int sweeps = wave_onesided_jacobi(M, nb);
+            if (tid == 0 && sweeps >= 60) bad_s = 1;
+            // sigma = column norms, descending (stable: ties by index), Ur = normalised columns in that order
+            if (tid < nb) {
+                double a2 = 0.0;
+                for (int i = 0; i < nb; ++i) a2 = fma(M[i * nb + tid], M[i * nb + tid], a2);
+                sgs[tid] = sqrt(a2);
             }
-            if (sweep >= 60) bad_s = 1;
-            // sigma = column norms, descending (stable), Ur = normalised columns in that order
-            double sg[SB_MAXB];
-            int ord[SB_MAXB];
-            for (int c = 0; c < nb; ++c) {
-                double a = 0.0;
-                for (int i = 0; i < nb; ++i) a = fma(M[i * nb + c], M[i * nb + c], a);
-                sg[c] = sqrt(a);
-                ord[c] = c;
+            if (tid < nb) {                                                // same wave: sgs is complete (LDS program order)
+                const double mine = sgs[tid];
+                int pos = 0;
+                for (int c = 0; c < nb; ++c) pos += (sgs[c] > mine || (sgs[c] == mine && c < tid)) ? 1 : 0;
+                ords[pos] = tid;
             }
-            for (int a = 1; a < nb; ++a) {                                 // insertion sort, descending, stable
-                const int oa = ord[a];
-                int b = a - 1;
-                while (b >= 0 && sg[ord[b]] < sg[oa]) { ord[b + 1] = ord[b]; --b; }
-                ord[b + 1] = oa;
-            }
-            int cnt = 0;
-            for (int c = 0; c < nb; ++c) {
-                const double sv = sg[ord[c]];
-                g.sigma[s * nb + c] = sv;
-                if (sv >= g.tol) ++cnt;
+            if (tid < nb) {
+                const int src = ords[tid];
+                const double sv = sgs[src];
+                g.sigma[s * nb + tid] = sv;
                 const double inv = sv > 0.0 ? 1.0 / sv : 0.0;
-                for (int i = 0; i < nb; ++i) Ur[i * nb + c] = M[i * nb + ord[c]] * inv;
+                for (int i = 0; i < nb; ++i) Ur[i * nb + tid] = M[i * nb + src] * inv;
             }
-            nbath_s[s] = cnt;
+            if (tid == 0) {
+                int cnt = 0;
+                for (int c = 0; c < nb; ++c) cnt += (sgs[c] >= g.tol) ? 1 : 0;
+                nbath_s[s] = cnt;
+            }
         }
         __syncthreads();
         // U = Q [Ur; 0]: the reflectors applied in reverse order to the rows of [Ur; 0] -- into the storage of A, whose reflector
@@ -374,7 +455,7 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
         // the reflector components are copied to registers per row batch instead -- simpler: keep a second array?  nenv * nb
         // doubles more of LDS is affordable for the sizes this kernel accepts: Y lives behind X.
         double *Y = X + nb * nb;                                           // [nenv][nb]
-        for (int t = tid; t < nenv * nb; t += SM_NT) {
+        for (int t = tid; t < nenv * nb; t += SB_NT) {
             const int r = t / nb, c = t % nb;
             Y[t] = r < nb ? Ur[r * nb + c] : 0.0;
         }
@@ -382,20 +463,20 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
         for (int j = (nb < nenv ? nb : nenv) - 1; j >= 0; --j) {
             double acc[SB_MAXB + 1];
             for (int k = 0; k < nb; ++k) acc[k] = 0.0;
-            for (int r = j + tid; r < nenv; r += SM_NT) {
+            for (int r = j + tid; r < nenv; r += SB_NT) {
                 const double vr = A[r * nb + j];
                 for (int k = 0; k < nb; ++k) acc[k] = fma(vr, Y[r * nb + k], acc[k]);
             }
             block_sum_vec(acc, nb, shv);
             const double tj = tau[j];
-            for (int r = j + tid; r < nenv; r += SM_NT) {
+            for (int r = j + tid; r < nenv; r += SB_NT) {
                 const double vr = A[r * nb + j];
                 for (int k = 0; k < nb; ++k) Y[r * nb + k] -= tj * acc[k] * vr;
             }
             __syncthreads();
         }
         // U of this spin -> A's storage (the reflectors are no longer needed), and to global memory when asked for
-        for (int t = tid; t < nenv * nb; t += SM_NT) {
+        for (int t = tid; t < nenv * nb; t += SB_NT) {
             A[t] = Y[t];
             if (g.U) g.U[(size_t)s * nenv * nb + t] = Y[t];
         }
@@ -405,24 +486,24 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
     int nbf = nb;
     for (int s = 0; s < spin; ++s) nbf = nbath_s[s] < nbf ? nbath_s[s] : nbf;
     const int ncol = g.nimp + nbf;
-    for (size_t t = tid; t < (size_t)spin * g.nsites * ncol; t += SM_NT) g.basis[t] = 0.0;
+    for (size_t t = tid; t < (size_t)spin * g.nsites * ncol; t += SB_NT) g.basis[t] = 0.0;
     __threadfence();
     __syncthreads();
     for (int s = 0; s < spin; ++s) {
         double *A = Aall + (size_t)s * nenv * nb;
         double *bs = g.basis + (size_t)s * g.nsites * ncol;
         const int nbs = nbath_s[s];
-        for (int i = tid; i < g.nimp && i < ncol; i += SM_NT) bs[(size_t)g.imp_idx[i] * ncol + i] = 1.0;
+        for (int i = tid; i < g.nimp && i < ncol; i += SB_NT) bs[(size_t)g.imp_idx[i] * ncol + i] = 1.0;
         if (nbs == 0) continue;
         if (g.orth) {
-            for (int t = tid; t < nenv * nb; t += SM_NT)
+            for (int t = tid; t < nenv * nb; t += SB_NT)
                 if (g.virt_mask[t / nb]) A[t] = 0.0;
             __syncthreads();
             // metric S = B^T B (nbs x nbs), one fused reduction per row of S
             for (int i = 0; i < nbs; ++i) {
                 double acc[SB_MAXB + 1];
                 for (int k = 0; k < nbs; ++k) acc[k] = 0.0;
-                for (int r = tid; r < nenv; r += SM_NT) {
+                for (int r = tid; r < nenv; r += SB_NT) {
                     const double bi = A[r * nb + i];
                     for (int k = 0; k < nbs; ++k) acc[k] = fma(bi, A[r * nb + k], acc[k]);
                 }
@@ -431,55 +512,36 @@ __global__ __launch_bounds__(SM_NT) void small_bath_kernel(const SmallBath g) {
                     for (int k = 0; k < nbs; ++k) X[i * nb + k] = acc[k];
             }
             __syncthreads();
-            if (tid == 0) {
-                // X = S^-1/2 = sum_{e_m > 1e-14} v_m v_m^T / sqrt(e_m) (lo/lowdin.py:83-91): cyclic Jacobi of the small metric
-                double Sm[SB_MAXB * SB_MAXB], Vm[SB_MAXB * SB_MAXB];
-                for (int i = 0; i < nbs; ++i)
-                    for (int k = 0; k < nbs; ++k) { Sm[i * nbs + k] = X[i * nb + k]; Vm[i * nbs + k] = (i == k) ? 1.0 : 0.0; }
-                for (int sweep = 0; sweep < 60; ++sweep) {
-                    double off = 0.0, dg = 0.0;
-                    for (int p = 0; p < nbs; ++p) {
-                        dg = fmax(dg, fabs(Sm[p * nbs + p]));
-                        for (int q = p + 1; q < nbs; ++q) off = fmax(off, fabs(Sm[p * nbs + q]));
-                    }
-                    if (!(off > 1.0e-17 * dg)) break;
-                    for (int p = 0; p < nbs; ++p)
-                        for (int q = p + 1; q < nbs; ++q) {
-                            const double apq = Sm[p * nbs + q];
-                            if (!(fabs(apq) > 1.0e-300)) continue;
-                            const double tau2 = (Sm[q * nbs + q] - Sm[p * nbs + p]) / (2.0 * apq);
-                            const double t = (tau2 >= 0.0 ? 1.0 : -1.0) / (fabs(tau2) + sqrt(1.0 + tau2 * tau2));
-                            const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
-                            for (int k = 0; k < nbs; ++k) {
-                                const double x = Sm[k * nbs + p], y = Sm[k * nbs + q];
-                                Sm[k * nbs + p] = c * x - sn * y;
-                                Sm[k * nbs + q] = sn * x + c * y;
-                            }
-                            for (int k = 0; k < nbs; ++k) {
-                                const double x = Sm[p * nbs + k], y = Sm[q * nbs + k];
-                                Sm[p * nbs + k] = c * x - sn * y;
-                                Sm[q * nbs + k] = sn * x + c * y;
-                            }
-                            for (int k = 0; k < nbs; ++k) {
-                                const double x = Vm[k * nbs + p], y = Vm[k * nbs + q];
-                                Vm[k * nbs + p] = c * x - sn * y;
-                                Vm[k * nbs + q] = sn * x + c * y;
-                            }
-                        }
+            if (tid < 64) {
+                // X = S^-1/2 = sum_{e_m > 1e-14} v_m v_m^T / sqrt(e_m) (lo/lowdin.py:83-91).  S is symmetric positive semi-definite:
+                // the one-sided Jacobi on its columns leaves S J = V Lambda -- column norms = eigenvalues, normalised columns =
+                // eigenvectors (the general path takes the same route, bath.hip dmk_bath_assemble)
+                double *Sm = Ms, *Vm = Ws;
+                for (int e = tid; e < nbs * nbs; e += 64) Sm[e] = X[(e / nbs) * nb + (e % nbs)];
+                const int sweeps = wave_onesided_jacobi(Sm, nbs);
+                if (tid == 0 && sweeps >= 60) bad_s = 1;
+                if (tid < nbs) {
+                    double a2 = 0.0;
+                    for (int i = 0; i < nbs; ++i) a2 = fma(Sm[i * nbs + tid], Sm[i * nbs + tid], a2);
+                    const double e = sqrt(a2);
+                    sgs[tid] = e;
+                    const double inv = e > 0.0 ? 1.0 / e : 0.0;
+                    for (int i = 0; i < nbs; ++i) Vm[i * nbs + tid] = Sm[i * nbs + tid] * inv;
                 }
-                for (int i = 0; i < nbs; ++i)
+                if (tid < nbs) {                                           // row tid of X
                     for (int k = 0; k < nbs; ++k) {
                         double a = 0.0;
                         for (int m = 0; m < nbs; ++m) {
-                            const double e = Sm[m * nbs + m];
-                            if (e > 1.0e-14) a += Vm[i * nbs + m] * Vm[k * nbs + m] / sqrt(e);
+                            const double e = sgs[m];
+                            if (e > 1.0e-14) a += Vm[tid * nbs + m] * Vm[k * nbs + m] / sqrt(e);
                         }
-                        X[i * nb + k] = a;
+                        X[tid * nb + k] = a;
                     }
+                }
             }
             __syncthreads();
         }
-        for (int t = tid; t < nenv * nbs; t += SM_NT) {
+        for (int t = tid; t < nenv * nbs; t += SB_NT) {
             const int r = t / nbs, c = t % nbs;
             double v;
             if (g.orth) {
@@ -513,7 +575,7 @@ int dmk_small_meanfield(dmk_ctx *ctx, const int mesh[3], int n, int spin, const 
     const long long nk = (long long)mesh[0] * mesh[1] * mesh[2];
     if (mesh[0] < 1 || mesh[1] < 1 || mesh[2] < 1) return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: bad mesh");
     const long long nmat = spin * nk;
-    if (n > SM_MAXN || nmat > 256 || nk > 128 || mesh[0] > 128 || mesh[1] > 128 || mesh[2] > 128) return DMK_OK;
+    if (n > SM_MAXN || nmat > SM_NT / 8 || nk > 128 || mesh[0] > 128 || mesh[1] > 128 || mesh[2] > 128) return DMK_OK;
     if (add && add_group < 1) return dmk_fail(ctx, DMK_ERR_INVALID, "small_meanfield: add_group must be positive");
     const bool zero_t = !(beta < INFINITY);
     const long long nlev = nmat * n;
@@ -531,7 +593,7 @@ int dmk_small_meanfield(dmk_ctx *ctx, const int mesh[3], int n, int spin, const 
     g.occ.occ = occ; g.occ.out = info_dev;
     g.zero_t = zero_t ? 1 : 0;
     g.Vt = static_cast<double2 *>(Vt); g.rho_k = static_cast<double2 *>(rho_k); g.rho_R = rho_R; g.info = info_dev;
-    const size_t lds = ((size_t)4 * n * n * g.mstride + 2 * 3 * 128) * sizeof(double);
+    const size_t lds = ((size_t)4 * n * n * g.mstride + 2 * 3 * 128) * sizeof(double) + (size_t)nmat * 8 * sizeof(int);
     if (lds > 120 * 1024) return DMK_OK;
     if (lds > 48 * 1024)
         DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(small_meanfield_kernel),
@@ -564,7 +626,7 @@ int dmk_small_bath(dmk_ctx *ctx, const int mesh[3], int nlo, int spin, const dou
         DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(small_bath_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
     FamScope fs(ctx, DMK_FAM_BATH);
-    hipLaunchKernelGGL(small_bath_kernel, dim3(1), dim3(SM_NT), lds, ctx->stream, g);
+    hipLaunchKernelGGL(small_bath_kernel, dim3(1), dim3(SB_NT), lds, ctx->stream, g);
     DMK_CHECK_LAUNCH(ctx);
     *handled = 1;
     return DMK_OK;

@@ -194,42 +194,50 @@ def small_lattice_stages(ctx, sysm, timers=None, tol_bath=1e-9):
         return None
     n, nk, spin = sysm.nlo, sysm.nk, sysm.spin
     nb, nenv, nimp = sysm.nval, len(sysm.env_idx), n
-    if n > 8 or nb > 8 or spin * nk > 256 or nk > 128:
+    if n > 8 or nb > 8 or spin * nk > 128 or nk > 128:
         return None
     timers = {} if timers is None else timers
     t = time.perf_counter()
-    nelec = mfd.check_nelec(spin * nk * n * sysm.filling, None)[0]
-    d_w, d_occ = ctx.empty((spin * nk, n), np.float64), ctx.empty((spin * nk, n), np.float64)
-    d_Vt, d_rho = ctx.empty((spin * nk, n, n), np.complex128), ctx.empty((spin * nk, n, n), np.complex128)
-    d_rhoR = ctx.empty((spin, nk, n * n), np.float64)
-    # one small result record: info[8] | sigma[spin][nb] | (ncol, nbath_s.., flag) as int32
-    nrec = 8 + spin * nb + 2
-    d_rec = ctx.empty((nrec,), np.float64)
+    # Everything that does not change from step to step lives with the system: the device arrays of the step (seven hipMalloc /
+    # hipFree pairs cost more than the two kernels), the mesh / electron count / views of the result record.  The products
+    # returned below are therefore valid until the next small-lattice step on the same system.
+    ws = sysm.__dict__.get("_small_ws")
+    if ws is None:
+        from libdmet_preview_amd._lib import mesh3
+        nrec = 12 + spin * nb + 2                   # one result record: info[12] | sigma[spin][nb] | (ncol, nbath_s.., flag) as int32
+        d_rec = ctx.empty((nrec,), np.float64)
+        ws = {"w": ctx.empty((spin * nk, n), np.float64), "occ": ctx.empty((spin * nk, n), np.float64),
+              "Vt": ctx.empty((spin * nk, n, n), np.complex128), "rho": ctx.empty((spin * nk, n, n), np.complex128),
+              "rhoR": ctx.empty((spin, nk, n * n), np.float64), "rec": d_rec,
+              "basis": ctx.empty((spin, nk * n, nimp + nb), np.float64), "sigma": d_rec.offset(12, (spin, nb)),
+              "iout": d_rec.offset(12 + spin * nb, (2,)), "mesh": mesh3(sysm.mesh),
+              "nelec": float(mfd.check_nelec(spin * nk * n * sysm.filling, None)[0]), "views": {}}
+        sysm.__dict__["_small_ws"] = ws
+    d_w, d_occ, d_rhoR, d_rec, d_basis_buf = ws["w"], ws["occ"], ws["rhoR"], ws["rec"], ws["basis"]
     handled = C.c_int(0)
-    from libdmet_preview_amd._lib import mesh3
-    ctx.check(lib.dmk_small_meanfield(ctx.h, mesh3(sysm.mesh), n, spin, sysm.d_Fock_k.ptr, sysm.d_vcor.ptr if sysm.d_vcor is not None else None,
-                                      nk, float(nelec), float("inf"), 0.0, 0, 1e-6, 1e-12, d_w.ptr, d_occ.ptr, d_Vt.ptr, d_rho.ptr,
+    ctx.check(lib.dmk_small_meanfield(ctx.h, ws["mesh"], n, spin, sysm.d_Fock_k.ptr, sysm.d_vcor.ptr if sysm.d_vcor is not None else None,
+                                      nk, ws["nelec"], float("inf"), 0.0, 0, 1e-6, 1e-12, d_w.ptr, d_occ.ptr, ws["Vt"].ptr, ws["rho"].ptr,
                                       d_rhoR.ptr, d_rec.ptr, C.byref(handled)))
     if not handled.value:
         return None
-    d_basis_buf = ctx.empty((spin, nk * n, nimp + nb), np.float64)
-    d_sigma = d_rec.offset(8, (spin, nb))
-    d_iout = d_rec.offset(8 + spin * nb, (2,))
-    ctx.check(lib.dmk_small_bath(ctx.h, mesh3(sysm.mesh), n, spin, d_rhoR.ptr, nk * n * n, sysm.d_env.ptr, nenv, sysm.d_col.ptr, nb,
-                                 sysm.d_virt.ptr, 1, sysm.d_imp.ptr, nimp, nk * n, float(tol_bath), d_sigma.ptr, None, d_basis_buf.ptr,
-                                 d_iout.ptr, C.byref(handled)))
+    ctx.check(lib.dmk_small_bath(ctx.h, ws["mesh"], n, spin, d_rhoR.ptr, nk * n * n, sysm.d_env.ptr, nenv, sysm.d_col.ptr, nb,
+                                 sysm.d_virt.ptr, 1, sysm.d_imp.ptr, nimp, nk * n, float(tol_bath), ws["sigma"].ptr, None, d_basis_buf.ptr,
+                                 ws["iout"].ptr, C.byref(handled)))
     if not handled.value:
         return None
     rec = d_rec.get()                                   # the ONE synchronising read-back of the step
-    info, sig = rec[:8], rec[8:8 + spin * nb].reshape(spin, nb)
-    iout = rec[8 + spin * nb:].view(np.int32)
+    info, sig = rec[:12], rec[12:12 + spin * nb].reshape(spin, nb)
+    iout = rec[12 + spin * nb:].view(np.int32)
     if info[4] != 0.0 or info[6] != 0.0 or iout[1 + spin] != 0:
         raise RuntimeError("small-lattice step failed: occupation status %g, eigensolver flag %g, SVD flag %d"
                            % (info[4], info[6], int(iout[1 + spin])))
     nemb = int(iout[0])
-    d_basis = ctx.wrap(d_basis_buf.address, (spin, nk * n, nemb), np.float64, keepalive=d_basis_buf)
+    d_basis = ws["views"].get(nemb)
+    if d_basis is None:
+        d_basis = ws["views"][nemb] = ctx.wrap(d_basis_buf.address, (spin, nk * n, nemb), np.float64, keepalive=d_basis_buf)
     timers["small_step"] = timers.get("small_step", 0.0) + (time.perf_counter() - t)
-    mf = {"mu": float(info[0]), "ew": d_w, "occ": d_occ, "nerr": float(info[1]), "imag_max": float(info[5])}
+    mf = {"mu": float(info[0]), "ew": d_w, "occ": d_occ, "nerr": float(info[1]), "imag_max": float(info[5]), "jacobi_sweeps": int(info[7]),
+          "phase_us": [float(x) for x in info[8:12]]}
     return d_rhoR, mf, d_basis, nemb, [sig[s] for s in range(spin)]
 
 
@@ -421,7 +429,7 @@ def iteration(ctx, sysm, eri_dev=None, kL_list=None, timers=None, max_blocks_per
         d_rhoR, mf = mean_field_stage(ctx, sysm, timers)
         d_basis, nemb, sigmas = bath_stage(ctx, sysm, d_rhoR, timers)
     out = {"rho_R": d_rhoR, "basis": d_basis, "nemb": nemb, "sigma": sigmas, "mu": mf["mu"], "ew": mf["ew"], "occ": mf["occ"],
-           "timers": timers}
+           "timers": timers, "jacobi_sweeps": mf.get("jacobi_sweeps"), "small_phase_us": mf.get("phase_us")}
     if sysm.naux > 0:
         d_C, d_bk = c_ao_emb_stage(ctx, sysm, d_basis, nemb, timers, return_basis_k=True)
         npair = nemb * (nemb + 1) // 2

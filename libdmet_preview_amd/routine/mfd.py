@@ -393,7 +393,7 @@ def _hf_small(ctx, kmesh, Fock, vcor, spin, nkpts, n, nelec, beta, mu0, fix_mu, 
     import ctypes as C
     import os
     from libdmet_preview_amd._lib import mesh3
-    if os.environ.get("DMK_SMALL", "1") == "0" or n > 8 or spin * nkpts > 256 or nkpts > 128:
+    if os.environ.get("DMK_SMALL", "1") == "0" or n > 8 or spin * nkpts > 128 or nkpts > 128:
         return None
     if int(np.prod(kmesh)) != nkpts:
         return None
@@ -403,7 +403,7 @@ def _hf_small(ctx, kmesh, Fock, vcor, spin, nkpts, n, nelec, beta, mu0, fix_mu, 
     d_w, d_occ = ctx.empty((spin * nkpts, n), np.float64), ctx.empty((spin * nkpts, n), np.float64)
     d_Vt, d_rho = ctx.empty((spin * nkpts, n, n), np.complex128), ctx.empty((spin * nkpts, n, n), np.complex128)
     d_rhoT = ctx.empty((spin, nkpts, n * n), np.float64)
-    d_info = ctx.empty((8,), np.float64)
+    d_info = ctx.empty((12,), np.float64)
     zero_t = not (beta < np.inf)
     if zero_t:
         if nelec > spin * nkpts * n:
