@@ -696,6 +696,12 @@ def main():
                 hbm[k] = {"ms_per_step": round(ms_step, 4), "launches_per_step": round(fam_out[k]["launches"] / a.steps, 1),
                           "algorithmic_GB_per_step": round(by / 1e9, 4), "GBps": round(by / (ms_step * 1e-3) / 1e9, 1),
                           "frac_of_hbm_peak": round(by / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+        if "eigh" in hbm:
+            # the eigensolver is flop / latency bound, not bandwidth bound (PMC: 3.45x the algorithmic bytes at 1 % of the HBM roof):
+            # its own rate against the (10/3) n^3 complex-Hermitian flop model (x 4 real flop per complex multiply-add pair)
+            fl = spin * nk * (10.0 / 3.0) * 4.0 * float(n) ** 3
+            hbm["eigh"]["flop_model"] = "(10/3) n^3 x 4 per matrix (tridiagonalisation + eigenvectors + back-transformation)"
+            hbm["eigh"]["tflops_of_flop_model"] = round(fl / (hbm["eigh"]["ms_per_step"] * 1e-3) / 1e12, 3)
         if fresh:
             # measured HBM bytes of the same stages (rocprofv3 PMC, profiles/traffic_latest.json): traffic / algorithmic = re-reads
             # per STEP: a family's bytes per launch x its launches per step of the profiled run (older files: one launch per step)

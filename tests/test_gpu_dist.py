@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(workload, dist_on, rank=0, world=1, over=None, device=0, exchange="allreduce", own_stream=False):
+    # The ERI and H1 compared below live in the GAUGE of the bath vectors.  The fused small-lattice kernels (csrc/small.hip) only
+    # serve single-process runs and return an equally valid but different gauge than the general chain the ranks run: both sides
+    # of the comparison take the general chain.
+    os.environ["DMK_SMALL"] = "0"
     from libdmet_preview_amd import _lib, pipeline
     from libdmet_preview_amd.basis_transform import eri_transform as et
     from libdmet_preview_amd.parallel import dist
@@ -116,6 +120,7 @@ def _run_light(workload, dist_on, rank=0, world=1, over=None, rows=48, seed=5):
     from libdmet_preview_amd import _lib, pipeline
     from libdmet_preview_amd.basis_transform import eri_transform as et
     from libdmet_preview_amd.parallel import dist
+    os.environ["DMK_SMALL"] = "0"                  # same gauge on both sides (see _run)
     ctx = _lib.Context(0)
     _lib.set_ctx(ctx)
     sysm = pipeline.SyntheticSystem.from_workload(ctx, workload, **(over or {}))
@@ -313,6 +318,7 @@ def test_bench_script_two_ranks_gloo_one_gpu(scaling):
 
 
 def _fit_run(dist_on, device=0, shard=None):
+    os.environ["DMK_SMALL"] = "0"                  # same gauge on both sides (see _run)
     from libdmet_preview_amd import _lib, pipeline
     ctx = _lib.Context(device)
     _lib.set_ctx(ctx)
@@ -342,6 +348,7 @@ def _local_fit_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as td
     out = None
+    os.environ["DMK_SMALL"] = "0"                  # same gauge on both sides (see _run)
     if rank == 0:                    # the single-process pipeline up to the fit, BEFORE a process group exists
         from libdmet_preview_amd import _lib, pipeline
         ctx = _lib.Context(0)
