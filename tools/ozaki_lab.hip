@@ -1,0 +1,274 @@
+// LAB (round 5; not part of the product): the contraction  C (N x N) = X^T Y,  X, Y (K x N) f64, K = 1600
+// (basis_transform/eri_transform.py:436-485 `_Lij_s4_to_eri`; product kernel: csrc/dgemm_tn.hip at 69-70 TF = 0.89 of the f64
+// matrix pipe) as an Ozaki-style sum of INT8 products on the i8 matrix cores (v_mfma_i32_16x16x64_i8, ~50x the f64 MFMA rate).
+//
+//   x_ka = 2^(e_a) * sum_s d_s[a][k] 2^(-6 - 7 s) + r,   d_s integers in [-64, 64], |r| <= 2^(e_a - 7 S)      (per COLUMN a)
+//   C_ab ~ 2^(e_a + e_b) * sum_{s + t < S} 2^(-12 - 7 (s + t)) * sum_k d^X_s[a][k] d^Y_t[b][k]
+//
+// every inner sum is EXACT in int32 (|d| <= 64, K <= 1600 + padding: < 2^24 per pair, < 2^27 per anti-diagonal), the only
+// error is the truncation: |dC_ab| <= (S + 1) K 2^(-7 S) 2^(e_a + e_b) (bound printed; the dropped pairs s + t >= S).  S is
+// chosen from the data so that the bound meets an ABSOLUTE tolerance (the north star's 1e-8 on the ERI, split over the kL sum):
+// the benchmark's planes need S = 4 (10 slice pairs), data with a 1e5 dynamic range in |eri| S = 7-8 (28-36 pairs: no gain).
+//
+// What the lab measures: slicing pass (f64 planes -> S int8 slice planes, transposed to k-contiguous rows), the fused slice-pair
+// GEMM with f64 recombination per anti-diagonal, accuracy against an f64 reference, and the time against the f64 pipe.
+//   hipcc -O3 --offload-arch=gfx950 tools/ozaki_lab.hip -o tools/ozaki_lab && tools/ozaki_lab [N=8192] [K=1600] [S=4]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---- inputs: uniform in (-1, 1) * column scale (a mild dynamic range across columns, like tril-packed pair densities) --------
+__global__ void fill_kernel(long long n, int N, unsigned long long seed, double *out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+        const int col = (int)(i % N);
+        out[i] = u * (0.25 + 0.75 * (double)((col * 2654435761u) >> 24) / 256.0) * 1.0e-2;
+    }
+}
+
+// ---- column exponents: e_a = smallest integer with max_k |x_ka| <= 2^e_a ------------------------------------------------------
+__global__ void colexp_kernel(int K, int N, const double *__restrict__ X, int *__restrict__ ex) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N) return;
+    double m = 0.0;
+    for (int k = 0; k < K; ++k) m = fmax(m, fabs(X[(long long)k * N + a]));
+    int e = 0;
+    if (m > 0.0) {
+        (void)frexp(m, &e);                 // m = f 2^e, 0.5 <= f < 1  ->  m < 2^e
+    } else {
+        e = -1000;
+    }
+    ex[a] = e;
+}
+
+// ---- slicing: Xs[s][a][k] (k contiguous, row pitch KP bytes), 32 x 32 tile transpose through LDS ------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void slice_kernel(int K, int KP, int N, const double *__restrict__ X, const int *__restrict__ ex,
+                                                    int8_t *__restrict__ Xs) {
+    __shared__ int8_t tile[S][32][33];
+    const int k0 = blockIdx.y * 32, a0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, a = a0 + tx;
+        double v = 0.0;
+        if (k < K && a < N) v = ldexp(X[(long long)k * N + a], -ex[a]);       // |v| <= 1
+        double scale = 64.0;                                                   // 2^6, then 2^13, ...
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const double d = rint(v * scale);                                 // |d| <= 64
+            tile[s][r][tx] = (int8_t)(int)d;
+            v -= d / scale;                                                    // exact: d / scale has <= 7 significant bits
+            scale *= 128.0;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, k = k0 + tx;
+        if (a < N && k < KP) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) Xs[((long long)s * N + a) * KP + k] = tile[s][tx][r];
+        }
+    }
+}
+
+// ---- the fused slice-pair GEMM ------------------------------------------------------------------------------------------------
+// workgroup tile 128 (a) x 128 (b), 2 x 2 waves of 64 x 64 (4 x 4 MFMA tiles, i32x4 each); a K step is 128 bytes (two MFMA k-steps of
+// 64).  For every anti-diagonal d = s + t < S: int32 accumulation over its pairs and all K steps, then acc_f64 += 2^(-12 - 7 d) acc_i32.
+// Operands: global -> registers -> LDS (double buffered through registers), LDS rows padded to 144 bytes.
+constexpr int BKB = 128;                 // bytes of k per step
+constexpr int LDP = BKB + 16;            // LDS row pitch
+template <int S>
+__global__ __launch_bounds__(256, 2) void ozaki_gemm_kernel(int N, int KP, const int8_t *__restrict__ Xs, const int8_t *__restrict__ Ys,
+                                                            const int *__restrict__ exX, const int *__restrict__ exY,
+                                                            double *__restrict__ C) {
+    __shared__ __attribute__((aligned(16))) int8_t lds[2][2][128 * LDP];      // [buffer][A | B][row][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a0 = blockIdx.y * 128, b0 = blockIdx.x * 128;
+    const int li = lane & 15, lg = lane >> 4;
+    // loader: thread t moves 16 bytes: row = t / 8 + 32 * pass (4 passes), k chunk = t % 8
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    // (first version: f64 accumulators of the whole wave tile in registers next to the int32 ones -- 256 VGPRs + 416 B of scratch,
+    // 400 TOPS.  The anti-diagonals are folded into the C tile through L2 instead: one read-modify-write of 128 KB per diagonal.)
+    const int T = KP / BKB;
+    for (int d = 0; d < S; ++d) {
+        i32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+        for (int s = 0; s <= d; ++s) {
+            const int t2 = d - s;
+            const int8_t *A = Xs + ((long long)s * N + a0) * KP, *B = Ys + ((long long)t2 * N + b0) * KP;
+            int4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;      // (scalars: as arrays behind lambdas they stayed in scratch)
+            const int8_t *Ag[4], *Bg[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = lrow + 32 * p;
+                const int ar = (a0 + row < N) ? row : 0, br = (b0 + row < N) ? row : 0;
+                Ag[p] = A + (long long)ar * KP + lchunk * 16;
+                Bg[p] = B + (long long)br * KP + lchunk * 16;
+            }
+#define gload(t) do { const int o_ = (t) * BKB; \
+                ra0 = *reinterpret_cast<const int4 *>(Ag[0] + o_); rb0 = *reinterpret_cast<const int4 *>(Bg[0] + o_); \
+                ra1 = *reinterpret_cast<const int4 *>(Ag[1] + o_); rb1 = *reinterpret_cast<const int4 *>(Bg[1] + o_); \
+                ra2 = *reinterpret_cast<const int4 *>(Ag[2] + o_); rb2 = *reinterpret_cast<const int4 *>(Bg[2] + o_); \
+                ra3 = *reinterpret_cast<const int4 *>(Ag[3] + o_); rb3 = *reinterpret_cast<const int4 *>(Bg[3] + o_); } while (0)
+#define lstore(buf) do { int8_t *la_ = &lds[buf][0][lrow * LDP + lchunk * 16], *lb_ = &lds[buf][1][lrow * LDP + lchunk * 16]; \
+                *reinterpret_cast<int4 *>(la_) = ra0;                *reinterpret_cast<int4 *>(lb_) = rb0; \
+                *reinterpret_cast<int4 *>(la_ + 32 * LDP) = ra1;     *reinterpret_cast<int4 *>(lb_ + 32 * LDP) = rb1; \
+                *reinterpret_cast<int4 *>(la_ + 64 * LDP) = ra2;     *reinterpret_cast<int4 *>(lb_ + 64 * LDP) = rb2; \
+                *reinterpret_cast<int4 *>(la_ + 96 * LDP) = ra3;     *reinterpret_cast<int4 *>(lb_ + 96 * LDP) = rb3; } while (0)
+            gload(0);
+            __syncthreads();                       // the previous pair's last reads of both buffers are done
+            lstore(0);
+            for (int t = 0; t < T; ++t) {
+                const int buf = t & 1;
+                if (t + 1 < T) gload(t + 1);
+                __syncthreads();                   // buffer `buf` is complete
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    i32x4 fa[4], fb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        fa[i] = *reinterpret_cast<const i32x4 *>(&lds[buf][0][(wm * 64 + i * 16 + li) * LDP + kk * 64 + lg * 16]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        fb[j] = *reinterpret_cast<const i32x4 *>(&lds[buf][1][(wn * 64 + j * 16 + li) * LDP + kk * 64 + lg * 16]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
+                if (t + 1 < T) lstore(buf ^ 1);    // the other buffer was last read in step t - 1: everyone is past that barrier
+            }
+#undef gload
+#undef lstore
+        }
+        // fold this anti-diagonal into the C tile (D layout, dtype independent: col = lane & 15, row = (lane >> 4) * 4 + reg);
+        // the column / row exponents are applied with the last one
+        const double sc = ldexp(1.0, -12 - 7 * d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = a0 + wm * 64 + i * 16 + lg * 4 + r, b = b0 + wn * 64 + j * 16 + li;
+                    if (a < N && b < N) {
+                        double *c = C + (long long)a * N + b;
+                        double v = sc * (double)acc[i][j][r];
+                        if (d > 0) v += *c;
+                        if (d == S - 1) v = ldexp(v, exX[a] + exY[b]);
+                        *c = v;
+                    }
+                }
+    }
+}
+
+// ---- f64 reference on sampled entries ------------------------------------------------------------------------------------------
+__global__ void ref_kernel(int K, int N, const double *__restrict__ X, const double *__restrict__ Y, int nsamp, const int *__restrict__ sa,
+                           const int *__restrict__ sb, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsamp) return;
+    double s = 0.0;
+    for (int k = 0; k < K; ++k) s = fma(X[(long long)k * N + sa[i]], Y[(long long)k * N + sb[i]], s);
+    out[i] = s;
+}
+
+// ---- f64 MFMA baseline (register-staged simple kernel is NOT the product's: the product's rate is quoted from profiles) ---------
+
+template <int S>
+double run(int N, int K, int KP, const double *X, const double *Y, const int *exX, const int *exY, int8_t *Xs, int8_t *Ys, double *C,
+           double *t_slice_ms) {
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    const dim3 gs((N + 31) / 32, (KP + 31) / 32);
+    const dim3 gg((N + 127) / 128, (N + 127) / 128);
+    float best_s = 1e30f, best_g = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(slice_kernel<S>, gs, dim3(256), 0, 0, K, KP, N, X, exX, Xs);
+        hipLaunchKernelGGL(slice_kernel<S>, gs, dim3(256), 0, 0, K, KP, N, Y, exY, Ys);
+        CK(hipEventRecord(e1));
+        hipLaunchKernelGGL(ozaki_gemm_kernel<S>, gg, dim3(256), 0, 0, N, KP, Xs, Ys, exX, exY, C);
+        CK(hipEventRecord(e2));
+        CK(hipEventSynchronize(e2));
+        float ms_s, ms_g;
+        CK(hipEventElapsedTime(&ms_s, e0, e1));
+        CK(hipEventElapsedTime(&ms_g, e1, e2));
+        if (rep > 0) { best_s = fminf(best_s, ms_s); best_g = fminf(best_g, ms_g); }
+    }
+    *t_slice_ms = best_s;
+    return best_g;
+}
+
+int main(int argc, char **argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 1600, S = argc > 3 ? atoi(argv[3]) : 4;
+    const int KP = ((K + BKB - 1) / BKB) * BKB;
+    printf("ozaki_lab: C = X^T Y, N = %d, K = %d (padded %d), S = %d slices -> %d slice pairs\n", N, K, KP, S, S * (S + 1) / 2);
+    double *X, *Y, *C;
+    int *exX, *exY;
+    int8_t *Xs, *Ys;
+    CK(hipMalloc(&X, (size_t)K * N * 8)); CK(hipMalloc(&Y, (size_t)K * N * 8)); CK(hipMalloc(&C, (size_t)N * N * 8));
+    CK(hipMalloc(&exX, N * 4)); CK(hipMalloc(&exY, N * 4));
+    CK(hipMalloc(&Xs, (size_t)S * N * KP)); CK(hipMalloc(&Ys, (size_t)S * N * KP));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (long long)K * N, N, 1234ull, X);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (long long)K * N, N, 99991ull, Y);
+    hipLaunchKernelGGL(colexp_kernel, dim3((N + 255) / 256), dim3(256), 0, 0, K, N, X, exX);
+    hipLaunchKernelGGL(colexp_kernel, dim3((N + 255) / 256), dim3(256), 0, 0, K, N, Y, exY);
+    CK(hipDeviceSynchronize());
+    double t_slice = 0.0, t_gemm = 0.0;
+    switch (S) {
+        case 2: t_gemm = run<2>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+        case 3: t_gemm = run<3>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+        case 4: t_gemm = run<4>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+        case 5: t_gemm = run<5>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+        case 6: t_gemm = run<6>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+        case 7: t_gemm = run<7>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+        default: t_gemm = run<8>(N, K, KP, X, Y, exX, exY, Xs, Ys, C, &t_slice); break;
+    }
+    // accuracy on sampled entries + a priori bound
+    const int nsamp = 4096;
+    std::vector<int> sa(nsamp), sb(nsamp), hx(N), hy(N);
+    for (int i = 0; i < nsamp; ++i) { sa[i] = (int)((i * 2654435761ull + 17) % N); sb[i] = (int)((i * 40503ull * 977 + 3) % N); }
+    int *dsa, *dsb;
+    double *dref;
+    CK(hipMalloc(&dsa, nsamp * 4)); CK(hipMalloc(&dsb, nsamp * 4)); CK(hipMalloc(&dref, nsamp * 8));
+    CK(hipMemcpy(dsa, sa.data(), nsamp * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dsb, sb.data(), nsamp * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_kernel, dim3((nsamp + 255) / 256), dim3(256), 0, 0, K, N, X, Y, nsamp, dsa, dsb, dref);
+    std::vector<double> ref(nsamp), got(nsamp);
+    CK(hipMemcpy(ref.data(), dref, nsamp * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hx.data(), exX, N * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hy.data(), exY, N * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0.0, maxref = 0.0, maxbound = 0.0;
+    for (int i = 0; i < nsamp; ++i) {
+        CK(hipMemcpy(&got[i], C + (long long)sa[i] * N + sb[i], 8, hipMemcpyDeviceToHost));
+        maxerr = fmax(maxerr, fabs(got[i] - ref[i]));
+        maxref = fmax(maxref, fabs(ref[i]));
+        maxbound = fmax(maxbound, (S + 1.0) * K * ldexp(1.0, -7 * S + hx[sa[i]] + hy[sb[i]]));
+    }
+    const double flop = 2.0 * (double)K * (double)N * (double)N;
+    const double f64_ms_at_product_rate = flop / 69.5e12 * 1e3;            // the product's rectangular launch: 69.3-69.7 TF (profiles/r04_d_*)
+    printf("  slicing (both operands): %.3f ms   gemm: %.3f ms   total %.3f ms\n", t_slice, t_gemm, t_slice + t_gemm);
+    printf("  f64-equivalent rate: gemm only %.1f TF, with slicing %.1f TF  (product f64 kernel: 69.5 TF = %.3f ms for this shape)\n",
+           flop / (t_gemm * 1e-3) / 1e12, flop / ((t_slice + t_gemm) * 1e-3) / 1e12, f64_ms_at_product_rate);
+    printf("  speed-up over the product's f64 kernel: gemm only %.2fx, with slicing %.2fx\n", f64_ms_at_product_rate / t_gemm,
+           f64_ms_at_product_rate / (t_slice + t_gemm));
+    const double i8ops = 2.0 * (double)KP * (double)N * (double)N * (S * (S + 1) / 2);
+    printf("  int8 rate: %.0f TOPS (micro-benchmark floor of the pipe: 3944)\n", i8ops / (t_gemm * 1e-3) / 1e12);
+    printf("  accuracy on %d sampled entries: max |C - ref| = %.3e (max |ref| %.3e, relative %.2e); a priori bound %.3e\n", nsamp, maxerr,
+           maxref, maxerr / maxref, maxbound);
+    return 0;
+}
