@@ -25,16 +25,92 @@ def get_emb_basis(lattice, GRho, local=True, kind='svd', **kwargs):
     """Embedding basis C_lo_eo in R, shape (ncells, nso, nimp*2 + nbath)."""
     if not local:
         raise NotImplementedError
-    if kwargs.get("bath_opt", False):
-        raise NotImplementedError("bath_opt (scipy brentq over full-lattice eigendecompositions, spinless.py:277-349) is outside "
-                                  "the HIP path")
     if kind == 'svd':
-        return _get_emb_basis_svd(lattice, np.asarray(GRho).real, **kwargs)
+        basis = _get_emb_basis_svd(lattice, np.asarray(GRho).real, **kwargs)
     elif kind == 'eig':
-        return _get_emb_basis_eig(lattice, np.asarray(GRho).real, **kwargs)
+        basis = _get_emb_basis_eig(lattice, np.asarray(GRho).real, **kwargs)
     elif kind == 'ph':
-        return _get_emb_basis_ph(lattice, np.asarray(GRho).real, **kwargs)
-    raise ValueError("get_emb_basis: Unknown kind %s" % kind)
+        basis = _get_emb_basis_ph(lattice, np.asarray(GRho).real, **kwargs)
+    else:
+        raise ValueError("get_emb_basis: Unknown kind %s" % kind)
+    if kwargs.get("bath_opt", False):
+        basis = get_emb_basis_opt(lattice, np.asarray(GRho).real, basis, keep_imp_identity=False, tol=kwargs.get("tol_bath", 1e-6))
+    return basis
+
+
+def get_emb_basis_opt(latt, rdm1_R, basis, keep_imp_identity=False, tol=1e-6):
+    """Rotate the embedding space until it holds an integer number of electrons (metals; routine/spinless.py:274-349): the span
+    of the top nemb eigenvectors of  B B^T - mu D  (D = the full-lattice density matrix) with mu from a bracketed root search
+    on [-1, 0] / [0, 1] -- scipy's brentq with the reference's tolerances, as there, so the iterates are the reference's.
+    Every evaluation is device work: the shifted matrix (two axpys), ONE real symmetric eigenproblem of the full lattice
+    dimension (dmk_eigh_batched_real, one workgroup; ncells * nso <= 2000) and the electron count  tr(E D E^T)  (two GEMMs);
+    the host only sees the scalar."""
+    from scipy import optimize as opt
+    rdm1_R = np.ascontiguousarray(np.asarray(rdm1_R).real, dtype=np.float64)
+    basis = np.ascontiguousarray(basis, dtype=np.float64)
+    ncells, nso, nemb = basis.shape
+    N = ncells * nso
+    if N > 2000:
+        raise NotImplementedError("bath_opt: the lattice dimension %d exceeds the eigensolver limit of 2000 (one workgroup per matrix)" % N)
+    ctx = get_ctx()
+    d_D = ctx.to_device(latt.expand(rdm1_R), np.float64)
+    d_Bt = ctx.to_device(np.ascontiguousarray(basis.reshape(N, nemb).T), np.float64)     # rows = basis vectors
+    d_G, d_n = ctx.empty((nemb, N), np.float64), ctx.empty((1,), np.float64)
+
+    def count(d_E):
+        """tr(E D E^T), E: nemb x N, rows = vectors."""
+        ctx.check(lib.dmk_dgemm_batched(ctx.h, 0, 0, nemb, N, N, 1, 1.0, d_E.ptr, N, 0, d_D.ptr, N, 0, 0.0, d_G.ptr, N, 0))
+        ctx.check(lib.dmk_dgemm_batched(ctx.h, 0, 0, 1, 1, nemb * N, 1, 1.0, d_G.ptr, nemb * N, 0, d_E.ptr, 1, 0, 0.0, d_n.ptr, 1, 0))
+        return float(d_n.get()[0])
+
+    nelec = count(d_Bt)
+    nelec_target = np.round(nelec)
+    log.debug(0, "get_emb_basis_opt: nelec current: %15.8f , nelec_target: %15.8f", nelec, nelec_target)
+    if abs(nelec - nelec_target) < tol:
+        return basis
+    lval, rval = (-1.0, 0.0) if nelec < nelec_target else (1.0, 0.0)
+
+    d_P = ctx.empty((N, N), np.float64)
+    ctx.check(lib.dmk_dgemm_batched(ctx.h, 1, 0, N, N, nemb, 1, 1.0, d_Bt.ptr, N, 0, d_Bt.ptr, N, 0, 0.0, d_P.ptr, N, 0))
+    d_M, d_w, d_Vt = ctx.empty((N, N), np.float64), ctx.empty((1, N), np.float64), ctx.empty((1, N, N), np.float64)
+
+    def top(mu):
+        """rows N - nemb .. N of Vt: the eigenvectors of the nemb largest eigenvalues, ascending (ev[:, -nemb:], :306)."""
+        d_M.zero_()
+        ctx.check(lib.dmk_axpy_f64(ctx.h, N * N, 1.0, d_P.ptr, d_M.ptr))
+        ctx.check(lib.dmk_axpy_f64(ctx.h, N * N, -float(mu), d_D.ptr, d_M.ptr))
+        ctx.check(lib.dmk_eigh_batched_real(ctx.h, N, 1, d_M.ptr, d_w.ptr, d_Vt.ptr))
+        return d_Vt.offset((N - nemb) * N, (nemb, N))
+
+    res = opt.brentq(lambda mu: count(top(mu)) - nelec_target, lval, rval, xtol=tol, rtol=tol, maxiter=1000,
+                     full_output=True, disp=False)
+    if not res[1].converged:
+        log.warn("get_emb_basis_opt fitting mu brentq fails.")
+    mu = res[0]
+    d_E = top(mu)
+    ev = np.ascontiguousarray(d_E.get().T)                                   # (N, nemb), columns ascending
+    if keep_imp_identity:
+        # the first nimp columns stay, the eigenvectors are appended after projecting them out (:326-341): a sequential
+        # Gram-Schmidt over nemb columns on the host (the only caller, get_emb_basis, passes False)
+        basis_R = basis.reshape(N, nemb)[:, :latt.nimp]
+        for i in range(ev.shape[-1]):
+            v = ev[:, i]
+            v = v - np.dot(basis_R, v @ basis_R)
+            norm_v = np.linalg.norm(v)
+            log.debug(0, "norm of orb %5d : %15.5g ,    keep: %s", i, norm_v, norm_v > tol)
+            if norm_v > tol:
+                if basis_R.shape[-1] < nemb:
+                    basis_R = np.hstack((basis_R, (v / norm_v)[:, None]))
+                else:
+                    log.warn("basis rank is more than nemb!")
+        out = basis_R.reshape(basis.shape)
+        d_B2 = ctx.to_device(np.ascontiguousarray(out.reshape(N, nemb).T), np.float64)
+        nelec = count(d_B2)
+    else:
+        out = ev.reshape(basis.shape)
+        nelec = count(d_E)
+    log.debug(0, "get_emb_basis_opt: nelec after fit: %15.8f, mu: %15.8f", nelec, mu)
+    return out
 
 
 embBasis = get_emb_basis

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1203,6 +1203,34 @@ def gen_G18():
                 out["%s/gso_%s_%s" % (name, kind, "val" if vb else "full")] = spinless.get_emb_basis(L, GRho, kind=kind, valence_bath=vb)
     np.savez_compressed(os.path.join(GOLD, "G18_branches.npz"), **out)
     print("G18 done")
+
+
+def gen_G19():
+    """bath_opt (routine/spinless.py:44-54, 274-349): the embedding space of a METALLIC generalised density matrix (Fermi-smeared
+    GHF of the G7 lattices, so that the Schmidt space holds a non-integer electron number) rotated to an integer one -- the
+    reference's get_emb_basis(kind='svd', bath_opt=True) and get_emb_basis_opt(keep_imp_identity=True) under the shim."""
+    from libdmet.routine import spinless
+    g7 = np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        GFk = synth.fold_R2k(g7[name + "/GFock_R"][None], mesh)[0]
+        ew, ev = np.linalg.eigh(GFk)
+        for tag, beta, mu in (("a", 3.0, 0.3), ("b", 5.0, -0.2)):
+            f = 1.0 / (1.0 + np.exp(beta * (ew - mu)))
+            GRho = L.k2R(np.einsum("kpm,km,kqm->kpq", ev, f, ev.conj())).real
+            out["%s/%s/GRho" % (name, tag)] = GRho
+            for vb in (True, False):
+                key = "%s/%s/%s" % (name, tag, "val" if vb else "full")
+                b0 = spinless.get_emb_basis(L, GRho, kind="svd", valence_bath=vb)
+                out[key + "/basis_svd"] = b0
+                try:
+                    out[key + "/basis_opt"] = spinless.get_emb_basis(L, GRho, kind="svd", valence_bath=vb, bath_opt=True)
+                    out[key + "/basis_opt_keep"] = spinless.get_emb_basis_opt(L, GRho, b0, keep_imp_identity=True)
+                except ValueError as e:           # brentq: no sign change on the bracket -- the reference raises, recorded as such
+                    out[key + "/raises"] = np.asarray(str(e))
+    np.savez_compressed(os.path.join(GOLD, "G19_bath_opt.npz"), **out)
+    print("G19 done", sorted(k for k in out if k.endswith("raises")))
 
 
 if __name__ == "__main__":

@@ -6,6 +6,8 @@ SURVEY.md section 8(f) rank 4:
   spinless._get_emb_basis_eig     routine/spinless.py:166-275    ... from the eigenvectors of the env-env block
   spinless._get_emb_basis_ph      routine/spinless.py:351-423    ... particle / hole projections, canonical orthogonalisation
                                                                  (both pinned by tests/golden/G18_branches.npz, gen_G18)
+  spinless.get_emb_basis_opt      routine/spinless.py:274-349    bath_opt: integer electron number of the embedding space
+                                                                 (pinned by tests/golden/G19_bath_opt.npz, gen_G19)
   eri_transform.get_emb_eri_gso   basis_transform/eri_transform.py:1104-1250
   _Lij_s4_to_eri_gso              basis_transform/eri_transform.py:1252-1310  (aaaa + bbbb - aabb - bbaa)
 
@@ -118,6 +120,46 @@ def get_emb_basis_gso_ph(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bat
     idx = e > tol_bath
     out = basis @ (v[:, idx] / np.sqrt(e[idx]))
     return out.reshape(ncells, nso, -1), e
+
+
+def get_emb_basis_opt(kmesh, rdm1_R, basis, keep_imp_identity=False, nimp=None, tol=1e-6):
+    """routine/spinless.py:274-349: shift mu (scipy brentq on [-1, 0] or [0, 1], xtol = rtol = tol) such that the span of the top
+    nemb eigenvectors of  B B^T - mu D  (D = lattice.expand(rdm1_R)) holds an integer number of electrons.  The electron number
+    is the trace of the folded density matrix (foldRho_k = the full-space  tr(E^T D E), :288).  Returns (basis, mu, nelec)."""
+    from scipy import optimize as opt
+    from oracle.restate import CellArith
+    rdm1_R = np.asarray(rdm1_R).real
+    basis = np.asarray(basis)
+    nemb = basis.shape[-1]
+    B = basis.reshape(-1, nemb)
+    D = CellArith(kmesh).expand(rdm1_R[None])[0]
+    count = lambda E: float(np.einsum("ai,ab,bi->", E, D, E))
+    nelec = count(B)
+    target = np.round(nelec)
+    if abs(nelec - target) < tol:
+        return basis, None, nelec
+    lval, rval = (-1.0, 0.0) if nelec < target else (1.0, 0.0)
+    P = B @ B.conj().T
+
+    def top(mu):
+        ew, ev = la.eigh(P - mu * D)
+        return ev[:, -nemb:]
+
+    res = opt.brentq(lambda mu: count(top(mu)) - target, lval, rval, xtol=tol, rtol=tol, maxiter=1000, full_output=True, disp=False)
+    mu = res[0]
+    ev = top(mu)
+    if keep_imp_identity:                                                   # :326-341
+        BR = B[:, :nimp]
+        for i in range(ev.shape[-1]):
+            v = ev[:, i]
+            v = v - BR @ (v @ BR)
+            nv = la.norm(v)
+            if nv > tol and BR.shape[-1] < nemb:
+                BR = np.hstack((BR, (v / nv)[:, None]))
+        out = BR.reshape(basis.shape)
+    else:
+        out = ev.reshape(basis.shape)
+    return out, mu, count(out.reshape(-1, nemb))
 
 
 def Lij_s4_to_eri_gso(Lij_s4, eri, weight=1, t_reversal_symm=False):

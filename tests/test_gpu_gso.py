@@ -53,10 +53,30 @@ def test_gso_bath(ctx, golden, name, n, val):
         assert bp.shape == refp.shape and span(bp, refp) < 1e-10
         Bm = bp.reshape(-1, bp.shape[-1])
         assert np.abs(Bm.T @ Bm - np.eye(Bm.shape[-1])).max() < 1e-10
-    with pytest.raises(NotImplementedError):
-        spinless.get_emb_basis(L, GRho, bath_opt=True)
     with pytest.raises(ValueError):
         spinless.get_emb_basis(L, GRho, kind="nope")
+    # bath_opt (routine/spinless.py:44-54, 274-349) on the metallic matrices of G19: the rotated space against what the reference
+    # returned (projector 1e-8: the root search stops at xtol = rtol = 1e-6 on both sides, on the same iterates), an integer electron
+    # number, the keep_imp_identity variant, and the gapped matrix of G7 handed back unchanged
+    g19 = golden("G19_bath_opt.npz")
+    from oracle.restate import CellArith
+    for tag in ("a", "b"):
+        GT = g19["%s/%s/GRho" % (name, tag)]
+        D = CellArith(mesh).expand(GT[None])[0]
+        for vb, vtag in ((True, "val"), (False, "full")):
+            key = "%s/%s/%s" % (name, tag, vtag)
+            bo = spinless.get_emb_basis(L, GT, kind="svd", valence_bath=vb, bath_opt=True)
+            ref = g19[key + "/basis_opt"]
+            assert bo.shape == ref.shape and span(bo, ref) < 1e-8
+            Bm = bo.reshape(-1, bo.shape[-1])
+            ne = np.trace(Bm.T @ D @ Bm)
+            assert abs(ne - round(ne)) < 1e-5 and np.abs(Bm.T @ Bm - np.eye(Bm.shape[-1])).max() < 1e-10
+            bk = spinless.get_emb_basis_opt(L, GT, g19[key + "/basis_svd"], keep_imp_identity=True)
+            refk = g19[key + "/basis_opt_keep"]
+            assert span(bk, refk) < 1e-8 and np.array_equal(bk[..., :L.nimp], refk[..., :L.nimp])
+    if min(val) == 0:
+        b0 = spinless.get_emb_basis(L, GRho)
+        assert np.array_equal(spinless.get_emb_basis(L, GRho, bath_opt=True), b0)
 
 
 @pytest.mark.parametrize("name", ERI)

@@ -84,3 +84,37 @@ def test_G18_gso_eig_and_ph_bath(golden, name, mesh, n, val):
         assert bp.shape == refp.shape and _same_span(bp, refp, 1e-10)
         B = bp.reshape(-1, bp.shape[-1])
         assert np.abs(B.T @ B - np.eye(B.shape[-1])).max() < 1e-10
+
+
+# ---- golden G19 (gen_G19): bath_opt, the embedding space rotated to an integer electron number ------------------------------------
+@pytest.mark.parametrize("name,mesh,n,val", G18_CASES)
+def test_G19_bath_opt(golden, name, mesh, n, val):
+    """routine/spinless.py:274-349 against what the reference returned on Fermi-smeared (metallic) generalised density matrices:
+    the rotated space (projector; the columns are eigenvectors of a nearly degenerate cluster), its electron number, and the
+    keep_imp_identity variant column by column (its columns are fixed by the Gram-Schmidt order up to the eigenvector signs)."""
+    from oracle import restate_gso as G
+    from oracle.restate import CellArith
+    g = golden("G19_bath_opt.npz")
+    imp = list(val) + [i for i in range(n) if i > max(val)]
+    for tag in ("a", "b"):
+        GRho = g["%s/%s/GRho" % (name, tag)]
+        D = CellArith(mesh).expand(GRho[None])[0]
+        for vb in ("val", "full"):
+            key = "%s/%s/%s" % (name, tag, vb)
+            b0, ref, refk = g[key + "/basis_svd"], g[key + "/basis_opt"], g[key + "/basis_opt_keep"]
+            out, mu, nelec = G.get_emb_basis_opt(mesh, GRho, b0)
+            assert mu is not None and abs(nelec - round(nelec)) < 1e-5
+            R = ref.reshape(-1, ref.shape[-1])
+            assert abs(np.trace(R.T @ D @ R) - nelec) < 1e-9
+            assert _same_span(out, ref, 1e-8)
+            outk, muk, _ = G.get_emb_basis_opt(mesh, GRho, b0, keep_imp_identity=True, nimp=len(imp))
+            assert abs(muk - mu) < 1e-12 and _same_span(outk, refk, 1e-8)
+            assert np.array_equal(outk[..., :len(imp)], refk[..., :len(imp)])
+    # an integer electron number already (the gapped T = 0 matrices of G7 without core orbitals): returned unchanged (:292-293)
+    g7 = golden("G7_bcs.npz")
+    GRho0 = g7[name + "/GRho"]
+    b = G.get_emb_basis_gso(GRho0, n, val, imp)
+    b = b[0] if isinstance(b, tuple) else b
+    same, mu0, nelec0 = G.get_emb_basis_opt(mesh, GRho0, b)
+    if min(val) == 0:
+        assert mu0 is None and same is b and abs(nelec0 - round(nelec0)) < 1e-6
