@@ -800,7 +800,7 @@ def main():
             # vcor least-squares fit of the BASELINE target (config 5): measured once, outside the timed region, on ALL ranks
             # (the dV_dparam table is sharded row-wise over them); run to convergence (tolerances in the entry)
             fit.pop("vcor")
-            res["vcor_fit"] = {k: (round(v, 9) if isinstance(v, float) else v) for k, v in fit.items()}
+            res["vcor_fit"] = {k: (float("%.6e" % v) if isinstance(v, float) else v) for k, v in fit.items()}    # (err_end ~ 1e-10: no fixed decimals)
             res["iteration_plus_fit_wall_s"] = round(elapsed / a.steps + fit["seconds_total"], 4)
             if full is not None:
                 res["full_config_iteration_plus_fit_wall_s"] = round(full["iteration_wall_s"] + fit["seconds_total"], 3)
