@@ -58,7 +58,7 @@ _FUNCTIONS = [
     ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis"]),
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
-    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis"]),
+    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt"]),
     ("dmet.HubPhSymm", ["dmet.HubPhSymm"], ["basisMatching"]),
     # driver layer: dmet/Hubbard.py:8 star-imports HubPhSymm, so it holds its own ConstructImpHam; it defines the RHF / UHF
     # HartreeFock wrapper (:14-41) and FitVcor (:1503) itself
