@@ -71,7 +71,7 @@ __device__ __forceinline__ double block_max_f64(double v, double *sh) {
 }
 
 __global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g) {
-    extern __shared__ double dyn[];            // Hr | Hi | Vr | Vi, each [n*n][mstride]; twiddles [3][128] complex; ranks [nmat][8] int
+    extern __shared__ __attribute__((aligned(16))) double dyn[];            // (16: the double2 views below use 128-bit LDS accesses)  Hr | Hi | Vr | Vi, each [n*n][mstride]; twiddles [3][128] complex; ranks [nmat][8] int
     __shared__ double shd[SM_NT / 64];
     const int n = g.n, nn = n * n, nmat = g.nmat, ms = g.mstride, tid = threadIdx.x;
     double *Hr = dyn, *Hi = Hr + (size_t)nn * ms, *Vr = Hi + (size_t)nn * ms, *Vi = Vr + (size_t)nn * ms;
@@ -238,29 +238,30 @@ __global__ __launch_bounds__(SM_NT) void small_meanfield_kernel(const SmallMF g)
         const int r0 = R / (n1 * n2), r1 = (R / n2) % n1, r2 = R % n2;
         const int n0 = g.mesh[0];
         double re = 0.0, im = 0.0;
-        // k = (k0 n1 + k1) n2 + k2 walked as three nested loops: the twiddle indices (k_d r_d) mod n_d advance by r_d with a
-        // conditional wrap -- no integer division inside (six of them per term made this loop two thirds of the kernel at C2)
+        // k = (k0 n1 + k1) n2 + k2 walked as ONE loop: the twiddle indices (k_d r_d) mod n_d advance by r_d with a conditional wrap
+        // and restart at 0 when their axis counter wraps -- no integer division inside (six of them per term made this loop two
+        // thirds of the kernel at C2), and no loop nest: as three nested loops with trip counts like 6 x 6 x 1 every term paid the
+        // LDS round trips of its twiddles and the loop-control branches in sequence (0.77 us per term); the flat loop is unrolled
+        // and the reads of four terms are in flight together
         const double2 *v = rl + (size_t)s * nk * nn + ij;
-        int i0 = 0;
-        for (int k0 = 0; k0 < n0; ++k0) {
-            const double2 w0 = tw[i0];
-            int i1 = 0;
-            for (int k1 = 0; k1 < n1; ++k1) {
-                const double2 w1 = tw[128 + i1];
-                const double ar = w0.x * w1.x - w0.y * w1.y, ai = w0.x * w1.y + w0.y * w1.x;
-                int i2 = 0;
-                for (int k2 = 0; k2 < n2; ++k2) {
-                    const double2 w2 = tw[256 + i2];
-                    const double pr = ar * w2.x - ai * w2.y, pi = ar * w2.y + ai * w2.x;
-                    const double2 x = *v;
-                    re += pr * x.x - pi * x.y;
-                    im += pr * x.y + pi * x.x;
-                    v += nn;
-                    i2 += r2; if (i2 >= n2) i2 -= n2;
-                }
+        int i0 = 0, i1 = 0, i2 = 0, c1 = 0, c2 = 0;
+#pragma unroll 4
+        for (int k = 0; k < nk; ++k) {
+            const double2 w0 = tw[i0], w1 = tw[128 + i1], w2 = tw[256 + i2], x = v[(size_t)k * nn];
+            const double ar = w0.x * w1.x - w0.y * w1.y, ai = w0.x * w1.y + w0.y * w1.x;
+            const double pr = ar * w2.x - ai * w2.y, pi = ar * w2.y + ai * w2.x;
+            re += pr * x.x - pi * x.y;
+            im += pr * x.y + pi * x.x;
+            ++c2;
+            i2 += r2; if (i2 >= n2) i2 -= n2;
+            if (c2 == n2) {
+                c2 = 0; i2 = 0; ++c1;
                 i1 += r1; if (i1 >= n1) i1 -= n1;
+                if (c1 == n1) {
+                    c1 = 0; i1 = 0;
+                    i0 += r0; if (i0 >= n0) i0 -= n0;
+                }
             }
-            i0 += r0; if (i0 >= n0) i0 -= n0;
         }
         g.rho_R[o] = re * inv;
         imax = fmax(imax, fabs(im * inv));
@@ -287,6 +288,7 @@ struct SmallBath {
     double *U;                                 // optional [spin][nenv][nb]
     double *basis;                             // [spin][nsites][ncol], ncol = nimp + min_s nbath_s, PACKED with that leading dimension
     int *iout;                                 // [0] ncol, [1 + s] nbath_s, [1 + spin] SVD sweeps not converged
+    unsigned long long *dbg;                   // DMK_SMALL_TIMING: 100 MHz stamps of thread 0 at the phase boundaries (else null)
 };
 
 constexpr int SB_MAXB = 8;
@@ -309,47 +311,71 @@ __device__ void block_sum_vec(double *v, int cnt, double *sh /* [SB_MAXB + 1][SB
     }
 }
 
-// One-sided (Hestenes) Jacobi on the columns of the nb x nb matrix M (LDS, row-major), run by ONE wave: lane i owns row i, the
-// three sums of a column pair are 8-lane shuffle reductions, so a pair costs two LDS reads, nine shuffles and two writes where a
-// single thread walked ~20 dependent LDS accesses.  On return the columns are mutually orthogonal: their norms are the singular
-// values, the normalised columns the left singular vectors (for a symmetric positive semi-definite M: eigenvalues / eigenvectors).
-// Returns the number of sweeps, 60 = not converged.  Call with all 64 lanes of the wave.
+// One-sided (Hestenes) Jacobi on the columns of the nb x nb matrix M (LDS, row-major), run by ONE wave as EIGHT groups of eight
+// lanes.  A sweep is a round-robin tournament: nb' - 1 steps (nb' = nb rounded up to even) of nb' / 2 mutually disjoint column
+// pairs, group g takes pair g of the step.  Every lane of a group forms the three sums of its pair itself from LDS reads of the two
+// columns (2 nb independent reads, three FMA chains of length nb) -- the lanes of a group run the same instructions on the same
+// numbers, so they agree on the decision and on the rotation by construction -- and lane i < nb of the group then rotates row i.
+// LDS operations of one wave complete in order, so the reads of a step see every write of the step before.
+// (Round 5, first form: one pair at a time, lane i owned row i and the sums were 8-lane shuffle butterflies: ~1000 cycles per pair
+// in four dependent cross-lane stages per sum and a chain of two reciprocals and two reciprocal square roots, 17-21 us for the SVD
+// of a 4 x 4 triangle; it also needed products rounded on their own so that the lanes of a pair could not disagree.)
+// Rotation from ONE reciprocal square root of the pair's (be - al, 2 ga) and one of (1 + cos 2theta) / 2 -- no division:
+//     cos 2theta = |d| / h,  c = sqrt(u),  s = sign(d) g2 / (2 h c),   d = be - al, g2 = 2 ga, h = hypot(d, g2), u = (1 + cos 2theta) / 2
+// (c and s share the factor rsqrt(u), so c^2 + s^2 = 1 to rounding whatever the estimate's error in h).
+// On return the columns are mutually orthogonal: their norms are the singular values, the normalised columns the left singular
+// vectors (for a symmetric positive semi-definite M: eigenvalues / eigenvectors).  Returns the number of sweeps, 60 = not
+// converged.  Call with all 64 lanes of the wave.
 __device__ int wave_onesided_jacobi(double *M, int nb) {
-    const int i = threadIdx.x & 63;
-    const bool on = i < nb;
-    // The eight lanes of a group must take the SAME decision and apply the SAME rotation: the sums are butterflies of products
-    // rounded on their own (__dmul_rn: a fused multiply-add of a lane's own product into its partner's would round differently in
-    // the two lanes of a pair) and lane 0's totals are broadcast to the group.
-    auto sum8 = [&](double v) {
-        v = __dadd_rn(v, __shfl_xor(v, 1, 64));
-        v = __dadd_rn(v, __shfl_xor(v, 2, 64));
-        v = __dadd_rn(v, __shfl_xor(v, 4, 64));
-        return __shfl(v, i & ~7, 64);
-    };
+    const int lane = threadIdx.x & 63, i = lane & 7, grp = lane >> 3;
+    const int np = (nb + 1) & ~1, nr = np - 1;                             // players, rounds
+    const bool row_on = i < nb;
     int sweep = 0;
     for (; sweep < 60; ++sweep) {
         bool rotated = false;
-        for (int p = 0; p < nb; ++p)
-            for (int q = p + 1; q < nb; ++q) {
-                const double x = on ? M[i * nb + p] : 0.0, y = on ? M[i * nb + q] : 0.0;
-                const double al = sum8(__dmul_rn(x, x)), be = sum8(__dmul_rn(y, y)), ga = sum8(__dmul_rn(x, y));
-                if (!(fabs(ga) > 2.220446049250313e-16 * sqrt(al * be)) || ga == 0.0) continue;     // uniform over the wave
-                rotated = true;
-                const double zeta = (be - al) / (2.0 * ga);
-                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                if (on) {
-                    M[i * nb + p] = c * x - sn * y;
-                    M[i * nb + q] = sn * x + c * y;
+        for (int r = 0; r < nr; ++r) {
+            // pair of this group in round r: (np - 1, r) for group 0, ((r + g) mod nr, (r - g) mod nr) otherwise
+            int p = r + grp, q = r - grp;
+            if (p >= nr) p -= nr;
+            if (q < 0) q += nr;
+            if (grp == 0) { p = r; q = nr; }
+            if (p > q) { const int t = p; p = q; q = t; }
+            const bool has = grp < (np >> 1) && q < nb;                    // (q = nb: the dummy player of an odd nb)
+            double al = 0.0, be = 0.0, ga = 0.0;
+            if (has) {
+                for (int k = 0; k < nb; ++k) {
+                    const double xr = M[k * nb + p], yr = M[k * nb + q];
+                    al = fma(xr, xr, al); be = fma(yr, yr, be); ga = fma(xr, yr, ga);
                 }
             }
-        if (!rotated) break;
+            // rotate when |ga| > eps sqrt(al be) (squared: no square root)
+            const bool rot = has && ga != 0.0 && ga * ga > 4.930380657631324e-32 * (al * be);
+            if (rot) {
+                const double d = be - al, g2 = 2.0 * ga;
+                const double h2 = d * d + g2 * g2;
+                if (h2 > 1.0e-290) {
+                    double rh = __builtin_amdgcn_rsq(h2);
+                    rh = rh * (1.5 - 0.5 * h2 * rh * rh);                  // one Newton step: the angle needs no more
+                    const double u = 0.5 + 0.5 * fabs(d) * rh;             // in [1/2, 1]
+                    const double ru = sm_rsqrt(u);
+                    const double c = u * ru;
+                    const double sn = (d >= 0.0 ? 0.5 : -0.5) * g2 * rh * ru;
+                    if (row_on) {
+                        const double x = M[i * nb + p], y = M[i * nb + q];
+                        M[i * nb + p] = c * x - sn * y;
+                        M[i * nb + q] = sn * x + c * y;
+                    }
+                    rotated = true;
+                }
+            }
+        }
+        if (!__any(rotated)) break;
     }
     return sweep;
 }
 
 __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
-    extern __shared__ double dyn[];            // A [spin][nenv][nb] (becomes Q-applied U) | R, Ur [spin][nb][nb] | tau [spin][nb] | X [nb][nb]
+    extern __shared__ __attribute__((aligned(16))) double dyn[];            // A [spin][nenv][nb] (becomes Q-applied U) | R, Ur [spin][nb][nb] | tau [spin][nb] | X [nb][nb]
     __shared__ double shv[(SB_MAXB + 1) * (SB_NT / 64)];
     __shared__ int nbath_s[2];
     __shared__ int bad_s;
@@ -364,6 +390,8 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
     double *tauall = Uall + (size_t)spin * nb * nb;
     double *X = tauall + (size_t)spin * nb;
     if (tid == 0) bad_s = 0;
+#define SB_STAMP(i) do { if (g.dbg && tid == 0) g.dbg[i] = wall_clock64(); } while (0)
+    SB_STAMP(0);
     for (int s = 0; s < spin; ++s) {
         double *A = Aall + (size_t)s * nenv * nb, *Rm = Rall + (size_t)s * nb * nb, *Ur = Uall + (size_t)s * nb * nb;
         double *tau = tauall + (size_t)s * nb;
@@ -380,6 +408,7 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
             A[t] = rd[((size_t)Rd * g.nlo + p) * g.nlo + q];
         }
         __syncthreads();
+        if (s == 0) SB_STAMP(1);
         // Householder QR, column by column: v = x + sign(x_j) |x| e_j (stored in place below the diagonal, v_j kept in `vj`),
         // tau = 2 / (v.v); one fused reduction gives |x|^2, a second one the dots v . a_k of all later columns
         for (int j = 0; j < nb && j < nenv; ++j) {
@@ -416,6 +445,7 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
             }
             __syncthreads();
         }
+        if (s == 0) SB_STAMP(2);
         // one-sided Jacobi SVD of the nb x nb triangle R = Ur diag(sigma) W^T: columns rotated until mutually orthogonal
         if (tid < 64) {
             const int k = nb < nenv ? nb : nenv;
@@ -423,6 +453,7 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
             for (int e = tid; e < nb * nb; e += 64) M[e] = (e / nb) < k ? Rm[e] : 0.0;
             const int sweeps = wave_onesided_jacobi(M, nb);
             if (tid == 0 && sweeps >= 60) bad_s = 1;
+            if (s == 0 && g.dbg && tid == 0) { g.dbg[7] = wall_clock64(); g.dbg[8] = (unsigned long long)sweeps; }
             // sigma = column norms, descending (stable: ties by index), Ur = normalised columns in that order
             if (tid < nb) {
                 double a2 = 0.0;
@@ -449,6 +480,7 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
             }
         }
         __syncthreads();
+        if (s == 0) SB_STAMP(3);
         // U = Q [Ur; 0]: the reflectors applied in reverse order to the rows of [Ur; 0] -- into the storage of A, whose reflector
         // columns are consumed as they are applied (column j's reflector lives in A[j.., j])
         // First move the reflectors out of the way: V[r][j] = A[r][j] (r >= j) is needed until step j; U overwrites A row-wise, so
@@ -482,6 +514,7 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
         }
         __syncthreads();
     }
+    SB_STAMP(4);
     // ---- assemble: basis[s] = [ imp identity | env rows: B X ], B = U[:, :nbath_s] with virtual rows zeroed, X = (B^T B)^-1/2 ----
     int nbf = nb;
     for (int s = 0; s < spin; ++s) nbf = nbath_s[s] < nbf ? nbath_s[s] : nbf;
@@ -489,6 +522,7 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
     for (size_t t = tid; t < (size_t)spin * g.nsites * ncol; t += SB_NT) g.basis[t] = 0.0;
     __threadfence();
     __syncthreads();
+    SB_STAMP(5);
     for (int s = 0; s < spin; ++s) {
         double *A = Aall + (size_t)s * nenv * nb;
         double *bs = g.basis + (size_t)s * g.nsites * ncol;
@@ -559,6 +593,8 @@ __global__ __launch_bounds__(SB_NT) void small_bath_kernel(const SmallBath g) {
         for (int s = 0; s < spin; ++s) g.iout[1 + s] = nbath_s[s];
         g.iout[1 + spin] = bad_s;
     }
+    SB_STAMP(6);
+#undef SB_STAMP
 }
 
 }  // namespace
@@ -622,12 +658,24 @@ int dmk_small_bath(dmk_ctx *ctx, const int mesh[3], int nlo, int spin, const dou
     g.nsites = nsites; g.orth = orth ? 1 : 0; g.ncol_max = nimp + nb; g.tol = tol_bath;
     g.rdm1 = rdm1; g.rdm1_stride = rdm1_stride; g.env_idx = env_idx; g.bath_col = bath_col; g.virt_mask = virt_mask;
     g.imp_idx = imp_idx; g.sigma = sigma; g.U = U; g.basis = basis; g.iout = iout_dev;
+    static const bool timing = getenv("DMK_SMALL_TIMING") != nullptr;       // the builder's phase profile; never set in production
+    static unsigned long long *dbg = nullptr;
+    if (timing && !dbg) DMK_HIP(ctx, hipMalloc(&dbg, 16 * sizeof(unsigned long long)));
+    g.dbg = timing ? dbg : nullptr;
     if (lds > 48 * 1024)
         DMK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(small_bath_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
     FamScope fs(ctx, DMK_FAM_BATH);
     hipLaunchKernelGGL(small_bath_kernel, dim3(1), dim3(SB_NT), lds, ctx->stream, g);
     DMK_CHECK_LAUNCH(ctx);
+    if (timing) {
+        unsigned long long t[9];
+        DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        DMK_HIP(ctx, hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[small_bath nenv=%d nb=%d spin=%d] us: gather %.2f, QR %.2f, SVD %.2f, apply Q (+ spin 1) %.2f, clear basis %.2f, "
+                        "Loewdin + scatter %.2f; total %.2f; Jacobi of the SVD alone %.2f (%llu sweeps)\n", nenv, nb, spin, 0.01 * (t[1] - t[0]), 0.01 * (t[2] - t[1]), 0.01 * (t[3] - t[2]),
+                0.01 * (t[4] - t[3]), 0.01 * (t[5] - t[4]), 0.01 * (t[6] - t[5]), 0.01 * (t[6] - t[0]), 0.01 * (t[7] - t[2]), t[8]);
+    }
     *handled = 1;
     return DMK_OK;
 }
