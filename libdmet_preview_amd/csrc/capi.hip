@@ -742,6 +742,7 @@ struct dmk_eri {
     double2 *ring = nullptr;
     size_t ring_bytes = 0;
     int ring_pending = 0;       // queued ring slots whose step 1 has not run yet (they are the first `ring_pending` slots)
+    const double2 *resident_src = nullptr;   // dmk_eri_push_resident: the queued group is read in place from here, not from the ring
     // PRODUCER STREAM of the ring (dmk_eri_ring_slot): the ring is double buffered and device-side producers of group g + 1
     // (a generator kernel, a decompressor) run on `gen_stream` while the compute stream transforms group g.  Ordering by events:
     // ev_free[half] = step 1 of the group that last used that half has run (recorded on the compute stream; the producer stream
@@ -922,14 +923,16 @@ static int eri_ring_step1(dmk_eri *h) {
     if (h->ring_pending == 0) return DMK_OK;
     const int nao = h->nao, naux = h->naux, nemb = h->nemb;
     const size_t slot_elems = (size_t)naux * nao * nemb;
-    const double2 *src = h->ring + (size_t)h->fill_half * h->group * naux * nao * nao;
-    if (h->gen_pending) DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_gen[h->fill_half], 0));      // the producers of this group
+    const bool resident = h->resident_src != nullptr;
+    const double2 *src = resident ? h->resident_src : h->ring + (size_t)h->fill_half * h->group * naux * nao * nao;
+    if (!resident && h->gen_pending) DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_gen[h->fill_half], 0));      // the producers of this group
     int rc = launch_half1_hot_multi(ctx, src, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->C, h->Ut,
                                     (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * nao * nemb,
                                     (long long)h->group * (long long)slot_elems);
     if (rc < 0) return rc;
     if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
-    if (h->ring_halves == 2) DMK_HIP(ctx, hipEventRecord(h->ev_free[h->fill_half], ctx->stream));           // the half may be refilled
+    if (!resident && h->ring_halves == 2) DMK_HIP(ctx, hipEventRecord(h->ev_free[h->fill_half], ctx->stream));           // the half may be refilled
+    h->resident_src = nullptr;
     h->ring_pending = 0;
     h->gen_pending = false;
     h->fill_half = 0;                                  // a producer on the compute stream (no dmk_eri_ring_slot) always uses half 0
@@ -1507,6 +1510,33 @@ int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise) {
                                         8.0 * h->naux * (double)h->nao * h->nemb * h->nemb);
     if (h->pending == h->group) return eri_flush(h);
     return DMK_OK;
+}
+
+int dmk_eri_push_resident(dmk_eri *h, const void *blocks, int nblk, const int32_t *ki, const int32_t *kj, const int32_t *symmetrise) {
+    if (!h) return DMK_ERR_INVALID;
+    dmk_ctx *ctx = h->ctx;
+    if (h->cur_kL < 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_resident: no kL in progress");
+    if (!h->ring || h->group <= 1) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_resident: this shape has no grouped hot path (dmk_eri_block_ring)");
+    if (!blocks || !ki || !kj || !symmetrise || nblk < 1 || nblk > h->group)
+        return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_resident: bad arguments (1 <= nblk <= %d queue slots)", h->group);
+    if ((reinterpret_cast<uintptr_t>(blocks) & 15) != 0) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_resident: blocks must be 16-byte aligned");
+    if (h->pending != 0) {                              // a resident group is a launch of its own
+        int rcf = eri_flush(h);
+        if (rcf) return rcf;
+    }
+    for (int b = 0; b < nblk; ++b) {
+        if (ki[b] < 0 || ki[b] >= h->mesh.nk || kj[b] < 0 || kj[b] >= h->mesh.nk)
+            return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_resident: k index out of range");
+        h->pend_ki[b] = ki[b];
+        h->pend_kj[b] = kj[b];
+        h->pend_sym[b] = symmetrise[b] ? 1 : 0;
+    }
+    h->pending = nblk;
+    h->ring_pending = nblk;
+    h->resident_src = reinterpret_cast<const double2 *>(blocks);
+    h->flops_half += (double)nblk * h->spin * (8.0 * h->naux * (double)h->nao * h->nao * h->nemb +
+                                               8.0 * h->naux * (double)h->nao * h->nemb * h->nemb);
+    return eri_flush(h);
 }
 
 int dmk_eri_flush(dmk_eri *h) {

@@ -55,6 +55,7 @@ class SyntheticSystem(object):
         ks = fourier.make_kpts_scaled(self.mesh)
         self.kpts = self.cell.get_abs_kpts(ks)
         self.df = et.GDFPhilox(self.kpts, naux, nlo, seed=seed + 2) if naux > 0 else None
+        self.df_resident = None                 # et.GDFResident of a kL shard (make_df_resident): the blocks kept in HBM
         # orbital index sets: impurity = cell 0, valence = first nval orbitals (ncore = 0)
         self.imp_idx = list(range(nlo))
         self.val_idx = list(range(nval))
@@ -73,6 +74,21 @@ class SyntheticSystem(object):
         w = dict(synth.WORKLOADS[name])
         w.update(over)
         return cls(ctx, w["mesh"], w["nlo"], w["naux"], w["nval"], w["spin"], seed=seed, name=name)
+
+    def make_df_resident(self, kL_list=None, max_fraction_of_free=0.45):
+        """Keep the AO DF blocks of `kL_list` (default: every irreducible kL) resident in HBM when they fit in
+        `max_fraction_of_free` of the free device memory; later ERI transforms of those kL read them in place instead of
+        regenerating / re-reading them (et.GDFResident).  Returns the bytes held (0: does not fit, nothing changed)."""
+        if self.df is None:
+            return 0
+        need = et.GDFResident.bytes_needed(self.mesh, self.nao, self.naux, kL_list)
+        free, _ = self.ctx.mem_info()
+        if need == 0 or need > max_fraction_of_free * free:
+            return 0
+        if self.df_resident is not None:
+            self.df_resident.free()
+        self.df_resident = et.GDFResident(self.ctx, self.df, self.mesh, self.nao, self.naux, kL_list)
+        return need
 
     def k_shard(self, rank, world):
         """k-points owned by `rank`: +-k pairs stay together."""
@@ -397,8 +413,10 @@ def eri_stage(ctx, sysm, d_C, nemb, eri_dev, kL_list=None, timers=None, max_bloc
         if probe is not None:
             eng.set_probe(probe[0], probe[1])
         nblk = 0
+        res = getattr(sysm, "df_resident", None)
         for kL in todo:
-            nblk += eng.run_kL(kL, sysm.df, max_blocks=max_blocks_per_kL)
+            src = res if (res is not None and int(kL) in res.offset) else sysm.df
+            nblk += eng.run_kL(kL, src, max_blocks=max_blocks_per_kL)
         fh, fc = eng.flops()
         if exchange == "row_sharded" and dist.is_initialized():
             npair = nemb * (nemb + 1) // 2
