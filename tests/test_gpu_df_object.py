@@ -166,3 +166,30 @@ def test_resident_df_blocks_bit_identical_to_the_ring():
         assert np.abs(mixed["eri"].get() - eri_ref).max() <= 1e-15 * np.abs(eri_ref).max()
         sysm.df_resident.free()
         sysm.df_resident = None
+
+
+@pytest.mark.parametrize("name,spin", [("m231", 2), ("mid411", 2), ("m222", 1)])
+def test_make_df_resident_through_the_entry_points(ctx, golden, name, spin):
+    """et.make_df_resident(cell, <the reference's GDF-shaped object>) -> a provider whose blocks sit in HBM; get_emb_eri /
+    get_unit_eri with it reproduce golden G6 (1e-8) and the ERIs of the file-backed object to rounding -- Gamma-centred meshes
+    (integer plan) and shifted ones (general plan), with and without time reversal."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    mesh, cell, kabs, cont, naux = _setup(g, name)
+    st = "%s/s%d" % (name, spin)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    duck = DuckGDF(cell, kabs, cont, blockdim=max(1, naux // 2 + 1))
+    for tr in (True, False):
+        res = et.make_df_resident(cell, duck, t_reversal_symm=tr)
+        assert res.nblocks > 0 and not hasattr(duck, "load_block")
+        e = et.get_emb_eri(cell, res, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
+        ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+        assert e.shape == ref.shape and np.abs(e - ref).max() < TOL
+        e_file = et.get_emb_eri(cell, duck, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
+        assert np.abs(e - e_file).max() <= 1e-14 * max(1.0, np.abs(ref).max())
+        if tr:
+            eu = et.get_unit_eri(cell, res, C_ao_lo=C)
+            assert np.abs(eu - g[st + "/eri_unit"]).max() < TOL
+        res.close()
+    with pytest.raises(MemoryError):
+        et.make_df_resident(cell, duck, max_fraction_of_free=1e-12)
