@@ -368,6 +368,16 @@ int dmk_df_blocks_philox_on(dmk_ctx *ctx, void *stream, uint64_t seed, int nblk,
 int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao,
                         void *Lpq_out);
 
+/* Modified (pivoted, incomplete) Cholesky vectors of a 4-fold ERI matrix: the arithmetic of convert_eri_to_gdf
+ * (eri_transform.py:1483-1535 -> utils/cholesky.py:21-52 modified_cholesky, :54-105 modified_cholesky_uhf), the writer that turns a
+ * molecular ERI into a Gamma-point cderi container.  n = norb (norb + 1) / 2 pair columns.  uhf = 0: m_aa (n x n); vecs
+ * [max_vecs][n].  uhf = 1: the aa, bb, ab blocks share one pivot sequence over their 2 n diagonal entries; vecs [2][max_vecs][n]
+ * (alpha set, then beta set).  The loop stops after the vector whose pivot residual falls below max_error (that vector is kept,
+ * as in the reference) or after 2 n + 1 cycles (*exhausted_out = 1: the reference's "does not converge" warning); max_vecs >=
+ * 2 n + 2.  Pivots (first maximum of |residual diagonal|) and vectors follow the host loop operation by operation. */
+int dmk_modified_cholesky(dmk_ctx *ctx, int n, int uhf, const double *m_aa, const double *m_bb, const double *m_ab, double max_error,
+                          int max_vecs, double *vecs, int32_t *nvec_out, int32_t *exhausted_out);
+
 /* a14: 4-fold (npair x npair) -> 1-fold (nemb^4) / 8-fold restore
  * (eri_transform.py:523-544 -> pyscf ao2mo.restore). */
 int dmk_eri_restore(dmk_ctx *ctx, int nemb, int symmetry, const double *eri4, double *out);

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "dmk_jk_s4": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_jk_s4_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "dmk_modified_cholesky": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_dbl, c_int, c_vp, P(c_int), P(c_int)]),
     "dmk_dgemv2": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "dmk_dgemm_batched": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_i64, c_vp, c_i64,
                                   c_i64, c_dbl, c_vp, c_i64, c_i64]),

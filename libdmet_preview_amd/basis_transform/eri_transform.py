@@ -321,6 +321,57 @@ class GDFPhilox(object):
                                               self.nao, out_ptr, int(stride_bytes)))
 
 
+def convert_eri_to_gdf(eri, norb, fname=None, tol=1e-8):
+    """
+    Convert a molecular ERI to a Gamma-point GDF container (eri_transform.py:1483-1535): modified Cholesky vectors of the 4-fold
+    ERI (utils/cholesky.py:21-131 get_cderi_rhf / get_cderi_uhf) stored as `j3c/0/0` with the one-pair `j3c-kptij` table.
+    The decomposition runs on the device (dmk_modified_cholesky: the reference's loop operation by operation, so the pivot
+    sequence -- which defines the vectors -- is the reference's), as do the restore to 4-fold symmetry (dmk_eri_to_s4) and the
+    unpacking of the vectors to (nchol, norb, norb) (dmk_sym_unpack).
+
+    eri: (nao^4) / 4-fold / 8-fold, without spin dimension, with spin dimension 1, or 3 blocks (aa, bb, ab).
+    Returns `fname` (written through a lazily imported h5py; .npz without it is NOT written silently: ImportError) or, for
+    fname None, the nested dictionary {'j3c': {'0': {'0': cderi}}, 'j3c-kptij': (1, 2, 3)} the reference returns.
+    """
+    from libdmet_preview_amd.system import integral
+    from libdmet_preview_amd.solver.scf import _block_to_dev_s4
+    ctx = get_ctx()
+    norb = int(norb)
+    eri = np.asarray(eri)
+    eri_format, spin_dim = integral.get_eri_format(eri, norb)
+    if spin_dim == 1:
+        eri = eri[0]
+    else:
+        assert spin_dim == 0 or spin_dim == 3
+    npair = norb * (norb + 1) // 2
+    uhf = spin_dim == 3
+    d_blk = [_block_to_dev_s4(ctx, eri[b], eri_format, norb) for b in range(3)] if uhf else [_block_to_dev_s4(ctx, eri, eri_format, norb)]
+    max_vecs = 2 * npair + 2
+    d_vecs = ctx.empty(((2 if uhf else 1), max_vecs, npair), np.float64)
+    nvec, exhausted = C.c_int(0), C.c_int(0)
+    ctx.check(lib.dmk_modified_cholesky(ctx.h, npair, 1 if uhf else 0, d_blk[0].ptr, d_blk[1].ptr if uhf else None,
+                                        d_blk[2].ptr if uhf else None, float(tol), max_vecs, d_vecs.ptr, C.byref(nvec), C.byref(exhausted)))
+    if exhausted.value:
+        log.warn("modified cholesky does not converge ...")
+    nchol = int(nvec.value)
+    d_full = ctx.empty(((2 if uhf else 1), nchol, norb, norb), np.float64)
+    for s_ in range(2 if uhf else 1):
+        ctx.check(lib.dmk_sym_unpack(ctx.h, norb, nchol, d_vecs.offset(s_ * max_vecs * npair, (nchol, npair)).ptr, None,
+                                     d_full.offset(s_ * nchol * norb * norb, (nchol, norb, norb)).ptr))
+    cderi = d_full.get()
+    cderi = cderi if uhf else cderi[0]
+    kptij_lst = np.zeros((1, 2, 3))                                  # the single (Gamma, Gamma) pair (:1521-1525)
+    dataname = 'j3c'
+    if fname is None:
+        return {dataname: {'0': {'0': cderi}}, dataname + '-kptij': kptij_lst}
+    import h5py                                                     # (not on the GPU box of this build: ImportError, nothing written)
+    feri = h5py.File(fname, 'w')
+    feri['%s/%d/%d' % (dataname, 0, 0)] = cderi
+    feri[dataname + '-kptij'] = kptij_lst
+    feri.close()
+    return fname
+
+
 class GDFResident(object):
     """The AO DF blocks a kL shard reads, RESIDENT in device memory in the order the pipeline consumes them (one contiguous
     array: kL by kL, records in plan order).  The reference reads every (ki, kj) block from the cderi file once per get_emb_eri
@@ -380,6 +431,13 @@ class GDFResident(object):
 
     def load_block(self, ctx, ki, kj, out):                 # (the ring path of a caller that does not know about group_ptr)
         return self.provider.load_block(ctx, ki, kj, out)
+
+    def __getattr__(self, name):
+        # everything else a driver may ask of a DF provider (get_block, blockdim, max_memory, cell, ...) is the source's
+        prov = self.__dict__.get("provider")
+        if prov is None or name.startswith("__") or name in ("load_block_host", "load_blocks_on", "load_block_on", "close"):
+            raise AttributeError(name)
+        return getattr(prov, name)
 
     def free(self):
         self.buf.free()

@@ -43,7 +43,7 @@ _FUNCTIONS = [
      ["get_emb_eri", "get_unit_eri"]),
     # spinless.py:518-538 imports get_emb_eri_gso lazily from the module; cderi layout helpers
     ("basis_transform.eri_transform", ["basis_transform.eri_transform"],
-     ["get_emb_eri_gso", "get_mask_kptij_lst", "transform_gdf_to_lo", "eri_restore", "get_emb_eri_fast_gdf",
+     ["get_emb_eri_gso", "get_mask_kptij_lst", "transform_gdf_to_lo", "convert_eri_to_gdf", "eri_restore", "get_emb_eri_fast_gdf",
       "transform_ao_to_emb", "_Lij_s4_to_eri", "get_basis_k", "get_weights_t_reversal"]),
     # J / K on the resident ERI (routine/slater.py:30 imports them by name)
     ("solver.scf", ["solver.scf", "routine.slater"], ["_get_jk", "_get_veff"]),

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1231,6 +1231,38 @@ def gen_G19():
                     out[key + "/raises"] = np.asarray(str(e))
     np.savez_compressed(os.path.join(GOLD, "G19_bath_opt.npz"), **out)
     print("G19 done", sorted(k for k in out if k.endswith("raises")))
+
+
+def gen_G20():
+    """convert_eri_to_gdf (basis_transform/eri_transform.py:1483-1535 over utils/cholesky.py): the reference's function on seeded
+    positive semi-definite 4-fold ERIs -- exact low rank with decaying weights (the loop stops on the tolerance), a spin-dependent
+    triple (aa, bb, ab) from two correlated factor sets, and the same restricted ERI handed over in s1 and s8 form."""
+    et = shim.patch_eri_transform()
+    out = {}
+    for name, norb, rank, seed in (("n4", 4, 5, 11), ("n6", 6, 9, 12), ("n9", 9, 30, 13)):
+        npair = norb * (norb + 1) // 2
+        rng = np.random.default_rng(seed)
+        L = rng.standard_normal((rank, npair)) * np.exp(-0.35 * np.arange(rank))[:, None]
+        eri = L.T @ L
+        out[name + "/eri_s4"] = eri
+        for tol in (1e-8, 1e-4):
+            f = et.convert_eri_to_gdf(eri, norb, fname=None, tol=tol)
+            out["%s/cderi_tol%g" % (name, tol)] = np.asarray(f["j3c"]["0"]["0"])
+            out[name + "/kptij"] = np.asarray(f["j3c-kptij"])
+        # the same ERI as (norb^4) and 8-fold, and with a spin dimension of one
+        e1 = shim.restore(1, eri, norb)
+        e8 = shim.restore(8, eri, norb)
+        for tag, e in (("s1", e1), ("s8", e8), ("s4x1", eri[None])):
+            f = et.convert_eri_to_gdf(e, norb, fname=None, tol=1e-8)
+            assert np.array_equal(np.asarray(f["j3c"]["0"]["0"]), out[name + "/cderi_tol1e-08"]), tag
+        La = rng.standard_normal((rank, npair)) * np.exp(-0.3 * np.arange(rank))[:, None]
+        Lb = 0.6 * La + 0.8 * rng.standard_normal((rank, npair)) * np.exp(-0.3 * np.arange(rank))[:, None]
+        e3 = np.asarray([La.T @ La, Lb.T @ Lb, La.T @ Lb])
+        out[name + "/eri3_s4"] = e3
+        f3 = et.convert_eri_to_gdf(e3, norb, fname=None, tol=1e-8)
+        out[name + "/cderi3"] = np.asarray(f3["j3c"]["0"]["0"])
+    np.savez_compressed(os.path.join(GOLD, "G20_convert_eri.npz"), **out)
+    print("G20 done", {k: out[k].shape for k in out if "cderi" in k})
 
 
 if __name__ == "__main__":

@@ -7,6 +7,9 @@ oracle/restate_cderi.py -- CPU restatement (numpy) of SURVEY.md section 8(f) ran
   sr_loop / _load3c       basis_transform/eri_transform.py:195-227     (reader: swap -> conjugate transpose,
                                                                         ki == kj -> Hermitian unpack of the packed triangle)
 
+  convert_eri_to_gdf      basis_transform/eri_transform.py:1483-1535  + utils/cholesky.py:21-131 (modified Cholesky vectors of a
+                                                                        molecular ERI as a Gamma-point container; golden G20)
+
 `_load3c` is PySCF code (absent here); its behaviour is restated from the layout the reference's writer produces and
 the unpack flag the reference passes (sr_loop: `unpack = is_zero(kpti - kptj) and not compact`).
 
@@ -84,3 +87,85 @@ def load_block(feri, nk, nao, i, j):
     else:
         L = L.astype(np.complex128).reshape(-1, nao, nao)
     return L.conj().transpose(0, 2, 1) if swap else L
+
+
+# ---- convert_eri_to_gdf (eri_transform.py:1483-1535) ------------------------------------------------------------------------------
+def modified_cholesky(mat, max_error=1e-6):
+    """utils/cholesky.py:21-52."""
+    mat = np.asarray(mat)
+    size = mat.shape[0]
+    diag = np.diag(mat)
+    idx = int(np.argmax(diag))
+    delta_max = diag[idx]
+    approx = np.zeros(size)
+    vecs = [mat[idx] / delta_max ** 0.5]
+    for i in range(size * 2 + 1):
+        approx = approx + vecs[i] * vecs[i]
+        delta = diag - approx
+        idx = int(np.argmax(np.abs(delta)))
+        delta_max = abs(delta[idx])
+        R = np.zeros(size)
+        for v in vecs:
+            R = R + v[idx] * v
+        vecs.append((mat[idx] - R) / delta_max ** 0.5)
+        if delta_max < max_error:
+            break
+    return np.asarray(vecs)
+
+
+def modified_cholesky_uhf(mat, max_error=1e-6):
+    """utils/cholesky.py:54-105; mat = (aa, bb, ab)."""
+    size = mat[0].shape[0]
+    diag = np.hstack((np.diag(mat[0]), np.diag(mat[1])))
+    idx = int(np.argmax(diag))
+    delta_max = diag[idx]
+    approx = np.zeros_like(diag)
+    va, vb = [], []
+
+    def rows(idx):
+        if idx < size:
+            return mat[0][idx], mat[2][idx]
+        return mat[2].T[idx - size], mat[1][idx - size]
+
+    ra, rb = rows(idx)
+    va.append(ra / delta_max ** 0.5)
+    vb.append(rb / delta_max ** 0.5)
+    for i in range(size * 2 + 1):
+        approx[:size] += va[i] * va[i]
+        approx[size:] += vb[i] * vb[i]
+        delta = diag - approx
+        idx = int(np.argmax(np.abs(delta)))
+        delta_max = abs(delta[idx])
+        Ra, Rb = np.zeros(size), np.zeros(size)
+        for a, b in zip(va, vb):
+            c = a[idx] if idx < size else b[idx - size]
+            Ra = Ra + c * a
+            Rb = Rb + c * b
+        ra, rb = rows(idx)
+        va.append((ra - Ra) / delta_max ** 0.5)
+        vb.append((rb - Rb) / delta_max ** 0.5)
+        if delta_max < max_error:
+            break
+    return np.asarray([va, vb])
+
+
+def unpack_tril_sym(tril, n):
+    """pyscf.lib.unpack_tril (symmetric fill) of (..., npair) -> (..., n, n)."""
+    tril = np.asarray(tril)
+    out = np.zeros(tril.shape[:-1] + (n, n))
+    il = np.tril_indices(n)
+    out[..., il[0], il[1]] = tril
+    out[..., il[1], il[0]] = tril
+    return out
+
+
+def convert_eri_to_gdf(eri_s4, norb, tol=1e-8):
+    """eri_transform.py:1483-1535 for an ERI already restored to 4-fold symmetry: (npair, npair) or three such blocks (aa, bb, ab).
+    Returns the nested dictionary of the fname=None branch."""
+    eri_s4 = np.asarray(eri_s4)
+    if eri_s4.ndim == 3:
+        ev = modified_cholesky_uhf([eri_s4[0], eri_s4[1], eri_s4[2]], max_error=tol)
+        cderi = unpack_tril_sym(ev, norb)
+    else:
+        cderi = unpack_tril_sym(modified_cholesky(eri_s4, max_error=tol), norb)
+    return {"j3c": {"0": {"0": cderi}}, "j3c-kptij": np.zeros((1, 2, 3))}

@@ -165,7 +165,7 @@ def r_e2(eri, mo_coeff, orbs_slice, tao, ao_loc, aosym="s1", out=None):
 
 
 def restore(symmetry, eri, norb):
-    """ao2mo.restore for 4-fold packed real input (npair, npair)."""
+    """ao2mo.restore for real input in 1-, 4- or 8-fold form."""
     eri = np.asarray(eri)
     npair = norb * (norb + 1) // 2
     symmetry = int(str(symmetry).replace("s", ""))
@@ -175,6 +175,11 @@ def restore(symmetry, eri, norb):
         e1 = eri.reshape(norb, norb, norb, norb)
         idx = np.tril_indices(norb)
         eri4 = e1[idx[0], idx[1]][:, idx[0], idx[1]]
+    elif eri.size == npair * (npair + 1) // 2:             # 8-fold input: the packed lower triangle of the (npair, npair) matrix
+        i2 = np.tril_indices(npair)
+        eri4 = np.zeros((npair, npair), dtype=eri.dtype)
+        eri4[i2[0], i2[1]] = eri.reshape(-1)
+        eri4[i2[1], i2[0]] = eri.reshape(-1)
     else:
         raise ValueError("restore: unsupported input size")
     if symmetry == 4:

@@ -90,3 +90,28 @@ def test_product_mask_bit_exact(golden, tag):
     kpts = cell.get_abs_kpts(R.make_kpts_scaled(mesh))
     kptij = np.asarray([(ki, kpts[j]) for i, ki in enumerate(kpts) for j in range(i + 1)])
     assert np.array_equal(get_mask_kptij_lst(cell, kptij), g["mask/" + tag])
+
+
+# ---- golden G20 (gen_G20): convert_eri_to_gdf, the molecular-ERI -> Gamma-point container writer ---------------------------------
+@pytest.mark.parametrize("name,norb", [("n4", 4), ("n6", 6), ("n9", 9)])
+def test_G20_convert_eri_to_gdf(golden, name, norb):
+    """eri_transform.py:1483-1535 over utils/cholesky.py:21-131 against what the reference returned: the vectors themselves (the
+    pivot sequence is part of the result), the tolerance-dependent count, the spin-dependent triple, and the defining property
+    sum_L cderi_L cderi_L^T = eri to the tolerance."""
+    g = golden("G20_convert_eri.npz")
+    eri = g[name + "/eri_s4"]
+    for tol in (1e-8, 1e-4):
+        ref = g["%s/cderi_tol%g" % (name, tol)]
+        out = Cd.convert_eri_to_gdf(eri, norb, tol=tol)
+        c = out["j3c"]["0"]["0"]
+        assert c.shape == ref.shape and np.abs(c - ref).max() < 1e-12
+        assert np.array_equal(out["j3c-kptij"], g[name + "/kptij"])
+        cp = np.asarray([R.pack_tril(x) for x in c])
+        assert np.abs(cp.T @ cp - eri).max() < 10 * tol
+    e3 = g[name + "/eri3_s4"]
+    c3 = Cd.convert_eri_to_gdf(e3, norb, tol=1e-8)["j3c"]["0"]["0"]
+    ref3 = g[name + "/cderi3"]
+    assert c3.shape == ref3.shape and np.abs(c3 - ref3).max() < 1e-12
+    pa = np.asarray([R.pack_tril(x) for x in c3[0]])
+    pb = np.asarray([R.pack_tril(x) for x in c3[1]])
+    assert np.abs(pa.T @ pa - e3[0]).max() < 1e-7 and np.abs(pb.T @ pb - e3[1]).max() < 1e-7 and np.abs(pa.T @ pb - e3[2]).max() < 1e-7
