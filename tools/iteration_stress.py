@@ -33,6 +33,8 @@ for trial in range(trials):
             break
     seed = int(rng.integers(1, 1 << 30))
     sysm = pipeline.SyntheticSystem(ctx, mesh, nlo, naux, nval, spin, seed=seed, name="iter_stress")
+    if trial % 2 == 1:                          # every other system with its DF blocks resident in HBM (et.GDFResident, dmk_eri_push_resident)
+        sysm.make_df_resident()
     npair_max = nemb_max * (nemb_max + 1) // 2
     out = pipeline.iteration(ctx, sysm)
     nemb = out["nemb"]
