@@ -178,6 +178,128 @@ __global__ __launch_bounds__(256, 2) void ozaki_gemm_kernel(int N, int KP, const
     }
 }
 
+// ---- second kernel: 256 x 256 workgroup tile, LDS-DMA ring ------------------------------------------------------------------------
+// What bounds the first kernel is the operand feed (a 128 x 128 tile consumes 64 B per clock and CU: 39 TB/s over the chip at the
+// int8 rate, above what the L2 delivers) and its one K step of prefetch distance.  Here: workgroup tile 256 x 256 (half the bytes
+// per operation), 2 x 2 waves of 128 x 128 (8 x 8 MFMA tiles: 256 accumulator registers, i.e. ONE workgroup per CU with the
+// accumulators in AGPRs), K step 64 bytes = one v_mfma_i32_16x16x64_i8 per tile, operands by LDS-DMA into a four-stage ring
+// (prefetch distance three K steps, one barrier per step), 64-byte LDS rows with the 16-byte chunk position XOR-swizzled by
+// (0, 3, 2, 1)[(row >> 2) & 3] so that the ds_read_b128 lane groups of a fragment read sixteen different bank quads.  The slice
+// pairs of ALL anti-diagonals run through the ring as one sequence of K steps; at the end of a diagonal the int32 tile is folded
+// into C through L2 as before.  N must be a multiple of 256 (lab).
+__device__ __forceinline__ unsigned oz_lds_addr(const void *p) {
+    typedef __attribute__((address_space(3))) void lds_void_t;
+    return (unsigned)(size_t)(lds_void_t *)p;
+}
+__device__ __forceinline__ void oz_glds16(const void *gsrc, unsigned lds_base) {
+    unsigned keep;
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(base) : "memory");
+}
+constexpr int OZ_STAGES = 4;
+constexpr int OZ_STAGE_BYTES = 2 * 256 * 64;          // A panel | B panel
+template <int S>
+__global__ __launch_bounds__(256, 1) void ozaki_gemm256_kernel(int N, int KP, const int8_t *__restrict__ Xs, const int8_t *__restrict__ Ys,
+                                                               const int *__restrict__ exX, const int *__restrict__ exY,
+                                                               double *__restrict__ C) {
+    extern __shared__ __attribute__((aligned(1024))) int8_t ring[];           // [OZ_STAGES][A 256 x 64 | B 256 x 64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, lg = lane >> 4;
+    // XCD-aware tile order: the 32 workgroups an XCD runs together form 8 x 4 tiles (8 A panels, 4 B panels shared in its L2)
+    const int NT = N / 256;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nblocks = gridDim.x, q = nblocks >> 3, r = nblocks & 7u;
+        const unsigned xcd = bid & 7u, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int cb = (int)(bid / (4u * NT)), rem = (int)(bid % (4u * NT));
+    const int width = min(4, NT - 4 * cb);
+    const int ta = rem / width, tb = 4 * cb + rem % width;
+    const int a0 = ta * 256, b0 = tb * 256;
+    const int T = KP / 64;
+    constexpr int NPAIR = S * (S + 1) / 2;
+    const int nsteps = NPAIR * T;
+    const unsigned ring0 = oz_lds_addr(ring);
+    // loader: a wave-instruction moves 16 rows x 64 bytes; wave w takes the row groups w, w + 4, ... of both panels (8 instructions)
+    const int lrow = lane >> 2, lpos = lane & 3;
+    const int lchunk = lpos ^ ((0x6C >> (2 * ((lrow >> 2) & 3))) & 3);       // (0, 3, 2, 1)[(row >> 2) & 3] = bits of 0b01101100
+    auto pair_of = [&](int pi, int &s, int &t2) {                            // pairs in anti-diagonal order: d = 0: (0,0); d = 1: (0,1), (1,0); ...
+        int d = 0;
+        while (pi > d) { pi -= d + 1; ++d; }
+        s = pi; t2 = d - pi;
+    };
+    auto issue = [&](int q) {                                                // K step q of the whole sequence -> ring stage q % OZ_STAGES
+        const int pi = q / T, t = q - pi * T;
+        int s, t2;
+        pair_of(pi, s, t2);
+        const int8_t *A = Xs + ((long long)s * N + a0) * KP + t * 64, *B = Ys + ((long long)t2 * N + b0) * KP + t * 64;
+        const unsigned st = ring0 + (unsigned)((q % OZ_STAGES) * OZ_STAGE_BYTES);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = wave + 4 * u;                                      // row group 0 .. 15
+            oz_glds16(A + (long long)(g * 16 + lrow) * KP + lchunk * 16, st + (unsigned)(g * 1024));
+            oz_glds16(B + (long long)(g * 16 + lrow) * KP + lchunk * 16, st + (unsigned)(256 * 64 + g * 1024));
+        }
+    };
+    i32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = i32x4{0, 0, 0, 0};
+    // fragment addresses inside a stage: row r, chunk lg at position lg ^ f(r); tile i of a wave is 16 rows = 1024 bytes further
+    // and has the same swizzle (bits 2-3 of the row come from the lane), so ONE base per operand and immediate offsets
+    const int ra0 = wm * 128 + li, rb0 = wn * 128 + li;
+    const unsigned offA0 = (unsigned)(ra0 * 64 + ((lg ^ ((0x6C >> (2 * ((ra0 >> 2) & 3))) & 3)) * 16));
+    const unsigned offB0 = (unsigned)(256 * 64 + rb0 * 64 + ((lg ^ ((0x6C >> (2 * ((rb0 >> 2) & 3))) & 3)) * 16));
+    issue(0);
+    if (nsteps > 1) issue(1);
+    if (nsteps > 2) issue(2);
+    int q = 0;
+    for (int d = 0; d < S; ++d) {
+        const int qend = q + (d + 1) * T;                                    // the K steps of this anti-diagonal (the ring runs through)
+#pragma unroll 1
+        for (; q < qend; ++q) {
+            // my pieces of stage q have landed when at most the 8 + 8 of the two later stages are outstanding
+            if (q + 2 < nsteps) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (q + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                                 // everybody's pieces; and stage (q - 1) % 4 is free
+            if (q + 3 < nsteps) issue(q + 3);
+            const int8_t *st = ring + (q % OZ_STAGES) * OZ_STAGE_BYTES;
+            i32x4 fa[8], fb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const i32x4 *>(st + offA0 + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[j] = *reinterpret_cast<const i32x4 *>(st + offB0 + j * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        // fold the anti-diagonal into the C tile (D layout: col = lane & 15, row = (lane >> 4) * 4 + reg)
+        const double sc = ldexp(1.0, -12 - 7 * d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = a0 + wm * 128 + i * 16 + lg * 4 + r, b = b0 + wn * 128 + j * 16 + li;
+                    double *c = C + (long long)a * N + b;
+                    double v = sc * (double)acc[i][j][r];
+                    if (d > 0) v += *c;
+                    if (d == S - 1) v = ldexp(v, exX[a] + exY[b]);
+                    *c = v;
+                }
+                acc[i][j] = i32x4{0, 0, 0, 0};
+            }
+    }
+}
+
 // ---- f64 reference on sampled entries ------------------------------------------------------------------------------------------
 __global__ void ref_kernel(int K, int N, const double *__restrict__ X, const double *__restrict__ Y, int nsamp, const int *__restrict__ sa,
                            const int *__restrict__ sb, double *__restrict__ out) {
@@ -190,6 +312,7 @@ __global__ void ref_kernel(int K, int N, const double *__restrict__ X, const dou
 
 // ---- f64 MFMA baseline (register-staged simple kernel is NOT the product's: the product's rate is quoted from profiles) ---------
 
+static int g_kernel = 1;
 template <int S>
 double run(int N, int K, int KP, const double *X, const double *Y, const int *exX, const int *exY, int8_t *Xs, int8_t *Ys, double *C,
            double *t_slice_ms) {
@@ -203,7 +326,13 @@ double run(int N, int K, int KP, const double *X, const double *Y, const int *ex
         hipLaunchKernelGGL(slice_kernel<S>, gs, dim3(256), 0, 0, K, KP, N, X, exX, Xs);
         hipLaunchKernelGGL(slice_kernel<S>, gs, dim3(256), 0, 0, K, KP, N, Y, exY, Ys);
         CK(hipEventRecord(e1));
-        hipLaunchKernelGGL(ozaki_gemm_kernel<S>, gg, dim3(256), 0, 0, N, KP, Xs, Ys, exX, exY, C);
+        if (g_kernel == 2) {
+            const size_t lds = (size_t)OZ_STAGES * OZ_STAGE_BYTES;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ozaki_gemm256_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ozaki_gemm256_kernel<S>, dim3((N / 256) * (N / 256)), dim3(256), lds, 0, N, KP, Xs, Ys, exX, exY, C);
+        } else {
+            hipLaunchKernelGGL(ozaki_gemm_kernel<S>, gg, dim3(256), 0, 0, N, KP, Xs, Ys, exX, exY, C);
+        }
         CK(hipEventRecord(e2));
         CK(hipEventSynchronize(e2));
         float ms_s, ms_g;
@@ -218,7 +347,10 @@ double run(int N, int K, int KP, const double *X, const double *Y, const int *ex
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 1600, S = argc > 3 ? atoi(argv[3]) : 4;
     const int KP = ((K + BKB - 1) / BKB) * BKB;
-    printf("ozaki_lab: C = X^T Y, N = %d, K = %d (padded %d), S = %d slices -> %d slice pairs\n", N, K, KP, S, S * (S + 1) / 2);
+    g_kernel = argc > 4 ? atoi(argv[4]) : (N % 256 == 0 ? 2 : 1);
+    if (g_kernel == 2 && N % 256 != 0) { printf("kernel 2 needs N %% 256 == 0\n"); return 1; }
+    printf("ozaki_lab: C = X^T Y, N = %d, K = %d (padded %d), S = %d slices -> %d slice pairs, kernel %d (%s)\n", N, K, KP, S, S * (S + 1) / 2,
+           g_kernel, g_kernel == 2 ? "256 x 256 tiles, LDS-DMA ring" : "128 x 128 tiles, register staged");
     double *X, *Y, *C;
     int *exX, *exY;
     int8_t *Xs, *Ys;
