@@ -199,7 +199,7 @@ __device__ __forceinline__ void oz_glds16(const void *gsrc, unsigned lds_base) {
 }
 constexpr int OZ_STAGES = 4;
 constexpr int OZ_STAGE_BYTES = 2 * 256 * 64;          // A panel | B panel
-template <int S>
+template <int S, int ABL = 0>       // ABL (ablation, wrong results, timing only): 1 = no LDS-DMA after the prologue, 2 = fragments read once, 4 = no barrier
 __global__ __launch_bounds__(256, 1) void ozaki_gemm256_kernel(int N, int KP, const int8_t *__restrict__ Xs, const int8_t *__restrict__ Ys,
                                                                const int *__restrict__ exX, const int *__restrict__ exY,
                                                                double *__restrict__ C) {
@@ -259,22 +259,27 @@ __global__ __launch_bounds__(256, 1) void ozaki_gemm256_kernel(int N, int KP, co
     if (nsteps > 1) issue(1);
     if (nsteps > 2) issue(2);
     int q = 0;
+    i32x4 fa[8], fb[8];
+    if (ABL & 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     for (int d = 0; d < S; ++d) {
         const int qend = q + (d + 1) * T;                                    // the K steps of this anti-diagonal (the ring runs through)
 #pragma unroll 1
         for (; q < qend; ++q) {
             // my pieces of stage q have landed when at most the 8 + 8 of the two later stages are outstanding
-            if (q + 2 < nsteps) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (q + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                                 // everybody's pieces; and stage (q - 1) % 4 is free
-            if (q + 3 < nsteps) issue(q + 3);
+            if (!(ABL & 1)) {
+                if (q + 2 < nsteps) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (q + 1 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (!(ABL & 4)) __syncthreads();                                 // everybody's pieces; and stage (q - 1) % 4 is free
+            if (!(ABL & 1) && q + 3 < nsteps) issue(q + 3);
             const int8_t *st = ring + (q % OZ_STAGES) * OZ_STAGE_BYTES;
-            i32x4 fa[8], fb[8];
+            if (!(ABL & 2) || q == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const i32x4 *>(st + offA0 + i * 1024);
+                for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const i32x4 *>(st + offA0 + i * 1024);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fb[j] = *reinterpret_cast<const i32x4 *>(st + offB0 + j * 1024);
+                for (int j = 0; j < 8; ++j) fb[j] = *reinterpret_cast<const i32x4 *>(st + offB0 + j * 1024);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -330,6 +335,13 @@ double run(int N, int K, int KP, const double *X, const double *Y, const int *ex
             const size_t lds = (size_t)OZ_STAGES * OZ_STAGE_BYTES;
             CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ozaki_gemm256_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(ozaki_gemm256_kernel<S>, dim3((N / 256) * (N / 256)), dim3(256), lds, 0, N, KP, Xs, Ys, exX, exY, C);
+        } else if (g_kernel >= 3 && g_kernel <= 9) {
+            const size_t lds = (size_t)OZ_STAGES * OZ_STAGE_BYTES;
+            const dim3 g256((N / 256) * (N / 256));
+#define OZ_ABL(a) case a: CK(hipFuncSetAttribute(reinterpret_cast<const void *>(ozaki_gemm256_kernel<S, a>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                          hipLaunchKernelGGL((ozaki_gemm256_kernel<S, a>), g256, dim3(256), lds, 0, N, KP, Xs, Ys, exX, exY, C); break;
+            switch (g_kernel - 2) { OZ_ABL(1) OZ_ABL(2) OZ_ABL(3) OZ_ABL(4) OZ_ABL(5) OZ_ABL(6) OZ_ABL(7) }
+#undef OZ_ABL
         } else {
             hipLaunchKernelGGL(ozaki_gemm_kernel<S>, gg, dim3(256), 0, 0, N, KP, Xs, Ys, exX, exY, C);
         }
@@ -348,9 +360,9 @@ int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 2 ? atoi(argv[2]) : 1600, S = argc > 3 ? atoi(argv[3]) : 4;
     const int KP = ((K + BKB - 1) / BKB) * BKB;
     g_kernel = argc > 4 ? atoi(argv[4]) : (N % 256 == 0 ? 2 : 1);
-    if (g_kernel == 2 && N % 256 != 0) { printf("kernel 2 needs N %% 256 == 0\n"); return 1; }
+    if (g_kernel >= 2 && N % 256 != 0) { printf("kernel 2 needs N %% 256 == 0\n"); return 1; }
     printf("ozaki_lab: C = X^T Y, N = %d, K = %d (padded %d), S = %d slices -> %d slice pairs, kernel %d (%s)\n", N, K, KP, S, S * (S + 1) / 2,
-           g_kernel, g_kernel == 2 ? "256 x 256 tiles, LDS-DMA ring" : "128 x 128 tiles, register staged");
+           g_kernel, g_kernel == 2 ? "256 x 256 tiles, LDS-DMA ring" : g_kernel > 2 ? "256 x 256 ABLATION (bits of kernel - 2: 1 no LDS-DMA, 2 no fragment reads, 4 no barrier): results wrong, timing only" : "128 x 128 tiles, register staged");
     double *X, *Y, *C;
     int *exX, *exY;
     int8_t *Xs, *Ys;
