@@ -688,12 +688,19 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
         __threadfence();
         const unsigned before = atomicAdd(&g.arrive[mat], 1u);
         last_s = (before == RF_SPLIT - 1) ? 1 : 0;
-        if (last_s) {
-            __threadfence();
-            for (int q = 0; q < RF_SPLIT; ++q) {
-                const volatile double *o = g.part + ((size_t)mat * RF_SPLIT + q) * 4;
-                m0 = fmax(m0, o[0]); m1 = fmax(m1, o[1]); m2 = fmax(m2, o[2]); m3 = fmax(m3, o[3]);
-            }
+    }
+    __syncthreads();
+    if (last_s && wave == 0) {
+        // the last workgroup of the matrix folds the RF_SPLIT x 4 partial maxima: one load per lane (they were 64 dependent
+        // volatile loads of one thread), a shuffle maximum over the lanes that hold the same quantity (lane & 3)
+        __threadfence();
+        double v = (lane < RF_SPLIT * 4) ? __hip_atomic_load(g.part + (size_t)mat * RF_SPLIT * 4 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        for (int o = 4; o < 64; o <<= 1) {
+            const double u = __shfl_xor(v, o, 64);
+            v = (fabs(u) <= 1.7e308 && fabs(v) <= 1.7e308) ? fmax(v, u) : INFINITY;        // NaN / Inf must not vanish in fmax
+        }
+        const double m0 = __shfl(v, 0, 64), m1 = __shfl(v, 1, 64), m2 = __shfl(v, 2, 64), m3 = __shfl(v, 3, 64);
+        if (lane == 0) {
             const double an = g.anorm[mat];
             double *st = g.stats + ((size_t)mat * 8 + g.pass) * RF_STAT;
             st[0] = m0; st[1] = m1; st[2] = m2; st[3] = delta; st[4] = an;
