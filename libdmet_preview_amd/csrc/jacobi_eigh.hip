@@ -693,6 +693,7 @@ __global__ __launch_bounds__(1024) void rf_analyse_kernel(RfAnalyse g) {
     if (last_s && wave == 0) {
         // the last workgroup of the matrix folds the RF_SPLIT x 4 partial maxima: one load per lane (they were 64 dependent
         // volatile loads of one thread), a shuffle maximum over the lanes that hold the same quantity (lane & 3)
+        static_assert(RF_SPLIT * 4 <= 64, "one partial maximum per lane of a wave");
         __threadfence();
         double v = (lane < RF_SPLIT * 4) ? __hip_atomic_load(g.part + (size_t)mat * RF_SPLIT * 4 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         for (int o = 4; o < 64; o <<= 1) {
