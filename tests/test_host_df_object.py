@@ -170,3 +170,17 @@ def test_patched_reference_names_accept_the_object(golden):
             with pytest.raises(Exception) as ei:
                 rs.get_emb_eri(cell, duck, C_ao_lo=np.zeros((1, len(ks), nao, nao), dtype=complex))
             assert not isinstance(ei.value, (ValueError, NotImplementedError, AttributeError, KeyError)), ei.value
+
+
+def test_resident_shard_sizes_follow_the_plan():
+    """GDFResident.bytes_needed: the blocks a kL shard reads = the plan's records of those kL (host bookkeeping, no GPU):
+    BASELINE config 4 -- 1184 blocks of 72 MB; config 5 -- 12 152 blocks of 512 MB, 1512 ... 1532 per rank of eight (§7's balance table)."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    blk4 = 416 * 104 * 104 * 16
+    assert et.GDFResident.bytes_needed((4, 4, 4), 104, 416) == 1184 * blk4
+    blk5 = 800 * 200 * 200 * 16
+    assert et.GDFResident.bytes_needed((6, 6, 6), 200, 800) == 12152 * blk5
+    shards = et.assign_workload((6, 6, 6), 8, True)
+    per_rank = [et.GDFResident.bytes_needed((6, 6, 6), 200, 800, kl) // blk5 for kl in shards]
+    assert sum(per_rank) == 12152 and per_rank == [1532, 1512, 1512, 1512, 1528, 1524, 1520, 1512]
+    assert et.GDFResident.bytes_needed((6, 6, 6), 200, 800, []) == 0
