@@ -381,7 +381,10 @@ class GDFResident(object):
     (dmk_eri_push_resident: step 1 takes the group straight from this array, nothing is copied into the block ring).
     The result is bit-identical to feeding the same blocks through the ring."""
 
-    def __init__(self, ctx, provider, kmesh, nao, naux, kL_list=None, t_reversal_symm=True, plan=None, user_of_mesh=None):
+    def __init__(self, ctx, provider, kmesh, nao, naux, kL_list=None, t_reversal_symm=True, plan=None, user_of_mesh=None,
+                 max_bytes=None):
+        """`max_bytes`: hold only the leading kL of the shard that fit (PARTIAL residency: the rest is still read from `provider`
+        on every transform -- for a host-fed tensor larger than HBM every resident block is one PCIe transfer less per iteration)."""
         self.ctx, self.provider = ctx, provider
         self.kpts = getattr(provider, "kpts", None)
         self.nao, self.naux = int(nao), int(naux)
@@ -391,12 +394,19 @@ class GDFResident(object):
             by.setdefault(int(r[0]), []).append(r)
         todo = [kL for kL in range(len(weights)) if weights[kL] > 0] if kL_list is None else \
             [int(k) for k in kL_list if weights[int(k)] > 0]
-        self.offset, n = {}, 0
-        for kL in todo:
-            self.offset[kL] = n
-            n += len(by.get(kL, []))
-        self.nblocks = n
         self.block_bytes = self.naux * self.nao * self.nao * 16
+        self.offset, n = {}, 0
+        held = []
+        for kL in todo:
+            cnt = len(by.get(kL, []))
+            if max_bytes is not None and (n + cnt) * self.block_bytes > max_bytes:
+                continue                                   # does not fit any more: this kL stays with the source
+            self.offset[kL] = n
+            held.append(kL)
+            n += cnt
+        self.shard_kL, self.nblocks_shard = list(todo), sum(len(by.get(kL, [])) for kL in todo)
+        todo = held
+        self.nblocks = n
         self.buf = ctx.empty((max(n, 1), self.naux, self.nao, self.nao), np.complex128)
         for kL in todo:
             recs = by.get(kL, [])
@@ -419,6 +429,9 @@ class GDFResident(object):
         keep = None if kL_list is None else set(int(k) for k in kL_list)
         nb = sum(1 for r in records if weights[int(r[0])] > 0 and (keep is None or int(r[0]) in keep))
         return nb * int(naux) * int(nao) * int(nao) * 16
+
+    def has_kL(self, kL):
+        return int(kL) in self.offset
 
     def group_ptr(self, kL, first):
         """Device address of record `first` of kL (the records of a kL are consecutive)."""
@@ -961,6 +974,8 @@ class EriEngine(object):
         else:
             ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
         nblk = 0
+        if hasattr(provider, "group_ptr") and not provider.has_kL(kL):
+            provider = provider.provider                     # partial residency: this kL is read from the source like before
         host_feed = hasattr(provider, "load_block_host")
         if host_feed and self.host_buf is None:
             from libdmet_preview_amd._lib import PinnedArray
@@ -1211,7 +1226,7 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
 
 
 def make_df_resident(cell, mydf, feri=None, kpts=None, kscaled_center=None, t_reversal_symm=True, kconserv_tol=KPT_DIFF_TOL,
-                     kL_list=None, max_fraction_of_free=0.6):
+                     kL_list=None, max_fraction_of_free=0.6, partial=False):
     """Load the AO DF blocks that get_emb_eri / get_unit_eri read from `mydf` (anything resolve_df accepts: the reference's GDF
     object, a cderi container or path, a provider) into device memory ONCE and return a provider to pass as `mydf` from then on:
 
@@ -1220,7 +1235,9 @@ def make_df_resident(cell, mydf, feri=None, kpts=None, kscaled_center=None, t_re
     Every later transform reads the blocks in place (GDFResident) instead of going back to the cderi file, which at PCIe rate costs
     2.6x the transform itself.  The blocks are the ones the pipeline's plan visits for this k list (and
     `kL_list`, a rank's share), in its order; raises MemoryError when they need more than `max_fraction_of_free` of the free
-    device memory (e.g. a 6 x 6 x 6 mesh with nao = 200: 6.2 TB)."""
+    device memory (e.g. a 6 x 6 x 6 mesh with nao = 200: 6.2 TB) -- unless `partial=True`: then the leading kL that fit are held
+    and the rest is read from the source on every transform, as before (each held block of a host-fed tensor is one PCIe
+    transfer less per DMET iteration; `res.nblocks` of `res.nblocks_shard` blocks are resident)."""
     ctx = get_ctx()
     prov = resolve_df(cell, mydf, feri, kpts)
     nao, naux = int(cell.nao_nr()), int(prov.naux)
@@ -1230,10 +1247,14 @@ def make_df_resident(cell, mydf, feri=None, kpts=None, kscaled_center=None, t_re
     nb = sum(1 for r in records if weights[int(r[0])] > 0 and (keep is None or int(r[0]) in keep))
     need = nb * naux * nao * nao * 16
     free, _ = ctx.mem_info()
+    budget = None
     if need > max_fraction_of_free * free:
-        raise MemoryError("make_df_resident: %d blocks = %.1f GB do not fit in %.0f %% of the %.1f GB of free device memory"
-                          % (nb, need / 1e9, 100 * max_fraction_of_free, free / 1e9))
-    res = GDFResident(ctx, prov, kmesh, nao, naux, kL_list, t_reversal_symm, plan=(weights, records))
+        if not partial:
+            raise MemoryError("make_df_resident: %d blocks = %.1f GB do not fit in %.0f %% of the %.1f GB of free device memory "
+                              "(partial=True keeps the kL that do fit and streams the rest)"
+                              % (nb, need / 1e9, 100 * max_fraction_of_free, free / 1e9))
+        budget = int(max_fraction_of_free * free)
+    res = GDFResident(ctx, prov, kmesh, nao, naux, kL_list, t_reversal_symm, plan=(weights, records), max_bytes=budget)
     res.cell = getattr(prov, "cell", cell)
     res._opened = prov if prov is not mydf else None      # what resolve_df opened for us: closed by res.close()
     return res

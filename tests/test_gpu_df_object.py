@@ -193,3 +193,27 @@ def test_make_df_resident_through_the_entry_points(ctx, golden, name, spin):
         res.close()
     with pytest.raises(MemoryError):
         et.make_df_resident(cell, duck, max_fraction_of_free=1e-12)
+
+
+def test_partial_residency_streams_the_rest(ctx, golden):
+    """make_df_resident(partial=True) with a budget that holds only some kL: the held ones are read in place, the others from the
+    source (here the file-backed GDF-shaped object, host-fed) -- the ERI is the one of the fully streamed transform, bit for bit."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    name, spin = "m222", 1
+    mesh, cell, kabs, cont, naux = _setup(g, name)
+    st = "%s/s%d" % (name, spin)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    duck = DuckGDF(cell, kabs, cont, blockdim=max(1, naux // 2 + 1))
+    full = et.make_df_resident(cell, duck)
+    free, _ = ctx.mem_info()
+    blk = full.block_bytes
+    part = et.make_df_resident(cell, duck, max_fraction_of_free=(0.5 * full.nblocks * blk + blk) / free, partial=True)
+    assert 0 < part.nblocks < full.nblocks == part.nblocks_shard and len(part.offset) < len(full.offset)
+    e_full = et.get_emb_eri(cell, full, C_ao_lo=C, basis=basis)
+    e_part = et.get_emb_eri(cell, part, C_ao_lo=C, basis=basis)
+    e_file = et.get_emb_eri(cell, duck, C_ao_lo=C, basis=basis)
+    ref = g[st + "/eri_tr"]
+    assert np.abs(e_part - ref).max() < TOL and np.array_equal(e_part, e_full) and np.array_equal(e_part, e_file)
+    full.close()
+    part.close()
