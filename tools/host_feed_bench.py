@@ -8,7 +8,10 @@ PCIe-inclusive rate of the ERI transform: C5-shaped AO blo
  (d) through CderiProvider.load_block_host on a cderi-layout mapping ("j3c-kptij", "j3c/<pair>/0": only pairs i >= j stored, every
      dataset served from one shared 512 MB array so that the box does not need 55 GB of host memory): the reader's single pass
      into the pinned buffer + the device-side conjugate-transpose of blocks stored for the swapped pair.
-One irreducible kL with time-reversal weight 2 (all its blocks + the contraction).  usage: python tools/host_feed_bench.py
+ (e) the same blocks made RESIDENT once (et.GDFResident over the provider of (d): loaded through the same reader, outside the timed
+     pass) and transformed in place (dmk_eri_push_resident): what every DMET iteration after the first pays for a tensor that fits.
+One irreducible kL with time-reversal weight 2 (all its blocks + the contraction).
+usage: python tools/host_feed_bench.py [C5 | C4]      (C4: 416 x 104 x 104 blocks of 72 MB, nemb 136, one spin)
 """
 import json
 import sys
@@ -22,13 +25,14 @@ def main():
     from libdmet_preview_amd._lib import get_ctx
     from libdmet_preview_amd.basis_transform import eri_transform as et
     ctx = get_ctx()
-    mesh, nao, naux, nemb, spin = (6, 6, 6), 200, 800, 256, 2
-    nk = 216
+    shape = sys.argv[1] if len(sys.argv) > 1 else "C5"
+    mesh, nao, naux, nemb, spin = ((6, 6, 6), 200, 800, 256, 2) if shape == "C5" else ((4, 4, 4), 104, 416, 136, 1)
+    nk = int(np.prod(mesh))
     npair = nemb * (nemb + 1) // 2
     rng = np.random.default_rng(1)
     C_dev = ctx.to_device((rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb)))
                           * nk ** -0.75 / np.sqrt(nao))
-    eri_dev = ctx.zeros((3, npair, npair), np.float64)
+    eri_dev = ctx.zeros((spin * (spin + 1) // 2, npair, npair), np.float64)
     eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
     kL = [k for k in eng.irreducible_kL() if eng.weights[k] == 2][0]
     nblk = len(eng.by_kL[kL])
@@ -71,14 +75,17 @@ def main():
     cderi = et.CderiProvider(SharedCderi(kabs), kabs, nao)
     swaps = sum(1 for r in eng.by_kL[kL] if (int(r[1]), int(r[2])) not in cderi.pair_of)
 
+    t_load = time.perf_counter()
+    resident = et.GDFResident(ctx, cderi, mesh, nao, naux, kL_list=[kL])
+    t_load = time.perf_counter() - t_load
     res = {}
     for name, prov in (("device_philox", Dev()), ("host_pinned_prefilled", HostPrefilled()), ("host_cpu_fill", HostMemcpy()),
-                       ("host_cderi_provider", cderi)):
-        if name != "device_philox" and eng.host_buf is not None:
+                       ("host_cderi_provider", cderi), ("resident_in_hbm", resident)):
+        if name not in ("device_philox", "resident_in_hbm") and eng.host_buf is not None:
             for b in eng.host_buf:
                 b.a[...] = pageable
         for rep in range(2):                       # first pass warms up (allocations, pinned buffers)
-            if name != "device_philox" and eng.host_buf is None:
+            if name not in ("device_philox", "resident_in_hbm") and eng.host_buf is None:
                 eng.run_kL(kL, prov, max_blocks=2)
                 for b in eng.host_buf:
                     b.a[...] = pageable
@@ -92,10 +99,13 @@ def main():
         fl = (f1[0] - f0[0]) + (f1[1] - f0[1])
         res[name] = {"blocks": n, "seconds": round(dt, 4), "ms_per_block": round(1e3 * dt / n, 3),
                      "tflops": round(fl / dt / 1e12, 2),
-                     "host_GBps": None if name == "device_philox" else round(n * block_bytes / dt / 1e9, 1)}
+                     "host_GBps": None if name in ("device_philox", "resident_in_hbm") else round(n * block_bytes / dt / 1e9, 1)}
     eng.close()
     res["host_cderi_provider"]["blocks_stored_for_the_swapped_pair"] = swaps
-    print(json.dumps({"workload": "C5 blocks, one kL (w=2), %d blocks of %.0f MB" % (nblk, block_bytes / 1e6), "results": res}))
+    res["resident_in_hbm"]["one_off_load_seconds"] = round(t_load, 3)
+    res["resident_in_hbm"]["resident_GB"] = round(resident.nblocks * block_bytes / 1e9, 2)
+    res["resident_in_hbm"]["speedup_over_host_cderi_provider"] = round(res["host_cderi_provider"]["seconds"] / res["resident_in_hbm"]["seconds"], 2)
+    print(json.dumps({"workload": "%s blocks, one kL (w=2), %d blocks of %.0f MB" % (shape, nblk, block_bytes / 1e6), "results": res}))
 
 
 if __name__ == "__main__":
