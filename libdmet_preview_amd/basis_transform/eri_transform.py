@@ -408,6 +408,7 @@ class GDFResident(object):
         todo = held
         self.nblocks = n
         self.buf = ctx.empty((max(n, 1), self.naux, self.nao, self.nao), np.complex128)
+        pin = None
         for kL in todo:
             recs = by.get(kL, [])
             pairs = [((int(r[1]), int(r[2])) if user_of_mesh is None else (int(user_of_mesh[int(r[1])]), int(user_of_mesh[int(r[2])])))
@@ -419,8 +420,20 @@ class GDFResident(object):
                                             C.c_void_p(ctx.stream_ptr))
             else:
                 for b, (ui, uj) in enumerate(pairs):
-                    provider.load_block(ctx, ui, uj, ctx.wrap(base + b * self.block_bytes, (self.naux, self.nao, self.nao), np.complex128,
-                                                             keepalive=self.buf))
+                    view = ctx.wrap(base + b * self.block_bytes, (self.naux, self.nao, self.nao), np.complex128, keepalive=self.buf)
+                    if hasattr(provider, "load_block_host"):
+                        # the reader's one-pass fill of a PINNED buffer + a copy at the PCIe rate; a block stored for the swapped
+                        # pair still takes the reader's own (host-side conjugate transpose) path
+                        if pin is None:
+                            from libdmet_preview_amd._lib import PinnedArray
+                            pin = PinnedArray(ctx, (self.naux, self.nao, self.nao), np.complex128)
+                        swapped = provider.load_block_host(ui, uj, pin.a)
+                        if not (swapped is True and getattr(provider, "host_swap_on_device", False)):
+                            view.set(pin.a)
+                            continue
+                    provider.load_block(ctx, ui, uj, view)
+        if pin is not None:
+            pin.free()
         ctx.sync()
 
     @staticmethod
