@@ -1230,12 +1230,63 @@ def get_emb_eri_fast_gdf(cell, mydf, C_ao_lo=None, basis=None, feri=None, kscale
     if not t_reversal_symm and not incore:
         raise NotImplementedError
     given = mydf
+    cached = _cached_resident(cell, given, feri, kscaled_center, t_reversal_symm, kconserv_tol) if (incore and not use_mpi) else None
+    if cached is not None:                             # RESIDENT_DF: the blocks of this DF object are already in HBM
+        return _emb_eri_fast_gdf(cell, cached, C_ao_lo, basis, kscaled_center, symmetry, C_ao_eo, kconserv_tol, unit_eri,
+                                 t_reversal_symm, incore, fout, use_mpi)
     mydf = resolve_df(cell, given, feri=feri)          # a pyscf-style GDF object -> CderiProvider over its _cderi (or feri)
     try:
         return _emb_eri_fast_gdf(cell, mydf, C_ao_lo, basis, kscaled_center, symmetry, C_ao_eo, kconserv_tol, unit_eri,
                                  t_reversal_symm, incore, fout, use_mpi)
     finally:
         _release_df(mydf, given)
+
+
+# ---- the DF tensor kept in HBM across the calls of a DMET run, without a change to the caller's script -------------------------------
+# RESIDENT_DF (patch.install(resident_df=True) or DMK_DF_RESIDENT=1): the first get_emb_eri / get_unit_eri with a given DF object
+# loads the blocks its plan visits into device memory (make_df_resident, partial=True: as many kL as fit in
+# RESIDENT_DF_FRACTION of the free memory); later calls with the SAME object (and the same cderi container, time-reversal flag and
+# k-mesh centre) read them in place.  The copy lives as long as the DF object (weak reference) or until drop_resident().
+RESIDENT_DF = os.environ.get("DMK_DF_RESIDENT", "0") == "1"
+RESIDENT_DF_FRACTION = float(os.environ.get("DMK_DF_RESIDENT_FRACTION", "0.5"))
+_resident_cache = {}
+
+
+def drop_resident():
+    """Free every cached resident DF tensor."""
+    for key in list(_resident_cache):
+        _, res = _resident_cache.pop(key)
+        res.close()
+
+
+def _cached_resident(cell, given, feri, kscaled_center, t_reversal_symm, kconserv_tol):
+    if not RESIDENT_DF or hasattr(given, "group_ptr"):
+        return None
+    if _df_kind(given) is not None or not (_is_provider(given) or (hasattr(given, "_cderi") and hasattr(given, "kpts"))):
+        return None                                    # let resolve_df raise what the reference's dispatch raises
+    import weakref
+    centre = None if kscaled_center is None else tuple(float(x) for x in np.ravel(kscaled_center))
+    key = (id(given), id(getattr(given, "_cderi", None)), bool(t_reversal_symm), centre)
+    hit = _resident_cache.get(key)
+    if hit is not None and hit[0]() is given:
+        return hit[1]
+    res = make_df_resident(cell, given, feri=feri, kscaled_center=kscaled_center, t_reversal_symm=t_reversal_symm,
+                           kconserv_tol=kconserv_tol, max_fraction_of_free=RESIDENT_DF_FRACTION, partial=True)
+    if res.nblocks == 0:                               # nothing fits: not worth a wrapper
+        res.close()
+        return None
+
+    def _gone(_ref, key=key):
+        old = _resident_cache.pop(key, None)
+        if old is not None:
+            old[1].close()
+    try:
+        ref = weakref.ref(given, _gone)
+    except TypeError:                                  # an object without weak references: held until drop_resident()
+        ref = (lambda g: (lambda: g))(given)
+    _resident_cache[key] = (ref, res)
+    log.debug(0, "DF tensor resident in HBM: %d of %d blocks (%.1f GB)", res.nblocks, res.nblocks_shard, res.nblocks * res.block_bytes / 1e9)
+    return res
 
 
 def make_df_resident(cell, mydf, feri=None, kpts=None, kscaled_center=None, t_reversal_symm=True, kconserv_tol=KPT_DIFF_TOL,

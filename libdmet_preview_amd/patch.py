@@ -86,8 +86,10 @@ def binding_table():
     return out
 
 
-def install(reference_package="libdmet", replace_hf=True, strict=True):
-    """Rebind the reference's hot-path entry points to the HIP implementations; returns the undo handle."""
+def install(reference_package="libdmet", replace_hf=True, strict=True, resident_df=None):
+    """Rebind the reference's hot-path entry points to the HIP implementations; returns the undo handle.
+    `resident_df=True`: the DF tensor behind `lattice.df` is loaded into HBM by the first get_emb_eri of a run and read in place by
+    every later one (eri_transform.RESIDENT_DF; as many kL as fit, the rest streamed as before) -- no change to the DMET script."""
     from libdmet_preview_amd import _lib          # noqa: F401 -- loading libdmetk.so fails loudly here if it is missing
     undo = []
 
@@ -108,6 +110,10 @@ def install(reference_package="libdmet", replace_hf=True, strict=True):
     from libdmet_preview_amd.system import lattice as my_lat
     for name in _LATTICE_METHODS:
         bind(ref_lat.Lattice, name, getattr(my_lat.Lattice, name))
+    if resident_df is not None:
+        from libdmet_preview_amd.basis_transform import eri_transform as my_et
+        undo.append((my_et, "RESIDENT_DF", my_et.RESIDENT_DF))
+        my_et.RESIDENT_DF = bool(resident_df)
     return undo
 
 

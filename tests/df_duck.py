@@ -67,7 +67,7 @@ def fake_h5py(registry):
 
 
 @contextlib.contextmanager
-def patched_reference():
+def patched_reference(**install_kwargs):
     """Yield `libdmet.routine.slater` with libdmet_preview_amd.patch installed (real reference tree under the import shim when
     it exists, placeholder tree otherwise); everything is undone on exit."""
     from libdmet_preview_amd import patch
@@ -90,7 +90,7 @@ def patched_reference():
             setattr(sys.modules["libdmet." + ref], name, ("placeholder", ref, name))
         lat = mk("libdmet.system.lattice")
         lat.Lattice = type("Lattice", (), {n: ("placeholder", n) for n in patch._LATTICE_METHODS})
-    handle = patch.install()
+    handle = patch.install(**install_kwargs)
     try:
         yield importlib.import_module("libdmet.routine.slater")
     finally:

@@ -106,7 +106,7 @@ ALLOWED_EXTRA = {
 # fallback): VcorLocal.grad_entries is this package's sparse description of vcor.gradient() (slater.get_dV_dparam_dev).
 OPTIONAL_PROBES = {"lattice": set(), "vcor": {"grad_entries"}, "cell": set()}
 DF_PROVIDER_PROTOCOL = {"kpts", "naux", "load_block", "load_block_host", "host_swap_on_device", "nao", "cell", "blockdim", "_cderi",
-                        "max_memory"}
+                        "max_memory", "group_ptr", "load_blocks_on", "load_block_on"}        # (group_ptr: blocks resident in HBM, GDFResident)
 # ... and a GDF-shaped object (no provider methods) is only asked for what the reference's own object offers (G17 `offered/df`
 # minus the stand-in's private block table): resolve_df probes the provider protocol / `build` with hasattr() first
 DF_OBJECT_PROBES = {"load_block", "build"}

@@ -217,3 +217,37 @@ def test_partial_residency_streams_the_rest(ctx, golden):
     assert np.abs(e_part - ref).max() < TOL and np.array_equal(e_part, e_full) and np.array_equal(e_part, e_file)
     full.close()
     part.close()
+
+
+def test_resident_df_without_touching_the_script(ctx, golden, monkeypatch):
+    """patch.install(resident_df=True): the reference-named get_emb_eri called twice with the SAME GDF-shaped object loads its blocks
+    into HBM once (one GDFResident built), both calls reproduce golden G6; a different time-reversal flag is a different plan and
+    gets its own copy; the copies go away with drop_resident() and the switch is undone by uninstall()."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    name, spin = "m231", 2
+    mesh, cell, kabs, cont, naux = _setup(g, name)
+    st = "%s/s%d" % (name, spin)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    duck = DuckGDF(cell, kabs, cont, blockdim=max(1, naux // 2 + 1))
+    built = []
+    real_init = et.GDFResident.__init__
+
+    def counting_init(self, *a, **k):
+        built.append(1)
+        return real_init(self, *a, **k)
+    monkeypatch.setattr(et.GDFResident, "__init__", counting_init)
+    assert et.RESIDENT_DF is False
+    with patched_reference(resident_df=True) as rs:
+        assert et.RESIDENT_DF is True
+        e1 = rs.get_emb_eri(cell, duck, C_ao_lo=C, basis=basis)
+        e2 = rs.get_emb_eri(cell, duck, C_ao_lo=C, basis=basis)
+        assert len(built) == 1 and np.array_equal(e1, e2) and np.abs(e1 - g[st + "/eri_tr"]).max() < TOL
+        e3 = rs.get_emb_eri(cell, duck, C_ao_lo=C, basis=basis, t_reversal_symm=False)
+        assert len(built) == 2 and np.abs(e3 - g[st + "/eri_notr"]).max() < TOL
+        eu = rs.get_unit_eri(cell, duck, C_ao_lo=C)
+        assert len(built) == 2 and np.abs(eu - g[st + "/eri_unit"]).max() < TOL
+        assert len(et._resident_cache) == 2
+        et.drop_resident()
+        assert len(et._resident_cache) == 0
+    assert et.RESIDENT_DF is False and not hasattr(duck, "load_block")
