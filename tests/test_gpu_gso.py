@@ -101,6 +101,10 @@ def test_gso_eri(ctx, golden, name):
             assert np.abs(e - ref).max() < 1e-8 * max(1.0, np.abs(ref).max())
         assert np.abs(et.get_emb_eri_gso(cell, mydf, C_ao_lo=C, basis=basis, symmetry=1) - g[st + "/eri_s1"]).max() < 1e-8
         assert np.abs(et.get_emb_eri_gso(cell, mydf, C_ao_lo=C, basis=basis, unit_eri=True) - g[st + "/eri_unit"]).max() < 1e-8
+        # the same tensor resident in HBM (GDFResident): the GSO pipeline reads its groups in place, same bits
+        res = et.make_df_resident(cell, mydf)
+        assert np.array_equal(et.get_emb_eri_gso(cell, res, C_ao_lo=C, basis=basis), et.get_emb_eri_gso(cell, mydf, C_ao_lo=C, basis=basis))
+        res.close()
 
 
 @pytest.mark.parametrize("name", ["m311", "m221", "m231"])
