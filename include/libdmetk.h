@@ -443,6 +443,10 @@ int dmk_eri_to_s4(dmk_ctx *ctx, int n, int from_symmetry, const double *in, doub
  * Per-block partials are reduced in a fixed order (no atomics). */
 int dmk_dgemv2(dmk_ctx *ctx, int64_t M, int64_t N, const double *A, int64_t lda, const double *xrow, const double *xcol,
                double *yrow, double *ycol);
+/* out[b] = min(max column sum, Frobenius norm) of the full symmetric matrix A[b] (n x n): the bound on |A|_2 the eigenbasis
+ * refinement scales its tolerances with.  A line search H0 + t V1 needs it once per ray (|H0 + t V1| <= |H0| + |t| |V1|:
+ * dmk_fit_args.ray_norm) instead of once per trial step. */
+int dmk_sym_norm_bound(dmk_ctx *ctx, int n, int batch, const double *A, double *out);
 /* C[b] = alpha op(A[b]) op(B[b]) + beta C[b]; real f64, row-major with leading dimensions, op 0 = N, 1 = T.
  * The nemb x nemb algebra of errfunc / gradfunc (np.dot / mdot at slater.py:1088, 1136-1138; ftsystem.py:183-186). */
 int dmk_dgemm_batched(dmk_ctx *ctx, int opA, int opB, int M, int N, int K, int batch, double alpha, const double *A,
@@ -512,6 +516,7 @@ int dmk_small_bath(dmk_ctx *ctx, const int mesh[3], int nlo, int spin, const dou
  *   w, occ       (spin, nb) out: levels ascending, occupations
  *   fit_idx      (nidx) int32; W, target, drho (spin, nidx, nidx); work: >= 2112 doubles of device scratch owned by the caller
  *   npass        refinement passes to enqueue (a pass that finds its matrix settled costs a few microseconds)
+ *   ray_norm     see the struct
  * *status: 0 ok -- *f2 = sum of squares (errfunc = sqrt(f2 / spin)); 1 the refinement did not verify its basis within npass
  * passes: NOTHING of w / occ / drho is valid, Vp still holds the previous basis, the caller falls back to dmk_eigh_jacobi_real
  * + the separate calls above; 2 non-finite levels.  *settle_pass: the measurement pass (0-based) that settled the slower matrix. */
@@ -525,6 +530,9 @@ typedef struct {
     const double *W, *target;
     double *drho, *work;
     void *slot;
+    const double *ray_norm;     /* optional, (2, spin) device: dmk_sym_norm_bound of unpack(v0 + H1) and of unpack(v1) -- constant along
+                                 * a ray, so the refinement's bound |H| <= ray_norm[0] + |t| ray_norm[1] costs nothing per trial step
+                                 * (NULL: bounded from H itself in every call, one more launch) */
 } dmk_fit_args;
 int dmk_fit_objective(dmk_ctx *ctx, const dmk_fit_args *args, double *f2, int *status, int *settle_pass);
 

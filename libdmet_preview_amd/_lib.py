@@ -107,6 +107,7 @@ PROTOTYPES = {
     "dmk_jk_s4": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_jk_s4_rows": (c_int, [c_vp, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "dmk_sym_norm_bound": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_modified_cholesky": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_dbl, c_int, c_vp, P(c_int), P(c_int)]),
     "dmk_dgemv2": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "dmk_dgemm_batched": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_i64, c_vp, c_i64,
@@ -137,7 +138,7 @@ class FitArgs(C.Structure):
                 ("H", c_vp), ("Vp", c_vp), ("w", c_vp), ("occ", c_vp),
                 ("nelec", c_vp), ("mu0", c_vp),
                 ("fit_idx", c_vp), ("W", c_vp), ("target", c_vp),
-                ("drho", c_vp), ("work", c_vp), ("slot", c_vp)]
+                ("drho", c_vp), ("work", c_vp), ("slot", c_vp), ("ray_norm", c_vp)]
 
 for _name, (_res, _args) in PROTOTYPES.items():
     _f = getattr(lib, _name)          # AttributeError here = header / library mismatch: fail loudly

@@ -93,7 +93,14 @@ int dmk_assign_occ_zero_t_batch(dmk_ctx *ctx, int64_t n, int batch, const double
                                 const double *mu0_host, int flags, double thr_deg, double *occ, double *info_dev);
 // jacobi_eigh.hip: warm Ogita-Aishima refinement, enqueued without any host read-back (used by dmk_fit_objective)
 int dmk_eigh_refine_enqueue(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int npass,
-                            int *verdict_dev);
+                            int *verdict_dev, int norm_done = 0);
+// scratch layout of the refinement (jacobi_eigh.hip): anorm / state / arrive may be produced by the kernel that writes A
+struct RfWorkspace {
+    double *Vb[2], *T1, *S, *G, *F, *stats, *lam, *anorm, *part, *sqS, *sqG;
+    int *state;
+    unsigned *arrive;
+};
+int rf_workspace(dmk_ctx *ctx, int n, int batch, RfWorkspace *W);
 int dmk_scratch2(dmk_ctx *ctx, size_t bytes, void **out);
 
 // XCD-aware, bijective remap of a 1-D block id: blocks that the dispatcher places on the

@@ -325,8 +325,20 @@ int grid_for(long long total, int cap = 8192) { return (int)std::min<long long>(
 // ---- fused T = 0 objective of the embedding fit (dmk_fit_objective) --------------------------------------------------------
 // full[b] = unpack(v0[b] + t v1[b] + H1[b]): the ray form of the embedding potential (V_emb is linear in the parameters) and the
 // fixed one-body part in one pass -- replaces a device copy, an axpy and sym_unpack
+// ... and, on a line-search ray whose two norm bounds the caller computed once (ray_norm), the refinement's bound on |H| together
+// with its cleared state words and arrival counters: |H0 + t V1| <= |H0| + |t| |V1| -- what rf_norm_kernel measured from the
+// unpacked matrix in a launch of its own (10.6 us) in front of every trial step.
 __global__ void fit_ray_unpack_kernel(int n, int batch, const double *__restrict__ v0, const double *__restrict__ v1, double t,
-                                      const double *__restrict__ h1, double *__restrict__ full) {
+                                      const double *__restrict__ h1, double *__restrict__ full, const double *__restrict__ ray_norm,
+                                      double *__restrict__ anorm, int *__restrict__ state, unsigned *__restrict__ arrive) {
+    if (ray_norm && blockIdx.x == 0 && threadIdx.x < batch) {
+        const int m = threadIdx.x;
+        const double bound = ray_norm[m] + fabs(t) * ray_norm[batch + m];
+        anorm[m] = bound > 0.0 ? 1.015625 * bound : 1.0;          // (the safety factor of rf_norm_kernel)
+        state[m] = 0;
+        state[batch + m] = -1;
+        arrive[m] = 0;
+    }
     const long long npair = (long long)n * (n + 1) / 2, total = (long long)n * n * batch;
     for (long long e0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += (long long)gridDim.x * blockDim.x) {
         const long long b = e0 / ((long long)n * n), e = e0 % ((long long)n * n);
@@ -612,13 +624,23 @@ int dmk_fit_objective(dmk_ctx *ctx, const dmk_fit_args *a, double *f2, int *stat
     const int gx = (nidx + 15) / 16;
     if (gx * gx * spin > 2048) return dmk_fail(ctx, DMK_ERR_INVALID, "fit_objective: %d fitted indices exceed the partial-sum table", nidx);
     const unsigned long long seq = ++ctx->fit_seq;
+    // with the ray's norm bounds the unpack kernel also leaves |H|, the state words and the counters in the refinement's workspace
+    static const bool ray_norm_on = !(getenv("DMK_FIT_RAY_NORM") && atoi(getenv("DMK_FIT_RAY_NORM")) == 0);
+    const bool norm_here = ray_norm_on && a->ray_norm != nullptr && a->v1 != nullptr && spin <= 256;
+    RfWorkspace W;
+    int rc = DMK_OK;
+    if (norm_here) {
+        rc = rf_workspace(ctx, nb, spin, &W);
+        if (rc) return rc;
+    }
     {
         FamScope fs(ctx, DMK_FAM_FIT);
         hipLaunchKernelGGL(fit_ray_unpack_kernel, dim3(grid_for((long long)nb * nb * spin)), dim3(256), 0, ctx->stream, nb, spin,
-                           a->v0, a->v1, a->t, a->H1, a->H);
+                           a->v0, a->v1, a->t, a->H1, a->H, norm_here ? a->ray_norm : nullptr, norm_here ? W.anorm : nullptr,
+                           norm_here ? W.state : nullptr, norm_here ? W.arrive : nullptr);
         DMK_CHECK_LAUNCH(ctx);
     }
-    int rc = dmk_eigh_refine_enqueue(ctx, nb, spin, a->H, a->Vp, a->w, a->Vp, a->npass, verdict);
+    rc = dmk_eigh_refine_enqueue(ctx, nb, spin, a->H, a->Vp, a->w, a->Vp, a->npass, verdict, norm_here ? 1 : 0);
     if (rc) return rc;
     rc = dmk_assign_occ_zero_t_batch(ctx, nb, spin, a->w, a->nelec, a->has_mu0 ? a->mu0 : nullptr, (a->has_mu0 ? 1 : 0) | 4,
                                      a->tol_deg, a->occ, occ_info);

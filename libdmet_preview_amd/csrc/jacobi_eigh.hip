@@ -487,7 +487,7 @@ __global__ __launch_bounds__(RF_T) void rf_gemm_kernel(RfGemm g) {
 // |A|_2 bound of a FULL symmetric matrix: min(max column sum, Frobenius norm).  Thread <-> column (column sums equal row sums),
 // four row groups per column: no wave reductions in the loop, every load coalesced and independent.  Also resets the state word.
 __global__ __launch_bounds__(1024) void rf_norm_kernel(int n, const double *__restrict__ A, double *__restrict__ anorm,
-                                                        int *__restrict__ state, unsigned *__restrict__ arrive) {
+                                                        int *__restrict__ state, unsigned *__restrict__ arrive, int raw) {
     __shared__ double cs[4][256];
     __shared__ double red[2][16];
     const int mat = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -518,6 +518,7 @@ __global__ __launch_bounds__(1024) void rf_norm_kernel(int n, const double *__re
         double f = 0.0, gm = 0.0;
         for (int w = 0; w < 16; ++w) { f += red[0][w]; gm = fmax(gm, red[1][w]); }
         const double bound = fmin(sqrt(f), gm);
+        if (raw) { anorm[mat] = bound; return; }  // dmk_sym_norm_bound: the bound itself, nothing else
         anorm[mat] = bound > 0.0 ? 1.015625 * bound : 1.0;
         state[mat] = 0;
         state[gridDim.x + mat] = -1;              // settling pass: none yet
@@ -931,9 +932,8 @@ int launch_dgemm_small_nn(dmk_ctx *ctx, int M, int N, int K, int batch, const do
 // `async_verdict` (device, [2][batch] ints) selects the ASYNCHRONOUS form used by the fused fit objective (dmk_fit_objective):
 // exactly `async_passes` passes are enqueued, nothing is read back, the finish launch writes w / Vt only for verified matrices
 // and leaves (state, settling pass) in `async_verdict`; *ok is then 1 and means "enqueued", not "converged".
-static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int *ok,
-                           int *passes_out, int *async_verdict = nullptr, int async_passes = 0) {
-    *ok = 0;
+// The scratch layout of the refinement (one dmk_scratch block): also handed to the kernel of fit.hip that leaves |A| in it.
+int rf_workspace(dmk_ctx *ctx, int n, int batch, RfWorkspace *W) {
     const size_t nn = (size_t)n * n;
     const size_t b_mat = ((nn * 8 * batch) + 255) & ~(size_t)255;
     const int nt16 = (n + 15) / 16;
@@ -944,23 +944,40 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
     int rc = dmk_scratch(ctx, 6 * b_mat + b_small, &ws);
     if (rc) return rc;
     char *p = static_cast<char *>(ws);
-    double *Vb[2];
-    Vb[0] = reinterpret_cast<double *>(p); p += b_mat;
-    Vb[1] = reinterpret_cast<double *>(p); p += b_mat;
-    double *T1 = reinterpret_cast<double *>(p); p += b_mat;
-    double *S = reinterpret_cast<double *>(p); p += b_mat;
-    double *G = reinterpret_cast<double *>(p); p += b_mat;
-    double *F = reinterpret_cast<double *>(p); p += b_mat;
-    double *stats = reinterpret_cast<double *>(p); p += (size_t)batch * 8 * RF_STAT * 8;
-    double *lam = reinterpret_cast<double *>(p); p += (size_t)batch * n * 8;
-    double *anorm = reinterpret_cast<double *>(p); p += (size_t)batch * 8;
+    W->Vb[0] = reinterpret_cast<double *>(p); p += b_mat;
+    W->Vb[1] = reinterpret_cast<double *>(p); p += b_mat;
+    W->T1 = reinterpret_cast<double *>(p); p += b_mat;
+    W->S = reinterpret_cast<double *>(p); p += b_mat;
+    W->G = reinterpret_cast<double *>(p); p += b_mat;
+    W->F = reinterpret_cast<double *>(p); p += b_mat;
+    W->stats = reinterpret_cast<double *>(p); p += (size_t)batch * 8 * RF_STAT * 8;
+    W->lam = reinterpret_cast<double *>(p); p += (size_t)batch * n * 8;
+    W->anorm = reinterpret_cast<double *>(p); p += (size_t)batch * 8;
     const int ntile16 = nt16 * nt16;
-    double *part = reinterpret_cast<double *>(p); p += (size_t)batch * std::max(RF_SPLIT, ntile16) * 32;
-    double *sqS = reinterpret_cast<double *>(p); p += (size_t)batch * nt16 * nt16 * 8;
-    double *sqG = reinterpret_cast<double *>(p); p += (size_t)batch * nt16 * nt16 * 8;
-    int *state = reinterpret_cast<int *>(p); p += (size_t)batch * 8;         // [2][batch]: verdict, settling pass
-    unsigned *arrive = reinterpret_cast<unsigned *>(p);
-    hipLaunchKernelGGL(rf_norm_kernel, dim3(batch), dim3(1024), 0, ctx->stream, n, A, anorm, state, arrive);
+    W->part = reinterpret_cast<double *>(p); p += (size_t)batch * std::max(RF_SPLIT, ntile16) * 32;
+    W->sqS = reinterpret_cast<double *>(p); p += (size_t)batch * nt16 * nt16 * 8;
+    W->sqG = reinterpret_cast<double *>(p); p += (size_t)batch * nt16 * nt16 * 8;
+    W->state = reinterpret_cast<int *>(p); p += (size_t)batch * 8;         // [2][batch]: verdict, settling pass
+    W->arrive = reinterpret_cast<unsigned *>(p);
+    return DMK_OK;
+}
+
+static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int *ok,
+                           int *passes_out, int *async_verdict = nullptr, int async_passes = 0, bool norm_done = false) {
+    *ok = 0;
+    const size_t nn = (size_t)n * n;
+    RfWorkspace W;
+    int rc = rf_workspace(ctx, n, batch, &W);
+    if (rc) return rc;
+    double *Vb[2] = {W.Vb[0], W.Vb[1]};
+    double *T1 = W.T1, *S = W.S, *G = W.G, *F = W.F, *stats = W.stats, *lam = W.lam, *anorm = W.anorm, *part = W.part, *sqS = W.sqS,
+           *sqG = W.sqG;
+    int *state = W.state;
+    unsigned *arrive = W.arrive;
+    const int nt16 = (n + 15) / 16;
+    // (norm_done: the caller has left a bound on |A|, the cleared state words and arrival counters in this workspace already --
+    // dmk_fit_objective on a line-search ray, where |H0 + t V1| <= |H0| + |t| |V1| with the two bounds computed once per ray)
+    if (!norm_done) hipLaunchKernelGGL(rf_norm_kernel, dim3(batch), dim3(1024), 0, ctx->stream, n, A, anorm, state, arrive, 0);
     const dim3 tiles((n + 15) / 16, (n + 15) / 16, 1);             // one 16 x 16 tile per workgroup, K split over its waves
     int cur = 0, pass = 0;
     auto gemm = [&](bool nn_mode, int nprob, const double *a0, const double *b0, const double *add0, double *c0, const double *a1,
@@ -1070,11 +1087,22 @@ static int eigh_refine_try(dmk_ctx *ctx, int n, int batch, const double *A, cons
 // eigh_refine_try).  verdict_dev [2][batch]: state (1 verified: w, Vt written; 0 not yet settled after `npass` passes; 2 failed)
 // and the measurement pass that settled it.
 int dmk_eigh_refine_enqueue(dmk_ctx *ctx, int n, int batch, const double *A, const double *V0, double *w, double *Vt, int npass,
-                            int *verdict_dev) {
+                            int *verdict_dev, int norm_done) {
     if (!ctx || n <= 0 || batch <= 0 || !A || !V0 || !w || !Vt || !verdict_dev) return DMK_ERR_INVALID;
     FamScope fs(ctx, DMK_FAM_EIGH);
     int ok = 0;
-    return eigh_refine_try(ctx, n, batch, A, V0, w, Vt, &ok, nullptr, verdict_dev, npass);
+    return eigh_refine_try(ctx, n, batch, A, V0, w, Vt, &ok, nullptr, verdict_dev, npass, norm_done != 0);
+}
+
+// The bound on |A|_2 the refinement uses, min(max column sum, Frobenius norm) of full symmetric matrices, WITHOUT its safety factor:
+// out[batch].  For callers that know how their matrix family moves (a line-search ray H0 + t V1) and bound it once.
+int dmk_sym_norm_bound(dmk_ctx *ctx, int n, int batch, const double *A, double *out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (n <= 0 || batch <= 0 || !A || !out) return dmk_fail(ctx, DMK_ERR_INVALID, "sym_norm_bound: bad arguments");
+    FamScope fs(ctx, DMK_FAM_EIGH);
+    hipLaunchKernelGGL(rf_norm_kernel, dim3(batch), dim3(1024), 0, ctx->stream, n, A, out, nullptr, nullptr, 1);
+    DMK_CHECK_LAUNCH(ctx);
+    return DMK_OK;
 }
 
 extern "C" {

@@ -597,6 +597,7 @@ class EmbFitDevice(object):
         a.fit_idx, a.W, a.target = self.d_fit.ptr, self.d_W.ptr, self.d_target.ptr
         a.drho, a.work, a.slot = self.d_drho.ptr, self._f_work.ptr, self._f_slot.ptr
         self._fused = a
+        self._ray_norm = None
         self._f_out = (C.c_double(), C.c_int(), C.c_int())
 
     def _forward_fused(self, d_v0, d_v1, t):
@@ -604,6 +605,11 @@ class EmbFitDevice(object):
         verify its basis (the caller then runs the chain of separate, synchronous calls)."""
         a = self._fused
         a.v0, a.v1, a.t = d_v0.ptr, (None if d_v1 is None else d_v1.ptr), float(t)
+        a.ray_norm = None
+        if d_v1 is not None and self._ray is not None and self._ray_norm is not None:
+            for slot in (0, 1):                            # the bounds belong to the ray buffers they were computed from
+                if self._ray[slot][0] is d_v0 and self._ray[slot][1] is d_v1:
+                    a.ray_norm = self._ray_norm[slot].ptr
         f2, st, sp = self._f_out
         self.ctx.check(lib.dmk_fit_objective(self.ctx.h, C.byref(a), C.byref(f2), C.byref(st), C.byref(sp)))
         self.fused_calls += 1
@@ -767,6 +773,17 @@ class EmbFitDevice(object):
             self._vemb_into(x, d_v0)
             self._ray_age = 0
         self._vemb_into(p, d_v1)
+        if self._fused is not None:
+            # the refinement's bound on |H| along this ray from TWO bounds computed once: |H0 + t V1| <= |H0| + |t| |V1|
+            # (dmk_sym_norm_bound of the unpacked matrices; it measured the bound from H in a launch of its own per trial step)
+            ctx = self.ctx
+            if self._ray_norm is None:
+                self._ray_norm = [ctx.empty((2, self.spin), np.float64), ctx.empty((2, self.spin), np.float64)]
+            d_rn = self._ray_norm[self._ray_cur]
+            ctx.check(lib.dmk_sym_unpack(ctx.h, self.nb, self.spin, d_v0.ptr, self.d_H1.ptr, self.d_H.ptr))
+            ctx.check(lib.dmk_sym_norm_bound(ctx.h, self.nb, self.spin, self.d_H.ptr, d_rn.ptr))
+            ctx.check(lib.dmk_sym_unpack(ctx.h, self.nb, self.spin, d_v1.ptr, None, self.d_H.ptr))
+            ctx.check(lib.dmk_sym_norm_bound(ctx.h, self.nb, self.spin, self.d_H.ptr, d_rn.offset(self.spin, (self.spin,)).ptr))
         self._ray_host = {"x": x, "p": p, "ts": [], "imax": int(np.argmax(np.abs(p))) if p.size else 0}
         self._ray_serial += 1
         ts = self._ray_host["ts"]
