@@ -153,7 +153,51 @@ int main(int argc, char **argv) {
         if (!f || fwrite(eri, 8, (size_t)npair * npair, f) != (size_t)npair * npair) { fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
         fclose(f);
     }
-    const int ok = ymax > 0.0 && err <= 1e-12 * (ymax > 1.0 ? ymax : 1.0) && asym <= 1e-12 * (emax > 1.0 ? emax : 1.0);
+    /* ---- the same transform with the DF blocks RESIDENT in device memory (what a DMET run does with a tensor that fits: loaded once,
+     *      every later get_emb_eri reads it in place): the shard's blocks in plan order, one dmk_eri_push_resident per group ---- */
+    int resident_same = 1;
+    if (ring_slots > 0) {
+        void *dRes = NULL, *dEri2 = NULL;
+        CHECK(dmk_malloc(ctx, (size_t)nblocks * blk_bytes, &dRes));
+        CHECK(dmk_malloc(ctx, (size_t)npair * npair * 8, &dEri2));
+        CHECK(dmk_memset(ctx, dEri2, 0, (size_t)npair * npair * 8));
+        size_t at = 0;
+        for (int kL = 0; kL < nk; ++kL) {                        /* load once */
+            if (weights[kL] <= 0) continue;
+            for (int64_t r = 0; r < nrec; ++r)
+                if (plan[5 * r] == kL) { CHECK(dmk_df_block_philox(ctx, seed, plan[5 * r + 1], plan[5 * r + 2], naux, nao, (char *)dRes + at)); at += blk_bytes; }
+        }
+        dmk_eri *h2 = NULL;
+        CHECK(dmk_eri_begin(ctx, mesh, nao, naux, nemb, spin, 1, dC, (double *)dEri2, &h2));
+        void *ring2 = NULL; int slots2 = 0;
+        CHECK(dmk_eri_block_ring(h2, &ring2, &slots2));
+        int32_t gi[16], gj[16], gs[16];
+        at = 0;
+        for (int kL = 0; kL < nk && slots2 > 0; ++kL) {
+            if (weights[kL] <= 0) continue;
+            CHECK(dmk_eri_begin_kL(h2, kL));
+            int n = 0;
+            for (int64_t r = 0; r <= nrec; ++r) {
+                const int mine = r < nrec && plan[5 * r] == kL;
+                if (mine) { gi[n] = plan[5 * r + 1]; gj[n] = plan[5 * r + 2]; gs[n] = plan[5 * r + 4]; ++n; }
+                if (n > 0 && (n == slots2 || n == 16 || r == nrec)) {
+                    CHECK(dmk_eri_push_resident(h2, (char *)dRes + at, n, gi, gj, gs));
+                    at += (size_t)n * blk_bytes;
+                    n = 0;
+                }
+            }
+            CHECK(dmk_eri_end_kL(h2, weights[kL]));
+        }
+        CHECK(dmk_eri_finish(h2));
+        double *eri2 = (double *)malloc((size_t)npair * npair * 8);
+        CHECK(dmk_memcpy_d2h(ctx, eri2, dEri2, (size_t)npair * npair * 8));
+        resident_same = slots2 > 0 && memcmp(eri, eri2, (size_t)npair * npair * 8) == 0;
+        printf("resident DF blocks (%d blocks, %.1f MB, read in place): ERI %s\n", nblocks, nblocks * (double)blk_bytes * 1e-6,
+               resident_same ? "bit-identical" : "DIFFERS");
+        free(eri2);
+        CHECK(dmk_free(ctx, dEri2)); CHECK(dmk_free(ctx, dRes));
+    }
+    const int ok = ymax > 0.0 && err <= 1e-12 * (ymax > 1.0 ? ymax : 1.0) && asym <= 1e-12 * (emax > 1.0 ? emax : 1.0) && resident_same;
     if (dBlk) CHECK(dmk_free(ctx, dBlk));
     CHECK(dmk_free(ctx, dY)); CHECK(dmk_free(ctx, dYref)); CHECK(dmk_free(ctx, dX)); CHECK(dmk_free(ctx, dEri)); CHECK(dmk_free(ctx, dC));
     CHECK(dmk_destroy(ctx));

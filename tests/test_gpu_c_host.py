@@ -50,6 +50,7 @@ def test_c_host_matches_ctypes_host_bitwise(tmp_path):
     run = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "OK" in run.stdout and "Freivalds" in run.stdout
+    assert "read in place): ERI bit-identical" in run.stdout, run.stdout        # its second pass: dmk_eri_push_resident from plain C
     npair = nemb * (nemb + 1) // 2
     eri_c = np.fromfile(fout, dtype=np.float64).reshape(npair, npair)
     # the ctypes host: same plan, same Philox blocks, same call sequence
