@@ -289,7 +289,8 @@ int dmk_eri_flush(dmk_eri *h);
  * across the DMET iterations instead of being re-read from the cderi file for every transform (eri_transform.py:358-366 reads each
  * block once per get_emb_eri call): `nblk` (<= the queue length of dmk_eri_block_ring) consecutive blocks starting at `blocks`
  * (stride naux * nao * nao c128, 16-byte aligned) are transformed as ONE group -- step 1 reads them in place, nothing is copied
- * into the ring.  ki / kj / symmetrise: per block, as for dmk_eri_push_ring_slot.  Blocks queued before the call are flushed. */
+ * into the ring.  ki / kj / symmetrise: per block, as for dmk_eri_push_ring_slot.  Blocks queued before the call are flushed; a
+ * ring slot handed out by dmk_eri_ring_slot and not pushed yet makes the call fail with DMK_ERR_STATE (push it first). */
 int dmk_eri_push_resident(dmk_eri *h, const void *blocks, int nblk, const int32_t *ki, const int32_t *kj, const int32_t *symmetrise);
 /* The same for an AO block in HOST memory (what sr_loop / _load3c hand over, eri_transform.py:195-227, 358-366): the
  * block is copied to one of two device staging blocks (`slot` 0 | 1) on a separate copy stream and transformed on the

@@ -338,6 +338,8 @@ def convert_eri_to_gdf(eri, norb, fname=None, tol=1e-8):
     ctx = get_ctx()
     norb = int(norb)
     eri = np.asarray(eri)
+    if not np.isfinite(eri).all():
+        raise ValueError("convert_eri_to_gdf: the ERI contains NaN / Inf")
     eri_format, spin_dim = integral.get_eri_format(eri, norb)
     if spin_dim == 1:
         eri = eri[0]
@@ -396,6 +398,8 @@ class GDFResident(object):
             [int(k) for k in kL_list if weights[int(k)] > 0]
         self.block_bytes = self.naux * self.nao * self.nao * 16
         self.offset, n = {}, 0
+        self.pairs = {}                                    # kL -> the (ki, kj) of its stored blocks, in stored order (source's k indices)
+        self.plan_key = (tuple(int(m) for m in kmesh), bool(t_reversal_symm))
         held = []
         for kL in todo:
             cnt = len(by.get(kL, []))
@@ -414,6 +418,7 @@ class GDFResident(object):
             pairs = [((int(r[1]), int(r[2])) if user_of_mesh is None else (int(user_of_mesh[int(r[1])]), int(user_of_mesh[int(r[2])])))
                      for r in recs]
             base = self.buf.address + self.offset[kL] * self.block_bytes
+            self.pairs[kL] = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
             if hasattr(provider, "load_blocks_on"):
                 for c0 in range(0, len(pairs), 16):
                     provider.load_blocks_on(ctx, pairs[c0:c0 + 16], C.c_void_p(base + c0 * self.block_bytes), self.block_bytes,
@@ -445,6 +450,14 @@ class GDFResident(object):
 
     def has_kL(self, kL):
         return int(kL) in self.offset
+
+    def matches(self, kL, pairs):
+        """True when the blocks stored for kL are exactly `pairs` ((n, 2) source k indices in visiting order): the engine's plan
+        (mesh, time reversal, centre, k order) is the one these blocks were laid out under.  group_ptr is a bare offset into that
+        layout, so a transform with another plan must not use it (it would read other (ki, kj) blocks, or past the kL region)."""
+        have = self.pairs.get(int(kL))
+        pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        return have is not None and have.shape == pairs.shape and bool(np.array_equal(have, pairs))
 
     def group_ptr(self, kL, first):
         """Device address of record `first` of kL (the records of a kL are consecutive)."""
@@ -987,8 +1000,18 @@ class EriEngine(object):
         else:
             ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))
         nblk = 0
-        if hasattr(provider, "group_ptr") and not provider.has_kL(kL):
-            provider = provider.provider                     # partial residency: this kL is read from the source like before
+        if hasattr(provider, "group_ptr"):
+            want = [((int(r[1]), int(r[2])) if user_of_mesh is None else (int(user_of_mesh[int(r[1])]), int(user_of_mesh[int(r[2])])))
+                    for r in self.by_kL[kL]]
+            if not provider.has_kL(kL):
+                provider = provider.provider                 # partial residency: this kL is read from the source like before
+            elif not provider.matches(kL, want):
+                # blocks laid out under ANOTHER plan (time reversal, centre, k order): group_ptr would address the wrong blocks
+                if not getattr(provider, "_warned_plan", False):
+                    log.warn("GDFResident: the transform's visiting plan differs from the one the resident blocks were stored "
+                             "under (kL %d); reading the DF blocks from the source instead", int(kL))
+                    provider._warned_plan = True
+                provider = provider.provider
         host_feed = hasattr(provider, "load_block_host")
         if host_feed and self.host_buf is None:
             from libdmet_preview_amd._lib import PinnedArray

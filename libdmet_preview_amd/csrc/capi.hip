@@ -754,6 +754,7 @@ struct dmk_eri {
     int fill_half = 0;          // half of the pending group
     int next_half = 0;          // half the next group of a ring_slot producer will fill
     bool gen_pending = false;   // the pending group was (partly) filled on the producer stream
+    int slot_reserved = -1;     // ring slot handed out by dmk_eri_ring_slot and not pushed yet (-1: none)
     int cur_kL = -1;
     double flops_half = 0.0, flops_contract = 0.0;
     // plane STACK (dmk_eri_stack): nslots > 1 defers the contraction -- the planes of up to nslots kL stay resident, weight-2 kL
@@ -899,6 +900,7 @@ static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
     if (h->sub_planes) DMK_HIP(ctx, hipMemsetAsync(h->sub_planes, 0, bytes * h->spin * (h->nsub_max - 1), ctx->stream));
     h->sub_used = 1;
     h->cur_kL = kL;
+    h->slot_reserved = -1;
     return DMK_OK;
 }
 
@@ -1474,6 +1476,7 @@ int dmk_eri_ring_slot(dmk_eri *h, int slot, void **ptr_out, void **stream_out) {
     if (slot != h->pending || slot >= h->group)
         return dmk_fail(ctx, DMK_ERR_INVALID, "eri_ring_slot: slots are filled in order (next is %d, asked for %d)", h->pending, slot);
     const size_t blk = (size_t)h->naux * h->nao * h->nao;
+    h->slot_reserved = slot;
     if (h->ring_halves < 2) {                          // single buffer: the producer shares the compute stream
         *ptr_out = h->ring + (size_t)slot * blk;
         *stream_out = reinterpret_cast<void *>(ctx->stream);
@@ -1500,6 +1503,7 @@ int dmk_eri_push_ring_slot(dmk_eri *h, int ki, int kj, int symmetrise) {
     if (h->ring_pending != h->pending)
         return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_ring_slot: ring slots and directly pushed blocks cannot share a group");
     const int slot = h->pending;
+    h->slot_reserved = -1;
     h->pend_ki[slot] = ki;
     h->pend_kj[slot] = kj;
     h->pend_sym[slot] = symmetrise ? 1 : 0;
@@ -1520,6 +1524,9 @@ int dmk_eri_push_resident(dmk_eri *h, const void *blocks, int nblk, const int32_
     if (!blocks || !ki || !kj || !symmetrise || nblk < 1 || nblk > h->group)
         return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_resident: bad arguments (1 <= nblk <= %d queue slots)", h->group);
     if ((reinterpret_cast<uintptr_t>(blocks) & 15) != 0) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_push_resident: blocks must be 16-byte aligned");
+    if (h->slot_reserved >= 0)                          // the resident launch resets the ring's producer state: the reservation would be lost
+        return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_resident: ring slot %d was handed out (dmk_eri_ring_slot) and not pushed yet",
+                        h->slot_reserved);
     if (h->pending != 0) {                              // a resident group is a launch of its own
         int rcf = eri_flush(h);
         if (rcf) return rcf;

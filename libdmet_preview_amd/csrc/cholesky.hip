@@ -32,12 +32,21 @@ struct CholArgs {
     int *out;                                  // [0] number of vectors, [1] 1 = the loop ran out of cycles (reference: a warning)
 };
 
+// np.argmax order: a NaN is the maximum (the FIRST NaN wins), otherwise the first largest value.  An all-zero or non-positive pair
+// diagonal makes the first vector 0 / 0 = NaN; with a plain `>` no candidate would ever be taken and the pivot would stay at its
+// out-of-range start value -- the reference returns NaN vectors with a warning there, and so does this kernel.
+__device__ __forceinline__ bool argmax_takes(double ov, int oi, double v, int idx) {
+    if (ov != ov) return !(v != v) || oi < idx;
+    if (v != v) return false;
+    return ov > v || (ov == v && oi < idx);
+}
+
 // (value, index) of the first maximum over the workgroup; every thread receives it
 __device__ void block_argmax(double &v, int &idx, double *shv, int *shi) {
     for (int o = 32; o > 0; o >>= 1) {
         const double ov = __shfl_xor(v, o, 64);
         const int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        if (argmax_takes(ov, oi, v, idx)) { v = ov; idx = oi; }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
@@ -45,7 +54,7 @@ __device__ void block_argmax(double &v, int &idx, double *shv, int *shi) {
     __syncthreads();
     v = shv[0]; idx = shi[0];
     for (int w = 1; w < CH_NT / 64; ++w)
-        if (shv[w] > v || (shv[w] == v && shi[w] < idx)) { v = shv[w]; idx = shi[w]; }
+        if (argmax_takes(shv[w], shi[w], v, idx)) { v = shv[w]; idx = shi[w]; }
 }
 
 __global__ __launch_bounds__(CH_NT) void modified_cholesky_kernel(const CholArgs g) {
@@ -70,8 +79,9 @@ __global__ __launch_bounds__(CH_NT) void modified_cholesky_kernel(const CholArgs
     double best = -INFINITY;
     int idx = 0x7fffffff;
     for (int t = tid; t < N; t += CH_NT)
-        if (diag[t] > best) { best = diag[t]; idx = t; }                       // (ascending t per thread: the first maximum)
+        if (argmax_takes(diag[t], t, best, idx)) { best = diag[t]; idx = t; }  // (ascending t per thread: the first maximum)
     block_argmax(best, idx, shv, shi);
+    idx = min(idx, N - 1);
     double delta_max = best;
     {
         const double sq = __dsqrt_rn(delta_max);
@@ -90,9 +100,10 @@ __global__ __launch_bounds__(CH_NT) void modified_cholesky_kernel(const CholArgs
             const double a = __dadd_rn(approx[t], __dmul_rn(v, v));
             approx[t] = a;
             const double d = fabs(__dsub_rn(diag[t], a));
-            if (d > best) { best = d; idx = t; }
+            if (argmax_takes(d, t, best, idx)) { best = d; idx = t; }
         }
         block_argmax(best, idx, shv, shi);
+        idx = min(idx, N - 1);
         delta_max = best;
         // R = sum_j v_j[idx] * v_j (j ascending), then the new vector; the coefficients v_j[idx] in chunks through LDS
         const int ipart = (g.uhf && idx >= n) ? 1 : 0, icol = ipart ? idx - n : idx;

@@ -397,6 +397,10 @@ def _hf_small(ctx, kmesh, Fock, vcor, spin, nkpts, n, nelec, beta, mu0, fix_mu, 
         return None
     if int(np.prod(kmesh)) != nkpts:
         return None
+    if beta < np.inf and fix_mu and mu0 is None:
+        # mu is FIXED at the frontier mid-point of the levels (mfd.py:326-332, 900-901): that default needs the sorted levels
+        # before the occupations, i.e. the general chain below
+        return None
     Fock_v, v = _fock_plus_vcor(Fock, vcor, spin)
     d_F = ctx.to_device(np.ascontiguousarray(Fock_v).reshape(spin * nkpts, n, n), np.complex128)
     d_add = ctx.to_device(v) if v is not None else None

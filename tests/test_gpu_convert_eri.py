@@ -77,3 +77,27 @@ def test_convert_to_file_needs_h5py():
         pass
     with pytest.raises(ImportError):
         et.convert_eri_to_gdf(np.eye(3), 2, fname="never_written.h5")
+
+
+def test_convert_degenerate_inputs_do_not_fault():
+    """A non-interacting (all-zero) ERI: the first vector is 0 / 0, every later residual is NaN and np.argmax takes the FIRST NaN
+    as the pivot -- the reference returns NaN vectors after its cycle limit with a warning (utils/cholesky.py:21-52).  The device
+    loop follows the same pivot rule (a plain `>` would leave the pivot out of range: a page fault); a zero ROW inside a regular
+    ERI (an orbital that carries no charge) is an ordinary input.  Non-finite input is refused on the host."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    norb = 3
+    npair = norb * (norb + 1) // 2
+    out = et.convert_eri_to_gdf(np.zeros((npair, npair)), norb, tol=1e-8)
+    c = out["j3c"]["0"]["0"]
+    assert c.shape == (2 * npair + 2, norb, norb) and np.isnan(c).all()
+    rng = np.random.default_rng(5)
+    L = rng.standard_normal((4, npair))
+    L[:, 2] = 0.0
+    eri = L.T @ L
+    got = et.convert_eri_to_gdf(eri, norb, tol=1e-9)["j3c"]["0"]["0"]
+    ref = Cd.convert_eri_to_gdf(eri, norb, tol=1e-9)["j3c"]["0"]["0"]
+    assert got.shape == ref.shape and np.abs(got[:-1] - ref[:-1]).max() < 1e-8
+    bad = eri.copy()
+    bad[1, 1] = np.nan
+    with pytest.raises(ValueError):
+        et.convert_eri_to_gdf(bad, norb)

@@ -195,6 +195,30 @@ def test_make_df_resident_through_the_entry_points(ctx, golden, name, spin):
         et.make_df_resident(cell, duck, max_fraction_of_free=1e-12)
 
 
+@pytest.mark.parametrize("name,spin", [("m231", 2), ("m222", 1)])
+def test_resident_blocks_of_another_plan_are_not_read_in_place(ctx, golden, name, spin):
+    """A GDFResident laid out under one plan (time reversal on) handed to a transform with ANOTHER plan (time reversal off: about
+    twice the records per kL) and the other way round: group_ptr is a bare offset into the stored order, so the engine compares its
+    (ki, kj) list per kL with the stored one (GDFResident.matches) and reads the source instead -- the ERI is still golden G6."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    g = golden("G6_eri.npz")
+    mesh, cell, kabs, cont, naux = _setup(g, name)
+    st = "%s/s%d" % (name, spin)
+    C, basis = g[st + "/C_ao_lo"], g[st + "/basis"]
+    duck = DuckGDF(cell, kabs, cont, blockdim=max(1, naux // 2 + 1))
+    for tr_stored in (True, False):
+        res = et.make_df_resident(cell, duck, t_reversal_symm=tr_stored)
+        for tr in (not tr_stored, tr_stored):
+            e = et.get_emb_eri(cell, res, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
+            ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
+            assert np.abs(e - ref).max() < TOL, (tr_stored, tr)
+        assert getattr(res, "_warned_plan", False)
+        kL = max(res.pairs, key=lambda k: len(res.pairs[k]))
+        mine = res.pairs[kL]
+        assert res.matches(kL, mine) and not res.matches(kL, mine[:-1]) and not res.matches(kL, np.roll(mine, 1, axis=0) + 1)
+        res.close()
+
+
 def test_partial_residency_streams_the_rest(ctx, golden):
     """make_df_resident(partial=True) with a budget that holds only some kL: the held ones are read in place, the others from the
     source (here the file-backed GDF-shaped object, host-fed) -- the ERI is the one of the fully streamed transform, bit for bit."""

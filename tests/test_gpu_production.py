@@ -361,6 +361,45 @@ def test_producer_stream_ring_is_bitwise_the_single_stream_result(ctx, nao, naux
         assert np.abs(a[blk][np.ix_(idx, idx)] - 2.0 * want[blk]).max() < 1e-8
 
 
+@pytest.mark.parametrize("gen_stream", ["0", "1"])
+def test_resident_push_refuses_an_outstanding_ring_slot(ctx, gen_stream):
+    """dmk_eri_push_resident while a ring slot handed out by dmk_eri_ring_slot has not been pushed: the resident launch resets the
+    ring's producer state (half, pending event), so the later dmk_eri_push_ring_slot would read the wrong half without waiting for
+    its generator -- the library returns DMK_ERR_STATE instead; pushing the slot first (or a new kL) clears the reservation."""
+    import ctypes as C
+    from libdmet_preview_amd import _lib
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, nk, nao, naux, nemb, spin = (2, 2, 1), 4, 16, 40, 256, 1
+    npair = nemb * (nemb + 1) // 2
+    rng = np.random.default_rng(3)
+    Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    os.environ["DMK_ERI_GEN_STREAM"] = gen_stream
+    try:
+        eri_dev = ctx.zeros((1, npair, npair), np.float64)
+        eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, ctx.to_device(Ce), eri_dev, True)
+    finally:
+        os.environ.pop("DMK_ERI_GEN_STREAM", None)
+    try:
+        assert eng.ring_slots > 0
+        lib = _lib.lib
+        kL = eng.irreducible_kL()[0]
+        blocks = ctx.zeros((1, naux, nao, nao), np.complex128)
+        one = np.zeros(1, dtype=np.int32)
+        args = (eng.h, C.c_void_p(blocks.address), 1, one.ctypes.data_as(C.c_void_p),
+                one.ctypes.data_as(C.c_void_p), one.ctypes.data_as(C.c_void_p))
+        ctx.check(lib.dmk_eri_begin_kL(eng.h, int(kL)))
+        ptr, stream = C.c_void_p(), C.c_void_p()
+        ctx.check(lib.dmk_eri_ring_slot(eng.h, 0, C.byref(ptr), C.byref(stream)))
+        with pytest.raises(_lib.DmkError):
+            ctx.check(lib.dmk_eri_push_resident(*args))
+        ctx.check(lib.dmk_eri_push_ring_slot(eng.h, 0, 0, 0))          # (the slot's content is whatever the ring held: only the state matters)
+        ctx.check(lib.dmk_eri_push_resident(*args))                    # flushes the pushed slot, then its own launch
+        ctx.check(lib.dmk_eri_end_kL(eng.h, int(eng.weights[kL])))
+        ctx.sync()
+    finally:
+        eng.close()
+
+
 def test_randomised_eri_campaign_short():
     """tools/eri_stress.py with a fixed seed: 30 random systems (meshes with odd axes, dimensions on and off the tile sizes, one and two
     spin channels, with and without time reversal, 4-fold and 1-fold results) through get_emb_eri against the oracle at 1e-8.  The long

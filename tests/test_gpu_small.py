@@ -81,9 +81,11 @@ def test_small_limits_fall_back(ctx):
     assert "small_step" not in got["timers"] and "diag" in got["timers"]
 
 
-@pytest.mark.parametrize("beta", [np.inf, 20.0])
-def test_hf_entry_point_takes_the_small_kernel(ctx, beta):
-    """mfd.HF on a small cell: fused kernel vs the general chain (DMK_SMALL=0), T = 0 and finite T -- rho, mu, E equal to rounding."""
+@pytest.mark.parametrize("beta,kw", [(np.inf, {}), (20.0, {}), (20.0, {"fix_mu": True}), (20.0, {"fix_mu": True, "mu0": 0.07}),
+                                     (np.inf, {"mu0": 0.07})])
+def test_hf_entry_point_takes_the_small_kernel(ctx, beta, kw):
+    """mfd.HF on a small cell: fused kernel vs the general chain (DMK_SMALL=0), T = 0 and finite T -- rho, mu, E equal to rounding;
+    fix_mu at finite T without a mu0 fixes mu at the frontier mid-point of the levels (mfd.py:326-332), not at 0."""
     from libdmet_preview_amd.routine import mfd
     from libdmet_preview_amd.system.lattice import Lattice
     from libdmet_preview_amd import synth
@@ -114,10 +116,14 @@ def test_hf_entry_point_takes_the_small_kernel(ctx, beta):
     for small in ("1", "0"):
         os.environ["DMK_SMALL"] = small
         try:
-            res[small] = mfd.HF(L, vc, 0.5, False, beta=beta, ires=True)
+            res[small] = mfd.HF(L, vc, 0.5, False, beta=beta, ires=True, **kw)
         finally:
             os.environ.pop("DMK_SMALL", None)
     a, b = res["1"], res["0"]
     assert np.abs(a[0] - b[0]).max() < 1e-12 and abs(a[1] - b[1]) < 1e-10 and abs(a[2] - b[2]) < 1e-11
     assert np.abs(a[3]["e"] - b[3]["e"]).max() < 1e-12 and np.abs(a[3]["rho_k"] - b[3]["rho_k"]).max() < 1e-12
     assert np.abs(a[3]["mo_occ"] - b[3]["mo_occ"]).max() < 1e-10
+    if kw.get("fix_mu") and "mu0" not in kw:
+        ew = np.sort(b[3]["e"], axis=None)
+        nel = ew.size // 2
+        assert abs(a[1] - 0.5 * (ew[nel - 1] + ew[nel])) < 1e-12
