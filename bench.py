@@ -768,6 +768,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "steps_requested": a.steps_requested, "warmup_requested": a.warmup_requested,
             "steps_note": steps_note, "input": input_note,
+            "df_mode": "regenerate" if df_resident_bytes == 0 else "resident", "df_resident_GB_per_gpu": round(df_resident_bytes / 1e9, 2),
             "ms_per_step": round(elapsed / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "vs_baseline_note": "null by contract: the reference publishes no number for this metric (BASELINE.md section 1); "
