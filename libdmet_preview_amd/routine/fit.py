@@ -7,6 +7,8 @@ routine/slater.py (FitVcorEmb).  Same algorithms and stopping rules as the refer
 coincide: steepest descent, Polak-Ribiere(+) conjugate gradient and BFGS, each with the bounded scalar line
 search `minimize_scalar(bounds=(0, scale))`, scale = max(|mean of the last two steps|, min_step), and the
 Nelder-Mead fallback when the bounded search lands above f(0).  Norms are max-abs (fit_helper.py:33).
+Round 6: the trust-region Newton-CG driver (fit.py:217-288 over fit_helper.py:486-668): Steihaug's truncated CG for the
+subproblem, Hessian-vector products from central differences of the gradient.  CIAH needs PySCF's solver and raises.
 """
 import numpy as np
 from scipy.optimize import minimize_scalar, fmin
@@ -194,6 +196,119 @@ def minimize_BFGS(fn, x0, MaxIter=300, fgrad=None, callback=None, ytol=1e-7, gto
     return _downhill(fn, x0, 'BFGS', MaxIter, fgrad, callback, ytol, gtol, dx_tol, **kwargs)
 
 
+def _boundary_steps(z, d, radius):
+    """The two t with |z + t d| = radius, ascending."""
+    a, b, c = np.dot(d, d), 2.0 * np.dot(z, d), np.dot(z, z) - radius ** 2
+    root = np.sqrt(b * b - 4.0 * a * c)
+    # numerically stable pair of roots (no cancellation in -b +- root)
+    aux = b + np.copysign(root, b)
+    return tuple(sorted([-aux / (2.0 * a), -2.0 * c / aux]))
+
+
+def _steihaug(g, hessp, radius, model):
+    """Truncated conjugate gradient for min_p g.p + p.B p / 2 inside |p| <= radius (Steihaug 1983; the subproblem solver the
+    reference takes from SciPy, fit_helper.py:18, 488): stops at the boundary on negative curvature or when an iterate leaves
+    the region, else when the residual drops below min(0.5, sqrt|g|) |g|.  Returns (p, hits_boundary)."""
+    gnorm = np.linalg.norm(g)
+    tol = min(0.5, np.sqrt(gnorm)) * gnorm
+    z = np.zeros_like(g)
+    if gnorm < tol:
+        return z, False
+    r, d = g, -g
+    while True:
+        Bd = hessp(d)
+        dBd = np.dot(d, Bd)
+        if dBd <= 0:
+            ta, tb = _boundary_steps(z, d, radius)
+            pa, pb = z + ta * d, z + tb * d
+            return (pa if model(pa) < model(pb) else pb), True
+        r2 = np.dot(r, r)
+        alpha = r2 / dBd
+        z_next = z + alpha * d
+        if np.linalg.norm(z_next) >= radius:
+            return z + _boundary_steps(z, d, radius)[1] * d, True
+        r_next = r + alpha * Bd
+        if np.linalg.norm(r_next) < tol:
+            return z_next, False
+        d = -r_next + (np.dot(r_next, r_next) / r2) * d
+        z, r = z_next, r_next
+
+
+def minimize_NCG(fn, x0, MaxIter=300, fgrad=None, callback=None, ytol=1e-7, gtol=1e-3, dx_tol=1e-7, **kwargs):
+    """Trust-region Newton-CG (fit.py:217-288).  Radii scale with sqrt(nx): initial 1e-5, maximal 3e-3, acceptance eta 1e-3;
+    Hessian-vector products (g(x + eps p) - g(x - eps p)) / (2 eps), eps 1e-5; without `fgrad` the gradient is numerical.
+    The loop is the textbook one (Nocedal & Wright, algorithm 4.1) with the reference's three extra exits (value below
+    ytol / 10, step below dx_tol, iteration count).  Returns (x, y, 3, max|g|)."""
+    x = np.asarray(x0, dtype=float).flatten()
+    nx = x.shape[0]
+    radius = kwargs.get("initial_trust_radius", 1e-5) * np.sqrt(nx)
+    radius_max = kwargs.get("max_trust_radius", 3e-3) * np.sqrt(nx)
+    eta, eps = kwargs.get("eta", 0.001), kwargs.get("eps", 1e-5)
+    if not (0 <= eta < 0.25):
+        raise Exception('invalid acceptance stringency')
+    if radius <= 0 or radius_max <= 0 or radius >= radius_max:
+        raise ValueError('trust radii: 0 < initial (%g) < max (%g) required' % (radius, radius_max))
+    if fgrad is None:
+        fgrad = _numeric_grad(fn, callback, eps)
+    log.debug(0, "NCG: initial_trust_radius: %.2e", radius)
+    log.debug(0, "NCG: max_trust_radius: %.2e", radius_max)
+    log.debug(0, "  Iter           Value               Grad                 Step              Radius\n"
+                 "-----------------------------------------------------------------------------------------")
+
+    def local_model(xc):
+        fc, gc = fn(xc), np.asarray(fgrad(xc), dtype=float)
+        hp = lambda p: (np.asarray(fgrad(xc + p * eps), dtype=float) - np.asarray(fgrad(xc - p * eps), dtype=float)) * (0.5 / eps)
+        return fc, gc, hp
+
+    f, g, hp = local_model(x)
+    k, flag = 0, 0
+    while np.linalg.norm(g) >= gtol:
+        quad = lambda p: f + np.dot(g, p) + 0.5 * np.dot(p, hp(p))
+        try:
+            p, on_boundary = _steihaug(g, hp, radius, quad)
+        except np.linalg.LinAlgError:
+            flag = 3
+            break
+        predicted = f - quad(p)
+        x_new = x + p
+        f_new, g_new, hp_new = local_model(x_new)
+        if predicted <= 0:
+            flag = 2
+            break
+        rho = (f - f_new) / predicted
+        if rho < 0.25:
+            radius *= 0.25
+        elif rho > 0.75 and on_boundary:
+            radius = min(1.75 * radius, radius_max)
+        x_old = x
+        if rho > eta:
+            x, f, g, hp = x_new, f_new, g_new, hp_new
+        if callback is not None:
+            callback(np.copy(x))
+        step = norm(x - x_old)
+        log.debug(0, "%4d %20.12f %20.12f %20.12f %15.3e", k, f, np.linalg.norm(g), step, radius)
+        k += 1
+        if np.linalg.norm(g) < gtol:
+            log.debug(0, "NCG: g = 0 condition reached.")
+            break
+        if f < ytol * 0.1:
+            log.debug(0, "NCG: y = 0 condition reached.")
+            break
+        if abs(step) < dx_tol:
+            log.debug(0, "NCG: dx = 0 condition reached.")
+            break
+        if k >= MaxIter:
+            flag = 1
+            break
+    if flag:
+        log.warn("Warning: %s", ("", "Maximum number of iterations has been exceeded.",
+                                 "A bad approximation caused failure to predict improvement.",
+                                 "A linalg error occurred, such as a non-psd Hessian.")[flag])
+    log.info("         Current function value: %f" % f)
+    log.info("         Iterations: %d" % k)
+    return x, f, 3, norm(g)
+
+
 def minimize(fn, x0, MaxIter=300, fgrad=None, callback=None, method='CG', ytol=1e-7, gtol=1e-3, dx_tol=1e-7, **kwargs):
     """Main wrapper for the minimisers: returns (x, y, converge_pattern, gnorm)."""
     log.info("%s used in minimizer", method)
@@ -204,8 +319,10 @@ def minimize(fn, x0, MaxIter=300, fgrad=None, callback=None, method='CG', ytol=1
         driver = minimize_BFGS
     elif method == 'sd':
         driver = minimize_SD
-    elif method in ('ciah', 'trust-ncg'):
-        raise NotImplementedError("minimiser %s needs PySCF's CIAH / SciPy trust-region internals; use CG, BFGS or SD" % method)
+    elif method == 'trust-ncg':
+        driver = minimize_NCG
+    elif method == 'ciah':
+        raise NotImplementedError("minimiser ciah needs PySCF's CIAH solver (pyscf.soscf.ciah); use CG, BFGS, SD or trust-ncg")
     else:
         raise ValueError("Unknown method %s" % method)
     return driver(fn, x0, MaxIter=MaxIter, fgrad=fgrad, callback=callback, ytol=ytol, gtol=gtol, dx_tol=dx_tol, **kwargs)

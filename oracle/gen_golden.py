@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1263,6 +1263,112 @@ def gen_G20():
         out[name + "/cderi3"] = np.asarray(f3["j3c"]["0"]["0"])
     np.savez_compressed(os.path.join(GOLD, "G20_convert_eri.npz"), **out)
     print("G20 done", {k: out[k].shape for k in out if "cderi" in k})
+
+def _tr_projector(mesh, nlo, nact, spin, seed):
+    """Active-space projector columns P(k) (spin, nk, nlo, nact) with orthonormal columns and P(-k) = conj(P(k)): the k -> R
+    image is real, like a projector built from real-space active orbitals."""
+    from libdmet.system import lattice as rl
+    nk = int(np.prod(mesh))
+    rng = np.random.default_rng(seed)
+    A = 0.4 * rng.standard_normal((spin, nk, nlo, nact))
+    A[:, 0, :nact, :] += np.eye(nact)
+    Ak = synth.fold_R2k(A.reshape(spin, nk, nlo, nact), mesh)               # real R image -> P(-k) = conj(P(k))
+    P = np.empty_like(Ak)
+    for s in range(spin):
+        for k in range(nk):
+            # Loewdin orthonormalisation keeps the time-reversal relation (QR's sign convention need not)
+            w, v = np.linalg.eigh(Ak[s, k].conj().T @ Ak[s, k])
+            P[s, k] = Ak[s, k] @ (v * w ** -0.5) @ v.conj().T
+    return P
+
+
+def gen_G21():
+    """FitVcorEmb options the earlier rounds refused (routine/slater.py:969-1058, 1227-1261): idem_fit (slater_helper.py:380-421
+    get_rdm1_idem), C_act (residual projected on active orbitals), P_act (active-space projector in dV_dparam, slater.py:878-892,
+    2195-2219), return_drho_dparam (ftsystem.py:147-221), and the trust-region Newton-CG driver (routine/fit.py:217-330)."""
+    from libdmet.routine import slater, slater_helper, fit as rfit
+    from libdmet.dmet import Hubbard
+    shim.patch_scf()
+    out = {}
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    cases = [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3], 11), ("rhf_411", (4, 1, 1), 5, 1, [1, 2, 3], 12)]
+    for name, mesh, nlo, spin, val, seed in cases:
+        L, FR, basis, target = _fit_case(name, mesh, nlo, spin, val, seed)
+        nk = int(np.prod(mesh))
+        nb = basis.shape[-1]
+        if spin == 2:
+            L.ovlp_lo_k = np.asarray([L.ovlp_lo_k] * 2)
+        ncore = min(val)
+        nelec = ncore + len(val) if spin == 1 else [ncore + len(val)] * 2
+        out[name + "/mesh"], out[name + "/val"], out[name + "/Fock_R"] = np.array(mesh), np.array(val), FR
+        out[name + "/basis"], out[name + "/target"] = basis, target
+        # get_rdm1_idem on the embedding density (3-d input) and on a k-space density (4-d input)
+        for btag, beta in (("t0", np.inf), ("ft", 15.0)):
+            out["%s/idem_%s" % (name, btag)] = slater_helper.get_rdm1_idem(target, nelec, beta)
+        rng = np.random.default_rng(seed + 3)
+        x = rng.standard_normal((spin, nk, nlo, nlo)) + 1j * rng.standard_normal((spin, nk, nlo, nlo))
+        rk = 0.5 * np.eye(nlo) + 0.08 * (x + x.conj().transpose(0, 1, 3, 2))
+        nel_k = nk * nlo // 2 if spin == 1 else [nk * nlo // 2, nk * nlo // 2 - 1]
+        out[name + "/nelec_k"] = np.asarray(nel_k)
+        out[name + "/rdm1_k"] = rk
+        out[name + "/idem_k_t0"] = slater_helper.get_rdm1_idem(rk, nel_k, np.inf)
+        out[name + "/idem_k_ft"] = slater_helper.get_rdm1_idem(rk, nel_k, 9.0)
+        nact = 3
+        q = np.linalg.qr(rng.standard_normal((spin, nb, nact)))[0]
+        P_act = _tr_projector(mesh, nlo, 2, spin, seed + 5)
+        out[name + "/C_act"], out[name + "/P_act"] = q, P_act
+        runs = [("idem_t0", np.inf, dict(idem_fit=True)), ("idem_ft", 15.0, dict(idem_fit=True)),
+                ("cact_t0", np.inf, dict(C_act=q)), ("cact_ft", 15.0, dict(C_act=q)),
+                ("cact_imp_t0", np.inf, dict(C_act=q[:, :L.nimp], imp_fit=True)),
+                ("pact_t0", np.inf, dict(P_act=list(P_act))), ("pact_ft", 15.0, dict(P_act=list(P_act))),
+                ("pact_cact_ft_fixmu", 15.0, dict(P_act=list(P_act), C_act=q, fix_mu=True, mu0=0.1)),
+                ("ncg_t0", np.inf, dict(method="trust-ncg")), ("ncg_ft", 15.0, dict(method="trust-ncg"))]
+        for tag, beta, kw in runs:
+            v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            vfit, e0, e1 = slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=40 if "ncg" not in tag else 12, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](p.copy()) for p in P])
+            out[key + "/probe_grad"] = np.asarray([captured["fgrad"](p.copy()) for p in P])
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        P_full = slater.get_active_projector_full(list(P_act), L.ovlp_lo_k)
+        out[name + "/P_full"] = P_full
+        out[name + "/dV_dparam_pact"] = slater.get_dV_dparam(v, basis, L.R2k_basis(basis), L, P_act=P_full)
+        for tag, kw in (("drho_dparam", dict()), ("drho_dparam_fixmu", dict(fix_mu=True, mu0=0.1))):
+            v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+            v.update(0.05 * np.random.default_rng(9).standard_normal(v.length()))
+            out["%s/%s_param" % (name, tag)] = np.array(v.param)
+            out["%s/%s" % (name, tag)] = slater.FitVcorEmb(target, L, basis, v, 15.0, return_drho_dparam=True, **kw)
+    slater.minimize = real_minimize
+    # the trust-region Newton-CG driver on analytic objectives (host control flow), with and without an analytic gradient
+    A = np.diag(np.arange(1.0, 7.0)) + 0.3 * np.ones((6, 6))
+    b = np.arange(6.0) - 2.0
+    quad = lambda x: float(np.sqrt(0.5 * x @ A @ x - b @ x + 20.0))
+    qgrad = lambda x: (A @ x - b) / (2.0 * quad(x))
+    rosen = lambda x: float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2) + 1e-3)
+    rgrad = lambda x: np.concatenate([[0.0], 200.0 * (x[1:] - x[:-1] ** 2)]) + \
+        np.concatenate([-400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1]), [0.0]])
+    out["opt/A"], out["opt/b"] = A, b
+    for tag, fn, fg, x0, kw in [("quad_ncg", quad, qgrad, np.zeros(6), dict(method="trust-ncg")),
+                                ("quad_ncg_num", quad, None, np.zeros(6), dict(method="trust-ncg")),
+                                ("quad_ncg_wide", quad, qgrad, np.zeros(6),
+                                 dict(method="trust-ncg", initial_trust_radius=0.05, max_trust_radius=0.5)),
+                                ("rosen_ncg", rosen, rgrad, np.array([-0.5, 0.4, 0.3]),
+                                 dict(method="trust-ncg", MaxIter=40, initial_trust_radius=0.02, max_trust_radius=0.3))]:
+        mi = kw.pop("MaxIter", 60)
+        x, y, pat, gn = rfit.minimize(fn, x0.copy(), mi, fg, **kw)
+        out["opt/%s_x" % tag], out["opt/%s_res" % tag] = x, np.asarray([y, pat, gn])
+        out["opt/%s_x0" % tag] = x0
+    np.savez_compressed(os.path.join(GOLD, "G21_fit_options.npz"), **out)
+    print("G21 done", {k: out[k] for k in out if k.endswith("/err") or k.endswith("_res")})
 
 
 if __name__ == "__main__":

@@ -11,8 +11,13 @@ The optimiser driver (routine/fit.py + fit_helper.py: Polak-Ribiere CG with a bo
 control flow; it is pinned on the product side directly against iterates captured from the reference
 (tests/test_host_fit.py).
 
+Round 6: the FitVcorEmb options idem_fit (slater_helper.py:380-421 get_rdm1_idem), C_act (slater.py:1083-1088, 1112-1124),
+P_act (slater.py:878-892 with get_active_projector_full :2195-2219, transform_trans_inv_k slater_helper.py:37-50) and
+return_drho_dparam (slater.py:1227-1261 over ftsystem.get_rho_grad ftsystem.py:147-221).
+
 TEST INFRASTRUCTURE ONLY.  Pinned against the reference through tests/golden/G9_vcorfit.npz
-(oracle/gen_golden.py gen_G9: the reference's own FitVcorEmb closures captured at fixed parameter vectors).
+(oracle/gen_golden.py gen_G9: the reference's own FitVcorEmb closures captured at fixed parameter vectors) and, for the
+round-6 options, tests/golden/G21_fit_options.npz (gen_G21).
 """
 import itertools as it
 from math import sqrt
@@ -123,14 +128,38 @@ def transform_local_sparseH(basis, H, thr=1e-7):
     return res
 
 
-def get_dV_dparam(vcor, basis, compact=True):
+def get_active_projector_full(P_act, ovlp):
+    """slater.py:2195-2219: P (P^H S P) P^H per spin and k point."""
+    ovlp = np.asarray(ovlp)
+    if ovlp.ndim == 3:
+        ovlp = ovlp[None]
+    spin, nk, nlo, _ = ovlp.shape
+    assert len(P_act) == spin
+    out = np.empty((spin, nk, nlo, nlo), dtype=ovlp.dtype)
+    for s in range(spin):
+        for k in range(nk):
+            P = np.asarray(P_act[s][k])
+            out[s, k] = P @ (P.conj().T @ ovlp[s][k] @ P) @ P.conj().T
+    return out
+
+
+def get_dV_dparam(vcor, basis, compact=True, P_full=None, kmesh=None):
+    """Local branch of slater.py:851-907.  With `P_full` (spin, nk, nlo, nlo), the output of get_active_projector_full, the
+    basis is projected in k space and every parameter's (k-independent) gradient matrix goes through transform_trans_inv_k
+    (:878-892): Re (1 / nk) sum_k C(k)^H g C(k), C(k) = P_full(k) basis_k(k)."""
     spin, nk, nlo, nb = basis.shape
     g = vcor.gradient()
     tril = np.tril_indices(nb)
     out = np.empty((vcor.length(), spin, nb * (nb + 1) // 2)) if compact else np.empty((vcor.length(), spin, nb, nb))
+    if P_full is not None:
+        basis_k = np.asarray([R2k(basis[s], kmesh) for s in range(spin)])
+        C = np.einsum('skij,skjb->skib', np.asarray(P_full), basis_k)
     for s in range(spin):
         for ip in range(vcor.length()):
-            m = transform_local_sparseH(basis[s], g[ip, s])
+            if P_full is None:
+                m = transform_local_sparseH(basis[s], g[ip, s])
+            else:
+                m = (np.einsum('kia,ij,kjb->ab', C[s].conj(), g[ip, s], C[s]) / nk).real
             out[ip, s] = m[tril] if compact else m
     return out
 
@@ -183,6 +212,60 @@ def get_dw_dv(mo_energy, mo_coeff, drho, mu, beta, fix_mu=True, compact=False, f
     return dw_dv
 
 
+def get_rho_grad(mo_energy, mo_coeff, mu, beta, fix_mu=True):
+    """ftsystem.py:147-221 with compact=True: d rho_r / d v_V for tril pairs V of the potential and r of the density,
+    (npair, npair); one spin channel."""
+    norb = mo_coeff.shape[-1]
+    f = fermi_smearing_occ(mu, mo_energy, beta)
+    h = 1.0 - f
+    de = mo_energy[:, None] - mo_energy
+    zero = np.abs(de) < ZERO_TOL
+    inv = np.zeros_like(de)
+    inv[~zero] = 1.0 / de[~zero]
+    K = inv * (f - f[:, None])
+    K[zero] = (f[:, None] * h)[zero] * beta
+    C = mo_coeff
+    scr = np.einsum('lp,mp->lmp', C.conj(), C)
+    g = -np.tensordot(np.dot(scr, K), scr, axes=((-1,), (-1,))).transpose(0, 3, 1, 2)       # [l, s, m, n]
+    g = g + g.transpose(1, 0, 2, 3)
+    g[np.arange(norb), np.arange(norb)] *= 0.5
+    tl = np.tril_indices(norb)
+    g = g[tl]                                                                                   # (V, m, n)
+    if not fix_mu:
+        ff = f * h
+        fsum = ff.sum()
+        if abs(fsum) > ZERO_TOL:
+            drho_dmu = np.dot(C * ff, C.conj().T) * beta
+            mg = np.dot(np.einsum('ki,li->kli', C.conj(), C), ff) / fsum
+            mg = mg + mg.T
+            mg[np.arange(norb), np.arange(norb)] *= 0.5
+            g = g + np.einsum('k,ij->kij', mg[tl], drho_dmu)
+    return g.transpose(1, 2, 0)[tl].transpose(1, 0)
+
+
+def get_rdm1_idem(rdm1, nelec, beta):
+    """slater_helper.py:380-421: natural orbitals of every (spin[, k]) block, occupations re-assigned by assignocc on the
+    NEGATED natural occupations (descending -> ascending levels, mu0 = -0.5), density rebuilt."""
+    rdm1 = np.asarray(rdm1)
+    shape = rdm1.shape
+    spin, nlo = shape[0], shape[-1]
+    blocks = rdm1.reshape(spin, -1, nlo, nlo)
+    nblk = blocks.shape[1]
+    ew = np.empty((spin, nblk, nlo))
+    ev = np.empty((spin, nblk, nlo, nlo), dtype=rdm1.dtype)
+    for s in range(spin):
+        for k in range(nblk):
+            ew[s, k], ev[s, k] = la.eigh(blocks[s, k])
+    ew, ev = -ew[:, :, ::-1], ev[:, :, :, ::-1]
+    if rdm1.ndim == 3:
+        occ, _, _ = assignocc(ew[:, 0], nelec, beta, -0.5)
+        occ = occ[:, None]
+    else:
+        occ, _, _ = assignocc(ew, nelec, beta, -0.5)
+    out = np.einsum('skpm,skm,skqm->skpq', ev, occ, ev.conj())
+    return out.reshape(shape)
+
+
 # ---------------------------------------------------------------------------------------------
 # the fit objective and its gradients (slater.py:1040-1215)
 # ---------------------------------------------------------------------------------------------
@@ -191,7 +274,10 @@ class EmbFit(object):
     """errfunc / gradfunc of FitVcorEmb for given (rho target, fock_k, ovlp_k, basis, vcor)."""
 
     def __init__(self, rho, kmesh, basis, vcor, beta, fock_k, ovlp_k, nelec, imp_idx=None, det_idx=None,
-                 mu0=None, fix_mu=False, tol_deg=1e-3, remove_diag_grad=False):
+                 mu0=None, fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, idem_fit=False, C_act=None, P_full=None):
+        if idem_fit:
+            rho = get_rdm1_idem(rho, nelec, beta)                                   # slater.py:975-978
+        self.C_act = None if C_act is None else np.asarray(C_act)
         self.spin, self.nb = basis.shape[0], basis.shape[-1]
         spin, nb = self.spin, self.nb
         self.beta, self.nelec, self.mu0, self.fix_mu, self.tol_deg = beta, nelec, mu0, fix_mu, tol_deg
@@ -209,7 +295,7 @@ class EmbFit(object):
             fock_k = fock_k[None]
         self.embH1 = transform_h1(fock_k, basis_k)
         self.ovlp = transform_h1(ovlp_k, basis_k)
-        self.dV = get_dV_dparam(vcor, basis, compact=True)
+        self.dV = get_dV_dparam(vcor, basis, compact=True, P_full=P_full, kmesh=kmesh)
         self.tril = np.tril_indices(nb)
         self.target = np.zeros((spin, nidx, nidx))
         for s in range(spin):
@@ -243,9 +329,26 @@ class EmbFit(object):
             rho1[s][self.det_fill] = tmp[self.det_mesh]
         return ew, ev, occ, mu, rho1 - self.target
 
+    def _residual(self, drho):
+        """(what the norm is taken of, what enters the gradient): with C_act the residual is projected on the active orbitals,
+        C^T drho C, and the gradient sees C (C^T drho C) C^T (slater.py:1083-1088, 1112-1124)."""
+        if self.C_act is None:
+            return drho, drho
+        act = np.asarray([self.C_act[s].T @ drho[s] @ self.C_act[s] for s in range(self.spin)])
+        return act, np.asarray([self.C_act[s] @ act[s] @ self.C_act[s].T for s in range(self.spin)])
+
     def errfunc(self, param):
         drho = self._solve(param)[4]
-        return la.norm(drho) / sqrt(self.spin)
+        return la.norm(self._residual(drho)[0]) / sqrt(self.spin)
+
+    def drho_dparam(self, param):
+        """return_drho_dparam (slater.py:1227-1261): (spin, nparam, npair) response of the tril-packed embedding density to the
+        parameters at finite temperature."""
+        assert self.beta < np.inf
+        ew, ev, occ, mu, _ = self._solve(param)
+        mu = np.atleast_1d(mu)
+        dv = np.asarray([get_rho_grad(ew[s], ev[s], mu[s], self.beta, fix_mu=self.fix_mu) for s in range(self.spin)])
+        return np.einsum('psV,sVr->spr', self.dV, dv, optimize=True)
 
     def _finish(self, res):
         if self.remove_diag_grad:
@@ -258,7 +361,8 @@ class EmbFit(object):
         """T = 0 analytic gradient (slater.py:1096-1154)."""
         spin, nb = self.spin, self.nb
         ew, ev, occ, mu, drho = self._solve(param)
-        val = la.norm(drho)
+        act, drho = self._residual(drho)
+        val = la.norm(act)
         nocc = int(np.round(np.sum(occ) / spin))
         dw = np.empty((spin, nb * (nb + 1) // 2))
         dg = (np.arange(nb), np.arange(nb))
@@ -276,7 +380,8 @@ class EmbFit(object):
     def gradfunc_ft(self, param):
         """finite-T analytic gradient (slater.py:1156-1197)."""
         ew, ev, occ, mu, drho = self._solve(param)
-        val = la.norm(drho)
+        act, drho = self._residual(drho)
+        val = la.norm(act)
         dw_dv = get_dw_dv(ew, ev, drho, mu, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=True)
         res = self.dV.reshape(self.dV.shape[0], -1).dot(dw_dv.ravel()) / (2.0 * val * sqrt(self.spin))
         return self._finish(res)

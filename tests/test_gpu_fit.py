@@ -170,8 +170,78 @@ def test_fit_nonorthogonal_overlap_and_numeric_gradient(ctx, golden):
     v4 = Hubbard.VcorLocal(False, False, nlo, idx_range=val)
     _, e0, e1 = slater.FitVcorEmb(target, L, basis, v4, np.inf, MaxIter=3, CG_check=True)
     assert e1 <= e0
-    with pytest.raises(NotImplementedError):
-        slater.FitVcorEmb(target, L, basis, v4, np.inf, idem_fit=True)
+
+
+@pytest.mark.parametrize("name", ["uhf_231", "rhf_411"])
+def test_fit_options_vs_reference(ctx, golden, name):
+    """FitVcorEmb options of slater.py:969-1058 on the device against the reference's own closures and fits (golden G21):
+    idem_fit (get_rdm1_idem on the target), C_act (residual projected on active orbitals; the fused T = 0 objective is bypassed),
+    P_act (active-space projector inside dV_dparam, alone and together with C_act and a fixed mu), and the trust-region
+    Newton-CG driver on the device objective."""
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.dmet import Hubbard
+    from tests.test_oracle_fit import option_runs
+    g = golden("G21_fit_options.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    L = _lattice(mesh, nlo, val, Fk, spin)
+    L.ovlp_lo_k = Sk if spin == 1 else np.asarray([Sk] * 2)
+    P_act = list(g[name + "/P_act"])
+    assert np.abs(slater.get_active_projector_full(P_act, L.ovlp_lo_k) - g[name + "/P_full"]).max() < 1e-13
+    v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    dV = slater.get_dV_dparam(v, basis, None, L, P_act=g[name + "/P_full"])
+    assert np.abs(dV - g[name + "/dV_dparam_pact"]).max() < 1e-13
+    runs = [(t, b, {("P_act" if k == "P_full" else k): (P_act if k == "P_full" else x) for k, x in kw.items()})
+            for t, b, kw in option_runs(g, name, nlo - min(val))]
+    runs += [("ncg_t0", np.inf, dict(method="trust-ncg")), ("ncg_ft", 15.0, dict(method="trust-ncg"))]
+    for tag, beta, kw in runs:
+        key = "%s/%s" % (name, tag)
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        vfit, e0, e1 = slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=40 if "ncg" not in tag else 12, **kw)
+        fit = slater.FitVcorEmb.last_fit
+        if "C_act" in kw:
+            assert fit._fused is None
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-11, key
+            assert np.abs(fit.gradfunc(p) - gr).max() < 1e-8 * max(1.0, np.abs(gr).max()), key
+        pref, (r0, r1) = g[key + "/param"], g[key + "/err"]
+        assert abs(e0 - r0) < 1e-11, key
+        assert abs(e1 - r1) < 1e-7, (key, e1, r1)
+        assert np.abs(vfit.param - pref).max() < 2e-4, (key, np.abs(vfit.param - pref).max())
+        assert vfit is v and e1 <= e0
+
+
+@pytest.mark.parametrize("name", ["uhf_231", "rhf_411"])
+def test_rdm1_idem_and_drho_dparam(ctx, golden, name):
+    """slater_helper.get_rdm1_idem (embedding and k-space densities, T = 0 and smeared) and the return_drho_dparam branch of
+    FitVcorEmb (slater.py:1227-1261: the finite-T response of the embedding density to every parameter, batched nb^3 products on
+    the device instead of the npair x npair response matrix) against the reference's outputs (golden G21)."""
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.dmet import Hubbard
+    g = golden("G21_fit_options.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    for btag, beta in (("t0", np.inf), ("ft", 15.0)):
+        assert np.abs(slater.get_rdm1_idem(target, nelec, beta) - g["%s/idem_%s" % (name, btag)]).max() < 1e-12
+    nel_k = g[name + "/nelec_k"]
+    nel_k = int(nel_k) if nel_k.ndim == 0 else [int(x) for x in nel_k]
+    got = slater.get_rdm1_idem(g[name + "/rdm1_k"], nel_k, np.inf)
+    assert got.dtype == np.complex128 and np.abs(got - g[name + "/idem_k_t0"]).max() < 1e-12
+    assert np.abs(slater.get_rdm1_idem(g[name + "/rdm1_k"], nel_k, 9.0) - g[name + "/idem_k_ft"]).max() < 1e-11
+    L = _lattice(mesh, nlo, val, Fk, spin)
+    for tag, kw in (("drho_dparam", dict()), ("drho_dparam_fixmu", dict(fix_mu=True, mu0=0.1))):
+        v = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+        v.update(g["%s/%s_param" % (name, tag)])
+        got = slater.FitVcorEmb(target, L, basis, v, 15.0, return_drho_dparam=True, **kw)
+        ref = g["%s/%s" % (name, tag)]
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-10 * max(1.0, np.abs(ref).max()), tag
+        # chunking of the parameter batches does not change the numbers
+        again = slater.FitVcorEmb.last_fit.drho_dparam(v.param, chunk=3)
+        assert np.abs(again - got).max() < 1e-13
+    with pytest.raises(AssertionError):
+        slater.FitVcorEmb(target, L, basis, v, np.inf, return_drho_dparam=True)
+    # use_drho_dparam only logs the norms and fits as usual; test_grad logs and fits
+    v2 = Hubbard.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    _, e0, e1 = slater.FitVcorEmb(target, L, basis, v2, 15.0, MaxIter=2, use_drho_dparam=True, test_grad=True)
+    assert e1 <= e0
 
 
 def test_pipeline_fit_round_trip(ctx):

@@ -56,6 +56,44 @@ def test_minimize_ray_objective_reproduces_reference_iterates(golden, tag):
     assert len(made) > 0 and min(made) > 0
 
 
+NCG_RUNS = {"quad_ncg": ("quad", True, dict(), 60), "quad_ncg_num": ("quad", False, dict(), 60),
+            "quad_ncg_wide": ("quad", True, dict(initial_trust_radius=0.05, max_trust_radius=0.5), 60),
+            "rosen_ncg": ("rosen", True, dict(initial_trust_radius=0.02, max_trust_radius=0.3), 40)}
+
+
+@pytest.mark.parametrize("tag", sorted(NCG_RUNS))
+def test_trust_ncg_matches_reference_iterates(golden, tag):
+    """The trust-region Newton-CG driver (routine/fit.py:217-288 over fit_helper.py:486-668 and SciPy's Steihaug subproblem)
+    against results captured from the reference (golden G21 `opt/*`): analytic and numerical gradient, default radii (the run
+    ends on the iteration count with the radius still growing) and wide ones (converged), a non-convex objective."""
+    from libdmet_preview_amd.routine import fit
+    g = golden("G21_fit_options.npz")
+    objs = _objectives(g)
+    which, analytic, kw, mi = NCG_RUNS[tag]
+    fn, fg = objs["quad_cg" if which == "quad" else "rosen_cg"][:2]
+    x, y, pat, gn = fit.minimize(fn, g["opt/%s_x0" % tag].copy(), mi, fg if analytic else None, method="trust-ncg", **kw)
+    xr, (yr, patr, gnr) = g["opt/%s_x" % tag], g["opt/%s_res" % tag]
+    assert np.abs(x - xr).max() < 1e-9, (x, xr)
+    assert abs(y - yr) < 1e-11 and int(pat) == int(patr) == 3 and abs(gn - gnr) < 1e-8
+
+
+def test_trust_ncg_argument_checks():
+    from libdmet_preview_amd.routine import fit
+    f, g = (lambda x: float(x @ x) + 1.0), (lambda x: 2.0 * x)
+    with pytest.raises(ValueError):
+        fit.minimize(f, np.ones(3), fgrad=g, method="trust-ncg", initial_trust_radius=1.0, max_trust_radius=0.5)
+    with pytest.raises(Exception):
+        fit.minimize(f, np.ones(3), fgrad=g, method="trust-ncg", eta=0.3)
+    # a start at the minimum: no step is taken
+    x, y, pat, gn = fit.minimize(f, np.zeros(3), fgrad=g, method="trust-ncg")
+    assert np.array_equal(x, np.zeros(3)) and y == 1.0 and gn == 0.0
+    # negative curvature: the subproblem walks to the boundary and the value still decreases
+    sad = lambda x: float(x[0] ** 2 - x[1] ** 2 + 0.1 * x[1] ** 4) + 5.0
+    gsad = lambda x: np.array([2.0 * x[0], -2.0 * x[1] + 0.4 * x[1] ** 3])
+    x, y, pat, gn = fit.minimize(sad, np.array([0.3, 0.01]), 80, gsad, method="trust-ncg", initial_trust_radius=0.05, max_trust_radius=0.5)
+    assert y < sad(np.array([0.3, 0.01])) - 1.0 and abs(abs(x[1]) - np.sqrt(5.0)) < 1e-3
+
+
 def test_minimize_rejects_unknown_method():
     from libdmet_preview_amd.routine import fit
     with pytest.raises(ValueError):

@@ -142,3 +142,76 @@ def test_G14_full_lattice_gradient(golden, name):
             fd = (fit.errfunc(p + e) - fit.errfunc(p - e)) / 2e-5
             assert abs(fd - fit.gradfunc_ft(p)[1]) < 1e-6, key
         assert abs(fit.errfunc(g[key + "/param"]) - g[key + "/err"][1]) < 1e-10
+
+
+# ---- round 6: FitVcorEmb options (golden G21) ------------------------------------------------------------------------
+
+OPT_CASES = ["uhf_231", "rhf_411"]
+
+
+def option_runs(g, name, nimp):
+    q, P = g[name + "/C_act"], g[name + "/P_full"]
+    return [("idem_t0", np.inf, dict(idem_fit=True)), ("idem_ft", 15.0, dict(idem_fit=True)),
+            ("cact_t0", np.inf, dict(C_act=q)), ("cact_ft", 15.0, dict(C_act=q)),
+            ("cact_imp_t0", np.inf, dict(C_act=q[:, :nimp], imp_fit=True)),
+            ("pact_t0", np.inf, dict(P_full=P)), ("pact_ft", 15.0, dict(P_full=P)),
+            ("pact_cact_ft_fixmu", 15.0, dict(P_full=P, C_act=q, fix_mu=True, mu0=0.1))]
+
+
+@pytest.mark.parametrize("name", OPT_CASES)
+def test_G21_rdm1_idem_and_projector(golden, name):
+    g = golden("G21_fit_options.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    for btag, beta in (("t0", np.inf), ("ft", 15.0)):
+        assert np.abs(F.get_rdm1_idem(target, nelec, beta) - g["%s/idem_%s" % (name, btag)]).max() < 1e-12
+    nel_k = g[name + "/nelec_k"]
+    nel_k = int(nel_k) if nel_k.ndim == 0 else [int(x) for x in nel_k]
+    assert np.abs(F.get_rdm1_idem(g[name + "/rdm1_k"], nel_k, np.inf) - g[name + "/idem_k_t0"]).max() < 1e-12
+    assert np.abs(F.get_rdm1_idem(g[name + "/rdm1_k"], nel_k, 9.0) - g[name + "/idem_k_ft"]).max() < 1e-11
+    Sk_s = np.asarray([Sk] * spin)
+    Pf = F.get_active_projector_full(list(g[name + "/P_act"]), Sk_s)
+    assert np.abs(Pf - g[name + "/P_full"]).max() < 1e-13
+    v = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    assert np.abs(F.get_dV_dparam(v, basis, P_full=Pf, kmesh=mesh) - g[name + "/dV_dparam_pact"]).max() < 1e-13
+
+
+@pytest.mark.parametrize("name", OPT_CASES)
+def test_G21_option_objectives_and_gradients(golden, name):
+    g = golden("G21_fit_options.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    nb = basis.shape[-1]
+    v = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    for tag, beta, kw in option_runs(g, name, nlo - min(val)):
+        kw = dict(kw)
+        imp_idx, det_idx = idx_sets(kw, nlo - min(val), nb)
+        kw.pop("imp_fit", None)
+        fit = F.EmbFit(target, mesh, basis, v, beta, Fk if spin == 2 else Fk[0], Sk, nelec, imp_idx=imp_idx, det_idx=det_idx, **kw)
+        key = "%s/%s" % (name, tag)
+        grad = fit.gradfunc if beta == np.inf else fit.gradfunc_ft
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-12, key
+            assert np.abs(grad(p) - gr).max() < 1e-9 * max(1.0, np.abs(gr).max()), key
+        pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
+        assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
+
+
+@pytest.mark.parametrize("name", OPT_CASES)
+def test_G21_drho_dparam(golden, name):
+    g = golden("G21_fit_options.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    v = F.VcorLocal(spin == 1, False, nlo, idx_range=val)
+    for tag, kw in (("drho_dparam", dict()), ("drho_dparam_fixmu", dict(fix_mu=True, mu0=0.1))):
+        fit = F.EmbFit(target, mesh, basis, v, 15.0, Fk if spin == 2 else Fk[0], Sk, nelec, **kw)
+        got = fit.drho_dparam(g["%s/%s_param" % (name, tag)])
+        ref = g["%s/%s" % (name, tag)]
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-10 * max(1.0, np.abs(ref).max())
+        # and it IS the derivative of the embedding density: central differences of the restated density
+        p0 = g["%s/%s_param" % (name, tag)]
+        tl = np.tril_indices(basis.shape[-1])
+        for ip in (0, len(p0) - 1):
+            dp = np.zeros_like(p0)
+            dp[ip] = 1e-5
+            rp = fit._solve(p0 + dp)[4] + fit.target
+            rm = fit._solve(p0 - dp)[4] + fit.target
+            fd = np.asarray([((rp[s] - rm[s]) / 2e-5)[tl] for s in range(spin)])
+            assert np.abs(fd - ref[:, ip]).max() < 1e-6
