@@ -725,6 +725,11 @@ struct dmk_eri {
     int nao, naux, nemb, spin, tr;
     int64_t npair;
     const double2 *C;     // spin x nk x nao x nemb
+    // AO dimensions off the K tile of the hot kernels (8): they loop over kdim = hot_kdim(nao) against Ch, the pipeline's own copy
+    // of C with kdim rows per k point, zero beyond nao (Ch == C and kdim == nao when nao is on the tile)
+    int kdim = 0;
+    const double2 *Ch = nullptr;
+    double2 *Cpad = nullptr;
     double *eri;
     size_t ws_bytes[2] = {0, 0};   // capacities of planes / Ut (they may come from the context's cache)
     double *planes = nullptr;   // spin x (2 naux) x npair
@@ -804,6 +809,8 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         }
     }
     h->C = reinterpret_cast<const double2 *>(C_ao_emb);
+    h->Ch = h->C;
+    h->kdim = nao;
     h->eri = no_out ? nullptr : eri_out;
     h->lchunk = naux;
     if (const char *e = getenv("DMK_ERI_3M")) h->use_3m = atoi(e) != 0;
@@ -823,8 +830,12 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         h->group = std::max(1, std::min(h->group, h->hot256 ? half2_hot_maxslot() : half2_tab_maxslot()));
         if (!h->hot256) h->nsub_max = half2_tab_subgroups(ctx, naux, nao, nemb, spin, h->group, 4);      // 1 unless DMK_ERI_TAB_SUB asks
     }
+    // K padding of the hot kernels: a zero-padded copy of C (made below) and Ut rows to read past the last auxiliary row
+    const bool kpad = half1_hot_usable(naux, nao, nemb) && hot_kdim(nao) != nao;
+    if (kpad) h->kdim = hot_kdim(nao);
     const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
-    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1);
+    const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1) +
+                            (size_t)(h->kdim - nao) * nemb * sizeof(double2);
     // reuse the workspace parked in the context by the previous pipeline when it is large enough
     const size_t want[2] = {plane_bytes, ut_bytes};
     void *got[2] = {nullptr, nullptr};
@@ -853,6 +864,27 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         if (h->imag) (void)hipFree(h->imag);
         delete h;
         return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_begin: workspace allocation failed (%zu + %zu bytes)", plane_bytes, ut_bytes);
+    }
+    if (kpad) {
+        // Step 2 reads kdim - nao rows past every L of Ut against the zero rows of Ch: whatever is there must be FINITE (a queue
+        // slot that step 1 has not written yet, the tail of a parked workspace) -- the buffer is zeroed once.
+        const size_t cb = (size_t)spin * m.nk * h->kdim * nemb * sizeof(double2);
+        bool ok = dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->Cpad), cb) == hipSuccess;
+        ok = ok && hipMemsetAsync(h->Cpad, 0, cb, ctx->stream) == hipSuccess;
+        ok = ok && hipMemcpy2DAsync(h->Cpad, (size_t)h->kdim * nemb * sizeof(double2), h->C, (size_t)nao * nemb * sizeof(double2),
+                                    (size_t)nao * nemb * sizeof(double2), (size_t)spin * m.nk, hipMemcpyDeviceToDevice,
+                                    ctx->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(h->Ut, 0, ut_bytes, ctx->stream) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (h->Cpad) (void)hipFree(h->Cpad);
+            (void)hipFree(h->planes);
+            (void)hipFree(h->Ut);
+            if (h->imag) (void)hipFree(h->imag);
+            delete h;
+            return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_begin: padded copy of C_ao_emb failed (%zu bytes)", cb);
+        }
+        h->Ch = h->Cpad;
     }
     if (h->nsub_max > 1) {
         const size_t sb = (size_t)(h->nsub_max - 1) * spin * 2 * naux * h->npair * sizeof(double);
@@ -928,9 +960,9 @@ static int eri_ring_step1(dmk_eri *h) {
     const bool resident = h->resident_src != nullptr;
     const double2 *src = resident ? h->resident_src : h->ring + (size_t)h->fill_half * h->group * naux * nao * nao;
     if (!resident && h->gen_pending) DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_gen[h->fill_half], 0));      // the producers of this group
-    int rc = launch_half1_hot_multi(ctx, src, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->C, h->Ut,
-                                    (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * nao * nemb,
-                                    (long long)h->group * (long long)slot_elems);
+    int rc = launch_half1_hot_multi(ctx, src, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->Ch, h->Ut,
+                                    (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * h->kdim * nemb,
+                                    (long long)h->group * (long long)slot_elems, h->kdim);
     if (rc < 0) return rc;
     if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
     if (!resident && h->ring_halves == 2) DMK_HIP(ctx, hipEventRecord(h->ev_free[h->fill_half], ctx->stream));           // the half may be refilled
@@ -953,17 +985,18 @@ static int eri_flush(dmk_eri *h) {
     // one launch for both spin channels: C, Ut and the planes of spin 1 sit at constant offsets from those of spin 0
     const void *cj[16];
     for (int i = 0; i < h->pending; ++i)
-        cj[i] = h->C + (size_t)h->pend_kj[i] * nao * nemb;
+        cj[i] = h->Ch + (size_t)h->pend_kj[i] * h->kdim * nemb;
     int rc;
     if (h->hot256) {
         rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair,
-                              naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb,
-                              (long long)h->nslots * 2LL * naux * h->npair);
+                              naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * h->kdim * nemb,
+                              (long long)h->nslots * 2LL * naux * h->npair, h->kdim);
     } else {
         const int nsub = h->sub_planes ? half2_tab_subgroups(ctx, naux, nao, nemb, h->spin, h->pending, h->nsub_max) : 1;
         rc = launch_half2_tab(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair,
-                              naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * nao * nemb,
-                              (long long)h->nslots * 2LL * naux * h->npair, nsub, h->sub_planes, (long long)h->spin * 2LL * naux * h->npair);
+                              naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * h->kdim * nemb,
+                              (long long)h->nslots * 2LL * naux * h->npair, nsub, h->sub_planes, (long long)h->spin * 2LL * naux * h->npair,
+                              h->kdim);
         if (rc == 1) h->sub_used = std::max(h->sub_used, nsub);
     }
     if (rc < 0) return rc;
@@ -1033,8 +1066,9 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
         }
         const int slot = h->pending;
         // both spin channels in one launch (they share the AO block); per-spin generic kernels only if it declines
-        int rc_hot = launch_half1_hot(ctx, L, h->C + (size_t)ki * nao * nemb, h->Ut + (size_t)slot * slot_elems, naux, nao, nemb,
-                                      h->spin, (long long)h->mesh.nk * nao * nemb, (long long)h->group * (long long)slot_elems);
+        int rc_hot = launch_half1_hot(ctx, L, h->Ch + (size_t)ki * h->kdim * nemb, h->Ut + (size_t)slot * slot_elems, naux, nao, nemb,
+                                      h->spin, (long long)h->mesh.nk * h->kdim * nemb, (long long)h->group * (long long)slot_elems,
+                                      h->kdim);
         if (rc_hot < 0) return rc_hot;
         for (int s = 0; s < h->spin && rc_hot == 0; ++s) {
             const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
@@ -1074,7 +1108,8 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g1.seg[0].B = Ci; g1.seg[0].ldb = nemb; g1.seg[0].strideB = 0; g1.seg[0].conjB = 1;
             g1.flatten_m = 1; g1.big_tile = 1; g1.use_3m = h->use_3m;
             g1.epi = ZEPI_STORE; g1.C = h->Ut; g1.ldc = nemb; g1.strideC = (int64_t)nao * nemb;
-            int rc = launch_half1_hot(ctx, g1.seg[0].A, Ci, h->Ut, nl, nao, nemb);
+            int rc = launch_half1_hot(ctx, g1.seg[0].A, h->Ch + ((size_t)s * h->mesh.nk + ki) * h->kdim * nemb, h->Ut, nl, nao, nemb, 1, 0, 0,
+                                      h->kdim);
             if (rc < 0) return rc;
             if (rc == 0) {
                 rc = launch_zgemm(ctx, g1, DMK_FAM_ZGEMM_HALF1);
@@ -1689,6 +1724,7 @@ int dmk_eri_finish(dmk_eri *h) {
     }
     if (h->imag) (void)hipFree(h->imag);
     if (h->sub_planes) (void)hipFree(h->sub_planes);
+    if (h->Cpad) (void)hipFree(h->Cpad);
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;

@@ -294,15 +294,19 @@ int launch_philox_block_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int 
 int launch_philox_blocks_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int nblk, const int *ij, int naux, int nao, void *out,
                             long long stride_bytes);
 
-// hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used
+// hot half-transform kernels (zhot.hip): return 1 if handled, 0 if the generic kernel must be used.
+// kdim (0: nao, which must then be a multiple of the K tile) is the K loop bound hot_kdim(nao) for AO dimensions off the K tile:
+// the C operands then hold kdim rows per k point, ZERO beyond nao (stride kdim * nemb), and the Ut buffer of step 2 is the
+// pipeline's own, initialised one (its rows of the padding are read against those zeros).
+int hot_kdim(int nao);
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin = 1,
-                     long long ci_spin_stride = 0, long long ut_spin_stride = 0);
+                     long long ci_spin_stride = 0, long long ut_spin_stride = 0, int kdim = 0);
 int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_stride, int nslot, const int *ki, const void *C,
                            void *Ut, long long ut_slot_stride, int nL, int nao, int nemb, int nspin, long long ci_spin_stride,
-                           long long ut_spin_stride);
+                           long long ut_spin_stride, int kdim = 0);
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
-                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride);
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int kdim = 0);
 int half2_hot_usable(int nao, int nemb);
 int half2_hot_maxslot();
 int half1_hot_usable(int nL, int nao, int nemb);
@@ -312,7 +316,7 @@ int half1_hot_usable(int nL, int nao, int nemb);
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int nsub = 1,
-                     double *planes_sub = nullptr, long long sub_stride = 0);
+                     double *planes_sub = nullptr, long long sub_stride = 0, int kdim = 0);
 int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int nslot, int max_sub);
 int half2_tab_usable(int nao, int nemb);
 int half2_tab_maxslot();

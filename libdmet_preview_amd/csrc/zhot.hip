@@ -55,6 +55,9 @@ struct H1Args {
     double2 *Ut;           // out [nL][mrows][nemb]
     int nL, nao, nemb, nblk;   // nao = K; nblk = ceil(mrows / 16)
     int mrows;
+    // K loop bound: nao rounded up to the K tile.  B must hold kdim rows, ZERO beyond nao (the pipeline keeps a padded copy of
+    // C_ao_emb); the A rows of the padding are the clamped row nao - 1 -- finite numbers against zeros, never read past a block
+    int kdim;
     int tiles_m, tiles_n;
     unsigned nblocks;
     // both spin channels in one launch: the same A tile (AO block) against C_i of spin 0 / spin 1 into their own Ut;
@@ -86,7 +89,9 @@ struct H1Args {
 // remove one ingredient of the K loop at a time so that its share of the time can be MEASURED on the real kernel -- 1: no Ut
 // stores, 2: no LDS-DMA after the prologue (the ring keeps stale tiles), 4: no s_barrier.  Results of a LAB != 0 instantiation are
 // meaningless by construction.
-template <bool CONJB, int BM, int OCC, bool NARROW, int LAB = 0>
+// KPAD: the K loop runs over g.kdim > g.nao (an AO dimension off the K tile); only then are the A rows clamped -- the instantiation
+// for dimensions on the tile is the kernel of rounds 2 - 5, instruction for instruction (the clamp measured 2.4 % on it).
+template <bool CONJB, int BM, int OCC, bool NARROW, int LAB = 0, bool KPAD = false>
 __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
     constexpr int MI = NARROW ? BM / 64 : BM / 32;       // 16-row blocks per wave
     constexpr int NJ = NARROW ? 3 : 2;                   // 16-column blocks per wave
@@ -133,6 +138,11 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
         const int k0 = wave * 2;
         const long long kg = (long long)t * H1_BK + k0;
         const double2 *a0 = Asl + kg * mrows, *a1 = a0 + mrows, *b0 = Bsp + kg * nemb, *b1 = b0 + nemb;      // wave-uniform
+        if constexpr (KPAD) {                                // rows of the padding: the block's last row (see H1Args::kdim)
+            const int last = (int)nao - 1, k32 = t * H1_BK + k0;
+            a0 = Asl + (long long)(k32 < last ? k32 : last) * mrows;
+            a1 = Asl + (long long)(k32 + 1 < last ? k32 + 1 : last) * mrows;
+        }
         if constexpr (AH == 2) {
             glds16s_x6(voffA[0], voffA[1], voffB, voffA[0], voffA[1], voffB, a0, a0, b0, a1, a1, b1, lds_addr_of(st + k0 * BM),
                        lds_addr_of(st + k0 * BM + 64), lds_addr_of(st + H1_BK * BM + k0 * H1_BN), lds_addr_of(st + (k0 + 1) * BM),
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(HNT, OCC) void half1_kernel(const H1Args g) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cacc_zero(acc[i][j]);
 
-    const int T = g.nao / H1_BK;
+    const int T = (KPAD ? g.kdim : g.nao) / H1_BK;
     issue(0);
     if (T > 1) issue(1);
     for (int t = 0; t < T; ++t) {
@@ -220,6 +230,8 @@ struct H2Args {
     double *planes;        // [(ri * naux + L) * npair + pair]
     long long naux, npair;
     int nL, nao, nslot;
+    int kdim;              // K loop bound: nao rounded up to the K tile; Cj holds kdim rows, zero beyond nao (Ut rows of the padding
+                           // are whatever follows in the pipeline's own, initialised buffer: finite numbers against zeros)
     unsigned nblocks;
     // both spin channels in ONE launch (4 nL nspin workgroups): one ramp-up / drain per group of queued blocks instead
     // of one per spin (measured at C5: 2 x 8.19 ms -> 15.75 ms).  Cutting the last rounds of workgroups into shorter
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     const int sp = Lall >= g.nL ? 1 : 0;     // nspin <= 2
     const int L = Lall - sp * g.nL;
     const long long nemb = H2_N;
-    const int Tb = g.nao / H2_BK;            // K-tiles per AO block
+    const int Tb = g.kdim / H2_BK;           // K-tiles per AO block
     const int T = Tb * g.nslot;              // the ring runs straight through all queued blocks
     const double2 *Ubase = g.Ut + (long long)sp * g.ut_spin_stride + (long long)L * g.nao * nemb;
     double *const g_planes = g.planes + (long long)sp * g.planes_spin_stride;
@@ -499,15 +511,22 @@ bool hot_enabled() {
 int half1_hot_usable(int nL, int nao, int nemb) {
     // the per-lane part of an LDS-DMA source address is a 32-bit byte offset from the block's base (glds16s): an AO block must stay
     // below 4 GiB (C5: 512 MB); larger ones take the generic kernels
-    return hot_enabled() && (nao % H1_BK) == 0 && nao >= 2 * H1_BK && nemb >= 32 && (long long)nL * nao >= 4 * H1_BM &&
+    // (nao need not be a multiple of the K tile: the K loop runs over hot_kdim(nao) with a zero-padded B operand)
+    return hot_enabled() && nao >= 2 * H1_BK && nemb >= 32 && (long long)nL * nao >= 4 * H1_BM &&
            (long long)nL * nao * nao * 16 < (1LL << 32);
 }
 
+// K loop bound of the hot kernels for an AO dimension: the next multiple of the step-1 K tile (8; the step-2 tiles are 4)
+int hot_kdim(int nao) { return (nao + H1_BK - 1) / H1_BK * H1_BK; }
+
 // Returns 1 if the hot path handled the launch, 0 if the caller must use the generic kernel, < 0 on error.
+// kdim: K loop bound (0: K itself, which must then be a multiple of the K tile); B holds kdim rows, zero beyond K.
 static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out, int nL, int K, int mrows, int N, bool conjB,
                            int fam, int nspin = 1, long long b_spin_stride = 0, long long out_spin_stride = 0, int nslot = 1,
                            long long a_slot_stride = 0, long long out_slot_stride = 0, long long b_k_stride = 0,
-                           const int *bk = nullptr) {
+                           const int *bk = nullptr, int kdim = 0) {
+    if (kdim == 0) kdim = K;
+    if (kdim < K || (kdim % H1_BK) != 0) return 0;
     if (!half1_hot_usable(nL, K, N) || (long long)nL * mrows < 4 * H1_BM) return 0;
     if ((long long)nL * K * mrows * 16 >= (1LL << 32)) return 0;           // see half1_hot_usable
     static const int bm = [] { const char *e = getenv("DMK_ERI_H1_BM"); return (e && atoi(e) == 64) ? 64 : 128; }();
@@ -516,7 +535,7 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     a.Lpq = reinterpret_cast<const double2 *>(A);
     a.Ci = reinterpret_cast<const double2 *>(B);
     a.Ut = reinterpret_cast<double2 *>(out);
-    a.nL = nL; a.nao = K; a.nemb = N; a.mrows = mrows;
+    a.nL = nL; a.nao = K; a.nemb = N; a.mrows = mrows; a.kdim = kdim;
     a.nblk = (mrows + 15) / 16;
     a.tiles_m = (int)(((long long)nL * mrows + bm - 1) / bm);        // flat rows: no padding between the nL batches
     // output tile width: 64 columns (2 x 2 waves) or 48 (4 x 1 waves), whichever pads N less; DMK_ERI_H1_BN = 64 | 48 overrides
@@ -532,41 +551,46 @@ static int launch_flat_hot(dmk_ctx *ctx, const void *A, const void *B, void *out
     if ((unsigned long long)a.per_slot * (unsigned)nslot > 0x7fffffffull) return 0;
     a.nblocks = a.per_slot * (unsigned)nslot;
     FamScope fs(ctx, fam);
-    fs.mfma_flops(6.0 * (double)a.nblocks * bm * bn * (double)K);
+    fs.mfma_flops(6.0 * (double)a.nblocks * bm * bn * (double)kdim);
+    const bool kp = kdim != K;
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a); };
     if (bm == 128 && bn == 48) {
-        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 128, 2, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((half1_kernel<false, 128, 2, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        if (conjB) kp ? go(half1_kernel<true, 128, 2, true, 0, true>) : go(half1_kernel<true, 128, 2, true>);
+        else kp ? go(half1_kernel<false, 128, 2, true, 0, true>) : go(half1_kernel<false, 128, 2, true>);
     } else if (bm == 128) {
-        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 128, 2, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((half1_kernel<false, 128, 2, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        if (conjB) kp ? go(half1_kernel<true, 128, 2, false, 0, true>) : go(half1_kernel<true, 128, 2, false>);
+        else kp ? go(half1_kernel<false, 128, 2, false, 0, true>) : go(half1_kernel<false, 128, 2, false>);
     } else {
-        if (conjB) hipLaunchKernelGGL((half1_kernel<true, 64, 3, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((half1_kernel<false, 64, 3, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        if (conjB) kp ? go(half1_kernel<true, 64, 3, false, 0, true>) : go(half1_kernel<true, 64, 3, false>);
+        else kp ? go(half1_kernel<false, 64, 3, false, 0, true>) : go(half1_kernel<false, 64, 3, false>);
     }
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }
 
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin,
-                     long long ci_spin_stride, long long ut_spin_stride) {
+                     long long ci_spin_stride, long long ut_spin_stride, int kdim) {
     if (nspin < 1 || nspin > 2) return 0;
-    return launch_flat_hot(ctx, Lpq, Ci, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1, nspin, ci_spin_stride, ut_spin_stride);
+    return launch_flat_hot(ctx, Lpq, Ci, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1, nspin, ci_spin_stride, ut_spin_stride,
+                           1, 0, 0, 0, nullptr, kdim);
 }
 
 // Step 1 of `nslot` queued AO blocks in one launch: block s at Lpq + s * a_slot_stride, transformed with
 // C[spin][ki[s]] (C: [spin][nk][nao][nemb], spin stride ci_spin_stride) into Ut + s * ut_slot_stride (+ spin stride).
 int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_stride, int nslot, const int *ki, const void *C,
                            void *Ut, long long ut_slot_stride, int nL, int nao, int nemb, int nspin, long long ci_spin_stride,
-                           long long ut_spin_stride) {
+                           long long ut_spin_stride, int kdim) {
     if (nspin < 1 || nspin > 2) return 0;
+    if (kdim == 0) kdim = nao;
     return launch_flat_hot(ctx, Lpq, C, Ut, nL, nao, nao, nemb, true, DMK_FAM_ZGEMM_HALF1, nspin, ci_spin_stride, ut_spin_stride,
-                           nslot, a_slot_stride, ut_slot_stride, (long long)nao * nemb, ki);
+                           nslot, a_slot_stride, ut_slot_stride, (long long)kdim * nemb, ki, kdim);
 }
 
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
-                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride) {
-    if (!hot_enabled() || nemb != H2_N || (nao % H2_BK) != 0 || nao < 3 * H2_BK || nslot < 1 || nslot > H2_MAXSLOT ||
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int kdim) {
+    if (kdim == 0) kdim = nao;
+    if (!hot_enabled() || nemb != H2_N || kdim < nao || (kdim % H2_BK) != 0 || nao < 3 * H2_BK || nslot < 1 || nslot > H2_MAXSLOT ||
         nspin < 1 || nspin > 2)
         return 0;
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
@@ -580,7 +604,7 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     }
     a.slot_stride = slot_stride;
     a.planes = planes; a.naux = naux; a.npair = npair;
-    a.nL = nL; a.nao = nao; a.nslot = nslot;
+    a.nL = nL; a.nao = nao; a.nslot = nslot; a.kdim = kdim;
     a.nspin = nspin;
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.nblocks = (unsigned)(4 * nL * nspin);
@@ -590,12 +614,12 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
         // (without the 16 diagonal blocks when the whole group is symmetrised: they are folded in the epilogue)
         double blocks = 0.0;
         for (int i = 0; i < nslot; ++i) blocks += 136.0 + (sym[i] ? (a.fold_diag ? 120.0 : 136.0) : 0.0);
-        fs.mfma_flops(6.0 * blocks * 256.0 * (double)nao * (double)nL * (double)nspin);
+        fs.mfma_flops(6.0 * blocks * 256.0 * (double)kdim * (double)nL * (double)nspin);
     }
     hipLaunchKernelGGL(half2_kernel<0>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }
 
-int half2_hot_usable(int nao, int nemb) { return hot_enabled() && nemb == H2_N && (nao % H2_BK) == 0 && nao >= 3 * H2_BK; }
+int half2_hot_usable(int nao, int nemb) { return hot_enabled() && nemb == H2_N && nao >= 3 * H2_BK; }
 int half2_hot_maxslot() { return H2_MAXSLOT; }

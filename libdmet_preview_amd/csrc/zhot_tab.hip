@@ -58,6 +58,7 @@ struct H2TArgs {
     double *planes;
     long long naux, npair;
     int nL, nao, nslot, nemb;
+    int kdim;                        // K loop bound: nao rounded up to the K tile (zhot.hip H2Args::kdim)
     unsigned nblocks;
     int nspin;
     long long ut_spin_stride, cj_spin_stride, planes_spin_stride;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
     const int sp = Lall >= g.nL ? 1 : 0;
     const int L = Lall - sp * g.nL;
     const long long nemb = g.nemb;
-    const int Tb = g.nao / T_BK;
+    const int Tb = g.kdim / T_BK;
     const int slot0 = sub * g.sub_slots;                                           // this run: queue slots [slot0, slot0 + nmine)
     const int nmine = g.nslot - slot0 < g.sub_slots ? g.nslot - slot0 : g.sub_slots;
     const int T = Tb * nmine;
@@ -405,7 +406,7 @@ void build_table(int nemb, int T_MAXBLK, int T_SEG, std::vector<int> &tab, doubl
 }  // namespace
 
 int half2_tab_usable(int nao, int nemb) {
-    return tab_enabled() && nemb >= 32 && nemb <= 4096 && (nao % T_BK) == 0 && nao >= 3 * T_BK;
+    return tab_enabled() && nemb >= 32 && nemb <= 4096 && nao >= 3 * T_BK;
 }
 int half2_tab_maxslot() { return T_MAXSLOT; }
 
@@ -426,7 +427,9 @@ int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int 
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj, const int *sym,
                      double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int nsub,
-                     double *planes_sub, long long sub_stride) {
+                     double *planes_sub, long long sub_stride, int kdim) {
+    if (kdim == 0) kdim = nao;
+    if (kdim < nao || (kdim % T_BK) != 0) return 0;
     if (!half2_tab_usable(nao, nemb) || nslot < 1 || nslot > T_MAXSLOT || nspin < 1 || nspin > 2) return 0;
     if (reinterpret_cast<uintptr_t>(Ut) & 15) return 0;
     // occupancy point (see Cfg2 / Cfg3).  Measured (MI355X, executed TF of this kernel): the evenly dealt WIDE items of small
@@ -468,7 +471,7 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     }
     a.slot_stride = slot_stride;
     a.planes = planes; a.naux = naux; a.npair = npair;
-    a.nL = nL; a.nao = nao; a.nslot = nslot; a.nemb = nemb;
+    a.nL = nL; a.nao = nao; a.nslot = nslot; a.nemb = nemb; a.kdim = kdim;
     a.nspin = nspin;
     a.ut_spin_stride = ut_spin_stride; a.cj_spin_stride = cj_spin_stride; a.planes_spin_stride = planes_spin_stride;
     a.table = tb->dev; a.nitems = tb->nitems;
@@ -485,7 +488,7 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     // a symmetrised block runs a second segment -- without the folded diagonal blocks when the whole group is symmetrised
     const double seg2 = (segs - (double)nslot) * (tb->useful_blocks - (a.fold_diag ? tb->folded_blocks : 0.0));
-    fs.mfma_flops(6.0 * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)nao * (double)nL * (double)nspin);
+    fs.mfma_flops(6.0 * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)kdim * (double)nL * (double)nspin);
     if (occ == 2) hipLaunchKernelGGL((half2_tab_kernel<Cfg2, 0>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     else hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 0>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);

@@ -150,7 +150,8 @@ def test_resident_df_blocks_bit_identical_to_the_ring():
     import numpy as np
     from libdmet_preview_amd import _lib, pipeline
     ctx = _lib.get_ctx()
-    for over in (dict(mesh=(3, 2, 2), nlo=40, naux=48, nval=24, spin=2), dict(mesh=(4, 4, 1), nlo=104, naux=64, nval=32, spin=1)):
+    for over in (dict(mesh=(3, 2, 2), nlo=40, naux=48, nval=24, spin=2), dict(mesh=(4, 4, 1), nlo=104, naux=64, nval=32, spin=1),
+                 dict(mesh=(3, 2, 1), nlo=42, naux=48, nval=23, spin=2)):             # (the last: an AO dimension off the K tile)
         sysm = pipeline.SyntheticSystem.from_workload(ctx, "C4", **over)
         ref = pipeline.iteration(ctx, sysm, emb_ham=False)
         eri_ref = ref["eri"].get()

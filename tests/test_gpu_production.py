@@ -27,7 +27,7 @@ def _eri_rows(eri_dev, blk, npair, rows):
     return np.stack([eri_dev.offset((blk * npair + int(r)) * npair, (npair,)).get() for r in rows])
 
 
-def _run_and_check(ctx, mesh, nao, naux, nemb, spin, kL_list, A, seed, check_planes=True):
+def _run_and_check(ctx, mesh, nao, naux, nemb, spin, kL_list, A, seed, check_planes=True, want_ring=False):
     from libdmet_preview_amd.basis_transform import eri_transform as et
     nk = int(np.prod(mesh))
     npair = nemb * (nemb + 1) // 2
@@ -38,6 +38,8 @@ def _run_and_check(ctx, mesh, nao, naux, nemb, spin, kL_list, A, seed, check_pla
     eri_dev = ctx.zeros((nblk, npair, npair), np.float64)
     df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=seed + 1)
     eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, C_dev, eri_dev, True)
+    if want_ring:
+        assert eng.ring_slots > 0, "the grouped hot path declined this shape"
     ref_eri, idx, ref_planes = ES.eri_sample(mesh, seed + 1, Ce, naux, A, kL_list)
     # Freivalds probe: the contraction is checked on ALL pair rows and columns, not only on the sampled ones
     d_x = ctx.to_device(rng.uniform(-1.0, 1.0, npair))
@@ -359,6 +361,23 @@ def test_producer_stream_ring_is_bitwise_the_single_stream_result(ctx, nao, naux
     want, idx, _ = ES.eri_sample(mesh, 41, Ce, naux, A, [int(k) for k in range(nk) if ES.plan_records(mesh)[0][k] > 0])
     for blk in range(nblk):
         assert np.abs(a[blk][np.ix_(idx, idx)] - 2.0 * want[blk]).max() < 1e-8
+
+
+@pytest.mark.parametrize("mesh,nao,naux,nemb,spin", [((3, 2, 1), 27, 40, 256, 2), ((2, 2, 2), 101, 24, 136, 1), ((3, 1, 1), 50, 33, 72, 2),
+                                                     ((2, 2, 1), 203, 16, 256, 1), ((2, 2, 1), 17, 64, 40, 2)])
+def test_off_tile_ao_dimension_takes_the_hot_path(ctx, mesh, nao, naux, nemb, spin):
+    """AO dimensions that are NOT a multiple of the K tile of the hot kernels (8): real basis sets rarely are (13 functions per
+    carbon atom in GTH-DZVP, 5 per hydrogen in cc-pVDZ).  Up to round 5 such a system fell to the generic kernels at about half the
+    rate; now the hot kernels loop over hot_kdim(nao) against the pipeline's zero-padded copy of C_ao_emb (step 1 clamps its A rows
+    inside the block, step 2 reads the padding rows of its own initialised Ut buffer against zeros).  Planes, ERI and the Freivalds
+    probe against the oracle, the block ring in use, both step-2 kernels (nemb = 256 and table-driven), one and two spins."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    nk = int(np.prod(mesh))
+    w, by = ES.plan_records(mesh)
+    kls = sorted(by)
+    A = sorted(set([0, 1, nemb // 3, nemb // 2, nemb - 2, nemb - 1]))
+    worst = _run_and_check(ctx, mesh, nao, naux, nemb, spin, kls, A, seed=500 + nao, want_ring=True)
+    assert worst < 1e-11
 
 
 @pytest.mark.parametrize("gen_stream", ["0", "1"])

@@ -61,7 +61,7 @@ int main() {
     // ---- step 1: as launch_flat_hot (BM 128, BN 64, both spins, 8 slots) ---------------------------------------------------
     H1Args a;
     a.Lpq = Lpq; a.Ci = C; a.Ut = Ut;
-    a.nL = nL; a.nao = nao; a.nemb = nemb; a.mrows = nao; a.nblk = (nao + 15) / 16;
+    a.nL = nL; a.nao = nao; a.kdim = nao; a.nemb = nemb; a.mrows = nao; a.nblk = (nao + 15) / 16;
     a.tiles_m = (int)(((long long)nL * nao + 127) / 128); a.tiles_n = nemb / 64;
     a.nspin = nspin; a.b_spin_stride = (long long)nk * nao * nemb; a.out_spin_stride = (long long)nslot * ut;
     a.nslot = nslot; a.a_slot_stride = (long long)blk; a.out_slot_stride = (long long)ut; a.b_k_stride = (long long)nao * nemb;
@@ -94,7 +94,7 @@ int main() {
     {   // ---- step 1 at C4: 16 queued blocks, naux 416, nao 104, nemb 136, one spin, 48-column tiles ---------------------------
         const int nL4 = 416, nao4 = 104, nemb4 = 136, nslot4 = 16;
         H1Args c = a;
-        c.nL = nL4; c.nao = nao4; c.nemb = nemb4; c.mrows = nao4; c.nblk = (nao4 + 15) / 16;
+        c.nL = nL4; c.nao = nao4; c.kdim = nao4; c.nemb = nemb4; c.mrows = nao4; c.nblk = (nao4 + 15) / 16;
         c.tiles_m = (int)(((long long)nL4 * nao4 + 127) / 128); c.tiles_n = (nemb4 + 47) / 48;
         c.nspin = 1; c.b_spin_stride = 0; c.out_spin_stride = 0;
         c.nslot = nslot4; c.a_slot_stride = (long long)nL4 * nao4 * nao4; c.out_slot_stride = (long long)nL4 * nao4 * nemb4;
@@ -132,7 +132,7 @@ int main() {
     h.Ut = Ut; h.symmask = (1u << nslot) - 1u;
     for (int i = 0; i < H2_MAXSLOT; ++i) h.Cj[i] = C + (size_t)((i * 3 + 1) % nk) * nao * nemb;
     h.slot_stride = (long long)ut; h.planes = planes; h.naux = nL; h.npair = npair;
-    h.nL = nL; h.nao = nao; h.nslot = nslot; h.nspin = nspin;
+    h.nL = nL; h.nao = nao; h.kdim = nao; h.nslot = nslot; h.nspin = nspin;
     h.ut_spin_stride = (long long)nslot * ut; h.cj_spin_stride = (long long)nk * nao * nemb; h.planes_spin_stride = 2LL * nL * npair;
     h.nblocks = (unsigned)(4 * nL * nspin); h.fold_diag = 1;
     const double f2 = 6.0 * (double)nslot * (136.0 + 120.0) * 256.0 * nao * nL * nspin;
@@ -159,7 +159,7 @@ int main() {
         t.Ut = Ut; t.symmask = 0xffffu;
         for (int i = 0; i < T_MAXSLOT; ++i) t.Cj[i] = C + (size_t)((i * 3 + 1) % nk) * nao4 * nemb4;
         t.slot_stride = (long long)ut4; t.planes = planes; t.naux = nL4; t.npair = npair4;
-        t.nL = nL4; t.nao = nao4; t.nslot = nslot4; t.nemb = nemb4; t.nspin = 1;
+        t.nL = nL4; t.nao = nao4; t.kdim = nao4; t.nslot = nslot4; t.nemb = nemb4; t.nspin = 1;
         t.ut_spin_stride = 0; t.cj_spin_stride = 0; t.planes_spin_stride = 0; t.fold_diag = 1;
         t.table = dtab; t.nitems = (int)(tab.size() / T_ITEM);
         t.nsub = 1; t.sub_slots = nslot4; t.planes_sub = nullptr; t.sub_stride = 0;
