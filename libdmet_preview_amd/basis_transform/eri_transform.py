@@ -931,7 +931,10 @@ class EriEngine(object):
 
     # ---- plane stack: deferred, K-stacked contraction (dmk_eri_stack) ---------------------------------------------------
     def slot_bytes(self):
-        return self.spin * 2 * self.naux * (self.nemb * (self.nemb + 1) // 2) * 8
+        """Bytes of one plane slot (all spins, Re and Im) in the library's plane geometry: naux rounded up to 8 rows, the pair
+        index to an even row length (capi.hip dmk_eri: pr, pl)."""
+        npair = self.nemb * (self.nemb + 1) // 2
+        return self.spin * 2 * ((self.naux + 7) // 8 * 8) * (npair + (npair & 1)) * 8
 
     def set_stack(self, nslots=None, budget_gb=None, n_kL=None):
         """Keep the planes of up to `nslots` kL resident and contract them together.  Without `nslots` the stack is sized

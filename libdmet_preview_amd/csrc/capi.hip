@@ -732,9 +732,18 @@ struct dmk_eri {
     double2 *Cpad = nullptr;
     double *eri;
     size_t ws_bytes[2] = {0, 0};   // capacities of planes / Ut (they may come from the context's cache)
-    double *planes = nullptr;   // spin x (2 naux) x npair
+    // PLANE GEOMETRY: a Re or Im plane has `pr` rows (naux rounded up to the K tile of the contraction kernel, 8) of `pl` doubles
+    // (npair rounded up to even).  The padding rows and the padding column are never written by the half transform and stay zero
+    // from the memset at the start of a kL, so the contraction always runs on the LDS-DMA kernel with its symmetric launch --
+    // up to round 5 an auxiliary basis off the tile (naux 411) or an odd pair count (nemb 250) fell to the register-staged kernel
+    // without the symmetric saving.  pr == naux and pl == npair for shapes on the tile: the layout of rounds 1 - 5.
+    int64_t pr = 0, pl = 0;
+    double *planes = nullptr;   // spin x (2 pr) x pl
+    double *planes_view = nullptr;      // dmk_eri_planes with a padded geometry: compact (spin, 2, naux, npair) copy
+    size_t planes_view_bytes = 0;
     double2 *Ut = nullptr;      // lchunk x nao x nemb
     int lchunk;
+    int hot_rows = 0;     // auxiliary rows per hot step-1 launch (half1_hot_max_rows): blocks of 4 GiB and more go in ranges of L
     int use_3m = 1;       // Karatsuba complex product in the generic half transform (DMK_ERI_3M=0 restores 4M)
     // hot path: step-1 outputs of up to `group` consecutive AO blocks are queued and transformed by ONE
     // step-2 launch whose accumulators (and tril-pack epilogue) are shared by all of them
@@ -767,7 +776,7 @@ struct dmk_eri {
     // weight class and spin block contracts them all (dmk_eri_contract, or automatically when the stack is full / at finish)
     int nslots = 1, n_w2 = 0, n_w1 = 0, cur_slot = 0, cur_weight = 1;
     double *slot_planes(int slot, int spin_idx) const {
-        return planes + ((size_t)spin_idx * nslots + slot) * 2 * (size_t)naux * npair;
+        return planes + ((size_t)spin_idx * nslots + slot) * 2 * (size_t)pr * pl;
     }
     // host feed (dmk_eri_push_block_host): two device staging blocks filled on a copy stream while the compute stream
     // transforms the other one; created on first use
@@ -799,6 +808,9 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     dmk_eri *h = new dmk_eri(ctx, mesh);
     h->nao = nao; h->naux = naux; h->nemb = nemb; h->spin = spin; h->tr = flags & 1;
     h->npair = (int64_t)nemb * (nemb + 1) / 2;
+    h->pr = ((int64_t)naux + 7) / 8 * 8;
+    h->pl = h->npair + (h->npair & 1);
+    if (const char *e = getenv("DMK_ERI_PLANE_PAD")) if (atoi(e) == 0) { h->pr = naux; h->pl = h->npair; }     // the unpadded layout (labs)
     if ((flags & 2) && !h->tr) {
         const size_t ib = (size_t)(spin == 2 ? 3 : 1) * h->npair * h->npair * sizeof(double);
         if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->imag), ib) != hipSuccess ||
@@ -823,7 +835,8 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     // kernel covers the shape too, so a queued group can never be left without a kernel
     h->hot256 = half2_hot_usable(nao, nemb) != 0;
     if (const char *e = getenv("DMK_ERI_TAB256")) if (atoi(e) != 0) h->hot256 = false;      // route nemb = 256 through the table kernel
-    if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(naux, nao, nemb)) {
+    h->hot_rows = std::min(naux, half1_hot_max_rows(nao));
+    if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(h->hot_rows, nao, nemb)) {
         h->lchunk = naux;
         h->group = h->hot256 ? 8 : 16;               // the table kernel cuts its queue into sub-group runs: a longer queue per launch
         if (const char *e = getenv("DMK_ERI_GROUP")) h->group = atoi(e);
@@ -831,9 +844,9 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         if (!h->hot256) h->nsub_max = half2_tab_subgroups(ctx, naux, nao, nemb, spin, h->group, 4);      // 1 unless DMK_ERI_TAB_SUB asks
     }
     // K padding of the hot kernels: a zero-padded copy of C (made below) and Ut rows to read past the last auxiliary row
-    const bool kpad = half1_hot_usable(naux, nao, nemb) && hot_kdim(nao) != nao;
+    const bool kpad = half1_hot_usable(h->hot_rows, nao, nemb) && hot_kdim(nao) != nao;
     if (kpad) h->kdim = hot_kdim(nao);
-    const size_t plane_bytes = (size_t)spin * 2 * naux * h->npair * sizeof(double);
+    const size_t plane_bytes = (size_t)spin * 2 * h->pr * h->pl * sizeof(double);
     const size_t ut_bytes = (size_t)h->lchunk * nao * nemb * sizeof(double2) * (h->group > 1 ? (size_t)h->group * spin : 1) +
                             (size_t)(h->kdim - nao) * nemb * sizeof(double2);
     // reuse the workspace parked in the context by the previous pipeline when it is large enough
@@ -878,6 +891,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         if (!ok) {
             (void)hipGetLastError();
             if (h->Cpad) (void)hipFree(h->Cpad);
+    if (h->planes_view) (void)hipFree(h->planes_view);
             (void)hipFree(h->planes);
             (void)hipFree(h->Ut);
             if (h->imag) (void)hipFree(h->imag);
@@ -887,7 +901,7 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         h->Ch = h->Cpad;
     }
     if (h->nsub_max > 1) {
-        const size_t sb = (size_t)(h->nsub_max - 1) * spin * 2 * naux * h->npair * sizeof(double);
+        const size_t sb = (size_t)(h->nsub_max - 1) * spin * 2 * h->pr * h->pl * sizeof(double);
         if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->sub_planes), sb) != hipSuccess) {
             (void)hipGetLastError();
             h->sub_planes = nullptr;                 // not fatal: one run per launch, as before
@@ -903,10 +917,10 @@ static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi);
 // the probe's share of one plane slot (see dmk_eri_probe)
 static int eri_probe_slot(dmk_eri *h, int slot, int nrows, double w) {
     void *tw = nullptr;
-    int rc = dmk_scratch(h->ctx, (size_t)4 * h->naux * sizeof(double), &tw);
+    int rc = dmk_scratch(h->ctx, (size_t)4 * h->pr * sizeof(double), &tw);
     if (rc) return rc;
-    return launch_eri_probe_slot(h->ctx, h->slot_planes(slot, 0), h->spin == 2 ? h->slot_planes(slot, 1) : nullptr, nrows, h->npair, w,
-                                 h->probe_x, h->probe_y, reinterpret_cast<double *>(tw));
+    return launch_eri_probe_slot(h->ctx, h->slot_planes(slot, 0), h->spin == 2 ? h->slot_planes(slot, 1) : nullptr, nrows, h->npair, h->pl,
+                                 w, h->probe_x, h->probe_y, reinterpret_cast<double *>(tw));
 }
 
 static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
@@ -927,7 +941,7 @@ static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
         h->cur_slot = weight == 2 ? h->n_w2 : h->nslots - 1 - h->n_w1;
         h->cur_weight = weight;
     }
-    const size_t bytes = (size_t)2 * h->naux * h->npair * sizeof(double);
+    const size_t bytes = (size_t)2 * h->pr * h->pl * sizeof(double);
     for (int s = 0; s < h->spin; ++s) DMK_HIP(ctx, hipMemsetAsync(h->slot_planes(h->cur_slot, s), 0, bytes, ctx->stream));
     if (h->sub_planes) DMK_HIP(ctx, hipMemsetAsync(h->sub_planes, 0, bytes * h->spin * (h->nsub_max - 1), ctx->stream));
     h->sub_used = 1;
@@ -960,11 +974,14 @@ static int eri_ring_step1(dmk_eri *h) {
     const bool resident = h->resident_src != nullptr;
     const double2 *src = resident ? h->resident_src : h->ring + (size_t)h->fill_half * h->group * naux * nao * nao;
     if (!resident && h->gen_pending) DMK_HIP(ctx, hipStreamWaitEvent(ctx->stream, h->ev_gen[h->fill_half], 0));      // the producers of this group
-    int rc = launch_half1_hot_multi(ctx, src, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->Ch, h->Ut,
-                                    (long long)slot_elems, naux, nao, nemb, h->spin, (long long)h->mesh.nk * h->kdim * nemb,
-                                    (long long)h->group * (long long)slot_elems, h->kdim);
-    if (rc < 0) return rc;
-    if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
+    for (int l0 = 0; l0 < naux; l0 += h->hot_rows) {         // (one launch unless an AO block reaches 4 GiB)
+        const int nl = std::min(h->hot_rows, naux - l0);
+        int rc = launch_half1_hot_multi(ctx, src + (size_t)l0 * nao * nao, (long long)naux * nao * nao, h->ring_pending, h->pend_ki, h->Ch,
+                                        h->Ut + (size_t)l0 * nao * nemb, (long long)slot_elems, nl, nao, nemb, h->spin,
+                                        (long long)h->mesh.nk * h->kdim * nemb, (long long)h->group * (long long)slot_elems, h->kdim);
+        if (rc < 0) return rc;
+        if (rc == 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri ring: hot step-1 kernel unavailable for the queued blocks");
+    }
     if (!resident && h->ring_halves == 2) DMK_HIP(ctx, hipEventRecord(h->ev_free[h->fill_half], ctx->stream));           // the half may be refilled
     h->resident_src = nullptr;
     h->ring_pending = 0;
@@ -988,14 +1005,14 @@ static int eri_flush(dmk_eri *h) {
         cj[i] = h->Ch + (size_t)h->pend_kj[i] * h->kdim * nemb;
     int rc;
     if (h->hot256) {
-        rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair,
+        rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), h->pr, h->pl,
                               naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * h->kdim * nemb,
-                              (long long)h->nslots * 2LL * naux * h->npair, h->kdim);
+                              (long long)h->nslots * 2LL * h->pr * h->pl, h->kdim);
     } else {
         const int nsub = h->sub_planes ? half2_tab_subgroups(ctx, naux, nao, nemb, h->spin, h->pending, h->nsub_max) : 1;
-        rc = launch_half2_tab(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), naux, h->npair,
+        rc = launch_half2_tab(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), h->pr, h->pl,
                               naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * h->kdim * nemb,
-                              (long long)h->nslots * 2LL * naux * h->npair, nsub, h->sub_planes, (long long)h->spin * 2LL * naux * h->npair,
+                              (long long)h->nslots * 2LL * h->pr * h->pl, nsub, h->sub_planes, (long long)h->spin * 2LL * h->pr * h->pl,
                               h->kdim);
         if (rc == 1) h->sub_used = std::max(h->sub_used, nsub);
     }
@@ -1014,7 +1031,7 @@ static int eri_flush(dmk_eri *h) {
                 g2.seg[1].A = Cj; g2.seg[1].lda = nemb; g2.seg[1].strideA = 0;
                 g2.seg[1].B = ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
                 g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
-                g2.planes = h->slot_planes(h->cur_slot, s); g2.naux = naux; g2.npair = h->npair;
+                g2.planes = h->slot_planes(h->cur_slot, s); g2.naux = h->pr; g2.npair = h->pl;
                 int rg = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
                 if (rg) return rg;
             }
@@ -1035,7 +1052,7 @@ __global__ void planes_add_kernel(long long n, double *__restrict__ a, const dou
 static int eri_fold_subplanes(dmk_eri *h, bool rezero = false) {
     dmk_ctx *ctx = h->ctx;
     if (!h->sub_planes || h->sub_used <= 1) return DMK_OK;
-    const long long n = 2LL * h->naux * h->npair;
+    const long long n = 2LL * h->pr * h->pl;
     for (int p = 1; p < h->sub_used; ++p)
         for (int s = 0; s < h->spin; ++s) {
             FamScope fs(ctx, DMK_FAM_MISC);
@@ -1066,9 +1083,14 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
         }
         const int slot = h->pending;
         // both spin channels in one launch (they share the AO block); per-spin generic kernels only if it declines
-        int rc_hot = launch_half1_hot(ctx, L, h->Ch + (size_t)ki * h->kdim * nemb, h->Ut + (size_t)slot * slot_elems, naux, nao, nemb,
-                                      h->spin, (long long)h->mesh.nk * h->kdim * nemb, (long long)h->group * (long long)slot_elems,
-                                      h->kdim);
+        int rc_hot = 1;
+        for (int l0 = 0; l0 < naux && rc_hot == 1; l0 += h->hot_rows) {
+            const int nl = std::min(h->hot_rows, naux - l0);
+            rc_hot = launch_half1_hot(ctx, L + (size_t)l0 * nao * nao, h->Ch + (size_t)ki * h->kdim * nemb,
+                                      h->Ut + (size_t)slot * slot_elems + (size_t)l0 * nao * nemb, nl, nao, nemb, h->spin,
+                                      (long long)h->mesh.nk * h->kdim * nemb, (long long)h->group * (long long)slot_elems, h->kdim);
+            if (rc_hot == 0 && l0 > 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_push_block: hot step-1 kernel declined a later range of L");
+        }
         if (rc_hot < 0) return rc_hot;
         for (int s = 0; s < h->spin && rc_hot == 0; ++s) {
             const double2 *Ci = h->C + ((size_t)s * h->mesh.nk + ki) * nao * nemb;
@@ -1123,7 +1145,7 @@ int dmk_eri_push_block(dmk_eri *h, int ki, int kj, int symmetrise, const void *L
             g2.seg[1].A = Cj; g2.seg[1].lda = nemb; g2.seg[1].strideA = 0;
             g2.seg[1].B = h->Ut; g2.seg[1].ldb = nemb; g2.seg[1].strideB = (int64_t)nao * nemb;
             g2.epi = ZEPI_PACK_ACC; g2.lower_only = 1; g2.use_3m = h->use_3m;
-            g2.planes = planes + (size_t)l0 * h->npair; g2.naux = naux; g2.npair = h->npair;
+            g2.planes = planes + (size_t)l0 * h->pl; g2.naux = h->pr; g2.npair = h->pl;
             rc = launch_zgemm(ctx, g2, DMK_FAM_ZGEMM_HALF2);
             if (rc) return rc;
         }
@@ -1142,17 +1164,19 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
         rcf = eri_fold_subplanes(h);
         if (rcf) return rcf;
     }
-    int K;
+    int K, Kalg;                        // rows of the planes that enter (padding rows are zero) / rows that count as work
     double alpha;
     if (h->tr) {
         if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL: weight must be 1 or 2");
-        K = weight == 1 ? h->naux : 2 * h->naux;
+        K = (int)(weight == 1 ? h->pr : 2 * h->pr);
+        Kalg = weight == 1 ? h->naux : 2 * h->naux;
         alpha = (double)weight;
     } else {
-        K = 2 * h->naux;
+        K = (int)(2 * h->pr);
+        Kalg = 2 * h->naux;
         alpha = 1.0;
     }
-    const int64_t np = h->npair;
+    const int64_t np = h->npair, pl = h->pl;
     if (h->nslots > 1) {
         // deferred: the planes stay in their slot until the stack is contracted
         if (!h->tr) return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: the plane stack needs time-reversal symmetry");
@@ -1161,7 +1185,7 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
                             h->cur_weight);
         if (weight == 2) h->n_w2 += 1; else h->n_w1 += 1;
         h->probe_pending = true;
-        h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
+        h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)Kalg * (double)np * (double)np;
         h->cur_kL = -1;
         return DMK_OK;
     }
@@ -1170,14 +1194,17 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
         int rcp = eri_probe_slot(h, 0, K, alpha);
         if (rcp) return rcp;
     }
-    const double *X0 = h->planes;
-    const double *X1 = h->planes + (size_t)2 * h->naux * np;
-    int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
+    const double *X0 = h->slot_planes(0, 0);
+    const double *X1 = h->slot_planes(0, 1);
+    auto gemm = [&](int Kr, double al, const double *A, const double *B, double *Cb) {
+        return launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, Kr, al, A, pl, B, pl, Cb, np, 0, 0, 0, -1, -1, (int)pl, (int)pl);
+    };
+    int rc = gemm(K, alpha, X0, X0, h->eri);
     if (rc) return rc;
     if (h->spin == 2) {
-        rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X1, np, h->eri + (size_t)np * np, np);
+        rc = gemm(K, alpha, X0, X1, h->eri + (size_t)np * np);
         if (rc) return rc;
-        rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X1, np, X1, np, h->eri + (size_t)2 * np * np, np);
+        rc = gemm(K, alpha, X1, X1, h->eri + (size_t)2 * np * np);
         if (rc) return rc;
     }
     if (h->imag) {
@@ -1185,15 +1212,15 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
         const int nb = h->spin == 2 ? 3 : 1;
         for (int b = 0; b < nb; ++b) {
             const double *A = (b == 2) ? X1 : X0, *B = (b == 0) ? X0 : X1;
-            const double *Are = A, *Aim = A + (size_t)h->naux * np, *Bre = B, *Bim = B + (size_t)h->naux * np;
+            const double *Are = A, *Aim = A + (size_t)h->pr * pl, *Bre = B, *Bim = B + (size_t)h->pr * pl;
             double *Cb = h->imag + (size_t)b * np * np;
-            rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, h->naux, 1.0, Are, np, Bim, np, Cb, np);
+            rc = gemm((int)h->pr, 1.0, Are, Bim, Cb);
             if (rc) return rc;
-            rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, h->naux, -1.0, Aim, np, Bre, np, Cb, np);
+            rc = gemm((int)h->pr, -1.0, Aim, Bre, Cb);
             if (rc) return rc;
         }
     }
-    h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)K * (double)np * (double)np;
+    h->flops_contract += (h->spin == 2 ? 3.0 : 1.0) * 2.0 * (double)Kalg * (double)np * (double)np;
     h->cur_kL = -1;
     return DMK_OK;
 }
@@ -1204,8 +1231,8 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
 static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
     dmk_ctx *ctx = h->ctx;
     if (!h->eri) return dmk_fail(ctx, DMK_ERR_STATE, "eri contraction: this pipeline was opened without an ERI of its own (flags bit 2)");
-    const int64_t np = h->npair;
-    const int64_t slot_stride = 2LL * h->naux * np;
+    const int64_t np = h->npair, pl = h->pl;
+    const int64_t slot_stride = 2LL * h->pr * pl;
     // slots per launch.  Measured at C5 (13 weight-2 kL resident): 1, 2, 4 or all 13 kL per launch run at the same 69.3-69.6 TF on
     // the matrix pipe -- there the contraction is not sensitive to K -- but the HBM traffic is not the same: with K = 1600 the
     // operand panels of the eight XCDs' super-blocks (8 x 16 panels x K x 128 x 8 B = 210 MB) still fit the 256 MB Infinity Cache
@@ -1223,11 +1250,11 @@ static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
     if (h->probe_x && h->probe_pending) {
         // once per resident plane set, however many bands the contraction is finished in
         for (int i = 0; i < h->n_w2; ++i) {
-            int rc = eri_probe_slot(h, i, 2 * h->naux, 2.0);
+            int rc = eri_probe_slot(h, i, (int)(2 * h->pr), 2.0);
             if (rc) return rc;
         }
         for (int i = 0; i < h->n_w1; ++i) {
-            int rc = eri_probe_slot(h, h->nslots - h->n_w1 + i, h->naux, 1.0);
+            int rc = eri_probe_slot(h, h->nslots - h->n_w1 + i, (int)h->pr, 1.0);
             if (rc) return rc;
         }
         h->probe_pending = false;
@@ -1235,21 +1262,21 @@ static int eri_contract_stack(dmk_eri *h, int band_lo, int band_hi) {
     for (int w = 2; w >= 1; --w) {
         const int n = w == 2 ? h->n_w2 : h->n_w1;
         const int first = w == 2 ? 0 : h->nslots - h->n_w1;
-        const int seg_rows = w == 2 ? 2 * h->naux : h->naux;
+        const int seg_rows = (int)(w == 2 ? 2 * h->pr : h->pr);
         const int kchunk = kchunk_for(seg_rows);
         for (int s0 = 0; s0 < n; s0 += kchunk) {
             const int K = std::min(kchunk, n - s0) * seg_rows;
             const double *X0 = h->slot_planes(first + s0, 0);
-            int rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X0, np, X0, np, h->eri, np, seg_rows, slot_stride,
-                                             slot_stride, band_lo, band_hi);
+            int rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X0, pl, X0, pl, h->eri, np, seg_rows, slot_stride,
+                                             slot_stride, band_lo, band_hi, (int)pl, (int)pl);
             if (rc) return rc;
             if (h->spin == 2) {
                 const double *X1 = h->slot_planes(first + s0, 1);
-                rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X0, np, X1, np, h->eri + (size_t)np * np, np, seg_rows,
-                                             slot_stride, slot_stride, band_lo, band_hi);
+                rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X0, pl, X1, pl, h->eri + (size_t)np * np, np, seg_rows,
+                                             slot_stride, slot_stride, band_lo, band_hi, (int)pl, (int)pl);
                 if (rc) return rc;
-                rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X1, np, X1, np, h->eri + (size_t)2 * np * np, np,
-                                             seg_rows, slot_stride, slot_stride, band_lo, band_hi);
+                rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, (double)w, X1, pl, X1, pl, h->eri + (size_t)2 * np * np, np,
+                                             seg_rows, slot_stride, slot_stride, band_lo, band_hi, (int)pl, (int)pl);
                 if (rc) return rc;
             }
         }
@@ -1263,7 +1290,7 @@ int dmk_eri_stack(dmk_eri *h, int nslots_wanted, int *nslots_granted) {
     if (nslots_wanted < 1) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_stack: needs at least one slot");
     if (h->cur_kL >= 0 || h->n_w2 + h->n_w1 > 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_stack: a kL is in progress or the stack is not empty");
     if ((h->imag || !h->tr) && nslots_wanted > 1) nslots_wanted = 1;          // the non-time-reversal branch contracts per kL
-    const size_t slot_bytes = (size_t)h->spin * 2 * h->naux * h->npair * sizeof(double);
+    const size_t slot_bytes = (size_t)h->spin * 2 * h->pr * h->pl * sizeof(double);
     int n = nslots_wanted;
     DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     while (true) {
@@ -1318,25 +1345,27 @@ int dmk_eri_contract_rows(dmk_eri *h, int64_t row_lo, int64_t row_hi, double *ou
     if (!out || row_lo < 0 || row_hi > np || row_lo >= row_hi || (row_lo & 1))
         return dmk_fail(ctx, DMK_ERR_INVALID, "eri_contract_rows: bad row range [%lld, %lld) (row_lo must be even)", (long long)row_lo, (long long)row_hi);
     const int rows = (int)(row_hi - row_lo);
-    const int64_t slot_stride = 2LL * h->naux * np;
+    const int64_t pl = h->pl;
+    const int64_t slot_stride = 2LL * h->pr * pl;
     const size_t blk = (size_t)rows * np;
+    const int rows_p = (row_hi == np) ? (int)(pl - row_lo) : rows;      // the last slab may load the padding column
     for (int w = 2; w >= 1; --w) {
         const int n = w == 2 ? h->n_w2 : h->n_w1;
         if (n == 0) continue;
         const int first = w == 2 ? 0 : h->nslots - h->n_w1;
-        const int seg_rows = w == 2 ? 2 * h->naux : h->naux;
+        const int seg_rows = (int)(w == 2 ? 2 * h->pr : h->pr);
         const int K = n * seg_rows;
         const double *X0 = h->slot_planes(first, 0);
-        int rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X0 + row_lo, np, X0, np, out, np, seg_rows, slot_stride,
-                                         slot_stride, -1, -1);
+        int rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X0 + row_lo, pl, X0, pl, out, np, seg_rows, slot_stride,
+                                         slot_stride, -1, -1, rows_p, (int)pl);
         if (rc) return rc;
         if (h->spin == 2) {
             const double *X1 = h->slot_planes(first, 1);
-            rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X0 + row_lo, np, X1, np, out + blk, np, seg_rows, slot_stride,
-                                         slot_stride, -1, -1);
+            rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X0 + row_lo, pl, X1, pl, out + blk, np, seg_rows, slot_stride,
+                                         slot_stride, -1, -1, rows_p, (int)pl);
             if (rc) return rc;
-            rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X1 + row_lo, np, X1, np, out + 2 * blk, np, seg_rows,
-                                         slot_stride, slot_stride, -1, -1);
+            rc = launch_dgemm_tn_acc_seg(ctx, rows, (int)np, K, (double)w, X1 + row_lo, pl, X1, pl, out + 2 * blk, np, seg_rows,
+                                         slot_stride, slot_stride, -1, -1, rows_p, (int)pl);
             if (rc) return rc;
         }
     }
@@ -1427,28 +1456,30 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
         rcf = eri_fold_subplanes(h);
         if (rcf) return rcf;
     }
-    int K;
+    int K, Kalg;
     double alpha;
     if (h->tr) {
         if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: weight must be 1 or 2");
-        K = weight == 1 ? h->naux : 2 * h->naux;
+        K = (int)(weight == 1 ? h->pr : 2 * h->pr);
+        Kalg = weight == 1 ? h->naux : 2 * h->naux;
         alpha = (double)weight;
     } else {
-        K = 2 * h->naux;
+        K = (int)(2 * h->pr);
+        Kalg = 2 * h->naux;
         alpha = 1.0;
     }
-    const int64_t np = h->npair;
-    double *X0 = h->planes;
-    const double *X1 = h->planes + (size_t)2 * h->naux * np;
-    const long long nel = (long long)2 * h->naux * np;
+    const int64_t np = h->npair, pl = h->pl;
+    double *X0 = h->slot_planes(0, 0);
+    const double *X1 = h->slot_planes(0, 1);
+    const long long nel = (long long)2 * h->pr * pl;
     {
         FamScope fs(ctx, DMK_FAM_MISC);
         hipLaunchKernelGGL(planes_sub_kernel, dim3(8192), dim3(256), 0, ctx->stream, nel, X0, X1);
         DMK_CHECK_LAUNCH(ctx);
     }
-    int rc = launch_dgemm_tn_acc(ctx, (int)np, (int)np, K, alpha, X0, np, X0, np, h->eri, np);
+    int rc = launch_dgemm_tn_acc_seg(ctx, (int)np, (int)np, K, alpha, X0, pl, X0, pl, h->eri, np, 0, 0, 0, -1, -1, (int)pl, (int)pl);
     if (rc) return rc;
-    h->flops_contract += 2.0 * (double)K * (double)np * (double)np;
+    h->flops_contract += 2.0 * (double)Kalg * (double)np * (double)np;
     h->cur_kL = -1;
     return DMK_OK;
 }
@@ -1598,8 +1629,28 @@ int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out) {
         }
     }
     if (h->nslots > 1) return dmk_fail(h->ctx, DMK_ERR_STATE, "eri_planes: with a plane stack the spin planes of a kL are not contiguous");
-    *planes_out = h->planes;
     if (elems_out) *elems_out = (int64_t)h->spin * 2 * h->naux * h->npair;
+    if (h->pr == h->naux && h->pl == h->npair) {
+        *planes_out = h->planes;
+        return DMK_OK;
+    }
+    // padded plane geometry: the caller is handed the documented (spin, 2, naux, npair) array, gathered into a buffer of the pipeline
+    dmk_ctx *ctx = h->ctx;
+    const size_t want = (size_t)h->spin * 2 * h->naux * h->npair * sizeof(double);
+    if (h->planes_view_bytes < want) {
+        if (h->planes_view) (void)hipFree(h->planes_view);
+        h->planes_view = nullptr;
+        h->planes_view_bytes = 0;
+        if (dmk_dev_alloc(ctx, reinterpret_cast<void **>(&h->planes_view), want) != hipSuccess)
+            return dmk_fail(ctx, DMK_ERR_NOMEM, "eri_planes: no memory for the compact copy (%zu bytes)", want);
+        h->planes_view_bytes = want;
+    }
+    for (int s = 0; s < h->spin; ++s)
+        for (int ri = 0; ri < 2; ++ri)
+            DMK_HIP(ctx, hipMemcpy2DAsync(h->planes_view + ((size_t)s * 2 + ri) * h->naux * h->npair, (size_t)h->npair * sizeof(double),
+                                          h->slot_planes(0, s) + (size_t)ri * h->pr * h->pl, (size_t)h->pl * sizeof(double),
+                                          (size_t)h->npair * sizeof(double), (size_t)h->naux, hipMemcpyDeviceToDevice, ctx->stream));
+    *planes_out = h->planes_view;
     return DMK_OK;
 }
 

@@ -245,9 +245,10 @@ __device__ double dmk_wave_sum(double v);
 int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
                         int64_t ldx, const double *Y, int64_t ldy, double *C, int64_t ldc);
 // K as a stack of row segments and / or the output restricted to a band of 128-wide tiles (dgemm_tn.hip)
+// Mp / Np (0: M / N): columns of X / Y that may be loaded, zero beyond M / N -- an odd M padded to the even row length of the planes
 int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X, int64_t ldx, const double *Y,
                             int64_t ldy, double *C, int64_t ldc, int seg_rows, int64_t seg_stride_x, int64_t seg_stride_y,
-                            int band_lo, int band_hi);
+                            int band_lo, int band_hi, int Mp = 0, int Np = 0);
 
 struct ZSeg {
     const void *A = nullptr;   // complex (or real if a_real) operand A
@@ -286,7 +287,7 @@ int launch_fold_fft(dmk_ctx *ctx, const int n[3], long long ncol, int batch, con
                     int inverse, double *imag_max);
 
 // Freivalds probe of the contraction (eri_probe.hip)
-int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int nrows, long long npair, double w, const double *x,
+int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int nrows, long long npair, long long ld, double w, const double *x,
                           double *yref, double *twork);
 
 int launch_philox_block(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, int nao, void *out);
@@ -299,6 +300,7 @@ int launch_philox_blocks_on(dmk_ctx *ctx, hipStream_t stream, uint64_t seed, int
 // the C operands then hold kdim rows per k point, ZERO beyond nao (stride kdim * nemb), and the Ut buffer of step 2 is the
 // pipeline's own, initialised one (its rows of the padding are read against those zeros).
 int hot_kdim(int nao);
+int half1_hot_max_rows(int nao);     // auxiliary rows per step-1 launch (32-bit lane offsets: < 4 GiB of the AO block)
 int launch_half1_hot(dmk_ctx *ctx, const void *Lpq, const void *Ci, void *Ut, int nL, int nao, int nemb, int nspin = 1,
                      long long ci_spin_stride = 0, long long ut_spin_stride = 0, int kdim = 0);
 int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_stride, int nslot, const int *ki, const void *C,

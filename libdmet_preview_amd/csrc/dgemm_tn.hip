@@ -190,11 +190,13 @@ constexpr int G_STAGE = 2 * GBK * G_LD;        // doubles per stage: A[8][136] |
 // contractions, i.e. 1/3 of the UHF contraction work.
 // SADDR: LDS-DMA pieces addressed as scalar row pointer + loop-invariant per-lane byte offset (common.h glds16s_x4) instead of
 // per-lane 64-bit pointers advanced with the vector ALU.
+// Mp / Np: columns of X / Y that may be LOADED (even; M <= Mp <= ldx): an odd pair count is padded by one zero column in the
+// plane layout, the 16-byte loads then stay aligned and inside the row, and the stores are masked with the real M and N.
 template <bool SYMM, bool SADDR>
 __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     int M, int N, int K, double alpha, const double *__restrict__ X, int64_t ldx,
     const double *__restrict__ Y, int64_t ldy, double *__restrict__ C, int64_t ldc,
-    const unsigned *__restrict__ tile_table, unsigned nblocks, int seg_tiles, int64_t jumpA, int64_t jumpB) {
+    const unsigned *__restrict__ tile_table, unsigned nblocks, int seg_tiles, int64_t jumpA, int64_t jumpB, int Mp, int Np) {
     __shared__ __attribute__((aligned(16))) double lds[GD * G_STAGE];
 
     const unsigned lid = xcd_remap(blockIdx.x, nblocks);
@@ -207,8 +209,8 @@ __global__ __launch_bounds__(NTHREADS, 3) void dgemm_tn_acc_dma_kernel(
     const int frag_k = lane >> 4, frag_x = lane & 15;
 
     int ca = m0 + 2 * lane, cb = n0 + 2 * lane;
-    if (ca + 1 >= M) ca = M - 2;
-    if (cb + 1 >= N) cb = N - 2;
+    if (ca + 1 >= Mp) ca = Mp - 2;
+    if (cb + 1 >= Np) cb = Np - 2;
     // wave w streams K rows 2w, 2w+1 of both operands; SCALAR running row pointers advance one K-tile per issue, the per-lane
     // part of an address is the loop-invariant column byte offset (common.h glds16s_x4: no vector ALU work per piece)
     const unsigned voffA = (unsigned)ca * 8u, voffB = (unsigned)cb * 8u;
@@ -355,7 +357,7 @@ static const unsigned *dgemm_tile_table(dmk_ctx *ctx, int tiles_m, int tiles_n, 
 
 int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X,
                         int64_t ldx, const double *Y, int64_t ldy, double *C, int64_t ldc) {
-    return launch_dgemm_tn_acc_seg(ctx, M, N, K, alpha, X, ldx, Y, ldy, C, ldc, 0, 0, 0, -1, -1);
+    return launch_dgemm_tn_acc_seg(ctx, M, N, K, alpha, X, ldx, Y, ldy, C, ldc, 0, 0, 0, -1, -1, 0, 0);
 }
 
 // The same product with (i) K given as K / seg_rows row segments that start seg_stride_x / seg_stride_y ELEMENTS apart
@@ -364,8 +366,10 @@ int launch_dgemm_tn_acc(dmk_ctx *ctx, int M, int N, int K, double alpha, const d
 // finishes the contraction band by band so that finished rows can be reduced over ranks while later bands are computed.
 int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, const double *X, int64_t ldx, const double *Y,
                             int64_t ldy, double *C, int64_t ldc, int seg_rows, int64_t seg_stride_x, int64_t seg_stride_y,
-                            int band_lo, int band_hi) {
+                            int band_lo, int band_hi, int Mp, int Np) {
     if (M <= 0 || N <= 0 || K <= 0) return DMK_OK;
+    if (Mp < M) Mp = M;                 // loadable columns of X / Y (>= M / N, zero beyond): see the LDS-DMA kernel
+    if (Np < N) Np = N;
     if (seg_rows <= 0 || seg_rows >= K) { seg_rows = K; seg_stride_x = seg_stride_y = 0; }
     if (K % seg_rows) return dmk_fail(ctx, DMK_ERR_INVALID, "dgemm_tn: K = %d is not a multiple of the segment length %d", K, seg_rows);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -375,8 +379,8 @@ int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, con
                       ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) && ((seg_stride_x & 1) == 0) && ((seg_stride_y & 1) == 0);
     static const bool dma_enabled = [] { const char *e = getenv("DMK_DGEMM_DMA"); return !(e && atoi(e) == 0); }();
-    if (dma_enabled && vec2 && (seg_rows % GBK) == 0 && K >= GBK && (M % 2) == 0 && (N % 2) == 0 && M >= 2 && N >= 2 &&
-        tiles_m < 65536 && tiles_n < 65536) {
+    if (dma_enabled && vec2 && (seg_rows % GBK) == 0 && K >= GBK && (Mp % 2) == 0 && (Np % 2) == 0 && Mp <= ldx && Np <= ldy &&
+        M >= 2 && N >= 2 && tiles_m < 65536 && tiles_n < 65536) {
         static const bool symm_enabled = [] { const char *e = getenv("DMK_DGEMM_SYMM"); return !(e && atoi(e) == 0); }();
         const bool symm = symm_enabled && X == Y && ldx == ldy && seg_stride_x == seg_stride_y && M == N && tiles_m >= 2;
         unsigned count = 0;
@@ -398,7 +402,7 @@ int launch_dgemm_tn_acc_seg(dmk_ctx *ctx, int M, int N, int K, double alpha, con
         const bool saddr = se && atoi(se) != 0;
 #define DGEMM_LAUNCH(SY, SA)                                                                                                  \
         hipLaunchKernelGGL((dgemm_tn_acc_dma_kernel<SY, SA>), dim3(count), dim3(NTHREADS), 0, ctx->stream, M, N, K, alpha, X, ldx, Y,   \
-                           ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB)
+                           ldy, C, ldc, table, count, seg_tiles, jumpA, jumpB, Mp, Np)
         if (symm) { if (saddr) DGEMM_LAUNCH(true, true); else DGEMM_LAUNCH(true, false); }
         else { if (saddr) DGEMM_LAUNCH(false, true); else DGEMM_LAUNCH(false, false); }
 #undef DGEMM_LAUNCH

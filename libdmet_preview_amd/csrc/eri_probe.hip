@@ -48,20 +48,20 @@ __global__ __launch_bounds__(PB_NT) void probe_colsum_kernel(const double *__res
 }  // namespace
 
 // yref[b] += w X_a^T (X_b x) for the spin blocks b = (aa) or (aa, ab, bb) of ONE plane slot: X0 / X1 point at the slot's planes of
-// spin 0 / 1 (`nrows` rows of length npair: 2 naux for a weight-2 kL, naux -- the Re half -- for a weight-1 kL).  `twork`:
-// 2 * nrows doubles of scratch.
-int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int nrows, long long npair, double w, const double *x,
-                          double *yref, double *twork) {
+// spin 0 / 1 (`nrows` rows of length npair, `ld` apart: both halves of a weight-2 kL, the Re half of a weight-1 kL; padding rows
+// of the plane layout are zero and may be included).  `twork`: 2 * nrows doubles of scratch.
+int launch_eri_probe_slot(dmk_ctx *ctx, const double *X0, const double *X1, int nrows, long long npair, long long ld, double w,
+                          const double *x, double *yref, double *twork) {
     FamScope fs(ctx, DMK_FAM_MISC);
     const dim3 cgrid((unsigned)((npair + PB_NT - 1) / PB_NT), (unsigned)((nrows + PB_ROWCH - 1) / PB_ROWCH));
     double *t0 = twork, *t1 = twork + nrows;
-    hipLaunchKernelGGL(probe_rowdot_kernel, dim3(nrows), dim3(PB_NT), 0, ctx->stream, X0, npair, npair, x, t0);
-    hipLaunchKernelGGL(probe_colsum_kernel, cgrid, dim3(PB_NT), 0, ctx->stream, X0, npair, nrows, npair, t0, w, yref);
+    hipLaunchKernelGGL(probe_rowdot_kernel, dim3(nrows), dim3(PB_NT), 0, ctx->stream, X0, ld, npair, x, t0);
+    hipLaunchKernelGGL(probe_colsum_kernel, cgrid, dim3(PB_NT), 0, ctx->stream, X0, ld, nrows, npair, t0, w, yref);
     if (X1) {
-        hipLaunchKernelGGL(probe_rowdot_kernel, dim3(nrows), dim3(PB_NT), 0, ctx->stream, X1, npair, npair, x, t1);
+        hipLaunchKernelGGL(probe_rowdot_kernel, dim3(nrows), dim3(PB_NT), 0, ctx->stream, X1, ld, npair, x, t1);
         // (ab): eri[1] = X0^T X1  ->  eri[1] x = X0^T (X1 x)
-        hipLaunchKernelGGL(probe_colsum_kernel, cgrid, dim3(PB_NT), 0, ctx->stream, X0, npair, nrows, npair, t1, w, yref + npair);
-        hipLaunchKernelGGL(probe_colsum_kernel, cgrid, dim3(PB_NT), 0, ctx->stream, X1, npair, nrows, npair, t1, w, yref + 2 * npair);
+        hipLaunchKernelGGL(probe_colsum_kernel, cgrid, dim3(PB_NT), 0, ctx->stream, X0, ld, nrows, npair, t1, w, yref + npair);
+        hipLaunchKernelGGL(probe_colsum_kernel, cgrid, dim3(PB_NT), 0, ctx->stream, X1, ld, nrows, npair, t1, w, yref + 2 * npair);
     }
     DMK_CHECK_LAUNCH(ctx);
     return DMK_OK;

@@ -35,6 +35,7 @@
 // 16-B aligned operands.
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 #include "zhot_common.h"
@@ -514,6 +515,15 @@ int half1_hot_usable(int nL, int nao, int nemb) {
     // (nao need not be a multiple of the K tile: the K loop runs over hot_kdim(nao) with a zero-padded B operand)
     return hot_enabled() && nao >= 2 * H1_BK && nemb >= 32 && (long long)nL * nao >= 4 * H1_BM &&
            (long long)nL * nao * nao * 16 < (1LL << 32);
+}
+
+// Auxiliary rows one step-1 launch may cover: the per-lane part of an LDS-DMA source address is a 32-bit byte offset from the
+// block's base, so a launch spans < 4 GiB of its AO block; blocks beyond that (naux nao^2 >= 2^28) are transformed in several
+// launches over ranges of L (capi.hip).  DMK_ERI_HOT_LCHUNK caps it (tests: the cut on small shapes).
+int half1_hot_max_rows(int nao) {
+    long long rows = ((1LL << 32) - 1) / ((long long)nao * nao * 16);
+    if (const char *e = getenv("DMK_ERI_HOT_LCHUNK")) { const int v = atoi(e); if (v > 0 && v < rows) rows = v; }
+    return (int)std::min<long long>(rows, 0x7fffffff);
 }
 
 // K loop bound of the hot kernels for an AO dimension: the next multiple of the step-1 K tile (8; the step-2 tiles are 4)

@@ -125,14 +125,20 @@ def test_c5_meanfield_bath_full_size(ctx):
     assert res["parity_stages_ok"]
 
 
-@pytest.mark.parametrize("nao,naux,nemb,spin,nslots", [(16, 40, 256, 2, 3), (24, 16, 40, 1, 2), (10, 7, 12, 2, 4), (104, 24, 136, 1, 16)])
-def test_plane_stack_and_banded_contraction(ctx, nao, naux, nemb, spin, nslots):
+@pytest.mark.parametrize("nao,naux,nemb,spin,nslots,pad", [(16, 40, 256, 2, 3, 1), (24, 16, 40, 1, 2, 1), (10, 7, 12, 2, 4, 1), (10, 7, 12, 2, 4, 0),
+                                                           (104, 24, 136, 1, 16, 1), (27, 21, 41, 2, 3, 1), (27, 21, 41, 2, 3, 0)])
+def test_plane_stack_and_banded_contraction(ctx, nao, naux, nemb, spin, nslots, pad, monkeypatch):
     """Deferred, K-stacked contraction (dmk_eri_stack): the planes of several kL stay resident -- weight-2 slots from the front,
     weight-1 slots (Re halves only) from the back -- and one segmented-K GEMM per weight class and spin block contracts them;
     a full stack flushes by itself; the final contraction run band by band (dmk_eri_contract) gives the same ERI and leaves
     every finished band of rows complete.  Against the per-kL contraction of the same engine and the sampled oracle; hot
-    (nemb 256 / 136) and generic kernels (odd naux: the register-staged GEMM fallback with per-segment launches)."""
+    (nemb 256 / 136) and generic half-transform kernels.  Auxiliary dimensions off the K tile of the contraction kernel and odd
+    pair counts (naux 7, 21; nemb 41 -> 861 pairs): with the padded plane geometry of round 6 (pad = 1: zero rows up to a multiple
+    of 8, one zero column) they run on the LDS-DMA kernel with its symmetric launch; pad = 0 (DMK_ERI_PLANE_PAD=0) is the
+    unpadded layout of rounds 1 - 5 on the register-staged kernel with per-segment launches."""
     from libdmet_preview_amd.basis_transform import eri_transform as et
+    if not pad:
+        monkeypatch.setenv("DMK_ERI_PLANE_PAD", "0")
     mesh = (3, 2, 1)                                 # weights 1, 2, 0 mixed: 2 weight-1 and 2 weight-2 irreducible kL
     nk = 6
     npair = nemb * (nemb + 1) // 2
@@ -378,6 +384,53 @@ def test_off_tile_ao_dimension_takes_the_hot_path(ctx, mesh, nao, naux, nemb, sp
     A = sorted(set([0, 1, nemb // 3, nemb // 2, nemb - 2, nemb - 1]))
     worst = _run_and_check(ctx, mesh, nao, naux, nemb, spin, kls, A, seed=500 + nao, want_ring=True)
     assert worst < 1e-11
+
+
+@pytest.mark.parametrize("nao,naux,nemb,spin,rows", [(40, 100, 256, 2, 32), (27, 90, 72, 1, 37), (104, 48, 136, 1, 16)])
+def test_step1_in_ranges_of_L_is_bitwise_the_single_launch(ctx, nao, naux, nemb, spin, rows):
+    """An AO block of 4 GiB or more (naux nao^2 >= 2^28: nao 500 with naux 1100) exceeds the 32-bit lane offsets of the step-1
+    kernel's LDS-DMA addressing; up to round 5 such a system fell to the generic kernels.  Step 1 now runs in ranges of L
+    (half1_hot_max_rows).  DMK_ERI_HOT_LCHUNK forces the cut on small shapes: the ERI must be BIT-identical to the single launch
+    (every output row is computed by the same instructions either way), on and off the K tile, both step-2 kernels."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    mesh, nk = (3, 1, 1), 3
+    npair = nemb * (nemb + 1) // 2
+    nblk = spin * (spin + 1) // 2
+    rng = np.random.default_rng(nao * naux)
+    Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+    df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=5)
+
+    def run(cut):
+        if cut:
+            os.environ["DMK_ERI_HOT_LCHUNK"] = str(rows)
+        try:
+            eri_dev = ctx.zeros((nblk, npair, npair), np.float64)
+            eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, ctx.to_device(Ce), eri_dev, True)
+            try:
+                assert eng.ring_slots > 0
+                for kL in eng.irreducible_kL():
+                    eng.run_kL(kL, df)
+                ctx.sync()
+                return eri_dev.get()
+            finally:
+                eng.close()
+        finally:
+            os.environ.pop("DMK_ERI_HOT_LCHUNK", None)
+    a, b = run(False), run(True)
+    assert np.abs(a).max() > 0 and np.array_equal(a, b)
+    A = [0, nemb // 2, nemb - 1]
+    want, idx, _ = ES.eri_sample(mesh, 5, Ce, naux, A, [int(k) for k in range(nk) if ES.plan_records(mesh)[0][k] > 0])
+    for blk in range(nblk):
+        assert np.abs(b[blk][np.ix_(idx, idx)] - want[blk]).max() < 1e-8
+
+
+def test_ao_block_beyond_4_GiB_takes_the_hot_path(ctx):
+    """The real thing: nao 500, naux 1100 -- AO blocks of 4.4 GB, a ring of 70 GB -- two kL of a 2 x 1 x 1 mesh through the block
+    ring against the sampled oracle.  Skipped when the device has less than 120 GB free."""
+    free, _ = ctx.mem_info()
+    if free < 120 * (1 << 30):
+        pytest.skip("needs 120 GB of free device memory")
+    _run_and_check(ctx, (2, 1, 1), 500, 1100, 40, 1, [0, 1], [0, 19, 39], seed=77, check_planes=True, want_ring=True)
 
 
 @pytest.mark.parametrize("gen_stream", ["0", "1"])

@@ -1,6 +1,7 @@
 """Randomised campaign of the HOT kernels at production-like tile geometry (K6 step 1 wide / narrow tiles, K6 step 2 for nemb = 256, K6b the
 table-driven step 2 for any other embedding dimension, K7 the symmetric / rectangular contraction with its band cuts and mirrored
-stores): whole momentum transfers kL through the block ring on random shapes -- nao 16 .. 208 (multiples of 8), naux 32 .. 640,
+stores): whole momentum transfers kL through the block ring on random shapes -- nao 16 .. 208 (two in three OFF the K tile of 8: the
+zero-padded K loop of round 6), naux 32 .. 640,
 nemb 32 .. 320 (256 one time in three), one and two spin channels, meshes of 3 .. 8 k-points -- checked as
 tests/test_gpu_production.py checks C5 / C4: the Lij_s4 planes and the ERI on a sample of embedding-orbital pairs against the sampled
 C oracle (oracle/eri_sample.py: exact entries, all auxiliary rows), the Freivalds probe of the contraction on EVERY pair row, and the
@@ -22,6 +23,8 @@ for trial in range(trials):
         mesh = [(2, 2, 1), (3, 1, 1), (2, 2, 2), (3, 2, 1), (4, 1, 1), (5, 1, 1)][int(rng.integers(0, 6))]
         big = os.environ.get('STRESS_BIG') == '1'
         nao = 8 * int(rng.integers(2, 33 if big else 27))
+        if rng.random() < 0.67:
+            nao = max(16, nao - int(rng.integers(1, 8)))          # off the K tile
         naux = int(rng.integers(32, 1201 if big else 641))
         nemb = 256 if rng.random() < 0.33 else int(rng.integers(32, 449 if big else 321))
         spin = int(rng.integers(1, 3))
