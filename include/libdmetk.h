@@ -254,7 +254,11 @@ typedef struct dmk_eri dmk_eri;
  * imaginary part of the contraction when bit0 is clear (dmk_eri_imag_norm), bit2 = ROWS-ONLY pipeline: eri_out is ignored
  * (may be NULL), the planes are only taken through dmk_eri_contract_rows, and everything that would contract into an
  * internal ERI (dmk_eri_end_kL without a stack, dmk_eri_contract, a full stack at dmk_eri_begin_kL) returns
- * DMK_ERR_STATE; dmk_eri_finish drops planes still resident (eri_transform.py:486-521, the out-of-core branch). */
+ * DMK_ERR_STATE; dmk_eri_finish drops planes still resident (eri_transform.py:486-521, the out-of-core branch).
+ * Dimensions are free: an nao off the K tile of the hot kernels (8) makes the pipeline keep a zero-padded COPY of C_ao_emb, taken
+ * here (change C afterwards and it is not seen; on the tile C is read in place as before); naux off the contraction's K tile and
+ * an odd pair count are padded inside the pipeline's own plane buffers; AO blocks of 4 GiB and more are transformed in ranges of
+ * auxiliary rows.  None of it changes what the caller passes in or gets back. */
 int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, int spin,
                   int flags, const void *C_ao_emb, double *eri_out, dmk_eri **out);
 /* Start a momentum-transfer index kL (zeroes the Lij_s4 planes). */
@@ -342,8 +346,9 @@ int dmk_eri_bands(const dmk_eri *h, int *nbands, int *band_rows);
 int dmk_eri_contract_rows(dmk_eri *h, int64_t row_lo, int64_t row_hi, double *out);
 int dmk_eri_stack_clear(dmk_eri *h);
 int dmk_eri_stack_free_slots(const dmk_eri *h, int *free_slots);
-/* Device pointers of the current kL's Lij_s4 planes (spin x 2 x naux x npair f64:
- * Re plane then Im plane) for inspection / tests. */
+/* Device pointer of the current kL's Lij_s4 planes (spin x 2 x naux x npair f64:
+ * Re plane then Im plane) for inspection / tests: the planes themselves for dimensions on the tile, else a compact copy owned by
+ * the pipeline (valid until the next call or dmk_eri_finish) of its padded buffers. */
 int dmk_eri_planes(dmk_eri *h, double **planes_out, int64_t *elems_out);
 int dmk_eri_finish(dmk_eri *h);
 /* ALGORITHMIC flop counters of the work pushed so far:

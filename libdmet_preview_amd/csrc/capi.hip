@@ -835,7 +835,11 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
     // kernel covers the shape too, so a queued group can never be left without a kernel
     h->hot256 = half2_hot_usable(nao, nemb) != 0;
     if (const char *e = getenv("DMK_ERI_TAB256")) if (atoi(e) != 0) h->hot256 = false;      // route nemb = 256 through the table kernel
-    h->hot_rows = std::min(naux, half1_hot_max_rows(nao));
+    {   // ranges of L of equal length (a short last range would fall under the kernel's minimum launch size)
+        const int cap = std::max(1, std::min(naux, half1_hot_max_rows(nao)));
+        const int nranges = (naux + cap - 1) / cap;
+        h->hot_rows = (naux + nranges - 1) / nranges;
+    }
     if ((h->hot256 || half2_tab_usable(nao, nemb)) && half1_hot_usable(h->hot_rows, nao, nemb)) {
         h->lchunk = naux;
         h->group = h->hot256 ? 8 : 16;               // the table kernel cuts its queue into sub-group runs: a longer queue per launch
