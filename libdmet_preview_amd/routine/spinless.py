@@ -169,7 +169,8 @@ def _get_emb_basis_eig(lattice, rdm1, **kwargs):
     env_env = lattice.expand(rdm1)[env_idx][:, env_idx]
     ctx = get_ctx()
     d_w, d_Vt = ctx.empty((1, nenv), np.float64), ctx.empty((1, nenv, nenv), np.float64)
-    ctx.check(lib.dmk_eigh_batched_real(ctx.h, nenv, 1, ctx.to_device(env_env, np.float64).ptr, d_w.ptr, d_Vt.ptr))
+    d_A = ctx.to_device(env_env, np.float64)                # (named: alive until the read-back below)
+    ctx.check(lib.dmk_eigh_batched_real(ctx.h, nenv, 1, d_A.ptr, d_w.ptr, d_Vt.ptr))
     ew, Vt = d_w.get().reshape(nenv), d_Vt.get().reshape(nenv, nenv)
     keep = [i for i, e in enumerate(ew) if abs(e) > tol_bath and abs(1 - e) > tol_bath]
     log.debug(0, "dm eigenvalues:\n%s", ew[keep])
