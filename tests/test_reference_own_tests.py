@@ -138,3 +138,38 @@ def test_vcor_local():
     v = VcorLocal(False, True, 2)
     v.update(np.asarray([1, 2, 3, 4, 5, 6, 7, 8, 9, 10]))
     assert v.get().shape == (3, 2, 2) and np.array_equal(v.get()[2], [[7, 8], [9, 10]]) and v.gradient().shape == (10, 3, 2, 2)
+
+
+@pytest.mark.gpu
+def test_get_cderi_rhf_and_uhf():
+    """utils/test/test_cholesky.py:8-91 with a seeded positive semi-definite 4-fold ERI in place of the PySCF molecule: the vectors
+    of get_cderi_rhf rebuild the ERI (1e-7, the reference's bound), and get_cderi_uhf on (0.5 E, E, 0.05 E)... the reference's own
+    cross-check: the spin-blocked routine equals modified_cholesky of the assembled [[aa, ab], [ab^T, bb]] matrix."""
+    from libdmet_preview_amd.utils import cholesky
+    from oracle import restate as R
+    norb, rank = 7, 18
+    npair = norb * (norb + 1) // 2
+    rng = np.random.default_rng(8)
+    Lm = rng.standard_normal((rank, npair)) * np.exp(-0.25 * np.arange(rank))[:, None]
+    eri_s4 = Lm.T @ Lm
+    cd = cholesky.get_cderi_rhf(eri_s4, norb, tol=1e-8)
+    assert cd.shape[1:] == (norb, norb) and np.abs(cd - cd.transpose(0, 2, 1)).max() == 0.0
+    packed = np.asarray([R.pack_tril(x) for x in cd])
+    assert la.norm(packed.T @ packed - eri_s4) < 1e-7
+    # a valid spin-dependent triple: aa, bb positive semi-definite and ab = A^T B of the same factors
+    La = rng.standard_normal((rank, npair)) * np.exp(-0.3 * np.arange(rank))[:, None]
+    Lb = 0.6 * La + 0.8 * rng.standard_normal((rank, npair)) * np.exp(-0.3 * np.arange(rank))[:, None]
+    eri3 = [La.T @ La, Lb.T @ Lb, La.T @ Lb]
+    cu = cholesky.get_cderi_uhf(eri3, norb, tol=1e-8)
+    block = np.block([[eri3[0], eri3[2]], [eri3[2].T, eri3[1]]])
+    ev = cholesky.modified_cholesky(block, max_error=1e-8)
+    assert ev.shape[0] == cu.shape[1]
+    def unpack(t):
+        m = np.zeros((norb, norb))
+        m[np.tril_indices(norb)] = t
+        return m + np.tril(m, -1).T
+    ref = np.asarray([[unpack(v[:npair]) for v in ev], [unpack(v[npair:]) for v in ev]])
+    assert la.norm(cu[:, :-1] - ref[:, :-1]) < 1e-7                       # (the last vector of a rank-deficient matrix: rounding residue)
+    pa, pb = (np.asarray([R.pack_tril(x) for x in cu[s]]) for s in (0, 1))
+    assert max(la.norm(pa.T @ pa - eri3[0]), la.norm(pb.T @ pb - eri3[1]), la.norm(pa.T @ pb - eri3[2])) < 1e-7
+    assert np.array_equal(cholesky.modified_cholesky_uhf(eri3, max_error=1e-8)[:, :npair], pa)
