@@ -1045,7 +1045,13 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
             fock_k[s] += vcor_mat[s]
     if P_act is not None:
         log.info("active space fitting? True.")
-        P_act = get_active_projector_full(P_act, lattice.ovlp_lo_k)     # slater.py:1021-1023
+        ovlp_lo_k = getattr(lattice, "ovlp_lo_k", None)
+        if ovlp_lo_k is None:                                           # (an orthonormal LO basis that never installed an overlap)
+            ovlp_lo_k = lattice.get_ovlp(kspace=True)
+        ovlp_lo_k = np.asarray(ovlp_lo_k)
+        if ovlp_lo_k.ndim == 3 and len(P_act) > 1:                      # one overlap for both spin channels
+            ovlp_lo_k = np.asarray([ovlp_lo_k] * len(P_act))
+        P_act = get_active_projector_full(P_act, ovlp_lo_k)             # slater.py:1021-1023
     # fitted index sets (slater.py:985-1005)
     if imp_fit:
         imp_idx, det_idx = list(range(lattice.nimp)), []
