@@ -58,6 +58,11 @@ if __name__ == "__main__":
         for nao, naux, nemb, spin in ((26, 110, 40, 1), (52, 230, 72, 2), (78, 330, 100, 1), (104, 416, 136, 2), (130, 560, 180, 1),
                                      (150, 640, 200, 2), (203, 811, 250, 2), (203, 811, 300, 1), (260, 1040, 330, 1), (300, 1210, 400, 1)):
             run((4, 4, 2) if nao <= 104 else (3, 3, 2), nao, naux, nemb, spin)
+    if "tab" in which:
+        # the table-driven step 2 over embedding dimensions (DMK_ERI_TAB_SEG / DMK_ERI_TAB256 are read when the table is built:
+        # one process per setting)
+        for nemb in (200, 208, 224, 240, 250, 256, 272, 300, 330, 400):
+            run((2, 2, 2), 200, 800, nemb, 1)
     if "c4" in which:
         for nao in (104, 100, 101, 107):
             run((4, 4, 4), nao, 416, 136, 1)
