@@ -51,6 +51,12 @@ _FUNCTIONS = [
     ("routine.slater_helper", ["routine.slater_helper", "routine.slater"],
      ["transform_trans_inv", "transform_trans_inv_k", "transform_local", "transform_imp", "transform_imp_env",
       "transform_4idx", "transform_eri_local", "unit2emb"]),
+    # round 6: the idempotent projection and the active-space projector of the fit, the finite-T single-matrix mean field and its
+    # response formulas, the Cholesky vectors behind convert_eri_to_gdf
+    ("routine.slater_helper", ["routine.slater_helper", "routine.slater"], ["get_rdm1_idem"]),
+    ("routine.slater", ["routine.slater"], ["get_active_projector_full"]),
+    ("routine.ftsystem", ["routine.ftsystem"], ["kernel", "make_rdm1", "get_rho_grad", "get_dw_dv"]),
+    ("utils.cholesky", ["utils.cholesky"], ["modified_cholesky", "modified_cholesky_uhf", "get_cderi_rhf", "get_cderi_uhf"]),
     # BCS twin (routine/bcs.py:13 star-imports bcs_helper)
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
