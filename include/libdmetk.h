@@ -383,6 +383,10 @@ int dmk_df_block_philox(dmk_ctx *ctx, uint64_t seed, int ki, int kj, int naux, i
  * 2 n + 2.  Pivots (first maximum of |residual diagonal|) and vectors follow the host loop operation by operation. */
 int dmk_modified_cholesky(dmk_ctx *ctx, int n, int uhf, const double *m_aa, const double *m_bb, const double *m_ab, double max_error,
                           int max_vecs, double *vecs, int32_t *nvec_out, int32_t *exhausted_out);
+/* Pivots of a column-pivoted QR (largest residual norm first; first index on ties) of the matrix whose COLUMNS are the rows of `cols`
+ * (ncol x vlen f64, device): the column selection of SCDM, lo/scdm.py:134 `la.qr(psiT, pivoting=True)` of which scdm_model keeps
+ * perm[:nmo] (routine/localizer.py:98-105 localize_bath_scdm).  piv_out: host, npiv indices. */
+int dmk_cpqr_pivots(dmk_ctx *ctx, int ncol, int vlen, const double *cols, int npiv, int32_t *piv_out);
 
 /* a14: 4-fold (npair x npair) -> 1-fold (nemb^4) / 8-fold restore
  * (eri_transform.py:523-544 -> pyscf ao2mo.restore). */

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "dmk_eri_to_s4": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_sym_norm_bound": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "dmk_modified_cholesky": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_dbl, c_int, c_vp, P(c_int), P(c_int)]),
+    "dmk_cpqr_pivots": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "dmk_dgemv2": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "dmk_dgemm_batched": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_dbl, c_vp, c_i64, c_i64, c_vp, c_i64,
                                   c_i64, c_dbl, c_vp, c_i64, c_i64]),

@@ -133,9 +133,81 @@ __global__ __launch_bounds__(CH_NT) void modified_cholesky_kernel(const CholArgs
     if (tid == 0) { g.out[0] = nvec; g.out[1] = exhausted; }
 }
 
+// Column-pivoted QR, pivots only (Businger-Golub: at every step the column with the largest residual norm) -- the column
+// selection of SCDM (lo/scdm.py:116-150 scdm_model: `la.qr(psiT, pivoting=True)` of the bath orbitals, of which only perm[:nmo] is
+// used; LAPACK dgeqp3 picks by the same rule, first index on ties).  The "columns" are the ROWS of the caller's (ncol x vlen)
+// array (psiT = B^T: column j of psiT is site j of the bath orbitals B).  Residuals by modified Gram-Schmidt against the chosen
+// directions, their norms recomputed exactly at every step (no downdating: ncol vlen npiv flop, 0.5 GFLOP at C5 sizes, one CU).
+__global__ __launch_bounds__(CH_NT) void cpqr_pivots_kernel(int ncol, int vlen, const double *__restrict__ cols, int npiv, double *R,
+                                                            double *nrm, int *piv) {
+    __shared__ double shv[CH_NT / 64];
+    __shared__ int shi[CH_NT / 64];
+    extern __shared__ double q[];                       // the current direction, vlen doubles
+    const int tid = threadIdx.x;
+    for (int j = tid; j < ncol; j += CH_NT) {
+        double s = 0.0;
+        for (int k = 0; k < vlen; ++k) {
+            const double v = cols[(long long)j * vlen + k];
+            R[(long long)j * vlen + k] = v;
+            s += v * v;
+        }
+        nrm[j] = s;
+    }
+    __syncthreads();
+    for (int t = 0; t < npiv; ++t) {
+        double best = -INFINITY;
+        int idx = 0x7fffffff;
+        for (int j = tid; j < ncol; j += CH_NT)
+            if (argmax_takes(nrm[j], j, best, idx)) { best = nrm[j]; idx = j; }     // chosen columns carry -1
+        block_argmax(best, idx, shv, shi);
+        idx = min(idx, ncol - 1);
+        if (tid == 0) piv[t] = idx;
+        const double inv = best > 0.0 ? 1.0 / sqrt(best) : 0.0;
+        for (int k = tid; k < vlen; k += CH_NT) q[k] = R[(long long)idx * vlen + k] * inv;
+        __syncthreads();
+        for (int j = tid; j < ncol; j += CH_NT) {
+            double *r = R + (long long)j * vlen;
+            if (j == idx) { nrm[j] = -1.0; continue; }
+            if (nrm[j] < 0.0) continue;
+            double dot = 0.0;
+            for (int k = 0; k < vlen; ++k) dot += q[k] * r[k];
+            double s = 0.0;
+            for (int k = 0; k < vlen; ++k) {
+                const double v = r[k] - dot * q[k];
+                r[k] = v;
+                s += v * v;
+            }
+            nrm[j] = s;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dmk_cpqr_pivots(dmk_ctx *ctx, int ncol, int vlen, const double *cols, int npiv, int32_t *piv_out) {
+    if (!ctx) return DMK_ERR_INVALID;
+    if (ncol < 1 || vlen < 1 || vlen > 4096 || npiv < 0 || npiv > ncol || !cols || (npiv > 0 && !piv_out))
+        return dmk_fail(ctx, DMK_ERR_INVALID, "cpqr_pivots: bad arguments (1 <= vector length <= 4096, npiv <= ncol)");
+    if (npiv == 0) return DMK_OK;
+    void *ws = nullptr;
+    const size_t rbytes = (size_t)ncol * vlen * sizeof(double), nbytes = (size_t)ncol * sizeof(double);
+    int rc = dmk_scratch(ctx, rbytes + nbytes + (size_t)npiv * sizeof(int) + 256, &ws);
+    if (rc) return rc;
+    double *R = static_cast<double *>(ws), *nrm = R + (size_t)ncol * vlen;
+    int *piv = reinterpret_cast<int *>(nrm + ncol);
+    {
+        FamScope fs(ctx, DMK_FAM_MISC);
+        hipLaunchKernelGGL(cpqr_pivots_kernel, dim3(1), dim3(CH_NT), (size_t)vlen * sizeof(double), ctx->stream, ncol, vlen, cols, npiv, R,
+                           nrm, piv);
+        DMK_CHECK_LAUNCH(ctx);
+    }
+    DMK_HIP(ctx, hipMemcpyAsync(piv_out, piv, (size_t)npiv * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DMK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DMK_OK;
+}
 
 int dmk_modified_cholesky(dmk_ctx *ctx, int n, int uhf, const double *m_aa, const double *m_bb, const double *m_ab, double max_error,
                           int max_vecs, double *vecs, int32_t *nvec_out, int32_t *exhausted_out) {

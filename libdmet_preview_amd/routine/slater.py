@@ -138,8 +138,7 @@ def _get_emb_basis_svd(lattice, rdm1, **kwargs):
     orth = kwargs.get("orth", True)
     tol_bath = kwargs.get("tol_bath", 1e-9)
     nbath = kwargs.get("nbath", None)
-    if kwargs.get("localize_bath", None) is not None:
-        raise NotImplementedError("localize_bath is outside the HIP path")
+    loc_method = kwargs.get("localize_bath", None)
 
     ncells, nlo = lattice.ncells, lattice.nscsites
     imp_idx = list(imp_idx)
@@ -176,6 +175,13 @@ def _get_emb_basis_svd(lattice, rdm1, **kwargs):
         d_basis = ctx.empty((nsites, ncol), np.float64)
         bath_assemble_dev(ctx, d_U, nenv, nb, nbath_s, d_virt, orth, d_env, d_imp, nimp, nsites, ncol, d_basis)
         basis[s] = d_basis.get()
+        if loc_method is not None and nbath_s > 0:
+            # localisation of the (orthonormalised) bath columns (slater.py:204-210, routine/localizer.py)
+            from libdmet_preview_amd.routine import localizer
+            if not lattice.is_model:
+                log.warn("Only model is currently supported for localization of bath.")
+            cols = np.arange(nimp, nimp + nbath_s)
+            basis[s][np.ix_(env_idx, cols)] = localizer.localize_bath(basis[s][np.ix_(env_idx, cols)], method=loc_method)
         nbath_final = min(nbath_final, nbath_s)
     log.debug(0, "nimp : %d", nimp)
     log.debug(0, "nbath: %d", nbath_final)

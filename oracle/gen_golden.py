@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1369,6 +1369,33 @@ def gen_G21():
         out["opt/%s_x0" % tag] = x0
     np.savez_compressed(os.path.join(GOLD, "G21_fit_options.npz"), **out)
     print("G21 done", {k: out[k] for k in out if k.endswith("/err") or k.endswith("_res")})
+
+def gen_G22():
+    """SCDM localisation of bath orbitals (routine/localizer.py:27-38, 98-105 over lo/scdm.py:116-150 scdm_model): the reference's own
+    control flow with the two PySCF primitives it calls restated in oracle/shim.py (pyscf.lo.vec_lowdin, pyscf.tools.mo_mapping.
+    mo_1to1map; PySCF >= 2.0 is the reference's pin and is absent here) -- on seeded orthonormal orbital sets, and through
+    slater.get_emb_basis(localize_bath='scdm') on the generic lattice of G4 (unrestricted, valence bath with virtuals)."""
+    loc = shim.patch_scdm()
+    from libdmet.routine import slater, mfd
+    out = {}
+    for name, nsite, nb, seed in (("a", 30, 5, 1), ("b", 96, 12, 2), ("c", 400, 33, 3)):
+        rng = np.random.default_rng(seed)
+        A = rng.standard_normal((nsite, nb)) * np.exp(-0.05 * rng.permutation(nsite))[:, None]      # uneven weight over the sites
+        B = np.linalg.qr(A)[0]
+        out[name + "/B"] = B
+        out[name + "/B_scdm"] = loc.localize_bath(B, "scdm")
+    mesh, nlo = (2, 2, 2), 7
+    Lg = _duck_lattice(mesh, nlo, val=[1, 2, 3], virt=[4, 5], core=[0])
+    Lg.is_model = True
+    FR = synth.make_fock_R(mesh, nlo, spin=2, seed=77)
+    Lg.fock_lo_k = Lg.hcore_lo_k = synth.fold_R2k(FR, mesh)
+    Lg.fock_lo_R = Lg.hcore_lo_R = FR
+    rhoT, mu, E = mfd.HF(Lg, _Vcor(np.zeros((2, nlo, nlo))), 0.45, False, beta=np.inf)
+    out["gen/Fock_R"], out["gen/rhoT"] = FR, rhoT
+    out["gen/basis_svd_scdm"] = slater.get_emb_basis(Lg, rhoT, localize_bath="scdm")
+    out["gen/basis_svd_scdm_fullbath"] = slater.get_emb_basis(Lg, rhoT, valence_bath=False, localize_bath="scdm")
+    np.savez_compressed(os.path.join(GOLD, "G22_scdm_bath.npz"), **out)
+    print("G22 done", {k: out[k].shape for k in out})
 
 
 if __name__ == "__main__":

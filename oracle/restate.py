@@ -634,8 +634,31 @@ def vec_lowdin(c, s=None):
     return np.dot(c, _lowdin(m))
 
 
+def localize_bath_scdm(B):
+    """routine/localizer.py:98-105 over lo/scdm.py:116-150 (scdm_model, Loewdin flavour): the bath orbitals rotated onto the
+    columns a pivoted QR of B^T selects.  PySCF's vec_lowdin / mo_1to1map restated (the Loewdin metric keeps eigenvalues > 1e-15;
+    every row takes the column of its largest |entry| that is still free)."""
+    B = np.asarray(B)
+    shape = B.shape
+    orb = B.reshape(-1, shape[-1])
+    nb = orb.shape[1]
+    psiT = orb.conj().T
+    _, _, perm = la.qr(psiT, pivoting=True)
+    M = psiT[:, perm[:nb]]
+    e, v = la.eigh(M.conj().T @ M)
+    keep = e > 1e-15
+    rot = M @ ((v[:, keep] / np.sqrt(e[keep])) @ v[:, keep].conj().T)
+    s1 = np.abs(rot.copy())
+    order = []
+    for i in range(nb):
+        k = int(np.argmax(s1[i]))
+        order.append(k)
+        s1[:, k] = 0
+    return (orb @ rot[:, order]).reshape(shape)
+
+
 def get_emb_basis(kmesh, nlo, rdm1, imp_idx, val_idx, kind="svd", valence_bath=True,
-                  orth=True, tol_bath=1e-9, nbath=None, return_info=False):
+                  orth=True, tol_bath=1e-9, nbath=None, return_info=False, localize_bath=None):
     """
     routine/slater.py:98-220 (svd) and :224-318 (eig).  `lattice` is replaced by
     (kmesh, nlo, imp_idx, val_idx); lattice.expand by CellArith.expand.
@@ -676,6 +699,9 @@ def get_emb_basis(kmesh, nlo, rdm1, imp_idx, val_idx, kind="svd", valence_bath=T
             if nbath_s > 0 and orth:
                 B[virt_mask] = 0.0
                 B = vec_lowdin(B)
+            if nbath_s > 0 and localize_bath is not None:           # slater.py:204-210
+                assert localize_bath == "scdm"
+                B = localize_bath_scdm(B)
             basis[s, imp_idx, :nimp] = np.eye(nimp)
             basis[s, env_idx, nimp:nimp + nbath_s] = B
             nbath_final = min(nbath_final, nbath_s)

@@ -245,6 +245,43 @@ def patch_scf():
     return rscf
 
 
+def pyscf_vec_lowdin(c, s=1):
+    """pyscf.lo.orth.vec_lowdin / lowdin (PySCF >= 2.0, the pin of the reference's pyproject.toml; absent here): Loewdin
+    orthonormalisation c (c^H s c)^(-1/2) with eigenvalues <= 1e-15 of the metric dropped."""
+    c = np.asarray(c)
+    m = c.conj().T.dot(c) if np.isscalar(s) and s == 1 else c.conj().T.dot(s).dot(c)
+    e, v = np.linalg.eigh(m)
+    keep = e > 1e-15
+    return c.dot((v[:, keep] / np.sqrt(e[keep])).dot(v[:, keep].conj().T))
+
+
+def pyscf_mo_1to1map(s):
+    """pyscf.tools.mo_mapping.mo_1to1map: for every row i of |<i|j>| the column of its largest entry, columns used once."""
+    s1 = abs(np.array(s, copy=True))
+    out = []
+    for i in range(s1.shape[0]):
+        k = int(np.argmax(s1[i]))
+        out.append(k)
+        s1[:, k] = 0
+    return out
+
+
+def patch_scdm():
+    """Bind the two PySCF primitives libdmet.lo.scdm.scdm_model needs (lo/scdm.py:116-150) and return libdmet.routine.localizer."""
+    install()
+    from libdmet.lo import scdm as rscdm
+
+    class _lo(object):
+        vec_lowdin = staticmethod(pyscf_vec_lowdin)
+
+    class _mm(object):
+        mo_1to1map = staticmethod(pyscf_mo_1to1map)
+    rscdm.lo = _lo
+    rscdm.mo_mapping = _mm
+    from libdmet.routine import localizer
+    return localizer
+
+
 def quiet():
     from libdmet.utils import logger as log
     log.verbose = "RESULT"

@@ -1102,3 +1102,38 @@ def test_bath_with_fixed_nbath_beyond_the_rank(ctx):
     ref = R.get_emb_basis(mesh, nlo, rdm1, imp_idx=[0, 1], val_idx=[0, 1], nbath=2, valence_bath=False)
     Bref = ref[0].reshape(-1, ref.shape[-1])
     assert abs(abs(Bref[nlo:, nlo] @ u) - 1.0) < 1e-12
+
+
+def test_G22_scdm_bath_localisation(ctx, golden):
+    """routine/localizer.localize_bath('scdm') on the device (dmk_cpqr_pivots + Loewdin + one product) against the reference's
+    output (golden G22), directly and through slater.get_emb_basis(localize_bath='scdm'); 'pm' needs PySCF's optimiser and raises."""
+    from libdmet_preview_amd.routine import slater, localizer
+    from tests.test_oracle_golden import _match_columns
+    g = golden("G22_scdm_bath.npz")
+    for name in ("a", "b", "c"):
+        B, ref = g[name + "/B"], g[name + "/B_scdm"]
+        got = localizer.localize_bath(B, "scdm")
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-10
+        # pivots agree with the column-pivoted QR of LAPACK on these (generic) orbitals
+        import scipy.linalg as sla
+        _, _, perm = sla.qr(B.T, pivoting=True)
+        import ctypes as C
+        from libdmet_preview_amd._lib import lib
+        piv = np.zeros(B.shape[1], dtype=np.int32)
+        d_B = ctx.to_device(np.ascontiguousarray(B))
+        ctx.check(lib.dmk_cpqr_pivots(ctx.h, B.shape[0], B.shape[1], d_B.ptr, B.shape[1], piv.ctypes.data_as(C.c_void_p)))
+        assert list(piv) == [int(x) for x in perm[:B.shape[1]]]
+    rho = g["gen/rhoT"]
+    Lg = _lattice((2, 2, 2), 7, val=[1, 2, 3], virt=[4, 5], core=[0])
+    Lg.is_model = True
+    for key, extra in (("basis_svd_scdm", {}), ("basis_svd_scdm_fullbath", {"valence_bath": False})):
+        bb = slater.get_emb_basis(Lg, rho, localize_bath="scdm", **extra)
+        ref = g["gen/" + key]
+        assert bb.shape == ref.shape and np.linalg.norm(_proj(bb) - _proj(ref)) < 1e-10
+        for s in range(bb.shape[0]):
+            err, _ = _match_columns(ref[s].reshape(-1, ref.shape[-1]), bb[s].reshape(-1, bb.shape[-1]))
+            assert err < 1e-8
+    with pytest.raises(NotImplementedError):
+        slater.get_emb_basis(Lg, rho, localize_bath="pm")
+    with pytest.raises(ValueError):
+        slater.get_emb_basis(Lg, rho, localize_bath="nope")

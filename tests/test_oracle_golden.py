@@ -248,3 +248,35 @@ def test_G15_eri_general_k_lists(golden, case, spin):
         assert np.abs(e - ref).max() < 1e-10 * np.abs(ref).max()
         if not tr:
             assert abs(im - float(g[st + "/imag_norm"])) < 1e-10 * float(g[st + "/imag_norm"])
+
+
+def _match_columns(a, b):
+    """Columns of b permuted to line up with those of a (largest overlap, every column once); max |a - b_perm|."""
+    ov = np.abs(a.T @ b)
+    perm = []
+    for i in range(a.shape[1]):
+        k = int(np.argmax(ov[i]))
+        perm.append(k)
+        ov[:, k] = -1.0
+    return np.abs(a - b[:, perm]).max(), perm
+
+
+def test_G22_scdm_bath(golden):
+    """routine/localizer.py localize_bath('scdm') restated (oracle/restate.py localize_bath_scdm) against the reference's output,
+    directly and inside get_emb_basis (the SVD gauge of the bath only permutes the localised columns: B rot is invariant)."""
+    g = golden("G22_scdm_bath.npz")
+    for name in ("a", "b", "c"):
+        B, ref = g[name + "/B"], g[name + "/B_scdm"]
+        got = R.localize_bath_scdm(B)
+        assert np.abs(got - ref).max() < 1e-11
+        assert np.abs(got.T @ got - np.eye(B.shape[1])).max() < 1e-12
+        assert (got ** 2).max(axis=0).min() > (B ** 2).max(axis=0).min()           # more weight on single sites than before
+    rho = g["gen/rhoT"]
+    kw = dict(imp_idx=[1, 2, 3, 4, 5], val_idx=[1, 2, 3])
+    for key, extra in (("basis_svd_scdm", {}), ("basis_svd_scdm_fullbath", {"valence_bath": False})):
+        bb = R.get_emb_basis((2, 2, 2), 7, rho, localize_bath="scdm", **kw, **extra)
+        ref = g["gen/" + key]
+        assert bb.shape == ref.shape and np.abs(_proj(bb) - _proj(ref)).max() < 1e-10
+        for s in range(bb.shape[0]):
+            err, _ = _match_columns(ref[s].reshape(-1, ref.shape[-1]), bb[s].reshape(-1, bb.shape[-1]))
+            assert err < 1e-9
