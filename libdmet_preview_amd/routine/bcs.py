@@ -27,14 +27,19 @@ def embBasis(lattice, GRho, local=True, **kwargs):
 get_emb_basis = embBasis
 
 
-def emb_basis_proj_dev(ctx, kmesh, ncells, nscsites, val_idx, d_GRho):
-    """Device form: d_GRho (ncells, 2n, 2n) f64 -> d_basis (2, ncells, 2n, n+nval), sigma, w, order, d_U."""
+def emb_basis_proj_dev(ctx, kmesh, ncells, nscsites, val_idx, d_GRho, localize_bath=None):
+    """Device form: d_GRho (ncells, 2n, 2n) f64 -> d_basis (2, ncells, 2n, n+nval), sigma, w, order, d_U.  `localize_bath`: the
+    bath orbitals are rotated by routine/localizer.localize_bath between the SVD and the particle weights (bcs.py:84-88)."""
     n, nval = int(nscsites), len(val_idx)
     nenv, nb = (ncells - 1) * 2 * n, 2 * nval
     cols = np.asarray(list(val_idx) + [i + n for i in val_idx], dtype=np.int32)
     env = np.arange(2 * n, 2 * n * ncells, dtype=np.int32)
     d_sigma, d_U = bath_svd_dev(ctx, kmesh, 2 * n, d_GRho, ctx.to_device(env), nenv, ctx.to_device(cols), nb)
     complete_null_columns(ctx, d_sigma.get().reshape(-1)[:nb], d_U, nenv, nb)     # bcs.py:46, 84: every column is kept
+    if localize_bath is not None:
+        from libdmet_preview_amd.routine import localizer
+        d_U.set(np.ascontiguousarray(localizer.localize_bath(d_U.get().reshape(ncells - 1, 2 * n, nb), method=localize_bath)
+                                     .reshape(nenv, nb)))
     d_w = ctx.empty((nb,), np.float64)
     ctx.check(lib.dmk_bcs_weight(ctx.h, ncells - 1, 2 * n, n, nb, d_U.ptr, d_w.ptr))
     w = d_w.get()
@@ -50,13 +55,14 @@ def _embBasis_proj(lattice, GRho, **kwargs):
     if "sites" in kwargs:
         # the reference's "sites" branch reads an undefined name (bcs.py:44-45) and cannot run
         raise NotImplementedError('keyword "sites" is not supported')
-    if kwargs.get("localize_bath", None) is not None:
-        raise NotImplementedError("localize_bath is outside the HIP path")
+    loc_method = kwargs.get("localize_bath", None)
+    if loc_method is not None:
+        log.eassert(lattice.is_model, "Only model is currently supported for localization of bath.")
     GRho = np.ascontiguousarray(np.asarray(GRho).real, dtype=np.float64)
     log.eassert(GRho.shape == (ncells, 2 * nscsites, 2 * nscsites), "GRho must be (ncells, 2*nscsites, 2*nscsites)")
     ctx = get_ctx()
     d_basis, sigma, w, order, d_U = emb_basis_proj_dev(ctx, lattice.kmesh, ncells, nscsites, lattice.val_idx,
-                                                       ctx.to_device(GRho))
+                                                       ctx.to_device(GRho), localize_bath=loc_method)
     log.debug(0, "Zero singular values number: %s", np.sum(np.abs(sigma) < 1e-8))
     log.debug(1, "Singular values:\n%s", sigma)
     w1 = w[order]

@@ -129,6 +129,20 @@ def _gso_index_sets(lattice, valence_bath):
     return imp_idx, imp_idx_bath, env_idx, virt_mask
 
 
+def _localize_assembled(ctx, lattice, d_basis, env_idx, nimp, nbath, method):
+    """Localisation of the orthonormalised bath columns of an assembled basis (spinless.py:139-146, 248-255): the env x bath block
+    goes through routine/localizer.localize_bath and back before the particle-hole sorting."""
+    from libdmet_preview_amd.routine import localizer
+    if not lattice.is_model:
+        log.warn("Only model is currently supported for localization of bath.")
+    if nbath == 0:
+        return
+    basis = d_basis.get()
+    cols = np.arange(nimp, nimp + nbath)
+    basis[np.ix_(env_idx, cols)] = localizer.localize_bath(basis[np.ix_(env_idx, cols)], method=method)
+    d_basis.set(basis)
+
+
 def _order_by_particle_character(ctx, d_basis, ncells, nso, nlo, nimp, nbath):
     """Bath columns ordered by their weight on the alpha rows, descending, stable (spinless.py:147-154): returns the host basis."""
     ncol = nimp + nbath
@@ -155,8 +169,7 @@ def _get_emb_basis_eig(lattice, rdm1, **kwargs):
     tol_bath = kwargs.get("tol_bath", 1e-9)
     if not kwargs.get("orth", True):
         raise NotImplementedError
-    if kwargs.get("localize_bath", None) is not None:
-        raise NotImplementedError("localize_bath is outside the HIP path")
+    loc_method = kwargs.get("localize_bath", None)
     ncells, nlo = lattice.ncells, lattice.nscsites
     nso = nlo * 2
     imp_idx, imp_idx_bath, env_idx, virt_mask = _gso_index_sets(lattice, valence_bath)
@@ -182,6 +195,8 @@ def _get_emb_basis_eig(lattice, rdm1, **kwargs):
     d_basis = ctx.empty((ncells * nso, ncol), np.float64)
     d_U = ctx.to_device(np.ascontiguousarray(Vt[keep].T) if nbath else np.zeros((nenv, 1)), np.float64)
     bath_assemble_dev(ctx, d_U, nenv, max(nbath, 1), nbath, d_virt, True, d_env, d_imp, nimp, ncells * nso, ncol, d_basis)
+    if loc_method is not None:
+        _localize_assembled(ctx, lattice, d_basis, env_idx, nimp, nbath, loc_method)
     basis = _order_by_particle_character(ctx, d_basis, ncells, nso, nlo, nimp, nbath)
     log.debug(0, "nimp : %d", nimp)
     log.debug(0, "nbath: %d", nbath)
@@ -222,8 +237,7 @@ def _get_emb_basis_svd(lattice, rdm1, **kwargs):
     nbath = kwargs.get("nbath", None)
     if not orth:
         raise NotImplementedError
-    if kwargs.get("localize_bath", None) is not None:
-        raise NotImplementedError("localize_bath is outside the HIP path")
+    loc_method = kwargs.get("localize_bath", None)
     ncells, nlo = lattice.ncells, lattice.nscsites
     nso = nlo * 2
     val_idx = list(lattice.val_idx) + [i + nlo for i in lattice.val_idx]
@@ -251,6 +265,8 @@ def _get_emb_basis_svd(lattice, rdm1, **kwargs):
     d_virt, d_imp = ctx.to_device(virt_mask), ctx.to_device(np.asarray(imp_idx, dtype=np.int32))
     d_basis = ctx.empty((ncells * nso, ncol), np.float64)
     bath_assemble_dev(ctx, d_U, nenv, nb, nbath, d_virt, True, d_env, d_imp, nimp, ncells * nso, ncol, d_basis)
+    if loc_method is not None:
+        _localize_assembled(ctx, lattice, d_basis, env_idx, nimp, nbath, loc_method)
     # particle character of every column: weight on the alpha rows (the bath columns vanish on non-env rows)
     d_w = ctx.empty((ncol,), np.float64)
     ctx.check(lib.dmk_bcs_weight(ctx.h, ncells, nso, nlo, ncol, d_basis.ptr, d_w.ptr))

@@ -1394,6 +1394,17 @@ def gen_G22():
     out["gen/Fock_R"], out["gen/rhoT"] = FR, rhoT
     out["gen/basis_svd_scdm"] = slater.get_emb_basis(Lg, rhoT, localize_bath="scdm")
     out["gen/basis_svd_scdm_fullbath"] = slater.get_emb_basis(Lg, rhoT, valence_bath=False, localize_bath="scdm")
+    # the BCS (Nambu) and GSO baths with the localisation between the SVD / orthogonalisation and the particle-hole sorting
+    # (routine/bcs.py:82-88, routine/spinless.py:139-146, 248-255), on the generalised density matrices of G7
+    from libdmet.routine import bcs, spinless
+    g7 = np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        L.is_model = True
+        GRho = g7[name + "/GRho"]
+        out[name + "/bcs_scdm"] = bcs.embBasis(L, GRho, localize_bath="scdm")
+        for kind in ("svd", "eig"):
+            out["%s/gso_%s_scdm" % (name, kind)] = spinless.get_emb_basis(L, GRho, kind=kind, localize_bath="scdm")
     np.savez_compressed(os.path.join(GOLD, "G22_scdm_bath.npz"), **out)
     print("G22 done", {k: out[k].shape for k in out})
 

@@ -309,8 +309,9 @@ def get_dV_dparam(basis, nparam):
 # a8: BCS embedding basis (routine/bcs.py:25-135)
 # ---------------------------------------------------------------------------------------------
 
-def embBasis_proj(GRho, nscsites, val_idx):
-    """bcs.py:78-104 (the branch without "sites").  Returns basis, sigma, B."""
+def embBasis_proj(GRho, nscsites, val_idx, localize_bath=None):
+    """bcs.py:78-104 (the branch without "sites").  Returns basis, sigma, B.  `localize_bath='scdm'`: the bath orbitals rotated by
+    routine/localizer.localize_bath between the SVD and the particle-weight sorting (bcs.py:84-88)."""
     ncells = GRho.shape[0]
     n, nval = nscsites, len(val_idx)
     basis = np.zeros((2, ncells, 2 * n, n + nval))
@@ -318,6 +319,10 @@ def embBasis_proj(GRho, nscsites, val_idx):
     A = GRho[1:].reshape(n * (ncells - 1) * 2, 2 * n)[:, cols]
     u, sigma, vt = la.svd(A, full_matrices=False)
     B = u.reshape((ncells - 1, 2 * n, 2 * nval))
+    if localize_bath is not None:
+        assert localize_bath == "scdm"
+        from oracle.restate import localize_bath_scdm
+        B = localize_bath_scdm(B)
     basis[0, 0, :n, :n] = np.eye(n)
     basis[1, 0, :n, :n] = np.eye(n)
     w = np.diag(np.tensordot(B[:, :n], B[:, :n], axes=((0, 1), (0, 1))))

@@ -21,8 +21,9 @@ from oracle.restate import (KPT_DIFF_TOL, add_spin_dim, eri_restore, get_basis_k
                             kpt_member, max_abs, multiply_basis, pack_tril, transform_ao_to_emb, vec_lowdin)
 
 
-def get_emb_basis_gso(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9, nbath=None):
-    """routine/spinless.py:58-163 (orth = True)."""
+def get_emb_basis_gso(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9, nbath=None, localize_bath=None):
+    """routine/spinless.py:58-163 (orth = True); `localize_bath='scdm'` rotates the orthonormalised bath before the particle-hole
+    sorting (:139-146)."""
     rdm1 = np.asarray(rdm1)
     ncells, nso, _ = rdm1.shape
     assert nso == 2 * nlo
@@ -47,6 +48,10 @@ def get_emb_basis_gso(rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1
     B = u[:, :nbath].copy()
     B[np.asarray(virt)] = 0.0
     B = vec_lowdin(B)
+    if localize_bath is not None:
+        assert localize_bath == "scdm"
+        from oracle.restate import localize_bath_scdm
+        B = localize_bath_scdm(B)
     w = np.einsum("ai,ai->i", B[np.asarray(alpha)], B[np.asarray(alpha)])
     order = np.argsort(w, kind="mergesort")[::-1]
     basis = np.zeros((ncells * nso, nimp + nbath))
@@ -75,7 +80,7 @@ def _gso_index_sets(ncells, nlo, val_idx, imp_idx, valence_bath):
     return imp2, bath_cols, env, np.asarray(virt, dtype=bool), np.asarray(alpha, dtype=bool), virt_idx
 
 
-def get_emb_basis_gso_eig(kmesh, rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9):
+def get_emb_basis_gso_eig(kmesh, rdm1, nlo, val_idx, imp_idx, valence_bath=True, tol_bath=1e-9, localize_bath=None):
     """routine/spinless.py:166-275 (kind = 'eig', orth = True): eigenvectors of the env-env block of the generalised density
     matrix whose eigenvalues are neither 0 nor 1 (lattice.expand restated by CellArith.expand)."""
     rdm1 = np.asarray(rdm1)
@@ -91,6 +96,10 @@ def get_emb_basis_gso_eig(kmesh, rdm1, nlo, val_idx, imp_idx, valence_bath=True,
     assert nbath % 2 == 0
     B[virt] = 0.0
     B = vec_lowdin(B)
+    if localize_bath is not None:
+        assert localize_bath == "scdm"
+        from oracle.restate import localize_bath_scdm
+        B = localize_bath_scdm(B)
     w = np.einsum("ai,ai->i", B[alpha], B[alpha])
     order = np.argsort(w, kind="mergesort")[::-1]
     basis = np.zeros((ncells * nso, nimp + nbath))

@@ -280,3 +280,24 @@ def test_G22_scdm_bath(golden):
         for s in range(bb.shape[0]):
             err, _ = _match_columns(ref[s].reshape(-1, ref.shape[-1]), bb[s].reshape(-1, bb.shape[-1]))
             assert err < 1e-9
+
+
+@pytest.mark.parametrize("name,mesh,n,val", [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])])
+def test_G22_scdm_in_the_bcs_and_gso_baths(golden, name, mesh, n, val):
+    """bcs.embBasis / spinless.get_emb_basis with localize_bath='scdm' restated against the reference's outputs: the localisation sits
+    between the SVD (or the orthogonalisation) and the particle-hole sorting (bcs.py:84-88, spinless.py:139-146, 248-255)."""
+    from oracle import restate_bcs as Bc, restate_gso as G
+    g, g7 = golden("G22_scdm_bath.npz"), golden("G7_bcs.npz")
+    GRho = g7[name + "/GRho"]
+    imp = list(val) + [i for i in range(n) if i > max(val)]
+    basis = Bc.embBasis_proj(GRho, n, val, localize_bath="scdm")[0]
+    ref = g[name + "/bcs_scdm"]
+    assert basis.shape == ref.shape
+    for s in range(2):
+        a, b = ref[s].reshape(-1, ref.shape[-1]), basis[s].reshape(-1, basis.shape[-1])
+        assert _match_columns(a, b)[0] < 1e-9
+    for kind, fn in (("svd", lambda: G.get_emb_basis_gso(GRho, n, val, imp, localize_bath="scdm")[0]),
+                     ("eig", lambda: G.get_emb_basis_gso_eig(mesh, GRho, n, val, imp, localize_bath="scdm")[0])):
+        got, ref = fn(), g["%s/gso_%s_scdm" % (name, kind)]
+        assert got.shape == ref.shape
+        assert _match_columns(ref.reshape(-1, ref.shape[-1]), got.reshape(-1, got.shape[-1]))[0] < 1e-9
