@@ -895,7 +895,6 @@ int dmk_eri_begin(dmk_ctx *ctx, const int mesh[3], int nao, int naux, int nemb, 
         if (!ok) {
             (void)hipGetLastError();
             if (h->Cpad) (void)hipFree(h->Cpad);
-    if (h->planes_view) (void)hipFree(h->planes_view);
             (void)hipFree(h->planes);
             (void)hipFree(h->Ut);
             if (h->imag) (void)hipFree(h->imag);
@@ -1780,6 +1779,7 @@ int dmk_eri_finish(dmk_eri *h) {
     if (h->imag) (void)hipFree(h->imag);
     if (h->sub_planes) (void)hipFree(h->sub_planes);
     if (h->Cpad) (void)hipFree(h->Cpad);
+    if (h->planes_view) (void)hipFree(h->planes_view);
     void *mine[2] = {h->planes, h->Ut};
     for (int w = 0; w < 2; ++w) {
         if (!mine[w]) continue;
