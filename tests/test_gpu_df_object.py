@@ -186,6 +186,7 @@ def test_make_df_resident_through_the_entry_points(ctx, golden, name, spin):
         e = et.get_emb_eri(cell, res, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
         ref = g[st + "/eri_%s" % ("tr" if tr else "notr")]
         assert e.shape == ref.shape and np.abs(e - ref).max() < TOL
+        assert not getattr(res, "_warned_plan", False)          # the blocks were read in place: the transform's plan is the stored one
         e_file = et.get_emb_eri(cell, duck, C_ao_lo=C, basis=basis, t_reversal_symm=tr)
         assert np.abs(e - e_file).max() <= 1e-14 * max(1.0, np.abs(ref).max())
         if tr:
