@@ -323,6 +323,9 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight);
  * pipelines only; call it before the first dmk_eri_begin_kL.  With a stack, k lists that are not the integer mesh must use
  * dmk_eri_begin_kL_weighted (the slot region depends on the weight of the kL). */
 int dmk_eri_stack(dmk_eri *h, int nslots_wanted, int *nslots_granted);
+/* (Also without a stack: a kL begun with weight 1 -- its own time-reversal partner -- only contributes the real part of its planes
+ * (eri_transform.py:453-455), so its blocks run a real-part-only step 2, 2/3 of the matrix work; dmk_eri_end_kL must then be given
+ * the same weight.  After such a kL the Im half of what dmk_eri_planes returns is zero.  DMK_ERI_RE_ONLY=0 switches it off.) */
 int dmk_eri_begin_kL_weighted(dmk_eri *h, int kL, int weight);
 /* Contract what is resident, restricted to the band [band_lo, band_hi) of 128-row tiles of the pair index (-1, -1: all;
  * dmk_eri_bands gives their number).  Bands must be issued in increasing order; after band b the ROWS of band b of every

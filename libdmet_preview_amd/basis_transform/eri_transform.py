@@ -998,7 +998,8 @@ class EriEngine(object):
 
     def run_kL(self, kL, provider, user_of_mesh=None, max_blocks=None):
         ctx = self.ctx
-        if self.nslots > 1:
+        if self.nslots > 1 or self.tr:
+            # the weight is known here: a kL that is its own time-reversal partner (weight 1) runs the real-part-only step 2
             ctx.check(lib.dmk_eri_begin_kL_weighted(self.h, int(kL), int(self.weights[kL])))
         else:
             ctx.check(lib.dmk_eri_begin_kL(self.h, int(kL)))

@@ -775,6 +775,10 @@ struct dmk_eri {
     // fill slots from the front, weight-1 kL (only their Re halves are contracted) from the back, and one K-stacked GEMM per
     // weight class and spin block contracts them all (dmk_eri_contract, or automatically when the stack is full / at finish)
     int nslots = 1, n_w2 = 0, n_w1 = 0, cur_slot = 0, cur_weight = 1;
+    // A kL that is its own time-reversal partner (weight 1) only ever contributes the REAL part of its planes (eri_transform.py:453-455,
+    // 464-467), so step 2 of its blocks computes Re S alone -- two real products instead of the three of 3M (zhot_common.h RE).
+    // Known when the kL is begun with its weight (dmk_eri_begin_kL_weighted); dmk_eri_begin_kL keeps the full product.
+    bool re_only = false;
     double *slot_planes(int slot, int spin_idx) const {
         return planes + ((size_t)spin_idx * nslots + slot) * 2 * (size_t)pr * pl;
     }
@@ -931,6 +935,8 @@ static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
     if (kL < 0 || kL >= h->mesh.nk) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin_kL: kL out of range");
     if (h->cur_kL >= 0) return dmk_fail(ctx, DMK_ERR_STATE, "eri_begin_kL: previous kL not ended");
     h->cur_slot = 0;
+    const char *re_env = getenv("DMK_ERI_RE_ONLY");             // read per kL (a handful per second): tests toggle it
+    h->re_only = !(re_env && atoi(re_env) == 0) && h->tr && weight == 1 && !h->imag;
     if (h->nslots > 1) {
         if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_begin_kL: a plane stack needs the weight (1 or 2) of the kL");
         if (h->n_w2 + h->n_w1 == h->nslots) {                 // stack full: contract everything that is resident
@@ -955,7 +961,7 @@ static int eri_begin_kL_impl(dmk_eri *h, int kL, int weight) {
 
 int dmk_eri_begin_kL(dmk_eri *h, int kL) {
     if (!h) return DMK_ERR_INVALID;
-    int weight = 1;
+    int weight = 0;                     // unknown: the full complex product (no stack: the weight only arrives with dmk_eri_end_kL)
     if (h->nslots > 1 && h->tr && kL >= 0 && kL < h->mesh.nk) {      // integer-mesh plan: the weight follows from the mesh
         std::vector<int> w;
         tr_weights(h->mesh, 1, w);
@@ -1010,13 +1016,13 @@ static int eri_flush(dmk_eri *h) {
     if (h->hot256) {
         rc = launch_half2_hot(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), h->pr, h->pl,
                               naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * h->kdim * nemb,
-                              (long long)h->nslots * 2LL * h->pr * h->pl, h->kdim);
+                              (long long)h->nslots * 2LL * h->pr * h->pl, h->kdim, h->re_only ? 1 : 0);
     } else {
         const int nsub = h->sub_planes ? half2_tab_subgroups(ctx, naux, nao, nemb, h->spin, h->pending, h->nsub_max) : 1;
         rc = launch_half2_tab(ctx, h->Ut, (long long)slot_elems, h->pending, cj, h->pend_sym, h->slot_planes(h->cur_slot, 0), h->pr, h->pl,
                               naux, nao, nemb, h->spin, (long long)h->group * (long long)slot_elems, (long long)h->mesh.nk * h->kdim * nemb,
                               (long long)h->nslots * 2LL * h->pr * h->pl, nsub, h->sub_planes, (long long)h->spin * 2LL * h->pr * h->pl,
-                              h->kdim);
+                              h->kdim, h->re_only ? 1 : 0);
         if (rc == 1) h->sub_used = std::max(h->sub_used, nsub);
     }
     if (rc < 0) return rc;
@@ -1171,6 +1177,9 @@ int dmk_eri_end_kL(dmk_eri *h, int weight) {
     double alpha;
     if (h->tr) {
         if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL: weight must be 1 or 2");
+        if (h->re_only && weight != 1)
+            return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL: weight %d, but the kL was begun with weight 1 (its imaginary planes were not computed)",
+                            weight);
         K = (int)(weight == 1 ? h->pr : 2 * h->pr);
         Kalg = weight == 1 ? h->naux : 2 * h->naux;
         alpha = (double)weight;
@@ -1463,6 +1472,8 @@ int dmk_eri_end_kL_gso(dmk_eri *h, int weight) {
     double alpha;
     if (h->tr) {
         if (weight != 1 && weight != 2) return dmk_fail(ctx, DMK_ERR_INVALID, "eri_end_kL_gso: weight must be 1 or 2");
+        if (h->re_only && weight != 1)
+            return dmk_fail(ctx, DMK_ERR_STATE, "eri_end_kL_gso: weight %d, but the kL was begun with weight 1", weight);
         K = (int)(weight == 1 ? h->pr : 2 * h->pr);
         Kalg = weight == 1 ? h->naux : 2 * h->naux;
         alpha = (double)weight;

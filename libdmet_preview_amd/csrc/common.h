@@ -308,7 +308,7 @@ int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_strid
                            long long ut_spin_stride, int kdim = 0);
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
-                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int kdim = 0);
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int kdim = 0, int re_only = 0);
 int half2_hot_usable(int nao, int nemb);
 int half2_hot_maxslot();
 int half1_hot_usable(int nL, int nao, int nemb);
@@ -318,7 +318,7 @@ int half1_hot_usable(int nL, int nao, int nemb);
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int nsub = 1,
-                     double *planes_sub = nullptr, long long sub_stride = 0, int kdim = 0);
+                     double *planes_sub = nullptr, long long sub_stride = 0, int kdim = 0, int re_only = 0);
 int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int nslot, int max_sub);
 int half2_tab_usable(int nao, int nemb);
 int half2_tab_maxslot();

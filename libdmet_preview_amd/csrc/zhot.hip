@@ -258,7 +258,7 @@ struct H2Args {
 
 // LAB: ablation bits of tools/zhot_lab.hip, as in half1_kernel (1: no plane atomics, 2: no LDS-DMA after the prologue, 4: no
 // s_barrier); the product instantiates LAB = 0.
-template <int LAB = 0>
+template <int LAB = 0, bool RE = false>
 __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
     __shared__ __attribute__((aligned(16))) double2 lds[H2_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar LDS-DMA addressing
@@ -336,21 +336,21 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 c_stage = c_stage + 1 == H2T_D ? 0 : c_stage + 1;
                 const double2 *C = U + H2_BK * 128;
                 {   // segment 1: S[a][b] += U[q][a] C[q][b]   (one B fragment live at a time)
-                    const cfrag a1 = cfrag_of(lds_frag(&U[R1 * 16])), a2 = cfrag_of(lds_frag(&U[R2 * 16]));
+                    const cfrag a1 = cfrag_of_t<RE>(lds_frag(&U[R1 * 16])), a2 = cfrag_of_t<RE>(lds_frag(&U[R2 * 16]));
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) {
-                        const cfrag b = cfrag_of(lds_frag(&C[c * 16]));
-                        if (c <= R1) cmfma(acc1[c <= R1 ? c : 0], a1, b);
-                        cmfma(acc2[c], a2, b);
+                        const cfrag b = cfrag_of_t<RE>(lds_frag(&C[c * 16]));
+                        if (c <= R1) cmfma_t<RE>(acc1[c <= R1 ? c : 0], a1, b);
+                        cmfma_t<RE>(acc2[c], a2, b);
                     }
                 }
                 if (c_sym) {   // segment 2: S[a][b] += C[q][a] U[q][b]   (same two panels)
-                    const cfrag a1 = cfrag_of(lds_frag(&C[R1 * 16])), a2 = cfrag_of(lds_frag(&C[R2 * 16]));
+                    const cfrag a1 = cfrag_of_t<RE>(lds_frag(&C[R1 * 16])), a2 = cfrag_of_t<RE>(lds_frag(&C[R2 * 16]));
 #pragma unroll
                     for (int c = 0; c <= R2; ++c) {
-                        const cfrag b = cfrag_of(lds_frag(&U[c * 16]));
-                        if (c < R1 || (c == R1 && !fold)) cmfma(acc1[c <= R1 ? c : 0], a1, b);
-                        if (c < R2 || !fold) cmfma(acc2[c], a2, b);
+                        const cfrag b = cfrag_of_t<RE>(lds_frag(&U[c * 16]));
+                        if (c < R1 || (c == R1 && !fold)) cmfma_t<RE>(acc1[c <= R1 ? c : 0], a1, b);
+                        if (c < R2 || !fold) cmfma_t<RE>(acc2[c], a2, b);
                     }
                 }
                 if (++c_t == Tb) {
@@ -367,19 +367,19 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         tr[(frag_k + 4 * r) * 17 + frag_x] = cacc_re(acc, r);
-                        tr[272 + (frag_k + 4 * r) * 17 + frag_x] = cacc_im(acc, r);
+                        if constexpr (!RE) tr[272 + (frag_k + 4 * r) * 17 + frag_x] = cacc_im(acc, r);
                     }
                     double tre[4], tim[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                      // the LDS pipe keeps a wave's own accesses in order
                         tre[r] = tr[frag_x * 17 + frag_k + 4 * r];
-                        tim[r] = tr[272 + frag_x * 17 + frag_k + 4 * r];
+                        tim[r] = RE ? 0.0 : tr[272 + frag_x * 17 + frag_k + 4 * r];
                     }
                     // fold into the T1 / T2 / T3 representation: Re += tre, Im += tim  (T1 += tre, T3 += tre + tim)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         acc.p[r] += tre[r];
-                        acc.t[r] += tre[r] + tim[r];
+                        if constexpr (!RE) acc.t[r] += tre[r] + tim[r];
                     }
                 };
                 fold_block(acc1[R1]);
@@ -391,10 +391,10 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
                 const int row1 = d0 + R1 * 16 + frag_k + 4 * r, row2 = d0 + R2 * 16 + frag_k + 4 * r;
 #pragma unroll
                 for (int c = 0; c <= R1; ++c)
-                    pack_acc(g_planes, g_naux, g_npair, L, row1, d0 + c * 16 + frag_x, cacc_re(acc1[c], r), cacc_im(acc1[c], r));
+                    pack_acc_t<RE>(g_planes, g_naux, g_npair, L, row1, d0 + c * 16 + frag_x, acc1[c], r);
 #pragma unroll
                 for (int c = 0; c <= R2; ++c)
-                    pack_acc(g_planes, g_naux, g_npair, L, row2, d0 + c * 16 + frag_x, cacc_re(acc2[c], r), cacc_im(acc2[c], r));
+                    pack_acc_t<RE>(g_planes, g_naux, g_npair, L, row2, d0 + c * 16 + frag_x, acc2[c], r);
             }
         };
         switch (wave) {
@@ -464,24 +464,24 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
         {
             cfrag a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(lds_frag(&Ua[i * 16]));
+            for (int i = 0; i < 2; ++i) a[i] = cfrag_of_t<RE>(lds_frag(&Ua[i * 16]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(lds_frag(&Cb[j * 16]));
+            for (int j = 0; j < 4; ++j) b[j] = cfrag_of_t<RE>(lds_frag(&Cb[j * 16]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cmfma(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 4; ++j) cmfma_t<RE>(acc[i][j], a[i], b[j]);
         }
         if (c_sym) {
             cfrag a[2], b[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = cfrag_of(lds_frag(&Ca[i * 16]));
+            for (int i = 0; i < 2; ++i) a[i] = cfrag_of_t<RE>(lds_frag(&Ca[i * 16]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = cfrag_of(lds_frag(&Ub[j * 16]));
+            for (int j = 0; j < 4; ++j) b[j] = cfrag_of_t<RE>(lds_frag(&Ub[j * 16]));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cmfma(acc[i][j], a[i], b[j]);
+                for (int j = 0; j < 4; ++j) cmfma_t<RE>(acc[i][j], a[i], b[j]);
         }
         if (++c_t == Tb) {
             c_t = 0;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(HNT, 2) void half2_kernel(const H2Args g) {
             const int row = r0 + wm * 32 + i * 16 + frag_k + 4 * r;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                pack_acc(g_planes, g_naux, g_npair, L, row, wn * 64 + j * 16 + frag_x, cacc_re(acc[i][j], r), cacc_im(acc[i][j], r));
+                pack_acc_t<RE>(g_planes, g_naux, g_npair, L, row, wn * 64 + j * 16 + frag_x, acc[i][j], r);
         }
 }
 
@@ -598,7 +598,7 @@ int launch_half1_hot_multi(dmk_ctx *ctx, const void *Lpq, long long a_slot_strid
 
 int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj,
                      const int *sym, double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
-                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int kdim) {
+                     long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int kdim, int re_only) {
     if (kdim == 0) kdim = nao;
     if (!hot_enabled() || nemb != H2_N || kdim < nao || (kdim % H2_BK) != 0 || nao < 3 * H2_BK || nslot < 1 || nslot > H2_MAXSLOT ||
         nspin < 1 || nspin > 2)
@@ -624,9 +624,10 @@ int launch_half2_hot(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
         // (without the 16 diagonal blocks when the whole group is symmetrised: they are folded in the epilogue)
         double blocks = 0.0;
         for (int i = 0; i < nslot; ++i) blocks += 136.0 + (sym[i] ? (a.fold_diag ? 120.0 : 136.0) : 0.0);
-        fs.mfma_flops(6.0 * blocks * 256.0 * (double)kdim * (double)nL * (double)nspin);
+        fs.mfma_flops((re_only ? 4.0 : 6.0) * blocks * 256.0 * (double)kdim * (double)nL * (double)nspin);
     }
-    hipLaunchKernelGGL(half2_kernel<0>, dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    if (re_only) hipLaunchKernelGGL((half2_kernel<0, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((half2_kernel<0, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }

@@ -33,6 +33,23 @@ __device__ __forceinline__ void cmfma(cacc &c, const cfrag &a, const cfrag &b) {
 __device__ __forceinline__ double cacc_re(const cacc &c, int r) { return c.p[r] - c.q[r]; }
 __device__ __forceinline__ double cacc_im(const cacc &c, int r) { return (c.t[r] - c.p[r]) - c.q[r]; }
 
+// RE = true: only the REAL part of the product is wanted -- a momentum transfer kL that is its own time-reversal partner
+// (weight 1) contributes Re(Lij)^T Re(Lij) only (eri_transform.py:453-455, 464-467: the imaginary part of its planes is never read),
+// so step 2 runs Re S = Ur Cr - Ui Ci: two real MFMAs per complex block step instead of the three of 3M, no operand sums, no T3
+// accumulator, one plane atomic per element.  RE = false is the code above, instruction for instruction.
+template <bool RE> __device__ __forceinline__ cfrag cfrag_of_t(double2 v) {
+    if constexpr (RE) { cfrag f; f.v = v; f.s = 0.0; return f; }
+    else return cfrag_of(v);
+}
+template <bool RE> __device__ __forceinline__ void cmfma_t(cacc &c, const cfrag &a, const cfrag &b) {
+    if constexpr (RE) {
+        c.p = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.x, b.v.x, c.p, 0, 0, 0);
+        c.q = __builtin_amdgcn_mfma_f64_16x16x4f64(a.v.y, b.v.y, c.q, 0, 0, 0);
+    } else {
+        cmfma(c, a, b);
+    }
+}
+
 // planes[(ri * naux + L) * npair + row (row + 1) / 2 + col] += value for row >= col, row < nrows.
 // Single writer per address per launch -> deterministic; fire-and-forget atomics: no load latency in the epilogue.
 __device__ __forceinline__ void pack_acc(double *planes, long long naux, long long npair, int L, int row, int col,
@@ -41,6 +58,16 @@ __device__ __forceinline__ void pack_acc(double *planes, long long naux, long lo
         const long long idx = (long long)row * (row + 1) / 2 + col;
         unsafeAtomicAdd(planes + (long long)L * npair + idx, vr);
         unsafeAtomicAdd(planes + (naux + (long long)L) * npair + idx, vi);
+    }
+}
+
+template <bool RE> __device__ __forceinline__ void pack_acc_t(double *planes, long long naux, long long npair, int L, int row, int col,
+                                                             const cacc &c, int r, int nrows = 0x7fffffff) {
+    if constexpr (RE) {
+        if (row >= col && row < nrows)
+            unsafeAtomicAdd(planes + (long long)L * npair + (long long)row * (row + 1) / 2 + col, cacc_re(c, r));
+    } else {
+        pack_acc(planes, naux, npair, L, row, col, cacc_re(c, r), cacc_im(c, r), nrows);
     }
 }
 

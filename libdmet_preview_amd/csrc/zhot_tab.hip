@@ -85,7 +85,7 @@ struct H2TArgs {
 
 // LAB: ablation bits of tools/zhot_lab.hip as in zhot.hip (1: no plane atomics, 2: no LDS-DMA after the prologue, 4: no
 // s_barrier); the product instantiates LAB = 0.
-template <class CFG, int LAB = 0>
+template <class CFG, int LAB = 0, bool RE = false>
 __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs g) {
     constexpr int T_MAXBLK = CFG::MAXBLK;
     __shared__ __attribute__((aligned(16))) double2 lds[lds_elems<CFG>()];
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                 const double2 *rowU = st + PUA + frag_k * PWR + frag_x, *colC = st + PCB + frag_k * PWC + frag_x;
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {                          // S[a][b] += U[q][a] C[q][b]
-                    const cfrag a = cfrag_of(lds_frag(rowU + ro[i])), b = cfrag_of(lds_frag(colC + co[i]));
-                    cmfma(acc[i], a, b);
+                    const cfrag a = cfrag_of_t<RE>(lds_frag(rowU + ro[i])), b = cfrag_of_t<RE>(lds_frag(colC + co[i]));
+                    cmfma_t<RE>(acc[i], a, b);
                 }
                 if (c_sym) {
                     const double2 *rowC = st + PCA + frag_k * PWR + frag_x, *colU = st + PUB + frag_k * PWC + frag_x;
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
                     for (int i = 0; i < NB; ++i) {                      // S[a][b] += C[q][a] U[q][b]
                         // at most the last two blocks of a list are diagonal ones: only they carry a (uniform) branch
                         if (i + 2 < NB || i < nb2) {
-                            const cfrag a = cfrag_of(lds_frag(rowC + ro[i])), b = cfrag_of(lds_frag(colU + co[i]));
-                            cmfma(acc[i], a, b);
+                            const cfrag a = cfrag_of_t<RE>(lds_frag(rowC + ro[i])), b = cfrag_of_t<RE>(lds_frag(colU + co[i]));
+                            cmfma_t<RE>(acc[i], a, b);
                         }
                     }
                 }
@@ -257,13 +257,13 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         tr[(frag_k + 4 * r) * 17 + frag_x] = cacc_re(acc[i], r);
-                        tr[272 + (frag_k + 4 * r) * 17 + frag_x] = cacc_im(acc[i], r);
+                        if constexpr (!RE) tr[272 + (frag_k + 4 * r) * 17 + frag_x] = cacc_im(acc[i], r);
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                  // the LDS pipe keeps a wave's own accesses in order
-                        const double tre = tr[frag_x * 17 + frag_k + 4 * r], tim = tr[272 + frag_x * 17 + frag_k + 4 * r];
+                        const double tre = tr[frag_x * 17 + frag_k + 4 * r], tim = RE ? 0.0 : tr[272 + frag_x * 17 + frag_k + 4 * r];
                         acc[i].p[r] += tre;                        // Re += tre, Im += tim in the (T1, T2, T3) representation
-                        acc[i].t[r] += tre + tim;
+                        if constexpr (!RE) acc[i].t[r] += tre + tim;
                     }
                 }
             }
@@ -273,8 +273,7 @@ __global__ __launch_bounds__(HNT, CFG::OCC) void half2_tab_kernel(const H2TArgs 
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                pack_acc(g_planes, g_naux, g_npair, L, r0 + ro[i] + frag_k + 4 * r, c0 + co[i] + frag_x, cacc_re(acc[i], r),
-                         cacc_im(acc[i], r), g.nemb);
+                pack_acc_t<RE>(g_planes, g_naux, g_npair, L, r0 + ro[i] + frag_k + 4 * r, c0 + co[i] + frag_x, acc[i], r, g.nemb);
     };
     auto by_len = [&](auto kindtag) {
         auto go = [&](auto nbtag) {
@@ -427,7 +426,7 @@ int half2_tab_subgroups(dmk_ctx *ctx, int nL, int nao, int nemb, int nspin, int 
 int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int nslot, const void *const *Cj, const int *sym,
                      double *planes, long long naux, long long npair, int nL, int nao, int nemb, int nspin,
                      long long ut_spin_stride, long long cj_spin_stride, long long planes_spin_stride, int nsub,
-                     double *planes_sub, long long sub_stride, int kdim) {
+                     double *planes_sub, long long sub_stride, int kdim, int re_only) {
     if (kdim == 0) kdim = nao;
     if (kdim < nao || (kdim % T_BK) != 0) return 0;
     if (!half2_tab_usable(nao, nemb) || nslot < 1 || nslot > T_MAXSLOT || nspin < 1 || nspin > 2) return 0;
@@ -488,9 +487,14 @@ int launch_half2_tab(dmk_ctx *ctx, const void *Ut, long long slot_stride, int ns
     FamScope fs(ctx, DMK_FAM_ZGEMM_HALF2);
     // a symmetrised block runs a second segment -- without the folded diagonal blocks when the whole group is symmetrised
     const double seg2 = (segs - (double)nslot) * (tb->useful_blocks - (a.fold_diag ? tb->folded_blocks : 0.0));
-    fs.mfma_flops(6.0 * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)kdim * (double)nL * (double)nspin);
-    if (occ == 2) hipLaunchKernelGGL((half2_tab_kernel<Cfg2, 0>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 0>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    fs.mfma_flops((re_only ? 4.0 : 6.0) * ((double)nslot * tb->useful_blocks + seg2) * 256.0 * (double)kdim * (double)nL * (double)nspin);
+    if (occ == 2) {
+        if (re_only) hipLaunchKernelGGL((half2_tab_kernel<Cfg2, 0, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half2_tab_kernel<Cfg2, 0, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    } else {
+        if (re_only) hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 0, true>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((half2_tab_kernel<Cfg3, 0, false>), dim3(a.nblocks), dim3(HNT), 0, ctx->stream, a);
+    }
     DMK_CHECK_LAUNCH(ctx);
     return 1;
 }

@@ -54,6 +54,11 @@ def _run_and_check(ctx, mesh, nao, naux, nemb, spin, kL_list, A, seed, check_pla
                 pl = eng.planes().get()                                  # (spin, 2, naux, npair) of this kL
                 got = pl[:, 0][:, :, idx] + 1j * pl[:, 1][:, :, idx]
                 ref = ref_planes[kL]
+                if int(eng.weights[kL]) == 1:
+                    # a kL that is its own time-reversal partner: only Re of its planes is ever read (eri_transform.py:453-455) and
+                    # only Re is computed (real-part-only step 2); the Im half stays zero
+                    assert np.abs(pl[:, 1]).max() == 0.0 or os.environ.get("DMK_ERI_RE_ONLY") == "0"
+                    got, ref = got.real, ref.real
                 err = np.abs(got - ref).max()
                 worst_p = max(worst_p, err / np.abs(ref).max())
                 assert err < 1e-11 * np.abs(ref).max(), (kL, err, np.abs(ref).max())
@@ -431,6 +436,55 @@ def test_ao_block_beyond_4_GiB_takes_the_hot_path(ctx):
     if free < 120 * (1 << 30):
         pytest.skip("needs 120 GB of free device memory")
     _run_and_check(ctx, (2, 1, 1), 500, 1100, 40, 1, [0, 1], [0, 19, 39], seed=77, check_planes=True, want_ring=True)
+
+
+@pytest.mark.parametrize("nao,naux,nemb,spin", [(40, 48, 256, 2), (27, 45, 72, 1), (104, 24, 136, 2)])
+def test_real_part_only_step2_of_weight_one_kL(ctx, nao, naux, nemb, spin, monkeypatch):
+    """A momentum transfer kL that is its own time-reversal partner (weight 1) contributes Re(Lij)^T Re(Lij) only
+    (eri_transform.py:453-455, 464-467), so its blocks run a real-part-only step 2 (Re S = Ur Cr - Ui Ci: two real MFMAs per complex
+    block step instead of 3M's three).  The Re planes -- and with them the ERI -- are BIT-identical to the full complex step 2
+    (DMK_ERI_RE_ONLY=0: the same two accumulators, the same order), the Im planes of those kL are zero, weight-2 kL are untouched; on
+    a 2 x 2 x 2 mesh EVERY kL has weight 1.  Both step-2 kernels, on and off the K tile, and against the sampled oracle."""
+    from libdmet_preview_amd.basis_transform import eri_transform as et
+    for mesh in ((2, 2, 2), (3, 2, 1)):
+        nk = int(np.prod(mesh))
+        npair = nemb * (nemb + 1) // 2
+        nblk = spin * (spin + 1) // 2
+        rng = np.random.default_rng(nao + nk)
+        Ce = (rng.standard_normal((spin, nk, nao, nemb)) + 1j * rng.standard_normal((spin, nk, nao, nemb))) / np.sqrt(nao)
+        df = et.GDFPhilox(np.zeros((nk, 3)), naux, nao, seed=9)
+
+        def run(re_only):
+            if not re_only:
+                monkeypatch.setenv("DMK_ERI_RE_ONLY", "0")
+            else:
+                monkeypatch.delenv("DMK_ERI_RE_ONLY", raising=False)
+            eri_dev = ctx.zeros((nblk, npair, npair), np.float64)
+            eng = et.EriEngine(ctx, mesh, nao, naux, nemb, spin, ctx.to_device(Ce), eri_dev, True)
+            planes = {}
+            try:
+                assert eng.ring_slots > 0
+                for kL in eng.irreducible_kL():
+                    eng.run_kL(kL, df)
+                    planes[kL] = eng.planes().get()
+                ctx.sync()
+                return eri_dev.get(), planes, {k: int(eng.weights[k]) for k in planes}
+            finally:
+                eng.close()
+        e_re, p_re, w = run(True)
+        e_full, p_full, _ = run(False)
+        assert np.array_equal(e_re, e_full) and np.abs(e_re).max() > 0
+        assert 1 in w.values() and (mesh != (2, 2, 2) or set(w.values()) == {1})
+        for kL, wk in w.items():
+            assert np.array_equal(p_re[kL][:, 0], p_full[kL][:, 0])
+            if wk == 1:
+                assert np.abs(p_re[kL][:, 1]).max() == 0.0 and np.abs(p_full[kL][:, 1]).max() > 0.0
+            else:
+                assert np.array_equal(p_re[kL][:, 1], p_full[kL][:, 1])
+        A = [0, nemb // 2, nemb - 1]
+        want, idx, _ = ES.eri_sample(mesh, 9, Ce, naux, A, sorted(w))
+        for blk in range(nblk):
+            assert np.abs(e_re[blk][np.ix_(idx, idx)] - want[blk]).max() < 1e-8
 
 
 @pytest.mark.parametrize("gen_stream", ["0", "1"])
