@@ -57,6 +57,7 @@ _FUNCTIONS = [
     ("routine.slater", ["routine.slater"], ["get_active_projector_full"]),
     ("routine.ftsystem", ["routine.ftsystem"], ["kernel", "make_rdm1", "get_rho_grad", "get_dw_dv"]),
     ("utils.cholesky", ["utils.cholesky"], ["modified_cholesky", "modified_cholesky_uhf", "get_cderi_rhf", "get_cderi_uhf"]),
+    ("routine.localizer", ["routine.localizer"], ["localize_bath", "localize_bath_scdm"]),
     # BCS twin (routine/bcs.py:13 star-imports bcs_helper)
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
