@@ -375,7 +375,8 @@ def test_producer_stream_ring_is_bitwise_the_single_stream_result(ctx, nao, naux
 
 
 @pytest.mark.parametrize("mesh,nao,naux,nemb,spin", [((3, 2, 1), 27, 40, 256, 2), ((2, 2, 2), 101, 24, 136, 1), ((3, 1, 1), 50, 33, 72, 2),
-                                                     ((2, 2, 1), 203, 16, 256, 1), ((2, 2, 1), 17, 64, 40, 2)])
+                                                     ((2, 2, 1), 203, 16, 256, 1), ((2, 2, 1), 17, 64, 40, 2), ((2, 2, 1), 19, 33, 33, 2),
+                                                     ((3, 1, 1), 31, 37, 257, 1)])
 def test_off_tile_ao_dimension_takes_the_hot_path(ctx, mesh, nao, naux, nemb, spin):
     """AO dimensions that are NOT a multiple of the K tile of the hot kernels (8): real basis sets rarely are (13 functions per
     carbon atom in GTH-DZVP, 5 per hydrogen in cc-pVDZ).  Up to round 5 such a system fell to the generic kernels at about half the
