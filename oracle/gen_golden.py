@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1407,6 +1407,82 @@ def gen_G22():
             out["%s/gso_%s_scdm" % (name, kind)] = spinless.get_emb_basis(L, GRho, kind=kind, localize_bath="scdm")
     np.savez_compressed(os.path.join(GOLD, "G22_scdm_bath.npz"), **out)
     print("G22 done", {k: out[k].shape for k in out})
+
+
+NONLOCAL_MODES = [("r", True, False, False), ("u", False, False, False), ("rb", True, True, False), ("ub_res", False, True, True),
+                  ("ub", False, True, False)]
+NONLOCAL_LATTICES = [("m411", (4, 1, 1), 3, None), ("m231", (2, 3, 1), 4, [1, 2]), ("m333", (3, 3, 3), 2, None), ("m221", (2, 2, 1), 3, [0, 2])]
+
+
+def gen_G23():
+    """The non-local (cell-resolved, translation-invariant) correlation potential, routine/vcor.py:105-524 VcorNonLocal, and the
+    branch of the fit it drives: slater.get_dV_dparam's `else` (slater.py:893-902, transform_trans_inv_k of the k-space gradient),
+    FitVcorEmb on top of it, and the lattice mean field with a potential that differs from k to k (mfd.py:369-392).
+    Tables: every (restricted, bogoliubov, bogo_res) mode on four meshes (odd / even extents, with and without an orbital subset):
+    value and value_k at seeded parameters, the non-zeros of gradient(), assign() of a seeded matrix."""
+    from libdmet.routine import slater, mfd, vcor as rvcor
+    out = {}
+    for lname, mesh, nlo, idx in NONLOCAL_LATTICES:
+        L = _duck_lattice(mesh, nlo)
+        for mname, res, bogo, bres in NONLOCAL_MODES:
+            key = "tab/%s/%s" % (lname, mname)
+            v = rvcor.VcorNonLocal(res, bogo, L, idx_range=idx, bogo_res=bres)
+            rng = np.random.default_rng(len(key) + 17 * nlo)
+            p = rng.standard_normal(v.length())
+            v.update(p)
+            g = v.gradient()
+            out[key + "/param"], out[key + "/value"], out[key + "/value_k"] = p, v.value, v.value_k
+            out[key + "/get_k1"], out[key + "/get_R1"] = v.get(1, True), v.get(1, False)
+            out[key + "/grad_shape"] = np.asarray(g.shape)
+            out[key + "/grad_nz"] = np.asarray(np.nonzero(g), dtype=np.int32)
+            out[key + "/grad_val"] = g[np.nonzero(g)]
+            if lname == "m411":
+                out[key + "/grad_k"] = np.asarray(v.grad_k)
+            v0 = rng.standard_normal(g.shape[1:])
+            v.assign(v0)
+            out[key + "/assign_in"], out[key + "/assign_param"] = v0, np.array(v.param)
+    shim.patch_scf()
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    cases = [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3], 11), ("rhf_411", (4, 1, 1), 5, 1, [1, 2, 3], 12), ("rhf_222", (2, 2, 2), 4, 1, [0, 1, 2, 3], 13)]
+    for name, mesh, nlo, spin, val, seed in cases:
+        L, FR, basis, target = _fit_case(name, mesh, nlo, spin, val, seed)
+        if spin == 2:
+            L.ovlp_lo_k = np.asarray([L.ovlp_lo_k] * 2)
+        out[name + "/mesh"], out[name + "/val"], out[name + "/Fock_R"] = np.array(mesh), np.array(val), FR
+        out[name + "/basis"], out[name + "/target"] = basis, target
+        v = rvcor.VcorNonLocal(spin == 1, False, L, idx_range=val)
+        out[name + "/dV_compact"] = slater.get_dV_dparam(v, basis, L.R2k_basis(basis), L)
+        v = rvcor.VcorNonLocal(spin == 1, False, L, idx_range=val)
+        out[name + "/dV_full"] = slater.get_dV_dparam(v, basis, L.R2k_basis(basis), L, compact=False)
+        for tag, beta, kw in [("t0", np.inf, {}), ("ft", 15.0, {}), ("imp_t0", np.inf, dict(imp_fit=True))]:
+            v = rvcor.VcorNonLocal(spin == 1, False, L, idx_range=val)
+            v.update(np.zeros(v.length()))
+            vfit, e0, e1 = slater.FitVcorEmb(target, L, basis, v, beta, MaxIter=30, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](q.copy()) for q in P])
+            out[key + "/probe_grad"] = np.asarray([captured["fgrad"](q.copy()) for q in P])
+        # the lattice mean field under a potential that differs from k to k (unrestricted potentials: the restricted table has one
+        # block and mfd.HF's energy line reads two, mfd.py:384-392)
+        v = rvcor.VcorNonLocal(spin == 1, False, L, idx_range=val)
+        pv = 0.05 * np.random.default_rng(seed + 9).standard_normal(v.length())
+        v.update(pv)
+        out[name + "/hf_param"] = pv
+        for tag, beta in (("t0", np.inf), ("ft", 12.0)):
+            rhoT, mu, E, res = mfd.HF(L, v, 0.5, spin == 1, beta=beta, ires=True)
+            out["%s/hf_%s/rho" % (name, tag)], out["%s/hf_%s/mu" % (name, tag)] = rhoT, np.asarray(mu)
+            out["%s/hf_%s/E" % (name, tag)], out["%s/hf_%s/ew" % (name, tag)] = np.asarray(E), np.asarray(res["e"])
+    slater.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G23_vcor_nonlocal.npz"), **out)
+    print("G23 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -3,7 +3,8 @@ oracle/restate_fit.py -- CPU restatement (numpy/scipy) of SURVEY.md section 8(f)
 least-squares fit in the embedding space,
 
   Hubbard.VcorLocal            dmet/Hubbard.py:551-786     local vcor parametrisation (evaluate / gradient / diag_indices)
-  slater.get_dV_dparam         routine/slater.py:851-907   (local branch, transform_local_sparseH slater_helper.py:91-100)
+  slater.get_dV_dparam         routine/slater.py:851-907   (local branch, transform_local_sparseH slater_helper.py:91-100; non-local
+                                                           branch :893-902 with vcor.VcorNonLocal, routine/vcor.py:105-524, golden G23)
   slater.FitVcorEmb            routine/slater.py:909-1329  errfunc, gradfunc (T = 0), gradfunc_ft (finite T)
   ftsystem.get_dw_dv           routine/ftsystem.py:151-213
 
@@ -115,6 +116,93 @@ class VcorLocal(object):
         return [idx, np.asarray(idx) + self.nV // 2]
 
 
+class VcorNonLocal(object):
+    """routine/vcor.py:105-524: a translation-invariant potential with one block per lattice vector, V(-R) = V(R)^T.  Cells are walked
+    in index order: a cell that is its own inverse carries symmetric blocks, the first member of a +-R pair carries free blocks and
+    fills its partner with the transposes (:128-137); per cell the parameters are [V spin 0 | V spin 1 | pairing] (:148-172).
+    `kmesh` stands for the lattice (cells = the Cartesian product of the mesh extents in C order)."""
+
+    def __init__(self, restricted, bogoliubov, kmesh, nscsites, idx_range=None, bogo_res=False):
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, bogoliubov, bogo_res
+        self.kmesh, self.nscsites = tuple(kmesh), nscsites
+        self.idx_range = list(range(nscsites)) if idx_range is None else list(idx_range)
+        cells = list(it.product(*[range(n) for n in self.kmesh]))
+        where = dict((c, i) for i, c in enumerate(cells))
+        self.ncells = len(cells)
+        self.partner = [where[tuple((-np.asarray(c)) % np.asarray(self.kmesh))] for c in cells]
+        self.weight = [1 if self.partner[R] == R else (2 if self.partner[R] > R else 0) for R in range(self.ncells)]
+        self.nblk = 3 if bogoliubov else (1 if restricted else 2)
+        self.param = None
+        self._table = self._build()
+
+    def _build(self):
+        """[(parameter, block, cell, row, col)] for every assignment of the five evaluate() bodies (:176-445)."""
+        n = len(self.idx_range)
+        sym = list(it.combinations_with_replacement(self.idx_range, 2))
+        full = list(it.product(self.idx_range, repeat=2))
+        free_pairing = self.bogoliubov and not (self.restricted or self.bogo_res)
+        rows, base = [], 0
+        for R in range(self.ncells):
+            if self.weight[R] == 0:
+                continue
+            own = self.weight[R] == 1
+            pairs, mate = (sym, R) if own else (full, self.partner[R])
+            per_spin = len(pairs)
+            nV = per_spin * (1 if self.restricted else 2)
+            for t, (i, j) in enumerate(pairs):
+                for b in range(1 if self.restricted else 2):
+                    rows += [(base + b * per_spin + t, b, R, i, j), (base + b * per_spin + t, b, mate, j, i)]
+                if self.bogoliubov and not free_pairing:
+                    rows += [(base + nV + t, 2, R, i, j), (base + nV + t, 2, mate, j, i)]
+            nD = 0
+            if self.bogoliubov and not free_pairing:
+                nD = per_spin
+            elif free_pairing:
+                for t, (i, j) in enumerate(full):
+                    rows.append((base + nV + t, 2, R, i, j))
+                    if not own:
+                        rows.append((base + nV + n * n + t, 2, mate, i, j))
+                nD = n * n * (1 if own else 2)
+            base += nV + nD
+        self.nparam = base
+        return rows
+
+    def length(self):
+        return self.nparam
+
+    def islocal(self):
+        return False
+
+    is_local = islocal
+
+    def evaluate(self):
+        V = np.zeros((self.nblk, self.ncells, self.nscsites, self.nscsites))
+        for p, b, R, i, j in self._table:
+            V[b, R, i, j] = self.param[p]
+        return V
+
+    def gradient(self):
+        g = np.zeros((self.nparam, self.nblk, self.ncells, self.nscsites, self.nscsites))
+        for p, b, R, i, j in self._table:
+            g[p, b, R, i, j] = 1
+        return g
+
+    def update(self, param):
+        assert len(param) == self.nparam
+        self.param = param
+        self.value = self.evaluate()
+        self.value_k = R2k(self.value, self.kmesh)
+
+    def get(self, i=0, kspace=True, return_all=False):
+        v = self.value_k if kspace else self.value
+        return v if return_all else v[:, i]
+
+    def assign(self, v0):
+        g = self.gradient()
+        assert v0.shape == g.shape[1:]
+        self.update(np.asarray([np.sum(g[i] * v0) / np.sum(g[i] * g[i]) for i in range(self.nparam)]))
+
+
 # ---------------------------------------------------------------------------------------------
 # dV / dparam (slater.py:851-907, local branch)
 # ---------------------------------------------------------------------------------------------
@@ -154,6 +242,15 @@ def get_dV_dparam(vcor, basis, compact=True, P_full=None, kmesh=None):
     if P_full is not None:
         basis_k = np.asarray([R2k(basis[s], kmesh) for s in range(spin)])
         C = np.einsum('skij,skjb->skib', np.asarray(P_full), basis_k)
+    if not vcor.islocal():
+        # slater.py:893-902: the gradient of a cell-resolved potential goes to k space and through transform_trans_inv_k
+        basis_k = np.asarray([R2k(basis[s], vcor.kmesh) for s in range(spin)])
+        for s in range(spin):
+            for ip in range(vcor.length()):
+                gk = R2k(g[ip, s], vcor.kmesh)
+                m = (np.einsum('kia,kij,kjb->ab', basis_k[s].conj(), gk, basis_k[s]) / nk).real
+                out[ip, s] = m[tril] if compact else m
+        return out
     for s in range(spin):
         for ip in range(vcor.length()):
             if P_full is None:

@@ -215,3 +215,52 @@ def test_G21_drho_dparam(golden, name):
             rm = fit._solve(p0 - dp)[4] + fit.target
             fd = np.asarray([((rp[s] - rm[s]) / 2e-5)[tl] for s in range(spin)])
             assert np.abs(fd - ref[:, ip]).max() < 1e-6
+
+
+# ---- round 6: the cell-resolved potential VcorNonLocal and the fit it drives (golden G23) ---------------------------------
+
+NONLOCAL_MODES = [("r", True, False, False), ("u", False, False, False), ("rb", True, True, False), ("ub_res", False, True, True),
+                  ("ub", False, True, False)]
+NONLOCAL_LATTICES = [("m411", (4, 1, 1), 3, None), ("m231", (2, 3, 1), 4, [1, 2]), ("m333", (3, 3, 3), 2, None), ("m221", (2, 2, 1), 3, [0, 2])]
+NONLOCAL_FITS = ["uhf_231", "rhf_411", "rhf_222"]
+
+
+@pytest.mark.parametrize("lat", NONLOCAL_LATTICES, ids=[x[0] for x in NONLOCAL_LATTICES])
+@pytest.mark.parametrize("mode", NONLOCAL_MODES, ids=[x[0] for x in NONLOCAL_MODES])
+def test_G23_nonlocal_tables(golden, lat, mode):
+    """Integer bookkeeping: bit-exact against the reference's closures (value, the non-zeros of gradient(), assign)."""
+    g = golden("G23_vcor_nonlocal.npz")
+    (lname, mesh, nlo, idx), (mname, res, bogo, bres) = lat, mode
+    key = "tab/%s/%s" % (lname, mname)
+    v = F.VcorNonLocal(res, bogo, mesh, nlo, idx, bres)
+    p = g[key + "/param"]
+    assert v.length() == len(p)
+    v.update(p)
+    assert np.array_equal(v.value, g[key + "/value"])
+    assert np.abs(v.value_k - g[key + "/value_k"]).max() < 1e-13
+    assert np.abs(v.get(1, True) - g[key + "/get_k1"]).max() < 1e-13 and np.array_equal(v.get(1, False), g[key + "/get_R1"])
+    gr = v.gradient()
+    assert gr.shape == tuple(g[key + "/grad_shape"])
+    assert np.array_equal(np.asarray(np.nonzero(gr)), g[key + "/grad_nz"]) and np.array_equal(gr[np.nonzero(gr)], g[key + "/grad_val"])
+    v.assign(g[key + "/assign_in"])
+    assert np.array_equal(v.param, g[key + "/assign_param"])
+
+
+@pytest.mark.parametrize("name", NONLOCAL_FITS)
+def test_G23_nonlocal_dV_and_objectives(golden, name):
+    g = golden("G23_vcor_nonlocal.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    nb = basis.shape[-1]
+    v = F.VcorNonLocal(spin == 1, False, mesh, nlo, val)
+    assert np.abs(F.get_dV_dparam(v, basis) - g[name + "/dV_compact"]).max() < 1e-13
+    assert np.abs(F.get_dV_dparam(v, basis, compact=False) - g[name + "/dV_full"]).max() < 1e-13
+    for tag, beta, kw in [("t0", np.inf, {}), ("ft", 15.0, {}), ("imp_t0", np.inf, dict(imp_fit=True))]:
+        imp_idx, det_idx = idx_sets(kw, nlo - min(val), nb)
+        fit = F.EmbFit(target, mesh, basis, v, beta, Fk if spin == 2 else Fk[0], Sk, nelec, imp_idx=imp_idx, det_idx=det_idx)
+        key = "%s/%s" % (name, tag)
+        grad = fit.gradfunc if beta == np.inf else fit.gradfunc_ft
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-12, key
+            assert np.abs(grad(p) - gr).max() < 1e-9 * max(1.0, np.abs(gr).max()), key
+        pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
+        assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
