@@ -124,6 +124,7 @@ def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, 
 
 
 vcor_zeros = VcorLocal
+VcorNonLocal = vcor.VcorNonLocal                 # dmet/Hubbard.py:1495
 
 
 # ---- driver layer (dmet/Hubbard.py:14-41, 1503): thin host wrappers over the device routines ------------------------------

@@ -567,7 +567,12 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
         E = E0 + weight * np.einsum("skpq,skqp->", vcor_k[:spin], rho_k_host)
     elif vcor is not None and not vcor.islocal():
         vcorT = np.array([vcor.get(i, kspace=False) for i in range(nkpts)])
-        E = E0 + weight * sum(np.sum(vcorT[:, s] * rhoT[s]) for s in range(spin))
+        if spin == 1:
+            # the reference's restricted line multiplies EVERY cell of the potential with cell 0 of the density (mfd.py:386:
+            # `vcorT[:, 0] * rhoT[0, 0]`, broadcast over cells); kept as is -- this number is what its callers log and compare
+            E = E0 + np.sum(vcorT[:, 0] * rhoT[0, 0])
+        else:
+            E = E0 + weight * sum(np.sum(vcorT[:, s] * rhoT[s]) for s in range(spin))
     elif vcor is not None:
         vcorT = np.asarray(vcor.get(0, kspace=False))
         E = E0 + weight * sum(np.sum(vcorT[s] * rhoT[s, 0]) for s in range(spin))

@@ -409,7 +409,7 @@ embHam = get_emb_Ham
 # correlation-potential fit in the embedding space (routine/slater.py:851-1329)
 # ---------------------------------------------------------------------------------------------
 
-def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7, rows=None):
+def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7, rows=None, lattice=None):
     """Device dV_dparam (nparam, spin, npair) f64, tril packed (slater.py:851-877 with transform_local_sparseH,
     slater_helper.py:91-100): gathered from the cell Gram matrix of the basis rows that any parameter touches.
     `rows` = (p_lo, p_hi): only that range of parameters (a rank's shard of the table), shape (p_hi - p_lo, spin, npair)."""
@@ -417,6 +417,8 @@ def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7, rows=None):
     spin, ncells, nlo, nb = basis.shape
     npair = nb * (nb + 1) // 2
     nparam = vcor.length()
+    if not vcor.is_local():
+        return _dV_dparam_cells_dev(ctx, vcor, basis, lattice if lattice is not None else getattr(vcor, "lattice", None), rows=rows)
     if hasattr(vcor, "grad_entries"):                                # sparse description, same order as np.nonzero below
         gp, gb, gi, gj, gv = vcor.grad_entries()
         keep = (gb < spin) & (np.abs(gv) > thr)
@@ -444,15 +446,90 @@ def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7, rows=None):
         d_G = ctx.zeros((m, m), np.float64)
         ctx.check(lib.dmk_dgemm_tn_acc(ctx.h, m, ncells, 1.0, d_X.ptr, d_X.ptr, m, d_G.ptr, m))
         off = ((ents.astype(np.int64) - p_lo) * spin + s) * npair
-        for e0 in range(0, len(ents), 32768):
-            e1 = min(len(ents), e0 + 32768)
-            sl = slice(ptr[e0], ptr[e1])
-            args = [ctx.to_device((ptr[e0:e1 + 1] - ptr[e0]).astype(np.int32)), ctx.to_device(zi[sl].astype(np.int32)),
-                    ctx.to_device(zj[sl].astype(np.int32)), ctx.to_device(zv[sl].astype(np.float64)),
-                    ctx.to_device(off[e0:e1])]
-            ctx.check(lib.dmk_vcor_dV_dparam(ctx.h, e1 - e0, nb, d_G.ptr, m, args[0].ptr, args[1].ptr, args[2].ptr,
-                                             args[3].ptr, args[4].ptr, d_dV.ptr))
-            ctx.sync()                           # the index arrays die with this iteration
+        _gather_dV(ctx, d_G, m, nb, ptr, zi, zj, zv, off, d_dV)
+    return d_dV
+
+
+def _gather_dV(ctx, d_G, ldg, nb, ptr, zi, zj, zv, off, d_dV):
+    """dV[off[e] + pair(p, q)] = sum over the entries ptr[e]:ptr[e+1] of zv * G[(zi, p), (zj, q)], 32768 parameters per launch."""
+    for e0 in range(0, len(off), 32768):
+        e1 = min(len(off), e0 + 32768)
+        sl = slice(ptr[e0], ptr[e1])
+        args = [ctx.to_device((ptr[e0:e1 + 1] - ptr[e0]).astype(np.int32)), ctx.to_device(zi[sl].astype(np.int32)),
+                ctx.to_device(zj[sl].astype(np.int32)), ctx.to_device(zv[sl].astype(np.float64)),
+                ctx.to_device(np.ascontiguousarray(off[e0:e1], dtype=np.int64))]
+        ctx.check(lib.dmk_vcor_dV_dparam(ctx.h, e1 - e0, nb, d_G.ptr, ldg, args[0].ptr, args[1].ptr, args[2].ptr,
+                                         args[3].ptr, args[4].ptr, d_dV.ptr))
+        ctx.sync()                               # the index arrays die with this iteration
+
+
+CELL_GRAM_DOUBLES = 1 << 28                      # 2 GiB of shifted Gram matrices per pass of _dV_dparam_cells_dev
+
+
+def _dV_dparam_cells_dev(ctx, vcor, basis, lat, rows=None):
+    """dV/dparam of a cell-resolved potential (vcor.VcorNonLocal), the `else` branch of slater.py:893-902.  The reference sends every
+    parameter's gradient to k space and through transform_trans_inv_k, (1/nk) Re sum_k B_k^H g_k B_k; a unit entry g[R0, i, j] of
+    it is the cell CORRELATION of two basis rows,  sum_R B[R, i, :]^T B[R - R0, j, :],  so the whole table is gathered from shifted
+    Gram matrices  G_R0 = X^T X(. - R0)  of the touched rows X (one rectangular real GEMM for a group of cells R0), with the
+    kernel of the local branch reading column block R0.  A parameter's entries sit on a cell and its inverse only
+    (vcor.py:128-137), and such pairs are never split across passes."""
+    spin, ncells, nlo, nb = basis.shape
+    npair = nb * (nb + 1) // 2
+    nparam = vcor.length()
+    log.eassert(lat is not None, "dV_dparam of a non-local potential needs the lattice (cell arithmetic)")
+    if hasattr(vcor, "cell_entries"):
+        P, B, CELL, I, J = vcor.cell_entries()
+        W = np.ones(len(P))
+    else:                                                  # the reference's own object: dense (nparam, nblk, ncells, nlo, nlo) gradient
+        g = np.asarray(vcor.gradient())
+        P, B, CELL, I, J = np.nonzero(g)
+        W = g[P, B, CELL, I, J]
+    keep = B < spin
+    P, B, CELL, I, J, W = P[keep], B[keep], CELL[keep], I[keep], J[keep], W[keep]
+    p_lo, p_hi = (0, nparam) if rows is None else (int(rows[0]), int(rows[1]))
+    d_dV = ctx.zeros((max(p_hi - p_lo, 1), spin, npair), np.float64)
+    if len(P) == 0 or p_hi <= p_lo:
+        return d_dV
+    used = np.unique(np.concatenate([I, J]))
+    pos = -np.ones(nlo, dtype=np.int64)
+    pos[used] = np.arange(len(used))
+    nu = len(used)
+    m = nu * nb
+    size = np.asarray(lat.csize, dtype=np.int64)
+    where = np.asarray([lat.cell_idx2pos(R) for R in range(ncells)], dtype=np.int64) % size
+    index_of = np.empty(ncells, dtype=np.int64)
+    index_of[np.ravel_multi_index(tuple(where.T), tuple(size))] = np.arange(ncells)
+    shift = index_of[np.ravel_multi_index(tuple(((where[:, None, :] - where[None, :, :]) % size).transpose(2, 0, 1)), tuple(size))]  # [R, R0] = R - R0
+    mate = index_of[np.ravel_multi_index(tuple(((-where) % size).T), tuple(size))]                                            # -R
+    present = set(int(R) for R in np.unique(CELL))
+    groups = [[R] if mate[R] == R else [R, int(mate[R])] for R in sorted(present) if mate[R] >= R or int(mate[R]) not in present]
+    per_pass = max(2, CELL_GRAM_DOUBLES // max(m * m, 1))
+    passes, cur = [], []
+    for grp in groups:
+        if cur and len(cur) + len(grp) > per_pass:
+            passes.append(cur)
+            cur = []
+        cur = cur + grp
+    passes.append(cur)
+    for cells in passes:
+        cells = np.asarray(cells, dtype=np.int64)
+        slot = -np.ones(ncells, dtype=np.int64)
+        slot[cells] = np.arange(len(cells))
+        width = len(cells) * m
+        for s in range(spin):
+            sel = (B == s) & (slot[CELL] >= 0) & (P >= p_lo) & (P < p_hi)
+            if not sel.any():
+                continue
+            ip = P[sel]
+            ents = np.unique(ip)
+            ptr = np.concatenate([[0], np.cumsum(np.bincount(np.searchsorted(ents, ip), minlength=len(ents)))])
+            X = np.ascontiguousarray(basis[s][:, used, :]).reshape(ncells, m)
+            d_X = ctx.to_device(X)
+            d_Y = ctx.to_device(np.ascontiguousarray(X[shift[:, cells]]).reshape(ncells, width))
+            d_G = ctx.zeros((m, width), np.float64)
+            ctx.check(lib.dmk_dgemm_tn_acc_rect(ctx.h, m, width, ncells, 1.0, d_X.ptr, m, d_Y.ptr, width, d_G.ptr, width))
+            off = ((ents.astype(np.int64) - p_lo) * spin + s) * npair
+            _gather_dV(ctx, d_G, width, nb, ptr, pos[I[sel]], slot[CELL[sel]] * nu + pos[J[sel]], W[sel], off, d_dV)
     return d_dV
 
 
@@ -487,11 +564,13 @@ def _projected_basis_rows(P_full, basis_k):
 def get_dV_dparam(vcor, basis, basis_k, lattice, P_act=None, compact=True):
     """dV / dparam: (nparam, spin, npair) if compact else (nparam, spin, nbasis, nbasis).  `P_act`: the FULL projector
     (spin, nkpts, nlo, nlo) of get_active_projector_full, applied to basis_k (slater.py:878-892)."""
-    if not vcor.is_local():
-        raise NotImplementedError("k-dependent correlation potentials are outside the HIP path")
+    if getattr(vcor, "is_vcor_kpts", False):
+        raise NotImplementedError("get_dV_dparam: VcorKpoints has no gradient in the reference either (routine/vcor.py gradient())")
     ctx = get_ctx()
     spin, _, _, nbasis = np.asarray(basis).shape
-    if P_act is not None:
+    if not vcor.is_local():
+        d = get_dV_dparam_dev(ctx, vcor, basis, lattice=lattice)   # the reference's non-local branch does not read P_act (slater.py:893-902)
+    elif P_act is not None:
         if basis_k is None:
             basis_k = lattice.R2k_basis(np.asarray(basis))
         d = get_dV_dparam_dev(ctx, vcor, _projected_basis_rows(P_act, basis_k), thr=0.0)
@@ -566,10 +645,10 @@ class EmbFitDevice(object):
         else:
             self.p_lo, self.p_hi = 0, self.nparam
         self.nloc = self.p_hi - self.p_lo
-        if P_act is not None:
+        if P_act is not None and vcor.is_local():            # the non-local branch of get_dV_dparam does not read P_act (slater.py:893-902)
             self.d_dV = get_dV_dparam_dev(ctx, vcor, _projected_basis_rows(P_act, basis_k), thr=0.0, rows=(self.p_lo, self.p_hi))
         else:
-            self.d_dV = get_dV_dparam_dev(ctx, vcor, basis, rows=(self.p_lo, self.p_hi))
+            self.d_dV = get_dV_dparam_dev(ctx, vcor, basis, rows=(self.p_lo, self.p_hi), lattice=lattice)
         # fitted entries: the imp x imp block and the det diagonal of rho[fit_idx, fit_idx] (slater.py:1012-1017)
         self.fit_idx = list(imp_idx) + list(det_idx)
         nimp, nidx = len(imp_idx), len(self.fit_idx)
@@ -1305,7 +1384,8 @@ def FitVcorFull(rho, lattice, basis, vcor, beta, filling, MaxIter=20, imp_fit=Fa
     slater.py:1480-1640) or, with `num_grad=True` (required at T = 0 as in the reference), central differences inside
     the minimiser.  The SCF variant and k-dependent vcor are outside the HIP path.
     """
-    if scf or getattr(vcor, "is_vcor_kpts", False):
+    if scf or getattr(vcor, "is_vcor_kpts", False) or not vcor.is_local():
+        # get_dV_dparam_full asserts a local potential too (slater.py:1341)
         raise NotImplementedError("scf / k-dependent vcor in FitVcorFull are outside the HIP path")
     if not kwargs.get("num_grad", False) and beta == np.inf:
         raise NotImplementedError("FitVcorFull: no analytic T = 0 gradient, pass num_grad=True (slater.py:1642-1645)")

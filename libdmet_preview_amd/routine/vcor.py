@@ -93,3 +93,140 @@ class Vcor(object):
 
     def __str__(self):
         return str(self.evaluate())
+
+
+# ---- cell-resolved (translation-invariant, non-local) potential: routine/vcor.py:105-524 ---------------------------------
+
+class _VcorNonLocal(Vcor):
+    """V(R) on every lattice vector with V(-R) = V(R)^T.  The parametrisation is ONE table of assignments
+    (parameter, block, cell, row, col), built with array arithmetic over whole classes of cells:
+
+      * cells that are their own inverse hold symmetric blocks (upper-triangle parameters),
+      * of a +-R pair the member with the smaller index holds free blocks and its partner receives the transposes,
+      * per cell the parameters run [spin-0 block | spin-1 block (unrestricted) | pairing block (bogoliubov)]; a pairing block
+        that is not restricted to D = D^T has its own parameters on BOTH members of a pair (vcor.py:441-445).
+
+    `value` is (nblk, ncells, nlo, nlo) with nblk = 1 (restricted), 2 (unrestricted) or 3 (bogoliubov; the restricted form leaves
+    block 1 empty like the reference, vcor.py:281-309), `value_k` its lattice Fourier transform; `get(i)` is the slice at k-point
+    / cell i.  `cell_entries()` is what the device dV/dparam builder reads (routine/slater.py); the dense `gradient()` and
+    `grad_k` exist for callers of the reference's attributes."""
+
+    def __init__(self, restricted, bogoliubov, Lat, idx_range, bogo_res):
+        Vcor.__init__(self)
+        self.local = False
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, bogoliubov, bogo_res
+        self.lattice, self.idx_range = Lat, list(idx_range)
+        self.grad = self.grad_k = self.value_k = None
+        self.nscsites, self.ncells = Lat.nscsites, Lat.nkpts
+        self.nblk = 3 if bogoliubov else (1 if restricted else 2)
+        cell = np.arange(self.ncells)
+        mate = np.asarray([Lat.cell_pos2idx(-np.asarray(Lat.cell_idx2pos(R))) for R in cell], dtype=np.int64)
+        log.eassert(np.array_equal(mate[mate], cell), "VcorNonLocal: cell inversion is not an involution on this lattice")
+        own, lead = cell[mate == cell], cell[mate > cell]
+        orb = np.asarray(self.idx_range, dtype=np.int64)
+        n = len(orb)
+        up = np.triu_indices(n)
+        sym = (orb[up[0]], orb[up[1]])                       # it.combinations_with_replacement order
+        full = (np.repeat(orb, n), np.tile(orb, n))          # it.product order
+        nspin = 1 if restricted else 2
+        free_pairing = bogoliubov and not (restricted or bogo_res)
+        width = {}                                           # parameters of one cell of either class
+        for tag, pairs, members in (("own", sym, 1), ("lead", full, 2)):
+            t = len(pairs[0])
+            width[tag] = nspin * t + (0 if not bogoliubov else (n * n * members if free_pairing else t))
+        count = np.zeros(self.ncells, dtype=np.int64)
+        count[own], count[lead] = width["own"], width["lead"]
+        first = np.concatenate([[0], np.cumsum(count)])      # the reference's param_range (vcor.py:166-172)
+        self.param_range, self.nparam = first, int(first[-1])
+        cols = []
+
+        def emit(par, blk, at, i, j):
+            par, at, i, j = np.broadcast_arrays(par, at, i, j)
+            cols.append(np.stack([par.ravel(), np.full(par.size, blk, dtype=np.int64), at.ravel(), i.ravel(), j.ravel()]))
+
+        for cells, (pi, pj), partner in ((own, sym, None), (lead, full, mate[lead])):
+            if len(cells) == 0:
+                continue
+            t = len(pi)
+            slot = first[cells][:, None] + np.arange(t)[None, :]
+            at = cells[:, None]
+            back = at if partner is None else partner[:, None]
+            off = np.nonzero(pi != pj)[0] if partner is None else np.arange(t)      # a diagonal entry of an own cell is its own mirror
+            blocks = [(b, b * t) for b in range(nspin)]
+            if bogoliubov and not free_pairing:
+                blocks.append((2, nspin * t))
+            for blk, shift in blocks:
+                emit(slot + shift, blk, at, pi[None, :], pj[None, :])
+                emit(slot[:, off] + shift, blk, back, pj[None, off], pi[None, off])
+            if free_pairing:
+                fslot = first[cells][:, None] + nspin * t + np.arange(n * n)[None, :]
+                emit(fslot, 2, at, full[0][None, :], full[1][None, :])
+                if partner is not None:
+                    emit(fslot + n * n, 2, back, full[0][None, :], full[1][None, :])
+        tab = np.concatenate(cols, axis=1) if cols else np.zeros((5, 0), dtype=np.int64)
+        self._tab = tab[:, np.lexsort(tab[::-1])]            # sorted by (parameter, block, cell, row, col) like np.nonzero of the dense form
+
+    def __deepcopy__(self, memo):
+        """A fitted copy shares the lattice (device handles) and the index table."""
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        for name in ("param", "value", "value_k"):
+            if getattr(self, name) is not None:
+                setattr(new, name, np.array(getattr(self, name)))
+        return new
+
+    def length(self):
+        return self.nparam
+
+    def cell_entries(self):
+        """(parameter, block, cell, row, col) index arrays of the unit entries of gradient()."""
+        return tuple(self._tab)
+
+    def evaluate(self):
+        P, B, C, I, J = self._tab
+        V = np.zeros((self.nblk, self.ncells, self.nscsites, self.nscsites))
+        V[B, C, I, J] = np.asarray(self.param)[P]
+        return V
+
+    def gradient(self):
+        if self.grad is None:
+            P, B, C, I, J = self._tab
+            g = np.zeros((self.nparam, self.nblk, self.ncells, self.nscsites, self.nscsites))
+            g[P, B, C, I, J] = 1
+            self.grad = g
+            flat = self.lattice.R2k(g.reshape(self.nparam * self.nblk, self.ncells, self.nscsites, self.nscsites))
+            self.grad_k = np.asarray(flat).reshape(g.shape)
+        return self.grad
+
+    def update(self, param):
+        log.eassert(len(param) == self.nparam, "VcorNonLocal.update: %d parameters given, %d expected", len(param), self.nparam)
+        self.param = param
+        self.value = self.evaluate()
+        self.value_k = self.lattice.R2k(self.value)
+
+    def get(self, i=0, kspace=True, return_all=False):
+        log.eassert(self.value is not None, "Vcor not initialized yet")
+        table = self.value_k if kspace else self.value
+        return table if return_all else table[:, i]
+
+    def project(self, v0):
+        """Least-squares parameters of a (nblk, ncells, nlo, nlo) table: the mean of the entries each parameter owns (vcor.py:488-499)."""
+        P, B, C, I, J = self._tab
+        v0 = np.asarray(v0)
+        log.eassert(v0.shape == (self.nblk, self.ncells, self.nscsites, self.nscsites),
+                    "The correlation potential should have shape %s, rather than %s",
+                    (self.nblk, self.ncells, self.nscsites, self.nscsites), v0.shape)
+        return np.bincount(P, weights=v0[B, C, I, J], minlength=self.nparam) / np.bincount(P, minlength=self.nparam)
+
+    def assign(self, v0):
+        v0 = np.asarray(v0)
+        self.update(self.project(v0))
+        if np.linalg.norm(v0 - self.get(kspace=False, return_all=True)) >= SYMMETRIZE_WARN:
+            log.warn("symmetrization imposed on initial guess")
+
+
+def VcorNonLocal(restricted, bogoliubov, Lat, idx_range=None, bogo_res=False):
+    """Non-local correlation potential on the orbitals `idx_range` of every cell (vcor.py:105-121)."""
+    if idx_range is None:
+        idx_range = list(range(0, Lat.nscsites))
+    return _VcorNonLocal(restricted, bogoliubov, Lat, idx_range, bogo_res)
