@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1483,6 +1483,71 @@ def gen_G23():
     slater.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G23_vcor_nonlocal.npz"), **out)
     print("G23 done", len(out), "arrays")
+
+
+KPTS_MESHES = [("m411", (4, 1, 1), 3), ("m231", (2, 3, 1), 2), ("m333", (3, 3, 3), 2), ("m221", (2, 2, 1), 4), ("m511", (5, 1, 1), 3)]
+
+
+def gen_G24():
+    """The k-point-resolved potential routine/vcor.py:546-812 VcorKpoints (restricted / unrestricted; the reference raises for the
+    pairing modes) and the branch of FitVcorFull that fits it (slater.py:1519-1628: analytic finite-T gradient per +-k group), plus
+    the mean field under it (mfd.py:372-392 `is_vcor_kpts`)."""
+    from libdmet.routine import slater, mfd, vcor as rvcor
+    out = {}
+    for lname, mesh, nlo in KPTS_MESHES:
+        L = _duck_lattice(mesh, nlo)
+        L.kpts = L.kpts_scaled
+        for mname, res in (("r", True), ("u", False)):
+            key = "tab/%s/%s" % (lname, mname)
+            v = rvcor.VcorKpoints(res, False, L)
+            p = np.random.default_rng(len(key) + nlo).standard_normal(v.length())
+            v.update(p)
+            out[key + "/param"], out[key + "/value"] = p, v.value
+            out[key + "/kpts_map"] = np.asarray([g + [-1] * (2 - len(g)) for g in v.kpts_map])
+            out[key + "/nparam_kpts"] = np.asarray(v.nparam_kpts)
+            out[key + "/get2"] = v.get(2)
+    shim.patch_scf()
+    captured = {}
+    real_minimize = slater.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    slater.minimize = spy
+    cases = [("uhf_231", (2, 3, 1), 4, 2, [0, 1, 2, 3], 11), ("rhf_411", (4, 1, 1), 5, 1, [0, 1, 2, 3, 4], 12), ("rhf_222", (2, 2, 2), 4, 1, [0, 1, 2, 3], 13)]
+    for name, mesh, nlo, spin, val, seed in cases:
+        L, FR, basis, _ = _fit_case(name, mesh, nlo, spin, val, seed)
+        L.kpts = L.kpts_scaled
+        v0 = _Vcor(np.zeros((2, nlo, nlo)))
+        rhoT, mu, E = mfd.HF(L, v0, 0.5, spin == 1, beta=15.0)
+        rng = np.random.default_rng(seed + 2)
+        noise = 0.05 * rng.standard_normal((spin, nlo, nlo))
+        target = rhoT[:, 0] + 0.5 * (noise + noise.transpose(0, 2, 1))
+        out[name + "/mesh"], out[name + "/val"], out[name + "/Fock_R"] = np.array(mesh), np.array(val), FR
+        out[name + "/basis"], out[name + "/target"] = basis, target
+        runs = [("ft_imp", 15.0, dict(imp_fit=True), 12), ("ft_det", 15.0, dict(det=True), 12),
+                ("ft_imp_fixmu", 15.0, dict(imp_fit=True, fix_mu=True), 12), ("t0_num", np.inf, dict(imp_fit=True, num_grad=True), 3)]
+        for tag, beta, kw, iters in runs:
+            v = rvcor.VcorKpoints(spin == 1, False, L)
+            vfit, e0, e1 = slater.FitVcorFull(target, L, basis, v, beta, 0.5, MaxIter=iters, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](q.copy()) for q in P])
+            if captured["fgrad"] is not None:
+                out[key + "/probe_grad"] = np.asarray([captured["fgrad"](q.copy()) for q in P])
+        v = rvcor.VcorKpoints(spin == 1, False, L)
+        pv = 0.05 * np.random.default_rng(seed + 9).standard_normal(v.length())
+        v.update(pv)
+        out[name + "/hf_param"] = pv
+        for tag, beta in (("t0", np.inf), ("ft", 12.0)):
+            rhoT, mu, E, res = mfd.HF(L, v, 0.5, spin == 1, beta=beta, ires=True)
+            out["%s/hf_%s/rho" % (name, tag)], out["%s/hf_%s/mu" % (name, tag)] = rhoT, np.asarray(mu)
+            out["%s/hf_%s/E" % (name, tag)], out["%s/hf_%s/ew" % (name, tag)] = np.asarray(E), np.asarray(res["e"])
+    slater.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G24_vcor_kpoints.npz"), **out)
+    print("G24 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -203,6 +203,70 @@ class VcorNonLocal(object):
         self.update(np.asarray([np.sum(g[i] * v0) / np.sum(g[i] * g[i]) for i in range(self.nparam)]))
 
 
+class VcorKpoints(object):
+    """routine/vcor.py:526-812 (the two modes the reference implements: restricted / unrestricted, no pairing): one Hermitian
+    matrix per k point with V(-k) = V(k)^*.  k points are walked in index order; a k that is its own inverse (:526-544
+    get_kpts_map) holds a real symmetric matrix (lower-triangle parameters), the first member of a +-k pair holds
+    [real lower triangle | imaginary strict lower triangle] and its partner the complex conjugate.  Unrestricted: per group the
+    alpha half of the parameters, then the beta half (:617-633).  `value` is (nkpts, 2, nlo, nlo) complex."""
+
+    def __init__(self, restricted, kmesh, nscsites):
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, False, False
+        self.kmesh, self.nscsites = tuple(kmesh), nscsites
+        pts = list(it.product(*[range(n) for n in self.kmesh]))
+        where = dict((c, i) for i, c in enumerate(pts))
+        self.nkpts = len(pts)
+        mate = [where[tuple((-np.asarray(c)) % np.asarray(self.kmesh))] for c in pts]
+        self.kpts_map = [[k] if mate[k] == k else [k, mate[k]] for k in range(self.nkpts) if mate[k] >= k]
+        n = nscsites
+        self.n_re, self.n_im = n * (n + 1) // 2, n * (n - 1) // 2
+        per_spin = [self.n_re if len(grp) == 1 else self.n_re + self.n_im for grp in self.kpts_map]
+        self.nparam_kpts = [c * (1 if restricted else 2) for c in per_spin]
+        self.start = np.concatenate([[0], np.cumsum(self.nparam_kpts)])
+        self.is_vcor_kpts, self.param, self.value = True, None, None
+        self.update(np.zeros(self.length()))
+
+    def length(self):
+        return int(self.start[-1])
+
+    def islocal(self):
+        return False
+
+    is_local = islocal
+
+    def spin_params(self, grp, s):
+        """The parameter positions of spin block `s` in group `grp`."""
+        lo, hi = self.start[grp], self.start[grp + 1]
+        if self.restricted:
+            return np.arange(lo, hi)
+        half = (hi - lo) // 2
+        return np.arange(lo + s * half, lo + (s + 1) * half)
+
+    def evaluate(self):
+        n = self.nscsites
+        lo, so = np.tril_indices(n), np.tril_indices(n, -1)
+        V = np.zeros((self.nkpts, 2, n, n), dtype=complex)
+        for grp, ks in enumerate(self.kpts_map):
+            for s in range(2):
+                p = self.param[self.spin_params(grp, s)]
+                m = np.zeros((n, n), dtype=complex)
+                m[lo] = p[:self.n_re]
+                m[(lo[1], lo[0])] = p[:self.n_re]
+                if len(ks) == 2:
+                    m[so] += 1j * p[self.n_re:]
+                    m[(so[1], so[0])] -= 1j * p[self.n_re:]
+                    V[ks[1], s] = m.conj()
+                V[ks[0], s] = m
+        return V
+
+    def update(self, param):
+        self.param = param
+        self.value = self.evaluate()
+
+    def get(self, i=0, kspace=True):
+        return self.value[i]
+
+
 # ---------------------------------------------------------------------------------------------
 # dV / dparam (slater.py:851-907, local branch)
 # ---------------------------------------------------------------------------------------------
@@ -513,12 +577,11 @@ class FullFit(object):
     def _solve(self, param):
         spin, nk, n = self.spin, self.nk, self.n
         self.vcor.update(param)
-        v = self.vcor.get(0, True)
         ew = np.empty((spin, nk, n))
         ev = np.empty((spin, nk, n, n), dtype=np.complex128)
         for s in range(spin):
             for k in range(nk):
-                ew[s, k], ev[s, k] = la.eigh(self.Fock[s, k] + v[s])
+                ew[s, k], ev[s, k] = la.eigh(self.Fock[s, k] + self.vcor.get(k, True)[s])
         occ, mu, _ = assignocc(ew, self.nelec, self.beta, 0.0, fix_mu=self.fix_mu)
         return ew, ev, occ, mu
 
@@ -536,6 +599,26 @@ class FullFit(object):
             rho1[s][self.det_fill] = rhoT[s][self.det_mesh]
         drho = rho1 - self.target
         val = la.norm(drho)
+        if getattr(self.vcor, "is_vcor_kpts", False):
+            # slater.py:1519-1628: the first k of every group answers for the group; a +-k pair sees dw(k1) and its conjugate
+            v = self.vcor
+            lo, so = np.tril_indices(n), np.tril_indices(n, -1)
+            res = np.zeros(v.length())
+            for grp, ks in enumerate(v.kpts_map):
+                dw = get_dw_dv(ew[:, ks[0]], ev[:, ks[0]], drho, mu, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=False)
+                for s in range(spin):
+                    if len(ks) == 1:
+                        re, im = dw[s].real.copy(), None
+                    elif v.restricted:
+                        re, im = (dw[s].conj() + dw[s]).real, (dw[s].conj() - dw[s]).imag
+                    else:
+                        re, im = (dw[s] + dw[s].conj()).real, -(dw[s] - dw[s].conj()).imag
+                    re[so] *= 2.0
+                    pos = v.spin_params(grp, s)
+                    res[pos[:v.n_re]] = re[lo]
+                    if im is not None:
+                        res[pos[v.n_re:]] = 2.0 * im[so]
+            return res / (2.0 * val * sqrt(spin) * nk)
         g = self.vcor.gradient()                                            # (nparam, 2|spin, n, n)
         nparam = g.shape[0]
         tril = np.tril_indices(n)

@@ -264,3 +264,46 @@ def test_G23_nonlocal_dV_and_objectives(golden, name):
             assert np.abs(grad(p) - gr).max() < 1e-9 * max(1.0, np.abs(gr).max()), key
         pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
         assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
+
+
+# ---- round 6: the k-point-resolved potential VcorKpoints and the FitVcorFull branch that fits it (golden G24) -------------
+
+KPTS_MESHES = [("m411", (4, 1, 1), 3), ("m231", (2, 3, 1), 2), ("m333", (3, 3, 3), 2), ("m221", (2, 2, 1), 4), ("m511", (5, 1, 1), 3)]
+KPTS_RUNS = [("ft_imp", 15.0, dict(imp_fit=True)), ("ft_det", 15.0, dict(det=True)), ("ft_imp_fixmu", 15.0, dict(imp_fit=True, fix_mu=True)),
+             ("t0_num", np.inf, dict(imp_fit=True, num_grad=True))]
+
+
+@pytest.mark.parametrize("lat", KPTS_MESHES, ids=[x[0] for x in KPTS_MESHES])
+@pytest.mark.parametrize("res", [True, False], ids=["r", "u"])
+def test_G24_kpoints_tables(golden, lat, res):
+    g = golden("G24_vcor_kpoints.npz")
+    lname, mesh, nlo = lat
+    key = "tab/%s/%s" % (lname, "r" if res else "u")
+    v = F.VcorKpoints(res, mesh, nlo)
+    p = g[key + "/param"]
+    assert v.length() == len(p)
+    v.update(p)
+    assert np.array_equal(v.value, g[key + "/value"]) and np.array_equal(v.get(2), g[key + "/get2"])
+    assert [[int(x) for x in r if x >= 0] for r in g[key + "/kpts_map"]] == v.kpts_map
+    assert list(g[key + "/nparam_kpts"]) == v.nparam_kpts
+
+
+@pytest.mark.parametrize("name", NONLOCAL_FITS)
+def test_G24_full_fit_objective_and_gradient(golden, name):
+    g = golden("G24_vcor_kpoints.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    basis, FR, target = g[name + "/basis"], g[name + "/Fock_R"], g[name + "/target"]
+    spin, nlo = basis.shape[0], FR.shape[-1]
+    Fk = R.R2k(FR, mesh)
+    for tag, beta, kw in KPTS_RUNS:
+        v = F.VcorKpoints(spin == 1, mesh, nlo)
+        fit = F.FullFit(target, mesh, basis, v, beta, Fk if spin == 2 else Fk[0], 0.5, imp_idx=list(range(nlo)) if kw.get("imp_fit") else [],
+                        det_idx=list(range(nlo)) if kw.get("det") else [], fix_mu=kw.get("fix_mu", False))
+        key = "%s/%s" % (name, tag)
+        for i, p in enumerate(g[key + "/probe"]):
+            assert abs(fit.errfunc(p) - g[key + "/probe_err"][i]) < 1e-12, key
+            if key + "/probe_grad" in g:
+                gr = g[key + "/probe_grad"][i]
+                assert np.abs(fit.gradfunc_ft(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
+        pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
+        assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-10
