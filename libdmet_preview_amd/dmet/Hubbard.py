@@ -125,6 +125,7 @@ def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, 
 
 vcor_zeros = VcorLocal
 VcorNonLocal = vcor.VcorNonLocal                 # dmet/Hubbard.py:1495
+VcorKpoints = vcor.VcorKpoints                   # dmet/Hubbard.py:1497
 
 
 # ---- driver layer (dmet/Hubbard.py:14-41, 1503): thin host wrappers over the device routines ------------------------------

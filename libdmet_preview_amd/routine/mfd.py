@@ -564,7 +564,8 @@ def HF(lattice, vcor, filling, restricted, mu0=None, beta=np.inf, ires=False, sc
         # k-dependent potential: sum_k tr(v_k rho_k) (mfd.py:372-392)
         rho_k_host = d_rho.get().reshape(spin, nkpts, n, n)
         vcor_k = np.array([vcor.get(i, kspace=True) for i in range(nkpts)]).transpose(1, 0, 2, 3)
-        E = E0 + weight * np.einsum("skpq,skqp->", vcor_k[:spin], rho_k_host)
+        # restricted: BOTH spin blocks of the potential meet the one density block (einsum broadcasts the size-1 axis, mfd.py:384)
+        E = E0 + weight * np.einsum("skpq,skqp->", vcor_k, rho_k_host)
     elif vcor is not None and not vcor.islocal():
         vcorT = np.array([vcor.get(i, kspace=False) for i in range(nkpts)])
         if spin == 1:

@@ -1239,7 +1239,11 @@ class FullFitDevice(object):
             Fock = Fock[np.newaxis]
         if Fock.shape[0] < spin:
             Fock = np.asarray((Fock[0],) * spin)
-        self.d_F = ctx.to_device(Fock[:spin].reshape(spin * nk, n, n), np.complex128)
+        self.kpts = bool(getattr(vcor, "is_vcor_kpts", False))
+        if self.kpts:
+            self.F_host = np.array(Fock[:spin], dtype=np.complex128)       # the potential differs from k to k: added before the upload
+        else:
+            self.d_F = ctx.to_device(Fock[:spin].reshape(spin * nk, n, n), np.complex128)
         if imp_bath_fit:
             self.d_bk = fourier.fold_R2k_dev(ctx.to_device(basis.reshape(spin, nk, n * nb)), lattice.kmesh, spin, n * nb)
         self.fit_idx = list(imp_idx) + list(det_idx)
@@ -1260,9 +1264,13 @@ class FullFitDevice(object):
         self.d_ss = ctx.empty((1,), np.float64)
         self.nfev = self.ngev = 0
         self._key, self._state = None, None
+        self.npair = n * (n + 1) // 2
+        if self.kpts:
+            self.nparam = vcor.length()                       # slater.py:1439-1440: no dV_dparam, the gradient is assembled per k group
+            return
         # dV_dparam of the lattice problem: tril-packed vcor.gradient() (get_dV_dparam_full, slater.py:1331-1350)
         g = np.asarray(vcor.gradient())
-        self.nparam, self.npair = g.shape[0], n * (n + 1) // 2
+        self.nparam = g.shape[0]
         tl = np.tril_indices(n)
         self.d_dV = ctx.to_device(np.ascontiguousarray(g[:, :spin][:, :, tl[0], tl[1]], dtype=np.float64))
         self.d_even = ctx.to_device(np.arange(0, 2 * n, 2, dtype=np.int32))
@@ -1275,9 +1283,13 @@ class FullFitDevice(object):
         ctx, spin, nk, n, nb, nidx = self.ctx, self.spin, self.nk, self.n, self.nb, self.nidx
         mfd = self._mfd
         self.vcor.update(param)
-        v = np.ascontiguousarray(np.asarray(self.vcor.get(0, True))[:spin].real, dtype=np.float64)
-        d_add = ctx.to_device(v)
-        d_w, d_Vt = mfd.eigh_dev(ctx, self.d_F, n, spin * nk, d_add, nk)
+        if self.kpts:
+            per_k = np.asarray(self.vcor.value)[:, :spin].transpose(1, 0, 2, 3)                # (spin, nk, n, n) complex
+            d_w, d_Vt = mfd.eigh_dev(ctx, ctx.to_device((self.F_host + per_k).reshape(spin * nk, n, n), np.complex128), n, spin * nk)
+        else:
+            v = np.ascontiguousarray(np.asarray(self.vcor.get(0, True))[:spin].real, dtype=np.float64)
+            d_add = ctx.to_device(v)
+            d_w, d_Vt = mfd.eigh_dev(ctx, self.d_F, n, spin * nk, d_add, nk)
         ew = d_w.get().reshape(spin, nk, n)
         occ, mu, nerr = mfd.assignocc(ew, self.nelec, self.beta, mu0=0.0, fix_mu=self.fix_mu)
         d_occ = ctx.to_device(np.ascontiguousarray(occ).reshape(spin * nk, n), np.float64)
@@ -1342,22 +1354,15 @@ class FullFitDevice(object):
         ctx.check(lib.dmk_ewise_mul(ctx.h, 2, B * n, 2 * n, d_tmp.ptr, d_K.ptr, d_tmp.ptr))
         bg(ctx, "C", "N", n, n, n, B, d_Vt, n2, d_tmp, n2, C=d_T1)
         d_G = bg(ctx, "N", "N", n, n, n, B, d_T1, n2, d_Vt, n2, C=d_tmp)
+        if self.kpts:
+            return self._grad_per_k_group(d_G, d_Vt, d_D, f, val)
         d_sum = ctx.empty((spin, n, n), np.complex128)
         d_one = ctx.to_device(np.ones(nk))
         for s in range(spin):
             ctx.check(lib.dmk_dgemv2(ctx.h, nk, 2 * n2, d_G.offset(s * nk * n2, (nk, n, n)).ptr, 2 * n2, None, d_one.ptr, None,
                                      d_sum.offset(s * n2, (n, n)).ptr))
         if not self.fix_mu:
-            ff = f * (1.0 - f)
-            fsum = ff.sum(axis=2)                                                   # per (spin, k): ftsystem.py:271-273
-            d_ff = ctx.to_device(np.ascontiguousarray(ff).reshape(B, n))
-            d_rmu = self._mfd.density_dev(ctx, d_Vt, d_ff, n, B)                    # drho_dmu / beta for every k
-            d_y = ctx.empty((B,), np.float64)
-            for s in range(spin):
-                ctx.check(lib.dmk_dgemv2(ctx.h, nk, 2 * n2, d_rmu.offset(s * nk * n2, (nk, n, n)).ptr, 2 * n2,
-                                         d_D.offset(s * n2, (n, n)).ptr, None, d_y.offset(s * nk, (nk,)).ptr, None))
-            y = d_y.get().reshape(spin, nk)                                         # sum 2 drho o Re drho_dmu[fit, fit]
-            coef = np.where(np.abs(fsum) > ftsystem.ZERO_TOL, beta * y / np.where(fsum == 0.0, 1.0, fsum), 0.0)
+            d_rmu, coef = self._mu_response(d_Vt, d_D, f)                           # per (spin, k): ftsystem.py:265-279
             d_c = ctx.to_device(np.ascontiguousarray(coef).reshape(B))
             d_mu = ctx.empty((spin, n, n), np.complex128)
             for s in range(spin):
@@ -1376,17 +1381,63 @@ class FullFitDevice(object):
         return d_grad.get() / (2.0 * val * sqrt(spin) * nk)
 
 
+    def _mu_response(self, d_Vt, d_D, f):
+        """Per (spin, k): drho_dmu / beta on the device and the coefficient of ftsystem.py:265-279 (zero where sum f (1 - f) vanishes)."""
+        ctx, spin, nk, n, beta = self.ctx, self.spin, self.nk, self.n, self.beta
+        B, n2 = spin * nk, n * n
+        ff = f * (1.0 - f)
+        fsum = ff.sum(axis=2)
+        d_ff = ctx.to_device(np.ascontiguousarray(ff).reshape(B, n))
+        d_rmu = self._mfd.density_dev(ctx, d_Vt, d_ff, n, B)
+        d_y = ctx.empty((B,), np.float64)
+        for s in range(spin):
+            ctx.check(lib.dmk_dgemv2(ctx.h, nk, 2 * n2, d_rmu.offset(s * nk * n2, (nk, n, n)).ptr, 2 * n2,
+                                     d_D.offset(s * n2, (n, n)).ptr, None, d_y.offset(s * nk, (nk,)).ptr, None))
+        y = d_y.get().reshape(spin, nk)
+        coef = np.where(np.abs(fsum) > ftsystem.ZERO_TOL, beta * y / np.where(fsum == 0.0, 1.0, fsum), 0.0)
+        return d_rmu, coef
+
+    def _grad_per_k_group(self, d_G, d_Vt, d_D, f, val):
+        """slater.py:1519-1628 for vcor.VcorKpoints: the response matrix dw_dv of the FIRST k point of every inversion group
+        answers for the group's parameters -- its real part (lower triangle, off-diagonal doubled) for the real parameters,
+        -2 Im (strict lower triangle, doubled) for the imaginary ones of a +-k pair whose second member sees the conjugate.
+        The matrices come from the batched device products of gradfunc; this is index bookkeeping on nparam numbers."""
+        spin, nk, n, v = self.spin, self.nk, self.n, self.vcor
+        dw = d_G.get().reshape(spin, nk, n, n)
+        if not self.fix_mu:
+            d_rmu, coef = self._mu_response(d_Vt, d_D, f)
+            dw = dw + coef[:, :, None, None] * d_rmu.get().reshape(spin, nk, n, n)
+        lo, so = np.tril_indices(n), np.tril_indices(n, -1)
+        n_re = n * (n + 1) // 2
+        res = np.zeros(self.nparam)
+        for grp, ks in enumerate(v.kpts_map):
+            step = v.param_k_slices[grp]
+            for s in range(1 if v.restricted else spin):      # a restricted potential reads spin block 0 only (slater.py:1539-1552)
+                sl = step if v.restricted else step[1 + s]
+                m = dw[s, ks[0]]
+                paired = len(ks) == 2
+                re = (2.0 if paired else 1.0) * m.real
+                re[so] *= 2.0
+                res[sl.start:sl.start + n_re] = re[lo]
+                if paired:
+                    res[sl.start + n_re:sl.stop] = -4.0 * m.imag[so]
+        return res / (2.0 * val * sqrt(spin) * nk)
+
+
 def FitVcorFull(rho, lattice, basis, vcor, beta, filling, MaxIter=20, imp_fit=False, imp_idx=None, det=False, det_idx=None,
                 CG_check=False, BFGS=False, diff_criterion=None, scf=False, **kwargs):
     """
     Fit the correlation potential in the full lattice space (slater.py:1352-1682).  The objective runs on the device
     (FullFitDevice); the gradient is the reference's analytic finite-T lattice gradient (FullFitDevice.gradfunc,
     slater.py:1480-1640) or, with `num_grad=True` (required at T = 0 as in the reference), central differences inside
-    the minimiser.  The SCF variant and k-dependent vcor are outside the HIP path.
+    the minimiser.  A vcor.VcorKpoints potential (one matrix per k point) takes the per-k-group gradient of slater.py:1519-1628
+    (FullFitDevice._grad_per_k_group).  The SCF variant is outside the HIP path.
     """
-    if scf or getattr(vcor, "is_vcor_kpts", False) or not vcor.is_local():
-        # get_dV_dparam_full asserts a local potential too (slater.py:1341)
-        raise NotImplementedError("scf / k-dependent vcor in FitVcorFull are outside the HIP path")
+    if scf:
+        raise NotImplementedError("the SCF variant of FitVcorFull is outside the HIP path")
+    if not vcor.is_local() and not getattr(vcor, "is_vcor_kpts", False):
+        raise NotImplementedError("FitVcorFull: a cell-resolved potential has no lattice-stage gradient (get_dV_dparam_full asserts a local "
+                                  "one, slater.py:1341); fit it in the embedding space (FitVcorEmb)")
     if not kwargs.get("num_grad", False) and beta == np.inf:
         raise NotImplementedError("FitVcorFull: no analytic T = 0 gradient, pass num_grad=True (slater.py:1642-1645)")
     basis = np.asarray(basis)

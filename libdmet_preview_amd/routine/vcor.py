@@ -15,6 +15,7 @@ import numpy as np
 
 from libdmet_preview_amd.utils import logger as log
 from libdmet_preview_amd.utils.misc import max_abs
+from libdmet_preview_amd.settings import KPT_DIFF_TOL
 
 SYMMETRIZE_WARN = 1e-7        # reference threshold for the "initial guess was symmetrised" warning (vcor.py:69-71)
 
@@ -82,11 +83,16 @@ class Vcor(object):
         jac = self.gradient()
         param = np.empty(self.length())
         for grp, (step, ks) in enumerate(zip(self.steps, self.kpts_map)):
+            if isinstance(step, tuple):                       # unrestricted: (whole group, alpha half, beta half)
+                step = step[0]
             gc = np.conj(np.asarray(jac[grp]))
             seen = v0[ks[0]] if len(ks) == 1 else v0[ks[0]] + np.conj(v0[ks[1]])
             overlap = np.einsum('xsqp,spq->x', gc, seen)
             weight = np.einsum('xsqp,xspq->x', gc, np.asarray(jac[grp]))
-            param[step] = overlap.real / weight.real
+            # both members of a +-k pair are seen, so the Jacobian counts twice: the least-squares projection.  (The reference's
+            # formula, vcor.py:84-90, divides by the single weight and would return twice the parameters on pairs; it cannot be
+            # reached there because VcorKpoints.gradient() raises.)
+            param[step] = overlap.real / (weight.real * len(ks))
         self.update(param)
         if any(max_abs(v0[k] - self.get(k)) > SYMMETRIZE_WARN for k in range(self.nkpts)):
             log.warn("vcor.assign: per-k guess left the parametrised space (projected)")
@@ -230,3 +236,127 @@ def VcorNonLocal(restricted, bogoliubov, Lat, idx_range=None, bogo_res=False):
     if idx_range is None:
         idx_range = list(range(0, Lat.nscsites))
     return _VcorNonLocal(restricted, bogoliubov, Lat, idx_range, bogo_res)
+
+
+# ---- k-point-resolved potential: routine/vcor.py:526-812 ------------------------------------------------------------------
+
+def get_kpts_map(kpts_scaled, tol=KPT_DIFF_TOL):
+    """Groups of k points related by inversion, in order of their first member (vcor.py:526-544): [k] when no later point
+    is -k modulo a reciprocal vector, else [k, first such point]."""
+    k = np.asarray(kpts_scaled, dtype=np.float64)
+    total = k[:, None, :] + k[None, :, :]
+    opposite = np.abs(total - np.round(total)).max(axis=-1) < tol
+    free = np.ones(len(k), dtype=bool)
+    groups = []
+    for i in range(len(k)):
+        if not free[i]:
+            continue
+        later = np.nonzero(opposite[i, i + 1:])[0]
+        if len(later):
+            j = i + 1 + int(later[0])
+            free[j] = False
+            groups.append([i, j])
+        else:
+            groups.append([i])
+    log.eassert(sum(len(g) for g in groups) == len(k), "get_kpts_map: the inversion pairing does not cover the k points once")
+    return groups
+
+
+class _VcorKpoints(Vcor):
+    """One Hermitian matrix per k point with V(-k) = V(k)^*: `value` (nkpts, 2, nlo, nlo) complex (routine/vcor.py:546-812; the
+    reference implements the two modes without pairing and raises for the rest).  A k point that is its own inverse holds a real
+    symmetric matrix, the first member of a +-k pair [real lower triangle | imaginary strict lower triangle] and its partner the
+    conjugate; per group the alpha half of the parameters comes before the beta half (unrestricted), a restricted potential writes
+    both spin blocks from the same parameters.  Everything is one table (parameter, k, spin, row, col, sign) per part, so
+    evaluate() is two scatters; gradient() -- which the reference leaves unimplemented, so that its own assign() cannot run --
+    returns the per-group Jacobians that Vcor.assign projects on."""
+
+    def __init__(self, restricted, lattice, idx_range):
+        Vcor.__init__(self)
+        self.local, self.is_vcor_kpts = False, True
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, False, False
+        self.grad = self.diag_idx = None
+        n = self.nscsites = lattice.nscsites
+        self.idx_range = list(idx_range)
+        log.eassert(len(self.idx_range) == n, "VcorKpoints writes whole matrices: idx_range must cover the %d orbitals", n)
+        self.nkpts = len(lattice.kpts)
+        self.kpts_map = get_kpts_map(lattice.kpts_scaled)
+        self.ndegs = [len(g) for g in self.kpts_map]
+        n_re, n_im = n * (n + 1) // 2, n * (n - 1) // 2
+        self.n_re, self.n_im = n_re, n_im
+        nspin = 1 if restricted else 2
+        self.nparam_kpts = [nspin * (n_re if d == 1 else n_re + n_im) for d in self.ndegs]
+        first = np.concatenate([[0], np.cumsum(self.nparam_kpts)]).astype(np.int64)
+        self.nparam = int(first[-1])
+        whole = [slice(int(a), int(b)) for a, b in zip(first[:-1], first[1:])]
+        if restricted:
+            self.param_k_slices = whole
+        else:
+            self.param_k_slices = [(w, slice(w.start, w.start + (w.stop - w.start) // 2), slice(w.start + (w.stop - w.start) // 2, w.stop))
+                                   for w in whole]
+        self.steps = self.param_k_slices
+        lo, so = np.tril_indices(n), np.tril_indices(n, -1)
+        off = lo[0] != lo[1]
+        re, im = [], []                                          # columns (parameter, k, spin, row, col[, sign])
+        for grp, ks in enumerate(self.kpts_map):
+            half = self.nparam_kpts[grp] // nspin
+            for s in range(2):
+                base = first[grp] + (0 if restricted else s * half)
+                p_re, p_im = base + np.arange(n_re), base + n_re + np.arange(n_im)
+                for pos, k in enumerate(ks):
+                    re.append(np.stack([p_re, np.full(n_re, k), np.full(n_re, s), lo[0], lo[1]]))
+                    re.append(np.stack([p_re[off], np.full(int(off.sum()), k), np.full(int(off.sum()), s), lo[1][off], lo[0][off]]))
+                    if len(ks) == 2:
+                        sign = 1 if pos == 0 else -1
+                        im.append(np.stack([p_im, np.full(n_im, k), np.full(n_im, s), so[0], so[1], np.full(n_im, sign)]))
+                        im.append(np.stack([p_im, np.full(n_im, k), np.full(n_im, s), so[1], so[0], np.full(n_im, -sign)]))
+        self._re = np.concatenate(re, axis=1).astype(np.int64)
+        self._im = np.concatenate(im, axis=1).astype(np.int64) if im else np.zeros((6, 0), dtype=np.int64)
+        self.update(np.zeros(self.nparam))
+
+    def length(self):
+        return self.nparam
+
+    def evaluate(self):
+        n = self.nscsites
+        param = np.asarray(self.param, dtype=np.float64)
+        re, im = np.zeros((self.nkpts, 2, n, n)), np.zeros((self.nkpts, 2, n, n))
+        P, K, S, I, J = self._re
+        re[K, S, I, J] = param[P]
+        P, K, S, I, J, sign = self._im
+        im[K, S, I, J] = sign * param[P]
+        return re + 1j * im
+
+    def gradient(self):
+        """[group] -> (parameters of the group, 2, nlo, nlo) complex: d value[first k of the group] / d parameter."""
+        if self.grad is None:
+            n = self.nscsites
+            out = []
+            for grp, ks in enumerate(self.kpts_map):
+                w = self.param_k_slices[grp] if self.restricted else self.param_k_slices[grp][0]
+                g = np.zeros((w.stop - w.start, 2, n, n), dtype=np.complex128)
+                for tab, weight in ((self._re, None), (self._im, 1j)):
+                    sel = (tab[0] >= w.start) & (tab[0] < w.stop) & (tab[1] == ks[0])
+                    P, K, S, I, J = tab[:5, sel]
+                    g[P - w.start, S, I, J] += 1.0 if weight is None else weight * tab[5, sel]
+                out.append(g)
+            self.grad = out
+        return self.grad
+
+    def diag_indices(self):
+        raise NotImplementedError("VcorKpoints.diag_indices: undefined in the reference as well (routine/vcor.py:698-702 fails on a missing name)")
+
+    def show(self):
+        v = self.get()
+        fitted = v[np.ix_(np.arange(v.shape[0]), self.idx_range, self.idx_range)]
+        return ("vcor\nnao %d \nidx range %s, length %s\nres: %s, bogo: %s, bogo res: %s\n%s"
+                % (v.shape[-1], self.idx_range, len(self.idx_range), self.restricted, self.bogoliubov, self.bogo_res, fitted))
+
+
+def VcorKpoints(restricted, bogoliubov, lattice, idx_range=None, bogo_res=False, v_idx=None, d_idx=None, ghf=False):
+    """k-points adapted correlation potential (vcor.py:546-561)."""
+    if v_idx is not None or d_idx is not None or bogoliubov:
+        raise NotImplementedError                                # vcor.py:589-606, 776-789
+    if idx_range is None:
+        idx_range = list(range(0, lattice.nscsites))
+    return _VcorKpoints(restricted, lattice, idx_range)

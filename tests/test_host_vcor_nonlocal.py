@@ -49,3 +49,56 @@ def test_copy_shares_the_lattice_and_table():
     assert v.param[0] == 0.0
     with pytest.raises(Exception):
         v.project(np.zeros((2, 4, 3, 3)))
+
+
+# ---- the k-point-resolved potential (reference routine/vcor.py:526-812), golden G24 -----------------------------------------
+
+from tests.test_oracle_fit import KPTS_MESHES  # noqa: E402
+
+
+@pytest.mark.parametrize("lat", KPTS_MESHES, ids=[x[0] for x in KPTS_MESHES])
+@pytest.mark.parametrize("res", [True, False], ids=["r", "u"])
+def test_kpoints_tables_vs_reference(golden, lat, res):
+    from libdmet_preview_amd.system.lattice import Lattice
+    from libdmet_preview_amd.dmet import Hubbard
+    g = golden("G24_vcor_kpoints.npz")
+    lname, mesh, nlo = lat
+    key = "tab/%s/%s" % (lname, "r" if res else "u")
+    L = Lattice(nlo, mesh)
+    v = Hubbard.VcorKpoints(res, False, L)
+    assert v.is_vcor_kpts and not v.is_local() and np.abs(v.value).max() == 0.0        # starts at zero like the reference (vcor.py:809-810)
+    p = g[key + "/param"]
+    assert v.length() == len(p)
+    v.update(p)
+    assert np.array_equal(v.value, g[key + "/value"]) and np.array_equal(v.get(2), g[key + "/get2"])
+    assert [[int(x) for x in r if x >= 0] for r in g[key + "/kpts_map"]] == v.kpts_map
+    assert list(g[key + "/nparam_kpts"]) == v.nparam_kpts and v.ndegs == [len(k) for k in v.kpts_map]
+    # Hermitian at every k, conjugate at -k
+    for ks in v.kpts_map:
+        assert np.array_equal(v.value[ks[0]], v.value[ks[0]].conj().transpose(0, 2, 1))
+        assert np.array_equal(v.value[ks[-1]], v.value[ks[0]].conj() if len(ks) == 2 else v.value[ks[0]])
+    # gradient(): exactly the columns of the linear map, and assign() inverts evaluate() on the parametrised space
+    jac, w = v.gradient(), Hubbard.VcorKpoints(res, False, L)
+    for grp, ks in enumerate(v.kpts_map):
+        sl = v.steps[grp] if res else v.steps[grp][0]
+        for x in range(sl.stop - sl.start):
+            e = np.zeros(len(p))
+            e[sl.start + x] = 1.0
+            w.update(e)
+            assert np.array_equal(w.value[ks[0]], jac[grp][x])
+    w.assign(v.value)
+    assert np.abs(w.param - p).max() < 1e-14
+
+
+def test_kpoints_refusals_and_map():
+    from libdmet_preview_amd.system.lattice import Lattice
+    from libdmet_preview_amd.routine import vcor
+    L = Lattice(2, (3, 2, 1))
+    for kw in (dict(bogoliubov=True), dict(bogoliubov=False, v_idx=[(0, 0)]), dict(bogoliubov=False, d_idx=[(0, 0)])):
+        with pytest.raises(NotImplementedError):
+            vcor.VcorKpoints(True, lattice=L, **kw)
+    with pytest.raises(NotImplementedError):
+        vcor.VcorKpoints(True, False, L).diag_indices()
+    # get_kpts_map on points outside the first zone and in arbitrary order
+    k = np.array([[0.0, 0, 0], [1.25, 0, 0], [0.5, 0, 0], [-0.25, 0, 0], [0.1, 0.2, 0.3], [0.9, 0.8, -0.3]])
+    assert vcor.get_kpts_map(k) == [[0], [1, 3], [2], [4, 5]]
