@@ -58,6 +58,10 @@ _FUNCTIONS = [
     ("routine.ftsystem", ["routine.ftsystem"], ["kernel", "make_rdm1", "get_rho_grad", "get_dw_dv"]),
     ("utils.cholesky", ["utils.cholesky"], ["modified_cholesky", "modified_cholesky_uhf", "get_cderi_rhf", "get_cderi_uhf"]),
     ("routine.localizer", ["routine.localizer"], ["localize_bath", "localize_bath_scdm"]),
+    # the cell-resolved and the k-point-resolved potentials (dmet/Hubbard.py:1495-1497 re-exports them): the index-table classes the
+    # device dV/dparam builder and the lattice-stage fit read without a dense (nparam, nblk, ncells, nlo, nlo) gradient
+    ("routine.vcor", ["routine.vcor", "dmet.Hubbard"], ["VcorNonLocal", "VcorKpoints"]),
+    ("routine.vcor", ["routine.vcor"], ["get_kpts_map"]),
     # BCS twin (routine/bcs.py:13 star-imports bcs_helper)
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
