@@ -47,6 +47,7 @@ _FUNCTIONS = [
       "transform_ao_to_emb", "_Lij_s4_to_eri", "get_basis_k", "get_weights_t_reversal"]),
     # J / K on the resident ERI (routine/slater.py:30 imports them by name)
     ("solver.scf", ["solver.scf", "routine.slater"], ["_get_jk", "_get_veff"]),
+    ("solver.scf", ["solver.scf", "routine.spinless"], ["_get_veff_ghf"]),          # routine/spinless.py:28 imports it by name
     # one-body folds (routine/slater.py:35 star-imports slater_helper)
     ("routine.slater_helper", ["routine.slater_helper", "routine.slater"],
      ["transform_trans_inv", "transform_trans_inv_k", "transform_local", "transform_imp", "transform_imp_env",

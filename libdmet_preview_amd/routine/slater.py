@@ -29,7 +29,7 @@ from libdmet_preview_amd.basis_transform.eri_transform import get_emb_eri, get_u
 from libdmet_preview_amd.routine.slater_helper import *       # noqa: F401,F403  (reference: slater.py:35)
 from libdmet_preview_amd.routine.slater_helper import (transform_trans_inv, transform_trans_inv_k, transform_local,
                                                        transform_imp, transform_eri_local, unit2emb)
-from libdmet_preview_amd.solver.scf import _get_jk, _get_veff
+from libdmet_preview_amd.solver.scf import _get_jk, _get_veff, _get_veff_ghf
 from libdmet_preview_amd.system import integral
 from libdmet_preview_amd.utils import logger as log
 from libdmet_preview_amd.utils.misc import add_spin_dim
@@ -264,9 +264,15 @@ def foldRho(rho, lattice, basis):
 
 def get_veff(rdm1, eri, hyb=1.0, ghf=False, hyb_j=1.0):
     """Effective potential of the embedding Hamiltonian (slater.py:477-523); rdm1 is spin traced if restricted."""
-    if ghf:
-        raise NotImplementedError("the GHF effective potential is outside the HIP path")
     rdm1 = np.asarray(rdm1)
+    if ghf:
+        # ONE spin-orbital density against a spinless ERI (slater.py:489-506): J - hyb K, J scaled by hyb_j in the DFT branches
+        assert rdm1.ndim == 2
+        if hyb == 1.0:
+            return _get_veff_ghf(rdm1, eri)
+        vj, vk = _get_jk(rdm1, eri, with_j=True, with_k=hyb != 0.0)
+        vj0 = vj[0] if hyb_j == 1.0 else vj[0] * hyb_j
+        return vj0 if hyb == 0.0 else vj0 - (vk[0] * hyb)
     if rdm1.ndim == 2:
         rdm1 = rdm1[None]
     spin = rdm1.shape[0]

@@ -110,3 +110,10 @@ def _get_veff(dm, eri):
     else:
         veff = vj[0] + vj[1] - vk
     return veff
+
+
+def _get_veff_ghf(dm, eri):
+    """HF effective potential of a generalised (spin-orbital) density against a spinless ERI, vj - vk (solver/scf.py:732-740)."""
+    dm = np.asarray(dm, dtype=np.double)
+    vj, vk = _get_jk(dm, eri)
+    return vj[0] - vk[0]

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1548,6 +1548,29 @@ def gen_G24():
     slater.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G24_vcor_kpoints.npz"), **out)
     print("G24 done", len(out), "arrays")
+
+
+def gen_G25():
+    """slater.get_veff(ghf=True) (slater.py:489-506 over solver/scf.py:732-740 _get_veff_ghf): one spin-orbital density against a
+    spinless ERI in 1-, 4- and 8-fold storage, HF / J-only / hybrid with and without a scaled J."""
+    shim.patch_scf()
+    from libdmet.routine import slater
+    from libdmet.solver import scf as rscf
+    out = {}
+    for name, nso, seed in (("n6", 6, 1), ("n10", 10, 2)):
+        rng = np.random.default_rng(seed)
+        eri = _psd_eri(rng, nso, 3 * nso, 1)[0]
+        x = rng.standard_normal((nso, nso))
+        dm = 0.5 * np.eye(nso) + 0.1 * (x + x.T)
+        out[name + "/eri_s4"], out[name + "/dm"] = eri, dm
+        for fmt in ("s1", "s4", "s8"):
+            e = eri if fmt == "s4" else shim.restore(1 if fmt == "s1" else 8, eri, nso)
+            for tag, kw in (("hf", dict()), ("j", dict(hyb=0.0)), ("j07", dict(hyb=0.0, hyb_j=0.7)), ("hyb", dict(hyb=0.25)),
+                            ("hyb_j07", dict(hyb=0.25, hyb_j=0.7))):
+                out["%s/%s/%s" % (name, fmt, tag)] = slater.get_veff(dm, e, ghf=True, **kw)
+        out[name + "/veff_ghf"] = rscf._get_veff_ghf(dm, eri)
+    np.savez_compressed(os.path.join(GOLD, "G25_veff_ghf.npz"), **out)
+    print("G25 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

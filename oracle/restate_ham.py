@@ -193,9 +193,17 @@ def get_jk(dm, eri, with_j=True, with_k=True):
     return np.asarray(((vj00, vj11), (vj01, vj10))), np.asarray((vk00, vk11))
 
 
-def get_veff(rdm1, eri, hyb=1.0, hyb_j=1.0):
-    """slater.py:477-523 (non-GHF branches)."""
+def get_veff(rdm1, eri, hyb=1.0, hyb_j=1.0, ghf=False):
+    """slater.py:477-523; ghf: ONE (nso, nso) density against a spinless ERI, J - hyb K with J scaled by hyb_j
+    (solver/scf.py:732-740 _get_veff_ghf for the HF case)."""
     rdm1 = np.asarray(rdm1)
+    if ghf:
+        assert rdm1.ndim == 2
+        vj, vk = get_jk(rdm1, eri, with_j=True, with_k=hyb != 0.0)
+        if hyb == 1.0:
+            return vj[0] - vk[0]
+        vj0 = vj[0] if hyb_j == 1.0 else vj[0] * hyb_j
+        return vj0 if hyb == 0.0 else vj0 - (vk[0] * hyb)
     if rdm1.ndim == 2:
         rdm1 = rdm1[None]
     spin = rdm1.shape[0]

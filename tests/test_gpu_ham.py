@@ -284,3 +284,24 @@ def test_set_Ham_and_update_Ham(ctx, golden, name):
         Lattice(int(C.shape[-1]), mesh).set_Ham(None, None, C, ovlp=S, hcore=hcore)       # no rdm1, no kmf
     with pytest.raises(NotImplementedError):
         L.set_Ham(None, None, C, ovlp=S, hcore=hcore, rdm1=rdm1, vhf=vhf, vxc=vhf)
+
+
+@pytest.mark.parametrize("name", ["n6", "n10"])
+def test_veff_ghf(ctx, golden, name):
+    """slater.get_veff(ghf=True) and scf._get_veff_ghf (slater.py:489-506, solver/scf.py:732-740) on dmk_jk_s4 against the
+    reference's values (golden G25), from 1-, 4- and 8-fold ERI storage."""
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.solver import scf
+    from libdmet_preview_amd.basis_transform.eri_transform import eri_restore
+    from tests.test_oracle_ham import GHF_VEFF
+    g = golden("G25_veff_ghf.npz")
+    dm, e4 = g[name + "/dm"], g[name + "/eri_s4"]
+    nso = dm.shape[-1]
+    stores = {"s4": e4, "s1": eri_restore(e4[None], 1, nso)[0], "s8": eri_restore(e4[None], 8, nso)[0]}
+    for fmt, e in stores.items():
+        for tag, kw in GHF_VEFF:
+            got = slater.get_veff(dm, e, ghf=True, **kw)
+            assert got.shape == (nso, nso) and np.abs(got - g["%s/%s/%s" % (name, fmt, tag)]).max() < 1e-12, (fmt, tag)
+    assert np.abs(scf._get_veff_ghf(dm, e4) - g[name + "/veff_ghf"]).max() < 1e-12
+    with pytest.raises(AssertionError):
+        slater.get_veff(dm[None], e4, ghf=True)

@@ -97,3 +97,18 @@ def test_G8_model(golden, name):
     assert np.array_equal(H2n, g[name + "/nib_H2"])
     H1n, _, _ = H.embHam1e(mesh, basis, H2n, Hk, Hk, Sk, g[name + "/rdm1_lo_k"], vcor_mat=v, int_bath=False)
     assert np.abs(H1n - g[name + "/nib_H1"]).max() < 1e-11
+
+
+GHF_VEFF = [("hf", dict()), ("j", dict(hyb=0.0)), ("j07", dict(hyb=0.0, hyb_j=0.7)), ("hyb", dict(hyb=0.25)), ("hyb_j07", dict(hyb=0.25, hyb_j=0.7))]
+
+
+@pytest.mark.parametrize("name", ["n6", "n10"])
+def test_G25_veff_ghf(golden, name):
+    """slater.get_veff(ghf=True) (slater.py:489-506): every branch, the three ERI storages agree."""
+    g = golden("G25_veff_ghf.npz")
+    dm, e4 = g[name + "/dm"], g[name + "/eri_s4"]
+    for tag, kw in GHF_VEFF:
+        ref = g["%s/s4/%s" % (name, tag)]
+        assert np.abs(H.get_veff(dm, e4, ghf=True, **kw) - ref).max() < 1e-13
+        assert np.abs(g["%s/s1/%s" % (name, tag)] - ref).max() < 1e-12 and np.abs(g["%s/s8/%s" % (name, tag)] - ref).max() < 1e-12
+    assert np.abs(g[name + "/veff_ghf"] - g[name + "/s4/hf"]).max() < 1e-13
