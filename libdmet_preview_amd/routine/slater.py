@@ -298,12 +298,22 @@ def _embHam2e(lattice, basis, vcor, local, int_bath=True, last_aabb=True, **kwar
                 H2 = transform_eri_local(basis, lattice, LatH2)
             else:
                 H2 = unit2emb(np.asarray((LatH2,) * (spin * (spin + 1) // 2)), nbasis)
-        elif lattice.H2_format == "spin local":
+        elif lattice.H2_format in ("nearest", "full", "spin local"):
+            # bare bath only (slater.py:407-426): the impurity block of the lattice ERI -- LatH2[0] of a neighbour list,
+            # LatH2[0, 0, 0] of a full cell-resolved tensor, LatH2[i] per spin block -- zero-padded to the embedding size
             if int_bath:
                 raise NotImplementedError
-            H2 = unit2emb(np.asarray(LatH2), nbasis)
+            nblk = spin * (spin + 1) // 2
+            LatH2 = np.asarray(LatH2)
+            if lattice.H2_format == "nearest":
+                blocks = np.asarray((LatH2[0],) * nblk)
+            elif lattice.H2_format == "full":
+                blocks = np.asarray((LatH2[0, 0, 0],) * nblk)
+            else:
+                blocks = LatH2[:nblk]
+            H2 = unit2emb(np.ascontiguousarray(blocks), nbasis)
         else:
-            raise NotImplementedError("H2_format %s is outside the HIP path" % lattice.H2_format)
+            raise ValueError("unknown H2_format %s" % lattice.H2_format)
     else:
         opts = dict(kscaled_center=kwargs.get("kscaled_center", None), symmetry=lattice.eri_symmetry,
                     max_memory=kwargs.get("max_memory", None), swap_idx=kwargs.get("swap_idx", None),

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1571,6 +1571,55 @@ def gen_G25():
         out[name + "/veff_ghf"] = rscf._get_veff_ghf(dm, eri)
     np.savez_compressed(os.path.join(GOLD, "G25_veff_ghf.npz"), **out)
     print("G25 done", len(out), "arrays")
+
+
+def gen_G26():
+    """A corner of get_emb_Ham: the model ERI formats other than 'local' with a bare bath (slater.py:407-426: 'nearest', 'full',
+    'spin local' -- the impurity block zero-padded), on the Hubbard lattices of G8."""
+    from libdmet.routine import slater, mfd
+    from libdmet.solver import scf as rscf
+    shim.patch_scf()
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+    out = {}
+    for name, mesh, cs, spin in [("C1", (6, 1, 1), (2,), 1), ("C1u", (6, 1, 1), (2,), 2)]:
+        H1 = synth.hubbard_h1_R(mesh, cs)
+        nlo, nk = H1.shape[-1], int(np.prod(mesh))
+        L = _duck_lattice(mesh, nlo, val=list(range(nlo)))
+        L.is_model, L.eri_symmetry = True, 1
+        rng = np.random.default_rng(31 + spin)
+        v = np.zeros((2, nlo, nlo))
+        v[0] = np.diag(2.0 + 0.3 * (-1.0) ** np.arange(nlo))
+        v[1] = np.diag(2.0 - 0.3 * (-1.0) ** np.arange(nlo)) if spin == 2 else v[0]
+        vc = _Vcor(v)
+        L.hcore_lo_k = L.fock_lo_k = synth.fold_R2k(H1, mesh)
+        L.hcore_lo_R = L.fock_lo_R = H1
+        SR = np.zeros_like(H1)
+        SR[0] = np.eye(nlo)
+        L.ovlp_lo_k = synth.fold_R2k(SR[None], mesh)[0]
+        L.JK_imp, L.Ham, L.H0 = None, None, 0.0
+        rhoT, mu, E, res = mfd.HF(L, vc, 0.5, spin == 1, beta=np.inf, ires=True)
+        L.rdm1_lo_k = res["rho_k"] * (2.0 if spin == 1 else 1.0)
+        basis = slater.get_emb_basis(L, rhoT)
+        out[name + "/mesh"], out[name + "/H1_R"], out[name + "/vcor"] = np.array(mesh), H1, v
+        out[name + "/rdm1_lo_k"], out[name + "/basis"] = L.rdm1_lo_k, basis
+        for fmt, shape in (("nearest", (3,)), ("full", (nk, nk, nk)), ("spin local", (3,))):
+            blocks = np.asarray([shim.restore(1, b, nlo) for b in _psd_eri(rng, nlo, 5, 2)])     # permutationally symmetric (aa, bb, ab)
+            if fmt == "full":
+                LatH2 = np.zeros(shape + (nlo,) * 4)
+                LatH2[0, 0, 0], LatH2[1, 0, 2] = blocks[0], blocks[1]
+            else:
+                LatH2 = blocks
+            L.H2_format = fmt
+            L.getH2 = lambda compact=False, kspace=False, _h=LatH2: _h
+            Hn, _ = slater.get_emb_Ham(L, basis, vc, int_bath=False)
+            tag = fmt.replace(" ", "_")
+            if fmt == "full":
+                out["%s/%s_LatH2_000" % (name, tag)], out["%s/%s_LatH2_102" % (name, tag)] = LatH2[0, 0, 0], LatH2[1, 0, 2]
+            else:
+                out["%s/%s_LatH2" % (name, tag)] = LatH2
+            out["%s/%s_H1" % (name, tag)], out["%s/%s_H2" % (name, tag)] = Hn.H1["cd"], Hn.H2["ccdd"]
+    np.savez_compressed(os.path.join(GOLD, "G26_embham_corners.npz"), **out)
+    print("G26 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

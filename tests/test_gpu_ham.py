@@ -305,3 +305,35 @@ def test_veff_ghf(ctx, golden, name):
     assert np.abs(scf._get_veff_ghf(dm, e4) - g[name + "/veff_ghf"]).max() < 1e-12
     with pytest.raises(AssertionError):
         slater.get_veff(dm[None], e4, ghf=True)
+
+
+@pytest.mark.parametrize("name", ["C1", "C1u"])
+def test_model_eri_formats_bare_bath(ctx, golden, name):
+    """The model ERI formats other than 'local' with a non-interacting bath (slater.py:407-426): the impurity block of a
+    neighbour list, of a full cell-resolved tensor, of per-spin blocks, zero-padded (dmk_pad_block_f64); an interacting bath
+    raises like the reference.  Golden G26."""
+    from libdmet_preview_amd.routine import slater
+    g = golden("G26_embham_corners.npz")
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    H1R, v, basis = g[name + "/H1_R"], g[name + "/vcor"], g[name + "/basis"]
+    n, nk = H1R.shape[-1], int(np.prod(mesh))
+    L = _lattice(mesh, n, list(range(n)))
+    L.set_Ham_lo(fock_lo_R=H1R, hcore_lo_R=H1R)
+    L.rdm1_lo_k = g[name + "/rdm1_lo_k"]
+    vc = _Vcor(v)
+    for fmt in ("nearest", "full", "spin local"):
+        tag = fmt.replace(" ", "_")
+        if fmt == "full":
+            LatH2 = np.zeros((nk, nk, nk) + (n,) * 4)
+            LatH2[0, 0, 0], LatH2[1, 0, 2] = g["%s/%s_LatH2_000" % (name, tag)], g["%s/%s_LatH2_102" % (name, tag)]
+        else:
+            LatH2 = g["%s/%s_LatH2" % (name, tag)]
+        L.set_H2_local(LatH2, H2_format=fmt)
+        Hn, _ = slater.get_emb_Ham(L, basis, vc, int_bath=False)
+        assert np.array_equal(Hn.H2["ccdd"], g["%s/%s_H2" % (name, tag)]), fmt
+        assert np.abs(Hn.H1["cd"] - g["%s/%s_H1" % (name, tag)]).max() < 1e-10, fmt
+        with pytest.raises(NotImplementedError):
+            slater.get_emb_Ham(L, basis, vc)
+    L.set_H2_local(LatH2, H2_format="diagonal")
+    with pytest.raises(ValueError):
+        slater.get_emb_Ham(L, basis, vc, int_bath=False)
