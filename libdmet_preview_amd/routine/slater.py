@@ -428,7 +428,9 @@ embHam = get_emb_Ham
 def get_dV_dparam_dev(ctx, vcor, basis, thr=1e-7, rows=None, lattice=None):
     """Device dV_dparam (nparam, spin, npair) f64, tril packed (slater.py:851-877 with transform_local_sparseH,
     slater_helper.py:91-100): gathered from the cell Gram matrix of the basis rows that any parameter touches.
-    `rows` = (p_lo, p_hi): only that range of parameters (a rank's shard of the table), shape (p_hi - p_lo, spin, npair)."""
+    `rows` = (p_lo, p_hi): only that range of parameters (a rank's shard of the table), shape (p_hi - p_lo, spin, npair).
+    A potential that is not local (vcor.VcorNonLocal, or the reference's own object of that kind) goes to _dV_dparam_cells_dev;
+    `lattice` supplies the cell arithmetic when the potential does not carry one."""
     basis = np.asarray(basis, dtype=np.float64)
     spin, ncells, nlo, nb = basis.shape
     npair = nb * (nb + 1) // 2

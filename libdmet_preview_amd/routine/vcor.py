@@ -10,6 +10,12 @@ written here around two ideas of this package:
     batch before the upload (routine/mfd.py `_fock_plus_vcor`).
 
 Host bookkeeping only; the fit itself runs on the device (routine/slater.py EmbFitDevice).
+
+Parametrisations defined here (the local one lives in dmet/Hubbard.py like in the reference):
+  VcorNonLocal  (vcor.py:105-524)  one block per lattice vector, V(-R) = V(R)^T; fitted in the embedding space, its dV/dparam is
+                                   gathered on the device from shifted Gram matrices (slater._dV_dparam_cells_dev);
+  VcorKpoints   (vcor.py:546-812)  one Hermitian matrix per k point, V(-k) = V(k)^*; fitted on the lattice (slater.FitVcorFull).
+Both keep ONE integer table of assignments instead of the reference's per-mode closures; evaluate() is a scatter.
 """
 import numpy as np
 
