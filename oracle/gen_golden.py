@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1620,6 +1620,86 @@ def gen_G26():
             out["%s/%s_H1" % (name, tag)], out["%s/%s_H2" % (name, tag)] = Hn.H1["cd"], Hn.H2["ccdd"]
     np.savez_compressed(os.path.join(GOLD, "G26_embham_corners.npz"), **out)
     print("G26 done", len(out), "arrays")
+
+
+def gen_G27():
+    """The GSO (partial particle-hole, spin-orbital) embedding Hamiltonian: routine/spinless.py:431-725 get_emb_Ham over
+    routine/spinless_helper.py:288-440 (unit2emb with the alpha / beta pair masks, transform_eri_local, transform_trans_inv_k,
+    transform_local, transform_imp) and slater.get_veff(ghf=True), on the generalised lattices of G7: every bath regime with a
+    given ERI, the model branch ('spin local' lattice ERI, interacting and bare bath) and the helpers on their own."""
+    spinless, sh = shim.patch_spinless()
+    from libdmet.routine import slater
+    from libdmet.solver import scf as rscf
+    from libdmet.system import lattice as rl
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+    g7 = np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        nk = int(np.prod(mesh))
+        rng = np.random.default_rng(2700 + n)
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        GRho_k = g7[name + "/ghf_rho_k"]
+        GRho = rl.FFTtoT(GRho_k, mesh)
+        basis = spinless.get_emb_basis(L, GRho)                         # (ncells, 2 n, neo)
+        neo = basis.shape[-1]
+        FR = g7[name + "/Fock_R"]
+        D_R = synth.make_fock_R(mesh, n, spin=1, seed=17 + n)[0] * 0.3
+        H3 = synth.fold_R2k(np.asarray([0.6 * FR[0], -0.6 * FR[1], 0.5 * D_R]), mesh)
+        F3 = synth.fold_R2k(np.asarray([FR[0], -FR[1], D_R]), mesh)
+        S3 = np.zeros((3, nk, n, n), dtype=complex)
+        S3[0] = S3[1] = np.eye(n)
+        L.hcore_lo_k, L.fock_lo_k, L.fock_hf_lo_k, L.ovlp_lo_k = H3, F3, 0.9 * F3, S3
+        L.rdm1_lo_k, L.JK_imp, L.Ham, L.H0 = GRho_k, None, None, 0.75
+        v = g7[name + "/vcor"]
+        vc = _Vcor(v)
+        mu = 0.37
+        H2 = _psd_eri(rng, neo, 7, 1)                                    # (1, neo_pair, neo_pair)
+        out[name + "/mesh"], out[name + "/val"], out[name + "/basis"], out[name + "/H2"] = np.array(mesh), np.array(val), basis, H2
+        out[name + "/H3_k"], out[name + "/F3_k"], out[name + "/vcor"], out[name + "/GRho_k"] = H3, F3, v, GRho_k
+        JK3 = rng.standard_normal((3, n, n))
+        JK3[0], JK3[1] = JK3[0] + JK3[0].T, JK3[1] + JK3[1].T
+        add2 = rng.standard_normal((2, n, n))
+        add2 = add2 + add2.transpose(0, 2, 1)
+        cust = synth.fold_R2k(np.asarray([0.3 * FR[0], -0.2 * FR[1]]), mesh)
+        out[name + "/JK_imp"], out[name + "/hcore_add"], out[name + "/hcore_custom"] = JK3, add2, cust
+        runs = [("ib", dict()), ("ib_vcor", dict(add_vcor=True)), ("ib_vcor_fit", dict(add_vcor=True, fitting=True)),
+                ("ib_add", dict(hcore_add=add2, H0_add=0.5)), ("ib_custom", dict(hcore_custom=cust)),
+                ("nib", dict(int_bath=False)), ("nib_jk", dict(int_bath=False, JK_imp=JK3)), ("nib_add", dict(int_bath=False, hcore_add=add2)),
+                ("nib_hcore", dict(int_bath=False, hcore=True, hcore_add=add2))]
+        for tag, kw in runs:
+            kw = dict(kw)
+            L.JK_imp = kw.pop("JK_imp", None)
+            L.use_hcore_as_emb_ham = kw.pop("hcore", False)
+            L.JK_core = "unset"
+            Himp, _ = spinless.get_emb_Ham(L, basis, vc, mu, H2_given=H2, **kw)
+            out["%s/%s_H1" % (name, tag)], out["%s/%s_ovlp" % (name, tag)] = Himp.H1["cd"], np.asarray(Himp.ovlp)
+            out["%s/%s_H0" % (name, tag)] = np.asarray(Himp.H0)
+            if L.JK_core is not None:
+                out["%s/%s_JK_core" % (name, tag)] = np.asarray(L.JK_core)
+            assert Himp.H2["ccdd"] is H2 and Himp.norb == neo and Himp.restricted and not Himp.bogoliubov
+        L.JK_imp, L.use_hcore_as_emb_ham = None, False
+        # helpers on their own
+        bka, bkb = sh.separate_basis(L.R2k_basis(basis))
+        bRa, bRb = sh.separate_basis(basis)
+        out[name + "/ti_k3"], out[name + "/ti_k2"] = sh.transform_trans_inv_k(bka, bkb, F3), sh.transform_trans_inv_k(bka, bkb, F3[:2])
+        out[name + "/loc3"], out[name + "/loc2"] = sh.transform_local(bRa, bRb, v), sh.transform_local(bRa, bRb, v[:2])
+        out[name + "/imp3"], out[name + "/imp2"] = sh.transform_imp(bRa, bRb, v), sh.transform_imp(bRa, bRb, v[:2])
+        out[name + "/foldRho_k"] = spinless.foldRho_k(GRho_k, L.R2k_basis(basis))
+        unit = _psd_eri(rng, n, 5, 2)                                   # (aa, bb, ab), 4-fold
+        out[name + "/unit"], out[name + "/unit2emb"] = unit, sh.unit2emb(unit, neo)
+        if n <= 4:
+            # model branch: the lattice ERI is the unit triple; the basis must be the identity on the impurity (spinless.py:483-484)
+            L.is_model, L.H2_format, L.eri_symmetry = True, "spin local", 4
+            L.getH2 = lambda compact=False, kspace=False, use_Ham=True, _h=unit: _h
+            out[name + "/eri_local"] = sh.transform_eri_local(bRa, bRb, unit)
+            for tag, kw in (("model_ib", dict()), ("model_nib", dict(int_bath=False))):
+                L.JK_core = "unset"
+                Himp, _ = spinless.get_emb_Ham(L, basis, vc, mu, **kw)
+                out["%s/%s_H1" % (name, tag)], out["%s/%s_H2" % (name, tag)] = Himp.H1["cd"], np.asarray(Himp.H2["ccdd"])
+                out["%s/%s_JK_core" % (name, tag)] = np.asarray(L.JK_core)
+            L.is_model = False
+    np.savez_compressed(os.path.join(GOLD, "G27_gso_embham.npz"), **out)
+    print("G27 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@ SURVEY.md section 8(f) rank 4:
   eri_transform.get_emb_eri_gso   basis_transform/eri_transform.py:1104-1250
   _Lij_s4_to_eri_gso              basis_transform/eri_transform.py:1252-1310  (aaaa + bbbb - aabb - bbaa)
 
+  spinless.get_emb_Ham            routine/spinless.py:431-725 over spinless_helper.py:261-440 (pinned by tests/golden/G27_gso_embham.npz)
+
 TEST INFRASTRUCTURE ONLY.  Pinned against tests/golden/G12_gso.npz (oracle/gen_golden.py gen_G12: the reference's
 own functions under oracle/shim.py; the ERI driver over the restated PySCF primitives of oracle/shim.py).
 """
@@ -224,3 +226,113 @@ def get_emb_eri_gso(kmesh, kpts_scaled, get_block, naux, nao, C_ao_lo, basis, sy
                     visited[jm] = True
         Lij_s4_to_eri_gso(Lij_s4, eri, weight=weights[kL], t_reversal_symm=t_reversal_symm)
     return eri_restore(eri.real, symmetry, nemb)
+
+
+# ---------------------------------------------------------------------------------------------
+# GSO embedding Hamiltonian (routine/spinless.py:431-725 over routine/spinless_helper.py:261-440); golden G27
+# ---------------------------------------------------------------------------------------------
+
+def spin_orbital_matrix(H):
+    """(2 | 3, ..., n, n) blocks (aa, bb[, ab]) -> (..., 2n, 2n) with the ba block the conjugate transpose of ab: the quadratic
+    forms of spinless_helper.py:349-440 are B^H M B with the stacked basis B = [B_a; B_b]."""
+    H = np.asarray(H)
+    assert H.shape[0] in (2, 3)
+    n = H.shape[-1]
+    M = np.zeros(H.shape[1:-2] + (2 * n, 2 * n), dtype=H.dtype)
+    M[..., :n, :n], M[..., n:, n:] = H[0], H[1]
+    if H.shape[0] == 3:
+        M[..., :n, n:] = H[2]
+        M[..., n:, :n] = np.swapaxes(H[2].conj(), -1, -2)
+    return M
+
+
+def transform_trans_inv_k_gso(basis_k, H_k):
+    """spinless_helper.py:349-381: (1/nk) Re sum_k B_k^H M_k B_k."""
+    M = spin_orbital_matrix(H_k)
+    return np.einsum('kpa,kpq,kqb->ab', basis_k.conj(), M, basis_k).real / basis_k.shape[0]
+
+
+def transform_local_gso(basis, H):
+    """spinless_helper.py:383-409: every cell sees the same block matrix."""
+    return np.einsum('Rpa,pq,Rqb->ab', basis, spin_orbital_matrix(H), basis)
+
+
+def transform_imp_gso(basis, H):
+    """spinless_helper.py:411-436: cell 0 only."""
+    return transform_local_gso(basis[:1], H)
+
+
+def pair_rows(idx, neo):
+    """Positions, in the lower-triangle pair list of neo orbitals, of the pairs drawn from `idx` (spinless_helper.py:261-286)."""
+    r, c = np.tril_indices(neo)
+    return np.nonzero(np.isin(r, idx) & np.isin(c, idx))[0]
+
+
+def unit2emb_gso(H2_unit, neo):
+    """spinless_helper.py:288-313: (aa, bb, ab) unit ERI into the alpha-alpha, beta-beta, alpha-beta and beta-alpha pair blocks of
+    the 4-fold embedding ERI, alpha = the first nao embedding orbitals, beta the next nao."""
+    nao = int(np.sqrt(H2_unit.shape[-1] * 2))
+    pa, pb = pair_rows(np.arange(nao), neo), pair_rows(np.arange(nao, 2 * nao), neo)
+    npair = neo * (neo + 1) // 2
+    out = np.zeros((npair, npair))
+    out[np.ix_(pa, pa)], out[np.ix_(pb, pb)] = H2_unit[0], H2_unit[1]
+    out[np.ix_(pa, pb)], out[np.ix_(pb, pa)] = H2_unit[2], H2_unit[2].T
+    return out
+
+
+def transform_eri_local_gso(basis, H2_unit):
+    """spinless_helper.py:319-347: per cell the aa, bb and ab (+ transposed) four-index transforms, 4-fold packed."""
+    ncells, nso, neo = basis.shape
+    nao = nso // 2
+    tl = np.tril_indices(nao)
+    full = []
+    for blk in H2_unit:
+        f = np.zeros((nao, nao, nao, nao))
+        sq = np.zeros((nao, nao, blk.shape[1]))
+        sq[tl[0], tl[1]] = blk
+        sq[tl[1], tl[0]] = blk
+        f[:, :, tl[0], tl[1]] = sq
+        f[:, :, tl[1], tl[0]] = sq
+        full.append(f)
+    t = np.tril_indices(neo)
+    out = np.zeros((len(t[0]), len(t[0])))
+    for R in range(ncells):
+        a, b = basis[R, :nao], basis[R, nao:]
+        for f, (l, r) in ((full[0], (a, a)), (full[1], (b, b))):
+            out += np.einsum('ijkl,ip,jq,kr,ls->pqrs', f, l, l, r, r, optimize=True)[t[0], t[1]][:, t[0], t[1]]
+        ab = np.einsum('ijkl,ip,jq,kr,ls->pqrs', full[2], a, a, b, b, optimize=True)[t[0], t[1]][:, t[0], t[1]]
+        out += ab + ab.T
+    return out
+
+
+def gso_embHam1e(kmesh, basis, H2_emb, hcore_k, fock_k, ovlp_k, rdm1_k, vcor_mat, mu, int_bath=True, add_vcor=False, JK_imp=None,
+                 use_hcore_as_emb_ham=False, fitting=False, hcore_add=None, hcore_custom=None):
+    """spinless.py:560-725, Hartree-Fock branches.  `fock_k` is what the reference folds in the branch taken (fock_hf_lo_k of an
+    ab-initio lattice with an interacting bath, the lattice Fock otherwise).  Returns H1 (1, neo, neo), ovlp_emb, JK_core."""
+    from oracle.restate import R2k
+    from oracle.restate_ham import get_veff
+    basis_k = R2k(basis, kmesh)
+    n = basis.shape[1] // 2
+    hcore_emb = transform_trans_inv_k_gso(basis_k, hcore_k if hcore_custom is None else hcore_custom)
+    ovlp_emb = transform_trans_inv_k_gso(basis_k, ovlp_k)
+    local_jk = lambda: get_veff(np.einsum('kpa,kpq,kqb->ab', basis_k.conj(), rdm1_k, basis_k).real / basis_k.shape[0],
+                                H2_emb, hyb=1.0, ghf=True)
+    extra = 0.0 if hcore_add is None else transform_imp_gso(basis, hcore_add)
+    if int_bath:
+        H1 = transform_trans_inv_k_gso(basis_k, fock_k) + extra - local_jk()
+        JK_core = H1 - hcore_emb
+    else:
+        add_vcor = True
+        if use_hcore_as_emb_ham:
+            H1, JK_core = hcore_emb + extra, None
+        else:
+            H1 = transform_trans_inv_k_gso(basis_k, fock_k) - local_jk() + extra
+            JK_core = H1 - hcore_emb
+    H1 = H1 + transform_local_gso(basis, np.asarray([-mu * np.eye(n), mu * np.eye(n)]))
+    if add_vcor:
+        H1 = H1 + transform_local_gso(basis, vcor_mat)
+        if not fitting:
+            H1 = H1 - transform_imp_gso(basis, vcor_mat)
+        if JK_imp is not None:
+            H1 = H1 - transform_imp_gso(basis, JK_imp)
+    return H1[None], ovlp_emb, JK_core

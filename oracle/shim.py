@@ -392,3 +392,42 @@ def patch_eri_transform():
     et.member = kpts_member
     et.unique = kpts_unique
     return et
+
+
+def pyscf_incore_general(eri, mo_coeffs, compact=True):
+    """pyscf.ao2mo.incore.general for real input: (ij|kl) -> (pq|rs) with four coefficient matrices; the pairs (p, q) and (r, s)
+    come back as lower triangles when `compact` and both members of the pair use the same coefficients (PySCF's rule)."""
+    c1, c2, c3, c4 = [np.asarray(c) for c in mo_coeffs]
+    n = c1.shape[0]
+    full = restore(1, eri, n)
+    out = np.einsum('ijkl,ip,jq,kr,ls->pqrs', full, c1, c2, c3, c4, optimize=True)
+    same12 = compact and c1.shape == c2.shape and np.array_equal(c1, c2)
+    same34 = compact and c3.shape == c4.shape and np.array_equal(c3, c4)
+    if same12:
+        t = np.tril_indices(c1.shape[1])
+        out = out[t[0], t[1]]
+    else:
+        out = out.reshape(c1.shape[1] * c2.shape[1], c3.shape[1], c4.shape[1])
+    if same34:
+        t = np.tril_indices(c3.shape[1])
+        out = out[:, t[0], t[1]]
+    else:
+        out = out.reshape(out.shape[0], -1)
+    return out
+
+
+def patch_spinless():
+    """Bind the restated PySCF primitives of routine/spinless_helper.py (ao2mo.restore, ao2mo.incore.general: :338-346) and of
+    solver/scf.py; returns (spinless, spinless_helper)."""
+    patch_scf()
+    from libdmet.routine import spinless_helper as sh, spinless
+
+    class _incore(object):
+        general = staticmethod(pyscf_incore_general)
+
+    class _ao2mo_mod(object):
+        restore = staticmethod(restore)
+        incore = _incore
+    sh.ao2mo = _ao2mo_mod
+    spinless.ao2mo = _ao2mo_mod
+    return spinless, sh

@@ -118,3 +118,46 @@ def test_G19_bath_opt(golden, name, mesh, n, val):
     same, mu0, nelec0 = G.get_emb_basis_opt(mesh, GRho0, b)
     if min(val) == 0:
         assert mu0 is None and same is b and abs(nelec0 - round(nelec0)) < 1e-6
+
+
+# ---- round 6: the GSO embedding Hamiltonian (golden G27) -------------------------------------------------------------------
+
+GSO_HAM = ["c611", "c441", "c222"]
+
+
+def gso_ham_inputs(g, name):
+    mesh = tuple(int(x) for x in g[name + "/mesh"])
+    basis = g[name + "/basis"]
+    n, nk = basis.shape[1] // 2, basis.shape[0]
+    S3 = np.zeros((3, nk, n, n), dtype=complex)
+    S3[0] = S3[1] = np.eye(n)
+    return mesh, basis, g[name + "/H2"], g[name + "/H3_k"], g[name + "/F3_k"], S3, g[name + "/GRho_k"], g[name + "/vcor"], 0.37
+
+
+def gso_ham_runs(g, name):
+    JK3, add2, cust = g[name + "/JK_imp"], g[name + "/hcore_add"], g[name + "/hcore_custom"]
+    return [("ib", dict()), ("ib_vcor", dict(add_vcor=True)), ("ib_vcor_fit", dict(add_vcor=True, fitting=True)),
+            ("ib_add", dict(hcore_add=add2)), ("ib_custom", dict(hcore_custom=cust)),
+            ("nib", dict(int_bath=False)), ("nib_jk", dict(int_bath=False, JK_imp=JK3)), ("nib_add", dict(int_bath=False, hcore_add=add2)),
+            ("nib_hcore", dict(int_bath=False, use_hcore_as_emb_ham=True, hcore_add=add2))]
+
+
+@pytest.mark.parametrize("name", GSO_HAM)
+def test_G27_gso_embedding_hamiltonian(golden, name):
+    g = golden("G27_gso_embham.npz")
+    mesh, basis, H2, H3, F3, S3, rk, v, mu = gso_ham_inputs(g, name)
+    for tag, kw in gso_ham_runs(g, name):
+        fock = 0.9 * F3 if kw.get("int_bath", True) else F3           # fock_hf_lo_k with an interacting bath (spinless.py:647-650)
+        H1, ov, JKc = G.gso_embHam1e(mesh, basis, H2, H3, fock, S3, rk, v, mu, **kw)
+        assert np.abs(H1 - g["%s/%s_H1" % (name, tag)]).max() < 1e-12, tag
+        assert np.abs(ov - g["%s/%s_ovlp" % (name, tag)]).max() < 1e-12, tag
+        key = "%s/%s_JK_core" % (name, tag)
+        assert (np.abs(JKc - g[key]).max() < 1e-12) if key in g else JKc is None
+    bk = R.R2k(basis, mesh)
+    assert np.abs(G.transform_trans_inv_k_gso(bk, F3) - g[name + "/ti_k3"]).max() < 1e-12
+    assert np.abs(G.transform_trans_inv_k_gso(bk, F3[:2]) - g[name + "/ti_k2"]).max() < 1e-12
+    for k3, k2, fn in (("loc3", "loc2", G.transform_local_gso), ("imp3", "imp2", G.transform_imp_gso)):
+        assert np.abs(fn(basis, v) - g[name + "/" + k3]).max() < 1e-12 and np.abs(fn(basis, v[:2]) - g[name + "/" + k2]).max() < 1e-12
+    assert np.array_equal(G.unit2emb_gso(g[name + "/unit"], basis.shape[-1]), g[name + "/unit2emb"])
+    if name + "/eri_local" in g:
+        assert np.abs(G.transform_eri_local_gso(basis, g[name + "/unit"]) - g[name + "/eri_local"]).max() < 1e-12
