@@ -35,6 +35,23 @@ def init_H2(norb, eri_symmetry, dtype=np.double, spin_dim=None):
     raise ValueError("unknown ERI symmetry: %s" % (eri_symmetry))
 
 
+def restore_eri_local(H2, norb):
+    """(spin, ...) cell-local ERI in 1- or 4-fold storage -> (spin, npair, npair) 4-fold (slater_helper.py:473-492)."""
+    H2 = np.asarray(H2)
+    spin = H2.shape[0]
+    npair = norb * (norb + 1) // 2
+    if H2.size == spin * npair * npair:
+        return H2.reshape(spin, npair, npair)
+    ctx = get_ctx()
+    out = np.empty((spin, npair, npair), dtype=np.float64)
+    for s in range(spin):
+        d = ctx.to_device(np.ascontiguousarray(H2[s], dtype=np.float64).reshape(-1))
+        d_out = ctx.empty((npair, npair), np.float64)
+        ctx.check(lib.dmk_eri_to_s4(ctx.h, int(norb), 1, d.ptr, d_out.ptr))
+        out[s] = d_out.get()
+    return out
+
+
 def unit2emb_dev(ctx, d_unit, spin_pair, shape_in, shape_out):
     """Device form: pad (spin_pair,) + shape_in into (spin_pair,) + shape_out (1- or 2-d trailing shapes)."""
     r_in, c_in = (1, shape_in[0]) if len(shape_in) == 1 else shape_in

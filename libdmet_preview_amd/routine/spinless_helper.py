@@ -1,0 +1,115 @@
+"""
+One-body folds and ERI containers of the GSO ("spinless", partial particle-hole) embedding Hamiltonian, mirror of
+libdmet/routine/spinless_helper.py:247-440.
+
+A generalised basis is the stack B = [B_a; B_b] of its alpha and beta rows, and every fold of the reference --
+sum over (aa, bb, ab + h.c.) of B_x^H H_xy B_y -- is ONE quadratic form B^H M B with the spin-orbital matrix
+M = [[H_aa, H_ab], [H_ab^H, H_bb]].  So the folds are the Slater kernels on 2 nlo orbitals per cell (K5 zgemm.hip for the
+k-space form, the cell Gram kernel for the local ones) after a block assembly, not three loops.
+
+unit2emb places the (aa, bb, ab) unit ERI on the alpha / beta PAIR rows of the 4-fold embedding ERI: one square scatter of the
+2 x 2 block matrix [[aa, ab], [ab^T, bb]] with the concatenated pair positions (dmk_scatter2d_add_f64).
+"""
+import numpy as np
+
+from libdmet_preview_amd._lib import lib, get_ctx
+from libdmet_preview_amd.routine import slater_helper
+from libdmet_preview_amd.routine.slater_helper import init_H2  # noqa: F401  (re-exported like the reference)
+
+
+def separate_basis(basis, copy=False):
+    """(..., nso, nbasis) -> alpha rows, beta rows (spinless_helper.py:31-46)."""
+    nso = basis.shape[-2]
+    a, b = basis[..., :nso // 2, :], basis[..., nso // 2:, :]
+    return (a.copy(), b.copy()) if copy else (a, b)
+
+
+def _stack(basis_a, basis_b):
+    return np.concatenate([np.asarray(basis_a), np.asarray(basis_b)], axis=-2)
+
+
+def spin_orbital_matrix(H):
+    """(2 | 3, ..., n, n) blocks (aa, bb[, ab]) -> (..., 2n, 2n), ba = ab^H."""
+    H = np.asarray(H)
+    assert H.shape[0] in (2, 3)
+    n = H.shape[-1]
+    M = np.zeros(H.shape[1:-2] + (2 * n, 2 * n), dtype=H.dtype)
+    M[..., :n, :n], M[..., n:, n:] = H[0], H[1]
+    if H.shape[0] == 3:
+        M[..., :n, n:] = H[2]
+        M[..., n:, :n] = np.swapaxes(H[2].conj(), -1, -2)
+    return M
+
+
+def transform_trans_inv_k(basis_ka, basis_kb, H_k):
+    """(nbasis, nbasis) = (1/nk) Re sum_k B_k^H M_k B_k for H_k (2 | 3, nkpts, nao, nao) (spinless_helper.py:349-381)."""
+    H_k = np.asarray(H_k)
+    assert H_k.ndim == 4
+    return slater_helper.transform_trans_inv_k(_stack(basis_ka, basis_kb), spin_orbital_matrix(H_k))
+
+
+def transform_local(basis_Ra, basis_Rb, H):
+    """sum over cells of B_R^T M B_R, H (2 | 3, nao, nao) (spinless_helper.py:383-409)."""
+    return slater_helper.transform_local(_stack(basis_Ra, basis_Rb), None, spin_orbital_matrix(np.asarray(H).real))
+
+
+def transform_imp(basis_Ra, basis_Rb, H):
+    """Cell 0 only (spinless_helper.py:411-436)."""
+    return slater_helper.transform_imp(_stack(basis_Ra, basis_Rb), None, spin_orbital_matrix(np.asarray(H).real))
+
+
+def idx_ao2so(idx_list, nao):
+    return [idx for idx in idx_list], [idx + nao for idx in idx_list]
+
+
+def _pair_rows(idx, neo):
+    r, c = np.tril_indices(neo)
+    return np.nonzero(np.isin(r, idx) & np.isin(c, idx))[0]
+
+
+def get_H2_mask(nao, neo):
+    """np.ix_ masks of the (aa, bb, ab, ba) pair blocks of the unit cell inside the 4-fold embedding ERI (spinless_helper.py:261-286)."""
+    pa, pb = _pair_rows(np.arange(nao), neo), _pair_rows(np.arange(nao, 2 * nao), neo)
+    full = neo * (neo + 1) // 2
+    ma, mb = np.zeros(full, dtype=bool), np.zeros(full, dtype=bool)
+    ma[pa], mb[pb] = True, True
+    return np.ix_(ma, ma), np.ix_(mb, mb), np.ix_(ma, mb), np.ix_(mb, ma)
+
+
+def unit2emb(H2_unit, neo):
+    """(3, nao_pair, nao_pair) unit ERI (aa, bb, ab) -> (neo_pair, neo_pair) embedding ERI with the impurity blocks filled
+    (spinless_helper.py:288-313)."""
+    H2_unit = np.asarray(H2_unit, dtype=np.float64)
+    assert H2_unit.ndim == 3 and H2_unit.shape[0] == 3
+    npu = H2_unit.shape[-1]
+    nao = int(np.sqrt(npu * 2))
+    pos = np.concatenate([_pair_rows(np.arange(nao), neo), _pair_rows(np.arange(nao, 2 * nao), neo)]).astype(np.int32)
+    src = np.empty((2 * npu, 2 * npu))
+    src[:npu, :npu], src[npu:, npu:] = H2_unit[0], H2_unit[1]
+    src[:npu, npu:], src[npu:, :npu] = H2_unit[2], H2_unit[2].T
+    ctx = get_ctx()
+    neo_pair = neo * (neo + 1) // 2
+    d_out = ctx.zeros((neo_pair, neo_pair), np.float64)
+    d_pos, d_src = ctx.to_device(pos), ctx.to_device(src)
+    ctx.check(lib.dmk_scatter2d_add_f64(ctx.h, 2 * npu, d_pos.ptr, d_src.ptr, 1.0, d_out.ptr, neo_pair, 1))
+    return d_out.get()
+
+
+def transform_eri_local(basis_Ra, basis_Rb, H2, symm=4):
+    """Spin-local lattice ERI (aa, bb, ab) into the embedding space, summed over cells, for the interacting bath of a model
+    (spinless_helper.py:319-347): per cell the aa and bb four-index transforms and ab + its transpose (device quarter chains)."""
+    from libdmet_preview_amd.basis_transform.eri_transform import eri_restore
+    basis_Ra, basis_Rb = np.asarray(basis_Ra, dtype=np.float64), np.asarray(basis_Rb, dtype=np.float64)
+    ncells, nao, neo = basis_Ra.shape
+    H2 = slater_helper.restore_eri_local(np.asarray(H2), nao)
+    full = eri_restore(H2, 1, nao)                                   # (3, nao, nao, nao, nao)
+    t = np.tril_indices(neo)
+    out = np.zeros((len(t[0]), len(t[0])))
+    pack = lambda x: x[t[0], t[1]][:, t[0], t[1]]
+    for R in range(ncells):
+        a, b = basis_Ra[R], basis_Rb[R]
+        out += pack(slater_helper.transform_4idx(full[0], a, a, a, a))
+        out += pack(slater_helper.transform_4idx(full[1], b, b, b, b))
+        ab = pack(slater_helper.transform_4idx(full[2], a, a, b, b))
+        out += ab + ab.T
+    return eri_restore(out[None], symm, neo)[0]

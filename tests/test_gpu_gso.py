@@ -168,3 +168,89 @@ def test_scdm_localised_bcs_and_gso_baths(golden, name, mesh, n, val):
         assert _match_columns(ref.reshape(-1, ref.shape[-1]), got.reshape(-1, got.shape[-1]))[0] < 1e-8
     with pytest.raises(NotImplementedError):
         spinless.get_emb_basis(L, GRho, localize_bath="pm")
+
+
+# ---- round 6: the GSO embedding Hamiltonian (golden G27) -------------------------------------------------------------------
+
+from tests.test_oracle_gso import GSO_HAM, gso_ham_inputs, gso_ham_runs  # noqa: E402
+
+
+class _V3(object):
+    def __init__(self, v):
+        self.v = np.asarray(v)
+
+    def islocal(self):
+        return True
+
+    is_local = islocal
+
+    def get(self, i=0, kspace=True):
+        return self.v
+
+
+def _gso_lattice(g, name):
+    from libdmet_preview_amd.system.lattice import Lattice
+    mesh, basis, H2, H3, F3, S3, rk, v, mu = gso_ham_inputs(g, name)
+    n = basis.shape[1] // 2
+    val = [int(x) for x in g[name + "/val"]]
+    L = Lattice(n, mesh)
+    L.val_idx, L.virt_idx, L.core_idx = val, [i for i in range(n) if i > max(val)], [i for i in range(n) if i < min(val)]
+    L.hcore_lo_k, L.fock_lo_k, L.fock_hf_lo_k, L.ovlp_lo_k = H3, F3, 0.9 * F3, S3
+    L.rdm1_lo_k, L.H0 = rk, 0.75
+    return L, mesh, basis, H2, F3, rk, v, mu
+
+
+@pytest.mark.parametrize("name", GSO_HAM)
+def test_gso_embedding_hamiltonian(ctx, golden, name):
+    """spinless.get_emb_Ham (routine/spinless.py:431-725) in every bath regime with a given ERI, against the reference's values
+    (golden G27) and the oracle; the folds, the ERI containers and the model branch on their own."""
+    from libdmet_preview_amd.routine import spinless, spinless_helper as sh
+    g = golden("G27_gso_embham.npz")
+    L, mesh, basis, H2, F3, rk, v, mu = _gso_lattice(g, name)
+    neo = basis.shape[-1]
+    vc = _V3(v)
+    for tag, kw in gso_ham_runs(g, name):
+        kw = dict(kw)
+        L.JK_imp = kw.pop("JK_imp", None)
+        L.use_hcore_as_emb_ham = kw.pop("use_hcore_as_emb_ham", False)
+        L.JK_core = "unset"
+        if tag == "ib_add":
+            kw["H0_add"] = 0.5
+        Himp, none = spinless.get_emb_Ham(L, basis, vc, mu, H2_given=H2, **kw)
+        assert none is None and Himp.norb == neo and Himp.restricted and not Himp.bogoliubov and Himp.H2["ccdd"] is H2
+        assert Himp.H1["cd"].shape == (1, neo, neo)
+        assert np.abs(Himp.H1["cd"] - g["%s/%s_H1" % (name, tag)]).max() < 1e-10, tag
+        assert np.abs(Himp.ovlp - g["%s/%s_ovlp" % (name, tag)]).max() < 1e-12, tag
+        assert abs(Himp.H0 - float(g["%s/%s_H0" % (name, tag)])) < 1e-14
+        key = "%s/%s_JK_core" % (name, tag)
+        assert (np.abs(L.JK_core - g[key]).max() < 1e-10) if key in g else L.JK_core is None
+    L.JK_imp, L.use_hcore_as_emb_ham = None, False
+    assert spinless.embHam is spinless.get_emb_Ham
+    with pytest.raises(NotImplementedError):
+        spinless.get_emb_Ham(L, basis, vc, mu, H2_given=H2, dft=True)
+    # helpers
+    bka, bkb = sh.separate_basis(L.R2k_basis(basis))
+    bRa, bRb = sh.separate_basis(basis)
+    assert np.abs(sh.transform_trans_inv_k(bka, bkb, F3) - g[name + "/ti_k3"]).max() < 1e-11
+    assert np.abs(sh.transform_trans_inv_k(bka, bkb, F3[:2]) - g[name + "/ti_k2"]).max() < 1e-11
+    for k3, k2, fn in (("loc3", "loc2", sh.transform_local), ("imp3", "imp2", sh.transform_imp)):
+        assert np.abs(fn(bRa, bRb, v) - g[name + "/" + k3]).max() < 1e-12 and np.abs(fn(bRa, bRb, v[:2]) - g[name + "/" + k2]).max() < 1e-12
+    assert np.abs(spinless.foldRho_k(rk, L.R2k_basis(basis)) - g[name + "/foldRho_k"]).max() < 1e-12
+    unit = g[name + "/unit"]
+    assert np.array_equal(sh.unit2emb(unit, neo), g[name + "/unit2emb"])
+    n = basis.shape[1] // 2
+    masks = sh.get_H2_mask(n, neo)
+    assert np.array_equal(g[name + "/unit2emb"][masks[2]], unit[2]) and np.array_equal(g[name + "/unit2emb"][masks[3]], unit[2].T)
+    if name + "/eri_local" in g:
+        assert np.abs(sh.transform_eri_local(bRa, bRb, unit) - g[name + "/eri_local"]).max() < 1e-11
+        assert np.abs(sh.transform_eri_local(bRa, bRb, unit) - G.transform_eri_local_gso(basis, unit)).max() < 1e-11
+        L.set_H2_local(unit, H2_format="spin local")
+        L.eri_symmetry = 4
+        for tag, kw in (("model_ib", dict()), ("model_nib", dict(int_bath=False))):
+            Himp, _ = spinless.get_emb_Ham(L, basis, vc, mu, **kw)
+            assert np.abs(np.asarray(Himp.H2["ccdd"]) - g["%s/%s_H2" % (name, tag)]).max() < 1e-11, tag
+            assert np.abs(Himp.H1["cd"] - g["%s/%s_H1" % (name, tag)]).max() < 1e-10, tag
+            assert np.abs(L.JK_core - g["%s/%s_JK_core" % (name, tag)]).max() < 1e-10, tag
+        L.set_H2_local(unit, H2_format="spin nearest")
+        with pytest.raises(NotImplementedError):
+            spinless.get_emb_Ham(L, basis, vc, mu)
