@@ -142,3 +142,76 @@ def _embBasis_phsymm(lattice, GRho, **kwargs):
     BA2 = _orthonormalize_dev(ctx, d_BA2, ncells * m, m).get().reshape(ncells, m, m)
     basis[1, :, :nscsites], basis[1, :, nscsites:] = BA2[:, nscsites:], BA2[:, :nscsites]
     return basis
+
+
+# ---- BCS embedding Hamiltonian of model lattices (routine/bcs.py:137-318) --------------------------------------------------
+
+def _embHam2e(lattice, basis, vcor, local, int_bath=False, last_aabb=True, **kwargs):
+    """Two-body part: ({"ccdd", "cccd", "cccc"}, one-body terms from it or None, H0 from it).  The reference implements the local
+    basis of a model with a bare bath: the lattice ERI sits on the impurity block of all three ccdd spin blocks, the anomalous
+    terms are zero (bcs.py:198-229); the ERI is zero-padded on the device (dmk_pad_block_f64)."""
+    from libdmet_preview_amd.routine.slater_helper import unit2emb
+    n, nb = lattice.nscsites, basis.shape[-1]
+    if not lattice.is_model:
+        raise NotImplementedError                                   # bcs.py:253-254: no ab-initio BCS Hamiltonian in the reference
+    if not local:
+        raise NotImplementedError("quasiparticle (non-local) BCS Hamiltonian: libdmet.integral.integral_nonlocal_emb is outside the HIP path")
+    if "sites" in kwargs:
+        raise NotImplementedError('keyword "sites" is not supported')
+    LatH2 = np.asarray(lattice.getH2(compact=False, kspace=False))
+    for s in range(2):
+        log.eassert(np.abs(basis[s, 0, :n, :n] - np.eye(n)).max() < 1e-10, "the embedding basis is not local")
+    if lattice.H2_format != "local":
+        # 'nearest' / 'full' write into an undefined name in the reference (bcs.py:214-225); anything else is its ValueError
+        if lattice.H2_format in ("nearest", "full"):
+            raise NotImplementedError("BCS model ERI in format %s" % lattice.H2_format)
+        raise ValueError
+    if int_bath:
+        raise NotImplementedError
+    ccdd = unit2emb(np.asarray((LatH2,) * 3), nb)
+    log.info("H2 memory allocated size = %d MB", ccdd.size * 2 * 8. / 1024 / 1024)
+    return {"ccdd": ccdd, "cccd": np.zeros((2,) + (nb,) * 4), "cccc": np.zeros((1,) + (nb,) * 4)}, None, 0.
+
+
+def _embHam1e(lattice, basis, vcor, mu, H2_emb, int_bath=False, add_vcor=False, **kwargs):
+    """One-body part (bcs.py:256-316): ((H1 {"cd", "cc"}, H0), (H1 for the energy, its H0)); all Nambu folds on the device
+    (bcs_helper: one quadratic form of the canonical basis each)."""
+    log.eassert(vcor.islocal(), "nonlocal correlation potential cannot be treated in this routine")
+    n = lattice.nscsites
+    hcore_R = np.asarray(lattice.getH1(kspace=False))
+    ImpJK = lattice.getImpJK()
+    if int_bath or not lattice.use_hcore_as_emb_ham:
+        raise NotImplementedError                                   # bcs.py:278-287: only the bare bath on hcore exists
+    lattice.JK_core = None
+    cd, cc, H0 = transform_trans_inv(basis, lattice, hcore_R)       # noqa: F405
+    cd, cc = np.array(cd), np.array(cc)
+    shifted = np.array(vcor.get(), copy=True)
+    shifted[0] -= mu * np.eye(n)
+    shifted[1] -= mu * np.eye(n)
+    terms = [(+1.0, transform_local(basis, lattice, shifted))]      # noqa: F405  vcor - mu everywhere ...
+    if not kwargs.get("fitting", False):
+        terms.append((-1.0, transform_imp(basis, lattice, np.asarray(vcor.get()))))   # noqa: F405  ... vcor off the impurity
+    if ImpJK is not None:
+        terms.append((-1.0, transform_imp(basis, lattice, np.asarray(ImpJK))))        # noqa: F405
+    for sign, (tcd, tcc, t0) in terms:
+        cd, cc, H0 = cd + sign * np.asarray(tcd), cc + sign * np.asarray(tcc), H0 + sign * t0
+    ecd, ecc, e0 = transform_imp_env(basis, lattice, hcore_R)       # noqa: F405
+    return ({"cd": cd, "cc": cc[np.newaxis]}, H0), ({"cd": np.asarray(ecd), "cc": np.asarray(ecc)[np.newaxis]}, e0)
+
+
+def embHam(lattice, basis, vcor, mu, local=True, **kwargs):
+    """BCS embedding Hamiltonian (bcs.py:137-155): (integral.Integral(norb, False, True, ...), (H1 for the energy, its H0))."""
+    from libdmet_preview_amd.system import integral
+    basis = np.asarray(basis)
+    log.info("Two-body part")
+    Int2e, Int1e_from2e, H0_from2e = _embHam2e(lattice, basis, vcor, local, **kwargs)
+    log.info("One-body part")
+    (Int1e, H0_from1e), (Int1e_energy, H0_energy_from1e) = _embHam1e(lattice, basis, vcor, mu, Int2e, **kwargs)
+    if Int1e_from2e is not None:
+        for target in (Int1e, Int1e_energy):
+            target["cd"] += Int1e_from2e["cd"]
+            target["cc"] += Int1e_from2e["cc"]
+    return integral.Integral(basis.shape[-1], False, True, H0_from1e + H0_from2e, Int1e, Int2e), (Int1e_energy, H0_energy_from1e + H0_from2e)
+
+
+get_emb_Ham = embHam

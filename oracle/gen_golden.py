@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1700,6 +1700,47 @@ def gen_G27():
             L.is_model = False
     np.savez_compressed(os.path.join(GOLD, "G27_gso_embham.npz"), **out)
     print("G27 done", len(out), "arrays")
+
+
+def gen_G28():
+    """The BCS (Nambu) embedding Hamiltonian of model lattices, routine/bcs.py:137-318 embHam -- the branch the reference
+    implements: local basis, bare bath, hcore as the embedding Hamiltonian, lattice ERI in 'local' format; with vcor / mu on the
+    bath only or everywhere (`fitting`), with an impurity JK taken out, and the energy Hamiltonian (transform_imp_env)."""
+    from types import SimpleNamespace
+    from libdmet.routine import bcs
+    g7 = np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3])]:
+        rng = np.random.default_rng(2800 + n)
+        L = _duck_lattice(mesh, n, val=val)
+        L.is_model, L.H2_format, L.eri_symmetry = True, "local", 1
+        L.cell = SimpleNamespace(max_memory=4000)
+        FR, v, mu = g7[name + "/Fock_R"], g7[name + "/vcor"], float(g7[name + "/mu"])
+        D_R = synth.make_fock_R(mesh, n, spin=1, seed=17 + n)[0] * 0.3
+        H3 = np.asarray([FR[0], FR[1], D_R])
+        L.hcore_lo_R, L.fock_lo_R = H3, H3
+        L.hcore_lo_k = L.fock_lo_k = synth.fold_R2k(H3, mesh)
+        L.JK_imp, L.Ham, L.H0, L.use_hcore_as_emb_ham = None, None, 0.0, True
+        LatH2 = shim.restore(1, _psd_eri(rng, n, 4, 1)[0], n)
+        L.getH2 = lambda compact=False, kspace=False, _h=LatH2: _h
+        basis = g7[name + "/basis_proj"]
+        vc = _Vcor(v)
+        JK3 = rng.standard_normal((3, n, n))
+        JK3[0], JK3[1] = JK3[0] + JK3[0].T, JK3[1] + JK3[1].T
+        out[name + "/H3_R"], out[name + "/LatH2"], out[name + "/JK_imp"] = H3, LatH2, JK3
+        for tag, kw, jk in (("nib", dict(), None), ("nib_fit", dict(fitting=True), None), ("nib_jk", dict(), JK3)):
+            L.JK_imp = jk
+            L.JK_core = "unset"
+            Himp, (H1e, H0e) = bcs.embHam(L, basis, vc, mu, **kw)
+            assert L.JK_core is None and Himp.bogoliubov and not Himp.restricted
+            key = "%s/%s" % (name, tag)
+            out[key + "_cd"], out[key + "_cc"], out[key + "_H0"] = Himp.H1["cd"], Himp.H1["cc"], np.asarray(Himp.H0)
+            out[key + "_ccdd"] = Himp.H2["ccdd"]
+            assert not np.any(Himp.H2["cccd"]) and not np.any(Himp.H2["cccc"])
+            out[key + "_shapes"] = np.asarray([Himp.H2["cccd"].shape[0], Himp.H2["cccc"].shape[0], Himp.norb])
+            out[key + "_ecd"], out[key + "_ecc"], out[key + "_eH0"] = H1e["cd"], H1e["cc"], np.asarray(H0e)
+    np.savez_compressed(os.path.join(GOLD, "G28_bcs_embham.npz"), **out)
+    print("G28 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

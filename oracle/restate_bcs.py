@@ -365,3 +365,31 @@ def embBasis_phsymm(GRho, nscsites):
     BA2 = orthonormalizeBasis(np.dot(Gh, la.inv(A2.T)))
     basis[1, :, :n], basis[1, :, n:] = BA2[:, n:], BA2[:, :n]
     return basis
+
+
+# ---------------------------------------------------------------------------------------------
+# BCS embedding Hamiltonian of model lattices (routine/bcs.py:137-318); golden G28
+# ---------------------------------------------------------------------------------------------
+
+def bcs_embHam(kmesh, basis, hcore_R, LatH2, vcor_mat, mu, ImpJK=None, fitting=False):
+    """The branch the reference implements: local basis, bare bath, hcore as the embedding Hamiltonian, 'local' lattice ERI.
+    Returns (H1 {"cd", "cc"}, H0, ccdd), (H1energy, H0energy)."""
+    n, nb = vcor_mat.shape[-1], basis.shape[-1]
+    for s in range(2):
+        assert np.abs(basis[s, 0, :n, :n] - np.eye(n)).max() < 1e-10                # bcs.py:200-202
+    ccdd = np.zeros((3,) + (nb,) * 4)
+    ccdd[:, :n, :n, :n, :n] = LatH2
+    cd, cc, H0 = transform_trans_inv(basis, kmesh, hcore_R)                          # transform_trans_inv_sparse, thr 1e-7
+    v = np.array(vcor_mat, copy=True)
+    v[0] -= mu * np.eye(n)
+    v[1] -= mu * np.eye(n)
+    terms = [(+1, transform_local(basis, kmesh, v))]
+    if not fitting:
+        terms.append((-1, transform_imp(basis, kmesh, vcor_mat)))
+    if ImpJK is not None:
+        terms.append((-1, transform_imp(basis, kmesh, ImpJK)))
+    cd, cc = np.array(cd), np.array(cc)
+    for sign, (tcd, tcc, t0) in terms:
+        cd, cc, H0 = cd + sign * np.asarray(tcd), cc + sign * tcc, H0 + sign * t0
+    ecd, ecc, e0 = transform_imp_env(basis, kmesh, hcore_R)
+    return ({"cd": cd, "cc": cc[None]}, H0, ccdd), ({"cd": np.asarray(ecd), "cc": np.asarray(ecc)[None]}, e0)

@@ -152,3 +152,24 @@ def test_G18_complex_vcor_in_bdg_and_ghf(golden, name):
         if mu_ is not None:
             rho = np.einsum("kpm,km,kqm->kpq", ev, (ew < 0).astype(float), ev.conj())
             assert np.abs(rho - g["%s/%s_rho_k" % (name, t)]).max() < 1e-10
+
+
+# ---- round 6: the BCS embedding Hamiltonian of model lattices (golden G28) -------------------------------------------------
+
+BCS_HAM = ["c611", "c441"]
+BCS_HAM_RUNS = [("nib", False, False), ("nib_fit", True, False), ("nib_jk", False, True)]
+
+
+@pytest.mark.parametrize("name", BCS_HAM)
+def test_G28_bcs_embedding_hamiltonian(golden, name):
+    g, g7 = golden("G28_bcs_embham.npz"), golden("G7_bcs.npz")
+    mesh = tuple(int(x) for x in g7[name + "/mesh"])
+    basis, v, mu = g7[name + "/basis_proj"], g7[name + "/vcor"], float(g7[name + "/mu"])
+    for tag, fitting, with_jk in BCS_HAM_RUNS:
+        (H1, H0, ccdd), (He, e0) = B.bcs_embHam(mesh, basis, g[name + "/H3_R"], g[name + "/LatH2"], v, mu,
+                                                ImpJK=g[name + "/JK_imp"] if with_jk else None, fitting=fitting)
+        k = "%s/%s" % (name, tag)
+        assert np.abs(H1["cd"] - g[k + "_cd"]).max() < 1e-12 and np.abs(H1["cc"] - g[k + "_cc"]).max() < 1e-12
+        assert abs(H0 - float(g[k + "_H0"])) < 1e-12 and np.array_equal(ccdd, g[k + "_ccdd"])
+        assert np.abs(He["cd"] - g[k + "_ecd"]).max() < 1e-12 and np.abs(He["cc"] - g[k + "_ecc"]).max() < 1e-12
+        assert abs(e0 - float(g[k + "_eH0"])) < 1e-12
