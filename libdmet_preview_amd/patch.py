@@ -70,7 +70,7 @@ _FUNCTIONS = [
     ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham"]),
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
-    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k"]),
+    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb"]),
     # the GSO one-body folds and ERI containers (routine/spinless.py:32 star-imports the helper module)
     ("routine.spinless_helper", ["routine.spinless_helper", "routine.spinless"],
      ["unit2emb", "transform_eri_local", "transform_trans_inv_k", "transform_local", "transform_imp", "get_H2_mask"]),

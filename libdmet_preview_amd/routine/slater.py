@@ -613,9 +613,13 @@ class EmbFitDevice(object):
     (ftsystem.py:151-213) are the same expression with different K."""
 
     def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, fock_k, ovlp_k, mu0=None,
-                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi", shard=False, C_act=None, P_act=None):
+                 fix_mu=False, tol_deg=1e-3, remove_diag_grad=False, eigh="jacobi", shard=False, C_act=None, P_act=None,
+                 operators=None, dV_table=None, norm=None):
         """`C_act` (spin, nidx, nact): the residual is projected on active orbitals, C^T drho C, before the norm (slater.py:1083-1088);
-        `P_act`: FULL active-space projector (spin, nkpts, nlo, nlo) applied to the basis inside dV_dparam (slater.py:878-892)."""
+        `P_act`: FULL active-space projector (spin, nkpts, nlo, nlo) applied to the basis inside dV_dparam (slater.py:878-892).
+        A twin of the fit hands over its own ingredients: `operators` = (embH1, ovlp_emb) as (spin, nb, nb) arrays in place of the
+        folds of fock_k / ovlp_k, `dV_table` = the device table (nparam, spin, npair), `norm` = the divisor of |drho| (default
+        sqrt(spin); the GSO fit divides by sqrt(2) with one block, routine/spinless.py:1259)."""
         from libdmet_preview_amd.routine import mfd
         self._mfd = mfd
         self.ctx, self.vcor = ctx, vcor
@@ -626,9 +630,14 @@ class EmbFitDevice(object):
         self.beta, self.nelec, self.mu0, self.fix_mu, self.tol_deg = beta, nelec, mu0, fix_mu, tol_deg
         self.remove_diag_grad = remove_diag_grad
         self.nparam = vcor.length()
-        basis_k = lattice.R2k_basis(basis)
-        embH1 = transform_h1(fock_k, basis_k)
-        ovlp = transform_h1(ovlp_k, basis_k)
+        self.norm = sqrt(spin) if norm is None else float(norm)
+        if operators is None:
+            basis_k = lattice.R2k_basis(basis)
+            embH1 = transform_h1(fock_k, basis_k)
+            ovlp = transform_h1(ovlp_k, basis_k)
+        else:
+            basis_k = None
+            embH1, ovlp = (np.asarray(x, dtype=np.float64).reshape(spin, nb, nb) for x in operators)
         tl = np.tril_indices(nb)
         self.d_H1 = ctx.to_device(np.asarray([h[tl] for h in embH1]))
         # generalised problem: X = S^-1/2 (symmetric), skipped for an orthonormal embedding basis
@@ -663,7 +672,11 @@ class EmbFitDevice(object):
         else:
             self.p_lo, self.p_hi = 0, self.nparam
         self.nloc = self.p_hi - self.p_lo
-        if P_act is not None and vcor.is_local():            # the non-local branch of get_dV_dparam does not read P_act (slater.py:893-902)
+        if dV_table is not None:
+            log.eassert(self._dist is None and tuple(dV_table.shape) == (self.nparam, spin, self.npair),
+                        "EmbFitDevice: a handed-over dV table is (nparam, spin, npair) and not sharded")
+            self.d_dV = dV_table
+        elif P_act is not None and vcor.is_local():          # the non-local branch of get_dV_dparam does not read P_act (slater.py:893-902)
             self.d_dV = get_dV_dparam_dev(ctx, vcor, _projected_basis_rows(P_act, basis_k), thr=0.0, rows=(self.p_lo, self.p_hi))
         else:
             self.d_dV = get_dV_dparam_dev(ctx, vcor, basis, rows=(self.p_lo, self.p_hi), lattice=lattice)
@@ -888,7 +901,7 @@ class EmbFitDevice(object):
 
     def errfunc(self, param):
         self.nfev += 1
-        return self._forward(param)[3] / sqrt(self.spin)
+        return self._forward(param)[3] / self.norm
 
     def _on_ray(self, param):
         """t with param == x + t p BITWISE for the current line-search ray and a step t that was evaluated on it (the optimiser
@@ -944,7 +957,7 @@ class EmbFitDevice(object):
         self._ray_host = {"x": x, "p": p, "ts": [], "imax": int(np.argmax(np.abs(p))) if p.size else 0}
         self._ray_serial += 1
         ts = self._ray_host["ts"]
-        inv = 1.0 / sqrt(self.spin)
+        inv = 1.0 / self.norm
 
         def phi(t):
             t = float(np.asarray(t).ravel()[0])                   # the Nelder-Mead fallback passes a 1-vector
@@ -1020,9 +1033,9 @@ class EmbFitDevice(object):
             full = np.zeros(self.nparam)                           # every rank fills its slice; the sum is the whole gradient
             if self.nloc > 0:
                 full[self.p_lo:self.p_hi] = self.d_grad.get()[:self.nloc]
-            res = self._dist.all_reduce_sum_numpy(full) / (2.0 * val * sqrt(spin))
+            res = self._dist.all_reduce_sum_numpy(full) / (2.0 * val * self.norm)
         else:
-            res = self.d_grad.get()[:self.nloc] / (2.0 * val * sqrt(spin))
+            res = self.d_grad.get()[:self.nloc] / (2.0 * val * self.norm)
         if self.remove_diag_grad:
             for s in range(spin):
                 d = self.vcor.diag_indices()[s]
@@ -1178,6 +1191,13 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
                        lattice.get_ovlp(kspace=True), mu0=kwargs.get("mu0", None), fix_mu=kwargs.get("fix_mu", False),
                        tol_deg=kwargs.get("tol_deg", 1e-3), remove_diag_grad=kwargs.get("remove_diag_grad", False),
                        eigh=kwargs.get("eigh", "jacobi"), shard=bool(kwargs.pop("shard", False)), C_act=C_act, P_act=P_act)
+    return drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, FitVcorEmb)
+
+
+def drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, owner, grad_check_steps=(1e-4, 1e-6)):
+    """Everything of FitVcorEmb after the objective exists (slater.py:1199-1329; shared with the GSO twin, spinless.py:1347-1430):
+    the optional gradient test and density response, the minimiser on the device objective, the SciPy cross-check.  `owner` is the
+    public function whose `last_fit` attribute keeps the device state of the most recent fit."""
     if fit._dist is not None:
         vcor.update(fit._dist.broadcast_numpy(np.asarray(vcor.param, dtype=np.float64), src=0))
     errfunc, gradfunc = fit.errfunc, fit.gradfunc
@@ -1192,14 +1212,14 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
         if param_rand is None:
             np.random.seed(10086)
             param_rand = (np.random.random(vcor.param.shape) - 0.5) * 0.1
-        for dx in (1e-4, 1e-6):
+        for dx in grad_check_steps:
             test_grad(param_rand.copy(), errfunc, gradfunc, dx=dx)
     if kwargs.get("use_drho_dparam", False) or kwargs.get("return_drho_dparam", False):
         log.info("compute drho_dparam")
         drho_dparam = fit.drho_dparam(vcor.param)
         log.info("norm: %s", np.linalg.norm(drho_dparam, axis=1))
         if kwargs.get("return_drho_dparam", False):
-            FitVcorEmb.last_fit = fit
+            owner.last_fit = fit
             return drho_dparam
     if kwargs.get("num_grad", False):
         log.warn("You are using numerical gradient...")
@@ -1232,7 +1252,7 @@ def FitVcorEmb(rho, lattice, basis, vcor, beta, MaxIter=300, imp_fit=False, imp_
         else:
             log.info("Old result used")
             vcor.update(param_new)
-    FitVcorEmb.last_fit = fit          # evaluation counters / device state of the most recent fit (bench, tests)
+    owner.last_fit = fit               # evaluation counters / device state of the most recent fit (bench, tests)
     return vcor, err_begin, err_end
 
 

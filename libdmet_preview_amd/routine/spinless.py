@@ -393,3 +393,111 @@ def get_emb_Ham(lattice, basis, vcor, mu, local=True, **kwargs):
 
 
 embHam = get_emb_Ham
+
+
+# ---- GSO correlation-potential fit in the embedding space (routine/spinless.py:1090-1430) ----------------------------------
+
+class _SpinOrbitalPotential(object):
+    """A local potential with blocks (aa, bb[, ab]) seen as ONE symmetric matrix on the 2 nlo spin orbitals of a cell,
+    [[g_aa, g_ab], [g_ab^T, g_bb]] -- the form in which spinless_helper.transform_local folds it -- described by the non-zeros of
+    its parameter gradient, so that the Slater table builder (slater.get_dV_dparam_dev: cell Gram matrix + gather) applies as is."""
+
+    def __init__(self, vcor, nlo):
+        self.vcor, self.nlo = vcor, nlo
+
+    def length(self):
+        return self.vcor.length()
+
+    def is_local(self):
+        return True
+
+    def grad_entries(self):
+        n = self.nlo
+        if hasattr(self.vcor, "grad_entries"):
+            gp, gb, gi, gj, gv = self.vcor.grad_entries()
+        else:
+            g = np.asarray(self.vcor.gradient())
+            gp, gb, gi, gj = np.nonzero(g)
+            gv = g[gp, gb, gi, gj]
+        rows, cols = np.where(gb == 1, gi + n, gi), np.where(gb >= 1, gj + n, gj)
+        ab = gb == 2                                              # the pairing block also fills its transpose
+        P, I, J, V = (np.concatenate([x, y[ab]]) for x, y in ((gp, gp), (rows, cols), (cols, rows), (gv, gv)))
+        order = np.lexsort((J, I, P))
+        return P[order], np.zeros(len(P), dtype=np.int64), I[order], J[order], V[order]
+
+
+def get_dV_dparam(vcor, basis, basis_k, lattice, P_act=None, compact=True):
+    """dV / dparam of the GSO fit, (nparam, npair) or (nparam, nbasis, nbasis) (spinless.py:1090-1127)."""
+    from libdmet_preview_amd.routine import slater
+    if P_act is not None or not vcor.is_local():
+        raise NotImplementedError                                 # spinless.py:1118-1121
+    basis = np.asarray(basis, dtype=np.float64)
+    nso, nb = basis.shape[-2], basis.shape[-1]
+    ctx = get_ctx()
+    d = slater.get_dV_dparam_dev(ctx, _SpinOrbitalPotential(vcor, nso // 2), basis[np.newaxis])
+    if not compact:
+        full = ctx.empty((vcor.length(), nb, nb), np.float64)
+        ctx.check(lib.dmk_sym_unpack(ctx.h, nb, vcor.length(), d.ptr, None, full.ptr))
+        d = full
+    vcor.grad = None
+    vcor.grad_k = None
+    return d.get().reshape((vcor.length(), -1) if compact else (vcor.length(), nb, nb))
+
+
+def FitVcorEmb(rho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, imp_fit=False, imp_idx=None, det=False, det_idx=None,
+               CG_check=False, BFGS=False, diff_criterion=None, **kwargs):
+    """
+    Fit the correlation potential in the GSO embedding space (spinless.py:1129-1430): the Slater fit on ONE generalised block --
+    embH1 = the GSO fold of the Fock (or hcore) triple with -mu / +mu on the particle / hole orbitals, half filling of the embedding
+    orbitals unless `nelec` is given, fitted indices (imp_idx, det_idx in spatial orbitals) doubled to alpha + beta, |drho| / sqrt(2).
+    The objective and both analytic gradients run on the device (slater.EmbFitDevice with the GSO operators handed over).
+    Kwargs: fix_mu, mu0, num_grad, test_grad, nelec, tol_deg, vcor_mat (3 blocks added to the Fock triple).
+    """
+    from libdmet_preview_amd.routine import slater, spinless_helper as sh
+    basis = np.asarray(basis, dtype=np.float64)
+    param_begin = vcor.param.copy()
+    nbasis, nao = basis.shape[-1], lattice.nscsites
+    basis_Ra, basis_Rb = sh.separate_basis(basis)
+    basis_ka, basis_kb = sh.separate_basis(lattice.R2k_basis(basis))
+    nelec = kwargs.get("nelec", None)
+    if nelec is None:
+        nelec = nbasis // 2
+    fock_k = np.array(lattice.getH1(kspace=True) if lattice.use_hcore_as_emb_ham else lattice.getFock(kspace=True), copy=True)
+    ovlp_k = np.asarray(lattice.get_ovlp(kspace=True))
+    assert fock_k.ndim == 4 and fock_k.shape[0] == 3
+    assert ovlp_k.ndim == 4 and ovlp_k.shape[0] == 3
+    imp_bath_fit = False
+    if imp_fit:
+        imp_idx, det_idx = list(range(lattice.nimp)), []
+    elif det:
+        imp_idx, det_idx = [], list(range(lattice.nimp))
+    elif imp_idx is None:
+        if det_idx is None:
+            imp_idx, det_idx, imp_bath_fit = list(range(nbasis)), [], True
+        else:
+            imp_idx = []
+    elif det_idx is None:
+        det_idx = []
+    imp_idx, det_idx = list(imp_idx), list(det_idx)
+    if not imp_bath_fit:                                          # spatial -> alpha + beta embedding orbitals (spinless.py:1189-1195)
+        doubled = lambda idx: sum(sh.idx_ao2so(idx, lattice.nimp), [])
+        imp_idx, det_idx = doubled(imp_idx), doubled(det_idx)
+    log.info("impurity fitting? %s", imp_fit)
+    log.info("det (diagonal fitting)? %s", det)
+    if len(np.unique(imp_idx + det_idx)) != len(imp_idx + det_idx):
+        log.warn("fit_idx has repeated indices: %s", imp_idx + det_idx)
+    vcor_mat = kwargs.get("vcor_mat", None)
+    if vcor_mat is not None:
+        for s in range(3):
+            fock_k[s] += vcor_mat[s]
+    embH1 = sh.transform_trans_inv_k(basis_ka, basis_kb, fock_k)
+    embH1 = embH1 + sh.transform_local(basis_Ra, basis_Rb, np.asarray([-mu * np.eye(nao), mu * np.eye(nao)]))
+    ovlp_emb = sh.transform_trans_inv_k(basis_ka, basis_kb, ovlp_k)
+    ctx = get_ctx()
+    d_dV = slater.get_dV_dparam_dev(ctx, _SpinOrbitalPotential(vcor, nao), basis[np.newaxis])
+    vcor.grad = None
+    fit = slater.EmbFitDevice(ctx, np.asarray(rho)[np.newaxis], lattice, basis[np.newaxis], vcor, beta, nelec, imp_idx, det_idx, None, None,
+                              mu0=kwargs.get("mu0", None), fix_mu=kwargs.get("fix_mu", False), tol_deg=kwargs.get("tol_deg", 1e-3),
+                              eigh=kwargs.get("eigh", "jacobi"), operators=(embH1, ovlp_emb), dV_table=d_dV, norm=np.sqrt(2.0))
+    return slater.drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, FitVcorEmb,
+                                grad_check_steps=(1e-4, 1e-5))

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1741,6 +1741,60 @@ def gen_G28():
             out[key + "_ecd"], out[key + "_ecc"], out[key + "_eH0"] = H1e["cd"], H1e["cc"], np.asarray(H0e)
     np.savez_compressed(os.path.join(GOLD, "G28_bcs_embham.npz"), **out)
     print("G28 done", len(out), "arrays")
+
+
+GSO_FIT_RUNS = [("t0", np.inf, dict()), ("ft", 15.0, dict()), ("imp_t0", np.inf, dict(imp_fit=True)), ("det_ft", 15.0, dict(det=True)),
+                ("fixmu_ft", 15.0, dict(fix_mu=True, mu0=0.05)), ("hcore_t0", np.inf, dict(hcore=True))]
+
+
+def gen_G29():
+    """The GSO correlation-potential fit in the embedding space, routine/spinless.py:1090-1430 (get_dV_dparam, FitVcorEmb): the
+    reference's objective / gradient closures at fixed parameters and its fits, with its own Hubbard.VcorLocal(unrestricted,
+    bogoliubov) potential, on the generalised lattices and bases of G27."""
+    spinless, sh = shim.patch_spinless()
+    from libdmet.dmet import Hubbard
+    g27 = np.load(os.path.join(GOLD, "G27_gso_embham.npz"))
+    out = {}
+    captured = {}
+    real_minimize = spinless.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    spinless.minimize = spy
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        nk = int(np.prod(mesh))
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        basis, H3, F3, GRho_k = g27[name + "/basis"], g27[name + "/H3_k"], g27[name + "/F3_k"], g27[name + "/GRho_k"]
+        S3 = np.zeros((3, nk, n, n), dtype=complex)
+        S3[0] = S3[1] = np.eye(n)
+        L.hcore_lo_k, L.fock_lo_k, L.ovlp_lo_k = H3, F3, S3
+        L.JK_imp, L.Ham = None, None
+        neo = basis.shape[-1]
+        rng = np.random.default_rng(2900 + n)
+        noise = 0.05 * rng.standard_normal((neo, neo))
+        target = spinless.foldRho_k(GRho_k, L.R2k_basis(basis)) + 0.5 * (noise + noise.T)
+        out[name + "/target"] = target
+        v = Hubbard.VcorLocal(False, True, n)
+        out[name + "/dV_compact"] = spinless.get_dV_dparam(v, basis, None, L)
+        v = Hubbard.VcorLocal(False, True, n)
+        out[name + "/dV_full"] = spinless.get_dV_dparam(v, basis, None, L, compact=False)
+        for tag, beta, kw in GSO_FIT_RUNS:
+            kw = dict(kw)
+            L.use_hcore_as_emb_ham = kw.pop("hcore", False)
+            v = Hubbard.VcorLocal(False, True, n)
+            v.update(np.zeros(v.length()))
+            vfit, e0, e1 = spinless.FitVcorEmb(target, L, basis, v, 0.37, beta=beta, MaxIter=30, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](q.copy()) for q in P])
+            out[key + "/probe_grad"] = np.asarray([captured["fgrad"](q.copy()) for q in P])
+        L.use_hcore_as_emb_ham = False
+    spinless.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G29_gso_fit.npz"), **out)
+    print("G29 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -463,6 +463,10 @@ class EmbFit(object):
             self.target[s][self.imp_fill] = rho[s][self.imp_mesh]
             self.target[s][self.det_fill] = rho[s][self.det_mesh]
 
+    def norm_div(self):
+        """|drho| is divided by sqrt(spin) (slater.py:1094); the GSO twin sets `norm` = sqrt(2) on its single block (spinless.py:1259)."""
+        return getattr(self, "norm", None) or sqrt(self.spin)
+
     def Vemb(self, param):
         tmp = np.tensordot(param, self.dV, axes=(0, 0))
         v = np.zeros((self.spin, self.nb, self.nb))
@@ -500,7 +504,7 @@ class EmbFit(object):
 
     def errfunc(self, param):
         drho = self._solve(param)[4]
-        return la.norm(self._residual(drho)[0]) / sqrt(self.spin)
+        return la.norm(self._residual(drho)[0]) / self.norm_div()
 
     def drho_dparam(self, param):
         """return_drho_dparam (slater.py:1227-1261): (spin, nparam, npair) response of the tril-packed embedding density to the
@@ -531,7 +535,7 @@ class EmbFit(object):
             eo, evirt = ew[s, :nocc], ew[s, nocc:]
             co, cv = ev[s][:, :nocc], ev[s][:, nocc:]
             e_mn = 1.0 / (-evirt.reshape((-1, 1)) + eo)
-            t = (cv[self.fit_idx].T @ drho[s] @ co[self.fit_idx]) * e_mn / (val * sqrt(spin))
+            t = (cv[self.fit_idx].T @ drho[s] @ co[self.fit_idx]) * e_mn / (val * self.norm_div())
             full = cv @ t @ co.T
             full = (full + full.T) * 2.0
             full[dg] *= 0.5
@@ -544,7 +548,7 @@ class EmbFit(object):
         act, drho = self._residual(drho)
         val = la.norm(act)
         dw_dv = get_dw_dv(ew, ev, drho, mu, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=True)
-        res = self.dV.reshape(self.dV.shape[0], -1).dot(dw_dv.ravel()) / (2.0 * val * sqrt(self.spin))
+        res = self.dV.reshape(self.dV.shape[0], -1).dot(dw_dv.ravel()) / (2.0 * val * self.norm_div())
         return self._finish(res)
 
 

@@ -336,3 +336,44 @@ def gso_embHam1e(kmesh, basis, H2_emb, hcore_k, fock_k, ovlp_k, rdm1_k, vcor_mat
         if JK_imp is not None:
             H1 = H1 - transform_imp_gso(basis, JK_imp)
     return H1[None], ovlp_emb, JK_core
+
+
+# ---------------------------------------------------------------------------------------------
+# GSO vcor fit in the embedding space (routine/spinless.py:1090-1430); golden G29
+# ---------------------------------------------------------------------------------------------
+
+def get_dV_dparam_gso(vcor, basis, compact=True):
+    """spinless.py:1090-1127: transform_local of every parameter's gradient blocks (aa, bb, ab)."""
+    g = vcor.gradient()
+    nb = basis.shape[-1]
+    tl = np.tril_indices(nb)
+    full = np.asarray([transform_local_gso(basis, g[ip]) for ip in range(vcor.length())])
+    return full[:, tl[0], tl[1]] if compact else full
+
+
+def gso_emb_fit(rho, kmesh, basis, vcor, mu, beta, fock_k, ovlp_k, nimp, nelec=None, imp_fit=False, det=False, mu0=None, fix_mu=False,
+                tol_deg=1e-3):
+    """The objective of spinless.FitVcorEmb as an oracle.restate_fit.EmbFit on one generalised block: GSO operators, half filling,
+    fitted spatial indices doubled to alpha + beta, |drho| / sqrt(2)."""
+    from oracle.restate import R2k
+    from oracle.restate_fit import EmbFit
+    nb, n = basis.shape[-1], basis.shape[1] // 2
+    fit = EmbFit.__new__(EmbFit)
+    fit.C_act, fit.spin, fit.nb, fit.norm = None, 1, nb, np.sqrt(2.0)
+    fit.beta, fit.nelec, fit.mu0, fit.fix_mu, fit.tol_deg = beta, (nb // 2 if nelec is None else nelec), mu0, fix_mu, tol_deg
+    fit.vcor, fit.remove_diag_grad = vcor, False
+    doubled = list(range(nimp)) + [i + nimp for i in range(nimp)]
+    imp_idx, det_idx = (doubled, []) if imp_fit else (([], doubled) if det else (list(range(nb)), []))
+    fit.fit_idx = imp_idx + det_idx
+    ni, nidx = len(imp_idx), len(fit.fit_idx)
+    fit.imp_mesh, fit.det_mesh = np.ix_(imp_idx, imp_idx), (det_idx, det_idx)
+    fit.imp_fill, fit.det_fill = (slice(ni), slice(ni)), (range(ni, nidx), range(ni, nidx))
+    basis_k = R2k(basis, kmesh)
+    H = transform_trans_inv_k_gso(basis_k, fock_k) + transform_local_gso(basis, np.asarray([-mu * np.eye(n), mu * np.eye(n)]))
+    fit.embH1, fit.ovlp = H[None], transform_trans_inv_k_gso(basis_k, ovlp_k)[None]
+    fit.dV = get_dV_dparam_gso(vcor, basis)[:, None, :]
+    fit.tril = np.tril_indices(nb)
+    fit.target = np.zeros((1, nidx, nidx))
+    fit.target[0][fit.imp_fill] = rho[fit.imp_mesh]
+    fit.target[0][fit.det_fill] = rho[fit.det_mesh]
+    return fit

@@ -254,3 +254,40 @@ def test_gso_embedding_hamiltonian(ctx, golden, name):
         L.set_H2_local(unit, H2_format="spin nearest")
         with pytest.raises(NotImplementedError):
             spinless.get_emb_Ham(L, basis, vc, mu)
+
+
+# ---- round 6: the GSO vcor fit in the embedding space (golden G29) ---------------------------------------------------------
+
+from tests.test_oracle_gso import GSO_FIT, GSO_FIT_RUNS  # noqa: E402
+
+
+@pytest.mark.parametrize("name,n,val", GSO_FIT)
+def test_gso_vcor_fit(ctx, golden, name, n, val):
+    """spinless.get_dV_dparam / FitVcorEmb (routine/spinless.py:1090-1430) on the device against the reference's own closures and
+    fits (golden G29): T = 0 and finite T, impurity block, diagonal, fixed mu, hcore as the embedding Hamiltonian."""
+    from libdmet_preview_amd.routine import spinless
+    from libdmet_preview_amd.dmet import Hubbard
+    g, g27 = golden("G29_gso_fit.npz"), golden("G27_gso_embham.npz")
+    L, mesh, basis, H2, F3, rk, vmat, mu = _gso_lattice(g27, name)
+    v = Hubbard.VcorLocal(False, True, n)
+    assert np.abs(spinless.get_dV_dparam(v, basis, None, L) - g[name + "/dV_compact"]).max() < 1e-13
+    assert np.abs(spinless.get_dV_dparam(v, basis, None, L, compact=False) - g[name + "/dV_full"]).max() < 1e-13
+    with pytest.raises(NotImplementedError):
+        spinless.get_dV_dparam(v, basis, None, L, P_act=np.zeros(1))
+    target = g[name + "/target"]
+    for tag, beta, kw in GSO_FIT_RUNS:
+        kw = dict(kw)
+        L.use_hcore_as_emb_ham = kw.pop("hcore", False)
+        v = Hubbard.VcorLocal(False, True, n)
+        v.update(np.zeros(v.length()))
+        vfit, e0, e1 = spinless.FitVcorEmb(target, L, basis, v, mu, beta=beta, MaxIter=30, **kw)
+        fit = spinless.FitVcorEmb.last_fit
+        key = "%s/%s" % (name, tag)
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-11, key
+            assert np.abs(fit.gradfunc(p) - gr).max() < 1e-8 * max(1.0, np.abs(gr).max()), key
+        pref, (r0, r1) = g[key + "/param"], g[key + "/err"]
+        assert abs(e0 - r0) < 1e-11, key
+        assert abs(e1 - r1) < 1e-6, (key, e1, r1)
+        assert vfit is v and e1 <= e0
+    L.use_hcore_as_emb_ham = False

@@ -161,3 +161,32 @@ def test_G27_gso_embedding_hamiltonian(golden, name):
     assert np.array_equal(G.unit2emb_gso(g[name + "/unit"], basis.shape[-1]), g[name + "/unit2emb"])
     if name + "/eri_local" in g:
         assert np.abs(G.transform_eri_local_gso(basis, g[name + "/unit"]) - g[name + "/eri_local"]).max() < 1e-12
+
+
+# ---- round 6: the GSO vcor fit in the embedding space (golden G29) ---------------------------------------------------------
+
+GSO_FIT = [("c611", 2, [0, 1]), ("c441", 4, [0, 1, 2, 3]), ("c222", 5, [1, 2, 3])]
+GSO_FIT_RUNS = [("t0", np.inf, dict()), ("ft", 15.0, dict()), ("imp_t0", np.inf, dict(imp_fit=True)), ("det_ft", 15.0, dict(det=True)),
+                ("fixmu_ft", 15.0, dict(fix_mu=True, mu0=0.05)), ("hcore_t0", np.inf, dict(hcore=True))]
+
+
+@pytest.mark.parametrize("name,n,val", GSO_FIT)
+def test_G29_gso_fit_objective_and_gradient(golden, name, n, val):
+    from oracle import restate_fit as F
+    g, g27 = golden("G29_gso_fit.npz"), golden("G27_gso_embham.npz")
+    mesh, basis, H2, H3, F3, S3, rk, vmat, mu = gso_ham_inputs(g27, name)
+    v = F.VcorLocal(False, True, n)
+    assert np.abs(G.get_dV_dparam_gso(v, basis) - g[name + "/dV_compact"]).max() < 1e-13
+    assert np.abs(G.get_dV_dparam_gso(v, basis, compact=False) - g[name + "/dV_full"]).max() < 1e-13
+    nimp = len(val) + len([i for i in range(n) if i > max(val)])
+    for tag, beta, kw in GSO_FIT_RUNS:
+        kw = dict(kw)
+        fock = H3 if kw.pop("hcore", False) else F3
+        fit = G.gso_emb_fit(g[name + "/target"], mesh, basis, v, mu, beta, fock, S3, nimp, **kw)
+        key = "%s/%s" % (name, tag)
+        grad = fit.gradfunc if beta == np.inf else fit.gradfunc_ft
+        for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+            assert abs(fit.errfunc(p) - e) < 1e-12, key
+            assert np.abs(grad(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
+        pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
+        assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
