@@ -67,7 +67,7 @@ _FUNCTIONS = [
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
       "contract_imp_env", "transform_imp_env", "transform_local_grad", "get_dV_dparam"]),
-    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham"]),
+    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb"]),
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
     ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb"]),

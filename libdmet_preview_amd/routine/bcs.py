@@ -215,3 +215,56 @@ def embHam(lattice, basis, vcor, mu, local=True, **kwargs):
 
 
 get_emb_Ham = embHam
+
+
+# ---- BCS correlation-potential fit in the embedding space (routine/bcs.py:356-530) -----------------------------------------
+
+def _nambu(A, B, D):
+    """[[A, D], [D^T, -B]] (bcs.py:389-392)."""
+    nb = A.shape[-1]
+    M = np.empty((2 * nb, 2 * nb))
+    M[:nb, :nb], M[nb:, nb:], M[:nb, nb:], M[nb:, :nb] = A, -np.asarray(B), D, np.asarray(D).T
+    return M
+
+
+def FitVcorEmb(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, CG_check=False, BFGS=False, diff_criterion=None,
+               imp_fit=False, fit_idx=None, **kwargs):
+    """
+    Fit the correlation potential (normal + pairing blocks) in the Nambu embedding space (bcs.py:356-530): minimise
+    |GRho_emb[vcor] - GRho|_F / sqrt(2) over the parameters, GRho_emb the lower half of the spectrum of
+    embH + V(param), a symmetric matrix of dimension 2 nbasis.  It is the Slater fit on one block -- all entries fitted, nbasis
+    levels filled at T = 0, the Fermi function around the fixed `mu0` (default 0, `fix_mu` default True) at finite T -- so the
+    objective and both analytic gradients run on the device (slater.EmbFitDevice with the Nambu operators handed over).
+    """
+    from libdmet_preview_amd.routine import slater
+    log.eassert(imp_fit is False and fit_idx is None, "Only imp+bath fit is supported.")
+    basis = np.asarray(basis, dtype=np.float64)
+    param_begin = vcor.param.copy()
+    n, nb = lattice.nscsites, basis.shape[-1]
+    fock_R = np.asarray(lattice.getH1(kspace=False) if lattice.use_hcore_as_emb_ham else lattice.getFock(kspace=False))
+    (HA, HB), HD, _ = transform_trans_inv(basis, lattice, fock_R)                                # noqa: F405
+    shift = np.zeros((3, n, n))
+    shift[0] = shift[1] = -mu * np.eye(n)                        # the zero potential with -mu on both normal blocks (bcs.py:403-409)
+    (A0, B0), D0, _ = transform_local(basis, lattice, shift)                                     # noqa: F405
+    embH = _nambu(np.asarray(HA), np.asarray(HB), np.asarray(HD)) + _nambu(np.asarray(A0), np.asarray(B0), np.asarray(D0))
+    if not vcor.restricted and vcor.bogoliubov and not getattr(vcor, "bogo_res", False) and getattr(vcor, "_v_idx_diag", None) is None:
+        table = get_dV_dparam(basis, lattice, vcor)             # noqa: F405  every parameter at once (bcs_helper.py:390-430)
+    else:
+        g = np.asarray(vcor.gradient())
+        table = np.empty((vcor.length(), 2 * nb, 2 * nb))
+        for ip in range(vcor.length()):
+            (dA, dB), dD, _ = transform_local(basis, lattice, g[ip])                             # noqa: F405
+            table[ip] = _nambu(np.asarray(dA), np.asarray(dB), np.asarray(dD))
+    dim = 2 * nb
+    tl = np.tril_indices(dim)
+    ctx = get_ctx()
+    d_dV = ctx.to_device(np.ascontiguousarray(table[:, tl[0], tl[1]]).reshape(vcor.length(), 1, len(tl[0])))
+    finite = beta < np.inf
+    fit = slater.EmbFitDevice(ctx, np.asarray(GRho)[np.newaxis], lattice, np.zeros((1, 1, 1, dim)), vcor, beta, nb, list(range(dim)), [],
+                              None, None, mu0=kwargs.get("mu0", 0.0) if finite else None,
+                              fix_mu=kwargs.get("fix_mu", True) if finite else False, eigh=kwargs.get("eigh", "jacobi"),
+                              operators=(embH, np.eye(dim)), dV_table=d_dV, norm=np.sqrt(2.0))
+    kwargs = dict(kwargs)
+    kwargs.pop("mu0", None), kwargs.pop("fix_mu", None)
+    return slater.drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, FitVcorEmb,
+                                grad_check_steps=(1e-4, 1e-5))

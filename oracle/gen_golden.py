@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1795,6 +1795,56 @@ def gen_G29():
     spinless.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G29_gso_fit.npz"), **out)
     print("G29 done", len(out), "arrays")
+
+
+def gen_G30():
+    """The BCS correlation-potential fit in the embedding space, routine/bcs.py:356-530 FitVcorEmb: Nambu embedding Hamiltonian of
+    dimension 2 nbasis, all entries fitted, fixed chemical potential 0 at finite T; the reference's closures at fixed parameters and
+    its fits, with its own Hubbard.VcorLocal potentials (unrestricted + pairing, and restricted + pairing), on the model lattices
+    of G28."""
+    from types import SimpleNamespace
+    from libdmet.routine import bcs
+    from libdmet.dmet import Hubbard
+    g7, g28 = np.load(os.path.join(GOLD, "G7_bcs.npz")), np.load(os.path.join(GOLD, "G28_bcs_embham.npz"))
+    out = {}
+    captured = {}
+    real_minimize = bcs.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    bcs.minimize = spy
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val)
+        L.is_model = True
+        L.cell = SimpleNamespace(max_memory=4000)
+        H3 = g28[name + "/H3_R"]
+        L.hcore_lo_R, L.fock_lo_R = H3, 1.1 * H3
+        L.hcore_lo_k, L.fock_lo_k = synth.fold_R2k(H3, mesh), synth.fold_R2k(1.1 * H3, mesh)
+        L.JK_imp, L.Ham, L.H0, L.use_hcore_as_emb_ham = None, None, 0.0, False
+        basis, GRho, mu = g7[name + "/basis_proj"], g7[name + "/GRho"], float(g7[name + "/mu"])
+        nb = basis.shape[-1]
+        rng = np.random.default_rng(3000 + n)
+        noise = 0.04 * rng.standard_normal((2 * nb, 2 * nb))
+        target = bcs.foldRho(GRho, L, basis) + 0.5 * (noise + noise.T)
+        out[name + "/target"] = target
+        for vtag, res in (("u", False), ("r", True)):
+            for tag, beta, kw in (("t0", np.inf, dict()), ("ft", 15.0, dict()), ("hcore_ft", 15.0, dict(hcore=True))):
+                kw = dict(kw)
+                L.use_hcore_as_emb_ham = kw.pop("hcore", False)
+                v = Hubbard.VcorLocal(res, True, n)
+                v.update(np.zeros(v.length()))
+                vfit, e0, e1 = bcs.FitVcorEmb(target, L, basis, v, mu, beta=beta, MaxIter=25, **kw)
+                key = "%s/%s_%s" % (name, vtag, tag)
+                out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+                P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+                out[key + "/probe"] = P
+                out[key + "/probe_err"] = np.asarray([captured["fn"](q.copy()) for q in P])
+                out[key + "/probe_grad"] = np.asarray([captured["fgrad"](q.copy()) for q in P])
+            L.use_hcore_as_emb_ham = False
+    bcs.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G30_bcs_fit.npz"), **out)
+    print("G30 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -393,3 +393,48 @@ def bcs_embHam(kmesh, basis, hcore_R, LatH2, vcor_mat, mu, ImpJK=None, fitting=F
         cd, cc, H0 = cd + sign * np.asarray(tcd), cc + sign * tcc, H0 + sign * t0
     ecd, ecc, e0 = transform_imp_env(basis, kmesh, hcore_R)
     return ({"cd": cd, "cc": cc[None]}, H0, ccdd), ({"cd": np.asarray(ecd), "cc": np.asarray(ecc)[None]}, e0)
+
+
+# ---------------------------------------------------------------------------------------------
+# BCS vcor fit in the embedding space (routine/bcs.py:356-530); golden G30
+# ---------------------------------------------------------------------------------------------
+
+def nambu(A, B, D):
+    """[[A, D], [D^T, -B]] (bcs.py:389-392, 398-401)."""
+    nb = A.shape[-1]
+    M = np.empty((2 * nb, 2 * nb))
+    M[:nb, :nb], M[nb:, nb:], M[:nb, nb:], M[nb:, :nb] = A, -B, D, D.T
+    return M
+
+
+def bcs_emb_fit(GRho, kmesh, basis, vcor, mu, beta, fock_R, mu0=0.0, fix_mu=True):
+    """The objective of bcs.FitVcorEmb as an oracle.restate_fit.EmbFit on ONE Nambu block of dimension 2 nbasis: every entry
+    fitted, nbasis levels filled at T = 0 (the reference's `ew < 0` on a particle-hole symmetric spectrum), Fermi function around
+    the fixed mu0 at finite T, |dGRho| / sqrt(2); the constant part holds the fold of the Fock stripe and of -mu."""
+    from oracle.restate_fit import EmbFit
+    n, nb = basis.shape[2] // 2, basis.shape[-1]
+    (HA, HB), HD, _ = transform_trans_inv(basis, kmesh, fock_R)
+    shift = np.zeros((3, n, n))
+    shift[0] = shift[1] = -mu * np.eye(n)
+    (A0, B0), D0, _ = transform_local(basis, kmesh, shift)
+    g = vcor.gradient()
+    table = []
+    for ip in range(vcor.length()):
+        (dA, dB), dD, _ = transform_local(basis, kmesh, g[ip])
+        table.append(nambu(dA, dB, dD))
+    dim = 2 * nb
+    tl = np.tril_indices(dim)
+    fit = EmbFit.__new__(EmbFit)
+    fit.C_act, fit.spin, fit.nb, fit.norm = None, 1, dim, np.sqrt(2.0)
+    fit.beta, fit.nelec, fit.mu0, fit.fix_mu, fit.tol_deg = beta, nb, mu0, (fix_mu if beta < np.inf else False), 1e-3
+    fit.vcor, fit.remove_diag_grad = vcor, False
+    idx = list(range(dim))
+    fit.fit_idx = idx
+    fit.imp_mesh, fit.det_mesh = np.ix_(idx, idx), ([], [])
+    fit.imp_fill, fit.det_fill = (slice(dim), slice(dim)), (range(dim, dim), range(dim, dim))
+    fit.embH1 = (nambu(np.asarray(HA), np.asarray(HB), np.asarray(HD)) + nambu(A0, B0, D0))[None]
+    fit.ovlp = np.eye(dim)[None]
+    fit.dV = np.asarray([m[tl] for m in table])[:, None, :]
+    fit.tril = tl
+    fit.target = np.array(GRho, copy=True)[None]
+    return fit

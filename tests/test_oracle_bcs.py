@@ -173,3 +173,27 @@ def test_G28_bcs_embedding_hamiltonian(golden, name):
         assert abs(H0 - float(g[k + "_H0"])) < 1e-12 and np.array_equal(ccdd, g[k + "_ccdd"])
         assert np.abs(He["cd"] - g[k + "_ecd"]).max() < 1e-12 and np.abs(He["cc"] - g[k + "_ecc"]).max() < 1e-12
         assert abs(e0 - float(g[k + "_eH0"])) < 1e-12
+
+
+# ---- round 6: the BCS vcor fit in the embedding space (golden G30) ---------------------------------------------------------
+
+BCS_FIT_RUNS = [("t0", np.inf, False), ("ft", 15.0, False), ("hcore_ft", 15.0, True)]
+
+
+@pytest.mark.parametrize("name,n", [("c611", 2), ("c441", 4)])
+def test_G30_bcs_fit_objective_and_gradient(golden, name, n):
+    from oracle import restate_fit as F
+    g, g7, g28 = golden("G30_bcs_fit.npz"), golden("G7_bcs.npz"), golden("G28_bcs_embham.npz")
+    mesh = tuple(int(x) for x in g7[name + "/mesh"])
+    basis, mu, H3 = g7[name + "/basis_proj"], float(g7[name + "/mu"]), g28[name + "/H3_R"]
+    for vtag, res in (("u", False), ("r", True)):
+        for tag, beta, hcore in BCS_FIT_RUNS:
+            v = F.VcorLocal(res, True, n)
+            fit = B.bcs_emb_fit(g[name + "/target"], mesh, basis, v, mu, beta, H3 if hcore else 1.1 * H3)
+            key = "%s/%s_%s" % (name, vtag, tag)
+            grad = fit.gradfunc if beta == np.inf else fit.gradfunc_ft
+            for p, e, gr in zip(g[key + "/probe"], g[key + "/probe_err"], g[key + "/probe_grad"]):
+                assert abs(fit.errfunc(p) - e) < 1e-12, key
+                assert np.abs(grad(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
+            pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
+            assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
