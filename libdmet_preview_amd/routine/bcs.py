@@ -268,3 +268,23 @@ def FitVcorEmb(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, CG_chec
     kwargs.pop("mu0", None), kwargs.pop("fix_mu", None)
     return slater.drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, FitVcorEmb,
                                 grad_check_steps=(1e-4, 1e-5))
+
+
+def FitVcorTwoStep(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter1=300, MaxIter2=0, kinetic=False, CG_check=False, BFGS=False,
+                   serial=True, method='CG', ytol=1e-7, gtol=5e-3, **kwargs):
+    """Main wrapper of the BCS fit (bcs.py:621-664): the embedding-space stage on a copy of `vcor`; returns (vcor_new, err_end).  The
+    lattice stages (`MaxIter2 > 0`: FitVcorFull; `kinetic`: FitVcorFullK, which needs a convex solver) are not built."""
+    from copy import deepcopy
+    if kinetic or MaxIter2 > 0:
+        raise NotImplementedError("the lattice stages of the BCS fit (bcs.FitVcorFull / FitVcorFullK) are not built; MaxIter2 = 0")
+    vcor_new = deepcopy(vcor)
+    log.result("Using two-step vcor fitting")
+    log.eassert(MaxIter1 > 0, "FitVcorTwoStep: no stage to run (MaxIter1 = MaxIter2 = 0)")
+    log.info("Impurity model stage max %d steps", MaxIter1)
+    log.info("Finite temperature used in fitting? beta = %15.6f ", beta)
+    vcor_new, err_begin, err_end = FitVcorEmb(GRho, lattice, basis, vcor_new, mu, beta=beta, MaxIter=MaxIter1, CG_check=CG_check,
+                                              serial=serial, BFGS=BFGS, method=method, ytol=ytol, gtol=gtol, **kwargs)
+    log.info("Embedding Stage:\nbegin %20.12f    end %20.12f" % (err_begin, err_end))
+    log.result("residue (begin) = %20.12f", err_begin)
+    log.result("residue (end)   = %20.12f", err_end)
+    return vcor_new, err_end

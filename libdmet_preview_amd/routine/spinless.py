@@ -501,3 +501,26 @@ def FitVcorEmb(rho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, imp_fit=
                               eigh=kwargs.get("eigh", "jacobi"), operators=(embH1, ovlp_emb), dV_table=d_dV, norm=np.sqrt(2.0))
     return slater.drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, FitVcorEmb,
                                 grad_check_steps=(1e-4, 1e-5))
+
+
+def FitVcorTwoStep(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter1=300, MaxIter2=0, kinetic=False, CG_check=False, BFGS=False,
+                   serial=True, method='CG', ytol=1e-7, gtol=1e-3, filling=None, **kwargs):
+    """Main wrapper of the GSO fit (spinless.py:2166-2231): the embedding-space stage on a copy of `vcor`; returns (vcor_new, err_end)
+    or, with `full_return`, (vcor_new, None, err_end, {}).  The lattice stage (`MaxIter2 > 0`: FitVcorFull / FitVcorFull_mu of the
+    reference) is not built."""
+    import copy
+    if MaxIter2 > 0:
+        raise NotImplementedError("the lattice stage of the GSO fit (spinless.FitVcorFull / FitVcorFull_mu) is not built; MaxIter2 = 0")
+    vcor_new = copy.deepcopy(vcor)
+    log.result("Using two-step vcor fitting")
+    log.eassert(MaxIter1 > 0, "FitVcorTwoStep: no stage to run (MaxIter1 = MaxIter2 = 0)")
+    log.info("Impurity model stage max %d steps", MaxIter1)
+    log.info("Finite temperature used in fitting? beta = %s ", beta)
+    vcor_new, err_begin, err_end = FitVcorEmb(GRho, lattice, basis, vcor_new, mu, beta=beta, MaxIter=MaxIter1, CG_check=CG_check,
+                                              serial=serial, BFGS=BFGS, method=method, ytol=ytol, gtol=gtol, **kwargs)
+    log.info("Embedding Stage:\nbegin %20.12f    end %20.12f" % (err_begin, err_end))
+    log.result("residue (begin) = %20.12f", err_begin)
+    log.result("residue (end)   = %20.12f", err_end)
+    if kwargs.get("full_return", False):
+        return vcor_new, None, err_end, {}
+    return vcor_new, err_end

@@ -364,3 +364,10 @@ def test_bcs_vcor_fit(ctx, golden, name, n):
     L.use_hcore_as_emb_ham = False
     with pytest.raises(Exception):
         bcs.FitVcorEmb(target, L, basis, v, mu, imp_fit=True)
+    v = Hubbard.VcorLocal(False, True, n)
+    v.update(np.zeros(v.length()))
+    vnew, err = bcs.FitVcorTwoStep(target, L, basis, v, mu, beta=np.inf, MaxIter1=25, MaxIter2=0)
+    assert vnew is not v and np.abs(np.asarray(v.param)).max() == 0.0 and abs(err - g[name + "/u_t0/err"][1]) < 1e-6
+    for kw in (dict(MaxIter2=2), dict(kinetic=True)):
+        with pytest.raises(NotImplementedError):
+            bcs.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, **kw)

@@ -291,3 +291,11 @@ def test_gso_vcor_fit(ctx, golden, name, n, val):
         assert abs(e1 - r1) < 1e-6, (key, e1, r1)
         assert vfit is v and e1 <= e0
     L.use_hcore_as_emb_ham = False
+    # the wrapper of the DMET loop: embedding stage on a COPY (spinless.py:2166-2231)
+    v = Hubbard.VcorLocal(False, True, n)
+    v.update(np.zeros(v.length()))
+    vnew, err = spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=np.inf, MaxIter1=30, MaxIter2=0)
+    assert vnew is not v and np.abs(np.asarray(v.param)).max() == 0.0 and abs(err - g[name + "/t0/err"][1]) < 1e-6
+    assert len(spinless.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, full_return=True)) == 4
+    with pytest.raises(NotImplementedError):
+        spinless.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, MaxIter2=2)
