@@ -67,10 +67,10 @@ _FUNCTIONS = [
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
       "contract_imp_env", "transform_imp_env", "transform_local_grad", "get_dV_dparam"]),
-    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb", "FitVcorTwoStep"]),
+    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb"]),      # FitVcorTwoStep stays the reference's: it calls the rebound FitVcorEmb and its own lattice stage
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
-    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb", "FitVcorTwoStep"]),
+    ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb"]),
     # the GSO one-body folds and ERI containers (routine/spinless.py:32 star-imports the helper module)
     ("routine.spinless_helper", ["routine.spinless_helper", "routine.spinless"],
      ["unit2emb", "transform_eri_local", "transform_trans_inv_k", "transform_local", "transform_imp", "get_H2_mask"]),
