@@ -67,7 +67,8 @@ _FUNCTIONS = [
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
       "contract_imp_env", "transform_imp_env", "transform_local_grad", "get_dV_dparam"]),
-    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb"]),      # FitVcorTwoStep stays the reference's: it calls the rebound FitVcorEmb and its own lattice stage
+    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb", "FitVcorFull", "foldRho", "foldRho_k"]),
+    # (FitVcorTwoStep stays the reference's own: it reaches the rebound stages and keeps its kinetic variant)
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
     ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb"]),
@@ -87,6 +88,8 @@ _FUNCTIONS = [
 _LATTICE_METHODS = ["set_Ham", "setHam", "set_Ham_model", "setHam_model", "update_Ham", "transform_obj_to_lo"]
 # HF itself: dmet/HubPhSymm.py:22 binds it by name, dmet/Hubbard.py:9 star-imports that module
 _HF_HOLDERS = ["routine.mfd", "dmet.HubPhSymm", "dmet.Hubbard"]
+# HFB: routine/bcs.py:15 and dmet/HubbardBCS.py:6 import it by name
+_HFB_HOLDERS = ["routine.mfd", "routine.bcs", "dmet.HubbardBCS"]
 
 
 def binding_table():
@@ -98,6 +101,8 @@ def binding_table():
                 out.append((ours, r, n))
     for r in _HF_HOLDERS:
         out.append(("routine.mfd", r, "HF"))
+    for r in _HFB_HOLDERS:
+        out.append(("routine.mfd", r, "HFB"))
     return out
 
 
@@ -117,7 +122,7 @@ def install(reference_package="libdmet", replace_hf=True, strict=True, resident_
         setattr(ref_mod, name, value)
 
     for ours, ref, name in binding_table():
-        if name == "HF" and not replace_hf:
+        if name in ("HF", "HFB") and not replace_hf:
             continue
         mine = importlib.import_module("libdmet_preview_amd." + ours)
         bind(importlib.import_module(reference_package + "." + ref), name, getattr(mine, name))

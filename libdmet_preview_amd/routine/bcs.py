@@ -273,18 +273,66 @@ def FitVcorEmb(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, CG_chec
 def FitVcorTwoStep(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter1=300, MaxIter2=0, kinetic=False, CG_check=False, BFGS=False,
                    serial=True, method='CG', ytol=1e-7, gtol=5e-3, **kwargs):
     """Main wrapper of the BCS fit (bcs.py:621-664): the embedding-space stage on a copy of `vcor`; returns (vcor_new, err_end).  The
-    lattice stages (`MaxIter2 > 0`: FitVcorFull; `kinetic`: FitVcorFullK, which needs a convex solver) are not built."""
+    kinetic-energy variant (`kinetic`: FitVcorFullK over scipy's default minimiser) is not built."""
     from copy import deepcopy
-    if kinetic or MaxIter2 > 0:
-        raise NotImplementedError("the lattice stages of the BCS fit (bcs.FitVcorFull / FitVcorFullK) are not built; MaxIter2 = 0")
+    if kinetic:
+        raise NotImplementedError("the kinetic-energy variant of the BCS fit (bcs.FitVcorFullK) is not built")
     vcor_new = deepcopy(vcor)
     log.result("Using two-step vcor fitting")
-    log.eassert(MaxIter1 > 0, "FitVcorTwoStep: no stage to run (MaxIter1 = MaxIter2 = 0)")
-    log.info("Impurity model stage max %d steps", MaxIter1)
-    log.info("Finite temperature used in fitting? beta = %15.6f ", beta)
-    vcor_new, err_begin, err_end = FitVcorEmb(GRho, lattice, basis, vcor_new, mu, beta=beta, MaxIter=MaxIter1, CG_check=CG_check,
-                                              serial=serial, BFGS=BFGS, method=method, ytol=ytol, gtol=gtol, **kwargs)
-    log.info("Embedding Stage:\nbegin %20.12f    end %20.12f" % (err_begin, err_end))
+    log.eassert(MaxIter1 > 0 or MaxIter2 > 0, "FitVcorTwoStep: no stage to run (MaxIter1 = MaxIter2 = 0)")
+    err_begin = None
+    if MaxIter1 > 0:
+        log.info("Impurity model stage max %d steps", MaxIter1)
+        log.info("Finite temperature used in fitting? beta = %15.6f ", beta)
+        vcor_new, err_begin, err_end = FitVcorEmb(GRho, lattice, basis, vcor_new, mu, beta=beta, MaxIter=MaxIter1, CG_check=CG_check,
+                                                  serial=serial, BFGS=BFGS, method=method, ytol=ytol, gtol=gtol, **kwargs)
+        log.info("Embedding Stage:\nbegin %20.12f    end %20.12f" % (err_begin, err_end))
+    if MaxIter2 > 0:
+        log.info("Full lattice stage  max %d steps", MaxIter2)
+        vcor_new, err_begin2, err_end = FitVcorFull(GRho, lattice, basis, vcor_new, mu, MaxIter=MaxIter2, beta=beta, method=method,
+                                                    ytol=ytol, gtol=gtol)
+        log.info("Full Lattice Stage:\nbegin %20.12f    end %20.12f" % (err_begin2, err_end))
+        err_begin = err_begin2 if err_begin is None else err_begin
     log.result("residue (begin) = %20.12f", err_begin)
     log.result("residue (end)   = %20.12f", err_end)
     return vcor_new, err_end
+
+
+# ---- lattice stage of the BCS fit (routine/bcs.py:319-346, 532-562) --------------------------------------------------------
+
+def foldRho(GRho, Lat, basis, thr=1e-7):
+    """Generalised density stripe (ncells, 2 n, 2 n) into the Nambu embedding space (2 nbasis, 2 nbasis): sum_ij C_i^T GRho[i - j] C_j
+    with the canonical basis C (bcs.py:319-343).  The stripe of a density matrix is Hermitian, so the double sum runs in k space
+    on the device (slater_helper.transform_trans_inv); the reference's `thr` only skips blocks that are zero."""
+    from libdmet_preview_amd.routine import slater_helper
+    return slater_helper.transform_trans_inv(basisToCanonical(np.asarray(basis, dtype=np.float64)), Lat, np.asarray(GRho).real)   # noqa: F405
+
+
+def foldRho_k(GRho_k, basis_k):
+    from libdmet_preview_amd.routine import slater_helper
+    return slater_helper.transform_trans_inv_k(np.asarray(basis_k), np.asarray(GRho_k))
+
+
+def FitVcorFull(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=20, method='CG', ytol=1e-7, gtol=1e-2, **kwargs):
+    """Lattice stage of the BCS fit (bcs.py:532-562): every evaluation is a full HFB mean field of the lattice (mfd.HFB: BdG
+    matrices of all k on the device) folded into the Nambu embedding space; the gradient is numerical, as in the reference.  The
+    reference re-centres the fold on a reference density through the minimiser's callback -- the fold is linear, so the value is
+    the same and the callback is not needed here."""
+    from libdmet_preview_amd.routine import mfd
+    from libdmet_preview_amd.routine.fit import minimize
+    quiet = log.verbose
+
+    def errfunc(param, ref=None):
+        vcor.update(param)
+        log.verbose = "RESULT"
+        try:
+            GRhoT = mfd.HFB(lattice, vcor, False, mu=mu, beta=beta)[0]
+        finally:
+            log.verbose = quiet
+        return np.linalg.norm(foldRho(GRhoT, lattice, basis, thr=1e-8) - GRho) / np.sqrt(2.0)
+
+    err_begin = errfunc(vcor.param)
+    param, err_end, pattern, gnorm_res = minimize(errfunc, vcor.param, MaxIter, method=method, ytol=ytol, gtol=gtol, **kwargs)
+    vcor.update(param)
+    FitVcorFull.last_errfunc = errfunc
+    return vcor, err_begin, err_end

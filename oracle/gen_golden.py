@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1845,6 +1845,66 @@ def gen_G30():
     bcs.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G30_bcs_fit.npz"), **out)
     print("G30 done", len(out), "arrays")
+
+
+HFB_RUNS = [("t0", np.inf, dict()), ("t0_symm", np.inf, dict(symm=True)), ("ft", 8.0, dict()), ("ft_fix", 8.0, dict(fix_mu=True)),
+            ("ft_symm", 8.0, dict(symm=True)), ("t0_hcore", np.inf, dict(use_hcore=True))]
+
+
+def gen_G31():
+    """The Hartree-Fock-Bogoliubov lattice mean field, routine/mfd.py:480-590 HFB, on the Nambu lattices of G7 (normal Fock blocks of
+    both spins, a local potential with a pairing block, mu): generalised density in real space, particle number, energy, levels,
+    k-space density, gap -- T = 0 and finite T, with and without the +-k symmetry, fixed and fitted half-filling level, and
+    FitVcorFull of the BCS twin on top of it (routine/bcs.py:532-562: numerical gradient with the reference-density callback)."""
+    from types import SimpleNamespace
+    from libdmet.routine import mfd, bcs
+    from libdmet.dmet import Hubbard
+    g7, g30 = np.load(os.path.join(GOLD, "G7_bcs.npz")), np.load(os.path.join(GOLD, "G30_bcs_fit.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val)
+        FR, v, mu = g7[name + "/Fock_R"], g7[name + "/vcor"], float(g7[name + "/mu"])
+        L.fock_lo_R, L.hcore_lo_R = FR, 0.7 * FR
+        L.fock_lo_k, L.hcore_lo_k = synth.fold_R2k(FR, mesh), synth.fold_R2k(0.7 * FR, mesh)
+        L.H0, L.use_hcore_as_emb_ham = 0.3, False
+        vc = _Vcor(v)
+        for tag, beta, kw in HFB_RUNS:
+            GRhoT, npart, E, res = mfd.HFB(L, vc, False, mu=mu, beta=beta, ires=True, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/GRhoT"], out[key + "/n"], out[key + "/E"] = GRhoT, np.asarray(npart), np.asarray(E)
+            out[key + "/ew"], out[key + "/rho_k"] = res["e"], res["rho_k"]
+            out[key + "/edges"] = np.asarray([res["gap"], res["homo"], res["lumo"]])
+    # the lattice stage of the BCS fit on top of HFB (numerical gradient: a handful of iterations on the two small lattices)
+    captured = {}
+    real_minimize = bcs.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"] = fn
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    bcs.minimize = spy
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val)
+        L.is_model = True
+        L.cell = SimpleNamespace(max_memory=4000)
+        FR, mu = g7[name + "/Fock_R"], float(g7[name + "/mu"])
+        L.fock_lo_R = L.hcore_lo_R = FR
+        L.fock_lo_k = L.hcore_lo_k = synth.fold_R2k(FR, mesh)
+        L.H0, L.use_hcore_as_emb_ham = 0.0, False
+        basis, target = g7[name + "/basis_proj"], g30[name + "/target"]
+        out[name + "/foldRho"] = bcs.foldRho(g7[name + "/GRho"], L, basis)
+        out[name + "/foldRho_k"] = bcs.foldRho_k(g7[name + "/bdg_GRho_k"], np.asarray(bcs.basisToCanonical(basis)).astype(complex))
+        for tag, beta in (("t0", np.inf), ("ft", 8.0)):
+            v = Hubbard.VcorLocal(False, True, n)
+            v.update(0.05 * np.random.default_rng(7).standard_normal(v.length()))
+            p0 = np.array(v.param)
+            vfit, e0, e1 = bcs.FitVcorFull(target, L, basis, v, mu, beta=beta, MaxIter=3)
+            key = "%s/full_%s" % (name, tag)
+            out[key + "/p0"], out[key + "/param"], out[key + "/err"] = p0, np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((2, v.length()))
+            out[key + "/probe"], out[key + "/probe_err"] = P, np.asarray([captured["fn"](q.copy()) for q in P])
+    bcs.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G31_hfb.npz"), **out)
+    print("G31 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

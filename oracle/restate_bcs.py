@@ -438,3 +438,62 @@ def bcs_emb_fit(GRho, kmesh, basis, vcor, mu, beta, fock_R, mu0=0.0, fix_mu=True
     fit.tril = tl
     fit.target = np.array(GRho, copy=True)[None]
     return fit
+
+
+# ---------------------------------------------------------------------------------------------
+# Hartree-Fock-Bogoliubov lattice mean field (routine/mfd.py:480-590) and the lattice stage of the BCS fit (bcs.py:319-343, 532-562);
+# golden G31
+# ---------------------------------------------------------------------------------------------
+
+def HFB(kmesh, Fock_k, Fock_R, H1_R, vcor_mat, mu, H0=0.0, beta=np.inf, fix_mu=False, symm=False):
+    """Returns GRhoT, n, E, {"e", "rho_k", "gap", "homo", "lumo"}."""
+    from oracle.restate import FFTtoT, fermi_smearing_occ, find_mu
+    ew, ev = DiagBdG(Fock_k, vcor_mat, mu, kmesh=kmesh if symm else None)
+    ew_sorted = np.sort(ew, axis=None, kind='mergesort')
+    mu_ref = 0.0
+    if beta == np.inf:
+        occ = (ew < mu_ref).astype(float)
+    else:
+        if not fix_mu:
+            # find_mu_by_density(0.5, ...) = find_mu(0.5 norb, ..., tol = 1e-12 norb)  (ftsystem.py:107-113)
+            mu_ref = find_mu(0.5 * ew_sorted.size, ew_sorted, beta, mu0=mu_ref, tol=1e-12 * ew_sorted.size)
+        occ = fermi_smearing_occ(mu_ref, ew, beta)
+    GRho = np.einsum('kpm,km,kqm->kpq', ev, occ, ev.conj())
+    GRhoT = FFTtoT(GRho, kmesh)
+    n = Fock_R.shape[-1]
+    FT = Fock_R if Fock_R.ndim == 4 else np.asarray((Fock_R, Fock_R))
+    HT = H1_R if H1_R.ndim == 4 else np.asarray((H1_R, H1_R))
+    rA, rB, kBA = GRhoT[:, :n, :n].copy(), np.eye(n) - GRhoT[:, n:, n:], GRhoT[:, n:, :n].copy()
+    rB[1:] -= np.eye(n)
+    npart = np.trace(rA[0]) + np.trace(rB[0])
+    E = 0.5 * np.sum((FT[0] + HT[0]) * rA + (FT[1] + HT[1]) * rB) + H0
+    E += 0.5 * np.sum(vcor_mat[0] * rA[0] + vcor_mat[1] * rB[0] + 2 * vcor_mat[2] * kBA[0])
+    homo = ew_sorted[max(np.searchsorted(ew_sorted, mu_ref, side='right') - 1, 0)]
+    lumo = ew_sorted[min(np.searchsorted(ew_sorted, mu_ref, side='left'), len(ew_sorted) - 1)]
+    return GRhoT, npart, E, {"e": ew, "rho_k": GRho, "gap": lumo - homo, "homo": homo, "lumo": lumo}
+
+
+def foldRho_bcs(GRho, kmesh, basis):
+    """bcs.py:319-343: sum_{ij} C_i^T GRho[i - j] C_j with the canonical basis C (ncells, 2 n, 2 nbasis)."""
+    from oracle.restate import cartesian_prod
+    cells = [tuple(c) for c in cartesian_prod([np.arange(x) for x in kmesh])]
+    where = dict((tuple(c), i) for i, c in enumerate(cells))
+    n, nb = basis.shape[2] // 2, basis.shape[-1]
+    C = np.empty((len(cells), 2 * n, 2 * nb))
+    C[:, :, :nb] = basis[0]
+    C[:, :n, nb:], C[:, n:, nb:] = basis[1, :, n:], basis[1, :, :n]
+    res = np.zeros((2 * nb, 2 * nb))
+    size = np.asarray(kmesh)
+    for i, ci in enumerate(cells):
+        for j, cj in enumerate(cells):
+            res += C[i].T @ GRho[where[tuple((np.asarray(ci) - np.asarray(cj)) % size)]] @ C[j]
+    return res
+
+
+def bcs_full_errfunc(GRho_target, kmesh, basis, vcor, mu, beta, Fock_k, Fock_R):
+    """errfunc of bcs.FitVcorFull without a reference point (bcs.py:545-554)."""
+    def errfunc(param):
+        vcor.update(param)
+        GRhoT = HFB(kmesh, Fock_k, Fock_R, Fock_R, vcor.get(), mu, beta=beta)[0]
+        return la.norm(foldRho_bcs(GRhoT, kmesh, basis) - GRho_target) / np.sqrt(2.0)
+    return errfunc

@@ -368,6 +368,68 @@ def test_bcs_vcor_fit(ctx, golden, name, n):
     v.update(np.zeros(v.length()))
     vnew, err = bcs.FitVcorTwoStep(target, L, basis, v, mu, beta=np.inf, MaxIter1=25, MaxIter2=0)
     assert vnew is not v and np.abs(np.asarray(v.param)).max() == 0.0 and abs(err - g[name + "/u_t0/err"][1]) < 1e-6
-    for kw in (dict(MaxIter2=2), dict(kinetic=True)):
-        with pytest.raises(NotImplementedError):
-            bcs.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, **kw)
+    with pytest.raises(NotImplementedError):
+        bcs.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, kinetic=True)
+
+
+@pytest.mark.parametrize("name", ["c611", "c441", "c222"])
+def test_hfb_mean_field(ctx, golden, name):
+    """mfd.HFB (routine/mfd.py:480-590) against the reference (golden G31): generalised density, particle number, energy, levels,
+    k-space density and band edges at T = 0 and finite T, with and without the +-k symmetry, fixed / fitted half-filling level,
+    Fock or hcore."""
+    from libdmet_preview_amd.routine import mfd
+    from tests.test_oracle_bcs import HFB_RUNS
+    g, g7 = golden("G31_hfb.npz"), golden("G7_bcs.npz")
+    mesh = tuple(int(x) for x in g7[name + "/mesh"])
+    FR, v, mu = g7[name + "/Fock_R"], g7[name + "/vcor"], float(g7[name + "/mu"])
+    n = FR.shape[-1]
+    L = _lattice(mesh, n, [int(x) for x in g7[name + "/val"]])
+    L.set_Ham_lo(fock_lo_R=FR, hcore_lo_R=0.7 * FR)
+    L.H0 = 0.3
+    vc = _Vcor(v)
+    vc.islocal = lambda: True
+    for tag, beta, kw in HFB_RUNS:
+        GT, npart, E, res = mfd.HFB(L, vc, False, mu=mu, beta=beta, ires=True, **kw)
+        key = "%s/%s" % (name, tag)
+        assert np.abs(res["e"] - g[key + "/ew"]).max() < 1e-11
+        assert np.abs(GT - g[key + "/GRhoT"]).max() < 1e-10 and np.abs(res["rho_k"] - g[key + "/rho_k"]).max() < 1e-10
+        assert abs(npart - float(g[key + "/n"])) < 1e-10 and abs(E - float(g[key + "/E"])) < 1e-9
+        assert np.abs(np.asarray([res["gap"], res["homo"], res["lumo"]]) - g[key + "/edges"]).max() < 1e-11
+        for k in range(GT.shape[0]):                       # eigenpairs through their residual, never raw vectors
+            ev, ew = res["coef"][k], res["e"][k]
+            assert np.abs(ev.conj().T @ ev - np.eye(2 * n)).max() < 1e-10
+        out3 = mfd.HFB(L, vc, False, mu=mu, beta=beta, **kw)
+        assert len(out3) == 3 and np.array_equal(out3[0], GT)
+    with pytest.raises(Exception):
+        mfd.HFB(L, vc, True, mu=mu)
+
+
+@pytest.mark.parametrize("name,n", [("c611", 2), ("c441", 4)])
+def test_bcs_lattice_stage_fit(ctx, golden, name, n):
+    """bcs.foldRho / FitVcorFull (routine/bcs.py:319-343, 532-562): the reference's objective at fixed parameters and its
+    numerical-gradient fits (golden G31); the two-step wrapper with both stages."""
+    from libdmet_preview_amd.routine import bcs
+    from libdmet_preview_amd.dmet import Hubbard
+    g, g7, g30 = golden("G31_hfb.npz"), golden("G7_bcs.npz"), golden("G30_bcs_fit.npz")
+    mesh = tuple(int(x) for x in g7[name + "/mesh"])
+    FR, mu, basis = g7[name + "/Fock_R"], float(g7[name + "/mu"]), g7[name + "/basis_proj"]
+    L = _lattice(mesh, n, [int(x) for x in g7[name + "/val"]])
+    L.set_Ham_lo(fock_lo_R=FR, hcore_lo_R=FR)
+    assert np.abs(bcs.foldRho(g7[name + "/GRho"], L, basis) - g[name + "/foldRho"]).max() < 1e-11
+    from libdmet_preview_amd.routine.bcs_helper import basisToCanonical
+    assert np.abs(bcs.foldRho_k(g7[name + "/bdg_GRho_k"], basisToCanonical(basis).astype(complex)) - g[name + "/foldRho_k"]).max() < 1e-11
+    target = g30[name + "/target"]
+    for tag, beta in (("t0", np.inf), ("ft", 8.0)):
+        key = "%s/full_%s" % (name, tag)
+        v = Hubbard.VcorLocal(False, True, n)
+        v.update(np.array(g[key + "/p0"]))
+        vfit, e0, e1 = bcs.FitVcorFull(target, L, basis, v, mu, beta=beta, MaxIter=3)
+        ef = bcs.FitVcorFull.last_errfunc
+        for p, e in zip(g[key + "/probe"], g[key + "/probe_err"]):
+            assert abs(ef(p) - e) < 1e-10
+        r0, r1 = g[key + "/err"]
+        assert abs(e0 - r0) < 1e-10 and abs(e1 - r1) < 1e-5 and e1 <= e0, (key, e0, e1, r0, r1)
+    v = Hubbard.VcorLocal(False, True, n)
+    v.update(np.zeros(v.length()))
+    vnew, err = bcs.FitVcorTwoStep(target, L, basis, v, mu, beta=np.inf, MaxIter1=10, MaxIter2=1)
+    assert vnew is not v and err <= g30[name + "/u_t0/err"][0]

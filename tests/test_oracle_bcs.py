@@ -197,3 +197,40 @@ def test_G30_bcs_fit_objective_and_gradient(golden, name, n):
                 assert np.abs(grad(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
             pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
             assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
+
+
+# ---- round 6: Hartree-Fock-Bogoliubov mean field and the lattice stage of the BCS fit (golden G31) ---------------------------
+
+HFB_RUNS = [("t0", np.inf, dict()), ("t0_symm", np.inf, dict(symm=True)), ("ft", 8.0, dict()), ("ft_fix", 8.0, dict(fix_mu=True)),
+            ("ft_symm", 8.0, dict(symm=True)), ("t0_hcore", np.inf, dict(use_hcore=True))]
+
+
+@pytest.mark.parametrize("name", ["c611", "c441", "c222"])
+def test_G31_hfb(golden, name):
+    g, g7 = golden("G31_hfb.npz"), golden("G7_bcs.npz")
+    mesh = tuple(int(x) for x in g7[name + "/mesh"])
+    FR, v, mu = g7[name + "/Fock_R"], g7[name + "/vcor"], float(g7[name + "/mu"])
+    Fk = R.R2k(FR, mesh)
+    for tag, beta, kw in HFB_RUNS:
+        kw = dict(kw)
+        f = 0.7 if kw.pop("use_hcore", False) else 1.0
+        GT, n, E, res = B.HFB(mesh, f * Fk, f * FR, 0.7 * FR, v, mu, H0=0.3, beta=beta, **kw)
+        key = "%s/%s" % (name, tag)
+        assert np.abs(GT - g[key + "/GRhoT"]).max() < 1e-12 and abs(n - float(g[key + "/n"])) < 1e-12 and abs(E - float(g[key + "/E"])) < 1e-12
+        assert np.abs(res["e"] - g[key + "/ew"]).max() < 1e-12
+        assert np.abs(np.asarray([res["gap"], res["homo"], res["lumo"]]) - g[key + "/edges"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("name,n", [("c611", 2), ("c441", 4)])
+def test_G31_bcs_full_fit_objective(golden, name, n):
+    from oracle import restate_fit as F
+    g, g7, g30 = golden("G31_hfb.npz"), golden("G7_bcs.npz"), golden("G30_bcs_fit.npz")
+    mesh = tuple(int(x) for x in g7[name + "/mesh"])
+    FR, mu, basis = g7[name + "/Fock_R"], float(g7[name + "/mu"]), g7[name + "/basis_proj"]
+    assert np.abs(B.foldRho_bcs(g7[name + "/GRho"], mesh, basis) - g[name + "/foldRho"]).max() < 1e-12
+    for tag, beta in (("t0", np.inf), ("ft", 8.0)):
+        ef = B.bcs_full_errfunc(g30[name + "/target"], mesh, basis, F.VcorLocal(False, True, n), mu, beta, R.R2k(FR, mesh), FR)
+        key = "%s/full_%s" % (name, tag)
+        for p, e in zip(g[key + "/probe"], g[key + "/probe_err"]):
+            assert abs(ef(p) - e) < 1e-12
+        assert abs(ef(g[key + "/p0"]) - g[key + "/err"][0]) < 1e-12 and abs(ef(g[key + "/param"]) - g[key + "/err"][1]) < 1e-11
