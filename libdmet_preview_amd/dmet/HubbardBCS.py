@@ -1,0 +1,65 @@
+"""
+The BCS driver layer in front of the impurity solver, mirror of libdmet/dmet/HubbardBCS.py:9-112: the lattice mean field with its
+chemical-potential search (HartreeFockBogoliubov over mfd.HFB), the impurity problem (ConstructImpHam: bcs.embBasis, the alpha /
+beta bath matching of HubPhSymm, bcs.embHam) and the chemical-potential shift on the impurity (apply_dmu).  Thin host wrappers:
+every array operation underneath runs on the device.
+"""
+import numpy as np
+
+from libdmet_preview_amd.dmet.HubPhSymm import basisMatching
+from libdmet_preview_amd.routine import bcs
+from libdmet_preview_amd.routine.bcs_helper import extractRdm, mono_fit, transform_imp
+from libdmet_preview_amd.routine.mfd import HFB
+from libdmet_preview_amd.utils import logger as log
+
+
+def HartreeFockBogoliubov(Lat, v, filling, mu0, beta=np.inf, fix_mu=False, thrnelec=1e-6, **kwargs):
+    """HFB with the particle chemical potential fitted so that the density per spin orbital is `filling` (None: `mu0` is used as
+    is); `fix_mu` keeps the quasiparticle level at 0.  Returns (GRho, mu) or, with `full_return`, (GRho, mu, res)."""
+    if beta == np.inf:
+        log.info("Using 0 T on lattice, beta = %s", beta)
+    else:
+        log.info("Using finite T on lattice, beta = %15.6f ", beta)
+        log.info("Using fixed quasi particle fermi_level = 0.0 ? %s", fix_mu)
+    if filling is None:
+        mu = mu0
+    else:
+        log.info("chemical potential fitting, target = %20.12f", filling)
+        log.info("before fitting, mu = %20.12f", mu0)
+        density = lambda x: HFB(Lat, v, False, mu=x, beta=beta, fix_mu=fix_mu, ires=False, **kwargs)[1] / 2. / Lat.nscsites
+        mu = mono_fit(density, filling, mu0, thrnelec, increase=True)
+        log.info("after fitting, mu = %20.12f", mu)
+        log.info("after fitting, f(x) = %20.12f", density(mu))
+    rho, n, E, res = HFB(Lat, v, False, mu=mu, beta=beta, fix_mu=fix_mu, ires=True, **kwargs)
+    if filling is None:
+        rhoA, rhoB, kappaBA = extractRdm(rho[0])
+        log.result("Local density matrix (mean-field): alpha, beta and pairing\n%s\n%s\n%s", rhoA, rhoB, kappaBA.T)
+        log.result("nelec per cell (mean-field) = %20.12f", n)
+        log.result("Energy per cell (mean-field) = %20.12f", E)
+        log.result("Gap (mean-field) = %20.12f" % res["gap"])
+    return (rho, mu, res) if kwargs.get("full_return", False) else (rho, mu)
+
+
+def ConstructImpHam(Lat, GRho, v, mu, matching=True, local=True, **kwargs):
+    """(ImpHam, (H1 for the energy, its H0), basis): bath, optional alpha / beta matching of the bath columns, Hamiltonian."""
+    log.result("Making embedding basis")
+    basis = bcs.embBasis(Lat, GRho, local=local, **kwargs)
+    if matching:
+        log.result("Rotate bath orbitals to match alpha and beta basis")
+        nbasis = basis.shape[-1]
+        if local:
+            basis[:, :, :, nbasis // 2:] = basisMatching(basis[:, :, :, nbasis // 2:])
+        else:
+            basis = basisMatching(basis)
+    log.result("Constructing impurity Hamiltonian")
+    ImpHam, (H1e, H0e) = bcs.embHam(Lat, basis, v, mu, local=local, **kwargs)
+    return ImpHam, (H1e, H0e), basis
+
+
+def apply_dmu(lattice, ImpHam, basis, dmu):
+    """Shift the chemical potential on the impurity orbitals of an embedding Hamiltonian by `dmu`."""
+    cd, cc, h0 = transform_imp(basis, lattice, dmu * np.eye(lattice.nscsites))
+    ImpHam.H1["cd"] -= cd
+    ImpHam.H1["cc"] -= cc
+    ImpHam.H0 -= h0
+    return ImpHam

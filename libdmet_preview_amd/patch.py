@@ -80,6 +80,9 @@ _FUNCTIONS = [
     # HartreeFock wrapper (:14-41) and FitVcor (:1503) itself
     ("dmet.HubPhSymm", ["dmet.HubPhSymm", "dmet.Hubbard"], ["ConstructImpHam"]),
     ("dmet.Hubbard", ["dmet.Hubbard"], ["HartreeFock", "RHartreeFock", "FitVcor"]),
+    # the BCS driver layer (dmet/HubbardBCS.py:9-112) and the root search under its chemical-potential fit
+    ("dmet.HubbardBCS", ["dmet.HubbardBCS"], ["HartreeFockBogoliubov", "ConstructImpHam", "apply_dmu"]),
+    ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs", "dmet.HubbardBCS"], ["mono_fit"]),
     # Loewdin orthogonalisation (routine/slater.py imports lo.lowdin's vec_lowdin by name)
     ("lo.lowdin", ["lo.lowdin"], ["_lowdin", "_vec_lowdin", "vec_lowdin", "vec_lowdin_k"]),
     ("lo.lowdin", ["routine.slater"], ["vec_lowdin"]),

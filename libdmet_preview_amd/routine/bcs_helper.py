@@ -253,3 +253,52 @@ def get_dV_dparam(basis, lattice, vcor):
     dV_dp[:, :nbasis, :nbasis], dV_dp[:, nbasis:, nbasis:] = dA[:nparam], -dB[:nparam]
     dV_dp[:, :nbasis, nbasis:], dV_dp[:, nbasis:, :nbasis] = dD[:nparam], dD[:nparam].transpose(0, 2, 1)
     return dV_dp
+
+
+# ---------------------------------------------------------------------------------------------
+# root of a monotonic function (bcs_helper.py:72-129): the chemical-potential search of the BCS mean field
+# ---------------------------------------------------------------------------------------------
+
+def mono_fit(fn, y0, x0, thr, increase=True, dx=1.0, verbose=True):
+    """x with |fn(x) - y0| < thr for a monotonic fn: unit steps from x0 until the target is bracketed, then false position with the
+    split clamped to [0.2, 0.8] of the bracket.  The sequence of evaluation points is the reference's (the fitted value is carried
+    from one DMET iteration to the next)."""
+    if not increase:
+        return mono_fit(lambda x: -fn(x), -y0, x0, thr, True)
+    calls = [0]
+
+    def evaluate(x):
+        y = fn(x)
+        if verbose:
+            log.debug(1, "Iter %2d, x = %20.12f, f(x) = %20.12f", calls[0], x, y)
+        calls[0] += 1
+        return y
+
+    if verbose:
+        log.debug(0, "target f(x) = %20.12f", y0)
+    hit = lambda y: abs(y - y0) < thr
+    lo_x, lo_y = x0, evaluate(x0)
+    if hit(lo_y):
+        return lo_x
+    step = -dx if lo_y > y0 else dx
+    while True:                                                  # walk until the target lies between two consecutive points
+        hi_x = lo_x + step
+        hi_y = evaluate(hi_x)
+        if hit(hi_y):
+            return hi_x
+        if (lo_y - y0) * (hi_y - y0) < 0:
+            break
+        lo_x, lo_y = hi_x, hi_y
+    if lo_x > hi_x:
+        lo_x, lo_y, hi_x, hi_y = hi_x, hi_y, lo_x, lo_y
+    while hi_x - lo_x > 0.1 * thr:
+        frac = min(max((y0 - lo_y) / (hi_y - lo_y), 0.2), 0.8)
+        mid_x = lo_x * (1. - frac) + hi_x * frac
+        mid_y = evaluate(mid_x)
+        if hit(mid_y):
+            return mid_x
+        if (mid_y - y0) * (lo_y - y0) < 0:
+            hi_x, hi_y = mid_x, mid_y
+        else:
+            lo_x, lo_y = mid_x, mid_y
+    return 0.5 * (lo_x + hi_x)

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1905,6 +1905,51 @@ def gen_G31():
     bcs.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G31_hfb.npz"), **out)
     print("G31 done", len(out), "arrays")
+
+
+def gen_G32():
+    """The BCS driver layer in front of the impurity solver, dmet/HubbardBCS.py:9-112: HartreeFockBogoliubov (chemical potential
+    fitted to a filling by bcs_helper.mono_fit over mfd.HFB), ConstructImpHam (bath, alpha / beta matching, Hamiltonian) and
+    apply_dmu, on the model lattices of G28."""
+    from types import SimpleNamespace
+    from libdmet.dmet import HubbardBCS as HB
+    from libdmet.routine import bcs_helper as bh
+    g7, g28 = np.load(os.path.join(GOLD, "G7_bcs.npz")), np.load(os.path.join(GOLD, "G28_bcs_embham.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val)
+        L.is_model, L.H2_format, L.eri_symmetry = True, "local", 1
+        L.cell = SimpleNamespace(max_memory=4000)
+        FR, v = g7[name + "/Fock_R"], g7[name + "/vcor"]
+        L.fock_lo_R = L.hcore_lo_R = FR
+        L.fock_lo_k = L.hcore_lo_k = synth.fold_R2k(FR, mesh)
+        L.JK_imp, L.Ham, L.H0, L.use_hcore_as_emb_ham = None, None, 0.0, True
+        LatH2 = g28[name + "/LatH2"]
+        L.getH2 = lambda compact=False, kspace=False, _h=LatH2: _h
+        vc = _Vcor(v)
+        for tag, filling, beta, kw in (("fit_t0", 0.4, np.inf, dict()), ("fit_ft", 0.55, 10.0, dict(fix_mu=True)), ("nofit", None, np.inf, dict())):
+            rho, mu, res = HB.HartreeFockBogoliubov(L, vc, filling, 0.2, beta=beta, full_return=True, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/GRho"], out[key + "/mu"], out[key + "/E"], out[key + "/ew"] = rho, np.asarray(mu), np.asarray(res["E"]), res["e"]
+        GRho = out[name + "/fit_t0/GRho"]
+        mu = float(out[name + "/fit_t0/mu"])
+        for tag, matching in (("match", True), ("nomatch", False)):
+            ImpHam, (H1e, H0e), basis = HB.ConstructImpHam(L, GRho, vc, mu, matching=matching)
+            key = "%s/imp_%s" % (name, tag)
+            out[key + "/basis"], out[key + "/cd"], out[key + "/cc"] = basis, ImpHam.H1["cd"].copy(), ImpHam.H1["cc"].copy()    # (apply_dmu works in place)
+            out[key + "/H0"] = np.asarray(ImpHam.H0).copy()
+            out[key + "/ecd"], out[key + "/ecc"], out[key + "/eH0"] = H1e["cd"], H1e["cc"], np.asarray(H0e)
+            if matching:
+                ImpHam = HB.apply_dmu(L, ImpHam, basis, 0.13)
+                out[key + "/dmu_cd"], out[key + "/dmu_cc"], out[key + "/dmu_H0"] = ImpHam.H1["cd"], ImpHam.H1["cc"], np.asarray(ImpHam.H0)
+    # mono_fit on its own: iterates are part of the contract (the fitted mu is what the reference prints and restarts from)
+    for tag, fn, y0, x0, thr, inc in (("cubic", lambda x: x ** 3 + x, 2.5, 0.0, 1e-9, True), ("tanh", lambda x: np.tanh(0.3 * x), -0.7, 1.0, 1e-7, True),
+                                      ("dec", lambda x: -np.arctan(x), 0.4, 3.0, 1e-8, False)):
+        trace = []
+        out["mono/" + tag] = np.asarray(bh.mono_fit(lambda x: (trace.append(x), fn(x))[1], y0, x0, thr, increase=inc))
+        out["mono/" + tag + "_trace"] = np.asarray(trace)
+    np.savez_compressed(os.path.join(GOLD, "G32_bcs_driver.npz"), **out)
+    print("G32 done", len(out), "arrays")
 
 
 if __name__ == "__main__":
