@@ -1,0 +1,67 @@
+"""
+The GSO (generalised spin orbital) driver layer in front of the impurity solver, mirror of libdmet/dmet/HubbardGSO.py:16-134: the
+lattice mean field with its chemical-potential search (GHartreeFock over mfd.GHF, bracketing + Brent), the impurity problem
+(ConstructImpHam: spinless bath and Hamiltonian) and the chemical-potential shift on the impurity (apply_dmu).  Thin host
+wrappers over device routines.
+"""
+import numpy as np
+
+from libdmet_preview_amd.routine import spinless
+from libdmet_preview_amd.routine.bcs_helper import extractRdm
+from libdmet_preview_amd.routine.mfd import GHF
+from libdmet_preview_amd.routine.spinless_helper import mono_fit_2, separate_basis, transform_imp, transform_local
+from libdmet_preview_amd.utils import logger as log
+
+
+def GHartreeFock(Lat, v, filling, mu0_elec, beta=np.inf, fix_mu=False, thrnelec=1e-8, **kwargs):
+    """GHF with the particle chemical potential fitted so that the density per spin orbital is `filling` (None: `mu0_elec` is used
+    as is).  Returns (GRho, mu) or, with `full_return`, (GRho, mu, res)."""
+    if beta == np.inf:
+        log.info("Using 0 T on lattice, beta = %s", beta)
+    else:
+        log.info("Using finite T on lattice, beta = %15.6f ", beta)
+        log.info("Using fixed quasi particle fermi_level = 0.0 ? %s", fix_mu)
+    if filling is None:
+        mu = mu0_elec
+    else:
+        log.info("chemical potential fitting, target = %20.12f", filling)
+        log.info("before fitting, mu = %20.12f", mu0_elec)
+        density = lambda x: GHF(Lat, v, False, mu=x, beta=beta, fix_mu=fix_mu, ires=False, **kwargs)[1] / (Lat.nscsites * 2.0)
+        mu = mono_fit_2(density, filling, mu0_elec, thrnelec, increase=True)
+        log.info("after fitting, mu = %20.12f", mu)
+        log.info("after fitting, f(x) = %20.12f", density(mu))
+    rho, n, E, res = GHF(Lat, v, False, mu=mu, beta=beta, fix_mu=fix_mu, ires=True, **kwargs)
+    if filling is None:
+        rhoA, rhoB, kappaAB = extractRdm(rho[0])
+        log.result("Local density matrix (mean-field): alpha, beta and pairing\n%s\n%s\n%s", rhoA, rhoB, kappaAB)
+        log.result("nelec per cell (mean-field) = %20.12f", n)
+        log.result("Energy per cell (mean-field) = %20.12f", E)
+        log.result("Gap (mean-field) = %20.12f" % res["gap"])
+    return (rho, mu, res) if kwargs.get("full_return", False) else (rho, mu)
+
+
+def ConstructImpHam(Lat, GRho, v, mu, matching=True, local=True, **kwargs):
+    """(ImpHam, None, basis)."""
+    log.result("Making embedding basis")
+    basis = spinless.embBasis(Lat, GRho, local=local, **kwargs)
+    log.result("Constructing impurity Hamiltonian")
+    ImpHam, _ = spinless.embHam(Lat, basis, v, mu, local=local, **kwargs)
+    return ImpHam, None, basis
+
+
+def apply_dmu(lattice, ImpHam, basis, dmu, fit_ghf=False, **kwargs):
+    """Shift the chemical potential by `dmu` (-dmu on the particle block, +dmu on the hole block): on the impurity orbitals `dmu_idx`
+    (default: all of them) of cell 0, or -- `fit_ghf`, used when the particle number is fitted in the embedding space -- on every
+    cell."""
+    basis_Ra, basis_Rb = separate_basis(np.asarray(basis))
+    if fit_ghf:
+        nao = basis_Ra.shape[-2]
+        mu_mat = np.asarray([-dmu * np.eye(nao), dmu * np.eye(nao)])
+        ImpHam.H1["cd"] += transform_local(basis_Ra, basis_Rb, mu_mat)
+    else:
+        nao = lattice.nao
+        idx = kwargs.get("dmu_idx", lattice.imp_idx)
+        mu_mat = np.zeros((2, nao, nao))
+        mu_mat[0][idx, idx], mu_mat[1][idx, idx] = -dmu, dmu
+        ImpHam.H1["cd"] += transform_imp(basis_Ra, basis_Rb, mu_mat)
+    return ImpHam

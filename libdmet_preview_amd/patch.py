@@ -83,6 +83,9 @@ _FUNCTIONS = [
     # the BCS driver layer (dmet/HubbardBCS.py:9-112) and the root search under its chemical-potential fit
     ("dmet.HubbardBCS", ["dmet.HubbardBCS"], ["HartreeFockBogoliubov", "ConstructImpHam", "apply_dmu"]),
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs", "dmet.HubbardBCS"], ["mono_fit"]),
+    # the GSO driver layer (dmet/HubbardGSO.py:16-134); mono_fit / mono_fit_2 reach it through spinless_helper's star import
+    ("dmet.HubbardGSO", ["dmet.HubbardGSO"], ["GHartreeFock", "ConstructImpHam", "apply_dmu"]),
+    ("routine.bcs_helper", ["routine.bcs_helper", "routine.spinless_helper", "dmet.HubbardGSO"], ["mono_fit_2"]),
     # Loewdin orthogonalisation (routine/slater.py imports lo.lowdin's vec_lowdin by name)
     ("lo.lowdin", ["lo.lowdin"], ["_lowdin", "_vec_lowdin", "vec_lowdin", "vec_lowdin_k"]),
     ("lo.lowdin", ["routine.slater"], ["vec_lowdin"]),
@@ -93,6 +96,8 @@ _LATTICE_METHODS = ["set_Ham", "setHam", "set_Ham_model", "setHam_model", "updat
 _HF_HOLDERS = ["routine.mfd", "dmet.HubPhSymm", "dmet.Hubbard"]
 # HFB: routine/bcs.py:15 and dmet/HubbardBCS.py:6 import it by name
 _HFB_HOLDERS = ["routine.mfd", "routine.bcs", "dmet.HubbardBCS"]
+# GHF: dmet/HubbardGSO.py imports it by name
+_GHF_HOLDERS = ["routine.mfd", "dmet.HubbardGSO"]
 
 
 def binding_table():
@@ -106,6 +111,8 @@ def binding_table():
         out.append(("routine.mfd", r, "HF"))
     for r in _HFB_HOLDERS:
         out.append(("routine.mfd", r, "HFB"))
+    for r in _GHF_HOLDERS:
+        out.append(("routine.mfd", r, "GHF"))
     return out
 
 
@@ -125,7 +132,7 @@ def install(reference_package="libdmet", replace_hf=True, strict=True, resident_
         setattr(ref_mod, name, value)
 
     for ours, ref, name in binding_table():
-        if name in ("HF", "HFB") and not replace_hf:
+        if name in ("HF", "HFB", "GHF") and not replace_hf:
             continue
         mine = importlib.import_module("libdmet_preview_amd." + ours)
         bind(importlib.import_module(reference_package + "." + ref), name, getattr(mine, name))

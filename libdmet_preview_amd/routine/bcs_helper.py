@@ -302,3 +302,31 @@ def mono_fit(fn, y0, x0, thr, increase=True, dx=1.0, verbose=True):
         else:
             lo_x, lo_y = mid_x, mid_y
     return 0.5 * (lo_x + hi_x)
+
+
+def mono_fit_2(fn, y0, x0, thr, increase=True, dx=1.0, verbose=True, maxiter=1000):
+    """mono_fit with Brent's method on the bracket (bcs_helper.py:131-174); a decreasing function goes to mono_fit like in the reference."""
+    from scipy.optimize import brentq
+    if not increase:
+        return mono_fit(lambda x: -fn(x), -y0, x0, thr, True)
+    if verbose:
+        log.debug(0, "target f(x) = %20.12f", y0)
+    lo_x, lo_y = x0, fn(x0)
+    if abs(lo_y - y0) < thr:
+        return lo_x
+    step = -dx if lo_y > y0 else dx
+    for _ in range(maxiter * 50):
+        hi_x = lo_x + step
+        hi_y = fn(hi_x)
+        if abs(hi_y - y0) < thr:
+            return hi_x
+        if (lo_y - y0) * (hi_y - y0) < 0:
+            break
+        lo_x, lo_y = hi_x, hi_y
+    else:
+        raise RuntimeError("Cannot find the section.")
+    left, right = min(lo_x, hi_x), max(lo_x, hi_x)
+    root, info = brentq(lambda x: fn(x) - y0, left, right, xtol=thr, rtol=thr, maxiter=maxiter, full_output=True, disp=False)
+    if not info.converged:
+        log.warn("mono_fit_2: brentq fails. x: %s, y: %s", root, fn(root) - y0)
+    return root

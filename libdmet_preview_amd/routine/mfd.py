@@ -342,6 +342,123 @@ def HFB(lattice, vcor, restricted, mu=0.0, beta=np.inf, fix_mu=False, ires=False
     return GRhoT, npart, E, res
 
 
+
+def H_k2GH_k(H_k):
+    """(3, nkpts, nao, nao) blocks (aa, bb, ab) -> generalised (nkpts, 2 nao, 2 nao), ba = ab^H (pbc_helper.py:1019-1041)."""
+    from libdmet_preview_amd.routine.spinless_helper import spin_orbital_matrix
+    H_k = np.asarray(H_k)
+    log.eassert(H_k.ndim == 4 and H_k.shape[0] == 3, "H_k2GH_k: (3, nkpts, nao, nao) expected, got %s", H_k.shape)
+    return spin_orbital_matrix(H_k)
+
+
+combine_H_k = combine_H1_k = H_k2GH_k
+
+
+def transform_H1_k(H1, compact=True):
+    """Particle-hole form of a k-space one-body operator in an orthonormal basis (pbc_helper.py:1239-1297 without overlap / C_ao_lo):
+    (HA, -HB, HD) and the constant (1/nk) sum_k tr HB_k."""
+    H1 = np.asarray(H1)
+    if H1.ndim == 3:
+        HA = HB = H1
+        HD = np.zeros_like(H1)
+    elif H1.shape[0] == 1:
+        HA = HB = H1[0]
+        HD = np.zeros_like(H1[0])
+    elif H1.shape[0] == 2:
+        HA, HB, HD = H1[0], H1[1], np.zeros_like(H1[0])
+    else:
+        HA, HB, HD = H1
+    nk = HA.shape[0]
+    GH0 = np.einsum('kii->', HB)
+    if abs(GH0.imag) > IMAG_DISCARD_TOL:
+        log.warn("transform_H1_k: GH0 has imaginary part: %s", GH0.imag)
+    GH1 = np.asarray([HA, -HB, HD])
+    return (GH1 if compact else H_k2GH_k(GH1)), GH0.real / float(nk)
+
+
+def GHF(lattice, vcor, restricted, filling=0.5, mu=0.0, mu0=None, beta=np.inf, ires=False, scf=False, use_hcore=None, ph_trans=False,
+        **kwargs):
+    """Generalised (spin-orbital / partial particle-hole) Hartree-Fock mean field of the lattice (mfd.py:735-858): the Fock triple
+    (aa, bb, ab) is assembled into one 2 nao matrix per k, diagonalised on the device with vcor and -mu / +mu as the shared shift
+    (`symm`, default True: one member of every +-k pair; `use_mpi`: the k pairs of this rank, mfd_mpi), filled to `filling` of all
+    levels, and the generalised density is formed from the resident eigenvectors and folded to real space.  Returns GRhoT
+    (ncells, 2 nao, 2 nao), the particle number of cell 0, the energy per cell and, with `ires`, the reference's result dict."""
+    from libdmet_preview_amd.routine.spinless_helper import spin_orbital_matrix
+    from libdmet_preview_amd.routine.bcs_helper import extractRdm
+    log.eassert(beta >= 0, "beta cannot be negative")
+    if scf:
+        raise NotImplementedError("scf=True needs a PySCF KGHF object (out of scope of the HIP path)")
+    if use_hcore is None:
+        use_hcore = lattice.use_hcore_as_emb_ham
+    H1 = np.asarray(lattice.getH1(kspace=True))
+    Fock = H1 if use_hcore else np.asarray(lattice.getFock(kspace=True))
+    nkpts, nao = lattice.nkpts, lattice.nao
+    if H1.shape[-1] == nao and ph_trans:
+        H1, h0_a = transform_H1_k(H1)
+        Fock, h0_b = transform_H1_k(Fock)
+        GH0 = (h0_a + h0_b) * 0.5 + lattice.getH0()
+    else:
+        GH0 = lattice.getH0()
+    if restricted:
+        log.error("restricted GHF not implemented")
+        raise NotImplementedError("restricted GHF")
+    GFock = H_k2GH_k(Fock)
+    ctx = get_ctx()
+    m = 2 * nao
+    if kwargs.get("use_mpi", False):
+        from libdmet_preview_amd.routine import mfd_mpi
+        kpairs, kidx = mfd_mpi.get_kpairs_kidx(lattice.cell, lattice.kpts)
+        ew, ev = mfd_mpi.DiagGHF_symm(lattice.cell, GFock, vcor.get(0, True), mu, kpairs=kpairs, kidx=kidx)
+        d_Vt = ctx.to_device(np.ascontiguousarray(np.swapaxes(ev, -1, -2)), np.complex128)
+        ew_rep, src, inherits = ew, np.arange(nkpts), np.zeros(nkpts, dtype=bool)
+    else:
+        ew_rep, d_Vt, src, inherits = _diag_with_shift(GFock, _ghf_shift(vcor, nao, mu),
+                                                      symm_lattice=lattice if kwargs.get("symm", True) else None, keep_device=True)
+        ew = ew_rep[src]
+    nrep = len(ew_rep)
+    v = np.asarray(vcor.get(0, True))
+    GFock = GFock + spin_orbital_matrix(np.asarray([v[0], v[1], v[2]]))[None]     # with vcor, without mu: the energy reads it
+    GH1 = H_k2GH_k(H1)
+    # ---- occupations (mfd.py:800-821) -------------------------------------------------------------------------------------
+    nelec = check_nelec(ew.size * filling, None)[0]
+    ew_sorted = np.sort(ew, axis=None, kind='mergesort')
+    nfrac = kwargs.get("nfrac", None)
+    ncore, nvirt = (0, 0) if nfrac is None else (nelec - nfrac, ew.size - (nelec + nfrac))
+    if mu0 is None:
+        mu0 = 0.5 * (ew_sorted[nelec - 1] + ew_sorted[nelec])
+    ewocc, mu_quasi, nerr = assignocc(ew, nelec, beta, mu0, fix_mu=kwargs.get("fix_mu", False), thr_deg=kwargs.get("tol_deg", 1e-6),
+                                      ncore=ncore, nvirt=nvirt)
+    # ---- density from the resident eigenvectors, fold to real space ------------------------------------------------------------
+    first = np.asarray([np.nonzero(src == r)[0][0] for r in range(nrep)])          # a k point of every representative (+-k share their levels)
+    d_rho = density_dev(ctx, d_Vt, ctx.to_device(np.ascontiguousarray(ewocc[first]).reshape(nrep, m), np.float64), m, nrep)
+    GRho = d_rho.get().reshape(nrep, m, m)
+    if nrep != nkpts:
+        GRho = GRho[src]
+        GRho[inherits] = GRho[inherits].conj()
+        d_rho = ctx.to_device(GRho, np.complex128)
+    d_imax = ctx.zeros((1,), np.float64)
+    GRhoT = fourier.fold_k2R_dev(d_rho.reshape(1, nkpts, m * m), lattice.kmesh, 1, m * m, imag_max=d_imax).get().reshape(nkpts, m, m)
+    imag = float(d_imax.get()[0])
+    if imag >= IMAG_DISCARD_TOL:
+        log.warn("GRhoT has imag part %s", imag)
+        GRhoT = lattice.k2R(GRho)
+    # ---- particle number and energy per cell (mfd.py:836-844) -----------------------------------------------------------------
+    rhoTA, rhoTB, kappaTBA = np.swapaxes(np.asarray([extractRdm(x) for x in GRhoT]), 0, 1)
+    for c in range(1, rhoTB.shape[0]):
+        rhoTB[c] -= np.eye(rhoTB.shape[1])
+    npart = (np.trace(rhoTA[0]) + np.trace(rhoTB[0])).real
+    E = (0.5 / nkpts) * np.einsum("kij,kji->", GFock + GH1, GRho, optimize=True).real + GH0
+    if not ires:
+        return GRhoT, npart, E
+    ev = _vt_to_ev(ctx, d_Vt, m, nrep).get().reshape(nrep, m, m)[src]
+    ev[inherits] = ev[inherits].conj()
+    homo = ew_sorted[max(np.searchsorted(ew_sorted, mu_quasi, side='right') - 1, 0)]
+    lumo = ew_sorted[min(np.searchsorted(ew_sorted, mu_quasi, side='left'), len(ew_sorted) - 1)]
+    res = {"gap": lumo - homo, "e": ew, "coef": ev, "nerr": nerr, "rho_k": GRho, "E": E, "mo_occ": ewocc, "homo": homo, "lumo": lumo,
+           "mu_quasi": mu_quasi}
+    return GRhoT, npart, E, res
+
+
 # ---------------------------------------------------------------------------------------------
 # a4: occupations (device: csrc/occ.hip)
 # ---------------------------------------------------------------------------------------------

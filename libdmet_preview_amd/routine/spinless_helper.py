@@ -15,6 +15,7 @@ import numpy as np
 from libdmet_preview_amd._lib import lib, get_ctx
 from libdmet_preview_amd.routine import slater_helper
 from libdmet_preview_amd.routine.slater_helper import init_H2  # noqa: F401  (re-exported like the reference)
+from libdmet_preview_amd.routine.bcs_helper import mono_fit, mono_fit_2  # noqa: F401  (spinless_helper.py:17)
 
 
 def separate_basis(basis, copy=False):

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -1950,6 +1950,87 @@ def gen_G32():
         out["mono/" + tag + "_trace"] = np.asarray(trace)
     np.savez_compressed(os.path.join(GOLD, "G32_bcs_driver.npz"), **out)
     print("G32 done", len(out), "arrays")
+
+
+GHF_RUNS = [("t0", np.inf, dict()), ("t0_nosymm", np.inf, dict(symm=False)), ("ft", 9.0, dict()), ("ft_fix", 9.0, dict(fix_mu=True, mu0=0.05)),
+            ("t0_hcore", np.inf, dict(use_hcore=True)), ("ft_f04", 9.0, dict(filling=0.4)), ("ft_nfrac", 9.0, dict(nfrac=2))]
+
+
+def gen_G33():
+    """The generalised Hartree-Fock lattice mean field, routine/mfd.py:735-858 GHF, on the GSO lattices of G27 (Fock / hcore triples
+    (aa, bb, ab), a local potential with a pairing block, mu), and its particle-hole entry (`ph_trans=True` on a two-spin H1,
+    pbc_helper.py:1239-1297 transform_H1_k): density, particle number, energy, levels, occupations, band edges."""
+    from libdmet.routine import mfd
+    g27, g7 = np.load(os.path.join(GOLD, "G27_gso_embham.npz")), np.load(os.path.join(GOLD, "G7_bcs.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val)
+        L.hcore_lo_k, L.fock_lo_k = g27[name + "/H3_k"], g27[name + "/F3_k"]
+        L.H0, L.use_hcore_as_emb_ham = 0.3, False
+        vc = _Vcor(g27[name + "/vcor"])
+        for tag, beta, kw in GHF_RUNS:
+            kw = dict(kw)
+            filling = kw.pop("filling", 0.5)
+            GRhoT, npart, E, res = mfd.GHF(L, vc, False, filling=filling, mu=0.37, beta=beta, ires=True, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/GRhoT"], out[key + "/n"], out[key + "/E"] = GRhoT, np.asarray(npart), np.asarray(E)
+            out[key + "/ew"], out[key + "/rho_k"], out[key + "/occ"] = res["e"], res["rho_k"], res["mo_occ"]
+            out[key + "/edges"] = np.asarray([res["gap"], res["homo"], res["lumo"], res["mu_quasi"], res["nerr"]])
+        # particle-hole entry: a plain two-spin Hamiltonian goes in, (HA, -HB, 0) and the trace constant come out
+        FR = g7[name + "/Fock_R"]
+        L.hcore_lo_k, L.fock_lo_k = synth.fold_R2k(0.7 * FR, mesh), synth.fold_R2k(FR, mesh)
+        GRhoT, npart, E, res = mfd.GHF(L, vc, False, mu=0.37, beta=np.inf, ires=True, ph_trans=True)
+        key = name + "/ph"
+        out[key + "/GRhoT"], out[key + "/n"], out[key + "/E"], out[key + "/ew"] = GRhoT, np.asarray(npart), np.asarray(E), res["e"]
+    np.savez_compressed(os.path.join(GOLD, "G33_ghf.npz"), **out)
+    print("G33 done", len(out), "arrays")
+
+
+def gen_G34():
+    """The GSO driver layer in front of the impurity solver, dmet/HubbardGSO.py:16-134: GHartreeFock (chemical potential fitted to a
+    filling by mono_fit_2 = bracketing + Brent over mfd.GHF), ConstructImpHam (spinless bath + Hamiltonian) and apply_dmu in both
+    forms, on the GSO lattices of G27."""
+    spinless, sh = shim.patch_spinless()
+    from libdmet.dmet import HubbardGSO as HG
+    from libdmet.routine import bcs_helper as bh, slater
+    from libdmet.solver import scf as rscf
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+    g27 = np.load(os.path.join(GOLD, "G27_gso_embham.npz"))
+    out = {}
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        nk = int(np.prod(mesh))
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        H3, F3 = g27[name + "/H3_k"], g27[name + "/F3_k"]
+        S3 = np.zeros((3, nk, n, n), dtype=complex)
+        S3[0] = S3[1] = np.eye(n)
+        L.hcore_lo_k, L.fock_lo_k, L.fock_hf_lo_k, L.ovlp_lo_k = H3, F3, 0.9 * F3, S3
+        L.JK_imp, L.Ham, L.H0, L.use_hcore_as_emb_ham = None, None, 0.75, False
+        vc = _Vcor(g27[name + "/vcor"])
+        for tag, filling, beta, kw in (("fit_t0", 0.45, np.inf, dict()), ("fit_ft", 0.55, 10.0, dict()), ("nofit", None, np.inf, dict())):
+            rho, mu, res = HG.GHartreeFock(L, vc, filling, 0.2, beta=beta, full_return=True, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/GRho"], out[key + "/mu"], out[key + "/E"], out[key + "/ew"] = rho, np.asarray(mu), np.asarray(res["E"]), res["e"]
+        GRho, mu = out[name + "/nofit/GRho"], 0.2
+        L.rdm1_lo_k = synth.fold_R2k(GRho[None], mesh)[0]
+        basis0 = spinless.get_emb_basis(L, GRho)
+        H2 = _psd_eri(np.random.default_rng(3400 + n), basis0.shape[-1], 7, 1)
+        ImpHam, none, basis = HG.ConstructImpHam(L, GRho, vc, mu, H2_given=H2)
+        out[name + "/imp/basis"], out[name + "/imp/H2"], out[name + "/imp/H1"] = basis, H2, ImpHam.H1["cd"].copy()
+        out[name + "/imp/H0"] = np.asarray(ImpHam.H0)
+        assert none is None
+        ImpHam = HG.apply_dmu(L, ImpHam, basis, 0.11)
+        out[name + "/imp/dmu_H1"] = ImpHam.H1["cd"].copy()
+        ImpHam = HG.apply_dmu(L, ImpHam, basis, 0.07, fit_ghf=True)
+        out[name + "/imp/dmu_ghf_H1"] = ImpHam.H1["cd"].copy()
+        ImpHam = HG.apply_dmu(L, ImpHam, basis, -0.05, dmu_idx=[0])
+        out[name + "/imp/dmu_idx_H1"] = ImpHam.H1["cd"].copy()
+    for tag, fn, y0, x0, thr, inc in (("cubic", lambda x: x ** 3 + x, 2.5, 0.0, 1e-9, True), ("tanh", lambda x: np.tanh(0.3 * x), -0.7, 1.0, 1e-7, True),
+                                      ("dec", lambda x: -np.arctan(x), 0.4, 3.0, 1e-8, False)):
+        trace = []
+        out["mono2/" + tag] = np.asarray(bh.mono_fit_2(lambda x: (trace.append(x), fn(x))[1], y0, x0, thr, increase=inc))
+        out["mono2/" + tag + "_trace"] = np.asarray(trace)
+    np.savez_compressed(os.path.join(GOLD, "G34_gso_driver.npz"), **out)
+    print("G34 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

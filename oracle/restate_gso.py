@@ -377,3 +377,44 @@ def gso_emb_fit(rho, kmesh, basis, vcor, mu, beta, fock_k, ovlp_k, nimp, nelec=N
     fit.target[0][fit.imp_fill] = rho[fit.imp_mesh]
     fit.target[0][fit.det_fill] = rho[fit.det_mesh]
     return fit
+
+
+# ---------------------------------------------------------------------------------------------
+# generalised Hartree-Fock lattice mean field (routine/mfd.py:735-858); golden G33
+# ---------------------------------------------------------------------------------------------
+
+def GHF(kmesh, H1_k, Fock_k, vcor_mat, mu, H0=0.0, filling=0.5, mu0=None, beta=np.inf, symm=True, fix_mu=False, nfrac=None, ph_trans=False,
+        tol_deg=1e-6):
+    """Returns GRhoT, n, E, result dict.  H1_k / Fock_k: (3, nk, n, n) triples, or with `ph_trans` any ((spin,) nk, n, n)."""
+    from oracle.restate import FFTtoT, assignocc, check_nelec
+    from oracle.restate_bcs import DiagGHF
+    def ph(H):
+        H = np.asarray(H)
+        HA, HB = (H, H) if H.ndim == 3 else (H[0], H[min(1, H.shape[0] - 1)])
+        HD = H[2] if (H.ndim == 4 and H.shape[0] == 3) else np.zeros_like(HA)
+        return np.asarray([HA, -HB, HD]), np.einsum('kii->', HB).real / HA.shape[0]
+    GH0 = H0
+    if ph_trans:
+        H1_k, a = ph(H1_k)
+        Fock_k, b = ph(Fock_k)
+        GH0 = 0.5 * (a + b) + H0
+    GFock, GH1 = spin_orbital_matrix(Fock_k), spin_orbital_matrix(H1_k)
+    nk = GFock.shape[0]
+    ew, ev = DiagGHF(GFock, vcor_mat, mu, kmesh=kmesh if symm else None)
+    GFock = GFock + spin_orbital_matrix(np.asarray(vcor_mat))[None]
+    nelec = check_nelec(ew.size * filling, None)[0]
+    ew_sorted = np.sort(ew, axis=None, kind='mergesort')
+    ncore, nvirt = (0, 0) if nfrac is None else (nelec - nfrac, ew.size - (nelec + nfrac))
+    if mu0 is None:
+        mu0 = 0.5 * (ew_sorted[nelec - 1] + ew_sorted[nelec])
+    occ, mu_quasi, nerr = assignocc(ew, nelec, beta, mu0, fix_mu=fix_mu, thr_deg=tol_deg, ncore=ncore, nvirt=nvirt)
+    GRho = np.einsum('kpm,km,kqm->kpq', ev, occ, ev.conj())
+    GRhoT = FFTtoT(GRho, kmesh)
+    n = GRhoT.shape[-1] // 2
+    rA, rB = GRhoT[:, :n, :n], np.eye(n) - GRhoT[:, n:, n:]
+    npart = (np.trace(rA[0]) + np.trace(rB[0])).real
+    E = (0.5 / nk) * np.einsum('kij,kji->', GFock + GH1, GRho).real + GH0
+    homo = ew_sorted[max(np.searchsorted(ew_sorted, mu_quasi, side='right') - 1, 0)]
+    lumo = ew_sorted[min(np.searchsorted(ew_sorted, mu_quasi, side='left'), len(ew_sorted) - 1)]
+    return GRhoT, npart, E, {"e": ew, "rho_k": GRho, "mo_occ": occ, "gap": lumo - homo, "homo": homo, "lumo": lumo, "mu_quasi": mu_quasi,
+                             "nerr": nerr}

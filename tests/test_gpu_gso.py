@@ -299,3 +299,80 @@ def test_gso_vcor_fit(ctx, golden, name, n, val):
     assert len(spinless.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, full_return=True)) == 4
     with pytest.raises(NotImplementedError):
         spinless.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, MaxIter2=2)
+
+
+# ---- round 6: generalised Hartree-Fock lattice mean field (golden G33) -----------------------------------------------------
+
+@pytest.mark.parametrize("name", GSO_HAM)
+def test_ghf_mean_field(ctx, golden, name):
+    """mfd.GHF (routine/mfd.py:735-858) against the reference (golden G33): T = 0 and finite T, with and without the +-k symmetry,
+    fixed level, hcore, another filling, frozen levels (`nfrac`), and the particle-hole entry on a plain two-spin Hamiltonian."""
+    from libdmet_preview_amd.routine import mfd
+    from libdmet_preview_amd.system.lattice import Lattice
+    from tests.test_oracle_gso import GHF_RUNS
+    g, g27, g7 = golden("G33_ghf.npz"), golden("G27_gso_embham.npz"), golden("G7_bcs.npz")
+    mesh = tuple(int(x) for x in g27[name + "/mesh"])
+    H3, F3, v = g27[name + "/H3_k"], g27[name + "/F3_k"], g27[name + "/vcor"]
+    n = v.shape[-1]
+    L = Lattice(n, mesh)
+    L.hcore_lo_k, L.fock_lo_k, L.H0 = H3, F3, 0.3
+    vc = _V3(v)
+    for tag, beta, kw in GHF_RUNS:
+        kw = dict(kw)
+        filling = kw.pop("filling", 0.5)
+        GT, npart, E, res = mfd.GHF(L, vc, False, filling=filling, mu=0.37, beta=beta, ires=True, **kw)
+        key = "%s/%s" % (name, tag)
+        assert np.abs(res["e"] - g[key + "/ew"]).max() < 1e-11 and np.abs(res["mo_occ"] - g[key + "/occ"]).max() < 1e-9
+        assert np.abs(GT - g[key + "/GRhoT"]).max() < 1e-10 and np.abs(res["rho_k"] - g[key + "/rho_k"]).max() < 1e-10
+        assert abs(npart - float(g[key + "/n"])) < 1e-10 and abs(E - float(g[key + "/E"])) < 1e-9
+        edges = np.asarray([res["gap"], res["homo"], res["lumo"], res["mu_quasi"]])
+        assert np.abs(edges - g[key + "/edges"][:4]).max() < 1e-9
+        for k in range(GT.shape[0]):
+            ev = res["coef"][k]
+            assert np.abs(ev.conj().T @ ev - np.eye(2 * n)).max() < 1e-10
+        assert len(mfd.GHF(L, vc, False, filling=filling, mu=0.37, beta=beta, **kw)) == 3
+    FR = g7[name + "/Fock_R"]
+    L.hcore_lo_k, L.fock_lo_k = R.R2k(0.7 * FR, mesh), R.R2k(FR, mesh)
+    GT, npart, E, res = mfd.GHF(L, vc, False, mu=0.37, beta=np.inf, ires=True, ph_trans=True)
+    assert np.abs(GT - g[name + "/ph/GRhoT"]).max() < 1e-10 and abs(E - float(g[name + "/ph/E"])) < 1e-9
+    assert np.abs(res["e"] - g[name + "/ph/ew"]).max() < 1e-11 and abs(npart - float(g[name + "/ph/n"])) < 1e-10
+    for bad in (dict(restricted=True), dict(restricted=False, scf=True)):
+        with pytest.raises(NotImplementedError):
+            mfd.GHF(L, vc, bad.pop("restricted"), mu=0.37, **bad)
+
+
+# ---- round 6: the GSO driver layer (golden G34) ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", GSO_HAM)
+def test_gso_driver_layer(ctx, golden, name):
+    """dmet/HubbardGSO.py:16-134: GHartreeFock with the chemical potential fitted to a filling (every iterate a GHF on the device),
+    ConstructImpHam and the three forms of apply_dmu, against the reference (golden G34).  The impurity Hamiltonian is compared
+    on the reference's own basis entry by entry (the bath columns have a gauge), the basis itself as a subspace."""
+    from libdmet_preview_amd.dmet import HubbardGSO as HG
+    from libdmet_preview_amd.routine import spinless
+    g, g27 = golden("G34_gso_driver.npz"), golden("G27_gso_embham.npz")
+    L, mesh, basis27, H2_27, F3, rk, v, mu27 = _gso_lattice(g27, name)
+    vc = _V3(v)
+    for tag, filling, beta in (("fit_t0", 0.45, np.inf), ("fit_ft", 0.55, 10.0), ("nofit", None, np.inf)):
+        rho, mu, res = HG.GHartreeFock(L, vc, filling, 0.2, beta=beta, full_return=True)
+        key = "%s/%s" % (name, tag)
+        assert abs(mu - float(g[key + "/mu"])) < 1e-8, (key, mu)
+        assert np.abs(rho - g[key + "/GRho"]).max() < 1e-7 and abs(res["E"] - float(g[key + "/E"])) < 1e-7
+        assert np.abs(res["e"] - g[key + "/ew"]).max() < 1e-7
+    assert len(HG.GHartreeFock(L, vc, None, 0.2)) == 2
+    GRho, H2 = g[name + "/nofit/GRho"], g[name + "/imp/H2"]
+    L.rdm1_lo_k = R.R2k(GRho, mesh)
+    ImpHam, none, basis = HG.ConstructImpHam(L, GRho, vc, 0.2, H2_given=H2)
+    ref = g[name + "/imp/basis"]
+    assert none is None and basis.shape == ref.shape and abs(ImpHam.H0 - float(g[name + "/imp/H0"])) < 1e-12
+    a, r = basis.reshape(-1, basis.shape[-1]), ref.reshape(-1, ref.shape[-1])       # same embedding space (a GIVEN ERI is not gauge covariant,
+    assert np.linalg.norm(r - a @ (a.T @ r)) < 1e-8                                  # so the Hamiltonian is compared on the reference's basis)
+    # on the reference's basis: the Hamiltonian and every shift entry by entry
+    ImpHam, _ = spinless.embHam(L, ref, vc, 0.2, H2_given=H2)
+    assert np.abs(ImpHam.H1["cd"] - g[name + "/imp/H1"]).max() < 1e-9
+    ImpHam = HG.apply_dmu(L, ImpHam, ref, 0.11)
+    assert np.abs(ImpHam.H1["cd"] - g[name + "/imp/dmu_H1"]).max() < 1e-9
+    ImpHam = HG.apply_dmu(L, ImpHam, ref, 0.07, fit_ghf=True)
+    assert np.abs(ImpHam.H1["cd"] - g[name + "/imp/dmu_ghf_H1"]).max() < 1e-9
+    ImpHam = HG.apply_dmu(L, ImpHam, ref, -0.05, dmu_idx=[0])
+    assert np.abs(ImpHam.H1["cd"] - g[name + "/imp/dmu_idx_H1"]).max() < 1e-9

@@ -150,3 +150,16 @@ def test_mono_fit_iterates_equal_the_reference(golden):
         x = mono_fit(lambda z: (trace.append(z), fn(z))[1], y0, x0, thr, increase=inc)
         assert x == float(g["mono/" + tag]) and np.array_equal(np.asarray(trace), g["mono/" + tag + "_trace"])
     assert mono_fit(lambda x: 2.0 * x, 1.0, 0.5, 1e-12) == 0.5                      # the start already hits the target
+
+
+def test_mono_fit_2_iterates_equal_the_reference(golden):
+    """bcs_helper.mono_fit_2 (bcs_helper.py:131-174: bracketing + Brent), the chemical-potential search of the GSO mean field."""
+    from libdmet_preview_amd.routine.spinless_helper import mono_fit_2
+    g = golden("G34_gso_driver.npz")
+    for tag, fn, y0, x0, thr, inc in (("cubic", lambda x: x ** 3 + x, 2.5, 0.0, 1e-9, True), ("tanh", lambda x: np.tanh(0.3 * x), -0.7, 1.0, 1e-7, True),
+                                      ("dec", lambda x: -np.arctan(x), 0.4, 3.0, 1e-8, False)):
+        trace = []
+        x = mono_fit_2(lambda z: (trace.append(z), fn(z))[1], y0, x0, thr, increase=inc)
+        assert x == float(g["mono2/" + tag]) and np.array_equal(np.asarray(trace), g["mono2/" + tag + "_trace"])
+    with pytest.raises(RuntimeError):
+        mono_fit_2(lambda x: 0.0, 1.0, 0.0, 1e-9, maxiter=1)

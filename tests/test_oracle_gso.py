@@ -190,3 +190,28 @@ def test_G29_gso_fit_objective_and_gradient(golden, name, n, val):
             assert np.abs(grad(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
         pfit, (e0, e1) = g[key + "/param"], g[key + "/err"]
         assert abs(fit.errfunc(np.zeros_like(pfit)) - e0) < 1e-12 and abs(fit.errfunc(pfit) - e1) < 1e-11
+
+
+# ---- round 6: generalised Hartree-Fock lattice mean field (golden G33) -----------------------------------------------------
+
+GHF_RUNS = [("t0", np.inf, dict()), ("t0_nosymm", np.inf, dict(symm=False)), ("ft", 9.0, dict()), ("ft_fix", 9.0, dict(fix_mu=True, mu0=0.05)),
+            ("t0_hcore", np.inf, dict(use_hcore=True)), ("ft_f04", 9.0, dict(filling=0.4)), ("ft_nfrac", 9.0, dict(nfrac=2))]
+
+
+@pytest.mark.parametrize("name", GSO_HAM)
+def test_G33_ghf(golden, name):
+    g, g27, g7 = golden("G33_ghf.npz"), golden("G27_gso_embham.npz"), golden("G7_bcs.npz")
+    mesh = tuple(int(x) for x in g27[name + "/mesh"])
+    H3, F3, v = g27[name + "/H3_k"], g27[name + "/F3_k"], g27[name + "/vcor"]
+    for tag, beta, kw in GHF_RUNS:
+        kw = dict(kw)
+        hcore = kw.pop("use_hcore", False)
+        GT, n, E, res = G.GHF(mesh, H3, H3 if hcore else F3, v, 0.37, H0=0.3, beta=beta, **kw)
+        key = "%s/%s" % (name, tag)
+        assert np.abs(GT - g[key + "/GRhoT"]).max() < 1e-12 and abs(n - float(g[key + "/n"])) < 1e-12 and abs(E - float(g[key + "/E"])) < 1e-12
+        assert np.abs(res["e"] - g[key + "/ew"]).max() < 1e-12 and np.abs(res["mo_occ"] - g[key + "/occ"]).max() < 1e-12
+        edges = np.asarray([res["gap"], res["homo"], res["lumo"], res["mu_quasi"], res["nerr"]])
+        assert np.abs(edges - g[key + "/edges"]).max() < 1e-12
+    FR = g7[name + "/Fock_R"]
+    GT, n, E, res = G.GHF(mesh, R.R2k(0.7 * FR, mesh), R.R2k(FR, mesh), v, 0.37, H0=0.3, ph_trans=True)
+    assert np.abs(GT - g[name + "/ph/GRhoT"]).max() < 1e-12 and abs(E - float(g[name + "/ph/E"])) < 1e-12
