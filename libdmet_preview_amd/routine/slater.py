@@ -1262,7 +1262,12 @@ class FullFitDevice(object):
     occupations on the host, density on the device and either its fold into the embedding space (imp + bath fit)
     or its cell-0 block (impurity / diagonal fit)."""
 
-    def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, imp_bath_fit, fix_mu=False):
+    def __init__(self, ctx, rho, lattice, basis, vcor, beta, nelec, imp_idx, det_idx, imp_bath_fit, fix_mu=False,
+                 fock_k=None, shift_of=None, dV=None, norm=None, mask=None):
+        """A twin of the fit hands over its own ingredients (the GSO lattice stage, routine/spinless.py:1464-1769): `fock_k`
+        (spin, nk, n, n) in place of lattice.getFock, `shift_of(vcor)` -> the real (spin, n, n) matrix the trial potential adds to
+        every k, `dV` the tril-packed parameter gradient (nparam, spin, npair), `norm` the divisor of |drho| (default sqrt(spin)),
+        `mask` (nidx, nidx) zeroing entries of the fitted block that are not to be fitted."""
         from libdmet_preview_amd.routine import mfd
         from libdmet_preview_amd.system import fourier
         from libdmet_preview_amd.basis_transform.make_basis import bgemm_dev
@@ -1272,11 +1277,13 @@ class FullFitDevice(object):
         spin, nk, n, nb = basis.shape
         self.spin, self.nk, self.n, self.nb = spin, nk, n, nb
         self.beta, self.nelec, self.fix_mu, self.imp_bath_fit = beta, nelec, fix_mu, imp_bath_fit
-        Fock = np.asarray(lattice.getFock(kspace=True))
+        Fock = np.asarray(lattice.getFock(kspace=True) if fock_k is None else fock_k)
         if Fock.ndim == 3:
             Fock = Fock[np.newaxis]
         if Fock.shape[0] < spin:
             Fock = np.asarray((Fock[0],) * spin)
+        self.norm = sqrt(spin) if norm is None else float(norm)
+        self._shift_of = shift_of if shift_of is not None else (lambda v: np.asarray(v.get(0, True))[:spin].real)
         self.kpts = bool(getattr(vcor, "is_vcor_kpts", False))
         if self.kpts:
             self.F_host = np.array(Fock[:spin], dtype=np.complex128)       # the potential differs from k to k: added before the upload
@@ -1290,10 +1297,13 @@ class FullFitDevice(object):
         W = np.zeros((nidx, nidx))
         W[:nimp, :nimp] = 1.0
         W[range(nimp, nidx), range(nimp, nidx)] = 1.0
+        if mask is not None:
+            W = W * np.asarray(mask, dtype=np.float64)
         target = np.zeros((spin, nidx, nidx))
         for s in range(spin):
             target[s][:nimp, :nimp] = rho[s][np.ix_(imp_idx, imp_idx)]
             target[s][range(nimp, nidx), range(nimp, nidx)] = rho[s][det_idx, det_idx]
+            target[s] *= W if mask is not None else 1.0
         self.d_W = ctx.to_device(np.asarray([W] * spin))
         self.d_target = ctx.to_device(target)
         self.d_fit = ctx.to_device(np.asarray(self.fit_idx, dtype=np.int32))
@@ -1303,6 +1313,12 @@ class FullFitDevice(object):
         self.nfev = self.ngev = 0
         self._key, self._state = None, None
         self.npair = n * (n + 1) // 2
+        if dV is not None:
+            dV = np.ascontiguousarray(dV, dtype=np.float64)
+            log.eassert(dV.ndim == 3 and dV.shape[1:] == (spin, self.npair), "FullFitDevice: dV is (nparam, spin, npair)")
+            self.nparam, self.d_dV = dV.shape[0], ctx.to_device(dV)
+            self.d_even = ctx.to_device(np.arange(0, 2 * n, 2, dtype=np.int32))
+            return
         if self.kpts:
             self.nparam = vcor.length()                       # slater.py:1439-1440: no dV_dparam, the gradient is assembled per k group
             return
@@ -1325,7 +1341,7 @@ class FullFitDevice(object):
             per_k = np.asarray(self.vcor.value)[:, :spin].transpose(1, 0, 2, 3)                # (spin, nk, n, n) complex
             d_w, d_Vt = mfd.eigh_dev(ctx, ctx.to_device((self.F_host + per_k).reshape(spin * nk, n, n), np.complex128), n, spin * nk)
         else:
-            v = np.ascontiguousarray(np.asarray(self.vcor.get(0, True))[:spin].real, dtype=np.float64)
+            v = np.ascontiguousarray(self._shift_of(self.vcor), dtype=np.float64)
             d_add = ctx.to_device(v)
             d_w, d_Vt = mfd.eigh_dev(ctx, self.d_F, n, spin * nk, d_add, nk)
         ew = d_w.get().reshape(spin, nk, n)
@@ -1357,7 +1373,7 @@ class FullFitDevice(object):
 
     def errfunc(self, param):
         self.nfev += 1
-        return self._forward(param)[2] / sqrt(self.spin)
+        return self._forward(param)[2] / self.norm
 
     def gradfunc(self, param):
         """Analytic finite-T gradient (slater.py:1480-1640, local vcor): for every k
@@ -1416,7 +1432,7 @@ class FullFitDevice(object):
         d_grad = ctx.empty((self.nparam,), np.float64)
         ctx.check(lib.dmk_dgemv2(ctx.h, self.nparam, spin * self.npair, self.d_dV.ptr, spin * self.npair, d_dw.ptr, None,
                                  d_grad.ptr, None))
-        return d_grad.get() / (2.0 * val * sqrt(spin) * nk)
+        return d_grad.get() / (2.0 * val * self.norm * nk)
 
 
     def _mu_response(self, d_Vt, d_D, f):
@@ -1459,7 +1475,7 @@ class FullFitDevice(object):
                 res[sl.start:sl.start + n_re] = re[lo]
                 if paired:
                     res[sl.start + n_re:sl.stop] = -4.0 * m.imag[so]
-        return res / (2.0 * val * sqrt(spin) * nk)
+        return res / (2.0 * val * self.norm * nk)
 
 
 def FitVcorFull(rho, lattice, basis, vcor, beta, filling, MaxIter=20, imp_fit=False, imp_idx=None, det=False, det_idx=None,

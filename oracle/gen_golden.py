@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -2031,6 +2031,53 @@ def gen_G34():
         out["mono2/" + tag + "_trace"] = np.asarray(trace)
     np.savez_compressed(os.path.join(GOLD, "G34_gso_driver.npz"), **out)
     print("G34 done", len(out), "arrays")
+
+
+GSO_FULL_RUNS = [("ft_imp", 12.0, dict(imp_fit=True), 10), ("ft_det", 12.0, dict(det=True), 10), ("ft_bogo", 12.0, dict(imp_fit=True, bogo_only=True), 10),
+                 ("ft_fixmu", 12.0, dict(imp_fit=True, fix_mu=True), 10), ("t0_num", np.inf, dict(imp_fit=True, num_grad=True), 2)]
+
+
+def gen_G35():
+    """The lattice stage of the GSO fit, routine/spinless.py:1431-1769 (get_dV_dparam_full, FitVcorFull): the reference's closures at
+    fixed parameters and its fits -- impurity block, diagonal, pairing blocks only, fixed quasiparticle level, numerical-gradient
+    T = 0 -- on the GSO lattices of G27."""
+    spinless, sh = shim.patch_spinless()
+    from libdmet.dmet import Hubbard
+    from libdmet.system import lattice as rl
+    g27 = np.load(os.path.join(GOLD, "G27_gso_embham.npz"))
+    out = {}
+    captured = {}
+    real_minimize = spinless.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    spinless.minimize = spy
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        L.hcore_lo_k, L.fock_lo_k = g27[name + "/H3_k"], g27[name + "/F3_k"]
+        basis = g27[name + "/basis"]
+        rng = np.random.default_rng(3500 + n)
+        noise = 0.04 * rng.standard_normal((2 * n, 2 * n))
+        target = rl.FFTtoT(g27[name + "/GRho_k"], mesh)[0].real + 0.5 * (noise + noise.T)
+        out[name + "/target"] = target
+        v = Hubbard.VcorLocal(False, True, n)
+        out[name + "/dV_full"] = spinless.get_dV_dparam_full(v, L)
+        for tag, beta, kw, iters in GSO_FULL_RUNS:
+            v = Hubbard.VcorLocal(False, True, n)
+            v.update(0.05 * np.random.default_rng(7).standard_normal(v.length()))
+            out["%s/%s/p0" % (name, tag)] = np.array(v.param)
+            vfit, e0, e1 = spinless.FitVcorFull(target, L, basis, v, 0.37, beta, None, MaxIter=iters, **kw)
+            key = "%s/%s" % (name, tag)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](q.copy()) for q in P])
+            if captured["fgrad"] is not None:
+                out[key + "/probe_grad"] = np.asarray([captured["fgrad"](q.copy()) for q in P])
+    spinless.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G35_gso_full_fit.npz"), **out)
+    print("G35 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

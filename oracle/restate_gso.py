@@ -418,3 +418,69 @@ def GHF(kmesh, H1_k, Fock_k, vcor_mat, mu, H0=0.0, filling=0.5, mu0=None, beta=n
     lumo = ew_sorted[min(np.searchsorted(ew_sorted, mu_quasi, side='left'), len(ew_sorted) - 1)]
     return GRhoT, npart, E, {"e": ew, "rho_k": GRho, "mo_occ": occ, "gap": lumo - homo, "homo": homo, "lumo": lumo, "mu_quasi": mu_quasi,
                              "nerr": nerr}
+
+
+# ---------------------------------------------------------------------------------------------
+# lattice stage of the GSO fit (routine/spinless.py:1431-1769); golden G35
+# ---------------------------------------------------------------------------------------------
+
+class GsoFullFit(object):
+    """errfunc / gradfunc_ft of spinless.FitVcorFull for an impurity-block or diagonal fit (the imp + bath form has no gradient in
+    the reference): every k point's generalised Fock + spin-orbital vcor, half filling with the quasiparticle level searched from 0,
+    cell-0 density on the doubled indices, |drho| / sqrt(2); `bogo_only` leaves the normal blocks out."""
+
+    def __init__(self, rho, kmesh, vcor, mu, beta, fock_k, imp_idx=(), det_idx=(), fix_mu=False, bogo_only=False):
+        from oracle.restate import check_nelec
+        self.vcor, self.beta, self.fix_mu = vcor, beta, fix_mu
+        n = fock_k.shape[-1]
+        GF = spin_orbital_matrix(fock_k).astype(complex)
+        GF[:, range(n), range(n)] -= mu
+        GF[:, range(n, 2 * n), range(n, 2 * n)] += mu
+        self.GFock, self.nk, self.nso = GF, GF.shape[0], 2 * n
+        dbl = lambda idx: list(idx) + [i + n for i in idx]
+        imp, det = dbl(imp_idx), dbl(det_idx)
+        self.fit_idx = imp + det
+        ni, nidx = len(imp), len(imp) + len(det)
+        self.imp_mesh, self.det_mesh = np.ix_(imp, imp), (det, det)
+        self.imp_fill, self.det_fill = (slice(ni), slice(ni)), (range(ni, nidx), range(ni, nidx))
+        self.mask = np.ones((nidx, nidx))
+        if bogo_only:
+            hi, hd = ni // 2, len(det) // 2
+            for lo, up in ((0, hi), (hi, ni), (ni, ni + hd), (ni + hd, nidx)):
+                self.mask[lo:up, lo:up] = 0.0
+        self.target = np.zeros((nidx, nidx))
+        self.target[self.imp_fill] = rho[self.imp_mesh]
+        self.target[self.det_fill] = rho[self.det_mesh]
+        self.target *= self.mask
+        self.nelec = check_nelec(self.nk * self.nso * 0.5, None)[0]
+        g = vcor.gradient()
+        tl = np.tril_indices(self.nso)
+        self.dV = spin_orbital_matrix(np.asarray([g[:, 0], g[:, 1], g[:, 2]]))[:, tl[0], tl[1]]
+
+    def _solve(self, param):
+        from oracle.restate import assignocc
+        self.vcor.update(param)
+        H = self.GFock + spin_orbital_matrix(np.asarray(self.vcor.get()))[None]
+        ew = np.empty((self.nk, self.nso))
+        ev = np.empty((self.nk, self.nso, self.nso), dtype=complex)
+        for k in range(self.nk):
+            ew[k], ev[k] = la.eigh(H[k])
+        occ, mu_q, _ = assignocc(ew, self.nelec, self.beta, 0.0, fix_mu=self.fix_mu)
+        rhoT = (np.einsum('kpm,km,kqm->pq', ev, occ, ev.conj()) / self.nk).real
+        rho1 = np.zeros_like(self.target)
+        rho1[self.imp_fill] = rhoT[self.imp_mesh]
+        rho1[self.det_fill] = rhoT[self.det_mesh]
+        return ew, ev, mu_q, rho1 * self.mask - self.target
+
+    def errfunc(self, param):
+        return la.norm(self._solve(param)[3]) / np.sqrt(2.0)
+
+    def gradfunc_ft(self, param):
+        from oracle.restate_fit import get_dw_dv
+        ew, ev, mu_q, drho = self._solve(param)
+        val = la.norm(drho)
+        res = 0.0
+        for k in range(self.nk):
+            dw = get_dw_dv(ew[k][None], ev[k][None], drho[None], mu_q, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=True)
+            res = res + self.dV.dot(dw.ravel())
+        return res.real / (2.0 * val * np.sqrt(2.0) * self.nk)

@@ -297,8 +297,6 @@ def test_gso_vcor_fit(ctx, golden, name, n, val):
     vnew, err = spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=np.inf, MaxIter1=30, MaxIter2=0)
     assert vnew is not v and np.abs(np.asarray(v.param)).max() == 0.0 and abs(err - g[name + "/t0/err"][1]) < 1e-6
     assert len(spinless.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, full_return=True)) == 4
-    with pytest.raises(NotImplementedError):
-        spinless.FitVcorTwoStep(target, L, basis, v, mu, MaxIter1=3, MaxIter2=2)
 
 
 # ---- round 6: generalised Hartree-Fock lattice mean field (golden G33) -----------------------------------------------------
@@ -376,3 +374,43 @@ def test_gso_driver_layer(ctx, golden, name):
     assert np.abs(ImpHam.H1["cd"] - g[name + "/imp/dmu_ghf_H1"]).max() < 1e-9
     ImpHam = HG.apply_dmu(L, ImpHam, ref, -0.05, dmu_idx=[0])
     assert np.abs(ImpHam.H1["cd"] - g[name + "/imp/dmu_idx_H1"]).max() < 1e-9
+
+
+# ---- round 6: the lattice stage of the GSO fit (golden G35) ----------------------------------------------------------------
+
+@pytest.mark.parametrize("name,n,val", GSO_FIT)
+def test_gso_lattice_stage_fit(ctx, golden, name, n, val):
+    """spinless.get_dV_dparam_full / FitVcorFull (routine/spinless.py:1431-1769) on the device against the reference's closures and
+    fits (golden G35): impurity block, diagonal, pairing blocks only, fixed quasiparticle level, the numerical-gradient T = 0 run;
+    both stages through FitVcorTwoStep."""
+    from libdmet_preview_amd.routine import spinless
+    from libdmet_preview_amd.dmet import Hubbard
+    from tests.test_oracle_gso import GSO_FULL_RUNS
+    g, g27 = golden("G35_gso_full_fit.npz"), golden("G27_gso_embham.npz")
+    L, mesh, basis, H2, F3, rk, vmat, mu = _gso_lattice(g27, name)
+    target = g[name + "/target"]
+    assert np.array_equal(spinless.get_dV_dparam_full(Hubbard.VcorLocal(False, True, n), L), g[name + "/dV_full"])
+    for tag, beta, kw, iters in GSO_FULL_RUNS:
+        key = "%s/%s" % (name, tag)
+        v = Hubbard.VcorLocal(False, True, n)
+        v.update(np.array(g[key + "/p0"]))
+        vfit, e0, e1 = spinless.FitVcorFull(target, L, basis, v, mu, beta, None, MaxIter=iters, **kw)
+        fit = spinless.FitVcorFull.last_fit
+        for i, p in enumerate(g[key + "/probe"]):
+            assert abs(fit.errfunc(p) - g[key + "/probe_err"][i]) < 1e-11, key
+            if key + "/probe_grad" in g:
+                gr = g[key + "/probe_grad"][i]
+                assert np.abs(fit.gradfunc(p) - gr).max() < 1e-8 * max(1.0, np.abs(gr).max()), key
+        r0, r1 = g[key + "/err"]
+        assert abs(e0 - r0) < 1e-11 and abs(e1 - r1) < 1e-5 and e1 <= e0, (key, e0, e1, r0, r1)
+    with pytest.raises(NotImplementedError):
+        spinless.FitVcorFull(target, L, basis, v, mu, np.inf, None, MaxIter=2, imp_fit=True)
+    v = Hubbard.VcorLocal(False, True, n)
+    v.update(np.zeros(v.length()))
+    emb_target = g29_target = golden("G29_gso_fit.npz")[name + "/target"]
+    vnew, err = spinless.FitVcorTwoStep(emb_target, L, basis, v, mu, beta=12.0, MaxIter1=5, MaxIter2=0)
+    assert vnew is not v
+    vnew2, err2 = spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=12.0, MaxIter1=0, MaxIter2=3, imp_fit=True)
+    assert vnew2 is not v and err2 <= g[name + "/ft_imp/err"][0] + 1.0
+    with pytest.raises(NotImplementedError):
+        spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=12.0, MaxIter1=0, MaxIter2=3, filling=0.5)

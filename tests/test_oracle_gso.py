@@ -215,3 +215,28 @@ def test_G33_ghf(golden, name):
     FR = g7[name + "/Fock_R"]
     GT, n, E, res = G.GHF(mesh, R.R2k(0.7 * FR, mesh), R.R2k(FR, mesh), v, 0.37, H0=0.3, ph_trans=True)
     assert np.abs(GT - g[name + "/ph/GRhoT"]).max() < 1e-12 and abs(E - float(g[name + "/ph/E"])) < 1e-12
+
+
+# ---- round 6: the lattice stage of the GSO fit (golden G35) ----------------------------------------------------------------
+
+GSO_FULL_RUNS = [("ft_imp", 12.0, dict(imp_fit=True), 10), ("ft_det", 12.0, dict(det=True), 10), ("ft_bogo", 12.0, dict(imp_fit=True, bogo_only=True), 10),
+                 ("ft_fixmu", 12.0, dict(imp_fit=True, fix_mu=True), 10), ("t0_num", np.inf, dict(imp_fit=True, num_grad=True), 2)]
+
+
+@pytest.mark.parametrize("name,n,val", GSO_FIT)
+def test_G35_gso_lattice_fit_objective_and_gradient(golden, name, n, val):
+    from oracle import restate_fit as F
+    g, g27 = golden("G35_gso_full_fit.npz"), golden("G27_gso_embham.npz")
+    mesh = tuple(int(x) for x in g27[name + "/mesh"])
+    idx = list(range(len(val) + len([i for i in range(n) if i > max(val)])))
+    for tag, beta, kw, _ in GSO_FULL_RUNS:
+        fit = G.GsoFullFit(g[name + "/target"], mesh, F.VcorLocal(False, True, n), 0.37, beta, g27[name + "/F3_k"],
+                           imp_idx=idx if kw.get("imp_fit") else [], det_idx=idx if kw.get("det") else [],
+                           fix_mu=kw.get("fix_mu", False), bogo_only=kw.get("bogo_only", False))
+        key = "%s/%s" % (name, tag)
+        for i, p in enumerate(g[key + "/probe"]):
+            assert abs(fit.errfunc(p) - g[key + "/probe_err"][i]) < 1e-12, key
+            if key + "/probe_grad" in g:
+                gr = g[key + "/probe_grad"][i]
+                assert np.abs(fit.gradfunc_ft(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
+        assert abs(fit.errfunc(g[key + "/p0"]) - g[key + "/err"][0]) < 1e-12 and abs(fit.errfunc(g[key + "/param"]) - g[key + "/err"][1]) < 1e-10
