@@ -152,4 +152,76 @@ def FitVcor(rho, lattice, basis, vcor, beta, filling, MaxIter1=300, MaxIter2=0, 
     return slater.FitVcorTwoStep(rho, lattice, basis, vcor, beta, filling, MaxIter1=MaxIter1, MaxIter2=MaxIter2, **kwargs)
 
 
+def apply_dmu(lattice, ImpHam, basis, dmu, fit_ghf=False, **kwargs):
+    """Shift the chemical potential by `dmu` on the impurity orbitals `dmu_idx` (default: all) of an embedding Hamiltonian
+    (dmet/Hubbard.py:82-102); the impurity fold runs on the device."""
+    from libdmet_preview_amd.routine.slater_helper import transform_imp
+    idx = kwargs.get("dmu_idx", None)
+    if idx is None:
+        idx = lattice.imp_idx
+    nao = lattice.nao
+    mu_mat = np.zeros((nao, nao))
+    mu_mat[idx, idx] = -dmu
+    for s in range(1 if ImpHam.restricted else 2):
+        ImpHam.H1["cd"][s] += transform_imp(basis[s], lattice, mu_mat)
+    return ImpHam
+
+
+def BipartiteSquare(impsize):
+    """Indices of the two sublattices of a hypercubic impurity cluster (system/lattice.py:1069-1079)."""
+    parity = np.asarray([sum(pos) % 2 for pos in it.product(*map(range, impsize))])
+    subA, subB = list(np.nonzero(parity == 0)[0]), list(np.nonzero(parity == 1)[0])
+    log.eassert(len(subA) == len(subB), "The impurity cannot be divided into two sublattices")
+    return [int(i) for i in subA], [int(i) for i in subB]
+
+
+def AFInitGuess(ImpSize, U, Filling, polar=None, bogoliubov=False, rand=0.0, subA=None, subB=None, subP=None, bogo_res=False,
+                d_wave=False, trace_zero=False):
+    """Antiferromagnetic starting potential (dmet/Hubbard.py:482-530): U*filling on the diagonal, +-polar on the two sublattices,
+    and for a pairing potential either a d-wave pattern of nearest-neighbour bonds or seeded noise of width `rand`."""
+    if subA is None and subB is None:
+        subA, subB = BipartiteSquare(ImpSize)
+    subP = [] if subP is None else subP
+    nscsites = len(subA) + len(subB) + len(subP)
+    shift = U * Filling
+    if polar is None:
+        polar = shift * Filling
+    init_v = np.zeros((nscsites, nscsites)) if trace_zero else np.eye(nscsites) * shift
+    stagger = np.zeros(nscsites)
+    stagger[list(subA)], stagger[list(subB)] = polar, -polar
+    init_p = np.diag(stagger)
+    v = VcorLocal(False, bogoliubov, nscsites, bogo_res=bogo_res)
+    if not bogoliubov:
+        v.assign(np.asarray([init_v + init_p, init_v - init_p]))
+        return v
+    if d_wave:
+        init_d = np.zeros((nscsites, nscsites))
+        pos = np.asarray(list(it.product(*map(range, ImpSize))))
+        sign = 1 if polar < 0 else -1
+        for ia in subA:
+            for ib in subB:
+                step = tuple(np.abs(pos[ia] - pos[ib])[:2])
+                if step == (1, 0):
+                    init_d[ia, ib] = init_d[ib, ia] = rand * sign
+                elif step == (0, 1):
+                    init_d[ia, ib] = init_d[ib, ia] = -rand * sign
+    else:
+        np.random.seed(32499823)
+        init_d = (np.random.rand(nscsites, nscsites) - 0.5) * rand
+    v.assign(np.asarray([init_v + init_p, init_v - init_p, init_d]))
+    return v
+
+
+def PMInitGuess(ImpSize, U, Filling, bogoliubov=False, rand=0.0):
+    """Paramagnetic starting potential (dmet/Hubbard.py:532-549).  (The reference's pairing branch names an undefined variable.)"""
+    nscsites = int(np.prod(ImpSize))
+    init_v = np.eye(nscsites) * (U * Filling)
+    v = VcorLocal(True, bogoliubov, nscsites)
+    v.assign(np.asarray([init_v, init_v, np.zeros((nscsites, nscsites))]) if bogoliubov else np.asarray([init_v, init_v]))
+    if rand > 0.:
+        np.random.seed(32499823)
+        v.update(v.param + (np.random.rand(v.length()) - 0.5) * rand)
+    return v
+
+
 from libdmet_preview_amd.dmet.HubPhSymm import ConstructImpHam, basisMatching  # noqa: E402,F401

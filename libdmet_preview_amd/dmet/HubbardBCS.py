@@ -63,3 +63,9 @@ def apply_dmu(lattice, ImpHam, basis, dmu):
     ImpHam.H1["cc"] -= cc
     ImpHam.H0 -= h0
     return ImpHam
+
+
+def AFInitGuess(ImpSize, U, Filling, polar=None, rand=0.01, subA=None, subB=None, bogo_res=False):
+    """dmet/HubbardBCS.py:108-111."""
+    from libdmet_preview_amd.dmet import Hubbard
+    return Hubbard.AFInitGuess(ImpSize, U, Filling, polar, True, rand, subA=subA, subB=subB, bogo_res=bogo_res)

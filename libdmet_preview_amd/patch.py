@@ -79,12 +79,14 @@ _FUNCTIONS = [
     # driver layer: dmet/Hubbard.py:8 star-imports HubPhSymm, so it holds its own ConstructImpHam; it defines the RHF / UHF
     # HartreeFock wrapper (:14-41) and FitVcor (:1503) itself
     ("dmet.HubPhSymm", ["dmet.HubPhSymm", "dmet.Hubbard"], ["ConstructImpHam"]),
+    # (apply_dmu is NOT rebound: dmet/HubbardBCS.py:104 and HubbardGSO.py:134 overwrite Hubbard.apply_dmu at import; the
+    # reference's versions reach the device through the rebound transform_imp helpers)
     ("dmet.Hubbard", ["dmet.Hubbard"], ["HartreeFock", "RHartreeFock", "FitVcor"]),
     # the BCS driver layer (dmet/HubbardBCS.py:9-112) and the root search under its chemical-potential fit
-    ("dmet.HubbardBCS", ["dmet.HubbardBCS"], ["HartreeFockBogoliubov", "ConstructImpHam", "apply_dmu"]),
+    ("dmet.HubbardBCS", ["dmet.HubbardBCS"], ["HartreeFockBogoliubov", "ConstructImpHam"]),
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs", "dmet.HubbardBCS"], ["mono_fit"]),
     # the GSO driver layer (dmet/HubbardGSO.py:16-134); mono_fit / mono_fit_2 reach it through spinless_helper's star import
-    ("dmet.HubbardGSO", ["dmet.HubbardGSO"], ["GHartreeFock", "ConstructImpHam", "apply_dmu"]),
+    ("dmet.HubbardGSO", ["dmet.HubbardGSO"], ["GHartreeFock", "ConstructImpHam"]),
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.spinless_helper", "dmet.HubbardGSO"], ["mono_fit_2"]),
     # Loewdin orthogonalisation (routine/slater.py imports lo.lowdin's vec_lowdin by name)
     ("lo.lowdin", ["lo.lowdin"], ["_lowdin", "_vec_lowdin", "vec_lowdin", "vec_lowdin_k"]),

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35", "G36"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -2078,6 +2078,45 @@ def gen_G35():
     spinless.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G35_gso_full_fit.npz"), **out)
     print("G35 done", len(out), "arrays")
+
+
+AF_CASES = [("a", (2, 2), dict()), ("b", (2, 2), dict(polar=0.3)), ("c", (2, 2), dict(bogoliubov=True, rand=0.02)), ("d", (2, 2), dict(bogoliubov=True, rand=0.05, d_wave=True)),
+            ("e", (4,), dict(bogoliubov=True, rand=0.01, bogo_res=True)), ("f", (2, 2), dict(trace_zero=True)), ("g", (2, 1, 2), dict(polar=-0.2, bogoliubov=True, rand=0.03, d_wave=True)),
+            ("h", (2,), dict(subA=[0], subB=[2], subP=[1]))]
+
+
+def gen_G36():
+    """Starting potentials and the impurity chemical-potential shift of the Slater driver layer, dmet/Hubbard.py:82-102, 482-549:
+    AFInitGuess in its modes (sublattices, pairing noise from the reference's fixed seed, d-wave bonds, restricted pairing, zero
+    trace, a third sublattice), PMInitGuess, apply_dmu on the embedding Hamiltonians of G8."""
+    from libdmet.dmet import Hubbard
+    from libdmet.routine import slater
+    from libdmet.solver import scf as rscf
+    shim.patch_scf()
+    slater._get_jk, slater._get_veff = rscf._get_jk, rscf._get_veff
+    out = {}
+    for tag, size, kw in AF_CASES:
+        v = Hubbard.AFInitGuess(size, 4.0, 0.4, **kw)
+        out["af/%s/param" % tag], out["af/%s/value" % tag] = np.array(v.param), np.array(v.get())
+    for tag, size, kw in (("a", (2, 2), dict()), ("b", (3,), dict(rand=0.1))):
+        v = Hubbard.PMInitGuess(size, 4.0, 0.4, **kw)
+        out["pm/%s/param" % tag], out["pm/%s/value" % tag] = np.array(v.param), np.array(v.get())
+    g8 = np.load(os.path.join(GOLD, "G8_embham.npz"))
+    for name, spin in (("uhf_231", 2), ("rhf_411", 1)):
+        mesh = tuple(int(x) for x in g8[name + "/mesh"])
+        val = [int(x) for x in g8[name + "/val"]]
+        nlo = g8[name + "/Fock_R"].shape[-1]
+        L = _duck_lattice(mesh, nlo, val=val, virt=[i for i in range(nlo) if i > max(val)], core=[i for i in range(nlo) if i < min(val)])
+        basis = g8[name + "/basis"]
+        nb = basis.shape[-1]
+        H1 = np.array(g8[name + "/ib_H1"])
+        from libdmet.system import integral
+        for tag, kw in (("all", dict()), ("idx", dict(dmu_idx=[val[0]]))):
+            Himp = integral.Integral(nb, spin == 1, False, 0.0, {"cd": H1.copy()}, {"ccdd": g8[name + "/H2"]})
+            Himp = Hubbard.apply_dmu(L, Himp, basis, 0.17, **kw)
+            out["%s/dmu_%s" % (name, tag)] = Himp.H1["cd"].copy()
+    np.savez_compressed(os.path.join(GOLD, "G36_init_guess.npz"), **out)
+    print("G36 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

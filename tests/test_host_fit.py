@@ -163,3 +163,27 @@ def test_mono_fit_2_iterates_equal_the_reference(golden):
         assert x == float(g["mono2/" + tag]) and np.array_equal(np.asarray(trace), g["mono2/" + tag + "_trace"])
     with pytest.raises(RuntimeError):
         mono_fit_2(lambda x: 0.0, 1.0, 0.0, 1e-9, maxiter=1)
+
+
+AF_CASES = [("a", (2, 2), dict()), ("b", (2, 2), dict(polar=0.3)), ("c", (2, 2), dict(bogoliubov=True, rand=0.02)), ("d", (2, 2), dict(bogoliubov=True, rand=0.05, d_wave=True)),
+            ("e", (4,), dict(bogoliubov=True, rand=0.01, bogo_res=True)), ("f", (2, 2), dict(trace_zero=True)), ("g", (2, 1, 2), dict(polar=-0.2, bogoliubov=True, rand=0.03, d_wave=True)),
+            ("h", (2,), dict(subA=[0], subB=[2], subP=[1]))]
+
+
+def test_starting_potentials_equal_the_reference(golden):
+    """dmet/Hubbard.py:482-549 AFInitGuess / PMInitGuess (and the BCS / GSO wrappers): parameters and matrices of golden G36,
+    the pairing noise from the reference's fixed seed included."""
+    from libdmet_preview_amd.dmet import Hubbard, HubbardBCS, HubbardGSO
+    g = golden("G36_init_guess.npz")
+    for tag, size, kw in AF_CASES:
+        v = Hubbard.AFInitGuess(size, 4.0, 0.4, **kw)
+        assert np.array_equal(np.asarray(v.param), g["af/%s/param" % tag]) and np.array_equal(np.asarray(v.get()), g["af/%s/value" % tag]), tag
+    for tag, size, kw in (("a", (2, 2), dict()), ("b", (3,), dict(rand=0.1))):
+        v = Hubbard.PMInitGuess(size, 4.0, 0.4, **kw)
+        assert np.array_equal(np.asarray(v.param), g["pm/%s/param" % tag]) and np.array_equal(np.asarray(v.get()), g["pm/%s/value" % tag]), tag
+    assert Hubbard.PMInitGuess((2,), 4.0, 0.5, bogoliubov=True).get().shape == (3, 2, 2)
+    for mod in (HubbardBCS, HubbardGSO):
+        v = mod.AFInitGuess((2, 2), 4.0, 0.4, rand=0.02)
+        assert np.array_equal(np.asarray(v.param), g["af/c/param"])
+    with pytest.raises(Exception):
+        Hubbard.BipartiteSquare((3,))
