@@ -260,7 +260,7 @@ def FitVcorEmb(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, CG_chec
     ctx = get_ctx()
     d_dV = ctx.to_device(np.ascontiguousarray(table[:, tl[0], tl[1]]).reshape(vcor.length(), 1, len(tl[0])))
     finite = beta < np.inf
-    fit = slater.EmbFitDevice(ctx, np.asarray(GRho)[np.newaxis], lattice, np.zeros((1, 1, 1, dim)), vcor, beta, nb, list(range(dim)), [],
+    fit = slater.EmbFitDevice(ctx, np.asarray(GRho)[np.newaxis], lattice, None, vcor, beta, nb, list(range(dim)), [],
                               None, None, mu0=kwargs.get("mu0", 0.0) if finite else None,
                               fix_mu=kwargs.get("fix_mu", True) if finite else False, eigh=kwargs.get("eigh", "jacobi"),
                               operators=(embH, np.eye(dim)), dV_table=d_dV, norm=np.sqrt(2.0))

@@ -623,8 +623,13 @@ class EmbFitDevice(object):
         from libdmet_preview_amd.routine import mfd
         self._mfd = mfd
         self.ctx, self.vcor = ctx, vcor
-        basis = np.asarray(basis, dtype=np.float64)
-        self.spin, self.nb = basis.shape[0], basis.shape[-1]
+        if operators is not None:                            # the embedded operators say how many blocks of which size there are
+            log.eassert(dV_table is not None or basis is not None, "EmbFitDevice: handed-over operators need the dV table or the basis")
+            embH1_given = np.asarray(operators[0], dtype=np.float64)
+            self.spin, self.nb = (1, embH1_given.shape[-1]) if embH1_given.ndim == 2 else (embH1_given.shape[0], embH1_given.shape[-1])
+        else:
+            basis = np.asarray(basis, dtype=np.float64)
+            self.spin, self.nb = basis.shape[0], basis.shape[-1]
         spin, nb = self.spin, self.nb
         self.npair = nb * (nb + 1) // 2
         self.beta, self.nelec, self.mu0, self.fix_mu, self.tol_deg = beta, nelec, mu0, fix_mu, tol_deg

@@ -496,7 +496,7 @@ def FitVcorEmb(rho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, imp_fit=
     ctx = get_ctx()
     d_dV = slater.get_dV_dparam_dev(ctx, _SpinOrbitalPotential(vcor, nao), basis[np.newaxis])
     vcor.grad = None
-    fit = slater.EmbFitDevice(ctx, np.asarray(rho)[np.newaxis], lattice, basis[np.newaxis], vcor, beta, nelec, imp_idx, det_idx, None, None,
+    fit = slater.EmbFitDevice(ctx, np.asarray(rho)[np.newaxis], lattice, None, vcor, beta, nelec, imp_idx, det_idx, None, None,
                               mu0=kwargs.get("mu0", None), fix_mu=kwargs.get("fix_mu", False), tol_deg=kwargs.get("tol_deg", 1e-3),
                               eigh=kwargs.get("eigh", "jacobi"), operators=(embH1, ovlp_emb), dV_table=d_dV, norm=np.sqrt(2.0))
     return slater.drive_emb_fit(fit, vcor, param_begin, beta, MaxIter, CG_check, BFGS, diff_criterion, kwargs, FitVcorEmb,
