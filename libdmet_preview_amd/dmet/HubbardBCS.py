@@ -16,42 +16,34 @@ from libdmet_preview_amd.utils import logger as log
 def HartreeFockBogoliubov(Lat, v, filling, mu0, beta=np.inf, fix_mu=False, thrnelec=1e-6, **kwargs):
     """HFB with the particle chemical potential fitted so that the density per spin orbital is `filling` (None: `mu0` is used as
     is); `fix_mu` keeps the quasiparticle level at 0.  Returns (GRho, mu) or, with `full_return`, (GRho, mu, res)."""
-    if beta == np.inf:
-        log.info("Using 0 T on lattice, beta = %s", beta)
-    else:
-        log.info("Using finite T on lattice, beta = %15.6f ", beta)
-        log.info("Using fixed quasi particle fermi_level = 0.0 ? %s", fix_mu)
+    log.info("lattice mean field at %s", "T = 0" if beta == np.inf else "beta = %.6f (quasiparticle level %s)" % (beta, "fixed at 0" if fix_mu else "fitted"))
     if filling is None:
         mu = mu0
     else:
-        log.info("chemical potential fitting, target = %20.12f", filling)
-        log.info("before fitting, mu = %20.12f", mu0)
+        log.info("fitting mu to the filling %.12f, starting from %.12f", filling, mu0)
         density = lambda x: HFB(Lat, v, False, mu=x, beta=beta, fix_mu=fix_mu, ires=False, **kwargs)[1] / 2. / Lat.nscsites
         mu = mono_fit(density, filling, mu0, thrnelec, increase=True)
-        log.info("after fitting, mu = %20.12f", mu)
-        log.info("after fitting, f(x) = %20.12f", density(mu))
+        log.info("fitted mu = %.12f, filling there = %.12f", mu, density(mu))
     rho, n, E, res = HFB(Lat, v, False, mu=mu, beta=beta, fix_mu=fix_mu, ires=True, **kwargs)
     if filling is None:
         rhoA, rhoB, kappaBA = extractRdm(rho[0])
-        log.result("Local density matrix (mean-field): alpha, beta and pairing\n%s\n%s\n%s", rhoA, rhoB, kappaBA.T)
-        log.result("nelec per cell (mean-field) = %20.12f", n)
-        log.result("Energy per cell (mean-field) = %20.12f", E)
-        log.result("Gap (mean-field) = %20.12f" % res["gap"])
+        log.result("mean-field cell-0 density blocks (alpha, beta, pairing):\n%s\n%s\n%s", rhoA, rhoB, kappaBA.T)
+        log.result("mean field per cell: nelec %.12f, energy %.12f, gap %.12f", n, E, res["gap"])
     return (rho, mu, res) if kwargs.get("full_return", False) else (rho, mu)
 
 
 def ConstructImpHam(Lat, GRho, v, mu, matching=True, local=True, **kwargs):
     """(ImpHam, (H1 for the energy, its H0), basis): bath, optional alpha / beta matching of the bath columns, Hamiltonian."""
-    log.result("Making embedding basis")
+    log.result("bath orbitals")
     basis = bcs.embBasis(Lat, GRho, local=local, **kwargs)
     if matching:
-        log.result("Rotate bath orbitals to match alpha and beta basis")
+        log.result("alpha / beta matching of the bath")
         nbasis = basis.shape[-1]
         if local:
             basis[:, :, :, nbasis // 2:] = basisMatching(basis[:, :, :, nbasis // 2:])
         else:
             basis = basisMatching(basis)
-    log.result("Constructing impurity Hamiltonian")
+    log.result("embedding Hamiltonian")
     ImpHam, (H1e, H0e) = bcs.embHam(Lat, basis, v, mu, local=local, **kwargs)
     return ImpHam, (H1e, H0e), basis
 

@@ -16,35 +16,27 @@ from libdmet_preview_amd.utils import logger as log
 def GHartreeFock(Lat, v, filling, mu0_elec, beta=np.inf, fix_mu=False, thrnelec=1e-8, **kwargs):
     """GHF with the particle chemical potential fitted so that the density per spin orbital is `filling` (None: `mu0_elec` is used
     as is).  Returns (GRho, mu) or, with `full_return`, (GRho, mu, res)."""
-    if beta == np.inf:
-        log.info("Using 0 T on lattice, beta = %s", beta)
-    else:
-        log.info("Using finite T on lattice, beta = %15.6f ", beta)
-        log.info("Using fixed quasi particle fermi_level = 0.0 ? %s", fix_mu)
+    log.info("lattice mean field at %s", "T = 0" if beta == np.inf else "beta = %.6f (quasiparticle level %s)" % (beta, "fixed at 0" if fix_mu else "fitted"))
     if filling is None:
         mu = mu0_elec
     else:
-        log.info("chemical potential fitting, target = %20.12f", filling)
-        log.info("before fitting, mu = %20.12f", mu0_elec)
+        log.info("fitting mu to the filling %.12f, starting from %.12f", filling, mu0_elec)
         density = lambda x: GHF(Lat, v, False, mu=x, beta=beta, fix_mu=fix_mu, ires=False, **kwargs)[1] / (Lat.nscsites * 2.0)
         mu = mono_fit_2(density, filling, mu0_elec, thrnelec, increase=True)
-        log.info("after fitting, mu = %20.12f", mu)
-        log.info("after fitting, f(x) = %20.12f", density(mu))
+        log.info("fitted mu = %.12f, filling there = %.12f", mu, density(mu))
     rho, n, E, res = GHF(Lat, v, False, mu=mu, beta=beta, fix_mu=fix_mu, ires=True, **kwargs)
     if filling is None:
         rhoA, rhoB, kappaAB = extractRdm(rho[0])
-        log.result("Local density matrix (mean-field): alpha, beta and pairing\n%s\n%s\n%s", rhoA, rhoB, kappaAB)
-        log.result("nelec per cell (mean-field) = %20.12f", n)
-        log.result("Energy per cell (mean-field) = %20.12f", E)
-        log.result("Gap (mean-field) = %20.12f" % res["gap"])
+        log.result("mean-field cell-0 density blocks (alpha, beta, pairing):\n%s\n%s\n%s", rhoA, rhoB, kappaAB)
+        log.result("mean field per cell: nelec %.12f, energy %.12f, gap %.12f", n, E, res["gap"])
     return (rho, mu, res) if kwargs.get("full_return", False) else (rho, mu)
 
 
 def ConstructImpHam(Lat, GRho, v, mu, matching=True, local=True, **kwargs):
     """(ImpHam, None, basis)."""
-    log.result("Making embedding basis")
+    log.result("bath orbitals")
     basis = spinless.embBasis(Lat, GRho, local=local, **kwargs)
-    log.result("Constructing impurity Hamiltonian")
+    log.result("embedding Hamiltonian")
     ImpHam, _ = spinless.embHam(Lat, basis, v, mu, local=local, **kwargs)
     return ImpHam, None, basis
 
