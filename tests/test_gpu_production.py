@@ -648,3 +648,16 @@ def test_engines_with_padded_geometry_give_their_memory_back(ctx):
         if it == 9:
             mark = free
     assert mark - free < (1 << 20), (mark, free)             # (it may grow: blocks parked by earlier tests are handed back over time)
+
+
+def test_randomised_twins_campaign_short():
+    """tools/twins_stress.py with a fixed seed: 60 random lattices through mfd.HFB / GHF, spinless.get_emb_Ham, the GSO embedding and
+    lattice fits, the cell-resolved potential's dV/dparam and the k-resolved lattice fit against the oracle.  The long campaign (1600
+    lattices, worst 1e-11) is profiles/r06_t_twins_stress_1600_trials.txt."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEED="20261003", STRESS_TRIALS="60", GRAFT_REPO_ROOT=root)
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "twins_stress.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    out = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["trials"] == 60 and len(out["worst"]) >= 12 and max(out["worst"].values()) < 1e-8
