@@ -58,9 +58,12 @@ class _VcorLocal(vcor.Vcor):
     def length(self):
         return self.nV + self.nD
 
+    def _blocks(self):
+        return getattr(self, "_nblk", None) or (3 if self.bogoliubov else 2)
+
     def evaluate(self):
         log.eassert(self.param.shape == (self.length(),), "wrong parameter shape, require %s", (self.length(),))
-        V = np.zeros((3 if self.bogoliubov else 2, self.nscsites, self.nscsites))
+        V = np.zeros((self._blocks(), self.nscsites, self.nscsites))
         for off, blk, sign, pairs, mirror in self._terms:
             for idx, (i, j) in enumerate(pairs):
                 V[blk, i, j] = sign * self.param[idx + off]
@@ -70,7 +73,7 @@ class _VcorLocal(vcor.Vcor):
 
     def gradient(self):
         if self.grad is None:
-            g = np.zeros((self.length(), 3 if self.bogoliubov else 2, self.nscsites, self.nscsites))
+            g = np.zeros((self.length(), self._blocks(), self.nscsites, self.nscsites))
             for off, blk, sign, pairs, mirror in self._terms:
                 for idx, (i, j) in enumerate(pairs):
                     g[idx + off, blk, i, j] = sign
@@ -112,6 +115,57 @@ class _VcorLocal(vcor.Vcor):
         head = ["vcor", "nao %d" % v.shape[-1], "fitted orbitals %s (%d)" % (self.idx_range, len(self.idx_range)),
                 "restricted %s, bogoliubov %s (restricted pairing %s)" % (self.restricted, self.bogoliubov, self.bogo_res)]
         return "\n".join(head + [str(fitted)])
+
+
+class _VcorRestricted(_VcorLocal):
+    """Full potential on the active orbitals, diagonal potential on the core orbitals, no pairing on the core
+    (dmet/Hubbard.py:788-938): the assignment table of _VcorLocal with two pair lists per normal block.  A restricted potential
+    without pairing has ONE block, like the reference."""
+
+    def __init__(self, restricted, bogoliubov, active_sites, core_sites, bogo_res, nscsites):
+        vcor.Vcor.__init__(self)
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, bogoliubov, bogo_res
+        active, core = [int(i) for i in active_sites], [int(i) for i in core_sites]
+        nact, ncor = len(active), len(core)
+        if nscsites is None:
+            nscsites = nact + ncor
+        elif nscsites != nact + ncor:
+            log.warn("nscsites (%s) != nAct (%s) + nCor (%s)", nscsites, nact, ncor)
+        self.nscsites, self.idx_range = nscsites, active
+        self.grad = self.diag_idx = self._v_idx_diag = None
+        ntri = nact * (nact + 1) // 2
+        sym, diag = list(it.combinations_with_replacement(active, 2)), [(i, i) for i in core]
+        nV0 = ntri if restricted else 2 * ntri
+        self.nV = nV0 + (ncor if restricted else 2 * ncor)
+        if not bogoliubov:
+            self.nD = 0
+        elif restricted or bogo_res:
+            self.nD = ntri
+        else:
+            self.nD = nact * nact
+        if bogoliubov and not restricted and bogo_res:
+            raise NotImplementedError("VcorRestricted(unrestricted, restricted pairing): the reference counts a symmetric pairing block "
+                                      "and writes a general one (dmet/Hubbard.py:822-825, 913-914)")
+        nV = self.nV
+        if restricted and not bogoliubov:
+            self._nblk = 1
+            self._terms = [(0, 0, 1, sym, True), (nV0, 0, 1, diag, False)]
+        elif not bogoliubov:
+            self._terms = [(0, 0, 1, sym, True), (nV0 // 2, 1, 1, sym, True), (nV0, 0, 1, diag, False), (nV0 + ncor, 1, 1, diag, False)]
+        elif restricted:
+            self._terms = [(0, 0, 1, sym, True), (0, 1, 1, sym, True), (nV, 2, 1, sym, True), (nV0, 0, 1, diag, False), (nV0, 1, 1, diag, False)]
+        else:
+            self._terms = [(0, 0, 1, sym, True), (nV0 // 2, 1, 1, sym, True), (nV0, 0, 1, diag, False), (nV0 + ncor, 1, 1, diag, False),
+                           (nV, 2, 1, list(it.product(active, repeat=2)), False)]
+        self.update(np.zeros(self.length()))
+
+    def diag_indices(self):
+        raise AttributeError("VcorRestricted has no diag_indices (dmet/Hubbard.py:788-938)")
+
+
+def VcorRestricted(restricted, bogoliubov, active_sites, core_sites, bogo_res=False, nscsites=None):
+    """Full correlation potential on the active sites, diagonal potential on the core sites (dmet/Hubbard.py:788-803)."""
+    return _VcorRestricted(restricted, bogoliubov, active_sites, core_sites, bogo_res, nscsites)
 
 
 def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, v_idx=None, d_idx=None, ghf=False):

@@ -2101,6 +2101,13 @@ def gen_G36():
     for tag, size, kw in (("a", (2, 2), dict()), ("b", (3,), dict(rand=0.1))):
         v = Hubbard.PMInitGuess(size, 4.0, 0.4, **kw)
         out["pm/%s/param" % tag], out["pm/%s/value" % tag] = np.array(v.param), np.array(v.get())
+    for tag, res, bogo in (("r", True, False), ("u", False, False), ("rb", True, True), ("ub", False, True)):
+        v = Hubbard.VcorRestricted(res, bogo, [0, 2, 3], [1, 4])
+        p = np.random.default_rng(len(tag) + 40).standard_normal(v.length())
+        v.update(p)
+        gr = v.gradient()
+        out["vr/%s/param" % tag], out["vr/%s/value" % tag] = p, np.array(v.get())
+        out["vr/%s/grad_shape" % tag], out["vr/%s/grad_nz" % tag] = np.asarray(gr.shape), np.asarray(np.nonzero(gr), dtype=np.int32)
     g8 = np.load(os.path.join(GOLD, "G8_embham.npz"))
     for name, spin in (("uhf_231", 2), ("rhf_411", 1)):
         mesh = tuple(int(x) for x in g8[name + "/mesh"])

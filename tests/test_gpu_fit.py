@@ -491,3 +491,22 @@ def test_fit_c5_shape_objective_and_gradient_vs_oracle(ctx):
     e_big = fit.errfunc(big)
     assert fit.fused_fallbacks >= 1 and abs(e_big - ref.errfunc(big)) < 1e-10
     assert fit.fused_calls > n_fused
+
+
+@pytest.mark.parametrize("name", ["uhf_231", "rhf_411"])
+def test_fit_with_restricted_core_potential(ctx, golden, name):
+    """Hubbard.VcorRestricted (dmet/Hubbard.py:788-938) under the device fit: the dV table from its sparse entries equals the oracle's
+    from the dense gradient, and a short fit lowers the residual."""
+    from libdmet_preview_amd.routine import slater
+    from libdmet_preview_amd.dmet import Hubbard
+    g = golden("G9_vcorfit.npz")
+    mesh, FR, Fk, Sk, basis, target, val, spin, nlo, nelec = fit_inputs(g, name)
+    L = _lattice(mesh, nlo, val, Fk, spin)
+    active, core = val[:-1], [val[-1]] + [i for i in range(nlo) if i not in val]
+    v = Hubbard.VcorRestricted(spin == 1, False, active, core, nscsites=nlo)
+    dV = slater.get_dV_dparam(v, basis, None, L)
+    assert dV.shape == (v.length(), spin, basis.shape[-1] * (basis.shape[-1] + 1) // 2)
+    assert np.abs(dV - F.get_dV_dparam(v, basis)).max() < 1e-13
+    v.update(np.zeros(v.length()))
+    vfit, e0, e1 = slater.FitVcorEmb(target, L, basis, v, np.inf, MaxIter=15)
+    assert vfit is v and e1 < e0
