@@ -168,6 +168,132 @@ def VcorRestricted(restricted, bogoliubov, active_sites, core_sites, bogo_res=Fa
     return _VcorRestricted(restricted, bogoliubov, active_sites, core_sites, bogo_res, nscsites)
 
 
+class _VcorIrreps(vcor.Vcor):
+    """Symmetry-adapted local potentials (dmet/Hubbard.py:940-1494): the potential on `idx_range` is a sum over irreducible
+    representations of  C T C^T  with a small matrix T per irrep -- symmetric (its lower triangle are the parameters) or, for an
+    unrestricted pairing block, general.  ONE list of terms (first parameter, count, block, sign, C, kind) describes every mode of
+    VcorSymm / VcorSymmSpin / VcorSymmBogo; evaluate() sums the terms, gradient() is their Jacobian (columns of C outer columns of
+    C), so the two cannot disagree."""
+
+    def __init__(self, restricted, bogoliubov, bogo_res, nscsites, idx_range, nblk, terms, nparam, diag=None):
+        vcor.Vcor.__init__(self)
+        self.restricted, self.bogoliubov, self.bogo_res = restricted, bogoliubov, bogo_res
+        self.nscsites, self.idx_range, self._nblk, self._terms, self.nparam = nscsites, list(idx_range), nblk, terms, int(nparam)
+        self.grad, self.diag_idx, self._diag = None, None, diag
+        self._mesh = np.ix_(self.idx_range, self.idx_range)
+        self.update(np.zeros(self.nparam))
+
+    def length(self):
+        return self.nparam
+
+    @staticmethod
+    def _small(kind, params, n):
+        if kind == "full":
+            return params.reshape(n, n)
+        T = np.zeros((n, n))
+        lo = np.tril_indices(n)
+        T[lo] = params
+        T[(lo[1], lo[0])] = params
+        return T
+
+    def evaluate(self):
+        log.eassert(self.param.shape == (self.nparam,), "wrong parameter shape, require %s", (self.nparam,))
+        V = np.zeros((self._nblk, self.nscsites, self.nscsites))
+        for start, count, blk, sign, C, kind in self._terms:
+            V[blk][self._mesh] += sign * (C @ self._small(kind, np.asarray(self.param[start:start + count]), C.shape[-1]) @ C.conj().T)
+        return V
+
+    def gradient(self):
+        if self.grad is None:
+            g = np.zeros((self.nparam, self._nblk, self.nscsites, self.nscsites))
+            for start, count, blk, sign, C, kind in self._terms:
+                n = C.shape[-1]
+                rows, cols = (np.repeat(np.arange(n), n), np.tile(np.arange(n), n)) if kind == "full" else np.tril_indices(n)
+                left, right = C[:, rows].T, C[:, cols].T                                   # (count, nidx)
+                block = left[:, :, None] * right[:, None, :]
+                if kind != "full":
+                    off = rows != cols
+                    block[off] += right[off][:, :, None] * left[off][:, None, :]
+                sub = np.zeros((count, self.nscsites, self.nscsites))
+                sub[(slice(None),) + self._mesh] = sign * block
+                g[start:start + count, blk] += sub
+            self.grad = g
+        return self.grad
+
+    def diag_indices(self):
+        if self._diag is not None and self.diag_idx is None:
+            self.diag_idx = self._diag()
+        return self.diag_idx
+
+
+def _irrep_setup(nscsites, idx_range, blocks):
+    if idx_range is None:
+        idx_range = list(range(0, nscsites))
+    blocks = [np.asarray(C, dtype=np.float64) for C in blocks]
+    assert sum(C.shape[-1] for C in blocks) == blocks[0].shape[0] and len(idx_range) == blocks[0].shape[0]
+    return list(idx_range), blocks
+
+
+def VcorSymm(restricted, bogoliubov, nscsites, C_symm, idx_range=None, bogo_res=False):
+    """Point-group adapted local potential, one symmetric block per irrep and spin (dmet/Hubbard.py:940-1144; the reference
+    implements the unrestricted mode without pairing)."""
+    if restricted or bogoliubov:
+        raise NotImplementedError
+    idx_range, Cs = _irrep_setup(nscsites, idx_range, C_symm)
+    terms, at = [], 0
+    for C in Cs:
+        ntri = C.shape[-1] * (C.shape[-1] + 1) // 2
+        terms += [(at, ntri, 0, 1.0, C, "tril"), (at + ntri, ntri, 1, 1.0, C, "tril")]
+        at += 2 * ntri
+
+    def diag():
+        a, b, offset = [], [], 0
+        for C in Cs:
+            n = C.shape[-1]
+            idx = np.cumsum([0] + list(range(2, n + 1))) + offset                     # utils.tril_diag_indices
+            a.extend(idx)
+            b.extend(idx + n * (n + 1) // 2)
+            offset += n * (n + 1)
+        return [a, b]
+    return _VcorIrreps(False, False, bogo_res, nscsites, idx_range, 2, terms, at, diag)
+
+
+def VcorSymmSpin(restricted, bogoliubov, nscsites, Ca, Cb, idx_range=None, bogo_res=False):
+    """Symmetry-adapted potential whose two spin blocks share their parameters through different orbital sets Ca / Cb
+    (dmet/Hubbard.py:1146-1352): V_a = Ca T Ca^T, V_b = +-Cb T Cb^T (minus with pairing), pairing Ca D Ca^T."""
+    if restricted:
+        raise NotImplementedError
+    assert len(Ca) == len(Cb)
+    idx_range, As = _irrep_setup(nscsites, idx_range, Ca)
+    Bs = [np.asarray(C, dtype=np.float64) for C in Cb]
+    terms, at = [], 0
+    for A, Bm in zip(As, Bs):
+        n = A.shape[-1]
+        ntri = n * (n + 1) // 2
+        terms += [(at, ntri, 0, 1.0, A, "tril"), (at, ntri, 1, -1.0 if bogoliubov else 1.0, Bm, "tril")]
+        at += ntri
+        if bogoliubov:
+            nD = ntri if bogo_res else n * n
+            terms.append((at, nD, 2, 1.0, A, "tril" if bogo_res else "full"))
+            at += nD
+    return _VcorIrreps(False, bogoliubov, bogo_res, nscsites, idx_range, 3 if bogoliubov else 2, terms, at, None)
+
+
+def VcorSymmBogo(restricted, bogoliubov, nscsites, Ca, Cb, idx_range=None, bogo_res=False):
+    """Symmetry-adapted PAIRING potential alone (dmet/Hubbard.py:1354-1494): only block 2 carries parameters."""
+    if restricted or not bogoliubov:
+        raise NotImplementedError
+    assert len(Ca) == len(Cb)
+    idx_range, As = _irrep_setup(nscsites, idx_range, Ca)
+    terms, at = [], 0
+    for A in As:
+        n = A.shape[-1]
+        nD = n * (n + 1) // 2 if bogo_res else n * n
+        terms.append((at, nD, 2, 1.0, A, "tril" if bogo_res else "full"))
+        at += nD
+    return _VcorIrreps(False, True, bogo_res, nscsites, idx_range, 3, terms, at, None)
+
+
 def VcorLocal(restricted, bogoliubov, nscsites, idx_range=None, bogo_res=False, v_idx=None, d_idx=None, ghf=False):
     """Local correlation potential on `idx_range` (default: all nscsites orbitals)."""
     if idx_range is None:

@@ -62,7 +62,7 @@ _FUNCTIONS = [
     # the cell-resolved and the k-point-resolved potentials (dmet/Hubbard.py:1495-1497 re-exports them): the index-table classes the
     # device dV/dparam builder and the lattice-stage fit read without a dense (nparam, nblk, ncells, nlo, nlo) gradient
     ("routine.vcor", ["routine.vcor", "dmet.Hubbard"], ["VcorNonLocal", "VcorKpoints"]),
-    ("dmet.Hubbard", ["dmet.Hubbard"], ["VcorRestricted"]),
+    ("dmet.Hubbard", ["dmet.Hubbard"], ["VcorRestricted", "VcorSymm", "VcorSymmSpin", "VcorSymmBogo"]),
     ("routine.vcor", ["routine.vcor"], ["get_kpts_map"]),
     # BCS twin (routine/bcs.py:13 star-imports bcs_helper)
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],

@@ -2108,6 +2108,25 @@ def gen_G36():
         gr = v.gradient()
         out["vr/%s/param" % tag], out["vr/%s/value" % tag] = p, np.array(v.get())
         out["vr/%s/grad_shape" % tag], out["vr/%s/grad_nz" % tag] = np.asarray(gr.shape), np.asarray(np.nonzero(gr), dtype=np.int32)
+    # symmetry-adapted potentials (dmet/Hubbard.py:940-1494): two irreps of sizes 2 and 3 on five of seven orbitals
+    rngs = np.random.default_rng(77)
+    Q, Qb = np.linalg.qr(rngs.standard_normal((5, 5)))[0], np.linalg.qr(rngs.standard_normal((5, 5)))[0]
+    Ca, Cb, idx = [Q[:, :2], Q[:, 2:]], [Qb[:, :2], Qb[:, 2:]], [0, 2, 3, 5, 6]
+    out["vs/Q"], out["vs/Qb"] = Q, Qb
+    makers = [("symm", lambda: Hubbard.VcorSymm(False, False, 7, Ca, idx_range=idx), True),
+              ("spin", lambda: Hubbard.VcorSymmSpin(False, False, 7, Ca, Cb, idx_range=idx), True),
+              ("spin_bres", lambda: Hubbard.VcorSymmSpin(False, True, 7, Ca, Cb, idx_range=idx, bogo_res=True), True),
+              ("spin_b", lambda: Hubbard.VcorSymmSpin(False, True, 7, Ca, Cb, idx_range=idx), False),
+              ("bogo_res", lambda: Hubbard.VcorSymmBogo(False, True, 7, Ca, Cb, idx_range=idx, bogo_res=True), True),
+              ("bogo", lambda: Hubbard.VcorSymmBogo(False, True, 7, Ca, Cb, idx_range=idx), False)]
+    for tag, make, with_grad in makers:
+        v = make()
+        p = rngs.standard_normal(v.length())
+        v.update(p)
+        out["vs/%s/param" % tag], out["vs/%s/value" % tag] = p, np.array(v.get())
+        if with_grad:                      # (the gradient loops of the general-pairing modes index the irrep block with lattice orbitals)
+            out["vs/%s/grad" % tag] = np.array(v.gradient())
+    out["vs/symm/diag"] = np.asarray(Hubbard.VcorSymm(False, False, 7, Ca, idx_range=idx).diag_indices())
     g8 = np.load(os.path.join(GOLD, "G8_embham.npz"))
     for name, spin in (("uhf_231", 2), ("rhf_411", 1)):
         mesh = tuple(int(x) for x in g8[name + "/mesh"])

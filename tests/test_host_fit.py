@@ -209,3 +209,34 @@ def test_vcor_restricted_equals_the_reference(golden, tag, res, bogo):
     if not res and bogo:
         with pytest.raises(NotImplementedError):
             Hubbard.VcorRestricted(False, True, [0, 1], [2], bogo_res=True)
+
+
+def test_symmetry_adapted_potentials_equal_the_reference(golden):
+    """dmet/Hubbard.py:940-1494 VcorSymm / VcorSymmSpin / VcorSymmBogo in every mode the reference implements: value and gradient
+    against golden G36 (1e-14: products of the irrep orbitals), gradient = Jacobian of the value, diag_indices."""
+    from libdmet_preview_amd.dmet import Hubbard
+    g = golden("G36_init_guess.npz")
+    Q, Qb = g["vs/Q"], g["vs/Qb"]
+    Ca, Cb, idx = [Q[:, :2], Q[:, 2:]], [Qb[:, :2], Qb[:, 2:]], [0, 2, 3, 5, 6]
+    makers = [("symm", lambda: Hubbard.VcorSymm(False, False, 7, Ca, idx_range=idx)),
+              ("spin", lambda: Hubbard.VcorSymmSpin(False, False, 7, Ca, Cb, idx_range=idx)),
+              ("spin_bres", lambda: Hubbard.VcorSymmSpin(False, True, 7, Ca, Cb, idx_range=idx, bogo_res=True)),
+              ("spin_b", lambda: Hubbard.VcorSymmSpin(False, True, 7, Ca, Cb, idx_range=idx)),
+              ("bogo_res", lambda: Hubbard.VcorSymmBogo(False, True, 7, Ca, Cb, idx_range=idx, bogo_res=True)),
+              ("bogo", lambda: Hubbard.VcorSymmBogo(False, True, 7, Ca, Cb, idx_range=idx))]
+    for tag, make in makers:
+        v = make()
+        p = g["vs/%s/param" % tag]
+        assert v.length() == len(p) and v.is_local() and np.abs(v.get()).max() == 0.0
+        v.update(p)
+        assert np.abs(v.get() - g["vs/%s/value" % tag]).max() < 1e-14, tag
+        gr = v.gradient()
+        if "vs/%s/grad" % tag in g:
+            assert np.abs(gr - g["vs/%s/grad" % tag]).max() < 1e-14, tag
+        assert np.abs(np.tensordot(p, gr, axes=(0, 0)) - v.get()).max() < 1e-14, tag
+    assert np.array_equal(np.asarray(Hubbard.VcorSymm(False, False, 7, Ca, idx_range=idx).diag_indices()), g["vs/symm/diag"])
+    assert Hubbard.VcorSymmSpin(False, False, 7, Ca, Cb, idx_range=idx).diag_indices() is None
+    for bad in (lambda: Hubbard.VcorSymm(True, False, 7, Ca, idx_range=idx), lambda: Hubbard.VcorSymm(False, True, 7, Ca, idx_range=idx),
+                lambda: Hubbard.VcorSymmSpin(True, False, 7, Ca, Cb, idx_range=idx), lambda: Hubbard.VcorSymmBogo(False, False, 7, Ca, Cb, idx_range=idx)):
+        with pytest.raises(NotImplementedError):
+            bad()
