@@ -404,4 +404,20 @@ def PMInitGuess(ImpSize, U, Filling, bogoliubov=False, rand=0.0):
     return v
 
 
+VcorLocal_new = VcorLocal
+VcorZeros = vcor_zeros
+
+
+def addDiag(v, val, idx_range=None):
+    """dmet/Hubbard.py:1499."""
+    from libdmet_preview_amd.routine import slater
+    return slater.addDiag(v, val, idx_range=idx_range)
+
+
+def make_vcor_trace_unchanged(v_new, v_old, idx_range=None):
+    """dmet/Hubbard.py:1501."""
+    from libdmet_preview_amd.routine import slater
+    return slater.make_vcor_trace_unchanged(v_new, v_old, idx_range=idx_range)
+
+
 from libdmet_preview_amd.dmet.HubPhSymm import ConstructImpHam, basisMatching  # noqa: E402,F401

@@ -68,3 +68,5 @@ def AFInitGuess(ImpSize, U, Filling, polar=None, rand=0.01, subA=None, subB=None
 
 FitVcor = spinless.FitVcorTwoStep
 foldRho_k = spinless.foldRho_k
+addDiag = spinless.addDiag
+keep_vcor_trace_fixed = spinless.keep_vcor_trace_fixed

@@ -1111,6 +1111,40 @@ class EmbFitDevice(object):
         return out
 
 
+def addDiag(v, val, idx_range=None):
+    """Add `val` (a number, or one per spin block) to the diagonal of the normal blocks of a potential on `idx_range` and re-project
+    it on its parameters (slater.py:757-778; the pairing block of a BCS / GSO potential is left alone)."""
+    rep = np.array(v.get(), copy=True)
+    nblk = rep.shape[0]
+    shifts = list(val) if isinstance(val, Iterable) else [val] * nblk
+    if idx_range is None:
+        idx_range = getattr(v, "idx_range", range(rep.shape[-1]))
+    idx = list(idx_range)
+    for s in range(min(nblk, 2)):
+        rep[s, idx, idx] += shifts[s]
+    v.assign(rep)
+    return v
+
+
+def vcor_diag_average(v, idx_range=None):
+    """Mean diagonal element of every block of a potential on `idx_range` (slater.py:780-795)."""
+    rep = np.asarray(v.get())
+    if idx_range is None:
+        idx_range = getattr(v, "idx_range", range(rep.shape[-1]))
+    idx = list(idx_range)
+    return np.average(rep[:, idx, idx], axis=1)
+
+
+def make_vcor_trace_unchanged(v_new, v_old, idx_range=None):
+    """Shift the diagonal of `v_new` so that its trace on `idx_range` equals that of `v_old`, block by block (slater.py:797-818)."""
+    new, old = np.asarray(v_new.get()), np.asarray(v_old.get())
+    if idx_range is None:
+        idx_range = getattr(v_new, "idx_range", range(new.shape[-1]))
+    idx = list(idx_range)
+    drift = np.average((new - old)[:, idx, idx], axis=1)
+    return addDiag(v_new, -drift, idx_range=idx_range)
+
+
 def test_grad(vcor, errfunc, gradfunc, dx=1e-5):
     """Analytic gradient against central differences of the objective, logged (slater.py:820-849); returns the two vectors."""
     param0 = vcor if isinstance(vcor, np.ndarray) else vcor.param.copy()

@@ -626,3 +626,21 @@ def FitVcorFull(rho, lattice, basis, vcor, mu, beta, filling, MaxIter=20, imp_fi
     log.info("Norm diff of x: %15.8f", np.abs(param - param_begin).max())
     FitVcorFull.last_fit = fit
     return vcor, err_begin, err_end
+
+
+def addDiag(v, scalar):
+    """+scalar on the particle block, -scalar on the hole block of a GSO potential, re-projected on its parameters
+    (spinless.py:739-745)."""
+    rep = np.array(v.get(), copy=True)
+    n = rep.shape[1]
+    rep[0] += np.eye(n) * scalar
+    rep[1] -= np.eye(n) * scalar
+    v.assign(rep)
+    return v
+
+
+def keep_vcor_trace_fixed(vcor_new, vcor):
+    """Remove the drift of (mean diagonal of block 0 - mean diagonal of block 1) / 2 between two potentials (spinless.py:747-752)."""
+    d = np.asarray(vcor_new.get()) - np.asarray(vcor.get())
+    drift = (np.average(np.diagonal(d[0])) - np.average(np.diagonal(d[1]))) * 0.5
+    return addDiag(vcor_new, -drift)

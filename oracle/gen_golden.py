@@ -2127,6 +2127,28 @@ def gen_G36():
         if with_grad:                      # (the gradient loops of the general-pairing modes index the irrep block with lattice orbitals)
             out["vs/%s/grad" % tag] = np.array(v.gradient())
     out["vs/symm/diag"] = np.asarray(Hubbard.VcorSymm(False, False, 7, Ca, idx_range=idx).diag_indices())
+    # diagonal helpers of the DMET loop (routine/slater.py:757-818, routine/spinless.py:739-752)
+    from libdmet.routine import spinless as rsp
+    for tag, res, bogo, rng_idx in (("u", False, False, [1, 2]), ("rb", True, True, None)):
+        v = Hubbard.VcorLocal(res, bogo, 4, idx_range=[0, 1, 2] if rng_idx else None)
+        v.update(np.random.default_rng(3).standard_normal(v.length()))
+        old = Hubbard.VcorLocal(res, bogo, 4, idx_range=[0, 1, 2] if rng_idx else None)
+        old.update(np.random.default_rng(4).standard_normal(old.length()))
+        out["vd/%s/p_new" % tag], out["vd/%s/p_old" % tag] = np.array(v.param), np.array(old.param)
+        out["vd/%s/ave" % tag] = slater.vcor_diag_average(v, idx_range=rng_idx)
+        slater.addDiag(v, [0.3, -0.2, 0.0][: v.get().shape[0]] if not res else 0.25, idx_range=rng_idx)
+        out["vd/%s/after_add" % tag] = np.array(v.param)
+        slater.make_vcor_trace_unchanged(v, old, idx_range=rng_idx)
+        out["vd/%s/after_trace" % tag] = np.array(v.param)
+    v = Hubbard.VcorLocal(False, True, 3)
+    v.update(np.random.default_rng(5).standard_normal(v.length()))
+    old = Hubbard.VcorLocal(False, True, 3)
+    old.update(np.random.default_rng(6).standard_normal(old.length()))
+    out["vd/gso/p_new"], out["vd/gso/p_old"] = np.array(v.param), np.array(old.param)
+    rsp.addDiag(v, 0.4)
+    out["vd/gso/after_add"] = np.array(v.param)
+    rsp.keep_vcor_trace_fixed(v, old)
+    out["vd/gso/after_trace"] = np.array(v.param)
     g8 = np.load(os.path.join(GOLD, "G8_embham.npz"))
     for name, spin in (("uhf_231", 2), ("rhf_411", 1)):
         mesh = tuple(int(x) for x in g8[name + "/mesh"])

@@ -240,3 +240,29 @@ def test_symmetry_adapted_potentials_equal_the_reference(golden):
                 lambda: Hubbard.VcorSymmSpin(True, False, 7, Ca, Cb, idx_range=idx), lambda: Hubbard.VcorSymmBogo(False, False, 7, Ca, Cb, idx_range=idx)):
         with pytest.raises(NotImplementedError):
             bad()
+
+
+def test_vcor_diagonal_helpers_equal_the_reference(golden):
+    """slater.addDiag / vcor_diag_average / make_vcor_trace_unchanged (slater.py:757-818) and the GSO forms spinless.addDiag /
+    keep_vcor_trace_fixed (spinless.py:739-752): parameters after every step equal the reference's (golden G36)."""
+    from libdmet_preview_amd.dmet import Hubbard, HubbardGSO
+    from libdmet_preview_amd.routine import slater, spinless
+    g = golden("G36_init_guess.npz")
+    for tag, res, bogo, rng_idx in (("u", False, False, [1, 2]), ("rb", True, True, None)):
+        v = Hubbard.VcorLocal(res, bogo, 4, idx_range=[0, 1, 2] if rng_idx else None)
+        old = Hubbard.VcorLocal(res, bogo, 4, idx_range=[0, 1, 2] if rng_idx else None)
+        v.update(np.array(g["vd/%s/p_new" % tag]))
+        old.update(np.array(g["vd/%s/p_old" % tag]))
+        assert np.abs(slater.vcor_diag_average(v, idx_range=rng_idx) - g["vd/%s/ave" % tag]).max() < 1e-15
+        Hubbard.addDiag(v, [0.3, -0.2, 0.0][: v.get().shape[0]] if not res else 0.25, idx_range=rng_idx)
+        assert np.abs(np.asarray(v.param) - g["vd/%s/after_add" % tag]).max() < 1e-15
+        Hubbard.make_vcor_trace_unchanged(v, old, idx_range=rng_idx)
+        assert np.abs(np.asarray(v.param) - g["vd/%s/after_trace" % tag]).max() < 1e-15
+    v, old = Hubbard.VcorLocal(False, True, 3), Hubbard.VcorLocal(False, True, 3)
+    v.update(np.array(g["vd/gso/p_new"]))
+    old.update(np.array(g["vd/gso/p_old"]))
+    spinless.addDiag(v, 0.4)
+    assert np.abs(np.asarray(v.param) - g["vd/gso/after_add"]).max() < 1e-15
+    HubbardGSO.keep_vcor_trace_fixed(v, old)
+    assert np.abs(np.asarray(v.param) - g["vd/gso/after_trace"]).max() < 1e-15
+    assert Hubbard.VcorZeros is Hubbard.VcorLocal and Hubbard.VcorLocal_new is Hubbard.VcorLocal
