@@ -68,8 +68,7 @@ _FUNCTIONS = [
     ("routine.bcs_helper", ["routine.bcs_helper", "routine.bcs"],
      ["contract_trans_inv", "transform_trans_inv", "contract_local", "transform_local", "transform_imp",
       "contract_imp_env", "transform_imp_env", "transform_local_grad", "get_dV_dparam"]),
-    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb", "FitVcorFull", "foldRho", "foldRho_k"]),
-    # (FitVcorTwoStep stays the reference's own: it reaches the rebound stages and keeps its kinetic variant)
+    ("routine.bcs", ["routine.bcs"], ["embBasis", "get_emb_basis", "embHam", "get_emb_Ham", "FitVcorEmb", "FitVcorFull", "FitVcorFullK", "FitVcorTwoStep", "foldRho", "foldRho_k"]),
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
     ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb", "get_dV_dparam_full", "FitVcorFull"]),

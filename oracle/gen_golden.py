@@ -1903,6 +1903,36 @@ def gen_G31():
             P = 0.1 * np.random.default_rng(5).standard_normal((2, v.length()))
             out[key + "/probe"], out[key + "/probe_err"] = P, np.asarray([captured["fn"](q.copy()) for q in P])
     bcs.minimize = real_minimize
+    # the kinetic-energy form of the lattice fit (bcs.py:564-619) on the smallest lattice: cost and gradient at fixed parameters
+    # (captured from scipy's driver), constraint values, fitted parameters
+    from scipy import optimize as sopt
+    name, mesh, n, val = "c611", (6, 1, 1), 2, [0, 1]
+    L = _duck_lattice(mesh, n, val=val)
+    FR, mu = g7[name + "/Fock_R"], float(g7[name + "/mu"])
+    L.fock_lo_R = L.hcore_lo_R = FR
+    L.fock_lo_k = L.hcore_lo_k = synth.fold_R2k(FR, mesh)
+    L.H0, L.use_hcore_as_emb_ham = 0.0, False
+    seen = {}
+    real_sp = sopt.minimize
+
+    def spy_sp(fun, x0, jac=None, **kw):
+        seen["fun"], seen["jac"] = fun, jac
+        return real_sp(fun, x0, jac=jac, **kw)
+    sopt.minimize = spy_sp
+    v = Hubbard.VcorLocal(False, True, n)
+    v.update(0.05 * np.random.default_rng(7).standard_normal(v.length()))
+    out["c611/fullK/p0"] = np.array(v.param)
+    GRho_t = g7[name + "/GRho"][0] if g7[name + "/GRho"].ndim == 3 else g7[name + "/GRho"]
+    noise = 0.02 * np.random.default_rng(8).standard_normal(GRho_t.shape)
+    GRho_t = GRho_t + 0.5 * (noise + noise.T)
+    out["c611/fullK/target"] = GRho_t
+    vfit, c0, c1 = bcs.FitVcorFullK(GRho_t, L, g7[name + "/basis_proj"], v, mu, 5)
+    sopt.minimize = real_sp
+    out["c611/fullK/param"], out["c611/fullK/c"] = np.array(vfit.param), np.asarray([c0, c1])
+    P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+    out["c611/fullK/probe"] = P
+    out["c611/fullK/probe_cost"] = np.asarray([seen["fun"](q.copy()) for q in P])
+    out["c611/fullK/probe_grad"] = np.asarray([seen["jac"](q.copy()) for q in P])
     np.savez_compressed(os.path.join(GOLD, "G31_hfb.npz"), **out)
     print("G31 done", len(out), "arrays")
 
