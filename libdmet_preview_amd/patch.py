@@ -72,6 +72,7 @@ _FUNCTIONS = [
     # optimiser of the vcor fit (routine/slater.py:27 imports minimize by name)
     ("routine.fit", ["routine.fit", "routine.slater"], ["minimize"]),
     ("routine.spinless", ["routine.spinless"], ["get_emb_basis", "embBasis", "get_emb_basis_opt", "get_emb_Ham", "embHam", "foldRho_k", "get_dV_dparam", "FitVcorEmb", "get_dV_dparam_full", "FitVcorFull"]),
+    # (FitVcorFull_mu and FitVcorTwoStep of the GSO twin stay the reference's: its convex `use_cvx_frac` branch is not built here)
     # the GSO one-body folds and ERI containers (routine/spinless.py:32 star-imports the helper module)
     ("routine.spinless_helper", ["routine.spinless_helper", "routine.spinless"],
      ["unit2emb", "transform_eri_local", "transform_trans_inv_k", "transform_local", "transform_imp", "get_H2_mask"]),

@@ -1323,6 +1323,8 @@ class FullFitDevice(object):
             Fock = np.asarray((Fock[0],) * spin)
         self.norm = sqrt(spin) if norm is None else float(norm)
         self._shift_of = shift_of if shift_of is not None else (lambda v: np.asarray(v.get(0, True))[:spin].real)
+        self.extra_shift, self.last_dens = None, None       # a second k-independent shift a caller may vary (a chemical potential searched
+                                                            # inside every evaluation, spinless.FitVcorFull_mu); the cell-0 density of the last evaluation
         self.kpts = bool(getattr(vcor, "is_vcor_kpts", False))
         if self.kpts:
             self.F_host = np.array(Fock[:spin], dtype=np.complex128)       # the potential differs from k to k: added before the upload
@@ -1370,7 +1372,7 @@ class FullFitDevice(object):
 
     def _forward(self, param):
         param = np.ascontiguousarray(param, dtype=np.float64)
-        key = param.tobytes()
+        key = param.tobytes() + (b"" if self.extra_shift is None else np.ascontiguousarray(self.extra_shift, dtype=np.float64).tobytes())
         if key == self._key:
             return self._state
         ctx, spin, nk, n, nb, nidx = self.ctx, self.spin, self.nk, self.n, self.nb, self.nidx
@@ -1381,6 +1383,8 @@ class FullFitDevice(object):
             d_w, d_Vt = mfd.eigh_dev(ctx, ctx.to_device((self.F_host + per_k).reshape(spin * nk, n, n), np.complex128), n, spin * nk)
         else:
             v = np.ascontiguousarray(self._shift_of(self.vcor), dtype=np.float64)
+            if self.extra_shift is not None:
+                v = v + np.asarray(self.extra_shift, dtype=np.float64)
             d_add = ctx.to_device(v)
             d_w, d_Vt = mfd.eigh_dev(ctx, self.d_F, n, spin * nk, d_add, nk)
         ew = d_w.get().reshape(spin, nk, n)
@@ -1396,6 +1400,7 @@ class FullFitDevice(object):
             imax = ctx.zeros((1,), np.float64)
             d_rhoR = self._fourier.fold_k2R_dev(d_rho.reshape(spin, nk, n * n), self.lattice.kmesh, spin, n * n, imag_max=imax)
             dens = np.ascontiguousarray(d_rhoR.get().reshape(spin, nk, n, n)[:, 0])      # (1/nk) sum_k rho_k, real part
+            self.last_dens = dens
             if float(imax.get()[0]) > IMAG_DISCARD_TOL:
                 log.warn("rhoT has imag part %s", float(imax.get()[0]))
             m = n

@@ -506,11 +506,9 @@ def FitVcorEmb(rho, lattice, basis, vcor, mu, beta=np.inf, MaxIter=300, imp_fit=
 def FitVcorTwoStep(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter1=300, MaxIter2=0, kinetic=False, CG_check=False, BFGS=False,
                    serial=True, method='CG', ytol=1e-7, gtol=1e-3, filling=None, **kwargs):
     """Main wrapper of the GSO fit (spinless.py:2166-2231): the embedding-space stage on a copy of `vcor`; returns (vcor_new, err_end)
-    or, with `full_return`, (vcor_new, None, err_end, {}); the lattice stage FitVcorFull follows for `MaxIter2 > 0` (its variant with
-    a fitted chemical potential, `filling` given: FitVcorFull_mu, is not built)."""
+    or, with `full_return`, (vcor_new, None, err_end, {}); the lattice stage follows for `MaxIter2 > 0`: FitVcorFull, or FitVcorFull_mu
+    when a `filling` is given (the convex `use_cvx_frac` variant is not built)."""
     import copy
-    if MaxIter2 > 0 and filling is not None:
-        raise NotImplementedError("the lattice stage with a fitted chemical potential (spinless.FitVcorFull_mu) is not built; filling=None")
     vcor_new = copy.deepcopy(vcor)
     log.result("Using two-step vcor fitting")
     log.eassert(MaxIter1 > 0 or MaxIter2 > 0, "FitVcorTwoStep: no stage to run (MaxIter1 = MaxIter2 = 0)")
@@ -523,8 +521,13 @@ def FitVcorTwoStep(GRho, lattice, basis, vcor, mu, beta=np.inf, MaxIter1=300, Ma
         log.info("Embedding Stage:\nbegin %20.12f    end %20.12f" % (err_begin, err_end))
     if MaxIter2 > 0:
         log.info("Full lattice stage  max %d steps", MaxIter2)
-        vcor_new, err_begin2, err_end = FitVcorFull(GRho, lattice, basis, vcor_new, mu=mu, beta=beta, filling=None, MaxIter=MaxIter2,
-                                                    method=method, ytol=ytol, gtol=gtol, **kwargs)
+        if filling is not None:
+            log.info("fit chemical potential while fitting.")
+            vcor_new, err_begin2, err_end = FitVcorFull_mu(GRho, lattice, basis, vcor_new, mu=mu, beta=beta, filling=filling,
+                                                           MaxIter=MaxIter2, method=method, ytol=ytol, gtol=gtol, **kwargs)
+        else:
+            vcor_new, err_begin2, err_end = FitVcorFull(GRho, lattice, basis, vcor_new, mu=mu, beta=beta, filling=None, MaxIter=MaxIter2,
+                                                        method=method, ytol=ytol, gtol=gtol, **kwargs)
         err_begin = err_begin2 if err_begin is None else err_begin
     log.result("residue (begin) = %20.12f", err_begin)
     log.result("residue (end)   = %20.12f", err_end)
@@ -644,3 +647,86 @@ def keep_vcor_trace_fixed(vcor_new, vcor):
     d = np.asarray(vcor_new.get()) - np.asarray(vcor.get())
     drift = (np.average(np.diagonal(d[0])) - np.average(np.diagonal(d[1]))) * 0.5
     return addDiag(vcor_new, -drift)
+
+
+def FitVcorFull_mu(rho, lattice, basis, vcor, mu, beta, filling, MaxIter=20, imp_fit=False, imp_idx=None, det=False, det_idx=None,
+                   CG_check=False, BFGS=False, diff_criterion=None, scf=False, use_cvx_frac=False, **kwargs):
+    """
+    Lattice stage of the GSO fit with the PARTICLE chemical potential re-fitted inside every evaluation (spinless.py:1771-2164): for
+    the trial potential, mu is searched (bcs_helper.mono_fit_2 from the previous solution) so that the physical electron number
+    of the cell -- tr rho_aa - tr rho_bb + nao of the cell-0 density -- equals 2 nao filling; then objective and finite-T gradient are
+    those of FitVcorFull at that mu (the gradient does not follow mu, like the reference).  The step and starting point of the search
+    move with every gradient evaluation.  Every inner iterate is a lattice diagonalisation on the device (slater.FullFitDevice with
+    -mu / +mu as a second shared shift).
+    """
+    from libdmet_preview_amd.routine import slater, spinless_helper as sh
+    from libdmet_preview_amd.routine.fit import minimize
+    from libdmet_preview_amd.routine.mfd import H_k2GH_k, check_nelec
+    if scf or use_cvx_frac or kwargs.get("use_mpi", False):
+        raise NotImplementedError("the SCF, convex (cvx_frac) and multi-process variants of the GSO lattice fit are outside the HIP path")
+    num_grad = kwargs.get("num_grad", False)
+    if not num_grad and beta == np.inf:
+        raise NotImplementedError("FitVcorFull_mu: no analytic T = 0 gradient, pass num_grad=True (spinless.py:2125-2128)")
+    param_begin = vcor.param.copy()
+    nao, nkpts = lattice.nscsites, lattice.nkpts
+    nso = 2 * nao
+    if imp_fit:
+        imp_idx, det_idx = (list(range(lattice.nimp)) if imp_idx is None else imp_idx), []
+    elif det:
+        imp_idx, det_idx = [], (list(range(lattice.nimp)) if det_idx is None else det_idx)
+    elif imp_idx is None and det_idx is None:
+        raise NotImplementedError("FitVcorFull_mu on the embedding space (imp + bath) is not built: choose imp_fit / det or index lists")
+    imp_idx, det_idx = list(imp_idx or []), list(det_idx or [])
+    doubled = lambda idx: sum(sh.idx_ao2so(idx, nao), [])
+    imp_idx, det_idx = doubled(imp_idx), doubled(det_idx)
+    nimp, nidx = len(imp_idx), len(imp_idx) + len(det_idx)
+    mask = None
+    if kwargs.get("bogo_only", False):
+        mask = np.ones((nidx, nidx))
+        hi, hd = nimp // 2, len(det_idx) // 2
+        for lo, up in ((0, hi), (hi, nimp), (nimp, nimp + hd), (nimp + hd, nidx)):
+            mask[lo:up, lo:up] = 0.0
+    GFock = H_k2GH_k(lattice.getFock(kspace=True)).astype(np.complex128)           # WITHOUT mu: it is the unknown of the inner search
+    nelec = check_nelec(nkpts * nso * 0.5, None)[0]
+    target_n = nso * filling
+    ctx = get_ctx()
+    fit = slater.FullFitDevice(ctx, np.asarray(rho)[np.newaxis], lattice, np.zeros((1, nkpts, nso, 1)), vcor, beta, nelec, imp_idx, det_idx, False,
+                               fix_mu=kwargs.get("fix_mu", False), fock_k=GFock[np.newaxis],
+                               shift_of=lambda v: sh.spin_orbital_matrix(np.asarray(v.get(0, True)).real)[np.newaxis],
+                               dV=get_dV_dparam_full(vcor, lattice)[:, np.newaxis, :], norm=np.sqrt(2.0), mask=mask)
+    chem = lambda m: np.diag(np.concatenate([-m * np.ones(nao), m * np.ones(nao)]))[np.newaxis]
+    mu_guess, step_guess = [mu], [0.1]
+
+    def solve_mu(param):
+        def nelec_phys(m):
+            fit.extra_shift = chem(m)
+            fit._forward(param)
+            d = fit.last_dens[0]
+            return np.trace(d[:nao, :nao]) - np.trace(d[nao:, nao:]) + nao
+        m = sh.mono_fit_2(nelec_phys, target_n, mu_guess[0], thr=1e-6, dx=step_guess[0], verbose=False, maxiter=20)
+        fit.extra_shift = chem(m)
+        return m
+
+    def errfunc(param):
+        solve_mu(param)
+        return fit.errfunc(param)
+
+    def gradfunc(param):
+        m = solve_mu(param)
+        step_guess[0] = min(max(0.05, abs(m - mu_guess[0])), 0.2)
+        mu_guess[0] = m
+        return fit.gradfunc(param)
+
+    if num_grad:
+        log.warn("You are using numerical gradient...")
+    else:
+        log.info("Using analytic gradient for finite T, beta = %s", beta)
+    err_begin = errfunc(param_begin)
+    param, err_end, pattern, gnorm_res = minimize(errfunc, param_begin.copy(), MaxIter, None if num_grad else gradfunc, **kwargs)
+    vcor.update(param)
+    log.info("Minimizer converge pattern: %d ", pattern)
+    log.info("Current function value: %15.8f", err_end)
+    log.info("Norm of gradients: %s", gnorm_res)
+    log.info("Norm diff of x: %15.8f", np.abs(param - param_begin).max())
+    FitVcorFull_mu.last_fit = (errfunc, gradfunc, mu_guess)
+    return vcor, err_begin, err_end

@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35", "G36"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35", "G36", "G37"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -2195,6 +2195,42 @@ def gen_G36():
             out["%s/dmu_%s" % (name, tag)] = Himp.H1["cd"].copy()
     np.savez_compressed(os.path.join(GOLD, "G36_init_guess.npz"), **out)
     print("G36 done", len(out), "arrays")
+
+
+def gen_G37():
+    """The lattice stage of the GSO fit with the particle chemical potential re-fitted inside every evaluation, routine/spinless.py:
+    1771-2164 FitVcorFull_mu (plain path: no convex solver, one process): objective / gradient at fixed parameters after the fit,
+    the fits, and the chemical potential the inner search ends on."""
+    spinless, sh = shim.patch_spinless()
+    from libdmet.dmet import Hubbard
+    g27, g35 = np.load(os.path.join(GOLD, "G27_gso_embham.npz")), np.load(os.path.join(GOLD, "G35_gso_full_fit.npz"))
+    out = {}
+    captured = {}
+    real_minimize = spinless.minimize
+
+    def spy(fn, x0, MaxIter=300, fgrad=None, **kw):
+        captured["fn"], captured["fgrad"] = fn, fgrad
+        return real_minimize(fn, x0, MaxIter, fgrad, **kw)
+    spinless.minimize = spy
+    for name, mesh, n, val in [("c611", (6, 1, 1), 2, [0, 1]), ("c441", (4, 4, 1), 4, [0, 1, 2, 3]), ("c222", (2, 2, 2), 5, [1, 2, 3])]:
+        L = _duck_lattice(mesh, n, val=val, virt=[i for i in range(n) if i > max(val)], core=[i for i in range(n) if i < min(val)])
+        L.hcore_lo_k, L.fock_lo_k = g27[name + "/H3_k"], g27[name + "/F3_k"]
+        target = g35[name + "/target"]
+        for tag, beta, filling, kw in (("ft_imp", 12.0, 0.5, dict(imp_fit=True)), ("ft_det", 12.0, 0.45, dict(det=True)),
+                                       ("ft_bogo", 12.0, 0.55, dict(imp_fit=True, bogo_only=True))):
+            v = Hubbard.VcorLocal(False, True, n)
+            v.update(0.05 * np.random.default_rng(7).standard_normal(v.length()))
+            key = "%s/%s" % (name, tag)
+            out[key + "/p0"] = np.array(v.param)
+            vfit, e0, e1 = spinless.FitVcorFull_mu(target, L, g27[name + "/basis"], v, 0.37, beta, filling, MaxIter=6, **kw)
+            out[key + "/param"], out[key + "/err"] = np.array(vfit.param), np.asarray([e0, e1])
+            P = 0.1 * np.random.default_rng(5).standard_normal((3, v.length()))
+            out[key + "/probe"] = P
+            out[key + "/probe_err"] = np.asarray([captured["fn"](q.copy()) for q in P])
+            out[key + "/probe_grad"] = np.asarray([captured["fgrad"](q.copy()) for q in P])
+    spinless.minimize = real_minimize
+    np.savez_compressed(os.path.join(GOLD, "G37_gso_full_fit_mu.npz"), **out)
+    print("G37 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -484,3 +484,52 @@ class GsoFullFit(object):
             dw = get_dw_dv(ew[k][None], ev[k][None], drho[None], mu_q, self.beta, fix_mu=self.fix_mu, fit_idx=self.fit_idx, compact=True)
             res = res + self.dV.dot(dw.ravel())
         return res.real / (2.0 * val * np.sqrt(2.0) * self.nk)
+
+
+class GsoFullFitMu(GsoFullFit):
+    """errfunc of spinless.FitVcorFull_mu (spinless.py:2030-2073): the particle chemical potential is searched, for every trial
+    potential, so that tr rho_aa - tr rho_bb + nao of the cell-0 density equals 2 nao filling (bracketing + Brent, 1e-6, from
+    `mu_start` with step `dx`), then the objective of GsoFullFit at that mu."""
+
+    def __init__(self, rho, kmesh, vcor, filling, beta, fock_k, mu_start, dx=0.1, **kw):
+        GsoFullFit.__init__(self, rho, kmesh, vcor, 0.0, beta, fock_k, **kw)
+        self.bare, self.filling, self.mu_start, self.dx = self.GFock.copy(), filling, mu_start, dx
+
+    def with_mu(self, m):
+        n = self.nso // 2
+        self.GFock = self.bare.copy()
+        self.GFock[:, range(n), range(n)] -= m
+        self.GFock[:, range(n, 2 * n), range(n, 2 * n)] += m
+
+    def solve_mu(self, param):
+        from scipy.optimize import brentq
+        from oracle.restate import assignocc
+        n = self.nso // 2
+        target = self.nso * self.filling
+
+        def nelec_phys(m):
+            self.with_mu(m)
+            self.vcor.update(param)
+            H = self.GFock + spin_orbital_matrix(np.asarray(self.vcor.get()))[None]
+            pairs = [la.eigh(H[k]) for k in range(self.nk)]
+            ews, evs = np.asarray([p[0] for p in pairs]), np.asarray([p[1] for p in pairs])
+            occ = assignocc(ews, self.nelec, self.beta, 0.0, fix_mu=self.fix_mu)[0]
+            w = (np.abs(evs[:, :n]) ** 2).sum(axis=1) - (np.abs(evs[:, n:]) ** 2).sum(axis=1)
+            return np.dot(w.ravel(), occ.ravel()) / self.nk + n
+        x, y = self.mu_start, nelec_phys(self.mu_start)
+        if abs(y - target) < 1e-6:
+            return x
+        step = -self.dx if y > target else self.dx
+        while True:
+            x1 = x + step
+            y1 = nelec_phys(x1)
+            if abs(y1 - target) < 1e-6:
+                return x1
+            if (y - target) * (y1 - target) < 0:
+                break
+            x, y = x1, y1
+        return brentq(lambda m: nelec_phys(m) - target, min(x, x1), max(x, x1), xtol=1e-6, rtol=1e-6, maxiter=20, disp=False)
+
+    def errfunc(self, param):
+        self.with_mu(self.solve_mu(param))
+        return GsoFullFit.errfunc(self, param)

@@ -412,5 +412,37 @@ def test_gso_lattice_stage_fit(ctx, golden, name, n, val):
     assert vnew is not v
     vnew2, err2 = spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=12.0, MaxIter1=0, MaxIter2=3, imp_fit=True)
     assert vnew2 is not v and err2 <= g[name + "/ft_imp/err"][0] + 1.0
+    vnew3, err3 = spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=12.0, MaxIter1=0, MaxIter2=2, filling=0.5, imp_fit=True)
+    assert vnew3 is not v and np.isfinite(err3)
+
+
+# ---- round 6: the lattice stage with the chemical potential re-fitted inside (golden G37) -----------------------------------
+
+@pytest.mark.parametrize("name,n,val", GSO_FIT)
+def test_gso_lattice_stage_fit_with_mu(ctx, golden, name, n, val):
+    """spinless.FitVcorFull_mu (routine/spinless.py:1771-2164): fits, and objective / gradient at fixed parameters in the order the
+    golden run took them (the inner chemical-potential search starts from the previous gradient evaluation's solution and stops at
+    1e-6 in the electron number, hence the tolerances)."""
+    from libdmet_preview_amd.routine import spinless
+    from libdmet_preview_amd.dmet import Hubbard
+    g, g27, g35 = golden("G37_gso_full_fit_mu.npz"), golden("G27_gso_embham.npz"), golden("G35_gso_full_fit.npz")
+    L, mesh, basis, H2, F3, rk, vmat, mu = _gso_lattice(g27, name)
+    target = g35[name + "/target"]
+    for tag, beta, filling, kw in (("ft_imp", 12.0, 0.5, dict(imp_fit=True)), ("ft_det", 12.0, 0.45, dict(det=True)),
+                                   ("ft_bogo", 12.0, 0.55, dict(imp_fit=True, bogo_only=True))):
+        key = "%s/%s" % (name, tag)
+        v = Hubbard.VcorLocal(False, True, n)
+        v.update(np.array(g[key + "/p0"]))
+        vfit, e0, e1 = spinless.FitVcorFull_mu(target, L, basis, v, mu, beta, filling, MaxIter=6, **kw)
+        errfunc, gradfunc, mu_state = spinless.FitVcorFull_mu.last_fit
+        r0, r1 = g[key + "/err"]
+        assert abs(e0 - r0) < 1e-5 and abs(e1 - r1) < 1e-4 and e1 <= e0 + 1e-9, (key, e0, e1, r0, r1)
+        for p, e in zip(g[key + "/probe"], g[key + "/probe_err"]):
+            assert abs(errfunc(p) - e) < 1e-5, key
+        for p, gr in zip(g[key + "/probe"], g[key + "/probe_grad"]):
+            assert np.abs(gradfunc(p) - gr).max() < 1e-4 * max(1.0, np.abs(gr).max()), key
+    for bad in (dict(use_cvx_frac=True, imp_fit=True), dict(), dict(imp_fit=True, scf=True)):
+        with pytest.raises(NotImplementedError):
+            spinless.FitVcorFull_mu(target, L, basis, v, mu, 12.0, 0.5, MaxIter=1, **bad)
     with pytest.raises(NotImplementedError):
-        spinless.FitVcorTwoStep(target, L, basis, v, mu, beta=12.0, MaxIter1=0, MaxIter2=3, filling=0.5)
+        spinless.FitVcorFull_mu(target, L, basis, v, mu, np.inf, 0.5, MaxIter=1, imp_fit=True)

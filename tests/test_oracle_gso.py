@@ -240,3 +240,17 @@ def test_G35_gso_lattice_fit_objective_and_gradient(golden, name, n, val):
                 gr = g[key + "/probe_grad"][i]
                 assert np.abs(fit.gradfunc_ft(p) - gr).max() < 1e-10 * max(1.0, np.abs(gr).max()), key
         assert abs(fit.errfunc(g[key + "/p0"]) - g[key + "/err"][0]) < 1e-12 and abs(fit.errfunc(g[key + "/param"]) - g[key + "/err"][1]) < 1e-10
+
+
+@pytest.mark.parametrize("name,n,val", GSO_FIT)
+def test_G37_gso_lattice_fit_with_mu_first_objective(golden, name, n, val):
+    """spinless.FitVcorFull_mu: the objective at the starting parameters -- the one evaluation whose inner chemical-potential search
+    starts from a known point -- against the reference (golden G37; the search stops at 1e-6 in the electron number)."""
+    from oracle import restate_fit as F
+    g, g27, g35 = golden("G37_gso_full_fit_mu.npz"), golden("G27_gso_embham.npz"), golden("G35_gso_full_fit.npz")
+    mesh = tuple(int(x) for x in g27[name + "/mesh"])
+    idx = list(range(len(val) + len([i for i in range(n) if i > max(val)])))
+    for tag, filling, kw in (("ft_imp", 0.5, dict(imp_idx=idx)), ("ft_det", 0.45, dict(det_idx=idx)), ("ft_bogo", 0.55, dict(imp_idx=idx, bogo_only=True))):
+        fit = G.GsoFullFitMu(g35[name + "/target"], mesh, F.VcorLocal(False, True, n), filling, 12.0, g27[name + "/F3_k"], 0.37, **kw)
+        key = "%s/%s" % (name, tag)
+        assert abs(fit.errfunc(g[key + "/p0"]) - g[key + "/err"][0]) < 1e-5, key
