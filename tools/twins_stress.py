@@ -12,7 +12,7 @@ from oracle import restate_gso as G
 from oracle import restate_fit as F
 from libdmet_preview_amd import synth
 from libdmet_preview_amd.utils import logger as log
-from libdmet_preview_amd.routine import mfd, spinless, bcs, slater, vcor as pvcor
+from libdmet_preview_amd.routine import mfd, spinless, slater, vcor as pvcor
 from libdmet_preview_amd.dmet import Hubbard
 from libdmet_preview_amd.system.lattice import Lattice
 
