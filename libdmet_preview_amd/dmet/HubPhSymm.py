@@ -9,6 +9,7 @@ embBasis -> basisMatching -> embHam (each of them on the device).
 import numpy as np
 
 from libdmet_preview_amd._lib import lib, get_ctx
+from libdmet_preview_amd.routine import vcor as pvcor
 from libdmet_preview_amd.utils import logger as log
 
 
@@ -61,3 +62,147 @@ def ConstructImpHam(Lat, rho, v, mu=None, afqmc=False, matching=True, local=True
     log.result("Constructing impurity Hamiltonian")
     ham, h1e = slater.embHam(Lat, basis, v, local=local, **kwargs)
     return ham, h1e, basis
+
+
+# ---- the rest of the particle-hole symmetric Hubbard driver (dmet/HubPhSymm.py:29-36, 114-327) ---------------------------------
+
+class _VcorSignedTable(pvcor.Vcor):
+    """A potential that is an AFFINE function of its parameters: value = constant + sum over table entries
+    (parameter, block, row, col, sign) of sign * param.  Serves VcorLocalPhSymm and VcorDCAPhSymm, whose particle-hole symmetry
+    ties the two spin blocks (and the pairing block) to one parameter set with sublattice-dependent signs and whose diagonal carries
+    the fixed U / 2.  gradient() is the table; assign() projects on it like Vcor.assign (the constant is not removed first: the
+    reference's behaviour, which InitGuess relies on)."""
+
+    def __init__(self, nblk, nscsites, nparam, table, constant):
+        pvcor.Vcor.__init__(self)
+        self._nblk, self.nscsites, self.nparam = nblk, nscsites, nparam
+        self._tab = np.asarray(table, dtype=np.int64).reshape(-1, 5).T        # rows: parameter, block, row, col, sign
+        self._const = constant
+        self.grad = None
+
+    def length(self):
+        return self.nparam
+
+    def evaluate(self):
+        log.eassert(np.shape(self.param) == (self.nparam,), "wrong parameter shape, require %s", (self.nparam,))
+        P, B, I, J, S = self._tab
+        V = np.zeros((self._nblk, self.nscsites, self.nscsites))
+        V[B, I, J] = S * np.asarray(self.param)[P]
+        return V + self._const
+
+    def gradient(self):
+        if self.grad is None:
+            P, B, I, J, S = self._tab
+            g = np.zeros((self.nparam, self._nblk, self.nscsites, self.nscsites))
+            g[P, B, I, J] = S
+            self.grad = g
+        return self.grad
+
+    def grad_entries(self):
+        P, B, I, J, S = self._tab
+        order = np.lexsort((J, I, B, P))
+        return P[order], B[order], I[order], J[order], S[order].astype(np.float64)
+
+
+def VcorLocalPhSymm(U, bogoliubov, ImpSize, subA, subB, r=None):
+    """Local potential of the half-filled bipartite Hubbard model with particle-hole symmetry (dmet/HubPhSymm.py:125-211):
+    V_b[i, j] = -(+-) V_a[i, j] with + when i, j sit on the same sublattice, pairing D[j, i] = +-D[i, j]; pairs within distance `r`
+    only; U / 2 on both diagonals."""
+    import itertools as it
+    assert np.asarray(ImpSize).shape in [(1,), (2,), (3,)]
+    subA, subB = set(subA), set(subB)
+    log.eassert(len(subA) == len(subB), "number of sites in two sublattices are equal")
+    nscsites = int(np.prod(ImpSize))
+    log.eassert(len(subA) * 2 == nscsites and subA | subB == set(range(nscsites)), "sublattice designation problematic")
+    if r is None:
+        pairs = list(it.combinations_with_replacement(range(nscsites), 2))
+    else:
+        sites = list(enumerate(it.product(*map(range, ImpSize))))
+        pairs = [(i, j) for (i, ri), (j, rj) in it.combinations_with_replacement(sites, 2)
+                 if np.linalg.norm(np.asarray(ri) - np.asarray(rj)) < r + 1e-6]
+    nV = len(pairs)
+    same = lambda i, j: 1 if (i in subA) == (j in subA) else -1
+    table = []
+    for p, (i, j) in enumerate(pairs):
+        s = same(i, j)
+        table += [(p, 0, i, j, 1), (p, 0, j, i, 1), (p, 1, i, j, -s), (p, 1, j, i, -s)]
+        if bogoliubov:
+            table.append((p + nV, 2, i, j, 1))
+            if i != j:
+                table.append((p + nV, 2, j, i, s))
+    table = sorted(set(table))                                    # (a diagonal pair lists its entry twice)
+    nblk = 3 if bogoliubov else 2
+    const = np.zeros((nblk, nscsites, nscsites))
+    const[0] = const[1] = np.eye(nscsites) * (U / 2)
+    return _VcorSignedTable(nblk, nscsites, nV * (2 if bogoliubov else 1), table, const)
+
+
+def VcorDCAPhSymm(U, ImpSize, subA, subB):
+    """Translation-invariant (DCA) particle-hole symmetric potential on a periodic cluster (dmet/HubPhSymm.py:213-295): one
+    parameter per +-displacement class; sign pattern (a, b) = (+, -) inside sublattice A, (-, +) inside B, (+, +) between."""
+    import itertools as it
+    assert np.asarray(ImpSize).shape in [(1,), (2,)]
+    subA, subB = set(subA), set(subB)
+    log.eassert(len(subA) == len(subB), "number of sites in two sublattices are equal")
+    nscsites = int(np.prod(ImpSize))
+    log.eassert(len(subA) * 2 == nscsites and subA | subB == set(range(nscsites)), "sublattice designation problematic")
+    sites = list(it.product(*map(range, ImpSize)))
+    index = dict(zip(sites, range(len(sites))))
+    seen, classes = set(), []
+    for s in sites:
+        members = []
+        for cand in (s, tuple((-np.asarray(s)) % ImpSize)):
+            if cand not in seen:
+                members.append(np.asarray(cand))
+                seen.add(cand)
+        if members:
+            classes.append(members)
+    entries = {}
+    for p, members in enumerate(classes):
+        for vec in members:
+            for i, site in enumerate(sites):
+                j = index[tuple((np.asarray(site) + vec) % ImpSize)]
+                sa, sb = (1, -1) if (i in subA and j in subA) else ((-1, 1) if (i in subB and j in subB) else (1, 1))
+                entries[(0, i, j)], entries[(1, i, j)] = (p, sa), (p, sb)       # a later class overwrites, like the reference's loops
+    table = [(p, b, i, j, s) for (b, i, j), (p, s) in sorted(entries.items())]
+    const = np.asarray([np.eye(nscsites) * (U / 2)] * 2)
+    return _VcorSignedTable(2, nscsites, len(classes), table, const)
+
+
+def InitGuess(ImpSize, U, polar=None, r=None):
+    """Antiferromagnetic starting potential of the particle-hole symmetric driver (dmet/HubPhSymm.py:114-123)."""
+    from libdmet_preview_amd.dmet.Hubbard import BipartiteSquare
+    subA, subB = BipartiteSquare(ImpSize)
+    v = VcorLocalPhSymm(U, False, ImpSize, subA, subB, r)
+    if polar is None:
+        polar = U * 0.5
+    nscsites = int(np.prod(ImpSize))
+    stagger = np.diag([polar if s in subA else -polar for s in range(nscsites)])
+    v.assign(np.asarray([np.eye(nscsites) * U * 0.5 + stagger, np.eye(nscsites) * U * 0.5 - stagger]))
+    return v
+
+
+def HartreeFock(Lat, v, U):
+    """Half-filled unrestricted lattice mean field started at mu = U / 2 (dmet/HubPhSymm.py:29-35)."""
+    from libdmet_preview_amd.routine.mfd import HF
+    rho, mu, E, res = HF(Lat, v, 0.5, False, mu0=U / 2, beta=np.inf, ires=True)
+    log.result("mean-field cell-0 density (alpha, beta):\n%s\n%s", rho[0][0], rho[1][0])
+    log.result("mean field: mu %.12f, energy per site %.12f, gap %.12f", mu, E / Lat.nscsites, res["gap"])
+    return rho, mu
+
+
+def FitVcor(rho, lattice, basis, vcor, beta, MaxIter1=300, MaxIter2=20):
+    """dmet/HubPhSymm.py:297-300: the two-step fit at half filling."""
+    from libdmet_preview_amd.routine import slater
+    log.info("degrees of freedom = %d", vcor.length())
+    return slater.FitVcorTwoStep(rho, lattice, basis, vcor, beta, 0.5, MaxIter1, MaxIter2)
+
+
+def foldRho(rho, lattice, basis):
+    from libdmet_preview_amd.routine import slater
+    return slater.foldRho(rho, lattice, basis)
+
+
+def foldRho_k(rho_k, basis_k):
+    from libdmet_preview_amd.routine import slater
+    return slater.foldRho_k(rho_k, basis_k)

@@ -76,7 +76,7 @@ _FUNCTIONS = [
     # the GSO one-body folds and ERI containers (routine/spinless.py:32 star-imports the helper module)
     ("routine.spinless_helper", ["routine.spinless_helper", "routine.spinless"],
      ["unit2emb", "transform_eri_local", "transform_trans_inv_k", "transform_local", "transform_imp", "get_H2_mask"]),
-    ("dmet.HubPhSymm", ["dmet.HubPhSymm"], ["basisMatching"]),
+    ("dmet.HubPhSymm", ["dmet.HubPhSymm"], ["basisMatching", "VcorLocalPhSymm", "VcorDCAPhSymm", "InitGuess", "HartreeFock", "FitVcor"]),
     # driver layer: dmet/Hubbard.py:8 star-imports HubPhSymm, so it holds its own ConstructImpHam; it defines the RHF / UHF
     # HartreeFock wrapper (:14-41) and FitVcor (:1503) itself
     ("dmet.HubPhSymm", ["dmet.HubPhSymm", "dmet.Hubbard"], ["ConstructImpHam"]),

@@ -2179,6 +2179,22 @@ def gen_G36():
     out["vd/gso/after_add"] = np.array(v.param)
     rsp.keep_vcor_trace_fixed(v, old)
     out["vd/gso/after_trace"] = np.array(v.param)
+    # the particle-hole symmetric potentials and starting guess (dmet/HubPhSymm.py:114-295)
+    from libdmet.dmet import HubPhSymm as HP
+    from libdmet.system.lattice import BipartiteSquare
+    for tag, make in (("loc22", lambda: HP.VcorLocalPhSymm(4.0, False, (2, 2), *BipartiteSquare((2, 2)))),
+                      ("loc22b", lambda: HP.VcorLocalPhSymm(4.0, True, (2, 2), *BipartiteSquare((2, 2)))),
+                      ("loc4r", lambda: HP.VcorLocalPhSymm(3.0, True, (4,), *BipartiteSquare((4,)), r=1.0)),
+                      ("dca22", lambda: HP.VcorDCAPhSymm(4.0, (2, 2), *BipartiteSquare((2, 2)))),
+                      ("dca4", lambda: HP.VcorDCAPhSymm(2.0, (4,), *BipartiteSquare((4,))))):
+        v = make()
+        p = np.random.default_rng(len(tag)).standard_normal(v.length())
+        v.update(p)
+        gr = v.gradient()
+        out["ph/%s/param" % tag], out["ph/%s/value" % tag], out["ph/%s/grad" % tag] = p, np.array(v.get()), np.array(gr)
+    for tag, kw in (("a", dict()), ("b", dict(polar=0.7)), ("c", dict(r=1.0))):
+        v = HP.InitGuess((2, 2), 4.0, **kw)
+        out["ph/init_%s/param" % tag], out["ph/init_%s/value" % tag] = np.array(v.param), np.array(v.get())
     g8 = np.load(os.path.join(GOLD, "G8_embham.npz"))
     for name, spin in (("uhf_231", 2), ("rhf_411", 1)):
         mesh = tuple(int(x) for x in g8[name + "/mesh"])

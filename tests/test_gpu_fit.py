@@ -510,3 +510,35 @@ def test_fit_with_restricted_core_potential(ctx, golden, name):
     v.update(np.zeros(v.length()))
     vfit, e0, e1 = slater.FitVcorEmb(target, L, basis, v, np.inf, MaxIter=15)
     assert vfit is v and e1 < e0
+
+
+def test_particle_hole_symmetric_driver(ctx):
+    """dmet/HubPhSymm.py: HartreeFock at half filling with the particle-hole symmetric starting potential, and FitVcor (two-step) with
+    VcorLocalPhSymm -- signed sparse gradient entries through the device dV builder against the oracle's dense route."""
+    from libdmet_preview_amd.dmet import HubPhSymm as HP
+    from libdmet_preview_amd.dmet.Hubbard import BipartiteSquare
+    from libdmet_preview_amd.routine import mfd, slater
+    from libdmet_preview_amd import synth
+    from libdmet_preview_amd.system.lattice import Lattice
+    mesh, cs, U = (6, 6, 1), (2, 2), 4.0
+    H1 = synth.hubbard_h1_R(mesh, cs)
+    n = H1.shape[-1]
+    L = Lattice(n, mesh)
+    L.val_idx, L.virt_idx, L.core_idx = list(range(n)), [], []
+    L.set_Ham_lo(fock_lo_R=H1, hcore_lo_R=H1)
+    v = HP.InitGuess(cs, U)
+    rho, mu = HP.HartreeFock(L, v, U)
+    rho2, mu2, E2 = mfd.HF(L, v, 0.5, False, mu0=U / 2)
+    assert np.array_equal(rho, rho2) and mu == mu2 and abs(mu - U / 2) < 1e-8          # particle-hole symmetry pins mu at U / 2
+    assert abs(np.trace(rho[0][0]) + np.trace(rho[1][0]) - n) < 1e-9
+    basis = slater.get_emb_basis(L, rho)
+    dV = slater.get_dV_dparam(v, basis, None, L)
+    assert np.abs(dV - F.get_dV_dparam(v, basis)).max() < 1e-13
+    rng = np.random.default_rng(2)
+    target = slater.foldRho(rho, L, basis)
+    noise = 0.03 * rng.standard_normal(target.shape)
+    target = target + 0.5 * (noise + noise.transpose(0, 2, 1))
+    w = HP.VcorLocalPhSymm(U, False, cs, *BipartiteSquare(cs))
+    w.update(np.array(v.param))
+    vnew, err = HP.FitVcor(target, L, basis, w, np.inf, MaxIter1=20, MaxIter2=0)
+    assert vnew is not w and np.isfinite(err)

@@ -266,3 +266,31 @@ def test_vcor_diagonal_helpers_equal_the_reference(golden):
     HubbardGSO.keep_vcor_trace_fixed(v, old)
     assert np.abs(np.asarray(v.param) - g["vd/gso/after_trace"]).max() < 1e-15
     assert Hubbard.VcorZeros is Hubbard.VcorLocal and Hubbard.VcorLocal_new is Hubbard.VcorLocal
+
+
+def test_particle_hole_symmetric_potentials_equal_the_reference(golden):
+    """dmet/HubPhSymm.py:114-295 VcorLocalPhSymm (with pairing, with a distance cut), VcorDCAPhSymm and InitGuess: value, gradient and
+    the projected starting parameters equal the reference's (golden G36); the sparse entries reproduce the dense gradient."""
+    from libdmet_preview_amd.dmet import HubPhSymm as HP
+    from libdmet_preview_amd.dmet.Hubbard import BipartiteSquare
+    g = golden("G36_init_guess.npz")
+    makers = (("loc22", lambda: HP.VcorLocalPhSymm(4.0, False, (2, 2), *BipartiteSquare((2, 2)))),
+              ("loc22b", lambda: HP.VcorLocalPhSymm(4.0, True, (2, 2), *BipartiteSquare((2, 2)))),
+              ("loc4r", lambda: HP.VcorLocalPhSymm(3.0, True, (4,), *BipartiteSquare((4,)), r=1.0)),
+              ("dca22", lambda: HP.VcorDCAPhSymm(4.0, (2, 2), *BipartiteSquare((2, 2)))),
+              ("dca4", lambda: HP.VcorDCAPhSymm(2.0, (4,), *BipartiteSquare((4,)))))
+    for tag, make in makers:
+        v = make()
+        p = g["ph/%s/param" % tag]
+        assert v.length() == len(p) and v.is_local(), tag
+        v.update(p)
+        assert np.array_equal(v.get(), g["ph/%s/value" % tag]), tag
+        gr = v.gradient()
+        assert np.array_equal(gr, g["ph/%s/grad" % tag]), tag
+        P, B, I, J, S = v.grad_entries()
+        dense = np.zeros_like(gr)
+        dense[P, B, I, J] = S
+        assert np.array_equal(dense, gr)
+    for tag, kw in (("a", dict()), ("b", dict(polar=0.7)), ("c", dict(r=1.0))):
+        v = HP.InitGuess((2, 2), 4.0, **kw)
+        assert np.array_equal(np.asarray(v.param), g["ph/init_%s/param" % tag]) and np.array_equal(v.get(), g["ph/init_%s/value" % tag]), tag
