@@ -9,6 +9,8 @@ index sets (`val_idx`, `virt_idx`, `core_idx`, `imp_idx`) and the Hamiltonian ho
 `nao_nr()`) and the k-mesh.
 """
 import ctypes as C
+import itertools as it
+
 import numpy as np
 
 from libdmet_preview_amd._lib import lib, mesh3
@@ -391,3 +393,174 @@ class Lattice(object):
         self.H2_format = H2_format
         self.eri_symmetry = 1
         self.is_model = True
+
+
+# ---- model lattices (system/lattice.py:796-1109): geometry of a supercell tiling, neighbour search, the standard constructors ----
+
+class UnitCell(object):
+    """Primitive cell of a model lattice: `size` (dim, dim) lattice vectors as rows, `sites` a list of (position, name)."""
+
+    def __init__(self, size, sites):
+        self.size = np.array(size)
+        log.eassert(self.size.ndim == 2 and self.size.shape[0] == self.size.shape[1], "Invalid unitcell constants")
+        self.dim = self.size.shape[0]
+        self.sites, self.names = [], []
+        for pos, name in sites:
+            log.eassert(np.shape(pos) == (self.dim,), "Invalid position for the site")
+            self.sites.append(np.asarray(pos))
+            self.names.append(name)
+        self.nsites = len(self.sites)
+        self.sitedict = dict(zip(map(tuple, self.sites), range(self.nsites)))
+
+    def __str__(self):
+        rows = ["%-10s%-10s" % (n, s) for n, s in zip(self.names, self.sites)]
+        return "UnitCell Shape\n%s\nSites:\n%s\n\n" % (self.size, "\t".join(rows))
+
+
+def translateSites(baseSites, usize, csize):
+    """Cells of a `csize` tiling (C order) and all sites: every cell's copy of the base sites, cell by cell."""
+    cells = [np.asarray(c) for c in it.product(*[range(int(n)) for n in csize])]
+    sites = [np.dot(c, usize) + s for c in cells for s in baseSites]
+    return cells, sites
+
+
+class SuperCell(object):
+    """`size` copies of a unit cell: the impurity cluster of a model."""
+
+    def __init__(self, uc, size):
+        self.unitcell, self.dim = uc, uc.dim
+        self.csize = np.array(size)
+        self.size = np.dot(np.diag(self.csize), uc.size)
+        self.ncells = int(np.prod(self.csize))
+        self.nsites = uc.nsites * self.ncells
+        self.cells, self.sites = translateSites(uc.sites, uc.size, size)
+        self.names = uc.names * self.ncells
+        self.celldict = dict(zip(map(tuple, self.cells), range(self.ncells)))
+        self.sitedict = dict(zip(map(tuple, self.sites), range(self.nsites)))
+
+    def __str__(self):
+        return "%sSuperCell Shape\n%s\nNumber of Sites:%d\n\n" % (self.unitcell, self.size, self.nsites)
+
+
+class LatticeModel(Lattice):
+    """A periodic tiling of `size` supercells (system/lattice.py:796-858): the Lattice of this package -- k mesh = the tiling, one
+    orbital per site of the supercell -- plus the real-space geometry that model Hamiltonians are written in (site positions,
+    neighbour search).  No PySCF cell is built: nothing on the device path reads one for a model."""
+
+    def __init__(self, sc, size):
+        size = [int(x) for x in np.asarray(size).ravel()]
+        Lattice.__init__(self, _UnitCell(sc.nsites, dimension=sc.dim), size)
+        self.supercell, self.dim = sc, sc.dim
+        self.csize = np.array(size)
+        self.size = np.dot(np.diag(self.csize), sc.size)
+        self.cells, self.sites = translateSites(sc.sites, sc.size, size)
+        self.celldict = dict(zip(map(tuple, self.cells), range(self.ncells)))
+        self.sitedict = dict(zip(map(tuple, self.sites), range(self.nsites)))
+        self.names = np.asarray(list(sc.names) * self.ncells)
+        self.coords = np.asarray(self.sites)
+        self.neighborDist = []
+        self.val_idx, self.virt_idx, self.core_idx = list(range(self.nao)), [], []
+        self.kmf = self.kmf_lo = None
+        self.eri_symmetry = None
+        self.is_model, self.has_Ham = True, False
+        self.set_Ham = self.setHam = self.set_Ham_model
+
+    def __str__(self):
+        return "%sLattice Shape\n%s\nNumber of SuperCells: %4d\nNumber of Sites:      %4d\n" % (self.supercell, self.size, self.ncells, self.nsites)
+
+    # cell arithmetic in the model's own dimension (the base class pads the mesh to three axes)
+    def cell_idx2pos(self, idx):
+        return np.asarray(self.cells[idx % self.ncells])
+
+    def cell_pos2idx(self, pos):
+        return self.celldict[tuple(np.asarray(pos) % self.csize)]
+
+    def add(self, i, j):
+        return self.cell_pos2idx(self.cell_idx2pos(i) + self.cell_idx2pos(j))
+
+    def subtract(self, i, j):
+        return self.cell_pos2idx(self.cell_idx2pos(i) - self.cell_idx2pos(j))
+
+    def site_idx2pos(self, idx):
+        return self.sites[idx % self.nsites]
+
+    def site_pos2idx(self, pos):
+        return self.sitedict[tuple(np.asarray(pos) % np.diag(self.size))]
+
+    def neighbor(self, dis=1.0, max_range=1, sitesA=None, sitesB=None, search_range=1):
+        """Pairs (siteA, siteB) of site INDICES at distance `dis` (system/lattice.py:894-925): siteB within `max_range` cells of
+        siteA's cell, distances taken modulo up to `search_range` lattice periods (0: open boundaries).  Vectorised: one distance
+        table per siteA against its candidate sites and all period shifts."""
+        sitesA = range(self.nsites) if sitesA is None else sitesA
+        allowed = None if sitesB is None else set(sitesB)
+        nsc = self.nscsites
+        cellshifts = [self.cell_pos2idx(np.asarray(s)) for s in it.product(range(-max_range, max_range + 1), repeat=self.dim)]
+        shifts = np.asarray([np.dot(s, self.size) for s in it.product(range(-search_range, search_range + 1), repeat=self.dim)])
+        pos = np.asarray(self.sites, dtype=float)
+        out = []
+        for a in sitesA:
+            cells = {self.add(a // nsc, x) for x in cellshifts}
+            cand = sorted(b for c in cells for b in range(c * nsc, (c + 1) * nsc) if allowed is None or b in allowed)
+            d = np.linalg.norm(pos[a][None, None, :] - pos[cand][:, None, :] - shifts[None, :, :], axis=-1)
+            hit = (np.abs(d - dis) < 1e-5).any(axis=1)
+            out += [(a, b) for b, h in zip(cand, hit) if h]
+        return out
+
+    def update_Ham(self, rdm1_lo_R, fock_lo_k=None, ghf=False, **kwargs):
+        """New mean-field Fock from the DMET density of a model (system/lattice.py:927-972): with a cell-local ERI the Coulomb and
+        exchange potentials come from the cell-0 density alone and are the same at every k -- J and K on the device (dmk_jk_s4),
+        fock = hcore + J - K / 2 (restricted, spin-traced density) or J_a + J_b - K_s."""
+        from libdmet_preview_amd.solver import scf
+        log.info("Update DMET mean-field Hamiltonian.")
+        assert self.has_Ham
+        if ghf:
+            raise NotImplementedError("update_Ham of a GSO model lattice (spin-local ERI) is not built")
+        rdm1 = np.asarray(rdm1_lo_R)
+        self.rdm1_lo_R = rdm1 if rdm1.ndim == 4 else rdm1[np.newaxis]
+        self.rdm1_lo_k = self.R2k(self.rdm1_lo_R)
+        if fock_lo_k is None:
+            if self.H2_format != "local":
+                raise NotImplementedError("update_Ham with a %s lattice ERI (cell-resolved J / K) is not built" % self.H2_format)
+            spin = self.rdm1_lo_R.shape[0]
+            dm0 = np.ascontiguousarray(self.rdm1_lo_R[:, 0].real)                # (1/nk) sum_k rho_k = the cell-0 block
+            vj, vk = scf._get_jk(dm0, np.asarray(self.getH2(compact=False, kspace=False)))
+            JK = (vj - vk * 0.5) if spin == 1 else (vj[0] + vj[1] - vk)
+            hcore = np.asarray(self.hcore_lo_k)
+            self.fock_lo_k = hcore + (JK[:, None] if hcore.ndim == 4 else JK[0][None])
+        else:
+            self.fock_lo_k = fock_lo_k
+        self.fock_lo_R = self.k2R(self.fock_lo_k)
+        self.check_imag()
+
+    def getH2(self, compact=False, kspace=False, use_Ham=True):
+        """The lattice two-body tensor of the installed Hamiltonian (system/lattice.py:1006-1010)."""
+        if self._H2_local is not None:
+            return self._H2_local
+        return self.Ham.getH2()
+
+
+def ChainLattice(length, scsites):
+    """1-D 1-band model: `length` sites in supercells of `scsites`."""
+    log.eassert(length % scsites == 0, "incompatible lattice and supercell sizes")
+    sc = SuperCell(UnitCell(np.eye(1), [(np.array([0]), "X")]), np.asarray([scsites]))
+    lat = LatticeModel(sc, np.asarray([length // scsites]))
+    lat.neighborDist = [1.0, 2.0, 3.0]
+    return lat
+
+
+def SquareLattice(lx, ly, scx, scy):
+    """2-D 1-band model on a square lattice."""
+    log.eassert(lx % scx == 0 and ly % scy == 0, "incompatible lattice and supercell sizes")
+    sc = SuperCell(UnitCell(np.eye(2), [(np.array([0, 0]), "X")]), np.asarray([scx, scy]))
+    lat = LatticeModel(sc, np.asarray([lx // scx, ly // scy]))
+    lat.neighborDist = [1.0, np.sqrt(2.0), 2.0]
+    return lat
+
+
+def CubicLattice(lx, ly, lz, scx, scy, scz):
+    """3-D 1-band model on a simple cubic lattice."""
+    log.eassert(lx % scx == 0 and ly % scy == 0 and lz % scz == 0, "incompatible lattice and supercell sizes")
+    sc = SuperCell(UnitCell(np.eye(3), [(np.array([0, 0, 0]), "X")]), np.asarray([scx, scy, scz]))
+    lat = LatticeModel(sc, np.asarray([lx // scx, ly // scy, lz // scz]))
+    lat.neighborDist = [1.0, np.sqrt(2.0), np.sqrt(3.0)]
+    return lat

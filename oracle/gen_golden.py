@@ -1160,7 +1160,7 @@ def main():
     shim.install()
     shim.quiet()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35", "G36", "G37"]
+    which = sys.argv[1:] or ["G1", "G2", "G3", "G4", "G5", "G6", "G7", "G8", "G9", "G10", "G11", "G12", "G13", "G14", "G15", "G16", "G17", "G18", "G19", "G20", "G21", "G22", "G23", "G24", "G25", "G26", "G27", "G28", "G29", "G30", "G31", "G32", "G33", "G34", "G35", "G36", "G37", "G38"]
     for g in which:
         globals()["gen_" + g]()
 
@@ -2247,6 +2247,91 @@ def gen_G37():
     spinless.minimize = real_minimize
     np.savez_compressed(os.path.join(GOLD, "G37_gso_full_fit_mu.npz"), **out)
     print("G37 done", len(out), "arrays")
+
+
+def _ref_model_lattice(sc, size, neighborDist):
+    """The reference's LatticeModel without its PySCF cell: geometry attributes set like system/lattice.py:797-858, methods the
+    reference's own (neighbor, cell arithmetic)."""
+    from libdmet.system import lattice as rl
+    L = rl.LatticeModel.__new__(rl.LatticeModel)
+    L.supercell, L.dim = sc, sc.dim
+    L.csize = np.array(size)
+    L.size = np.dot(np.diag(L.csize), sc.size)
+    L.ncells = int(np.prod(L.csize))
+    L.nsites = sc.nsites * L.ncells
+    L.cells, L.sites = rl.translateSites(sc.sites, sc.size, size)
+    L.celldict = dict(zip(map(tuple, L.cells), range(L.ncells)))
+    L.sitedict = dict(zip(map(tuple, L.sites), range(L.nsites)))
+    L.nao = L.nscsites = sc.nsites
+    L.neighborDist = neighborDist
+    return L
+
+
+MODEL_LATTICES = [("chain12_2", "chain", (12, 2)), ("chain8_4", "chain", (8, 4)), ("sq44_22", "square", (4, 4, 2, 2)), ("sq62_21", "square", (6, 2, 2, 1)),
+                  ("cub442_221", "cubic", (4, 4, 2, 2, 2, 1))]
+
+
+def gen_G38():
+    """Model lattices and the 1-band Hubbard Hamiltonian: system/lattice.py:894-925 LatticeModel.neighbor, :1013-1109 UnitCell /
+    SuperCell / translateSites and the chain / square / cubic constructors' geometry, system/hamiltonian.py:18-165 HamNonInt /
+    HubbardHamiltonian (several hopping ranges, open boundaries, 4-fold U)."""
+    from libdmet.system import lattice as rl, hamiltonian as rh
+    out = {}
+    for name, kind, args in MODEL_LATTICES:
+        if kind == "chain":
+            length, scs = args
+            sc = rl.SuperCell(rl.UnitCell(np.eye(1), [(np.array([0]), "X")]), np.asarray([scs]))
+            L = _ref_model_lattice(sc, np.asarray([length // scs]), [1.0, 2.0, 3.0])
+        elif kind == "square":
+            lx, ly, sx, sy = args
+            sc = rl.SuperCell(rl.UnitCell(np.eye(2), [(np.array([0, 0]), "X")]), np.asarray([sx, sy]))
+            L = _ref_model_lattice(sc, np.asarray([lx // sx, ly // sy]), [1.0, np.sqrt(2.0), 2.0])
+        else:
+            lx, ly, lz, sx, sy, sz = args
+            sc = rl.SuperCell(rl.UnitCell(np.eye(3), [(np.array([0.0, 0.0, 0.0]), "X")]), np.asarray([sx, sy, sz]))
+            L = _ref_model_lattice(sc, np.asarray([lx // sx, ly // sy, lz // sz]), [1.0, np.sqrt(2.0), np.sqrt(3.0)])
+        out[name + "/sites"], out[name + "/cells"], out[name + "/size"] = np.asarray(L.sites), np.asarray(L.cells), np.asarray(L.size)
+        for dtag, dis in (("d1", L.neighborDist[0]), ("d2", L.neighborDist[1])):
+            out["%s/nb_%s" % (name, dtag)] = np.asarray(sorted(L.neighbor(dis=dis, sitesA=range(L.nscsites))))
+            out["%s/nb_%s_obc" % (name, dtag)] = np.asarray(sorted(L.neighbor(dis=dis, sitesA=range(L.nscsites), search_range=0))).reshape(-1, 2)
+        out[name + "/nb_all"] = np.asarray(sorted(L.neighbor(dis=L.neighborDist[0])))
+        for htag, kw in (("t", dict()), ("tt", dict(tlist=[1.0, -0.25])), ("ttt", dict(tlist=[1.0, 0.0, 0.1])), ("obc", dict(obc=True))):
+            H = rh.HubbardHamiltonian(L, 4.0, **kw)
+            out["%s/H1_%s" % (name, htag)] = H.getH1()
+        H = rh.HubbardHamiltonian(L, 6.0, compact=True)
+        out[name + "/H2_compact"], out[name + "/H2_format"] = H.getH2(), np.asarray(H.H2_format)
+        out[name + "/H2_full"] = rh.HubbardHamiltonian(L, 6.0).getH2()
+        if name in ("chain12_2", "sq44_22"):
+            # the model's Fock update from a DMET density (system/lattice.py:927-972), restricted and unrestricted
+            from types import SimpleNamespace
+            from libdmet.routine import pbc_helper as pbc_hp
+            from oracle import restate_ham
+            pbc_hp.ao2mo = SimpleNamespace(restore=shim.restore)
+            pbc_hp.scf = SimpleNamespace(hf=SimpleNamespace(dot_eri_dm=restate_ham.dot_eri_dm))
+            Hm = rh.HubbardHamiltonian(L, 4.0)
+            L.kmesh = [int(x) for x in L.csize] + [1] * (3 - L.dim)
+            L.nkpts = L.ncells
+            L.Ham, L.has_Ham, L.H2_format = Hm, True, Hm.H2_format
+            L.hcore_lo_R = Hm.getH1()
+            L.vxc_lo_R = None
+            n = L.nao
+            for spin in (1, 2):
+                L.hcore_lo_k = L.R2k(L.hcore_lo_R) if spin == 1 else np.asarray([L.R2k(L.hcore_lo_R)] * 2)
+                L.fock_lo_R = L.hcore_lo_R
+                rng = np.random.default_rng(38 + spin)
+                stripe = rng.standard_normal((spin, L.ncells, n, n)) * 0.1
+                stripe[:, 0] = 0.5 * np.eye(n) + 0.1 * (stripe[:, 0] + stripe[:, 0].transpose(0, 2, 1))
+                for c in range(1, L.ncells):                       # Hermitian stripe: block(-R) = block(R)^T
+                    m = L.cell_pos2idx(-L.cell_idx2pos(c))
+                    if m >= c:
+                        stripe[:, m] = stripe[:, c].transpose(0, 2, 1)
+                        if m == c:
+                            stripe[:, c] = 0.5 * (stripe[:, c] + stripe[:, c].transpose(0, 2, 1))
+                out["%s/upd%d_rdm1" % (name, spin)] = stripe
+                rl.LatticeModel.update_Ham(L, stripe * (2.0 if spin == 1 else 1.0))
+                out["%s/upd%d_fock_k" % (name, spin)] = np.asarray(L.fock_lo_k)
+    np.savez_compressed(os.path.join(GOLD, "G38_model_lattices.npz"), **out)
+    print("G38 done", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -354,3 +354,46 @@ def test_apply_dmu(ctx, golden, name):
         Himp = integral.Integral(nb, spin == 1, False, 0.0, {"cd": np.array(g8[name + "/ib_H1"])}, {"ccdd": g8[name + "/H2"]})
         Himp = Hubbard.apply_dmu(L, Himp, basis, 0.17, **kw)
         assert np.abs(Himp.H1["cd"] - g["%s/dmu_%s" % (name, tag)]).max() < 1e-12
+
+
+@pytest.mark.parametrize("name,make", [("C1", lambda lat: lat.ChainLattice(12, 2)), ("C2", lambda lat: lat.SquareLattice(12, 12, 2, 2))])
+def test_model_lattice_constructors_drive_the_path(ctx, golden, name, make):
+    """BASELINE configs 1 / 2 the way a libDMET script builds them -- ChainLattice / SquareLattice + HubbardHamiltonian + setHam
+    (system/lattice.py:1085-1107, hamiltonian.py:118-165) -- through the lattice mean field, the bath and the embedding Hamiltonian:
+    the values of golden G8 (captured from the reference on the same lattices)."""
+    from libdmet_preview_amd.system import lattice, hamiltonian
+    from libdmet_preview_amd.routine import mfd, slater
+    g = golden("G8_embham.npz")
+    L = make(lattice)
+    Ham = hamiltonian.HubbardHamiltonian(L, 4.0)
+    assert np.array_equal(Ham.getH1(), g[name + "/H1_R"]) and np.array_equal(Ham.getH2(), g[name + "/LatH2"])
+    L.setHam(Ham)
+    assert L.is_model and L.has_Ham and L.H2_format == "local" and L.use_hcore_as_emb_ham
+    vc = _Vcor(g[name + "/vcor"])
+    rhoT, mu, E, res = mfd.HF(L, vc, 0.5, True, beta=np.inf, ires=True)
+    assert np.abs(res["rho_k"] * 2.0 - g[name + "/rdm1_lo_k"]).max() < 1e-10
+    L.rdm1_lo_k = res["rho_k"] * 2.0
+    L.use_hcore_as_emb_ham = False                              # G8's model runs fold the Fock (= hcore here) with the JK correction
+    basis = g[name + "/basis"]
+    Himp, _ = slater.get_emb_Ham(L, basis, vc)
+    assert np.abs(Himp.H2["ccdd"] - g[name + "/H2"]).max() < 1e-12 and np.abs(Himp.H1["cd"] - g[name + "/H1"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("name,make", [("chain12_2", lambda lat: lat.ChainLattice(12, 2)), ("sq44_22", lambda lat: lat.SquareLattice(4, 4, 2, 2))])
+def test_model_lattice_update_ham(ctx, golden, name, make):
+    """LatticeModel.update_Ham (system/lattice.py:927-972): the Fock of a Hubbard lattice from a DMET density, J / K of the cell-0
+    block on the device, restricted (spin-traced density) and unrestricted (golden G38)."""
+    from libdmet_preview_amd.system import lattice, hamiltonian
+    g = golden("G38_model_lattices.npz")
+    for spin in (1, 2):
+        L = make(lattice)
+        L.setHam(hamiltonian.HubbardHamiltonian(L, 4.0))
+        if spin == 2:
+            L.hcore_lo_k = np.asarray([L.hcore_lo_k] * 2)
+        stripe = g["%s/upd%d_rdm1" % (name, spin)]
+        L.update_Ham(stripe * (2.0 if spin == 1 else 1.0))
+        ref = g["%s/upd%d_fock_k" % (name, spin)]
+        got = np.asarray(L.fock_lo_k)
+        assert got.shape == ref.shape or got.squeeze().shape == ref.squeeze().shape
+        assert np.abs(got.squeeze() - ref.squeeze()).max() < 1e-12
+        assert np.abs(np.asarray(L.fock_lo_R).imag).max() < 1e-12 if np.iscomplexobj(L.fock_lo_R) else True
