@@ -564,3 +564,22 @@ def CubicLattice(lx, ly, lz, scx, scy, scz):
     lat = LatticeModel(sc, np.asarray([lx // scx, ly // scy, lz // scz]))
     lat.neighborDist = [1.0, np.sqrt(2.0), np.sqrt(3.0)]
     return lat
+
+
+def SquareAFM(lx, ly, scx, scy):
+    """2-D 1-band model in the two-site antiferromagnetic cell (lattice vectors sqrt(2) along the diagonals, sites A at the corner
+    and B at the centre); system/lattice.py:1109-1127."""
+    log.eassert(lx % scx == 0 and ly % scy == 0, "incompatible lattice and supercell sizes")
+    uc = UnitCell(np.eye(2) * np.sqrt(2.0), [(np.zeros(2), "X1"), (np.ones(2) * (np.sqrt(2.0) * 0.5), "X2")])
+    lat = LatticeModel(SuperCell(uc, np.asarray([scx, scy])), np.asarray([lx // scx, ly // scy]))
+    lat.neighborDist = [1.0, np.sqrt(2.0), 2.0]
+    return lat
+
+
+def Square3Band(lx, ly, scx, scy):
+    """2-D 3-band (CuO2) model, one Cu and two O per unit cell of side 2; system/lattice.py:1129-1148."""
+    log.eassert(lx % scx == 0 and ly % scy == 0, "incompatible lattice and supercell sizes")
+    uc = UnitCell(np.eye(2) * 2.0, [(np.array([0.0, 0.0]), "Cu"), (np.array([1.0, 0.0]), "O"), (np.array([0.0, 1.0]), "O")])
+    lat = LatticeModel(SuperCell(uc, np.asarray([scx, scy])), np.asarray([lx // scx, ly // scy]))
+    lat.neighborDist = [1.0, np.sqrt(2.0), 2.0]
+    return lat

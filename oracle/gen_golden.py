@@ -2268,7 +2268,7 @@ def _ref_model_lattice(sc, size, neighborDist):
 
 
 MODEL_LATTICES = [("chain12_2", "chain", (12, 2)), ("chain8_4", "chain", (8, 4)), ("sq44_22", "square", (4, 4, 2, 2)), ("sq62_21", "square", (6, 2, 2, 1)),
-                  ("cub442_221", "cubic", (4, 4, 2, 2, 2, 1))]
+                  ("cub442_221", "cubic", (4, 4, 2, 2, 2, 1)), ("afm42_21", "afm", (4, 2, 2, 1)), ("band3_42_21", "band3", (4, 2, 2, 1))]
 
 
 def gen_G38():
@@ -2286,6 +2286,14 @@ def gen_G38():
             lx, ly, sx, sy = args
             sc = rl.SuperCell(rl.UnitCell(np.eye(2), [(np.array([0, 0]), "X")]), np.asarray([sx, sy]))
             L = _ref_model_lattice(sc, np.asarray([lx // sx, ly // sy]), [1.0, np.sqrt(2.0), 2.0])
+        elif kind == "afm":
+            lx, ly, sx, sy = args
+            uc = rl.UnitCell(np.eye(2) * np.sqrt(2.0), [(np.zeros(2), "X1"), (np.ones(2) * (np.sqrt(2.0) * 0.5), "X2")])
+            L = _ref_model_lattice(rl.SuperCell(uc, np.asarray([sx, sy])), np.asarray([lx // sx, ly // sy]), [1.0, np.sqrt(2.0), 2.0])
+        elif kind == "band3":
+            lx, ly, sx, sy = args
+            uc = rl.UnitCell(np.eye(2) * 2.0, [(np.array([0.0, 0.0]), "Cu"), (np.array([1.0, 0.0]), "O"), (np.array([0.0, 1.0]), "O")])
+            L = _ref_model_lattice(rl.SuperCell(uc, np.asarray([sx, sy])), np.asarray([lx // sx, ly // sy]), [1.0, np.sqrt(2.0), 2.0])
         else:
             lx, ly, lz, sx, sy, sz = args
             sc = rl.SuperCell(rl.UnitCell(np.eye(3), [(np.array([0.0, 0.0, 0.0]), "X")]), np.asarray([sx, sy, sz]))
